@@ -1,0 +1,280 @@
+/*
+ * rl_env.h - C-ABI of the MI355X-native vectorised locomotion RL environment.
+ *
+ * The reference (fan-ziqi/robot_lab v2.3.2) has NO FFI: its hot path is reached through
+ * `gym.make(id, cfg=env_cfg)` -> `isaaclab.envs:ManagerBasedRLEnv(cfg)`
+ * (source/robot_lab/robot_lab/tasks/manager_based/locomotion/velocity/config/quadruped/unitree_a1/__init__.py:12-32,
+ *  scripts/reinforcement_learning/rsl_rl/train.py:177) and `env.step(action)` / `env.reset()`
+ * (scripts/tools/zero_agent.py:56-73).  This header is the boundary a native binding of that
+ * class would use (last row): plain pointers and sizes, no torch types.
+ * The Python class `robot_lab_amd.env.ManagerBasedRLEnv` is the binding; INTEGRATION.md shows it.
+ *
+ * All device buffers are env-owned, device-resident, valid until rl_env_destroy, and are
+ * rewritten in place by every rl_env_step (callers get the same pointer every time - the reference
+ * returns its tensors by reference too, SURVEY.md 8(b) "Ownership").  All calls are stream-ordered
+ * on the hipStream_t passed in; no call synchronises the host except rl_env_read_log.
+ *
+ * Return value: 0 on success, negative on error; rl_env_last_error() gives the message.
+ */
+#ifndef RL_ENV_H_
+#define RL_ENV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RL_MAX_LINKS 32
+#define RL_MAX_DOF 31
+#define RL_MAX_BODIES 48
+#define RL_MAX_SPHERES 96
+#define RL_MAX_REWARD_TERMS 40
+#define RL_MAX_OBS_TERMS 12
+#define RL_TERM_NPARAM 8
+
+/* ---- reward term kinds (each cites the reference function it restates) ------------------- */
+enum rl_reward_kind {
+  RL_REW_TRACK_LIN_VEL_XY_EXP = 0,  /* VEL/mdp/rewards.py:22-35   p0 = std^2 */
+  RL_REW_TRACK_ANG_VEL_Z_EXP = 1,   /* rewards.py:38-48           p0 = std^2 */
+  RL_REW_LIN_VEL_Z_L2 = 2,          /* rewards.py:647-653 */
+  RL_REW_ANG_VEL_XY_L2 = 3,         /* rewards.py:656-662 */
+  RL_REW_JOINT_TORQUES_L2 = 4,      /* [UPSTREAM isaaclab.envs.mdp] velocity_env_cfg.py:401-403 ; joint mask */
+  RL_REW_JOINT_ACC_L2 = 5,          /* [UPSTREAM] velocity_env_cfg.py:407-409 ; joint mask */
+  RL_REW_JOINT_POS_LIMITS = 6,      /* [UPSTREAM] velocity_env_cfg.py:419-421 ; joint mask */
+  RL_REW_JOINT_POWER = 7,           /* rewards.py:81-90 ; joint mask */
+  RL_REW_STAND_STILL = 8,           /* rewards.py:93-104 ; p0 = command_threshold ; joint mask */
+  RL_REW_JOINT_POS_PENALTY = 9,     /* rewards.py:107-129 ; p0 stand_still_scale p1 velocity_threshold p2 command_threshold */
+  RL_REW_JOINT_MIRROR = 10,         /* rewards.py:259-278 ; pairs in idx_a/idx_b, p0 = 1/len(mirror_joints) */
+  RL_REW_ACTION_RATE_L2 = 11,       /* [UPSTREAM] velocity_env_cfg.py:506 */
+  RL_REW_UNDESIRED_CONTACTS = 12,   /* rewards.py:665-675 ; p0 threshold ; body mask */
+  RL_REW_CONTACT_FORCES = 13,       /* [UPSTREAM] velocity_env_cfg.py:519-523 ; p0 threshold ; body mask */
+  RL_REW_FEET_CONTACT_WITHOUT_CMD = 14, /* rewards.py:416-425 ; body mask */
+  RL_REW_FEET_HEIGHT_BODY = 15,     /* rewards.py:527-554 ; p0 target_height p1 tanh_mult ; body mask */
+  RL_REW_UPWARD = 16,               /* rewards.py:608-613 */
+  RL_REW_FEET_AIR_TIME = 17,        /* rewards.py:340-360 ; p0 threshold ; body mask */
+  RL_REW_FEET_AIR_TIME_VARIANCE = 18, /* rewards.py:386-397 ; body mask */
+  RL_REW_FEET_SLIDE = 19,           /* rewards.py:557-587 ; body mask */
+  RL_REW_FEET_GAIT = 20,            /* rewards.py:156-256 ; p0 std p1 max_err p2 velocity_threshold p3 command_threshold ; idx_a = (pair0a,pair0b,pair1a,pair1b) */
+  RL_REW_FLAT_ORIENTATION_L2 = 21,  /* rewards.py:678-687 */
+  RL_REW_IS_TERMINATED = 22,        /* [UPSTREAM] velocity_env_cfg.py:379 */
+  RL_REW_JOINT_DEVIATION_L1 = 23,   /* [UPSTREAM] velocity_env_cfg.py:411-417 ; joint mask */
+  RL_REW_JOINT_VEL_L2 = 24,         /* [UPSTREAM] velocity_env_cfg.py:404-406 ; joint mask */
+  RL_REW_FEET_CONTACT = 25,         /* rewards.py:399-413 ; p0 expect_contact_num ; body mask */
+  RL_REW_FEET_STUMBLE = 26,         /* rewards.py:428-436 ; body mask */
+  RL_REW_FEET_HEIGHT = 27,          /* rewards.py:507-524 ; p0 target_height p1 tanh_mult ; body mask */
+  RL_REW_NUM_KINDS
+};
+
+/* ---- observation term kinds (velocity_env_cfg.py:134-254) -------------------------------- */
+enum rl_obs_kind {
+  RL_OBS_BASE_LIN_VEL = 0,
+  RL_OBS_BASE_ANG_VEL = 1,
+  RL_OBS_PROJECTED_GRAVITY = 2,
+  RL_OBS_VELOCITY_COMMANDS = 3,
+  RL_OBS_JOINT_POS_REL = 4,
+  RL_OBS_JOINT_VEL_REL = 5,
+  RL_OBS_LAST_ACTION = 6,
+  RL_OBS_HEIGHT_SCAN = 7,
+  RL_OBS_JOINT_POS_REL_NO_WHEEL = 8 /* VEL/mdp/observations.py:17-27 */
+};
+
+typedef struct rl_reward_term {
+  int32_t kind;
+  float weight;
+  float p[RL_TERM_NPARAM];
+  uint32_t joint_mask;   /* bit j: joint j (task joint order) takes part */
+  uint64_t body_mask;    /* bit b: body b takes part */
+  int32_t idx_a[16];     /* kind-specific index lists (mirror pairs, gait feet) */
+  int32_t idx_b[16];
+  int32_t n_idx;
+} rl_reward_term;
+
+typedef struct rl_obs_term {
+  int32_t kind;
+  float scale;
+  float clip_lo, clip_hi;
+  float noise_lo, noise_hi; /* additive uniform noise; applied only if the group corrupts */
+  int32_t has_noise;
+} rl_obs_term;
+
+/* ---- articulated model: what the reference passes as ArticulationCfg + URDF -------------- */
+typedef struct rl_model_desc {
+  int32_t num_links;    /* moving rigid bodies incl. base (A1: 13) */
+  int32_t num_dof;      /* actuated joints, task joint order (A1: 12) */
+  int32_t num_bodies;   /* sensor/randomisation bodies (A1: 17) */
+  int32_t num_spheres;  /* collision spheres */
+  int32_t num_chains;   /* star topology: base + num_chains serial chains of chain_len joints */
+  int32_t chain_len;
+  int32_t link_parent[RL_MAX_LINKS];
+  float link_origin[RL_MAX_LINKS][3];   /* joint origin in parent link frame (rotations are identity) */
+  float link_axis[RL_MAX_LINKS][3];
+  float joint_lower[RL_MAX_DOF], joint_upper[RL_MAX_DOF];
+  float joint_vel_limit[RL_MAX_DOF];
+  float joint_armature[RL_MAX_DOF];
+  float default_joint_pos[RL_MAX_DOF], default_joint_vel[RL_MAX_DOF];
+  float soft_lower[RL_MAX_DOF], soft_upper[RL_MAX_DOF];
+  int32_t body_link[RL_MAX_BODIES];
+  float body_pos[RL_MAX_BODIES][3];      /* body frame origin in its link frame */
+  float body_mass[RL_MAX_BODIES];
+  float body_com[RL_MAX_BODIES][3];      /* link frame */
+  float body_inertia[RL_MAX_BODIES][6];  /* about com, link axes: xx yy zz xy xz yz */
+  int32_t sphere_body[RL_MAX_SPHERES];
+  float sphere_center[RL_MAX_SPHERES][3]; /* link frame */
+  float sphere_radius[RL_MAX_SPHERES];
+  float default_root_pos[3];
+  float default_root_quat[4];            /* w x y z */
+  /* actuators (unitree.py:55-63 DCMotorCfg ; :158-173 ImplicitActuatorCfg) */
+  int32_t act_implicit[RL_MAX_DOF];      /* 0 = explicit DC motor, 1 = implicit PD */
+  float act_kp[RL_MAX_DOF], act_kd[RL_MAX_DOF];
+  float act_effort_limit[RL_MAX_DOF], act_saturation[RL_MAX_DOF], act_vel_limit[RL_MAX_DOF];
+  /* action terms (velocity_env_cfg.py:124-126 ; unitree_go2w/rough_env_cfg.py:29-31) */
+  int32_t action_is_vel[RL_MAX_DOF];
+  float action_scale[RL_MAX_DOF], action_offset[RL_MAX_DOF];
+  float action_clip_lo[RL_MAX_DOF], action_clip_hi[RL_MAX_DOF];
+} rl_model_desc;
+
+/* ---- simulator constants (ours; the reference delegates these to PhysX) ------------------ */
+typedef struct rl_sim_desc {
+  float dt;               /* velocity_env_cfg.py:717 */
+  int32_t decimation;     /* :714 */
+  float gravity;          /* 9.81 */
+  float contact_k;        /* normal stiffness N/m */
+  float contact_c;        /* normal damping N s/m at full engagement */
+  float contact_phi_ref;  /* penetration at which damping is fully engaged */
+  float contact_ct;       /* tangential (stick) damping N s/m */
+  float contact_vdep;     /* max depenetration velocity (unitree.py:33 -> 1.0) */
+  float contact_vstick;   /* |v_t| below which static friction applies */
+  float limit_k, limit_c; /* joint-limit spring / damper */
+  float force_threshold;  /* contact sensor threshold, 1.0 N [UPSTREAM ContactSensorCfg] */
+} rl_sim_desc;
+
+/* ---- terrain ------------------------------------------------------------------------------ */
+typedef struct rl_terrain_desc {
+  int32_t is_plane;       /* flat_env_cfg.py:18-19 */
+  int32_t nx, ny;         /* heightfield samples (x-major: h[ix*ny+iy]) */
+  float hscale;           /* sample spacing */
+  float x0, y0;           /* world coords of sample (0,0) */
+  int32_t num_rows, num_cols; /* sub-terrain grid (levels x types) */
+  float tile_size;        /* 8 m */
+  float border;           /* 20 m */
+  int32_t max_init_level; /* velocity_env_cfg.py:51 */
+  int32_t curriculum;     /* terrain_levels_vel enabled (velocity_env_cfg.py:671) */
+} rl_terrain_desc;
+
+/* ---- task: term stack of ManagerBasedRLEnv.step() ---------------------------------------- */
+typedef struct rl_task_desc {
+  float episode_length_s; /* velocity_env_cfg.py:715 */
+  /* commands: velocity_env_cfg.py:106-117, VEL/mdp/commands.py:22-92 */
+  float cmd_range[4][2];  /* vx, vy, wz, heading */
+  float cmd_resample[2];
+  float cmd_rel_standing, cmd_rel_heading, cmd_heading_stiffness;
+  int32_t cmd_heading;
+  float cmd_small_threshold; /* commands.py:47 -> 0.2 */
+  /* observations */
+  int32_t n_policy, n_critic;
+  rl_obs_term policy[RL_MAX_OBS_TERMS], critic[RL_MAX_OBS_TERMS];
+  int32_t policy_corrupt, critic_corrupt;
+  int32_t scan_nx, scan_ny; float scan_res; float scan_offset; /* 17 x 11 @0.1, offset 0.5 */
+  uint32_t wheel_joint_mask;
+  /* rewards */
+  int32_t n_rewards;
+  rl_reward_term rewards[RL_MAX_REWARD_TERMS];
+  /* terminations: velocity_env_cfg.py:648-664 */
+  int32_t term_time_out, term_out_of_bounds, term_illegal_contact;
+  float oob_buffer; uint64_t illegal_body_mask; float illegal_threshold;
+  /* events: velocity_env_cfg.py:262-371 */
+  int32_t ev_material, ev_mass_base, ev_mass_others, ev_com, ev_wrench, ev_reset_joints, ev_gains, ev_reset_base, ev_push;
+  float friction_static[2], friction_dynamic[2], restitution[2]; int32_t friction_buckets;
+  float mass_base_add[2]; uint64_t mass_base_mask;
+  float mass_scale[2]; uint64_t mass_scale_mask;
+  float com_range[3][2]; uint64_t com_mask;
+  float wrench_force[2], wrench_torque[2];
+  float reset_joint_pos_scale[2], reset_joint_vel_scale[2];
+  float gain_kp_scale[2], gain_kd_scale[2];
+  float reset_pose[6][2], reset_vel[6][2];
+  float push_interval[2], push_vel[6][2];
+  int32_t base_body;
+} rl_task_desc;
+
+typedef struct rl_env_desc {
+  rl_model_desc model;
+  rl_sim_desc sim;
+  rl_terrain_desc terrain;
+  rl_task_desc task;
+} rl_env_desc;
+
+/* ---- buffers a caller may look at (device pointers) -------------------------------------- */
+enum rl_buffer {
+  RL_BUF_OBS_POLICY = 0,   /* float [N, obs_policy_dim]  */
+  RL_BUF_OBS_CRITIC = 1,   /* float [N, obs_critic_dim]  */
+  RL_BUF_REWARD = 2,       /* float [N] */
+  RL_BUF_TERMINATED = 3,   /* uint8 [N] */
+  RL_BUF_TIME_OUT = 4,     /* uint8 [N] */
+  RL_BUF_EPISODE_LENGTH = 5, /* int64 [N]  (settable: rsl_rl init_at_random_ep_len, train.py:224) */
+  RL_BUF_ROOT_STATE = 6,   /* float [N, 13] pos(3) quat wxyz(4) lin vel(3) ang vel(3), world; written by rl_env_export_state */
+  RL_BUF_JOINT_POS = 7,    /* float [N, D] */
+  RL_BUF_JOINT_VEL = 8,    /* float [N, D] */
+  RL_BUF_REWARD_TERMS = 9, /* float [T, N] per-term weighted value of the last step (parity checks) */
+  RL_BUF_EPISODE_SUMS = 10,/* float [T, N] reward_manager._episode_sums (VEL/mdp/curriculums.py:44) */
+  RL_BUF_COMMAND = 11,     /* float [N, 3] */
+  RL_BUF_CONTACT_FORCE = 12, /* float [N, B, 3] net_forces_w of the last substep; written by rl_env_export_state */
+  RL_BUF_CONTACT_TIMERS = 13, /* float [N, B, 4] current_air, current_contact, last_air, last_contact */
+  RL_BUF_LOG = 14,         /* float [RL_LOG_SIZE] device-side episode log accumulators */
+  RL_BUF_ACTION = 15,      /* float [N, A] last (raw) action */
+  RL_BUF_JOINT_TORQUE = 16,/* float [N, D] applied torque of the last substep */
+  RL_BUF_JOINT_ACC = 17,   /* float [N, D] */
+  RL_BUF_ENV_ORIGIN = 18,  /* float [N, 3] */
+  RL_BUF_TERRAIN_LEVEL = 19, /* int32 [N] */
+  RL_BUF_COUNT
+};
+
+#define RL_LOG_SIZE 64
+
+typedef struct rl_env rl_env; /* opaque */
+
+/* Replaces: ManagerBasedRLEnv.__init__(cfg) [UPSTREAM ctor; call site train.py:177].
+ * `terrain_heights` is a HOST array of nx*ny floats (NULL for a plane).  `device` is the HIP
+ * device ordinal.  Runs the "startup" events (velocity_env_cfg.py:262-314). */
+int rl_env_create(const rl_env_desc* desc, const float* terrain_heights, int32_t num_envs,
+                  uint64_t seed, int32_t device, rl_env** out);
+
+/* Replaces: ManagerBasedRLEnv.reset() -> _reset_idx(all) + observation compute.
+ * env_ids == NULL resets every env. env_ids is a HOST array. */
+int rl_env_reset(rl_env* env, const int32_t* env_ids, int32_t n, void* stream);
+
+/* Replaces: ManagerBasedRLEnv.step(action).  `action_dev` is a device pointer to
+ * float [N, A] row-major.  Stream-ordered; no host synchronisation. */
+int rl_env_step(rl_env* env, const float* action_dev, void* stream);
+
+/* Device pointer + shape of one of the env-owned buffers.  shape[] gets up to 3 dims, ndim out. */
+int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[3], int32_t* ndim,
+                      int32_t* elem_size);
+
+/* Gathers the SoA simulator state into the AoS debug/inspection buffers (ROOT_STATE, JOINT_*,
+ * CONTACT_*).  Not part of step(); callers such as rl_utils.py:12-13 (camera follow) use it. */
+int rl_env_export_state(rl_env* env, void* stream);
+
+/* Overwrites simulator state from AoS host arrays (teacher-forced parity tests, and
+ * write_root_state_to_sim-style callers).  Any pointer may be NULL to leave that part as is.
+ * root_state [N,13], joint_pos [N,D], joint_vel [N,D]. */
+int rl_env_import_state(rl_env* env, const float* root_state, const float* joint_pos,
+                        const float* joint_vel, void* stream);
+
+/* Copies the RL_LOG_SIZE episode-log accumulators to host and zeroes them (synchronises `stream`). */
+int rl_env_read_log(rl_env* env, float* out_host, void* stream);
+
+int32_t rl_env_num_envs(const rl_env* env);
+int32_t rl_env_num_actions(const rl_env* env);
+int32_t rl_env_obs_dim(const rl_env* env, int32_t group); /* 0 policy, 1 critic */
+int32_t rl_env_max_episode_length(const rl_env* env);
+
+int rl_env_destroy(rl_env* env);
+const char* rl_env_last_error(void);
+/* ABI guard: sizeof(rl_env_desc) the library was built with. */
+uint64_t rl_env_desc_size(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RL_ENV_H_ */

@@ -1,0 +1,271 @@
+"""RobotModel + neutral spec dict -> EnvDesc (host logic).
+
+The *spec* is a plain dict (see ``cfg_compile.compile_cfg`` which produces it from the reference's
+cfg objects, and ``tests`` which write it by hand).  Name patterns follow the upstream
+``resolve_matching_names`` semantics the reference relies on (``re.fullmatch`` of every pattern
+against every name; e.g. ``"^(?!.*_foot).*"`` in ``.../unitree_a1/rough_env_cfg.py:116``).
+"""
+from __future__ import annotations
+
+import math
+import re
+
+import numpy as np
+
+from ..desc import EnvDesc, OBS, REW, RL_MAX_BODIES, RL_MAX_DOF, RL_MAX_LINKS, RL_MAX_SPHERES, mask_of, set_arr
+from .urdf import RobotModel
+
+
+def find_names(patterns, names, preserve_order=False):
+    """Indices of ``names`` matching any regex in ``patterns`` (fullmatch)."""
+    if isinstance(patterns, str):
+        patterns = [patterns]
+    if preserve_order:
+        out = []
+        for p in patterns:
+            for i, n in enumerate(names):
+                if re.fullmatch(p, n) and i not in out:
+                    out.append(i)
+        return out
+    return [i for i, n in enumerate(names) if any(re.fullmatch(p, n) for p in patterns)]
+
+
+def resolve_dict(val, names, default=None):
+    """float | {regex: float} -> per-name list."""
+    if isinstance(val, dict):
+        out = [default] * len(names)
+        for k, v in val.items():
+            for i in find_names(k, names):
+                out[i] = v
+        if any(o is None for o in out):
+            missing = [n for n, o in zip(names, out) if o is None]
+            raise ValueError(f"no value for {missing}")
+        return out
+    return [val] * len(names)
+
+
+DEFAULT_SIM = dict(
+    dt=0.005, decimation=4, gravity=9.81,
+    contact_k=2.0e4, contact_c=400.0, contact_phi_ref=0.005, contact_ct=4000.0, contact_vdep=1.0,
+    contact_vstick=0.01, limit_k=2000.0, limit_c=20.0, force_threshold=1.0,
+)
+
+
+def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
+    d = EnvDesc()
+    m = d.model
+    L, D, B, G = len(model.links), len(model.links) - 1, len(model.bodies), len(model.spheres)
+    if L > RL_MAX_LINKS or D > RL_MAX_DOF or B > RL_MAX_BODIES or G > RL_MAX_SPHERES:
+        raise ValueError("model exceeds descriptor capacity")
+    jn, bn = model.joint_names, model.body_names
+    d.joint_names, d.body_names = list(jn), list(bn)
+    m.num_links, m.num_dof, m.num_bodies, m.num_spheres = L, D, B, G
+    # star topology check: chains hanging off the base
+    roots = [i for i in range(1, L) if model.links[i].parent == 0]
+    clen = D // max(1, len(roots))
+    star = len(roots) * clen == D
+    for c, r in enumerate(roots):
+        for k in range(clen):
+            i = 1 + c * clen + k
+            star = star and i < L and model.links[i].parent == (0 if k == 0 else i - 1)
+    m.num_chains, m.chain_len = (len(roots), clen) if star else (0, 0)
+    for i, l in enumerate(model.links):
+        m.link_parent[i] = l.parent
+        set_arr(m.link_origin[i], l.origin)
+        set_arr(m.link_axis[i], l.axis)
+    rob = spec["robot"]
+    set_arr(m.joint_lower, [l.lower for l in model.links[1:]])
+    set_arr(m.joint_upper, [l.upper for l in model.links[1:]])
+    set_arr(m.joint_vel_limit, [l.vel_limit for l in model.links[1:]])
+    dq = resolve_dict(rob["init_joint_pos"], jn, 0.0)
+    dqd = resolve_dict(rob.get("init_joint_vel", 0.0), jn, 0.0)
+    set_arr(m.default_joint_pos, dq)
+    set_arr(m.default_joint_vel, dqd)
+    f = rob.get("soft_joint_pos_limit_factor", 1.0)
+    lo = np.array([l.lower for l in model.links[1:]])
+    hi = np.array([l.upper for l in model.links[1:]])
+    mid, rng = 0.5 * (lo + hi), hi - lo
+    set_arr(m.soft_lower, mid - 0.5 * rng * f)
+    set_arr(m.soft_upper, mid + 0.5 * rng * f)
+    for b, body in enumerate(model.bodies):
+        m.body_link[b] = body.link
+        set_arr(m.body_pos[b], body.pos)
+        m.body_mass[b] = body.mass
+        set_arr(m.body_com[b], body.com)
+        I = body.inertia
+        set_arr(m.body_inertia[b], [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]])
+    for g, s in enumerate(model.spheres):
+        m.sphere_body[g] = s.body
+        set_arr(m.sphere_center[g], s.center)
+        m.sphere_radius[g] = s.radius
+    set_arr(m.default_root_pos, rob["init_pos"])
+    set_arr(m.default_root_quat, rob.get("init_rot", (1.0, 0.0, 0.0, 0.0)))
+    # actuators
+    assigned = [False] * D
+    arm = [0.0] * D
+    for act in rob["actuators"]:
+        ids = find_names(act["joint_names_expr"], jn)
+        for key, dst in (("stiffness", m.act_kp), ("damping", m.act_kd), ("effort_limit", m.act_effort_limit),
+                         ("saturation_effort", m.act_saturation), ("velocity_limit", m.act_vel_limit)):
+            vals = resolve_dict(act[key], [jn[i] for i in ids]) if act.get(key) is not None else [1e9] * len(ids)
+            for i, v in zip(ids, vals):
+                dst[i] = v
+        a = resolve_dict(act.get("armature") or 0.0, [jn[i] for i in ids], 0.0)
+        for i, v in zip(ids, a):
+            m.act_implicit[i] = 1 if act["type"] == "implicit" else 0
+            arm[i] = v
+            assigned[i] = True
+    if not all(assigned):
+        raise ValueError(f"joints without actuator: {[n for n, a in zip(jn, assigned) if not a]}")
+    set_arr(m.joint_armature, arm)
+    # actions: terms consume consecutive slices of the action vector in declaration order [UPSTREAM B2]
+    a_idx = 0
+    seen = [False] * D
+    order = []
+    for at in spec["actions"]:
+        ids = find_names(at["joint_names"], jn, preserve_order=at.get("preserve_order", False))
+        names = [jn[i] for i in ids]
+        scale = resolve_dict(at["scale"], names)
+        clip = at.get("clip")
+        for k, i in enumerate(ids):
+            m.action_is_vel[i] = 1 if at["type"] == "vel" else 0
+            m.action_scale[i] = scale[k]
+            off = (dqd[i] if at["type"] == "vel" else dq[i]) if at.get("use_default_offset", True) else 0.0
+            m.action_offset[i] = off
+            lohi = (-1e30, 1e30)
+            if clip:
+                for pat, v in clip.items():
+                    if re.fullmatch(pat, jn[i]):
+                        lohi = v
+            m.action_clip_lo[i], m.action_clip_hi[i] = lohi
+            seen[i] = True
+            order.append(i)
+        a_idx += len(ids)
+    if order != list(range(D)):
+        raise ValueError("action terms must cover the joints in task joint order")
+    # sim
+    sim = dict(DEFAULT_SIM)
+    sim.update(spec.get("sim", {}))
+    for k, v in sim.items():
+        setattr(d.sim, k, v)
+    # terrain
+    ter = spec["terrain"]
+    for k, v in ter.items():
+        if k != "heights":
+            setattr(d.terrain, k, v)
+    # task
+    t = d.task
+    ts = spec["task"]
+    t.episode_length_s = ts["episode_length_s"]
+    c = ts["command"]
+    set_arr(t.cmd_range, [c["lin_vel_x"], c["lin_vel_y"], c["ang_vel_z"], c["heading"]])
+    set_arr(t.cmd_resample, c["resampling_time_range"])
+    t.cmd_rel_standing, t.cmd_rel_heading = c["rel_standing_envs"], c["rel_heading_envs"]
+    t.cmd_heading_stiffness, t.cmd_heading = c["heading_control_stiffness"], int(c["heading_command"])
+    t.cmd_small_threshold = c.get("small_threshold", 0.2)
+    for gname, dst, cnt_attr in (("policy", t.policy, "n_policy"), ("critic", t.critic, "n_critic")):
+        grp = ts["observations"][gname]
+        for i, ot in enumerate(grp["terms"]):
+            o = dst[i]
+            o.kind = OBS[ot["func"]]
+            o.scale = 1.0 if ot.get("scale") is None else ot["scale"]
+            clip = ot.get("clip") or (-1e30, 1e30)
+            o.clip_lo, o.clip_hi = clip
+            if ot.get("noise"):
+                o.has_noise, (o.noise_lo, o.noise_hi) = 1, ot["noise"]
+            if ot["func"] == "joint_pos_rel_without_wheel":
+                t.wheel_joint_mask = mask_of(find_names(ot["wheel_joint_names"], jn))
+        setattr(t, cnt_attr, len(grp["terms"]))
+        setattr(t, f"{gname}_corrupt", int(grp.get("enable_corruption", False)))
+    sc = ts.get("height_scan") or dict(size=(1.6, 1.0), resolution=0.1, offset=0.5)
+    t.scan_res = sc["resolution"]
+    t.scan_nx = int(round(sc["size"][0] / sc["resolution"])) + 1
+    t.scan_ny = int(round(sc["size"][1] / sc["resolution"])) + 1
+    t.scan_offset = sc.get("offset", 0.5)
+    d.reward_names = []
+    for i, rt in enumerate(ts["rewards"]):
+        r = t.rewards[i]
+        r.kind = REW[rt["func"]]
+        r.weight = rt["weight"]
+        set_arr(r.p, rt.get("p", []))
+        if rt.get("joint_names") is not None:
+            r.joint_mask = mask_of(find_names(rt["joint_names"], jn))
+        else:
+            r.joint_mask = (1 << D) - 1
+        if rt.get("body_names") is not None:
+            r.body_mask = mask_of(find_names(rt["body_names"], bn))
+        if rt["func"] == "joint_mirror":
+            ia, ib = [], []
+            for pa, pb in rt["mirror_joints"]:
+                a, b = find_names(pa, jn), find_names(pb, jn)
+                if len(a) != len(b):
+                    raise ValueError("mirror joint groups differ in size")
+                ia += a
+                ib += b
+            set_arr(r.idx_a, ia)
+            set_arr(r.idx_b, ib)
+            r.n_idx = len(ia)
+            r.p[0] = 1.0 / len(rt["mirror_joints"]) if rt["mirror_joints"] else 0.0
+        if rt["func"] == "GaitReward":
+            pairs = rt["synced_feet_pair_names"]
+            feet = [find_names(list(pairs[0]), bn, True), find_names(list(pairs[1]), bn, True)]
+            set_arr(r.idx_a, [feet[0][0], feet[0][1], feet[1][0], feet[1][1]])
+            r.n_idx = 4
+        d.reward_names.append(rt["name"])
+    t.n_rewards = len(ts["rewards"])
+    tm = ts["terminations"]
+    t.term_time_out = int(tm.get("time_out", True))
+    t.term_out_of_bounds = int(tm.get("terrain_out_of_bounds") is not None)
+    t.oob_buffer = (tm.get("terrain_out_of_bounds") or {}).get("distance_buffer", 3.0)
+    if tm.get("illegal_contact") is not None:
+        t.term_illegal_contact = 1
+        t.illegal_body_mask = mask_of(find_names(tm["illegal_contact"]["body_names"], bn))
+        t.illegal_threshold = tm["illegal_contact"]["threshold"]
+    ev = ts["events"]
+    t.base_body = find_names(ts["base_body_name"], bn)[0]
+    if ev.get("material"):
+        e = ev["material"]
+        t.ev_material = 1
+        set_arr(t.friction_static, e["static_friction_range"])
+        set_arr(t.friction_dynamic, e["dynamic_friction_range"])
+        set_arr(t.restitution, e["restitution_range"])
+        t.friction_buckets = e["num_buckets"]
+    if ev.get("mass_base"):
+        t.ev_mass_base = 1
+        set_arr(t.mass_base_add, ev["mass_base"]["range"])
+        t.mass_base_mask = mask_of(find_names(ev["mass_base"]["body_names"], bn))
+    if ev.get("mass_others"):
+        t.ev_mass_others = 1
+        set_arr(t.mass_scale, ev["mass_others"]["range"])
+        t.mass_scale_mask = mask_of(find_names(ev["mass_others"]["body_names"], bn))
+    if ev.get("com"):
+        t.ev_com = 1
+        set_arr(t.com_range, [ev["com"]["range"].get(k, (0.0, 0.0)) for k in "xyz"])
+        t.com_mask = mask_of(find_names(ev["com"]["body_names"], bn))
+    if ev.get("wrench"):
+        t.ev_wrench = 1
+        set_arr(t.wrench_force, ev["wrench"]["force_range"])
+        set_arr(t.wrench_torque, ev["wrench"]["torque_range"])
+    if ev.get("reset_joints"):
+        t.ev_reset_joints = 1
+        set_arr(t.reset_joint_pos_scale, ev["reset_joints"]["position_range"])
+        set_arr(t.reset_joint_vel_scale, ev["reset_joints"]["velocity_range"])
+    if ev.get("gains"):
+        t.ev_gains = 1
+        set_arr(t.gain_kp_scale, ev["gains"]["stiffness"])
+        set_arr(t.gain_kd_scale, ev["gains"]["damping"])
+    if ev.get("reset_base"):
+        t.ev_reset_base = 1
+        keys = ["x", "y", "z", "roll", "pitch", "yaw"]
+        set_arr(t.reset_pose, [ev["reset_base"]["pose_range"].get(k, (0.0, 0.0)) for k in keys])
+        set_arr(t.reset_vel, [ev["reset_base"]["velocity_range"].get(k, (0.0, 0.0)) for k in keys])
+    if ev.get("push"):
+        t.ev_push = 1
+        keys = ["x", "y", "z", "roll", "pitch", "yaw"]
+        set_arr(t.push_interval, ev["push"]["interval_range_s"])
+        set_arr(t.push_vel, [ev["push"]["velocity_range"].get(k, (0.0, 0.0)) for k in keys])
+    return d
+
+
+def max_episode_length(desc: EnvDesc) -> int:
+    return int(math.ceil(desc.task.episode_length_s / (desc.sim.decimation * desc.sim.dt) - 1e-9))

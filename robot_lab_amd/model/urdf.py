@@ -1,0 +1,299 @@
+"""URDF -> articulated-model tables (host logic, numpy only).
+
+Consumes the robot description data the reference points its ``ArticulationCfg`` at
+(``/root/reference/source/robot_lab/robot_lab/assets/unitree.py:19-65`` for A1,
+``:71-117`` Go2, ``:121-175`` Go2W) and reproduces what the upstream URDF importer does with
+``merge_fixed_joints=True`` (``unitree.py:22``): links connected by ``fixed`` joints are collapsed
+into their parent *body* unless the joint carries ``dont_collapse="true"``
+(``a1.urdf:461``), in which case the child stays a separate (sensor) body.
+
+Two index spaces come out of this:
+
+* **links** - the rigid bodies that move relative to each other (base + one per actuated joint);
+  this is what the dynamics see.  A ``dont_collapse`` foot is rigidly attached to its calf, so it
+  is *not* a link.
+* **bodies** - the body list the contact sensor / randomisation events / ``body_names`` regexes
+  of the reference address (A1: 17 = base + 4x{hip, thigh, calf, foot}).  Each body belongs to one
+  link.
+
+Collision primitives (``a1.urdf:326-331,379-384,397-404,421-426,449-454``) are converted to a small
+set of collision *spheres* per body (see :func:`_geom_to_spheres`); the simulator's contact model
+is sphere-vs-heightfield.
+"""
+from __future__ import annotations
+
+import math
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+def rpy_to_mat(rpy) -> np.ndarray:
+    r, p, y = (float(v) for v in rpy)
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    return np.array(
+        [
+            [cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+            [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+            [-sp, cp * sr, cp * cr],
+        ]
+    )
+
+
+def _vec(s, n=3, default=0.0):
+    if s is None:
+        return np.full(n, default, dtype=np.float64)
+    return np.array([float(v) for v in s.split()], dtype=np.float64)
+
+
+@dataclass
+class _Inertial:
+    mass: float
+    com: np.ndarray  # in owner frame
+    inertia: np.ndarray  # 3x3 about com, owner-frame axes
+
+
+@dataclass
+class Sphere:
+    body: int
+    center: np.ndarray  # in LINK frame
+    radius: float
+
+
+@dataclass
+class Body:
+    name: str
+    link: int
+    pos: np.ndarray  # body frame origin in link frame
+    rot: np.ndarray  # body frame axes in link frame
+    mass: float
+    com: np.ndarray  # in LINK frame
+    inertia: np.ndarray  # 3x3 about com, LINK-frame axes
+
+
+@dataclass
+class Link:
+    name: str
+    parent: int
+    joint_name: str
+    joint_type: str  # "floating" | "revolute" | "continuous"
+    origin: np.ndarray  # joint origin in parent link frame
+    axis: np.ndarray
+    lower: float
+    upper: float
+    vel_limit: float
+    effort_limit: float
+
+
+@dataclass
+class RobotModel:
+    name: str
+    links: list[Link] = field(default_factory=list)
+    bodies: list[Body] = field(default_factory=list)
+    spheres: list[Sphere] = field(default_factory=list)
+
+    @property
+    def joint_names(self):
+        return [l.joint_name for l in self.links[1:]]
+
+    @property
+    def body_names(self):
+        return [b.name for b in self.bodies]
+
+    def total_mass(self):
+        return float(sum(b.mass for b in self.bodies))
+
+
+def _geom_to_spheres(geom: ET.Element, T_pos: np.ndarray, T_rot: np.ndarray):
+    """Collision primitive -> list of (center, radius) in the frame T maps into.
+
+    sphere   -> itself.
+    box      -> slender (longest side >= 3x the second longest): 3 spheres along the long axis with
+                radius = half the smaller cross-section side; otherwise 8 corner spheres inset by
+                r = min(0.02, min_half_extent) (a rounded box).
+    cylinder -> length <= 2.5 r: one sphere of the cylinder radius at the centre; else 3 along the axis.
+    mesh     -> ignored (no mesh collision in this simulator).
+    """
+    out = []
+    sph = geom.find("sphere")
+    box = geom.find("box")
+    cyl = geom.find("cylinder")
+    if sph is not None:
+        out.append((np.zeros(3), float(sph.get("radius"))))
+    elif box is not None:
+        size = _vec(box.get("size"))
+        if np.max(size) < 0.01:
+            return []  # marker boxes (imu etc., a1.urdf:353-358)
+        order = np.argsort(size)[::-1]
+        if size[order[0]] >= 3.0 * size[order[1]]:
+            r = 0.5 * size[order[2]]
+            half = 0.5 * size[order[0]]
+            for t in (-half, 0.0, half):
+                c = np.zeros(3)
+                c[order[0]] = t
+                out.append((c, r))
+        else:
+            r = min(0.02, 0.5 * float(np.min(size)))
+            for sx in (-1, 1):
+                for sy in (-1, 1):
+                    for sz in (-1, 1):
+                        c = 0.5 * size * np.array([sx, sy, sz]) - r * np.array([sx, sy, sz])
+                        out.append((c, r))
+    elif cyl is not None:
+        r = float(cyl.get("radius"))
+        length = float(cyl.get("length"))
+        if length <= 2.5 * r:
+            out.append((np.zeros(3), r))
+        else:
+            for t in (-0.5 * length, 0.0, 0.5 * length):
+                out.append((np.array([0.0, 0.0, t]), r))
+    return [(T_pos + T_rot @ c, r) for c, r in out]
+
+
+def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None = None) -> RobotModel:
+    """Parse a URDF and collapse fixed joints.
+
+    ``joint_order``: the order the task config addresses the joints in
+    (``.../unitree_a1/rough_env_cfg.py:22-27``, ``preserve_order=True``); links are emitted in that
+    order (link i+1 <-> joint_order[i]).  Default: breadth-first URDF order.
+    """
+    root = ET.parse(path).getroot()
+    ulinks = {l.get("name"): l for l in root.findall("link")}
+    children: dict[str, list[ET.Element]] = {}
+    child_names = set()
+    for j in root.findall("joint"):
+        if j.find("parent") is None or j.find("child") is None:
+            continue  # <transmission><joint .../> entries have no parent/child
+        p = j.find("parent").get("link")
+        if p not in ulinks:
+            continue
+        children.setdefault(p, []).append(j)
+        child_names.add(j.find("child").get("link"))
+    roots = [n for n in ulinks if n not in child_names]
+    if len(roots) != 1:
+        raise ValueError(f"URDF {path}: expected one root link, found {roots}")
+
+    model = RobotModel(name=name or root.get("name", "robot"))
+    # BFS over moving joints; fixed children are folded into the current link.
+    model.links.append(Link(roots[0], -1, "floating_base", "floating", np.zeros(3), np.array([0, 0, 1.0]), 0, 0, 0, 0))
+    pending = [(roots[0], 0, np.zeros(3), np.eye(3), None)]  # (urdf link, link idx, pos, rot in link frame, body idx)
+    raw_bodies: list[dict] = []
+
+    def new_body(bname, link_idx, pos, rot):
+        raw_bodies.append(dict(name=bname, link=link_idx, pos=pos.copy(), rot=rot.copy(), inertials=[], spheres=[]))
+        return len(raw_bodies) - 1
+
+    queue = list(pending)
+    while queue:
+        uname, lidx, pos, rot, bidx = queue.pop(0)
+        if bidx is None:
+            bidx = new_body(uname, lidx, pos, rot)
+        ul = ulinks[uname]
+        ine = ul.find("inertial")
+        if ine is not None:
+            o = ine.find("origin")
+            ipos = _vec(o.get("xyz")) if o is not None else np.zeros(3)
+            irot = rpy_to_mat(_vec(o.get("rpy"))) if o is not None and o.get("rpy") else np.eye(3)
+            m = float(ine.find("mass").get("value"))
+            it = ine.find("inertia")
+            I = np.array(
+                [
+                    [float(it.get("ixx")), float(it.get("ixy")), float(it.get("ixz"))],
+                    [float(it.get("ixy")), float(it.get("iyy")), float(it.get("iyz"))],
+                    [float(it.get("ixz")), float(it.get("iyz")), float(it.get("izz"))],
+                ]
+            )
+            R = rot @ irot
+            raw_bodies[bidx]["inertials"].append(_Inertial(m, pos + rot @ ipos, R @ I @ R.T))
+        for col in ul.findall("collision"):
+            o = col.find("origin")
+            cpos = _vec(o.get("xyz")) if o is not None else np.zeros(3)
+            crot = rpy_to_mat(_vec(o.get("rpy"))) if o is not None and o.get("rpy") else np.eye(3)
+            g = col.find("geometry")
+            raw_bodies[bidx]["spheres"] += _geom_to_spheres(g, pos + rot @ cpos, rot @ crot)
+        for j in children.get(uname, []):
+            cname = j.find("child").get("link")
+            o = j.find("origin")
+            jpos = _vec(o.get("xyz")) if o is not None else np.zeros(3)
+            jrot = rpy_to_mat(_vec(o.get("rpy"))) if o is not None and o.get("rpy") else np.eye(3)
+            jtype = j.get("type")
+            if jtype == "fixed":
+                keep = j.get("dont_collapse", "false").lower() == "true"
+                queue.append((cname, lidx, pos + rot @ jpos, rot @ jrot, None if keep else bidx))
+            elif jtype in ("revolute", "continuous"):
+                if not np.allclose(jrot, np.eye(3), atol=1e-9) or not np.allclose(rot, np.eye(3), atol=1e-9):
+                    raise NotImplementedError(f"joint {j.get('name')}: rotated joint frames are not supported")
+                lim = j.find("limit")
+                lo = float(lim.get("lower", "-1e9")) if (lim is not None and jtype == "revolute") else -1e9
+                hi = float(lim.get("upper", "1e9")) if (lim is not None and jtype == "revolute") else 1e9
+                vl = float(lim.get("velocity", "1e9")) if lim is not None else 1e9
+                ef = float(lim.get("effort", "1e9")) if lim is not None else 1e9
+                ax = _vec(j.find("axis").get("xyz")) if j.find("axis") is not None else np.array([1.0, 0, 0])
+                model.links.append(Link(cname, lidx, j.get("name"), jtype, pos + rot @ jpos, ax / np.linalg.norm(ax), lo, hi, vl, ef))
+                queue.append((cname, len(model.links) - 1, np.zeros(3), np.eye(3), None))
+            else:
+                raise NotImplementedError(f"joint type {jtype}")
+
+    # reorder links to the task's joint order
+    if joint_order is not None:
+        names = [l.joint_name for l in model.links]
+        perm = [0] + [names.index(n) for n in joint_order]
+        if sorted(perm) != list(range(len(model.links))):
+            raise ValueError("joint_order must list every moving joint exactly once")
+        inv = {old: new for new, old in enumerate(perm)}
+        model.links = [model.links[i] for i in perm]
+        for l in model.links[1:]:
+            l.parent = inv[l.parent]
+        for b in raw_bodies:
+            b["link"] = inv[b["link"]]
+        for i, l in enumerate(model.links[1:], 1):
+            if l.parent >= i:
+                raise ValueError("joint_order must be topological (parents before children)")
+
+    # finalise bodies: composite inertial per body, expressed in the link frame
+    for bi, rb in enumerate(raw_bodies):
+        m = sum(i.mass for i in rb["inertials"])
+        if m > 0:
+            com = sum(i.mass * i.com for i in rb["inertials"]) / m
+            I = np.zeros((3, 3))
+            for i in rb["inertials"]:
+                d = i.com - com
+                I += i.inertia + i.mass * (d @ d * np.eye(3) - np.outer(d, d))
+        else:
+            com, I = rb["pos"].copy(), np.zeros((3, 3))
+        model.bodies.append(Body(rb["name"], rb["link"], rb["pos"], rb["rot"], m, com, I))
+        for c, r in rb["spheres"]:
+            model.spheres.append(Sphere(bi, c, r))
+    _prune_contained_spheres(model)
+    return model
+
+
+def _prune_contained_spheres(model: RobotModel):
+    """Drop spheres that can never touch anything first:
+    (a) fully inside another sphere rigidly attached to the same link;
+    (b) centred on the link's own joint origin and fully inside a sphere of the parent link
+        (pose independent, e.g. the top of the A1 thigh box inside the thigh_shoulder cylinder)."""
+    keep = []
+    for i, s in enumerate(model.spheres):
+        li = model.bodies[s.body].link
+        contained = False
+        for k, t in enumerate(model.spheres):
+            if k == i:
+                continue
+            lk = model.bodies[t.body].link
+            if lk == li:
+                c_t = t.center
+                c_s = s.center
+            elif lk == model.links[li].parent and np.linalg.norm(s.center) < 1e-9:
+                c_t = t.center
+                c_s = model.links[li].origin
+            else:
+                continue
+            d = np.linalg.norm(c_s - c_t)
+            if d + s.radius <= t.radius + 1e-12 and (s.radius < t.radius or i > k):
+                contained = True
+                break
+        if not contained:
+            keep.append(s)
+    model.spheres = keep

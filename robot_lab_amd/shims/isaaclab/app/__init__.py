@@ -1,0 +1,28 @@
+"""[UPSTREAM isaaclab.app] `AppLauncher` boots Omniverse Kit upstream
+(`scripts/reinforcement_learning/rsl_rl/train.py:54`); on MI355X there is nothing to boot."""
+import argparse
+
+
+class _App:
+    def is_running(self):
+        return True
+
+    def close(self):
+        pass
+
+
+class AppLauncher:
+    def __init__(self, launcher_args=None, **kwargs):
+        self.app = _App()
+        self.local_rank = 0
+        self.global_rank = 0
+
+    @staticmethod
+    def add_app_launcher_args(parser: argparse.ArgumentParser):
+        g = parser.add_argument_group("app_launcher arguments")
+        g.add_argument("--headless", action="store_true", default=True)
+        g.add_argument("--device", type=str, default="cuda:0")
+        g.add_argument("--enable_cameras", action="store_true", default=False)
+        g.add_argument("--livestream", type=int, default=-1)
+        g.add_argument("--experience", type=str, default="")
+        g.add_argument("--kit_args", type=str, default="")
