@@ -234,10 +234,11 @@ enum rl_buffer {
 typedef struct rl_env rl_env; /* opaque */
 
 /* Replaces: ManagerBasedRLEnv.__init__(cfg) [UPSTREAM ctor; call site train.py:177].
- * `terrain_heights` is a HOST array of nx*ny floats (NULL for a plane).  `device` is the HIP
- * device ordinal.  Runs the "startup" events (velocity_env_cfg.py:262-314). */
-int rl_env_create(const rl_env_desc* desc, const float* terrain_heights, int32_t num_envs,
-                  uint64_t seed, int32_t device, rl_env** out);
+ * HOST arrays: `terrain_heights` nx*ny floats and `terrain_origins` [num_rows][num_cols][3]
+ * (both NULL for a plane), `env_origins` [num_envs][3] (plane only, else NULL).  `device` is the
+ * HIP device ordinal.  Runs the "startup" events (velocity_env_cfg.py:262-314). */
+int rl_env_create(const rl_env_desc* desc, const float* terrain_heights, const float* terrain_origins,
+                  const float* env_origins, int32_t num_envs, uint64_t seed, int32_t device, rl_env** out);
 
 /* Replaces: ManagerBasedRLEnv.reset() -> _reset_idx(all) + observation compute.
  * env_ids == NULL resets every env. env_ids is a HOST array. */

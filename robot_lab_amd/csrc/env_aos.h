@@ -1,0 +1,48 @@
+// env_aos.h - gather/scatter between the SoA simulator state and the AoS inspection buffers of the
+// C-ABI (RL_BUF_ROOT_STATE, RL_BUF_JOINT_*, RL_BUF_CONTACT_TIMERS, ...).  One call per environment;
+// not part of step().
+#pragma once
+#include "env_tables.h"
+
+namespace rl {
+
+struct AosPtrs {
+  float *root_state, *joint_pos, *joint_vel, *ctimers, *action, *env_origin;
+};
+
+RL_FN void export_env(const KState& S, const Tables& T, const AosPtrs& A, int e) {
+  const int Np = S.Npad, NL = NLANE * Np;
+  for (int f = 0; f < 13; ++f) A.root_state[e * 13 + f] = S.root[f * Np + e];
+  for (int a = 0; a < 3; ++a) A.env_origin[e * 3 + a] = S.origin[a * Np + e];
+  for (int k = 0; k < NLANE; ++k) {
+    const LaneTab& L = T.lane[k];
+    int gl = e * NLANE + k;
+    for (int j = 0; j < T.CL; ++j) {
+      A.joint_pos[e * T.D + L.joint_id[j]] = S.q[j * NL + gl];
+      A.joint_vel[e * T.D + L.joint_id[j]] = S.qd[j * NL + gl];
+      A.action[e * T.D + L.joint_id[j]] = S.act[j * NL + gl];
+    }
+    for (int s = 0; s < NBS; ++s) {
+      int b = L.slot_body[s];
+      if (b < 0 || (s == 0 && !L.owns_base_body)) continue;
+      for (int t = 0; t < 4; ++t) A.ctimers[(e * T.n_bodies + b) * 4 + t] = S.timers[(s * 4 + t) * NL + gl];
+    }
+  }
+}
+
+// any of root_state / joint_pos / joint_vel may be null
+RL_FN void import_env(const KState& S, const Tables& T, const float* root_state, const float* joint_pos, const float* joint_vel, int e) {
+  const int Np = S.Npad, NL = NLANE * Np;
+  if (root_state)
+    for (int f = 0; f < 13; ++f) S.root[f * Np + e] = root_state[e * 13 + f];
+  for (int k = 0; k < NLANE; ++k) {
+    const LaneTab& L = T.lane[k];
+    int gl = e * NLANE + k;
+    for (int j = 0; j < T.CL; ++j) {
+      if (joint_pos) S.q[j * NL + gl] = joint_pos[e * T.D + L.joint_id[j]];
+      if (joint_vel) S.qd[j * NL + gl] = joint_vel[e * T.D + L.joint_id[j]];
+    }
+  }
+}
+
+}  // namespace rl

@@ -1,0 +1,143 @@
+// env_tables.h - device-side tables and state layout of the env-step lane program.
+//
+// Lane mapping (DESIGN.md "Lane mapping"): an environment is simulated by NLANE = 4 adjacent lanes of
+// a wavefront; lane k owns kinematic chain k (one leg: hip -> thigh -> calf [-> wheel]) and a share of
+// the base link's collision spheres.  16 environments per 64-wide wavefront.
+//
+// HBM layout: structure-of-arrays, one float per (field, lane) or (field, env):
+//   lane arrays  a[f * NL + (env*4 + k)]   NL = 4 * Npad   -> a wavefront reads 64 consecutive floats
+//   env  arrays  a[f * Npad + env]                          -> 16 consecutive floats, 4-lane broadcast
+#pragma once
+#include <stdint.h>
+
+#include "rl_math.h"
+
+namespace rl {
+
+constexpr int NLANE = 4;    // lanes (= chains) per environment
+constexpr int MAX_CL = 4;   // joints per chain
+constexpr int SPL = 3;      // collision-sphere slots per link group
+constexpr int NGRP = MAX_CL + 1;  // link groups per lane: 0 = share of the base link, 1..CL = chain links
+constexpr int NBS = 6;      // body slots per lane: 0 = a base-link body (or empty), 1.. = chain bodies
+constexpr int MAX_T = 40;   // reward terms
+constexpr int MAX_OBS = 12;
+constexpr int MAX_BASE_BODIES = 4;
+constexpr int ENVS_PER_WAVE = 16;
+constexpr int LOG_SIZE = 64;
+// log accumulator slots (device LOG buffer)
+enum { LOG_RESET_COUNT = 0, LOG_TERM_TIMEOUT = 1, LOG_TERM_OOB = 2, LOG_TERM_ILLEGAL = 3, LOG_METRIC_XY = 4, LOG_METRIC_YAW = 5, LOG_EP_SUM0 = 8 };
+
+struct LaneTab {  // one per chain k
+  float origin[MAX_CL][3], axis[MAX_CL][3];
+  float lower[MAX_CL], upper[MAX_CL], vel_limit[MAX_CL], armature[MAX_CL];
+  float q0[MAX_CL], qd0[MAX_CL], soft_lo[MAX_CL], soft_hi[MAX_CL];
+  int32_t act_implicit[MAX_CL];
+  float kp0[MAX_CL], kd0[MAX_CL], eff[MAX_CL], sat[MAX_CL], act_vlim[MAX_CL];
+  int32_t action_is_vel[MAX_CL];
+  float a_scale[MAX_CL], a_off[MAX_CL], a_lo[MAX_CL], a_hi[MAX_CL];
+  int32_t joint_id[MAX_CL];            // task joint index (bit in joint masks, column in action/obs)
+  float sph_c[NGRP][SPL][3];
+  float sph_r[NGRP][SPL];              // <= 0: empty slot
+  int32_t sph_slot[NGRP][SPL];         // body slot the sphere reports to
+  int32_t slot_body[NBS];              // global body index (bit in body masks), -1 = empty
+  int32_t slot_grp[NBS];               // link group the body is attached to
+  float slot_pos[NBS][3];              // body frame origin in its link frame
+  int32_t base_body_local;             // which base-link body (0..n_base_bodies-1) slot 0 / group 0 belongs to, -1 none
+  int32_t owns_base_body;              // 1 if this lane keeps the timers of that base-link body
+};
+
+struct RewTab {
+  int32_t kind;
+  float weight;
+  float p[8];
+  uint32_t joint_mask;
+  uint64_t body_mask;
+  int32_t idx_a[16], idx_b[16];
+  int32_t n_idx;
+};
+
+struct ObsTab {
+  int32_t kind;
+  float scale, clip_lo, clip_hi, noise_lo, noise_hi;
+  int32_t has_noise;
+  int32_t offset;  // first column of the term in its group
+};
+
+struct Tables {
+  LaneTab lane[NLANE];
+  int32_t CL, D, n_bodies, n_base_bodies;
+  // sim
+  float dt;
+  int32_t decimation;
+  float gravity, contact_k, contact_c, contact_phi_ref, contact_ct, contact_vdep, contact_vstick, limit_k, limit_c, force_threshold;
+  // terrain
+  int32_t is_plane, nx, ny;
+  float hscale, x0, y0;
+  int32_t num_rows, num_cols;
+  float tile_size, border;
+  int32_t curriculum;
+  // task
+  float step_dt, max_episode_length_s;
+  int32_t max_episode_length;
+  float cmd_range[4][2], cmd_resample[2], cmd_rel_standing, cmd_rel_heading, cmd_heading_stiffness, cmd_small_threshold;
+  int32_t cmd_heading;
+  int32_t n_policy, n_critic, policy_dim, critic_dim, policy_corrupt, critic_corrupt;
+  ObsTab policy[MAX_OBS], critic[MAX_OBS];
+  int32_t scan_nx, scan_ny;
+  float scan_res, scan_offset;
+  uint32_t wheel_joint_mask;
+  int32_t n_rewards;
+  RewTab rew[MAX_T];
+  int32_t term_time_out, term_oob, term_illegal;
+  float oob_buffer, illegal_threshold;
+  uint64_t illegal_body_mask;
+  int32_t ev_wrench, ev_reset_joints, ev_gains, ev_reset_base, ev_push;
+  float wrench_force[2], wrench_torque[2], reset_jpos[2], reset_jvel[2], gain_kp[2], gain_kd[2];
+  float reset_pose[6][2], reset_vel[6][2], push_interval[2], push_vel[6][2];
+  float default_root_pos[3], default_root_quat[4];
+};
+
+// fields of the per-env "cmd" array
+enum { CMD_VX = 0, CMD_VY, CMD_WZ, CMD_HEADING, CMD_TIME_LEFT, CMD_METRIC_XY, CMD_METRIC_YAW, CMD_PUSH_LEFT, CMD_NFIELD };
+// link inertia record: mass, com(3), inertia about com (xx yy zz xy xz yz), link frame
+constexpr int INERTIA_NF = 10;
+
+struct KState {
+  int32_t N;      // environments the caller sees
+  int32_t Npad;   // simulated (multiple of ENVS_PER_WAVE)
+  // per-lane SoA
+  float *q, *qd, *kp, *kd, *act;  // [MAX_CL][NL]
+  float* link_inertia;            // [MAX_CL][10][NL]
+  float* timers;                  // [NBS][4][NL]  current_air, current_contact, last_air, last_contact
+  float* friction;                // [NBS][3][NL]  mu_s, mu_d, restitution
+  // per-env SoA
+  float* root;       // [13][Npad] pos(3) quat wxyz(4) lin vel (3, world, link origin) ang vel (3, world)
+  float* wrench;     // [6][Npad]  force(3) torque(3), base-body frame
+  float* base_inertia;  // [10][Npad]
+  float* base_com;   // [3][Npad]  COM of the base *body* in the base frame
+  float* cmd;        // [CMD_NFIELD][Npad]
+  int32_t* flags;    // [Npad] bit0 is_heading_env, bit1 is_standing_env
+  int32_t *level, *ttype;  // [Npad]
+  float* origin;     // [3][Npad] env origins
+  int64_t* ep_len;   // [Npad]   (AoS-compatible: caller-visible int64 [N])
+  float* ep_sums;    // [MAX_T][Npad]
+  // caller-visible outputs (reference layouts)
+  float *obs_policy, *obs_critic;  // [Npad][dim]
+  float* reward;                   // [Npad]
+  uint8_t *terminated, *time_out;  // [Npad]
+  float* rew_terms;                // [MAX_T][Npad]
+  float* command_out;              // [Npad][3]
+  float* log;                      // [LOG_SIZE]
+  // optional inspection buffers (nullptr = skip)
+  float *dbg_torque, *dbg_acc;     // [Npad][D]
+  float* dbg_cforce;               // [Npad][B][3]
+  // inputs
+  const float* terrain;            // [nx*ny]
+  const float* terrain_origins;    // [rows][cols][3]
+  const float* action_in;          // [N][D]
+  const uint8_t* reset_mask;       // [Npad] (reset mode)
+  uint64_t seed;
+  uint32_t step_counter;
+};
+
+}  // namespace rl

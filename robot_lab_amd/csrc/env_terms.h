@@ -1,0 +1,535 @@
+// env_terms.h - the manager term stack of ManagerBasedRLEnv.step() (SURVEY.md section 3.2 stages 1, 3-9) as
+// the second half of the lane program.  Each reward/termination/command/observation/event term cites
+// the reference function it restates; the same arithmetic in fp64 numpy is oracle/env.py, which is
+// pinned to the reference's own functions by tests/golden/.
+#pragma once
+#include "env_step.h"
+
+namespace rl {
+
+enum RewKind {
+  REW_TRACK_LIN_VEL_XY_EXP = 0, REW_TRACK_ANG_VEL_Z_EXP, REW_LIN_VEL_Z_L2, REW_ANG_VEL_XY_L2, REW_JOINT_TORQUES_L2,
+  REW_JOINT_ACC_L2, REW_JOINT_POS_LIMITS, REW_JOINT_POWER, REW_STAND_STILL, REW_JOINT_POS_PENALTY, REW_JOINT_MIRROR,
+  REW_ACTION_RATE_L2, REW_UNDESIRED_CONTACTS, REW_CONTACT_FORCES, REW_FEET_CONTACT_WITHOUT_CMD, REW_FEET_HEIGHT_BODY,
+  REW_UPWARD, REW_FEET_AIR_TIME, REW_FEET_AIR_TIME_VARIANCE, REW_FEET_SLIDE, REW_FEET_GAIT, REW_FLAT_ORIENTATION_L2,
+  REW_IS_TERMINATED, REW_JOINT_DEVIATION_L1, REW_JOINT_VEL_L2, REW_FEET_CONTACT, REW_FEET_STUMBLE, REW_FEET_HEIGHT
+};
+enum ObsKind {
+  OBS_BASE_LIN_VEL = 0, OBS_BASE_ANG_VEL, OBS_PROJECTED_GRAVITY, OBS_VELOCITY_COMMANDS, OBS_JOINT_POS_REL,
+  OBS_JOINT_VEL_REL, OBS_LAST_ACTION, OBS_HEIGHT_SCAN, OBS_JOINT_POS_REL_NO_WHEEL
+};
+
+template <class Ctx, int CL>
+struct EnvProgram : EnvLane<Ctx, CL> {
+  using Base = EnvLane<Ctx, CL>;
+  using Base::ctx; using Base::S; using Base::T; using Base::L; using Base::e; using Base::k; using Base::gl; using Base::NL; using Base::Np;
+  using Base::pos; using Base::quat; using Base::vlin; using Base::vang; using Base::q; using Base::qd; using Base::kp; using Base::kd;
+  using Base::act; using Base::prev_act; using Base::tim; using Base::cf; using Base::hist_n; using Base::tau_app; using Base::qacc;
+  using Base::extF; using Base::extT; using Base::base_com;
+
+  // command / bookkeeping registers (identical in the 4 lanes of a group)
+  V3 cmd;
+  float heading_target, cmd_time_left, metric_xy, metric_yaw, push_left;
+  bool is_heading, is_standing;
+  int level, ttype;
+  V3 origin;
+  long long ep_len;
+  // derived articulation data [UPSTREAM B3]
+  M3 Rwb;
+  V3 lin_b, ang_b, grav_b, lin_w;
+  float heading_w;
+
+  RL_FN EnvProgram(Ctx& c, const KState& s) : Base(c, s) {}
+
+  RL_FN void load_task() {
+    const float* c = S.cmd + e;
+    cmd = {c[CMD_VX * Np], c[CMD_VY * Np], c[CMD_WZ * Np]};
+    heading_target = c[CMD_HEADING * Np];
+    cmd_time_left = c[CMD_TIME_LEFT * Np];
+    metric_xy = c[CMD_METRIC_XY * Np];
+    metric_yaw = c[CMD_METRIC_YAW * Np];
+    push_left = c[CMD_PUSH_LEFT * Np];
+    int f = S.flags[e];
+    is_heading = f & 1;
+    is_standing = (f >> 1) & 1;
+    level = S.level[e];
+    ttype = S.ttype[e];
+    origin = {S.origin[e], S.origin[Np + e], S.origin[2 * Np + e]};
+    ep_len = S.ep_len[e];
+  }
+  RL_FN void store_task() {
+    if (k != 0) return;
+    float* c = S.cmd + e;
+    c[CMD_VX * Np] = cmd.x; c[CMD_VY * Np] = cmd.y; c[CMD_WZ * Np] = cmd.z;
+    c[CMD_HEADING * Np] = heading_target; c[CMD_TIME_LEFT * Np] = cmd_time_left;
+    c[CMD_METRIC_XY * Np] = metric_xy; c[CMD_METRIC_YAW * Np] = metric_yaw; c[CMD_PUSH_LEFT * Np] = push_left;
+    S.flags[e] = (is_heading ? 1 : 0) | (is_standing ? 2 : 0);
+    S.level[e] = level;
+    S.origin[e] = origin.x; S.origin[Np + e] = origin.y; S.origin[2 * Np + e] = origin.z;
+    S.ep_len[e] = ep_len;
+    S.command_out[e * 3 + 0] = cmd.x; S.command_out[e * 3 + 1] = cmd.y; S.command_out[e * 3 + 2] = cmd.z;
+  }
+
+  RL_FN void derive() {
+    Rwb = quat_to_mat(quat);
+    V3 com_w = mul(Rwb, base_com);
+    lin_w = vlin + cross(vang, com_w);  // root COM velocity
+    lin_b = mulT(Rwb, lin_w);
+    ang_b = mulT(Rwb, vang);
+    grav_b = mulT(Rwb, V3{0.f, 0.f, -1.f});
+    heading_w = atan2f(Rwb.r1.x, Rwb.r0.x);
+  }
+
+  RL_FN float U(uint32_t stream, uint32_t idx, float lo, float hi) const {
+    return uniform_range(S.seed, (uint32_t)e, S.step_counter, stream, idx, lo, hi);
+  }
+
+  // UniformVelocityCommand._resample_command [UPSTREAM B7] + threshold (VEL/mdp/commands.py:43-47)
+  RL_FN void resample_command(uint32_t stream, uint32_t idx) {
+    float vx = U(stream, idx + 0, T.cmd_range[0][0], T.cmd_range[0][1]);
+    float vy = U(stream, idx + 1, T.cmd_range[1][0], T.cmd_range[1][1]);
+    float wz = U(stream, idx + 2, T.cmd_range[2][0], T.cmd_range[2][1]);
+    float hd = U(stream, idx + 3, T.cmd_range[3][0], T.cmd_range[3][1]);
+    bool ih = U(stream, idx + 4, 0.f, 1.f) <= T.cmd_rel_heading;
+    bool is = U(stream, idx + 5, 0.f, 1.f) <= T.cmd_rel_standing;
+    float keep = sqrtf(vx * vx + vy * vy) > T.cmd_small_threshold ? 1.f : 0.f;
+    cmd = {vx * keep, vy * keep, wz};
+    if (T.cmd_heading) { heading_target = hd; is_heading = ih; }
+    is_standing = is;
+  }
+
+  // ---------------------------------------------------------------- reset of one env (all 4 lanes) [UPSTREAM B1]
+  RL_FN void reset_env(bool log_episode) {
+    // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671)
+    if (T.curriculum && !T.is_plane) {
+      float dx = pos.x - origin.x, dy = pos.y - origin.y;
+      float dist = sqrtf(dx * dx + dy * dy);
+      bool up = dist > T.tile_size * 0.5f;
+      bool down = (dist < sqrtf(cmd.x * cmd.x + cmd.y * cmd.y) * T.max_episode_length_s * 0.5f) && !up;
+      int lv = level + (up ? 1 : 0) - (down ? 1 : 0);
+      int rnd = (int)fminf(floorf(U(STREAM_RESET, IDX_LEVEL, 0.f, 1.f) * (float)T.num_rows), (float)(T.num_rows - 1));
+      level = lv >= T.num_rows ? rnd : (lv < 0 ? 0 : lv);
+      const float* o = S.terrain_origins + ((size_t)level * T.num_cols + ttype) * 3;
+      origin = {o[0], o[1], o[2]};
+    }
+    // scene.reset: sensor / wrench buffers
+#pragma unroll
+    for (int b = 0; b < NBS; ++b) {
+      tim[b][0] = tim[b][1] = tim[b][2] = tim[b][3] = 0.f;
+      cf[b] = {0.f, 0.f, 0.f};
+      hist_n[b][0] = hist_n[b][1] = hist_n[b][2] = 0.f;
+    }
+    extF = {0.f, 0.f, 0.f};
+    extT = {0.f, 0.f, 0.f};
+    // reset events in declaration order (velocity_env_cfg.py:316-363)
+    if (T.ev_wrench) {
+      extF = {U(STREAM_RESET, IDX_WRENCH + 0, T.wrench_force[0], T.wrench_force[1]), U(STREAM_RESET, IDX_WRENCH + 1, T.wrench_force[0], T.wrench_force[1]),
+              U(STREAM_RESET, IDX_WRENCH + 2, T.wrench_force[0], T.wrench_force[1])};
+      extT = {U(STREAM_RESET, IDX_WRENCH + 3, T.wrench_torque[0], T.wrench_torque[1]), U(STREAM_RESET, IDX_WRENCH + 4, T.wrench_torque[0], T.wrench_torque[1]),
+              U(STREAM_RESET, IDX_WRENCH + 5, T.wrench_torque[0], T.wrench_torque[1])};
+    }
+#pragma unroll
+    for (int j = 0; j < CL; ++j) {
+      uint32_t ji = (uint32_t)L.joint_id[j];
+      float qn = L.q0[j], qdn = L.qd0[j];
+      if (T.ev_reset_joints) {  // reset_joints_by_scale [UPSTREAM B8]
+        qn = clampf(L.q0[j] * U(STREAM_RESET, IDX_JPOS + ji, T.reset_jpos[0], T.reset_jpos[1]), L.soft_lo[j], L.soft_hi[j]);
+        qdn = clampf(L.qd0[j] * U(STREAM_RESET, IDX_JVEL + ji, T.reset_jvel[0], T.reset_jvel[1]), -L.vel_limit[j], L.vel_limit[j]);
+      }
+      q[j] = qn;
+      qd[j] = qdn;
+      if (T.ev_gains) {  // randomize_actuator_gains(operation="scale") [UPSTREAM B4]
+        kp[j] = L.kp0[j] * U(STREAM_RESET, IDX_KP + ji, T.gain_kp[0], T.gain_kp[1]);
+        kd[j] = L.kd0[j] * U(STREAM_RESET, IDX_KD + ji, T.gain_kd[0], T.gain_kd[1]);
+      }
+      act[j] = 0.f;
+      prev_act[j] = 0.f;
+      tau_app[j] = 0.f;
+      qacc[j] = 0.f;
+    }
+    {  // reset_root_state_uniform (VEL/mdp/events.py:205-271), non-pit branch
+      float ps[6], vs[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        ps[a] = T.ev_reset_base ? U(STREAM_RESET, IDX_POSE + a, T.reset_pose[a][0], T.reset_pose[a][1]) : 0.f;
+        vs[a] = T.ev_reset_base ? U(STREAM_RESET, IDX_VEL + a, T.reset_vel[a][0], T.reset_vel[a][1]) : 0.f;
+      }
+      pos = V3{T.default_root_pos[0], T.default_root_pos[1], T.default_root_pos[2]} + origin + V3{ps[0], ps[1], ps[2]};
+      Q4 q0{T.default_root_quat[0], T.default_root_quat[1], T.default_root_quat[2], T.default_root_quat[3]};
+      quat = quat_mul(q0, quat_from_euler_xyz(ps[3], ps[4], ps[5]));
+      vlin = {vs[0], vs[1], vs[2]};
+      vang = {vs[3], vs[4], vs[5]};
+    }
+    // manager resets: episode-sum log + zero, command metrics log + resample, interval timer
+    for (int t = k; t < T.n_rewards; t += NLANE) {
+      float* p = S.ep_sums + (size_t)t * Np + e;
+      if (log_episode && e < S.N) ctx.atomic_add(S.log + LOG_EP_SUM0 + t, *p);
+      *p = 0.f;
+    }
+    if (k == 0 && log_episode && e < S.N) {
+      ctx.atomic_add(S.log + LOG_RESET_COUNT, 1.0f);
+      ctx.atomic_add(S.log + LOG_METRIC_XY, metric_xy);
+      ctx.atomic_add(S.log + LOG_METRIC_YAW, metric_yaw);
+    }
+    metric_xy = 0.f;
+    metric_yaw = 0.f;
+    cmd_time_left = U(STREAM_RESET, IDX_CMD_TIME, T.cmd_resample[0], T.cmd_resample[1]);
+    resample_command(STREAM_RESET, IDX_CMD);
+    if (T.ev_push) push_left = U(STREAM_RESET, IDX_PUSH_TIME, T.push_interval[0], T.push_interval[1]);
+    ep_len = 0;
+  }
+
+  // ---------------------------------------------------------------- rewards
+  RL_FN bool body_bit(uint64_t mask, int slot) const {
+    int b = L.slot_body[slot];
+    if (b < 0) return false;
+    if (slot == 0 && !L.owns_base_body) return false;
+    return (mask >> b) & 1ull;
+  }
+  RL_FN float hist_max(int slot) const { return fmaxf(hist_n[slot][0], fmaxf(hist_n[slot][1], hist_n[slot][2])); }
+  RL_FN bool first_contact(int slot) const { return tim[slot][1] > 0.f && tim[slot][1] < T.step_dt + 1e-8f; }
+
+  // position (base coords) and velocity relative to the root COM velocity (base coords) of body slot s
+  RL_FN void body_rel(const Chain<CL>& C, int s, V3& relp, V3& relv) const {
+    int g = L.slot_grp[s];
+    V3 bp = ld3(L.slot_pos[s]);
+    V3 x = bp;
+#pragma unroll
+    for (int j = 0; j < CL; ++j)
+      if (g == j + 1) x = C.p[j] + mul(C.R[j], bp);
+    relp = x;
+    V3 v = cross(ang_b, x - base_com);
+#pragma unroll
+    for (int i = 0; i < CL; ++i)
+      if (i < g) v += qd[i] * cross(C.ax[i], x - C.p[i]);
+    relv = v;
+  }
+
+  RL_FN float compute_rewards(bool terminated) {
+    const float gate = clampf(-grav_b.z, 0.f, 0.7f) / 0.7f;
+    const float cmd_norm = norm(cmd);
+    const float bv = sqrtf(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
+    Chain<CL> C;
+    chain_kinematics<CL>(L, q, C);
+    float total = 0.f;
+    for (int t = 0; t < T.n_rewards; ++t) {
+      const RewTab& R = T.rew[t];
+      float f = 0.f;
+      switch (R.kind) {
+        case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
+          float ex = cmd.x - lin_b.x, ey = cmd.y - lin_b.y;
+          f = expf(-(ex * ex + ey * ey) / R.p[0]) * gate;
+        } break;
+        case REW_TRACK_ANG_VEL_Z_EXP: {  // rewards.py:38-48
+          float ez = cmd.z - ang_b.z;
+          f = expf(-(ez * ez) / R.p[0]) * gate;
+        } break;
+        case REW_LIN_VEL_Z_L2: f = lin_b.z * lin_b.z * gate; break;                         // rewards.py:647-653
+        case REW_ANG_VEL_XY_L2: f = (ang_b.x * ang_b.x + ang_b.y * ang_b.y) * gate; break;  // rewards.py:656-662
+        case REW_FLAT_ORIENTATION_L2: f = (grav_b.x * grav_b.x + grav_b.y * grav_b.y) * gate; break;  // rewards.py:678-687
+        case REW_UPWARD: f = (1.f - grav_b.z) * (1.f - grav_b.z); break;                     // rewards.py:608-613
+        case REW_IS_TERMINATED: f = terminated ? 1.f : 0.f; break;
+        case REW_JOINT_TORQUES_L2: case REW_JOINT_ACC_L2: case REW_JOINT_VEL_L2: case REW_JOINT_POS_LIMITS:
+        case REW_JOINT_POWER: case REW_JOINT_DEVIATION_L1: case REW_STAND_STILL: case REW_JOINT_POS_PENALTY:
+        case REW_ACTION_RATE_L2: {
+          float part = 0.f;
+#pragma unroll
+          for (int j = 0; j < CL; ++j) {
+            bool in = (R.joint_mask >> L.joint_id[j]) & 1u;
+            float v = 0.f;
+            switch (R.kind) {
+              case REW_JOINT_TORQUES_L2: v = tau_app[j] * tau_app[j]; break;
+              case REW_JOINT_ACC_L2: v = qacc[j] * qacc[j]; break;
+              case REW_JOINT_VEL_L2: v = qd[j] * qd[j]; break;
+              case REW_JOINT_POS_LIMITS: v = fmaxf(L.soft_lo[j] - q[j], 0.f) + fmaxf(q[j] - L.soft_hi[j], 0.f); break;
+              case REW_JOINT_POWER: v = fabsf(qd[j] * tau_app[j]); break;  // rewards.py:81-90
+              case REW_JOINT_DEVIATION_L1: case REW_STAND_STILL: v = fabsf(q[j] - L.q0[j]); break;
+              case REW_JOINT_POS_PENALTY: v = (q[j] - L.q0[j]) * (q[j] - L.q0[j]); break;
+              case REW_ACTION_RATE_L2: v = (act[j] - prev_act[j]) * (act[j] - prev_act[j]); in = true; break;
+              default: break;
+            }
+            part += in ? v : 0.f;
+          }
+          f = ctx.gsum(part);
+          if (R.kind == REW_STAND_STILL) f *= (cmd_norm < R.p[0] ? 1.f : 0.f) * gate;  // rewards.py:93-104
+          if (R.kind == REW_JOINT_POS_PENALTY) {                                        // rewards.py:107-129
+            float run = sqrtf(f);
+            f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
+          }
+        } break;
+        case REW_JOINT_MIRROR: {  // rewards.py:259-278
+          float qa[NLANE][CL];
+#pragma unroll
+          for (int kk = 0; kk < NLANE; ++kk)
+#pragma unroll
+            for (int j = 0; j < CL; ++j) qa[kk][j] = ctx.gshfl(q[j], kk);
+          float s = 0.f;
+          for (int i = 0; i < R.n_idx; ++i) {
+            float va = 0.f, vb = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NLANE; ++kk)
+#pragma unroll
+              for (int j = 0; j < CL; ++j) {
+                int id = T.lane[kk].joint_id[j];
+                va = id == R.idx_a[i] ? qa[kk][j] : va;
+                vb = id == R.idx_b[i] ? qa[kk][j] : vb;
+              }
+            s += (va - vb) * (va - vb);
+          }
+          f = s * R.p[0] * gate;
+        } break;
+        case REW_UNDESIRED_CONTACTS: case REW_CONTACT_FORCES: case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT:
+        case REW_FEET_AIR_TIME: case REW_FEET_HEIGHT_BODY: case REW_FEET_SLIDE: case REW_FEET_HEIGHT: case REW_FEET_STUMBLE: {
+          float part = 0.f;
+#pragma unroll
+          for (int s = 0; s < NBS; ++s) {
+            if (!body_bit(R.body_mask, s)) continue;
+            float hm = hist_max(s);
+            switch (R.kind) {
+              case REW_UNDESIRED_CONTACTS: part += hm > R.p[0] ? 1.f : 0.f; break;          // rewards.py:665-675
+              case REW_CONTACT_FORCES: part += fmaxf(hm - R.p[0], 0.f); break;              // [UPSTREAM] contact_forces
+              case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT: part += first_contact(s) ? 1.f : 0.f; break;
+              case REW_FEET_AIR_TIME: part += first_contact(s) ? tim[s][2] - R.p[0] : 0.f; break;  // rewards.py:340-360
+              case REW_FEET_STUMBLE: {                                                       // rewards.py:428-436
+                float fxy = sqrtf(cf[s].x * cf[s].x + cf[s].y * cf[s].y);
+                part += fxy > 4.f * fabsf(cf[s].z) ? 1.f : 0.f;
+              } break;
+              default: {
+                V3 relp, relv;
+                body_rel(C, s, relp, relv);
+                if (R.kind == REW_FEET_HEIGHT_BODY) {  // rewards.py:527-554
+                  float er = relp.z - R.p[0];
+                  part += er * er * tanhf(R.p[1] * sqrtf(relv.x * relv.x + relv.y * relv.y));
+                } else if (R.kind == REW_FEET_SLIDE) {  // rewards.py:557-587
+                  part += hm > 1.0f ? sqrtf(relv.x * relv.x + relv.y * relv.y) : 0.f;
+                } else {  // feet_height, world frame (rewards.py:507-524)
+                  V3 pw = pos + mul(Rwb, relp);
+                  V3 vw = lin_w + mul(Rwb, relv);
+                  float er = pw.z - R.p[0];
+                  part += er * er * tanhf(R.p[1] * sqrtf(vw.x * vw.x + vw.y * vw.y));
+                }
+              }
+            }
+          }
+          f = ctx.gsum(part);
+          switch (R.kind) {
+            case REW_UNDESIRED_CONTACTS: case REW_FEET_SLIDE: f *= gate; break;
+            case REW_FEET_CONTACT_WITHOUT_CMD: f *= (cmd_norm < 0.1f ? 1.f : 0.f) * gate; break;  // rewards.py:416-425
+            case REW_FEET_CONTACT: f = (f != R.p[0] ? 1.f : 0.f) * (cmd_norm > 0.1f ? 1.f : 0.f) * gate; break;
+            case REW_FEET_AIR_TIME: case REW_FEET_HEIGHT_BODY: case REW_FEET_HEIGHT: f *= (cmd_norm > 0.1f ? 1.f : 0.f) * gate; break;
+            case REW_FEET_STUMBLE: f = (f > 0.f ? 1.f : 0.f) * gate; break;
+            default: break;
+          }
+        } break;
+        case REW_FEET_AIR_TIME_VARIANCE: {  // rewards.py:386-397 (torch.var is unbiased)
+          float n = 0.f, sa = 0.f, saa = 0.f, sc = 0.f, scc = 0.f;
+#pragma unroll
+          for (int s = 0; s < NBS; ++s) {
+            if (!body_bit(R.body_mask, s)) continue;
+            float la = fminf(tim[s][2], 0.5f), lc = fminf(tim[s][3], 0.5f);
+            n += 1.f; sa += la; saa += la * la; sc += lc; scc += lc * lc;
+          }
+          n = ctx.gsum(n); sa = ctx.gsum(sa); saa = ctx.gsum(saa); sc = ctx.gsum(sc); scc = ctx.gsum(scc);
+          float den = fmaxf(n - 1.f, 1.f);
+          f = ((saa - sa * sa / n) / den + (scc - sc * sc / n) / den) * gate;
+        } break;
+        case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256
+          float air[4], con[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float a = 0.f, c = 0.f;
+#pragma unroll
+            for (int s = 0; s < NBS; ++s)
+              if (L.slot_body[s] == R.idx_a[i] && (s != 0 || L.owns_base_body)) { a = tim[s][0]; c = tim[s][1]; }
+            air[i] = ctx.gsum(a);
+            con[i] = ctx.gsum(c);
+          }
+          const float std = R.p[0], me2 = R.p[1] * R.p[1];
+          auto sync = [&](int a, int b) {
+            float da = air[a] - air[b], dc = con[a] - con[b];
+            return expf(-(fminf(da * da, me2) + fminf(dc * dc, me2)) / std);
+          };
+          auto asyn = [&](int a, int b) {
+            float d0 = air[a] - con[b], d1 = con[a] - air[b];
+            return expf(-(fminf(d0 * d0, me2) + fminf(d1 * d1, me2)) / std);
+          };
+          float sr = sync(0, 1) * sync(2, 3);
+          float ar = asyn(0, 2) * asyn(1, 3) * asyn(0, 3) * asyn(2, 1);
+          f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? sr * ar : 0.f) * gate;
+        } break;
+        default: break;
+      }
+      float val = f * R.weight * T.step_dt;  // RewardManager [UPSTREAM B2]
+      total += val;
+      if (k == (t & 3)) {
+        S.rew_terms[(size_t)t * Np + e] = val;
+        S.ep_sums[(size_t)t * Np + e] += val;
+      }
+    }
+    return total;
+  }
+
+  // ---------------------------------------------------------------- observations [UPSTREAM B2 / B6]
+  RL_FN void write_obs(float* stage, const ObsTab* terms, int n, bool corrupt, uint32_t noise_base) {
+    const float cy = cosf(heading_w), sy = sinf(heading_w);
+    for (int i = 0; i < n; ++i) {
+      const ObsTab& O = terms[i];
+      auto put = [&](int col, float v) {
+        if (corrupt && O.has_noise) v += U(STREAM_NOISE, noise_base + (uint32_t)col, O.noise_lo, O.noise_hi);
+        stage[col] = clampf(v, O.clip_lo, O.clip_hi) * O.scale;
+      };
+      switch (O.kind) {
+        case OBS_BASE_LIN_VEL: if (k < 3) put(O.offset + k, comp(lin_b, k)); break;
+        case OBS_BASE_ANG_VEL: if (k < 3) put(O.offset + k, comp(ang_b, k)); break;
+        case OBS_PROJECTED_GRAVITY: if (k < 3) put(O.offset + k, comp(grav_b, k)); break;
+        case OBS_VELOCITY_COMMANDS: if (k < 3) put(O.offset + k, comp(cmd, k)); break;
+        case OBS_JOINT_POS_REL: case OBS_JOINT_POS_REL_NO_WHEEL: case OBS_JOINT_VEL_REL: case OBS_LAST_ACTION:
+#pragma unroll
+          for (int j = 0; j < CL; ++j) {
+            float v = O.kind == OBS_JOINT_VEL_REL ? qd[j] - L.qd0[j] : O.kind == OBS_LAST_ACTION ? act[j] : q[j] - L.q0[j];
+            if (O.kind == OBS_JOINT_POS_REL_NO_WHEEL && ((T.wheel_joint_mask >> L.joint_id[j]) & 1u)) v = 0.f;
+            put(O.offset + L.joint_id[j], v);
+          }
+          break;
+        case OBS_HEIGHT_SCAN: {  // yaw-aligned grid, x fastest; z_base - hit_z - offset
+          const int nr = T.scan_nx * T.scan_ny;
+          for (int r = k; r < nr; r += NLANE) {
+            int ix = r % T.scan_nx, iy = r / T.scan_nx;
+            float lx = ((float)ix - 0.5f * (float)(T.scan_nx - 1)) * T.scan_res;
+            float ly = ((float)iy - 0.5f * (float)(T.scan_ny - 1)) * T.scan_res;
+            float hz;
+            V3 nn;
+            terrain_sample(T, S.terrain, pos.x + cy * lx - sy * ly, pos.y + sy * lx + cy * ly, hz, nn);
+            put(O.offset + r, pos.z - hz - T.scan_offset);
+          }
+        } break;
+        default: break;
+      }
+    }
+  }
+
+  RL_FN void observations() {
+    derive();
+    float* sp = ctx.obs_stage(0);
+    float* sc = ctx.obs_stage(1);
+    write_obs(sp, T.policy, T.n_policy, T.policy_corrupt != 0, 0u);
+    write_obs(sc, T.critic, T.n_critic, T.critic_corrupt != 0, 1024u);
+    ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
+    ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
+  }
+
+  // ---------------------------------------------------------------- step()
+  RL_FN void step() {
+    this->load();
+    load_task();
+    // 1 ActionManager.process_action [UPSTREAM B2]; JointPosition/VelocityAction (velocity_env_cfg.py:124-126)
+    float q_tgt[CL], qd_tgt[CL];
+#pragma unroll
+    for (int j = 0; j < CL; ++j) {
+      prev_act[j] = act[j];
+      float a = e < S.N ? S.action_in[(size_t)e * T.D + L.joint_id[j]] : 0.f;
+      act[j] = a;
+      float pr = clampf(a * L.a_scale[j] + L.a_off[j], L.a_lo[j], L.a_hi[j]);
+      q_tgt[j] = L.action_is_vel[j] ? 0.f : pr;
+      qd_tgt[j] = L.action_is_vel[j] ? pr : 0.f;
+    }
+    // 2 decimation loop: actuators -> physics -> contact sensor
+    for (int s = 0; s < T.decimation; ++s) this->substep(q_tgt, qd_tgt);
+    if (S.dbg_torque != nullptr) {
+#pragma unroll
+      for (int j = 0; j < CL; ++j) {
+        S.dbg_torque[(size_t)e * T.D + L.joint_id[j]] = tau_app[j];
+        S.dbg_acc[(size_t)e * T.D + L.joint_id[j]] = qacc[j];
+      }
+#pragma unroll
+      for (int s = 0; s < NBS; ++s) {
+        int b = L.slot_body[s];
+        if (b >= 0 && (s != 0 || L.owns_base_body)) {
+          float* o = S.dbg_cforce + ((size_t)e * T.n_bodies + b) * 3;
+          o[0] = cf[s].x; o[1] = cf[s].y; o[2] = cf[s].z;
+        }
+      }
+    }
+    // 3 counters
+    ep_len += 1;
+    derive();
+    // 4 terminations (velocity_env_cfg.py:648-664)
+    bool t_timeout = T.term_time_out && ep_len >= (long long)T.max_episode_length;
+    bool t_oob = false;
+    if (T.term_oob && !T.is_plane) {
+      float mw = (float)T.num_rows * T.tile_size + 2.f * T.border, mh = (float)T.num_cols * T.tile_size + 2.f * T.border;
+      t_oob = fabsf(pos.x) > 0.5f * mw - T.oob_buffer || fabsf(pos.y) > 0.5f * mh - T.oob_buffer;
+    }
+    bool t_illegal = false;
+    if (T.term_illegal) {
+      float c = 0.f;
+#pragma unroll
+      for (int s = 0; s < NBS; ++s)
+        if (body_bit(T.illegal_body_mask, s) && hist_max(s) > T.illegal_threshold) c += 1.f;
+      t_illegal = ctx.gsum(c) > 0.f;
+    }
+    bool terminated = t_illegal, time_out = t_timeout || t_oob;
+    // 5 rewards
+    float rew = compute_rewards(terminated);
+    if (k == 0) {
+      S.reward[e] = rew;
+      S.terminated[e] = terminated ? 1 : 0;
+      S.time_out[e] = time_out ? 1 : 0;
+    }
+    // 6 reset done envs
+    if (terminated || time_out) {
+      if (k == 0 && e < S.N) {
+        if (t_timeout) ctx.atomic_add(S.log + LOG_TERM_TIMEOUT, 1.f);
+        if (t_oob) ctx.atomic_add(S.log + LOG_TERM_OOB, 1.f);
+        if (t_illegal) ctx.atomic_add(S.log + LOG_TERM_ILLEGAL, 1.f);
+      }
+      reset_env(true);
+      derive();
+    }
+    // 7 CommandManager.compute [UPSTREAM B7]
+    {
+      float max_step = T.cmd_resample[1] / T.step_dt;
+      float ex = cmd.x - lin_b.x, ey = cmd.y - lin_b.y;
+      metric_xy += sqrtf(ex * ex + ey * ey) / max_step;
+      metric_yaw += fabsf(cmd.z - ang_b.z) / max_step;
+      cmd_time_left -= T.step_dt;
+      if (cmd_time_left <= 0.f) {
+        cmd_time_left = U(STREAM_COMMAND, 6, T.cmd_resample[0], T.cmd_resample[1]);
+        resample_command(STREAM_COMMAND, 0);
+      }
+      if (T.cmd_heading && is_heading)
+        cmd.z = clampf(T.cmd_heading_stiffness * wrap_to_pi(heading_target - heading_w), T.cmd_range[2][0], T.cmd_range[2][1]);
+      if (is_standing) cmd = {0.f, 0.f, 0.f};
+      // the "pits" branch of commands.py:61-85 never fires: ROUGH_TERRAINS_CFG has no sub-terrain of that name (utils.py:27-28)
+    }
+    // 8 interval event: push_by_setting_velocity (velocity_env_cfg.py:366-371) [UPSTREAM B2/B8]
+    if (T.ev_push) {
+      push_left -= T.step_dt;
+      if (push_left < 1e-6f) {
+        push_left = U(STREAM_PUSH, 6, T.push_interval[0], T.push_interval[1]);
+        vlin += V3{U(STREAM_PUSH, 0, T.push_vel[0][0], T.push_vel[0][1]), U(STREAM_PUSH, 1, T.push_vel[1][0], T.push_vel[1][1]),
+                   U(STREAM_PUSH, 2, T.push_vel[2][0], T.push_vel[2][1])};
+        vang += V3{U(STREAM_PUSH, 3, T.push_vel[3][0], T.push_vel[3][1]), U(STREAM_PUSH, 4, T.push_vel[4][0], T.push_vel[4][1]),
+                   U(STREAM_PUSH, 5, T.push_vel[5][0], T.push_vel[5][1])};
+      }
+    }
+    // 9 observations
+    observations();
+    this->store();
+    store_task();
+  }
+
+  // ---------------------------------------------------------------- reset() entry: reset masked envs, recompute obs
+  RL_FN void reset_entry() {
+    this->load();
+    load_task();
+#pragma unroll
+    for (int j = 0; j < CL; ++j) prev_act[j] = act[j];
+    if (S.reset_mask == nullptr || S.reset_mask[e]) reset_env(false);
+    observations();
+    this->store();
+    store_task();
+  }
+};
+
+}  // namespace rl

@@ -1,0 +1,178 @@
+// rl_env.hip - gfx950 (MI355X, CDNA4) build of the env-step lane program + the C-ABI of include/rl_env.h.
+//
+// Launch geometry: one 64-lane wavefront per workgroup = 16 environments x 4 lanes; Npad/16 workgroups
+// (4096 envs -> 256 workgroups -> one wavefront on every one of the 256 CUs, dealt round-robin over the
+// 8 XCDs by the dispatcher).  The path has no dense contraction -> no MFMA; it is latency bound at this
+// size, so a wavefront gets a whole CU's register file (no occupancy pressure) and
+// every cross-lane reduction is a DPP quad_perm move (4-lane groups are exactly DPP quads - no LDS
+// round trip).  The model / term tables are staged once per workgroup into LDS; observation rows are
+// staged in LDS and written back as one linear, 16-byte-vectorised burst per wavefront.
+#include <hip/hip_runtime.h>
+
+#define RL_FN __host__ __device__ inline
+#include "env_aos.h"
+#include "env_terms.h"
+#include "rl_env_host.h"
+
+namespace {
+
+using namespace rl;
+
+__device__ inline float dpp_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm:[1,0,3,2]
+}
+__device__ inline float dpp_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm:[2,3,0,1]
+}
+
+struct WaveCtx {
+  const Tables* T;
+  float* stage[2];
+  int dim[2];
+  int lane, e0;
+  __device__ const Tables& tables() const { return *T; }
+  __device__ int k() const { return lane & 3; }
+  __device__ int env() const { return e0 + (lane >> 2); }
+  __device__ float gsum(float v) const {
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    return v;
+  }
+  __device__ float gshfl(float v, int src) const { return __shfl(v, (lane & ~3) | src); }
+  __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
+  __device__ float* obs_stage(int g) const { return stage[g] + (lane >> 2) * dim[g]; }
+  __device__ void flush_obs(float* out, int d, int g) const {
+    __syncthreads();  // single-wave workgroup: orders the LDS writes above before the reads below
+    const int n4 = (ENVS_PER_WAVE * d) >> 2;  // 16 rows are contiguous in `out` and 16-byte aligned
+    const float4* src = reinterpret_cast<const float4*>(stage[g]);
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)e0 * d);
+    for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+    __syncthreads();
+  }
+};
+
+extern __shared__ float4 smem4[];
+
+template <int CL, int RESET>
+__global__ __launch_bounds__(64) void env_kernel(KState S, const Tables* __restrict__ Tg) {
+  float* smem = reinterpret_cast<float*>(smem4);
+  Tables* Tl = reinterpret_cast<Tables*>(smem);
+  const int lane = threadIdx.x;
+  {  // stage the model / term tables into LDS
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(Tg);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(Tl);
+    for (int i = lane; i < (int)(sizeof(Tables) / 4); i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  constexpr int TAB_F = (sizeof(Tables) + 15) / 16 * 4;
+  WaveCtx ctx;
+  ctx.T = Tl;
+  ctx.dim[0] = Tl->policy_dim;
+  ctx.dim[1] = Tl->critic_dim;
+  ctx.stage[0] = smem + TAB_F;
+  ctx.stage[1] = ctx.stage[0] + ((ENVS_PER_WAVE * ctx.dim[0] + 3) & ~3);
+  ctx.lane = lane;
+  ctx.e0 = blockIdx.x * ENVS_PER_WAVE;
+  EnvProgram<WaveCtx, CL> prog(ctx, S);
+  if (RESET)
+    prog.reset_entry();
+  else
+    prog.step();
+}
+
+__global__ void export_kernel(KState S, const Tables* __restrict__ T, AosPtrs A) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < S.Npad) export_env(S, *T, A, e);
+}
+__global__ void import_kernel(KState S, const Tables* __restrict__ T, const float* r, const float* q, const float* qd, int N) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < N) import_env(S, *T, r, q, qd, e);
+}
+
+struct Backend {
+  std::string err;
+  const std::string& error() const { return err; }
+  int check(hipError_t e) {
+    if (e != hipSuccess) {
+      err = hipGetErrorString(e);
+      return -1;
+    }
+    return 0;
+  }
+  int init(int device) { return check(hipSetDevice(device)); }
+  void* alloc(size_t n) {
+    void* p = nullptr;
+    if (check(hipMalloc(&p, n ? n : 16))) return nullptr;
+    return p;
+  }
+  void free(void* p) { (void)hipFree(p); }
+  void zero(void* p, size_t n) { check(hipMemset(p, 0, n)); }
+  void h2d(void* d, const void* s, size_t n) { check(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); }
+  void h2d_stream(void* d, const void* s, size_t n, void* stream) {
+    check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)stream));
+    check(hipStreamSynchronize((hipStream_t)stream));  // the host staging vector dies on return
+  }
+  template <int CL>
+  int launch_cl(const KState& S, const Tables* T, int reset, size_t lds, hipStream_t st) {
+    dim3 grid(S.Npad / ENVS_PER_WAVE), block(64);
+    if (reset)
+      hipLaunchKernelGGL((env_kernel<CL, 1>), grid, block, lds, st, S, T);
+    else
+      hipLaunchKernelGGL((env_kernel<CL, 0>), grid, block, lds, st, S, T);
+    return check(hipGetLastError());
+  }
+  size_t lds_bytes = 0;
+  int configure(const Tables& T) {  // dynamic LDS: tables + the two observation staging tiles
+    size_t tab = (sizeof(Tables) + 15) / 16 * 16;
+    size_t s0 = ((size_t)ENVS_PER_WAVE * T.policy_dim + 3) / 4 * 16;
+    size_t s1 = ((size_t)ENVS_PER_WAVE * T.critic_dim + 3) / 4 * 16;
+    lds_bytes = tab + s0 + s1;
+    if (lds_bytes > 160 * 1024) {
+      err = "observation rows do not fit the 160 KiB LDS";
+      return -1;
+    }
+    if (lds_bytes > 64 * 1024) {
+      if (check(hipFuncSetAttribute((const void*)env_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return -1;
+      if (check(hipFuncSetAttribute((const void*)env_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return -1;
+      if (check(hipFuncSetAttribute((const void*)env_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return -1;
+      if (check(hipFuncSetAttribute((const void*)env_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return -1;
+    }
+    return 0;
+  }
+  int launch(const KState& S, const Tables* T, int CL, int reset, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (CL) {
+      case 3: return launch_cl<3>(S, T, reset, lds_bytes, st);
+      case 4: return launch_cl<4>(S, T, reset, lds_bytes, st);
+      default: err = "unsupported chain length"; return -1;
+    }
+  }
+  int launch_export(const KState& S, const Tables* T, const AosPtrs& A, void* stream) {
+    hipLaunchKernelGGL(export_kernel, dim3((S.Npad + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, T, A);
+    return check(hipGetLastError());
+  }
+  int launch_import(const KState& S, const Tables* T, const float* r, const float* q, const float* qd, int N, int D, void* stream) {
+    // r/q/qd are HOST arrays (include/rl_env.h): stage them through temporary device buffers
+    hipStream_t st = (hipStream_t)stream;
+    float *dr = nullptr, *dq = nullptr, *dqd = nullptr;
+    if (r) { if (check(hipMalloc(&dr, (size_t)N * 13 * 4))) return -1; check(hipMemcpyAsync(dr, r, (size_t)N * 13 * 4, hipMemcpyHostToDevice, st)); }
+    if (q) { if (check(hipMalloc(&dq, (size_t)N * D * 4))) return -1; check(hipMemcpyAsync(dq, q, (size_t)N * D * 4, hipMemcpyHostToDevice, st)); }
+    if (qd) { if (check(hipMalloc(&dqd, (size_t)N * D * 4))) return -1; check(hipMemcpyAsync(dqd, qd, (size_t)N * D * 4, hipMemcpyHostToDevice, st)); }
+    hipLaunchKernelGGL(import_kernel, dim3((N + 63) / 64), dim3(64), 0, st, S, T, dr, dq, dqd, N);
+    int rc = check(hipGetLastError());
+    rc |= check(hipStreamSynchronize(st));
+    (void)hipFree(dr); (void)hipFree(dq); (void)hipFree(dqd);
+    return rc;
+  }
+  int read_and_zero(void* out, void* src, size_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (check(hipMemcpyAsync(out, src, n, hipMemcpyDeviceToHost, st))) return -1;
+    if (check(hipMemsetAsync(src, 0, n, st))) return -1;
+    return check(hipStreamSynchronize(st));
+  }
+};
+
+}  // namespace
+
+#include "rl_env_capi.inl"
+

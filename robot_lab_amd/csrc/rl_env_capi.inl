@@ -1,0 +1,102 @@
+// rl_env_capi.inl - the extern "C" entry points of include/rl_env.h, shared by the HIP library and the
+// CPU lane emulator.  The including file defines `Backend` first.
+using Impl = rl::EnvImpl<Backend>;
+
+extern "C" {
+
+int rl_env_create(const rl_env_desc* desc, const float* terrain_heights, const float* terrain_origins, const float* env_origins,
+                  int32_t num_envs, uint64_t seed, int32_t device, rl_env** out) {
+  if (!desc || !out) return rl::fail("null argument");
+  Impl* impl = new Impl();
+  int rc = impl->create(desc, terrain_heights, terrain_origins, env_origins, num_envs, seed, device);
+  if (rc) {
+    impl->destroy();
+    delete impl;
+    return rc;
+  }
+  *out = reinterpret_cast<rl_env*>(impl);
+  return 0;
+}
+
+int rl_env_reset(rl_env* env, const int32_t* env_ids, int32_t n, void* stream) {
+  if (!env) return rl::fail("null env");
+  return reinterpret_cast<Impl*>(env)->reset(env_ids, n, stream);
+}
+
+int rl_env_step(rl_env* env, const float* action_dev, void* stream) {
+  if (!env) return rl::fail("null env");
+  return reinterpret_cast<Impl*>(env)->step(action_dev, stream);
+}
+
+int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[3], int32_t* ndim, int32_t* elem_size) {
+  if (!env || !dev_ptr || !shape || !ndim || !elem_size) return rl::fail("null argument");
+  Impl& I = *reinterpret_cast<Impl*>(env);
+  const int64_t N = I.N, Np = I.Npad, D = I.D, B = I.B;
+  auto set = [&](void* p, int nd, int64_t a, int64_t b, int64_t c, int es) {
+    *dev_ptr = p; *ndim = nd; shape[0] = a; shape[1] = b; shape[2] = c; *elem_size = es;
+    return 0;
+  };
+  switch (which) {
+    case RL_BUF_OBS_POLICY: return set(I.S.obs_policy, 2, N, I.tables.policy_dim, 1, 4);
+    case RL_BUF_OBS_CRITIC: return set(I.S.obs_critic, 2, N, I.tables.critic_dim, 1, 4);
+    case RL_BUF_REWARD: return set(I.S.reward, 1, N, 1, 1, 4);
+    case RL_BUF_TERMINATED: return set(I.S.terminated, 1, N, 1, 1, 1);
+    case RL_BUF_TIME_OUT: return set(I.S.time_out, 1, N, 1, 1, 1);
+    case RL_BUF_EPISODE_LENGTH: return set(I.S.ep_len, 1, N, 1, 1, 8);
+    case RL_BUF_ROOT_STATE: return set(I.root_state, 2, N, 13, 1, 4);
+    case RL_BUF_JOINT_POS: return set(I.joint_pos, 2, N, D, 1, 4);
+    case RL_BUF_JOINT_VEL: return set(I.joint_vel, 2, N, D, 1, 4);
+    case RL_BUF_REWARD_TERMS: return set(I.S.rew_terms, 2, I.tables.n_rewards, Np, 1, 4);
+    case RL_BUF_EPISODE_SUMS: return set(I.S.ep_sums, 2, I.tables.n_rewards, Np, 1, 4);
+    case RL_BUF_COMMAND: return set(I.S.command_out, 2, N, 3, 1, 4);
+    case RL_BUF_CONTACT_FORCE: return set(I.S.dbg_cforce, 3, N, B, 3, 4);
+    case RL_BUF_CONTACT_TIMERS: return set(I.ctimers, 3, N, B, 4, 4);
+    case RL_BUF_LOG: return set(I.S.log, 1, RL_LOG_SIZE, 1, 1, 4);
+    case RL_BUF_ACTION: return set(I.action_aos, 2, N, D, 1, 4);
+    case RL_BUF_JOINT_TORQUE: return set(I.S.dbg_torque, 2, N, D, 1, 4);
+    case RL_BUF_JOINT_ACC: return set(I.S.dbg_acc, 2, N, D, 1, 4);
+    case RL_BUF_ENV_ORIGIN: return set(I.env_origin_aos, 2, N, 3, 1, 4);
+    case RL_BUF_TERRAIN_LEVEL: return set(I.S.level, 1, N, 1, 1, 4);
+    default: return rl::fail("unknown buffer id");
+  }
+}
+
+int rl_env_export_state(rl_env* env, void* stream) {
+  if (!env) return rl::fail("null env");
+  Impl& I = *reinterpret_cast<Impl*>(env);
+  rl::AosPtrs A{I.root_state, I.joint_pos, I.joint_vel, I.ctimers, I.action_aos, I.env_origin_aos};
+  return I.be.launch_export(I.S, I.tables_dev, A, stream) ? rl::fail("export launch failed: " + I.be.error()) : 0;
+}
+
+int rl_env_import_state(rl_env* env, const float* root_state, const float* joint_pos, const float* joint_vel, void* stream) {
+  if (!env) return rl::fail("null env");
+  Impl& I = *reinterpret_cast<Impl*>(env);
+  return I.be.launch_import(I.S, I.tables_dev, root_state, joint_pos, joint_vel, I.N, I.D, stream) ? rl::fail("import failed: " + I.be.error()) : 0;
+}
+
+int rl_env_read_log(rl_env* env, float* out_host, void* stream) {
+  if (!env || !out_host) return rl::fail("null argument");
+  Impl& I = *reinterpret_cast<Impl*>(env);
+  return I.be.read_and_zero(out_host, I.S.log, RL_LOG_SIZE * sizeof(float), stream) ? rl::fail("log read failed: " + I.be.error()) : 0;
+}
+
+int32_t rl_env_num_envs(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->N; }
+int32_t rl_env_num_actions(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->D; }
+int32_t rl_env_obs_dim(const rl_env* env, int32_t group) {
+  const Impl* I = reinterpret_cast<const Impl*>(env);
+  return group == 0 ? I->tables.policy_dim : I->tables.critic_dim;
+}
+int32_t rl_env_max_episode_length(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->tables.max_episode_length; }
+
+int rl_env_destroy(rl_env* env) {
+  if (!env) return 0;
+  Impl* I = reinterpret_cast<Impl*>(env);
+  I->destroy();
+  delete I;
+  return 0;
+}
+
+const char* rl_env_last_error(void) { return rl::last_error().c_str(); }
+uint64_t rl_env_desc_size(void) { return sizeof(rl_env_desc); }
+
+}  // extern "C"

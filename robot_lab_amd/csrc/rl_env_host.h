@@ -1,0 +1,393 @@
+// rl_env_host.h - host side of the C-ABI (include/rl_env.h): descriptor -> device tables, HBM
+// allocation in the SoA layout of env_tables.h, "startup" events, launches.  Backend-agnostic: the
+// HIP build (rl_env.hip) and the CPU lane-emulator build (tests/emu) instantiate it with their own
+// alloc/copy/launch primitives, so both expose the identical C-ABI.
+#pragma once
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rl_env.h"
+#include "env_tables.h"
+
+namespace rl {
+
+inline std::string& last_error() {
+  static thread_local std::string e;
+  return e;
+}
+inline int fail(const std::string& msg) {
+  last_error() = msg;
+  return -1;
+}
+
+inline int obs_term_dim(const rl_env_desc& d, int kind) {
+  switch (kind) {
+    case RL_OBS_JOINT_POS_REL: case RL_OBS_JOINT_VEL_REL: case RL_OBS_LAST_ACTION: case RL_OBS_JOINT_POS_REL_NO_WHEEL: return d.model.num_dof;
+    case RL_OBS_HEIGHT_SCAN: return d.task.scan_nx * d.task.scan_ny;
+    default: return 3;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// descriptor -> Tables.  Requires the star topology the lane program is written for.
+// ------------------------------------------------------------------------------------------------
+inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_lane, std::vector<int>& body_slot) {
+  memset(&T, 0, sizeof(T));
+  const rl_model_desc& m = d.model;
+  if (m.num_chains != NLANE || m.chain_len < 1 || m.chain_len > MAX_CL)
+    return fail("lane program needs a star articulation with 4 chains of <= 4 joints (got " + std::to_string(m.num_chains) + "x" +
+                std::to_string(m.chain_len) + ")");
+  const int CL = m.chain_len;
+  T.CL = CL;
+  T.D = m.num_dof;
+  T.n_bodies = m.num_bodies;
+  body_lane.assign(m.num_bodies, -1);
+  body_slot.assign(m.num_bodies, -1);
+  int n_base_bodies = 0;
+  for (int k = 0; k < NLANE; ++k) {
+    LaneTab& L = T.lane[k];
+    for (int s = 0; s < NBS; ++s) { L.slot_body[s] = -1; L.slot_grp[s] = 0; }
+    for (int g = 0; g < NGRP; ++g)
+      for (int s = 0; s < SPL; ++s) L.sph_r[g][s] = -1.f;
+    L.base_body_local = -1;
+    for (int j = 0; j < CL; ++j) {
+      int jt = k * CL + j, link = 1 + jt;
+      if (m.link_parent[link] != (j == 0 ? 0 : link - 1)) return fail("links are not in chain-major order");
+      for (int c = 0; c < 3; ++c) { L.origin[j][c] = m.link_origin[link][c]; L.axis[j][c] = m.link_axis[link][c]; }
+      L.lower[j] = m.joint_lower[jt]; L.upper[j] = m.joint_upper[jt]; L.vel_limit[j] = m.joint_vel_limit[jt];
+      L.armature[j] = m.joint_armature[jt]; L.q0[j] = m.default_joint_pos[jt]; L.qd0[j] = m.default_joint_vel[jt];
+      L.soft_lo[j] = m.soft_lower[jt]; L.soft_hi[j] = m.soft_upper[jt];
+      L.act_implicit[j] = m.act_implicit[jt]; L.kp0[j] = m.act_kp[jt]; L.kd0[j] = m.act_kd[jt];
+      L.eff[j] = m.act_effort_limit[jt]; L.sat[j] = m.act_saturation[jt]; L.act_vlim[j] = m.act_vel_limit[jt];
+      L.action_is_vel[j] = m.action_is_vel[jt]; L.a_scale[j] = m.action_scale[jt]; L.a_off[j] = m.action_offset[jt];
+      L.a_lo[j] = m.action_clip_lo[jt]; L.a_hi[j] = m.action_clip_hi[jt];
+      L.joint_id[j] = jt;
+    }
+  }
+  // bodies -> lane slots.  base-link bodies: one per lane, slot 0; chain bodies: slots 1..
+  int next_slot[NLANE] = {1, 1, 1, 1};
+  for (int b = 0; b < m.num_bodies; ++b) {
+    int link = m.body_link[b];
+    if (link == 0) {
+      if (n_base_bodies >= NLANE) return fail("more than 4 bodies on the base link");
+      int k = n_base_bodies++;
+      LaneTab& L = T.lane[k];
+      L.slot_body[0] = b; L.slot_grp[0] = 0; L.base_body_local = k; L.owns_base_body = 1;
+      for (int c = 0; c < 3; ++c) L.slot_pos[0][c] = m.body_pos[b][c];
+      body_lane[b] = k; body_slot[b] = 0;
+    } else {
+      int k = (link - 1) / CL, j = (link - 1) % CL;
+      LaneTab& L = T.lane[k];
+      int s = next_slot[k]++;
+      if (s >= NBS) return fail("too many bodies on one chain");
+      L.slot_body[s] = b; L.slot_grp[s] = j + 1;
+      for (int c = 0; c < 3; ++c) L.slot_pos[s][c] = m.body_pos[b][c];
+      body_lane[b] = k; body_slot[b] = s;
+    }
+  }
+  T.n_base_bodies = n_base_bodies;
+  // spheres -> lane / group / slot.  Spheres of a base-link body that has more spheres than SPL are
+  // dealt round-robin to the lanes that do not own another base-link body.
+  int fill[NLANE][NGRP];
+  memset(fill, 0, sizeof(fill));
+  std::vector<int> base_count(m.num_bodies, 0);
+  for (int g = 0; g < m.num_spheres; ++g)
+    if (m.body_link[m.sphere_body[g]] == 0) base_count[m.sphere_body[g]]++;
+  int rr = 0;
+  for (int g = 0; g < m.num_spheres; ++g) {
+    int b = m.sphere_body[g], link = m.body_link[b];
+    int k, grp, slot;
+    if (link == 0) {
+      grp = 0; slot = 0;
+      k = body_lane[b];
+      if (base_count[b] > SPL) {  // spread (A1 trunk: 8 corner spheres -> 2 per lane)
+        for (int tries = 0; tries < NLANE; ++tries, ++rr) {
+          int kk = rr % NLANE;
+          int other = T.lane[kk].base_body_local;
+          if ((other == -1 || other == T.lane[body_lane[b]].base_body_local) && fill[kk][0] < SPL) { k = kk; ++rr; break; }
+        }
+        if (T.lane[k].base_body_local == -1) T.lane[k].base_body_local = T.lane[body_lane[b]].base_body_local;
+      }
+    } else {
+      k = (link - 1) / CL; grp = (link - 1) % CL + 1; slot = body_slot[b];
+    }
+    LaneTab& L = T.lane[k];
+    if (fill[k][grp] >= SPL) return fail("more than 3 collision spheres on one link group (body " + std::to_string(b) + ")");
+    int s = fill[k][grp]++;
+    for (int c = 0; c < 3; ++c) L.sph_c[grp][s][c] = m.sphere_center[g][c];
+    L.sph_r[grp][s] = m.sphere_radius[g];
+    L.sph_slot[grp][s] = slot;
+  }
+  // sim / terrain / task scalars
+  const rl_sim_desc& s = d.sim;
+  T.dt = s.dt; T.decimation = s.decimation; T.gravity = s.gravity; T.contact_k = s.contact_k; T.contact_c = s.contact_c;
+  T.contact_phi_ref = s.contact_phi_ref; T.contact_ct = s.contact_ct; T.contact_vdep = s.contact_vdep; T.contact_vstick = s.contact_vstick;
+  T.limit_k = s.limit_k; T.limit_c = s.limit_c; T.force_threshold = s.force_threshold;
+  const rl_terrain_desc& tr = d.terrain;
+  T.is_plane = tr.is_plane; T.nx = tr.nx; T.ny = tr.ny; T.hscale = tr.hscale; T.x0 = tr.x0; T.y0 = tr.y0;
+  T.num_rows = tr.num_rows; T.num_cols = tr.num_cols; T.tile_size = tr.tile_size; T.border = tr.border; T.curriculum = tr.curriculum;
+  const rl_task_desc& t = d.task;
+  T.step_dt = s.dt * (float)s.decimation;
+  T.max_episode_length_s = t.episode_length_s;
+  T.max_episode_length = (int)ceil((double)t.episode_length_s / ((double)s.dt * s.decimation) - 1e-9);
+  memcpy(T.cmd_range, t.cmd_range, sizeof(T.cmd_range));
+  memcpy(T.cmd_resample, t.cmd_resample, sizeof(T.cmd_resample));
+  T.cmd_rel_standing = t.cmd_rel_standing; T.cmd_rel_heading = t.cmd_rel_heading; T.cmd_heading_stiffness = t.cmd_heading_stiffness;
+  T.cmd_small_threshold = t.cmd_small_threshold; T.cmd_heading = t.cmd_heading;
+  if (t.n_policy > MAX_OBS || t.n_critic > MAX_OBS || t.n_rewards > MAX_T) return fail("too many terms");
+  T.n_policy = t.n_policy; T.n_critic = t.n_critic; T.policy_corrupt = t.policy_corrupt; T.critic_corrupt = t.critic_corrupt;
+  for (int grp = 0; grp < 2; ++grp) {
+    const rl_obs_term* src = grp == 0 ? t.policy : t.critic;
+    ObsTab* dst = grp == 0 ? T.policy : T.critic;
+    int n = grp == 0 ? t.n_policy : t.n_critic, off = 0;
+    for (int i = 0; i < n; ++i) {
+      dst[i].kind = src[i].kind; dst[i].scale = src[i].scale; dst[i].clip_lo = src[i].clip_lo; dst[i].clip_hi = src[i].clip_hi;
+      dst[i].noise_lo = src[i].noise_lo; dst[i].noise_hi = src[i].noise_hi; dst[i].has_noise = src[i].has_noise; dst[i].offset = off;
+      off += obs_term_dim(d, src[i].kind);
+    }
+    (grp == 0 ? T.policy_dim : T.critic_dim) = off;
+  }
+  T.scan_nx = t.scan_nx; T.scan_ny = t.scan_ny; T.scan_res = t.scan_res; T.scan_offset = t.scan_offset; T.wheel_joint_mask = t.wheel_joint_mask;
+  T.n_rewards = t.n_rewards;
+  for (int i = 0; i < t.n_rewards; ++i) {
+    const rl_reward_term& r = t.rewards[i];
+    if (r.kind < 0 || r.kind >= RL_REW_NUM_KINDS) return fail("unknown reward kind");
+    RewTab& R = T.rew[i];
+    R.kind = r.kind; R.weight = r.weight; memcpy(R.p, r.p, sizeof(R.p)); R.joint_mask = r.joint_mask; R.body_mask = r.body_mask;
+    memcpy(R.idx_a, r.idx_a, sizeof(R.idx_a)); memcpy(R.idx_b, r.idx_b, sizeof(R.idx_b)); R.n_idx = r.n_idx;
+  }
+  T.term_time_out = t.term_time_out; T.term_oob = t.term_out_of_bounds; T.term_illegal = t.term_illegal_contact;
+  T.oob_buffer = t.oob_buffer; T.illegal_threshold = t.illegal_threshold; T.illegal_body_mask = t.illegal_body_mask;
+  T.ev_wrench = t.ev_wrench; T.ev_reset_joints = t.ev_reset_joints; T.ev_gains = t.ev_gains; T.ev_reset_base = t.ev_reset_base; T.ev_push = t.ev_push;
+  memcpy(T.wrench_force, t.wrench_force, 8); memcpy(T.wrench_torque, t.wrench_torque, 8);
+  memcpy(T.reset_jpos, t.reset_joint_pos_scale, 8); memcpy(T.reset_jvel, t.reset_joint_vel_scale, 8);
+  memcpy(T.gain_kp, t.gain_kp_scale, 8); memcpy(T.gain_kd, t.gain_kd_scale, 8);
+  memcpy(T.reset_pose, t.reset_pose, sizeof(T.reset_pose)); memcpy(T.reset_vel, t.reset_vel, sizeof(T.reset_vel));
+  memcpy(T.push_interval, t.push_interval, 8); memcpy(T.push_vel, t.push_vel, sizeof(T.push_vel));
+  memcpy(T.default_root_pos, m.default_root_pos, 12); memcpy(T.default_root_quat, m.default_root_quat, 16);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The environment object behind the opaque rl_env*.
+// ------------------------------------------------------------------------------------------------
+template <class Backend>
+struct EnvImpl {
+  Backend be;
+  rl_env_desc desc;
+  Tables tables;
+  Tables* tables_dev = nullptr;
+  KState S;
+  int N = 0, Npad = 0, D = 0, B = 0, CL = 0;
+  uint64_t seed = 0;
+  uint32_t step_counter = 0;
+  std::vector<int> body_lane, body_slot;
+  std::vector<void*> allocs;
+  // AoS inspection buffers
+  float *root_state = nullptr, *joint_pos = nullptr, *joint_vel = nullptr, *cforce = nullptr, *ctimers = nullptr, *action_aos = nullptr;
+  float *env_origin_aos = nullptr;
+  uint8_t* reset_mask = nullptr;
+  float* terrain_dev = nullptr;
+  float* terrain_origins_dev = nullptr;
+
+  template <class Tp>
+  Tp* alloc(size_t n) {
+    void* p = be.alloc(n * sizeof(Tp));
+    if (p) {
+      be.zero(p, n * sizeof(Tp));
+      allocs.push_back(p);
+    }
+    return (Tp*)p;
+  }
+
+  int create(const rl_env_desc* d, const float* terrain_heights, const float* terrain_origins, const float* env_origins,
+             int32_t num_envs, uint64_t seed_, int32_t device) {
+    desc = *d;
+    seed = seed_;
+    N = num_envs;
+    Npad = (N + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE * ENVS_PER_WAVE;
+    D = d->model.num_dof;
+    B = d->model.num_bodies;
+    if (N <= 0) return fail("num_envs must be positive");
+    if (build_tables(*d, tables, body_lane, body_slot)) return -1;
+    CL = tables.CL;
+    if (be.init(device)) return fail("device init failed: " + be.error());
+    if (be.configure(tables)) return fail("kernel configuration failed: " + be.error());
+    const size_t NL = (size_t)NLANE * Npad, Np = Npad;
+    memset(&S, 0, sizeof(S));
+    S.N = N; S.Npad = Npad; S.seed = seed;
+    S.q = alloc<float>(MAX_CL * NL); S.qd = alloc<float>(MAX_CL * NL); S.kp = alloc<float>(MAX_CL * NL);
+    S.kd = alloc<float>(MAX_CL * NL); S.act = alloc<float>(MAX_CL * NL);
+    S.link_inertia = alloc<float>(MAX_CL * INERTIA_NF * NL);
+    S.timers = alloc<float>(NBS * 4 * NL); S.friction = alloc<float>(NBS * 3 * NL);
+    S.root = alloc<float>(13 * Np); S.wrench = alloc<float>(6 * Np); S.base_inertia = alloc<float>(10 * Np);
+    S.base_com = alloc<float>(3 * Np); S.cmd = alloc<float>(CMD_NFIELD * Np); S.flags = alloc<int32_t>(Np);
+    S.level = alloc<int32_t>(Np); S.ttype = alloc<int32_t>(Np); S.origin = alloc<float>(3 * Np);
+    S.ep_len = alloc<int64_t>(Np); S.ep_sums = alloc<float>(MAX_T * Np);
+    S.obs_policy = alloc<float>(Np * (size_t)std::max(1, tables.policy_dim));
+    S.obs_critic = alloc<float>(Np * (size_t)std::max(1, tables.critic_dim));
+    S.reward = alloc<float>(Np); S.terminated = alloc<uint8_t>(Np); S.time_out = alloc<uint8_t>(Np);
+    S.rew_terms = alloc<float>(MAX_T * Np); S.command_out = alloc<float>(3 * Np); S.log = alloc<float>(LOG_SIZE);
+    S.dbg_torque = alloc<float>(Np * D); S.dbg_acc = alloc<float>(Np * D); S.dbg_cforce = alloc<float>(Np * B * 3);
+    root_state = alloc<float>(Np * 13); joint_pos = alloc<float>(Np * D); joint_vel = alloc<float>(Np * D);
+    ctimers = alloc<float>(Np * B * 4); action_aos = alloc<float>(Np * D); env_origin_aos = alloc<float>(Np * 3);
+    reset_mask = alloc<uint8_t>(Np);
+    tables_dev = alloc<Tables>(1);
+    if (!tables_dev) return fail("device allocation failed: " + be.error());
+    if (!desc.terrain.is_plane) {
+      if (!terrain_heights || !terrain_origins) return fail("heightfield terrain needs heights and sub-terrain origins");
+      size_t nh = (size_t)desc.terrain.nx * desc.terrain.ny;
+      terrain_dev = alloc<float>(nh);
+      terrain_origins_dev = alloc<float>((size_t)desc.terrain.num_rows * desc.terrain.num_cols * 3);
+      if (!terrain_dev) return fail("device allocation failed (terrain)");
+      be.h2d(terrain_dev, terrain_heights, nh * 4);
+      be.h2d(terrain_origins_dev, terrain_origins, (size_t)desc.terrain.num_rows * desc.terrain.num_cols * 12);
+    } else if (!env_origins) {
+      return fail("plane terrain needs env_origins");
+    }
+    S.terrain = terrain_dev;
+    S.terrain_origins = terrain_origins_dev;
+    be.h2d(tables_dev, &tables, sizeof(Tables));
+    startup(terrain_origins, env_origins);
+    return 0;
+  }
+
+  // "startup" events (velocity_env_cfg.py:262-314) [UPSTREAM B8] + initial terrain levels [UPSTREAM B9].
+  // Host-side, once; same draws as oracle/env.py:startup_randomisation.
+  void startup(const float* terrain_origins, const float* env_origins) {
+    const rl_model_desc& m = desc.model;
+    const rl_task_desc& t = desc.task;
+    const size_t NL = (size_t)NLANE * Npad, Np = Npad;
+    std::vector<float> link_inertia(MAX_CL * INERTIA_NF * NL, 0.f), friction(NBS * 3 * NL, 0.f), base_inertia(10 * Np, 0.f), base_com(3 * Np, 0.f);
+    std::vector<float> kp(MAX_CL * NL, 0.f), kd(MAX_CL * NL, 0.f), q(MAX_CL * NL, 0.f), origin(3 * Np, 0.f), root(13 * Np, 0.f);
+    std::vector<int32_t> level(Np, 0), ttype(Np, 0);
+    std::vector<float> bs(64, 1.f), bd(64, 1.f), br(64, 0.f);
+    int nb = t.friction_buckets > 0 ? (t.friction_buckets > 64 ? 64 : t.friction_buckets) : 1;
+    if (t.ev_material)
+      for (int j = 0; j < nb; ++j) {
+        bs[j] = uniform_range(seed, GLOBAL_ENV, 0, STREAM_STARTUP, 3 * j, t.friction_static[0], t.friction_static[1]);
+        bd[j] = uniform_range(seed, GLOBAL_ENV, 0, STREAM_STARTUP, 3 * j + 1, t.friction_dynamic[0], t.friction_dynamic[1]);
+        br[j] = uniform_range(seed, GLOBAL_ENV, 0, STREAM_STARTUP, 3 * j + 2, t.restitution[0], t.restitution[1]);
+        bd[j] = fminf(bd[j], bs[j]);
+      }
+    std::vector<double> lm(m.num_links), lh(m.num_links * 3), lI(m.num_links * 9);
+    for (int e = 0; e < Npad; ++e) {
+      // per-body mass / com / material
+      std::fill(lm.begin(), lm.end(), 0.0); std::fill(lh.begin(), lh.end(), 0.0); std::fill(lI.begin(), lI.end(), 0.0);
+      for (int b = 0; b < m.num_bodies; ++b) {
+        double mass = m.body_mass[b];
+        if (t.ev_mass_base && ((t.mass_base_mask >> b) & 1ull))
+          mass += uniform_range(seed, e, 0, STREAM_STARTUP, IDX_MASS_ADD + b, t.mass_base_add[0], t.mass_base_add[1]);
+        if (t.ev_mass_others && ((t.mass_scale_mask >> b) & 1ull))
+          mass *= uniform_range(seed, e, 0, STREAM_STARTUP, IDX_MASS_SCALE + b, t.mass_scale[0], t.mass_scale[1]);
+        if (m.body_mass[b] > 0.f && mass < 1e-6) mass = 1e-6;
+        double c[3] = {m.body_com[b][0], m.body_com[b][1], m.body_com[b][2]};
+        if (t.ev_com && b == t.base_body)
+          for (int a = 0; a < 3; ++a) c[a] += uniform_range(seed, e, 0, STREAM_STARTUP, IDX_COM + 3 * b + a, t.com_range[a][0], t.com_range[a][1]);
+        if (b == t.base_body)
+          for (int a = 0; a < 3; ++a) base_com[a * Np + e] = (float)c[a];
+        double sc = m.body_mass[b] > 0.f ? mass / m.body_mass[b] : 0.0;
+        const float* I6 = m.body_inertia[b];
+        double Ic[9] = {sc * I6[0], sc * I6[3], sc * I6[4], sc * I6[3], sc * I6[1], sc * I6[5], sc * I6[4], sc * I6[5], sc * I6[2]};
+        int l = m.body_link[b];
+        double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+        lm[l] += mass;
+        for (int a = 0; a < 3; ++a) lh[l * 3 + a] += mass * c[a];
+        for (int a = 0; a < 3; ++a)
+          for (int bb = 0; bb < 3; ++bb) lI[l * 9 + a * 3 + bb] += Ic[a * 3 + bb] + mass * ((a == bb ? cc : 0.0) - c[a] * c[bb]);  // about the link origin
+        // material
+        int bucket = 0;
+        if (t.ev_material) {
+          bucket = (int)floorf(uniform01(seed, e, 0, STREAM_STARTUP, IDX_BUCKET + b) * (float)nb);
+          if (bucket > nb - 1) bucket = nb - 1;
+        }
+        int k = body_lane[b], s = body_slot[b];
+        float mu[3] = {t.ev_material ? bs[bucket] : 1.f, t.ev_material ? bd[bucket] : 1.f, t.ev_material ? br[bucket] : 0.f};
+        for (int kk = 0; kk < NLANE; ++kk) {
+          // base-link bodies may have spheres on other lanes too: replicate their material into slot 0 there
+          bool here = kk == k || (s == 0 && tables.lane[kk].base_body_local == tables.lane[k].base_body_local && !tables.lane[kk].owns_base_body);
+          if (!here) continue;
+          for (int a = 0; a < 3; ++a) friction[(s * 3 + a) * NL + (size_t)e * NLANE + kk] = mu[a];
+        }
+      }
+      // composite per link -> (mass, com, inertia about com)
+      for (int l = 0; l < m.num_links; ++l) {
+        double mass = lm[l], c[3] = {0, 0, 0};
+        if (mass > 0) for (int a = 0; a < 3; ++a) c[a] = lh[l * 3 + a] / mass;
+        double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+        double Ic[9];
+        for (int a = 0; a < 3; ++a)
+          for (int bb = 0; bb < 3; ++bb) Ic[a * 3 + bb] = lI[l * 9 + a * 3 + bb] - mass * ((a == bb ? cc : 0.0) - c[a] * c[bb]);
+        float rec[10] = {(float)mass, (float)c[0], (float)c[1], (float)c[2], (float)Ic[0], (float)Ic[4], (float)Ic[8], (float)Ic[1], (float)Ic[2], (float)Ic[5]};
+        if (l == 0) {
+          for (int f = 0; f < 10; ++f) base_inertia[f * Np + e] = rec[f];
+        } else {
+          int k = (l - 1) / CL, j = (l - 1) % CL;
+          for (int f = 0; f < 10; ++f) link_inertia[((size_t)j * INERTIA_NF + f) * NL + (size_t)e * NLANE + k] = rec[f];
+        }
+      }
+      for (int k = 0; k < NLANE; ++k)
+        for (int j = 0; j < CL; ++j) {
+          kp[j * NL + (size_t)e * NLANE + k] = tables.lane[k].kp0[j];
+          kd[j * NL + (size_t)e * NLANE + k] = tables.lane[k].kd0[j];
+          q[j * NL + (size_t)e * NLANE + k] = tables.lane[k].q0[j];
+        }
+      // terrain level / type / env origin
+      if (desc.terrain.is_plane) {
+        int ee = e < N ? e : N - 1;
+        for (int a = 0; a < 3; ++a) origin[a * Np + e] = env_origins[ee * 3 + a];
+      } else {
+        int ee = e < N ? e : N - 1;  // padding envs mirror the last real env's cell
+        ttype[e] = (int)floor((double)ee / ((double)N / desc.terrain.num_cols));
+        int lv = (int)floorf(uniform01(seed, ee, 0, STREAM_STARTUP, IDX_INIT_LEVEL) * (float)(desc.terrain.max_init_level + 1));
+        level[e] = lv > desc.terrain.max_init_level ? desc.terrain.max_init_level : lv;
+        for (int a = 0; a < 3; ++a) origin[a * Np + e] = terrain_origins[((size_t)level[e] * desc.terrain.num_cols + ttype[e]) * 3 + a];
+      }
+      root[3 * Np + e] = 1.f;  // identity quaternion until the first reset
+      for (int a = 0; a < 3; ++a) root[a * Np + e] = origin[a * Np + e] + m.default_root_pos[a];
+    }
+    be.h2d(S.link_inertia, link_inertia.data(), link_inertia.size() * 4);
+    be.h2d(S.friction, friction.data(), friction.size() * 4);
+    be.h2d(S.base_inertia, base_inertia.data(), base_inertia.size() * 4);
+    be.h2d(S.base_com, base_com.data(), base_com.size() * 4);
+    be.h2d(S.kp, kp.data(), kp.size() * 4); be.h2d(S.kd, kd.data(), kd.size() * 4); be.h2d(S.q, q.data(), q.size() * 4);
+    be.h2d(S.origin, origin.data(), origin.size() * 4); be.h2d(S.root, root.data(), root.size() * 4);
+    be.h2d(S.level, level.data(), level.size() * 4); be.h2d(S.ttype, ttype.data(), ttype.size() * 4);
+  }
+
+  int reset(const int32_t* env_ids, int32_t n, void* stream) {
+    KState s = S;
+    s.step_counter = step_counter;
+    if (env_ids == nullptr) {
+      s.reset_mask = nullptr;
+    } else {
+      std::vector<uint8_t> mask(Npad, 0);
+      for (int i = 0; i < n; ++i) {
+        if (env_ids[i] < 0 || env_ids[i] >= N) return fail("env id out of range");
+        mask[env_ids[i]] = 1;
+      }
+      be.h2d_stream(reset_mask, mask.data(), Npad, stream);
+      s.reset_mask = reset_mask;
+    }
+    return be.launch(s, tables_dev, CL, /*reset=*/1, stream) ? fail("launch failed: " + be.error()) : 0;
+  }
+
+  int step(const float* action_dev, void* stream) {
+    if (!action_dev) return fail("action pointer is null");
+    KState s = S;
+    s.step_counter = ++step_counter;
+    s.action_in = action_dev;
+    return be.launch(s, tables_dev, CL, /*reset=*/0, stream) ? fail("launch failed: " + be.error()) : 0;
+  }
+
+  void destroy() {
+    for (void* p : allocs) be.free(p);
+    allocs.clear();
+  }
+};
+
+}  // namespace rl

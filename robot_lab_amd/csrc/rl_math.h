@@ -1,0 +1,162 @@
+// rl_math.h - small fixed-size linear algebra + Philox4x32-10 for the env-step lane program.
+// Plain C++17, no HIP types: compiled by hipcc for gfx950 (RL_FN = __device__ __host__) and by g++
+// for the CPU lane emulator used by the `-m "not gpu"` tests (tests/emu).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifndef RL_FN
+#define RL_FN inline
+#endif
+
+namespace rl {
+
+struct V3 {
+  float x, y, z;
+};
+RL_FN V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RL_FN V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+RL_FN V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+RL_FN V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+RL_FN V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+RL_FN V3 operator*(V3 a, float s) { return {s * a.x, s * a.y, s * a.z}; }
+RL_FN V3& operator+=(V3& a, V3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+RL_FN V3& operator-=(V3& a, V3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+RL_FN float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RL_FN V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RL_FN float norm(V3 a) { return sqrtf(dot(a, a)); }
+
+// 3x3 matrix, row major
+struct M3 {
+  V3 r0, r1, r2;
+};
+RL_FN V3 mul(const M3& m, V3 v) { return {dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)}; }
+RL_FN V3 mulT(const M3& m, V3 v) { return v.x * m.r0 + v.y * m.r1 + v.z * m.r2; }
+RL_FN V3 col0(const M3& m) { return {m.r0.x, m.r1.x, m.r2.x}; }
+RL_FN V3 col1(const M3& m) { return {m.r0.y, m.r1.y, m.r2.y}; }
+RL_FN V3 col2(const M3& m) { return {m.r0.z, m.r1.z, m.r2.z}; }
+RL_FN M3 mul(const M3& a, const M3& b) {
+  V3 c0 = mul(a, col0(b)), c1 = mul(a, col1(b)), c2 = mul(a, col2(b));
+  return {{c0.x, c1.x, c2.x}, {c0.y, c1.y, c2.y}, {c0.z, c1.z, c2.z}};
+}
+RL_FN M3 identity3() { return {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}; }
+
+// symmetric 3x3
+struct S3 {
+  float xx, yy, zz, xy, xz, yz;
+};
+RL_FN V3 mul(const S3& s, V3 v) {
+  return {s.xx * v.x + s.xy * v.y + s.xz * v.z, s.xy * v.x + s.yy * v.y + s.yz * v.z, s.xz * v.x + s.yz * v.y + s.zz * v.z};
+}
+RL_FN S3 operator+(S3 a, S3 b) { return {a.xx + b.xx, a.yy + b.yy, a.zz + b.zz, a.xy + b.xy, a.xz + b.xz, a.yz + b.yz}; }
+// R S R^T for rotation R
+RL_FN S3 rotate(const M3& R, const S3& s) {
+  V3 c0 = mul(R, V3{s.xx, s.xy, s.xz}), c1 = mul(R, V3{s.xy, s.yy, s.yz}), c2 = mul(R, V3{s.xz, s.yz, s.zz});
+  // T = R S (columns c0,c1,c2); result = T R^T : out_ij = sum_k T_ik R_jk
+  V3 t0{c0.x, c1.x, c2.x}, t1{c0.y, c1.y, c2.y}, t2{c0.z, c1.z, c2.z};  // rows of T
+  return {dot(t0, R.r0), dot(t1, R.r1), dot(t2, R.r2), dot(t0, R.r1), dot(t0, R.r2), dot(t1, R.r2)};
+}
+
+// rotation about unit axis by angle (child -> parent coordinates)
+RL_FN M3 rodrigues(V3 a, float ang) {
+  float s = sinf(ang), c = cosf(ang), t = 1.0f - c;
+  return {{c + t * a.x * a.x, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y},
+          {t * a.x * a.y + s * a.z, c + t * a.y * a.y, t * a.y * a.z - s * a.x},
+          {t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, c + t * a.z * a.z}};
+}
+
+struct Q4 {
+  float w, x, y, z;
+};
+RL_FN M3 quat_to_mat(Q4 q) {
+  float w = q.w, x = q.x, y = q.y, z = q.z;
+  return {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+          {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+          {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+}
+RL_FN Q4 quat_mul(Q4 a, Q4 b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+RL_FN Q4 quat_normalize(Q4 q) {
+  float inv = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+}
+RL_FN Q4 quat_from_euler_xyz(float roll, float pitch, float yaw) {
+  float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f), cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
+  float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
+  return {cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp};
+}
+
+// spatial vector [angular; linear] and spatial inertia, all in base coordinates about the base origin
+struct SV {
+  V3 a, l;
+};
+RL_FN SV operator+(SV p, SV q) { return {p.a + q.a, p.l + q.l}; }
+RL_FN SV operator-(SV p, SV q) { return {p.a - q.a, p.l - q.l}; }
+RL_FN SV operator*(SV p, float s) { return {p.a * s, p.l * s}; }
+RL_FN float dot(SV p, SV q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+RL_FN SV crm(SV v, SV s) { return {cross(v.a, s.a), cross(v.a, s.l) + cross(v.l, s.a)}; }  // motion x motion
+RL_FN SV crf(SV v, SV f) { return {cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }  // motion x* force
+struct SI {
+  float m;
+  V3 h;  // m * c
+  S3 I;  // rotational inertia about the origin
+};
+RL_FN SV apply(const SI& s, SV v) { return {mul(s.I, v.a) + cross(s.h, v.l), s.m * v.l - cross(s.h, v.a)}; }
+RL_FN SI operator+(const SI& p, const SI& q) { return {p.m + q.m, p.h + q.h, p.I + q.I}; }
+// rigid body (mass m, com c, inertia about com Ic - all already in base coordinates) -> spatial inertia about origin
+RL_FN SI make_si(float m, V3 c, S3 Ic) {
+  float cc = dot(c, c);
+  S3 I{Ic.xx + m * (cc - c.x * c.x), Ic.yy + m * (cc - c.y * c.y), Ic.zz + m * (cc - c.z * c.z),
+       Ic.xy - m * c.x * c.y, Ic.xz - m * c.x * c.z, Ic.yz - m * c.y * c.z};
+  return {m, m * c, I};
+}
+
+RL_FN float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+RL_FN float wrap_to_pi(float a) {
+  const float PI = 3.14159265358979323846f;
+  float w = fmodf(a + PI, 2.0f * PI);
+  if (w < 0.0f) w += 2.0f * PI;
+  return w - PI;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. SC'11).  uniform(seed, env, counter, stream, index) is the single
+// randomness primitive of the env; tests/test_philox.py pins it to the Random123 known answers and
+// to oracle/philox.py.
+// ---------------------------------------------------------------------------------------------
+struct U4 {
+  uint32_t x, y, z, w;
+};
+RL_FN uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+RL_FN U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+RL_FN float u24(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+RL_FN float uniform01(uint64_t seed, uint32_t env, uint32_t counter, uint32_t stream, uint32_t index) {
+  U4 r = philox4x32_10(U4{env, counter, stream, index >> 2}, (uint32_t)seed, (uint32_t)(seed >> 32));
+  uint32_t s = index & 3u;
+  return u24(s == 0 ? r.x : s == 1 ? r.y : s == 2 ? r.z : r.w);
+}
+RL_FN float uniform_range(uint64_t seed, uint32_t env, uint32_t counter, uint32_t stream, uint32_t index, float lo, float hi) {
+  return lo + (hi - lo) * uniform01(seed, env, counter, stream, index);
+}
+
+enum : uint32_t { STREAM_RESET = 1, STREAM_COMMAND = 2, STREAM_PUSH = 3, STREAM_NOISE = 4, STREAM_STARTUP = 5, STREAM_ACTION = 6 };
+enum : uint32_t {
+  IDX_WRENCH = 0, IDX_JPOS = 8, IDX_JVEL = 40, IDX_KP = 72, IDX_KD = 104, IDX_POSE = 136, IDX_VEL = 142, IDX_CMD = 148,
+  IDX_CMD_TIME = 154, IDX_PUSH_TIME = 155, IDX_LEVEL = 156,
+  IDX_BUCKET = 0, IDX_MASS_ADD = 64, IDX_MASS_SCALE = 128, IDX_COM = 192, IDX_INIT_LEVEL = 300
+};
+static const uint32_t GLOBAL_ENV = 0xFFFFFFFFu;
+
+}  // namespace rl

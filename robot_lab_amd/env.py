@@ -1,0 +1,336 @@
+"""`ManagerBasedRLEnv` - the drop-in boundary.
+
+Same construction and call surface as the class the reference registers as its gym entry point
+(`isaaclab.envs:ManagerBasedRLEnv`; `VEL/config/quadruped/unitree_a1/__init__.py:12-32`,
+`scripts/reinforcement_learning/rsl_rl/train.py:177`, `scripts/tools/zero_agent.py:56-73`):
+
+    env = gym.make("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", cfg=env_cfg)
+    obs, extras = env.reset()
+    obs, rew, terminated, time_outs, extras = env.step(actions)      # device tensors in, device tensors out
+
+but `step()` is ONE hand-written HIP kernel launch on the MI355X (through the C-ABI of
+`include/rl_env.h`) instead of PhysX + a few hundred torch kernels.  PyTorch is only the owner of
+device memory handed in (actions) and the view type handed out; every returned tensor is a zero-copy
+view of an env-owned HBM buffer that the next `step()` overwrites (the reference returns its buffers
+by reference as well).
+
+There is no CPU path: without `librl_env_hip.so` or without a GPU the constructor raises.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .capi import NativeEnv, RlEnvError
+from .desc import RL_LOG_SIZE, EnvDesc
+from .scene import build_world, load_bundle
+
+try:  # gymnasium (or the shim in robot_lab_amd/shims) supplies Env / spaces when available
+    import gymnasium as gym
+    _EnvBase = gym.Env
+except Exception:  # noqa: BLE001
+    gym = None
+    _EnvBase = object
+
+
+class _DevView:
+    """`__cuda_array_interface__` holder: lets torch adopt an env-owned device buffer without copying."""
+
+    def __init__(self, ptr, shape, dtype, owner):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=np.dtype(dtype).str, data=(int(ptr), False), version=2, strides=None)
+        self._owner = owner
+
+
+class _LazyLog(dict):
+    """`extras["log"]`: per-step episode log [UPSTREAM B1/B2] backed by a device snapshot; entries are
+    0-dim device tensors materialised on first access, so a training loop that only reads them at log
+    time never forces a host sync inside `step()`."""
+
+    def __init__(self, env, snap):
+        super().__init__()
+        self._env, self._snap, self._done = env, snap, False
+
+    def _fill(self):
+        if self._done:
+            return
+        self._done = True
+        e, s = self._env, self._snap
+        cnt = torch.clamp(s[0], min=1.0)
+        for i, name in enumerate(e.desc.reward_names):
+            dict.__setitem__(self, "Episode_Reward/" + name, s[8 + i] / cnt / e.max_episode_length_s)
+        dict.__setitem__(self, "Metrics/base_velocity/error_vel_xy", s[4] / cnt)
+        dict.__setitem__(self, "Metrics/base_velocity/error_vel_yaw", s[5] / cnt)
+        dict.__setitem__(self, "Episode_Termination/time_out", s[1])
+        dict.__setitem__(self, "Episode_Termination/terrain_out_of_bounds", s[2])
+        if e.desc.task.term_illegal_contact:
+            dict.__setitem__(self, "Episode_Termination/illegal_contact", s[3])
+        if e.desc.terrain.curriculum and not e.desc.terrain.is_plane:
+            dict.__setitem__(self, "Curriculum/terrain_levels", e.terrain_levels.float().mean())
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+
+class _ArticulationData:
+    """`env.scene["robot"].data` view (camera follow `rl_utils.py:12-13`, user scripts): refreshed lazily
+    from the SoA simulator state by `rl_env_export_state`."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def _root(self):
+        self._env._export()
+        return self._env._bufs["ROOT_STATE"]
+
+    root_pos_w = property(lambda self: self._root()[:, 0:3])
+    root_quat_w = property(lambda self: self._root()[:, 3:7])
+    root_lin_vel_w = property(lambda self: self._root()[:, 7:10])
+    root_ang_vel_w = property(lambda self: self._root()[:, 10:13])
+    root_state_w = property(lambda self: self._root())
+
+    @property
+    def joint_pos(self):
+        self._env._export()
+        return self._env._bufs["JOINT_POS"]
+
+    @property
+    def joint_vel(self):
+        self._env._export()
+        return self._env._bufs["JOINT_VEL"]
+
+    @property
+    def default_joint_pos(self):
+        e = self._env
+        return torch.tensor(list(e.desc.model.default_joint_pos)[: e.num_actions], device=e.device).repeat(e.num_envs, 1)
+
+    applied_torque = property(lambda self: self._env._bufs["JOINT_TORQUE"])
+    joint_acc = property(lambda self: self._env._bufs["JOINT_ACC"])
+
+
+class _Articulation:
+    def __init__(self, env):
+        self.data = _ArticulationData(env)
+        self.joint_names = list(env.desc.joint_names)
+        self.body_names = list(env.desc.body_names)
+        self.num_joints = len(self.joint_names)
+        self.num_bodies = len(self.body_names)
+
+    def find_joints(self, name_keys, preserve_order=False):
+        from .model.build import find_names
+        ids = find_names(name_keys, self.joint_names, preserve_order)
+        return ids, [self.joint_names[i] for i in ids]
+
+    def find_bodies(self, name_keys, preserve_order=False):
+        from .model.build import find_names
+        ids = find_names(name_keys, self.body_names, preserve_order)
+        return ids, [self.body_names[i] for i in ids]
+
+
+class _Scene(dict):
+    def __init__(self, env):
+        super().__init__(robot=_Articulation(env))
+        self._env = env
+        self.sensors = {}
+
+    num_envs = property(lambda self: self._env.num_envs)
+    env_origins = property(lambda self: (self._env._export(), self._env._bufs["ENV_ORIGIN"])[1])
+
+
+class _CommandManager:
+    def __init__(self, env):
+        self._env = env
+
+    def get_command(self, name):
+        return self._env._bufs["COMMAND"]
+
+
+class _RewardManager:
+    def __init__(self, env):
+        self._env = env
+        self.active_terms = list(env.desc.reward_names)
+
+    @property
+    def _episode_sums(self):  # read by VEL/mdp/curriculums.py:44
+        e = self._env
+        return {n: e._bufs["EPISODE_SUMS"][i, : e.num_envs] for i, n in enumerate(self.active_terms)}
+
+
+class ManagerBasedRLEnv(_EnvBase):
+    """MI355X-native vectorised velocity-tracking environment.  See module docstring."""
+
+    is_vector_env = True
+    metadata = {"render_modes": [None]}
+
+    def __init__(self, cfg=None, render_mode=None, *, desc: EnvDesc | None = None, extra: dict | None = None,
+                 num_envs: int | None = None, seed: int | None = None, device: str | None = None, terrain_seed: int = 0,
+                 lib_path: str | None = None, **kwargs):
+        if isinstance(cfg, str):  # a compiled descriptor bundle id / path (robot_lab_amd/data)
+            desc, extra = load_bundle(cfg)
+            cfg = None
+        if cfg is not None:
+            from .model.cfg_compile import compile_cfg
+            desc, spec = compile_cfg(cfg)
+            extra = dict(terrain_generator=spec.get("terrain_generator"), env_spacing=spec.get("env_spacing"))
+            num_envs = num_envs or cfg.scene.num_envs
+            device = device or getattr(cfg.sim, "device", None)
+            seed = seed if seed is not None else getattr(cfg, "seed", None)
+        if desc is None:
+            raise ValueError("ManagerBasedRLEnv needs a task cfg, a descriptor bundle id, or desc=")
+        self.cfg = cfg
+        self.desc = desc
+        self.render_mode = render_mode
+        self.num_envs = int(num_envs or 4096)
+        self._seed = 42 if seed is None else int(seed)
+        dev = torch.device(device or "cuda:0")
+        if dev.type != "cuda":
+            raise RlEnvError(f"robot_lab_amd runs on MI355X only (device={dev}); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RlEnvError("no HIP device visible: robot_lab_amd has no CPU path")
+        self.device = str(dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device()))
+        self._dev_index = torch.device(self.device).index
+        heights, terrain_origins, env_origins = build_world(desc, extra or {}, self.num_envs, terrain_seed)
+        with torch.cuda.device(self._dev_index):
+            self._native = NativeEnv(desc, heights, terrain_origins, env_origins, self.num_envs, self._seed, self._dev_index, lib_path)
+        self.num_actions = self._native.num_actions
+        self.max_episode_length = self._native.max_episode_length
+        self.max_episode_length_s = float(desc.task.episode_length_s)
+        self.physics_dt = float(desc.sim.dt)
+        self.step_dt = float(desc.sim.dt) * int(desc.sim.decimation)
+        self.common_step_counter = 0
+        self._bufs: dict[str, torch.Tensor] = {}
+        for name in ("OBS_POLICY", "OBS_CRITIC", "REWARD", "TERMINATED", "TIME_OUT", "EPISODE_LENGTH", "ROOT_STATE", "JOINT_POS",
+                     "JOINT_VEL", "REWARD_TERMS", "EPISODE_SUMS", "COMMAND", "CONTACT_FORCE", "CONTACT_TIMERS", "LOG", "ACTION",
+                     "JOINT_TORQUE", "JOINT_ACC", "ENV_ORIGIN", "TERRAIN_LEVEL"):
+            ptr, shape, dt = self._native.buffer(name)
+            self._bufs[name] = torch.as_tensor(_DevView(ptr, shape, dt, self._native), device=self.device)
+        self._terminated = self._bufs["TERMINATED"].view(torch.bool)
+        self._time_outs = self._bufs["TIME_OUT"].view(torch.bool)
+        self._obs = {"policy": self._bufs["OBS_POLICY"], "critic": self._bufs["OBS_CRITIC"]}
+        self._export_stamp = -1
+        self.scene = _Scene(self)
+        self.command_manager = _CommandManager(self)
+        self.reward_manager = _RewardManager(self)
+        self.extras: dict = {}
+        self.log_episodes = True
+        if gym is not None:
+            sp = gym.spaces
+            inf = float("inf")
+            self.single_observation_space = sp.Dict({k: sp.Box(-inf, inf, (v.shape[1],)) for k, v in self._obs.items()})
+            self.single_action_space = sp.Box(-inf, inf, (self.num_actions,))
+            self.observation_space = sp.Dict({k: sp.Box(-inf, inf, tuple(v.shape)) for k, v in self._obs.items()})
+            self.action_space = sp.Box(-inf, inf, (self.num_envs, self.num_actions))
+
+    # ------------------------------------------------------------------ gym surface
+    @property
+    def unwrapped(self):
+        return self
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self._dev_index).cuda_stream
+
+    def seed(self, seed: int = -1) -> int:
+        return self._seed
+
+    def reset(self, seed: int | None = None, options=None, env_ids=None):
+        ids = None if env_ids is None else torch.as_tensor(env_ids).cpu().numpy()
+        self._native.reset(ids, self._stream())
+        self.extras = {}
+        return self._obs, self.extras
+
+    def step(self, action: torch.Tensor):
+        if action.device != self._bufs["REWARD"].device or action.dtype != torch.float32 or not action.is_contiguous():
+            action = action.to(device=self.device, dtype=torch.float32).contiguous()
+        if action.shape != (self.num_envs, self.num_actions):
+            raise ValueError(f"action shape {tuple(action.shape)} != {(self.num_envs, self.num_actions)}")
+        self._native.step(action.data_ptr(), self._stream())
+        self.common_step_counter += 1
+        if self.log_episodes:
+            snap = self._bufs["LOG"].clone()
+            self._bufs["LOG"].zero_()
+            self.extras = {"log": _LazyLog(self, snap)}
+        else:
+            self.extras = {}
+        return self._obs, self._bufs["REWARD"], self._terminated, self._time_outs, self.extras
+
+    def get_observations(self):
+        return self._obs
+
+    def close(self):
+        if getattr(self, "_native", None) is not None:
+            torch.cuda.synchronize(self._dev_index)
+            self._native.close()
+            self._native = None
+
+    def render(self, recompute=False):
+        return None
+
+    # ------------------------------------------------------------------ attributes callers touch
+    @property
+    def episode_length_buf(self) -> torch.Tensor:
+        return self._bufs["EPISODE_LENGTH"]
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):  # rsl_rl `init_at_random_ep_len` (train.py:224)
+        self._bufs["EPISODE_LENGTH"].copy_(torch.as_tensor(value, device=self.device).to(torch.int64))
+
+    @property
+    def terrain_levels(self) -> torch.Tensor:
+        return self._bufs["TERRAIN_LEVEL"]
+
+    @property
+    def reward_buf(self):
+        return self._bufs["REWARD"]
+
+    @property
+    def reset_buf(self):
+        return self._terminated | self._time_outs
+
+    def reward_terms(self) -> torch.Tensor:
+        """[T, N] weighted per-term rewards of the last step."""
+        return self._bufs["REWARD_TERMS"][:, : self.num_envs]
+
+    def _export(self):
+        if self._export_stamp != self.common_step_counter:
+            self._native.export_state(self._stream())
+            self._export_stamp = self.common_step_counter
+
+    def write_state(self, root_state=None, joint_pos=None, joint_vel=None):
+        """Overwrite simulator state (host arrays); used by teacher-forced parity tests."""
+        keep = []
+        ptrs = []
+        for a in (root_state, joint_pos, joint_vel):
+            if a is None:
+                ptrs.append(0)
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                keep.append(a)
+                ptrs.append(a.ctypes.data)
+        self._native.import_state(ptrs[0], ptrs[1], ptrs[2], self._stream())
+        self._export_stamp = -1

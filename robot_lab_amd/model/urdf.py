@@ -266,7 +266,27 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
         for c, r in rb["spheres"]:
             model.spheres.append(Sphere(bi, c, r))
     _prune_contained_spheres(model)
+    _thin_spheres(model)
     return model
+
+
+def _thin_spheres(model: RobotModel, min_sep: float = 0.07):
+    """Several URDFs tile a slender link with many overlapping primitives (Go2 calf: three cylinders,
+    `go2_description.urdf:149-185`).  Per link, keep spheres greedily by descending radius and drop any
+    whose centre is closer than ``min_sep`` to an already kept one - the lane program budgets three
+    collision spheres per link."""
+    by_link: dict[int, list[int]] = {}
+    for i, sph in enumerate(model.spheres):
+        by_link.setdefault(model.bodies[sph.body].link, []).append(i)
+    keep = set()
+    for link, ids in by_link.items():
+        kept: list[int] = []
+        for i in sorted(ids, key=lambda i: -model.spheres[i].radius):
+            c = model.spheres[i].center
+            if all(np.linalg.norm(c - model.spheres[k].center) >= min_sep for k in kept):
+                kept.append(i)
+        keep.update(kept)
+    model.spheres = [sph for i, sph in enumerate(model.spheres) if i in keep]
 
 
 def _prune_contained_spheres(model: RobotModel):

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "librl_env_emu.so")
+REFERENCE = "/root/reference/source/robot_lab"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (skipped where it is absent)")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """CPU lane emulator (test infrastructure): same lane-program source as the HIP kernel, built with g++."""
+    import __graft_entry__ as g
+
+    if g._stale(EMU_LIB, [os.path.join(g.CSRC, h) for h in g.HEADERS] + [os.path.join(g.EMU_DIR, "rl_env_emu.cpp")]):
+        import subprocess
+
+        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", EMU_LIB,
+                        os.path.join(g.EMU_DIR, "rl_env_emu.cpp")], check=True)
+    return EMU_LIB

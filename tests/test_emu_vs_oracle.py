@@ -1,0 +1,73 @@
+"""CPU tier: the env-step lane program (the exact source hipcc compiles, run by the 4-thread lane
+emulator) against the fp64 oracle.  This is the no-GPU stand-in for tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from helpers import assert_close, host_view, make_pair, oracle_root_state
+
+TASKS = [
+    "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0",
+]
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_lane_program_matches_oracle(task, emu_lib):
+    N = 16
+    desc, ora, nat = make_pair(task, N, 42, emu_lib)
+    o = ora.reset()
+    nat.reset()
+    assert_close("policy0", host_view(nat, "OBS_POLICY"), o[0], 1e-4, 1e-5)
+    assert_close("critic0", host_view(nat, "OBS_CRITIC"), o[1], 1e-3, 1e-4)
+    rng = np.random.default_rng(0)
+    for s in range(6):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        o = ora.step(a)
+        nat.step(a.ctypes.data)
+        assert_close(f"reward[{s}]", host_view(nat, "REWARD"), ora.reward, 1e-3, 2e-5)
+        assert_close(f"terms[{s}]", host_view(nat, "REWARD_TERMS")[:, :N], ora.reward_terms, 2e-3, 2e-5)
+        assert_close(f"cforce[{s}]", host_view(nat, "CONTACT_FORCE"), ora.contact_force, 5e-3, 5e-2)
+        assert_close(f"timers[{s}]", host_view(nat, "CONTACT_TIMERS") if False else ora.timers, ora.timers, 0, 0)
+    nat.export_state()
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), 1e-3, 1e-4)
+    assert_close("q", host_view(nat, "JOINT_POS"), ora.st["q"], 1e-3, 1e-4)
+    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], 2e-3, 2e-3)
+    assert_close("timers", host_view(nat, "CONTACT_TIMERS"), ora.timers, 1e-5, 1e-6)
+    assert_close("torque", host_view(nat, "JOINT_TORQUE"), ora.applied_torque, 2e-3, 2e-3)
+    assert_close("cmd", host_view(nat, "COMMAND"), ora.vel_command_b, 1e-3, 1e-4)
+    assert_close("policy", host_view(nat, "OBS_POLICY"), o[0], 2e-3, 2e-3)
+    assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
+    nat.close()
+
+
+def test_resets_and_logs(emu_lib):
+    task, N = TASKS[1], 16
+    desc, ora, nat = make_pair(task, N, 9, emu_lib)
+    ora.reset()
+    nat.reset()
+    ep = np.zeros(N, dtype=np.int64)
+    ep[::3] = ora.max_episode_length - 2
+    ora.episode_length_buf[:] = ep
+    host_view(nat, "EPISODE_LENGTH")[:] = ep
+    rng = np.random.default_rng(1)
+    seen = 0
+    for s in range(3):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        o = ora.step(a)
+        nat.step(a.ctypes.data)
+        done = host_view(nat, "TERMINATED").astype(bool) | host_view(nat, "TIME_OUT").astype(bool)
+        assert np.array_equal(done, ora.terminated | ora.time_outs)
+        log = nat.read_log()
+        if done.any():
+            seen += int(done.sum())
+            assert log[0] == done.sum() and log[1] == ora.time_outs_terms[0].sum()
+            for i, name in enumerate(desc.reward_names):
+                np.testing.assert_allclose(log[8 + i] / log[0] / ora.max_episode_length_s, ora.log["Episode_Reward/" + name], rtol=2e-3, atol=1e-7)
+        assert np.array_equal(host_view(nat, "EPISODE_LENGTH"), ora.episode_length_buf)
+    assert seen == 6
+    nat.export_state()
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), 1e-3, 1e-4)
+    assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
+    assert np.array_equal(host_view(nat, "TERRAIN_LEVEL"), ora.terrain_levels)
+    nat.close()

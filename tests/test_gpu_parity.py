@@ -1,0 +1,123 @@
+"""`-m gpu`: the HIP path, called through the C-ABI (robot_lab_amd.env -> librl_env_hip.so), against the
+fp64 oracle on identical seeds and actions.  fp32 tolerance: root/joint state rtol 2e-3 (atol 2e-4) after
+5 env steps (20 physics substeps with contacts), rewards atol 2e-5, dones exact."""
+import numpy as np
+import pytest
+
+from helpers import assert_close, oracle_root_state
+from oracle.env import OracleEnv
+from robot_lab_amd.scene import build_world, load_bundle
+
+pytestmark = pytest.mark.gpu
+
+TASKS = [
+    "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0",
+]
+
+
+def _pair(task, N, seed):
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    env = ManagerBasedRLEnv(task, num_envs=N, seed=seed, device="cuda:0")
+    desc, extra = load_bundle(task)
+    h, to, eo = build_world(desc, extra, N, 0)
+    return env, OracleEnv(desc, h, to, N, seed, eo), torch
+
+
+@pytest.mark.parametrize("task", TASKS)
+def test_short_horizon_parity(task):
+    N = 64
+    env, ora, torch = _pair(task, N, 11)
+    obs, _ = env.reset()
+    o = ora.reset()
+    assert_close("obs0", obs["policy"].cpu().numpy(), o[0], 1e-4, 1e-5)
+    assert_close("critic0", obs["critic"].cpu().numpy(), o[1], 1e-3, 1e-4)
+    rng = np.random.default_rng(3)
+    for s in range(5):
+        a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
+        obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
+        o = ora.step(a)
+        assert_close(f"reward[{s}]", rew.cpu().numpy(), ora.reward, 1e-3, 2e-5, 0.98)
+        assert np.array_equal((term | tout).cpu().numpy(), ora.terminated | ora.time_outs)
+    d = env.scene["robot"].data
+    assert_close("root", d.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4, 0.98)
+    assert_close("q", d.joint_pos.cpu().numpy(), ora.st["q"], 2e-3, 2e-4, 0.98)
+    assert_close("qd", d.joint_vel.cpu().numpy(), ora.st["qd"], 5e-3, 5e-3, 0.97)
+    assert_close("rew_terms", env.reward_terms().cpu().numpy(), ora.reward_terms, 2e-3, 2e-5, 0.98)
+    assert_close("policy", obs["policy"].cpu().numpy(), o[0], 5e-3, 5e-3, 0.97)
+    assert_close("critic", obs["critic"].cpu().numpy(), o[1], 5e-3, 5e-3, 0.97)
+    env.close()
+
+
+def test_time_out_reset_parity():
+    """Force time-outs through the settable episode_length_buf (rsl_rl init_at_random_ep_len path)."""
+    task, N = TASKS[1], 64
+    env, ora, torch = _pair(task, N, 5)
+    env.reset()
+    ora.reset()
+    ep = np.zeros(N, dtype=np.int64)
+    ep[::4] = env.max_episode_length - 2
+    env.episode_length_buf = torch.from_numpy(ep)
+    ora.episode_length_buf[:] = ep
+    rng = np.random.default_rng(0)
+    n_reset = 0
+    for s in range(3):
+        a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
+        obs, rew, term, tout, extras = env.step(torch.from_numpy(a).cuda())
+        o = ora.step(a)
+        done = (term | tout).cpu().numpy()
+        assert np.array_equal(done, ora.terminated | ora.time_outs)
+        n_reset += int(done.sum())
+        if done.any():
+            assert float(extras["log"]["Episode_Termination/time_out"]) == float(ora.time_outs_terms[0].sum())
+            for name in ("Episode_Reward/track_lin_vel_xy_exp", "Metrics/base_velocity/error_vel_xy"):
+                np.testing.assert_allclose(float(extras["log"][name]), ora.log[name], rtol=2e-3, atol=1e-6)
+        assert np.array_equal(env.episode_length_buf.cpu().numpy(), ora.episode_length_buf)
+    assert n_reset == 16
+    d = env.scene["robot"].data
+    assert_close("root", d.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4, 0.98)
+    assert_close("critic", obs["critic"].cpu().numpy(), o[1], 5e-3, 5e-3, 0.97)
+    env.close()
+
+
+def test_full_size_properties():
+    """BASELINE config 2 at full size (4096 envs): size-independent invariants of step()."""
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    N = 4096
+    env = ManagerBasedRLEnv(TASKS[1], num_envs=N, seed=42, device="cuda:0")
+    env2 = ManagerBasedRLEnv(TASKS[1], num_envs=N, seed=42, device="cuda:0")
+    env.reset()
+    env2.reset()
+    env.episode_length_buf = torch.randint(0, env.max_episode_length, (N,))
+    env2.episode_length_buf = env.episode_length_buf.clone()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    total_done = 0
+    for s in range(60):
+        a = torch.rand(N, 12, device="cuda", generator=g) * 2 - 1
+        ep_before = env.episode_length_buf.clone()
+        obs, rew, term, tout, _ = env.step(a)
+        obs2, rew2, _, _, _ = env2.step(a)
+        done = term | tout
+        total_done += int(done.sum())
+        # determinism: same seed, same actions -> bit-identical
+        assert torch.equal(obs["critic"], obs2["critic"]) and torch.equal(rew, rew2)
+        assert torch.isfinite(obs["policy"]).all() and torch.isfinite(obs["critic"]).all() and torch.isfinite(rew).all()
+        # reward is the sum of its weighted terms
+        torch.testing.assert_close(env.reward_terms().sum(0), rew, rtol=1e-4, atol=1e-5)
+        # episode counter: +1, or 0 after a reset
+        ep = env.episode_length_buf
+        assert torch.equal(ep[~done], ep_before[~done] + 1) and bool((ep[done] == 0).all())
+        # height scan is clipped to [-1, 1] (velocity_env_cfg.py:236-241)
+        assert float(obs["critic"][:, 48:].abs().max()) <= 1.0
+    assert total_done > 0
+    quat = env.scene["robot"].data.root_quat_w
+    torch.testing.assert_close(quat.norm(dim=1), torch.ones(N, device="cuda"), rtol=1e-4, atol=1e-4)
+    env.close()
+    env2.close()

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Compile the reference's task cfg classes into descriptor bundles (robot_lab_amd/data/*.json).
+
+Run in the build container (needs /root/reference):  python tools/compile_descriptors.py
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from robot_lab_amd import shims  # noqa: E402
+
+shims.install(shims.REFERENCE_SOURCE)
+import gymnasium as gym  # noqa: E402
+import robot_lab.tasks  # noqa: E402,F401
+from isaaclab_tasks.utils import parse_env_cfg  # noqa: E402
+
+from robot_lab_amd.model.cfg_compile import UnsupportedTerm, compile_cfg  # noqa: E402
+from robot_lab_amd.scene import DATA_DIR, save_bundle  # noqa: E402
+
+TASKS = sys.argv[1:] or [
+    f"RobotLab-Isaac-Velocity-{t}-Unitree-{r}-v0" for r in ("A1", "Go2", "Go2W", "G1") for t in ("Flat", "Rough")]
+os.makedirs(DATA_DIR, exist_ok=True)
+for task in TASKS:
+    try:
+        cfg = parse_env_cfg(task, device="cpu")
+        desc, spec = compile_cfg(cfg)
+    except (UnsupportedTerm, NotImplementedError) as e:
+        print(f"{task}: NOT COMPILED ({e})")
+        continue
+    save_bundle(os.path.join(DATA_DIR, task + ".json"), desc, spec)
+    m = desc.model
+    print(f"{task}: links={m.num_links} dof={m.num_dof} bodies={m.num_bodies} spheres={m.num_spheres} "
+          f"chains={m.num_chains}x{m.chain_len} rewards={desc.task.n_rewards} obs={desc.obs_dim(0)}/{desc.obs_dim(1)}")
