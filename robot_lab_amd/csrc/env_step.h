@@ -28,26 +28,57 @@ RL_FN float comp(V3 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : v.z; }
 RL_FN V3 unit(int i) { return {i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f}; }
 RL_FN V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
-// bilinear heightfield: height + unit normal at world (x, y)     (oracle/physics.py TerrainSampler)
-RL_FN void terrain_sample(const Tables& T, const float* __restrict__ hf, float x, float y, float& h, V3& n) {
-  if (T.is_plane) {
-    h = 0.f;
-    n = {0.f, 0.f, 1.f};
-    return;
+// Wave-uniform hot scalars.  On the GPU they are pinned into SGPRs with readfirstlane once per kernel:
+// read as LDS table entries each one cost a ~64-cycle ds_read round trip at every use, which a lone
+// wavefront per SIMD cannot hide (profiles/r01: 62 % of wave time was s_waitcnt).
+struct Uni {
+  float dt, inv_dt, gravity, contact_k, contact_c, inv_phi_ref, contact_ct, contact_vdep, contact_vstick, limit_k, limit_c, force_threshold;
+  float inv_hscale, x0, y0;
+  int is_plane, nx, ny;
+};
+template <class Ctx>
+RL_FN Uni make_uni(const Ctx& ctx, const Tables& T) {
+  Uni u;
+  u.dt = ctx.uniform(T.dt); u.inv_dt = ctx.uniform(1.0f / T.dt); u.gravity = ctx.uniform(T.gravity);
+  u.contact_k = ctx.uniform(T.contact_k); u.contact_c = ctx.uniform(T.contact_c); u.inv_phi_ref = ctx.uniform(1.0f / T.contact_phi_ref);
+  u.contact_ct = ctx.uniform(T.contact_ct); u.contact_vdep = ctx.uniform(T.contact_vdep); u.contact_vstick = ctx.uniform(T.contact_vstick);
+  u.limit_k = ctx.uniform(T.limit_k); u.limit_c = ctx.uniform(T.limit_c); u.force_threshold = ctx.uniform(T.force_threshold);
+  u.inv_hscale = ctx.uniform(T.is_plane ? 1.0f : 1.0f / T.hscale); u.x0 = ctx.uniform(T.x0); u.y0 = ctx.uniform(T.y0);
+  u.is_plane = ctx.uniform_i(T.is_plane); u.nx = ctx.uniform_i(T.nx); u.ny = ctx.uniform_i(T.ny);
+  return u;
+}
+
+// bilinear heightfield (oracle/physics.py TerrainSampler), split so that the 4 corner loads of several
+// query points can be in flight together before any of them is consumed
+struct TerrainPatch {
+  float h00, h01, h10, h11, fx, fy;
+};
+RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, float x, float y) {
+  TerrainPatch p;
+  if (u.is_plane) {
+    p.h00 = p.h01 = p.h10 = p.h11 = 0.f;
+    p.fx = p.fy = 0.f;
+    return p;
   }
-  float gx = (x - T.x0) / T.hscale, gy = (y - T.y0) / T.hscale;
-  float fxf = floorf(gx), fyf = floorf(gy);
-  int ix = (int)fminf(fmaxf(fxf, 0.f), (float)(T.nx - 2));
-  int iy = (int)fminf(fmaxf(fyf, 0.f), (float)(T.ny - 2));
-  float fx = clampf(gx - (float)ix, 0.f, 1.f), fy = clampf(gy - (float)iy, 0.f, 1.f);
-  const float* b = hf + (size_t)ix * T.ny + iy;
-  float h00 = b[0], h01 = b[1], h10 = b[T.ny], h11 = b[T.ny + 1];
-  float hx0 = h00 + fx * (h10 - h00), hx1 = h01 + fx * (h11 - h01);
-  h = hx0 + fy * (hx1 - hx0);
-  float dzdx = ((1.f - fy) * (h10 - h00) + fy * (h11 - h01)) / T.hscale;
-  float dzdy = ((1.f - fx) * (h01 - h00) + fx * (h11 - h10)) / T.hscale;
-  float inv = 1.0f / sqrtf(dzdx * dzdx + dzdy * dzdy + 1.0f);
+  float gx = (x - u.x0) * u.inv_hscale, gy = (y - u.y0) * u.inv_hscale;
+  int ix = (int)fminf(fmaxf(floorf(gx), 0.f), (float)(u.nx - 2));
+  int iy = (int)fminf(fmaxf(floorf(gy), 0.f), (float)(u.ny - 2));
+  p.fx = clampf(gx - (float)ix, 0.f, 1.f);
+  p.fy = clampf(gy - (float)iy, 0.f, 1.f);
+  const float* b = hf + (size_t)ix * u.ny + iy;
+  p.h00 = b[0]; p.h01 = b[1]; p.h10 = b[u.ny]; p.h11 = b[u.ny + 1];
+  return p;
+}
+RL_FN void terrain_eval(const Uni& u, const TerrainPatch& p, float& h, V3& n) {
+  float hx0 = p.h00 + p.fx * (p.h10 - p.h00), hx1 = p.h01 + p.fx * (p.h11 - p.h01);
+  h = hx0 + p.fy * (hx1 - hx0);
+  float dzdx = ((1.f - p.fy) * (p.h10 - p.h00) + p.fy * (p.h11 - p.h01)) * u.inv_hscale;
+  float dzdy = ((1.f - p.fx) * (p.h01 - p.h00) + p.fx * (p.h11 - p.h10)) * u.inv_hscale;
+  float inv = frsqrt(dzdx * dzdx + dzdy * dzdy + 1.0f);
   n = {-dzdx * inv, -dzdy * inv, inv};
+}
+RL_FN void terrain_sample(const Uni& u, const float* __restrict__ hf, float x, float y, float& h, V3& n) {
+  terrain_eval(u, terrain_fetch(u, hf, x, y), h, n);
 }
 
 template <int CL>
@@ -81,8 +112,24 @@ RL_FN V3 point_velocity(const Chain<CL>& C, int g, V3 x, SV V0, const float (&qd
   return u;
 }
 
+// Lane-private LDS scratchpad: word f of a lane lives at base[f * STRIDE] (STRIDE = 64 on the GPU, so
+// a wavefront access hits 64 different banks).  It holds the per-body contact-sensor state (timers,
+// force history, last force) and friction - ~80 values that would otherwise sit in VGPRs all step.
+template <int STRIDE, int W>
+struct LsRow {
+  float* p;
+  RL_FN float& operator[](int t) const { return p[t * STRIDE]; }
+};
+template <int STRIDE, int W>
+struct LsMat {
+  float* p;
+  RL_FN LsRow<STRIDE, W> operator[](int b) const { return {p + b * W * STRIDE}; }
+};
+enum { LS_TIM = 0, LS_HIST = LS_TIM + NBS * 4, LS_CF = LS_HIST + NBS * 3, LS_FRIC = LS_CF + NBS * 3, LS_WORDS = LS_FRIC + NBS * 3 };
+
 template <class Ctx, int CL>
 struct EnvLane {
+  static constexpr int LSS = Ctx::LS_STRIDE;
   static constexpr int NV = 6 + CL;
   using UI = SymIdx<NV>;
   static constexpr int NSPH = (CL + 1) * SPL;
@@ -91,99 +138,93 @@ struct EnvLane {
   const KState& S;
   const Tables& T;
   const LaneTab& L;
-  int e, k, gl, NL, Np;
+  const Uni u;
+  int e, k, Np;
+  float* lt;  // this lane's column of the wave tile:  field f -> lt[f * 64]
+  float* et;  // this env's column of the env tile:    field f -> et[f * 16]
   // persistent state in registers
   V3 pos, vlin, vang;
   Q4 quat;
   float q[CL], qd[CL], kp[CL], kd[CL], act[CL], prev_act[CL];
-  float Im[CL];
-  V3 Icom_c[CL];
-  S3 Icom_I[CL];
-  SI I0;       // base link inertia (base coords)
   V3 base_com; // COM of the base body
   V3 extF, extT;
-  float tim[NBS][4], fric[NBS][3];
   // per-step scratch
   float tau_app[CL], qacc[CL];
-  V3 cf[NBS];
-  float hist_n[NBS][3];  // |F| of the last three substeps, newest first
+  // contact-sensor state + friction in the lane-private LDS scratchpad
+  LsMat<LSS, 4> tim;     // [slot][current_air, current_contact, last_air, last_contact]
+  LsMat<LSS, 3> hist_n;  // [slot][|F| of the last three substeps, newest first]
+  LsMat<LSS, 3> cf;      // [slot][net contact force of the last substep, world]
+  LsMat<LSS, 3> fric;    // [slot][mu_s, mu_d, restitution]
 
-  RL_FN EnvLane(Ctx& c, const KState& s) : ctx(c), S(s), T(c.tables()), L(c.tables().lane[c.k()]) {
+  RL_FN EnvLane(Ctx& c, const KState& s)
+      : ctx(c), S(s), T(c.tables()), L(c.tables().lane[c.k()]), u(make_uni(c, c.tables())), tim{c.lane_scratch() + LS_TIM * LSS}, hist_n{c.lane_scratch() + LS_HIST * LSS},
+        cf{c.lane_scratch() + LS_CF * LSS}, fric{c.lane_scratch() + LS_FRIC * LSS} {
     e = ctx.env();
     k = ctx.k();
     Np = S.Npad;
-    NL = NLANE * Np;
-    gl = e * NLANE + k;
+    lt = S.lane_state + (size_t)ctx.tile() * LANE_TILE + (uint32_t)ctx.lane_in_tile();
+    et = S.env_state + (size_t)ctx.tile() * ENV_TILE + (uint32_t)(ctx.lane_in_tile() >> 2);
   }
+  RL_FN float& LF(int f) const { return lt[(uint32_t)f * 64u]; }
+  RL_FN float& EF(int f) const { return et[(uint32_t)f * (uint32_t)ENVS_PER_WAVE]; }
 
   // ------------------------------------------------------------------ load / store
   RL_FN void load() {
-    const float* r = S.root + e;
-    pos = {r[0 * Np], r[1 * Np], r[2 * Np]};
-    quat = {r[3 * Np], r[4 * Np], r[5 * Np], r[6 * Np]};
-    vlin = {r[7 * Np], r[8 * Np], r[9 * Np]};
-    vang = {r[10 * Np], r[11 * Np], r[12 * Np]};
-    const float* w = S.wrench + e;
-    extF = {w[0], w[Np], w[2 * Np]};
-    extT = {w[3 * Np], w[4 * Np], w[5 * Np]};
-    const float* bi = S.base_inertia + e;
-    I0 = make_si(bi[0], V3{bi[Np], bi[2 * Np], bi[3 * Np]},
-                 S3{bi[4 * Np], bi[5 * Np], bi[6 * Np], bi[7 * Np], bi[8 * Np], bi[9 * Np]});
-    base_com = {S.base_com[e], S.base_com[Np + e], S.base_com[2 * Np + e]};
+    pos = {EF(EF_ROOT + 0), EF(EF_ROOT + 1), EF(EF_ROOT + 2)};
+    quat = {EF(EF_ROOT + 3), EF(EF_ROOT + 4), EF(EF_ROOT + 5), EF(EF_ROOT + 6)};
+    vlin = {EF(EF_ROOT + 7), EF(EF_ROOT + 8), EF(EF_ROOT + 9)};
+    vang = {EF(EF_ROOT + 10), EF(EF_ROOT + 11), EF(EF_ROOT + 12)};
+    extF = {EF(EF_WRENCH + 0), EF(EF_WRENCH + 1), EF(EF_WRENCH + 2)};
+    extT = {EF(EF_WRENCH + 3), EF(EF_WRENCH + 4), EF(EF_WRENCH + 5)};
+    base_com = {EF(EF_BASE_COM + 0), EF(EF_BASE_COM + 1), EF(EF_BASE_COM + 2)};
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
-      q[j] = S.q[j * NL + gl];
-      qd[j] = S.qd[j * NL + gl];
-      kp[j] = S.kp[j * NL + gl];
-      kd[j] = S.kd[j * NL + gl];
-      act[j] = S.act[j * NL + gl];
-      const float* li = S.link_inertia + (size_t)j * INERTIA_NF * NL + gl;
-      Im[j] = li[0];
-      Icom_c[j] = {li[NL], li[2 * NL], li[3 * NL]};
-      Icom_I[j] = {li[4 * NL], li[5 * NL], li[6 * NL], li[7 * NL], li[8 * NL], li[9 * NL]};
+      q[j] = LF(LF_Q + j);
+      qd[j] = LF(LF_QD + j);
+      kp[j] = LF(LF_KP + j);
+      kd[j] = LF(LF_KD + j);
+      act[j] = LF(LF_ACT + j);
       tau_app[j] = 0.f;
       qacc[j] = 0.f;
     }
 #pragma unroll
     for (int s = 0; s < NBS; ++s) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) tim[s][t] = S.timers[(s * 4 + t) * NL + gl];
+      for (int t = 0; t < 4; ++t) tim[s][t] = LF(LF_TIMERS + s * 4 + t);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) fric[s][t] = S.friction[(s * 3 + t) * NL + gl];
-      cf[s] = {0.f, 0.f, 0.f};
+      for (int t = 0; t < 3; ++t) fric[s][t] = LF(LF_FRICTION + s * 3 + t);
+      cf[s][0] = cf[s][1] = cf[s][2] = 0.f;
       hist_n[s][0] = hist_n[s][1] = hist_n[s][2] = 0.f;
     }
   }
 
   RL_FN void store() {
     if (k == 0) {
-      float* r = S.root + e;
-      r[0 * Np] = pos.x; r[1 * Np] = pos.y; r[2 * Np] = pos.z;
-      r[3 * Np] = quat.w; r[4 * Np] = quat.x; r[5 * Np] = quat.y; r[6 * Np] = quat.z;
-      r[7 * Np] = vlin.x; r[8 * Np] = vlin.y; r[9 * Np] = vlin.z;
-      r[10 * Np] = vang.x; r[11 * Np] = vang.y; r[12 * Np] = vang.z;
-      float* w = S.wrench + e;
-      w[0] = extF.x; w[Np] = extF.y; w[2 * Np] = extF.z;
-      w[3 * Np] = extT.x; w[4 * Np] = extT.y; w[5 * Np] = extT.z;
+      EF(EF_ROOT + 0) = pos.x; EF(EF_ROOT + 1) = pos.y; EF(EF_ROOT + 2) = pos.z;
+      EF(EF_ROOT + 3) = quat.w; EF(EF_ROOT + 4) = quat.x; EF(EF_ROOT + 5) = quat.y; EF(EF_ROOT + 6) = quat.z;
+      EF(EF_ROOT + 7) = vlin.x; EF(EF_ROOT + 8) = vlin.y; EF(EF_ROOT + 9) = vlin.z;
+      EF(EF_ROOT + 10) = vang.x; EF(EF_ROOT + 11) = vang.y; EF(EF_ROOT + 12) = vang.z;
+      EF(EF_WRENCH + 0) = extF.x; EF(EF_WRENCH + 1) = extF.y; EF(EF_WRENCH + 2) = extF.z;
+      EF(EF_WRENCH + 3) = extT.x; EF(EF_WRENCH + 4) = extT.y; EF(EF_WRENCH + 5) = extT.z;
     }
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
-      S.q[j * NL + gl] = q[j];
-      S.qd[j * NL + gl] = qd[j];
-      S.kp[j * NL + gl] = kp[j];
-      S.kd[j * NL + gl] = kd[j];
-      S.act[j * NL + gl] = act[j];
+      LF(LF_Q + j) = q[j];
+      LF(LF_QD + j) = qd[j];
+      LF(LF_KP + j) = kp[j];
+      LF(LF_KD + j) = kd[j];
+      LF(LF_ACT + j) = act[j];
     }
 #pragma unroll
     for (int s = 0; s < NBS; ++s)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) S.timers[(s * 4 + t) * NL + gl] = tim[s][t];
+      for (int t = 0; t < 4; ++t) LF(LF_TIMERS + s * 4 + t) = tim[s][t];
   }
 
   // ------------------------------------------------------------------ actuators [UPSTREAM B4]
   // returns explicit torque; fills tau_app (applied torque estimate) and the implicit-PD diagonal terms
   RL_FN void actuators(const float (&q_tgt)[CL], const float (&qd_tgt)[CL], float (&tau_e)[CL], float (&pd_diag)[CL], float (&pd_rhs)[CL]) {
-    const float dt = T.dt;
+    const float dt = u.dt;
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
       float qt = L.action_is_vel[j] ? q[j] : q_tgt[j];
@@ -198,8 +239,9 @@ struct EnvLane {
         pd_diag[j] = sat ? 0.f : dt * (kd[j] + kp[j] * dt);
         pd_rhs[j] = sat ? 0.f : dt * (kp[j] * er + kd[j] * qd_tgt[j]);
       } else {  // DCMotor torque-speed clip (unitree.py:55-63)
-        float tmax = clampf(L.sat[j] * (1.0f - qd[j] / L.act_vlim[j]), 0.f, eff);
-        float tmin = clampf(L.sat[j] * (-1.0f - qd[j] / L.act_vlim[j]), -eff, 0.f);
+        float vr = qd[j] * frcp(L.act_vlim[j]);
+        float tmax = clampf(L.sat[j] * (1.0f - vr), 0.f, eff);
+        float tmin = clampf(L.sat[j] * (-1.0f - vr), -eff, 0.f);
         float t = clampf(tc, tmin, tmax);
         tau_app[j] = t;
         tau_e[j] = t;
@@ -209,15 +251,65 @@ struct EnvLane {
     }
   }
 
+  // ------------------------------------------------------------------ contact of one sphere slot
+  struct Contact {
+    bool act;
+    V3 x, n;            // contact point and terrain normal, base coordinates
+    float bias, dn, dt; // spring bias force, normal / tangential damping
+  };
+  // sphere centre in base coordinates (cb) and world (cw); empty slots (radius <= 0) sit at the base origin
+  RL_FN void sphere_center(const Chain<CL>& C, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
+    rad = L.sph_r[g][s];
+    V3 cl = ld3(L.sph_c[g][s]);
+    cb = cl;
+#pragma unroll
+    for (int j = 0; j < CL; ++j)
+      if (g == j + 1) cb = C.p[j] + mul(C.R[j], cl);
+    cw = pos + mul(Rwb, cb);
+  }
+  RL_FN Contact contact_from_patch(const Chain<CL>& C, const M3& Rwb, SV V0, const float (&qdv)[CL], int g, int s, float rad, V3 cb, V3 cw,
+                                   const TerrainPatch& tp) const {
+    Contact c;
+    c.act = false;
+    float hz;
+    V3 nw;
+    terrain_eval(u, tp, hz, nw);
+    float phi = rad - (cw.z - hz) * nw.z;
+    if (rad > 0.f && phi > 0.f) {
+      V3 nb = mulT(Rwb, nw);
+      V3 x = cb - rad * nb;
+      V3 uu = point_velocity<CL>(C, g, x, V0, qdv);
+      float un = dot(nb, uu);
+      V3 ut = uu - un * nb;
+      float utn = norm(ut);
+      int slot = L.sph_slot[g][s];
+      float mus = fric[slot][0], mud = fric[slot][1], rest = fric[slot][2];
+      float cnrm = u.contact_c * fminf(1.0f, phi * u.inv_phi_ref) * (1.0f - rest);
+      float dn = cnrm + u.contact_k * u.dt;
+      float bias = fminf(u.contact_k * phi, u.contact_vdep * dn);
+      float fn0 = bias - dn * un;
+      if (fn0 > 0.f) {
+        float mu = utn < u.contact_vstick ? mus : mud;
+        c.act = true;
+        c.x = x; c.n = nb; c.bias = bias; c.dn = dn;
+        c.dt = fminf(u.contact_ct, mu * fn0 * frcp(fmaxf(utn, 1e-6f)));
+      }
+    }
+    return c;
+  }
+
   // ------------------------------------------------------------------ one physics substep
   RL_FN void substep(const float (&q_tgt)[CL], const float (&qd_tgt)[CL]) {
-    const float dt = T.dt;
+    // keep the compiler from hoisting the (loop-invariant) LDS table reads of all four substeps to the
+    // top of the kernel, where ~200 of them stayed live and spilled to scratch
+    asm volatile("" ::: "memory");
+    const float dt = u.dt;
     float tau_e[CL], pd_diag[CL], pd_rhs[CL];
     actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
 
     const M3 Rwb = quat_to_mat(quat);
     SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
-    SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, T.gravity})};
+    SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
     Chain<CL> C;
     chain_kinematics<CL>(L, q, C);
 
@@ -240,8 +332,10 @@ struct EnvLane {
         SV vj = Sj[j] * qd[j];
         SV Vj = Vp + vj;
         SV aj = ap + crm(Vj, vj);
-        V3 cb = C.p[j] + mul(C.R[j], Icom_c[j]);
-        Ic[j] = make_si(Im[j], cb, rotate(C.R[j], Icom_I[j]));
+        // per-env link inertia (mass, com, inertia about com; randomised at startup) straight from HBM/L1
+        const int li = LF_INERTIA + j * INERTIA_NF;
+        V3 cb = C.p[j] + mul(C.R[j], V3{LF(li + 1), LF(li + 2), LF(li + 3)});
+        Ic[j] = make_si(LF(li), cb, rotate(C.R[j], S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
         Hs[j] = apply(Ic[j], Vj);
         Fs[j] = apply(Ic[j], aj) + crf(Vj, Hs[j]);
         Vp = Vj;
@@ -257,6 +351,8 @@ struct EnvLane {
     SI Itop = Ic[0];
     SV ftop = Fs[0], htop = Hs[0];
     if (k == 0) {  // the base link itself, its bias force and the persistent external wrench [UPSTREAM B8]
+      const int bi = EF_BASE_INERTIA;
+      const SI I0 = make_si(EF(bi), V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)}, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)});
       SV h0 = apply(I0, V0);
       SV f0 = apply(I0, a0) + crf(V0, h0);
       f0.a -= extT + cross(base_com, extF);
@@ -289,67 +385,46 @@ struct EnvLane {
       float below = L.lower[j] - q[j], above = q[j] - L.upper[j];
       float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
       bool lim = (below > 0.f) || (above > 0.f);
-      U[UI::at(6 + j, 6 + j)] += pd_diag[j] + (lim ? dt * (T.limit_k * dt + T.limit_c) : 0.f);
-      rv[6 + j] += dt * T.limit_k * viol;
+      U[UI::at(6 + j, 6 + j)] += pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+      rv[6 + j] += dt * u.limit_k * viol;
     }
 
-    // ---- contacts: collision spheres vs heightfield, linearly-implicit (oracle/physics.py header)
-    V3 cx[NSPH], cn[NSPH];
-    float cbias[NSPH], cdn[NSPH], cdt[NSPH];
-    bool cact[NSPH];
-#pragma unroll
+    // ---- contacts: collision spheres vs heightfield, linearly-implicit (oracle/physics.py header).
+    // Pass 1 adds J^T D J / J^T n bias of every active sphere to the system; the per-sphere data is NOT
+    // kept (12 slots x 10 values would spill) - pass 2 after the solve re-evaluates the active spheres.
+    // One iteration per link group (base share, then each chain link): the terrain corner loads of the
+    // group's SPL sphere slots are issued together, then consumed.
+    uint32_t active_mask = 0;
+#pragma unroll 1
     for (int g = 0; g <= CL; ++g) {
+      float rad[SPL];
+      V3 cb[SPL], cw[SPL];
+      TerrainPatch tp[SPL];
 #pragma unroll
       for (int s = 0; s < SPL; ++s) {
-        const int ci = g * SPL + s;
-        cact[ci] = false;
-        float rad = L.sph_r[g][s];
-        if (rad > 0.f) {
-          V3 cl = ld3(L.sph_c[g][s]);
-          V3 cb = g == 0 ? cl : C.p[g > 0 ? g - 1 : 0] + mul(C.R[g > 0 ? g - 1 : 0], cl);
-          V3 cw = pos + mul(Rwb, cb);
-          float hz;
-          V3 nw;
-          terrain_sample(T, S.terrain, cw.x, cw.y, hz, nw);
-          float phi = rad - (cw.z - hz) * nw.z;
-          if (phi > 0.f) {
-            V3 nb = mulT(Rwb, nw);
-            V3 x = cb - rad * nb;
-            V3 u = point_velocity<CL>(C, g, x, V0, qd);
-            float un = dot(nb, u);
-            V3 ut = u - un * nb;
-            float utn = norm(ut);
-            int slot = L.sph_slot[g][s];
-            float mus = 0.f, mud = 0.f, rest = 0.f;
+        sphere_center(C, Rwb, g, s, rad[s], cb[s], cw[s]);
+        tp[s] = terrain_fetch(u, S.terrain, cw[s].x, cw[s].y);
+      }
 #pragma unroll
-            for (int b = 0; b < NBS; ++b)
-              if (b == slot) { mus = fric[b][0]; mud = fric[b][1]; rest = fric[b][2]; }
-            float cnrm = T.contact_c * fminf(1.0f, phi / T.contact_phi_ref) * (1.0f - rest);
-            float dn = cnrm + T.contact_k * dt;
-            float bias = fminf(T.contact_k * phi, T.contact_vdep * dn);
-            float fn0 = bias - dn * un;
-            if (fn0 > 0.f) {
-              float mu = utn < T.contact_vstick ? mus : mud;
-              float dtan = fminf(T.contact_ct, mu * fn0 / fmaxf(utn, 1e-6f));
-              cact[ci] = true;
-              cx[ci] = x; cn[ci] = nb; cbias[ci] = bias; cdn[ci] = dn; cdt[ci] = dtan;
-              // Jacobian columns of the point velocity wrt [omega_b, v_b, qd]
-              V3 col[NV];
-              col[0] = cross(unit(0), x); col[1] = cross(unit(1), x); col[2] = cross(unit(2), x);
-              col[3] = unit(0); col[4] = unit(1); col[5] = unit(2);
+      for (int s = 0; s < SPL; ++s) {
+        Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad[s], cb[s], cw[s], tp[s]);
+        if (c.act) {
+          active_mask |= 1u << (g * SPL + s);
+          // Jacobian columns of the point velocity wrt [omega_b, v_b, qd]
+          V3 col[NV];
+          col[0] = cross(unit(0), c.x); col[1] = cross(unit(1), c.x); col[2] = cross(unit(2), c.x);
+          col[3] = unit(0); col[4] = unit(1); col[5] = unit(2);
 #pragma unroll
-              for (int i = 0; i < CL; ++i) col[6 + i] = i < g ? cross(C.ax[i], x - C.p[i]) : V3{0.f, 0.f, 0.f};
-              float gn[NV];
+          for (int i = 0; i < CL; ++i) col[6 + i] = i < g ? cross(C.ax[i], c.x - C.p[i]) : V3{0.f, 0.f, 0.f};
+          float gn[NV];
 #pragma unroll
-              for (int i = 0; i < NV; ++i) gn[i] = dot(col[i], nb);
-              const float kt = dt * dtan, kn = dt * (dn - dtan);
+          for (int i = 0; i < NV; ++i) gn[i] = dot(col[i], c.n);
+          const float kt = dt * c.dt, kn = dt * (c.dn - c.dt);
 #pragma unroll
-              for (int i = 0; i < NV; ++i) {
-                rv[i] += dt * bias * gn[i];
+          for (int i = 0; i < NV; ++i) {
+            rv[i] += dt * c.bias * gn[i];
 #pragma unroll
-                for (int jj = i; jj < NV; ++jj) U[UI::at(i, jj)] += kt * dot(col[i], col[jj]) + kn * gn[i] * gn[jj];
-              }
-            }
+            for (int jj = i; jj < NV; ++jj) U[UI::at(i, jj)] += kt * dot(col[i], col[jj]) + kn * gn[i] * gn[jj];
           }
         }
       }
@@ -362,9 +437,8 @@ struct EnvLane {
       float s = U[UI::at(6 + j, 6 + j)];
 #pragma unroll
       for (int m = 0; m < j; ++m) s -= Lc[j][m] * Lc[j][m];
-      float d = sqrtf(s);
-      Lc[j][j] = d;
-      float inv = 1.0f / d;
+      float inv = frsqrt(s);
+      Lc[j][j] = inv;  // the diagonal holds 1 / L_jj
 #pragma unroll
       for (int i = j + 1; i < CL; ++i) {
         float t = U[UI::at(6 + j, 6 + i)];
@@ -381,14 +455,14 @@ struct EnvLane {
         float t = U[UI::at(r, 6 + j)];
 #pragma unroll
         for (int m = 0; m < j; ++m) t -= Lc[j][m] * Y[r][m];
-        Y[r][j] = t / Lc[j][j];
+        Y[r][j] = t * Lc[j][j];
       }
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
       float t = rv[6 + j];
 #pragma unroll
       for (int m = 0; m < j; ++m) t -= Lc[j][m] * z[m];
-      z[j] = t / Lc[j][j];
+      z[j] = t * Lc[j][j];
     }
     using BI = SymIdx<6>;
     float Cb[BI::size], db[6];
@@ -414,9 +488,8 @@ struct EnvLane {
         float s = Cb[BI::at(j, j)];
 #pragma unroll
         for (int m = 0; m < j; ++m) s -= G[j][m] * G[j][m];
-        float d = sqrtf(s);
-        G[j][j] = d;
-        float inv = 1.0f / d;
+        float inv = frsqrt(s);
+        G[j][j] = inv;  // 1 / G_jj
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
           float t = Cb[BI::at(j, i)];
@@ -431,14 +504,14 @@ struct EnvLane {
         float t = db[j];
 #pragma unroll
         for (int m = 0; m < j; ++m) t -= G[j][m] * y6[m];
-        y6[j] = t / G[j][j];
+        y6[j] = t * G[j][j];
       }
 #pragma unroll
       for (int j = 5; j >= 0; --j) {
         float t = y6[j];
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) t -= G[i][j] * nu0[i];
-        nu0[j] = t / G[j][j];
+        nu0[j] = t * G[j][j];
       }
     }
     float qdn[CL];
@@ -449,7 +522,7 @@ struct EnvLane {
       for (int r = 0; r < 6; ++r) t -= Y[r][j] * nu0[r];
 #pragma unroll
       for (int i = j + 1; i < CL; ++i) t -= Lc[i][j] * qdn[i];
-      qdn[j] = t / Lc[j][j];
+      qdn[j] = t * Lc[j][j];
     }
 #pragma unroll
     for (int j = 0; j < CL; ++j) qdn[j] = clampf(qdn[j], -L.vel_limit[j], L.vel_limit[j]);
@@ -459,22 +532,26 @@ struct EnvLane {
     V3 fslot[NBS];
 #pragma unroll
     for (int b = 0; b < NBS; ++b) fslot[b] = {0.f, 0.f, 0.f};
+    // pass 2: only the spheres that were active in pass 1 are re-evaluated (same state -> same contact)
+#pragma unroll 1
+    for (uint32_t m = active_mask; m != 0; m &= m - 1) {
+      const int ci = __builtin_ctz(m);
+      const int g = ci / SPL, s = ci - g * SPL;
+      float rad;
+      V3 cb, cw;
+      sphere_center(C, Rwb, g, s, rad, cb, cw);
+      Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
+      if (c.act) {
+        V3 uu = point_velocity<CL>(C, g, c.x, V0n, qdn);
+        float un = dot(c.n, uu);
+        V3 Fb = (c.bias - (c.dn - c.dt) * un) * c.n - c.dt * uu;
+        V3 Fw = mul(Rwb, Fb);
+        int slot = L.sph_slot[g][s];
 #pragma unroll
-    for (int g = 0; g <= CL; ++g)
-#pragma unroll
-      for (int s = 0; s < SPL; ++s) {
-        const int ci = g * SPL + s;
-        if (cact[ci]) {
-          V3 u = point_velocity<CL>(C, g, cx[ci], V0n, qdn);
-          float un = dot(cn[ci], u);
-          V3 Fb = (cbias[ci] - (cdn[ci] - cdt[ci]) * un) * cn[ci] - cdt[ci] * u;
-          V3 Fw = mul(Rwb, Fb);
-          int slot = L.sph_slot[g][s];
-#pragma unroll
-          for (int b = 0; b < NBS; ++b)
-            if (b == slot) fslot[b] += Fw;
-        }
+        for (int b = 0; b < NBS; ++b)
+          if (b == slot) fslot[b] += Fw;
       }
+    }
     // base-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes)
     for (int bi = 0; bi < T.n_base_bodies; ++bi) {
       bool mine = L.base_body_local == bi;
@@ -484,12 +561,12 @@ struct EnvLane {
     // [UPSTREAM B5] ContactSensor: history roll + air/contact timers, every physics step
 #pragma unroll
     for (int b = 0; b < NBS; ++b) {
-      cf[b] = fslot[b];
+      cf[b][0] = fslot[b].x; cf[b][1] = fslot[b].y; cf[b][2] = fslot[b].z;
       float fn = norm(fslot[b]);
       hist_n[b][2] = hist_n[b][1];
       hist_n[b][1] = hist_n[b][0];
       hist_n[b][0] = fn;
-      bool contact = fn > T.force_threshold;
+      bool contact = fn > u.force_threshold;
       float ca = tim[b][0], cc = tim[b][1];
       bool first_contact = (ca > 0.f) && contact, first_detach = (cc > 0.f) && !contact;
       tim[b][2] = first_contact ? ca + dt : tim[b][2];
@@ -500,7 +577,7 @@ struct EnvLane {
     // ---- integrate (semi-implicit Euler: new velocities move the positions)
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
-      qacc[j] = (qdn[j] - qd[j]) / dt;
+      qacc[j] = (qdn[j] - qd[j]) * u.inv_dt;
       q[j] += dt * qdn[j];
       qd[j] = qdn[j];
     }

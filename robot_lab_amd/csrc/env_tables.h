@@ -4,9 +4,7 @@
 // a wavefront; lane k owns kinematic chain k (one leg: hip -> thigh -> calf [-> wheel]) and a share of
 // the base link's collision spheres.  16 environments per 64-wide wavefront.
 //
-// HBM layout: structure-of-arrays, one float per (field, lane) or (field, env):
-//   lane arrays  a[f * NL + (env*4 + k)]   NL = 4 * Npad   -> a wavefront reads 64 consecutive floats
-//   env  arrays  a[f * Npad + env]                          -> 16 consecutive floats, 4-lane broadcast
+// HBM layout: wave-tiled structure-of-arrays (see "HBM state layout" below).
 #pragma once
 #include <stdint.h>
 
@@ -97,29 +95,46 @@ struct Tables {
   float default_root_pos[3], default_root_quat[4];
 };
 
-// fields of the per-env "cmd" array
+// fields of the per-env "cmd" record
 enum { CMD_VX = 0, CMD_VY, CMD_WZ, CMD_HEADING, CMD_TIME_LEFT, CMD_METRIC_XY, CMD_METRIC_YAW, CMD_PUSH_LEFT, CMD_NFIELD };
 // link inertia record: mass, com(3), inertia about com (xx yy zz xy xz yz), link frame
 constexpr int INERTIA_NF = 10;
 
+// ---- HBM state layout: wave-tiled structure-of-arrays -------------------------------------------
+// A tile is the state of one wavefront (16 envs x 4 lanes).  Inside a tile every field is one
+// contiguous row: 64 floats (256 B) for lane fields, 16 floats for env fields.  A wavefront therefore
+// reads/writes whole coalesced rows, and - the reason for tiling rather than [field][N] planes - every
+// access is `tile base (SGPR) + lane offset (ONE VGPR) + compile-time row offset`; with [field][N]
+// planes hipcc kept ~60 separate 64-bit address pairs live across the kernel (120 VGPRs, profiles/r01).
+enum {  // lane fields (rows of 64)
+  LF_Q = 0, LF_QD = LF_Q + MAX_CL, LF_KP = LF_QD + MAX_CL, LF_KD = LF_KP + MAX_CL, LF_ACT = LF_KD + MAX_CL,
+  LF_INERTIA = LF_ACT + MAX_CL,                    // [MAX_CL][10]
+  LF_TIMERS = LF_INERTIA + MAX_CL * INERTIA_NF,    // [NBS][4] current_air, current_contact, last_air, last_contact
+  LF_FRICTION = LF_TIMERS + NBS * 4,               // [NBS][3] mu_s, mu_d, restitution
+  NF_LANE = LF_FRICTION + NBS * 3
+};
+enum {  // env fields (rows of 16)
+  EF_ROOT = 0,                 // pos(3) quat wxyz(4) lin vel (3, world, link origin) ang vel (3, world)
+  EF_WRENCH = EF_ROOT + 13,    // force(3) torque(3), base-body frame
+  EF_BASE_INERTIA = EF_WRENCH + 6,
+  EF_BASE_COM = EF_BASE_INERTIA + INERTIA_NF,  // COM of the base *body* in the base frame
+  EF_CMD = EF_BASE_COM + 3,
+  EF_ORIGIN = EF_CMD + CMD_NFIELD,
+  NF_ENV = EF_ORIGIN + 3
+};
+constexpr uint32_t LANE_TILE = (uint32_t)NF_LANE * 64u;          // floats per tile
+constexpr uint32_t ENV_TILE = (uint32_t)NF_ENV * ENVS_PER_WAVE;  // floats per tile
+RL_FN size_t lane_index(int e, int k, int f) { return (size_t)(e / ENVS_PER_WAVE) * LANE_TILE + (size_t)f * 64 + (size_t)(e % ENVS_PER_WAVE) * NLANE + k; }
+RL_FN size_t env_index(int e, int f) { return (size_t)(e / ENVS_PER_WAVE) * ENV_TILE + (size_t)f * ENVS_PER_WAVE + (size_t)(e % ENVS_PER_WAVE); }
+
 struct KState {
   int32_t N;      // environments the caller sees
   int32_t Npad;   // simulated (multiple of ENVS_PER_WAVE)
-  // per-lane SoA
-  float *q, *qd, *kp, *kd, *act;  // [MAX_CL][NL]
-  float* link_inertia;            // [MAX_CL][10][NL]
-  float* timers;                  // [NBS][4][NL]  current_air, current_contact, last_air, last_contact
-  float* friction;                // [NBS][3][NL]  mu_s, mu_d, restitution
-  // per-env SoA
-  float* root;       // [13][Npad] pos(3) quat wxyz(4) lin vel (3, world, link origin) ang vel (3, world)
-  float* wrench;     // [6][Npad]  force(3) torque(3), base-body frame
-  float* base_inertia;  // [10][Npad]
-  float* base_com;   // [3][Npad]  COM of the base *body* in the base frame
-  float* cmd;        // [CMD_NFIELD][Npad]
+  float* lane_state;  // [Npad/16][NF_LANE][64]
+  float* env_state;   // [Npad/16][NF_ENV][16]
   int32_t* flags;    // [Npad] bit0 is_heading_env, bit1 is_standing_env
   int32_t *level, *ttype;  // [Npad]
-  float* origin;     // [3][Npad] env origins
-  int64_t* ep_len;   // [Npad]   (AoS-compatible: caller-visible int64 [N])
+  int64_t* ep_len;   // [Npad]   (caller-visible int64 [N])
   float* ep_sums;    // [MAX_T][Npad]
   // caller-visible outputs (reference layouts)
   float *obs_policy, *obs_critic;  // [Npad][dim]

@@ -22,7 +22,7 @@ enum ObsKind {
 template <class Ctx, int CL>
 struct EnvProgram : EnvLane<Ctx, CL> {
   using Base = EnvLane<Ctx, CL>;
-  using Base::ctx; using Base::S; using Base::T; using Base::L; using Base::e; using Base::k; using Base::gl; using Base::NL; using Base::Np;
+  using Base::ctx; using Base::S; using Base::T; using Base::L; using Base::e; using Base::k; using Base::Np;
   using Base::pos; using Base::quat; using Base::vlin; using Base::vang; using Base::q; using Base::qd; using Base::kp; using Base::kd;
   using Base::act; using Base::prev_act; using Base::tim; using Base::cf; using Base::hist_n; using Base::tau_app; using Base::qacc;
   using Base::extF; using Base::extT; using Base::base_com;
@@ -42,30 +42,28 @@ struct EnvProgram : EnvLane<Ctx, CL> {
   RL_FN EnvProgram(Ctx& c, const KState& s) : Base(c, s) {}
 
   RL_FN void load_task() {
-    const float* c = S.cmd + e;
-    cmd = {c[CMD_VX * Np], c[CMD_VY * Np], c[CMD_WZ * Np]};
-    heading_target = c[CMD_HEADING * Np];
-    cmd_time_left = c[CMD_TIME_LEFT * Np];
-    metric_xy = c[CMD_METRIC_XY * Np];
-    metric_yaw = c[CMD_METRIC_YAW * Np];
-    push_left = c[CMD_PUSH_LEFT * Np];
+    cmd = {this->EF(EF_CMD + CMD_VX), this->EF(EF_CMD + CMD_VY), this->EF(EF_CMD + CMD_WZ)};
+    heading_target = this->EF(EF_CMD + CMD_HEADING);
+    cmd_time_left = this->EF(EF_CMD + CMD_TIME_LEFT);
+    metric_xy = this->EF(EF_CMD + CMD_METRIC_XY);
+    metric_yaw = this->EF(EF_CMD + CMD_METRIC_YAW);
+    push_left = this->EF(EF_CMD + CMD_PUSH_LEFT);
     int f = S.flags[e];
     is_heading = f & 1;
     is_standing = (f >> 1) & 1;
     level = S.level[e];
     ttype = S.ttype[e];
-    origin = {S.origin[e], S.origin[Np + e], S.origin[2 * Np + e]};
+    origin = {this->EF(EF_ORIGIN + 0), this->EF(EF_ORIGIN + 1), this->EF(EF_ORIGIN + 2)};
     ep_len = S.ep_len[e];
   }
   RL_FN void store_task() {
     if (k != 0) return;
-    float* c = S.cmd + e;
-    c[CMD_VX * Np] = cmd.x; c[CMD_VY * Np] = cmd.y; c[CMD_WZ * Np] = cmd.z;
-    c[CMD_HEADING * Np] = heading_target; c[CMD_TIME_LEFT * Np] = cmd_time_left;
-    c[CMD_METRIC_XY * Np] = metric_xy; c[CMD_METRIC_YAW * Np] = metric_yaw; c[CMD_PUSH_LEFT * Np] = push_left;
+    this->EF(EF_CMD + CMD_VX) = cmd.x; this->EF(EF_CMD + CMD_VY) = cmd.y; this->EF(EF_CMD + CMD_WZ) = cmd.z;
+    this->EF(EF_CMD + CMD_HEADING) = heading_target; this->EF(EF_CMD + CMD_TIME_LEFT) = cmd_time_left;
+    this->EF(EF_CMD + CMD_METRIC_XY) = metric_xy; this->EF(EF_CMD + CMD_METRIC_YAW) = metric_yaw; this->EF(EF_CMD + CMD_PUSH_LEFT) = push_left;
     S.flags[e] = (is_heading ? 1 : 0) | (is_standing ? 2 : 0);
     S.level[e] = level;
-    S.origin[e] = origin.x; S.origin[Np + e] = origin.y; S.origin[2 * Np + e] = origin.z;
+    this->EF(EF_ORIGIN + 0) = origin.x; this->EF(EF_ORIGIN + 1) = origin.y; this->EF(EF_ORIGIN + 2) = origin.z;
     S.ep_len[e] = ep_len;
     S.command_out[e * 3 + 0] = cmd.x; S.command_out[e * 3 + 1] = cmd.y; S.command_out[e * 3 + 2] = cmd.z;
   }
@@ -92,7 +90,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     float hd = U(stream, idx + 3, T.cmd_range[3][0], T.cmd_range[3][1]);
     bool ih = U(stream, idx + 4, 0.f, 1.f) <= T.cmd_rel_heading;
     bool is = U(stream, idx + 5, 0.f, 1.f) <= T.cmd_rel_standing;
-    float keep = sqrtf(vx * vx + vy * vy) > T.cmd_small_threshold ? 1.f : 0.f;
+    float keep = fsqrt(vx * vx + vy * vy) > T.cmd_small_threshold ? 1.f : 0.f;
     cmd = {vx * keep, vy * keep, wz};
     if (T.cmd_heading) { heading_target = hd; is_heading = ih; }
     is_standing = is;
@@ -103,9 +101,9 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671)
     if (T.curriculum && !T.is_plane) {
       float dx = pos.x - origin.x, dy = pos.y - origin.y;
-      float dist = sqrtf(dx * dx + dy * dy);
+      float dist = fsqrt(dx * dx + dy * dy);
       bool up = dist > T.tile_size * 0.5f;
-      bool down = (dist < sqrtf(cmd.x * cmd.x + cmd.y * cmd.y) * T.max_episode_length_s * 0.5f) && !up;
+      bool down = (dist < fsqrt(cmd.x * cmd.x + cmd.y * cmd.y) * T.max_episode_length_s * 0.5f) && !up;
       int lv = level + (up ? 1 : 0) - (down ? 1 : 0);
       int rnd = (int)fminf(floorf(U(STREAM_RESET, IDX_LEVEL, 0.f, 1.f) * (float)T.num_rows), (float)(T.num_rows - 1));
       level = lv >= T.num_rows ? rnd : (lv < 0 ? 0 : lv);
@@ -116,7 +114,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
 #pragma unroll
     for (int b = 0; b < NBS; ++b) {
       tim[b][0] = tim[b][1] = tim[b][2] = tim[b][3] = 0.f;
-      cf[b] = {0.f, 0.f, 0.f};
+      cf[b][0] = cf[b][1] = cf[b][2] = 0.f;
       hist_n[b][0] = hist_n[b][1] = hist_n[b][2] = 0.f;
     }
     extF = {0.f, 0.f, 0.f};
@@ -208,7 +206,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
   RL_FN float compute_rewards(bool terminated) {
     const float gate = clampf(-grav_b.z, 0.f, 0.7f) / 0.7f;
     const float cmd_norm = norm(cmd);
-    const float bv = sqrtf(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
+    const float bv = fsqrt(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
     Chain<CL> C;
     chain_kinematics<CL>(L, q, C);
     float total = 0.f;
@@ -253,7 +251,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
           f = ctx.gsum(part);
           if (R.kind == REW_STAND_STILL) f *= (cmd_norm < R.p[0] ? 1.f : 0.f) * gate;  // rewards.py:93-104
           if (R.kind == REW_JOINT_POS_PENALTY) {                                        // rewards.py:107-129
-            float run = sqrtf(f);
+            float run = fsqrt(f);
             f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
           }
         } break;
@@ -291,22 +289,22 @@ struct EnvProgram : EnvLane<Ctx, CL> {
               case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT: part += first_contact(s) ? 1.f : 0.f; break;
               case REW_FEET_AIR_TIME: part += first_contact(s) ? tim[s][2] - R.p[0] : 0.f; break;  // rewards.py:340-360
               case REW_FEET_STUMBLE: {                                                       // rewards.py:428-436
-                float fxy = sqrtf(cf[s].x * cf[s].x + cf[s].y * cf[s].y);
-                part += fxy > 4.f * fabsf(cf[s].z) ? 1.f : 0.f;
+                float fx = cf[s][0], fy = cf[s][1];
+                part += fsqrt(fx * fx + fy * fy) > 4.f * fabsf(cf[s][2]) ? 1.f : 0.f;
               } break;
               default: {
                 V3 relp, relv;
                 body_rel(C, s, relp, relv);
                 if (R.kind == REW_FEET_HEIGHT_BODY) {  // rewards.py:527-554
                   float er = relp.z - R.p[0];
-                  part += er * er * tanhf(R.p[1] * sqrtf(relv.x * relv.x + relv.y * relv.y));
+                  part += er * er * tanhf(R.p[1] * fsqrt(relv.x * relv.x + relv.y * relv.y));
                 } else if (R.kind == REW_FEET_SLIDE) {  // rewards.py:557-587
-                  part += hm > 1.0f ? sqrtf(relv.x * relv.x + relv.y * relv.y) : 0.f;
+                  part += hm > 1.0f ? fsqrt(relv.x * relv.x + relv.y * relv.y) : 0.f;
                 } else {  // feet_height, world frame (rewards.py:507-524)
                   V3 pw = pos + mul(Rwb, relp);
                   V3 vw = lin_w + mul(Rwb, relv);
                   float er = pw.z - R.p[0];
-                  part += er * er * tanhf(R.p[1] * sqrtf(vw.x * vw.x + vw.y * vw.y));
+                  part += er * er * tanhf(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
                 }
               }
             }
@@ -391,16 +389,27 @@ struct EnvProgram : EnvLane<Ctx, CL> {
             put(O.offset + L.joint_id[j], v);
           }
           break;
-        case OBS_HEIGHT_SCAN: {  // yaw-aligned grid, x fastest; z_base - hit_z - offset
-          const int nr = T.scan_nx * T.scan_ny;
-          for (int r = k; r < nr; r += NLANE) {
-            int ix = r % T.scan_nx, iy = r / T.scan_nx;
-            float lx = ((float)ix - 0.5f * (float)(T.scan_nx - 1)) * T.scan_res;
-            float ly = ((float)iy - 0.5f * (float)(T.scan_ny - 1)) * T.scan_res;
-            float hz;
-            V3 nn;
-            terrain_sample(T, S.terrain, pos.x + cy * lx - sy * ly, pos.y + sy * lx + cy * ly, hz, nn);
-            put(O.offset + r, pos.z - hz - T.scan_offset);
+        case OBS_HEIGHT_SCAN: {  // yaw-aligned grid, x fastest; z_base - hit_z - offset.  4 rays per trip so 16 loads overlap
+          const int nr = T.scan_nx * T.scan_ny, snx = T.scan_nx;
+          const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1), soff = T.scan_offset;
+          for (int r0 = k; r0 < nr; r0 += 4 * NLANE) {
+            TerrainPatch tp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              int r = r0 + i * NLANE;
+              r = r < nr ? r : nr - 1;
+              int iy = r / snx, ix = r - iy * snx;
+              float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
+              tp[i] = terrain_fetch(this->u, S.terrain, pos.x + cy * lx - sy * ly, pos.y + sy * lx + cy * ly);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              int r = r0 + i * NLANE;
+              float hz;
+              V3 nn;
+              terrain_eval(this->u, tp[i], hz, nn);
+              if (r < nr) put(O.offset + r, pos.z - hz - soff);
+            }
           }
         } break;
         default: break;
@@ -421,7 +430,6 @@ struct EnvProgram : EnvLane<Ctx, CL> {
   // ---------------------------------------------------------------- step()
   RL_FN void step() {
     this->load();
-    load_task();
     // 1 ActionManager.process_action [UPSTREAM B2]; JointPosition/VelocityAction (velocity_env_cfg.py:124-126)
     float q_tgt[CL], qd_tgt[CL];
 #pragma unroll
@@ -446,11 +454,12 @@ struct EnvProgram : EnvLane<Ctx, CL> {
         int b = L.slot_body[s];
         if (b >= 0 && (s != 0 || L.owns_base_body)) {
           float* o = S.dbg_cforce + ((size_t)e * T.n_bodies + b) * 3;
-          o[0] = cf[s].x; o[1] = cf[s].y; o[2] = cf[s].z;
+          o[0] = cf[s][0]; o[1] = cf[s][1]; o[2] = cf[s][2];
         }
       }
     }
-    // 3 counters
+    // 3 counters (the task registers are only loaded now: nothing above needs them)
+    load_task();
     ep_len += 1;
     derive();
     // 4 terminations (velocity_env_cfg.py:648-664)
@@ -490,7 +499,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     {
       float max_step = T.cmd_resample[1] / T.step_dt;
       float ex = cmd.x - lin_b.x, ey = cmd.y - lin_b.y;
-      metric_xy += sqrtf(ex * ex + ey * ey) / max_step;
+      metric_xy += fsqrt(ex * ex + ey * ey) / max_step;
       metric_yaw += fabsf(cmd.z - ang_b.z) / max_step;
       cmd_time_left -= T.step_dt;
       if (cmd_time_left <= 0.f) {

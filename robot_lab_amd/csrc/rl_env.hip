@@ -9,7 +9,7 @@
 // staged in LDS and written back as one linear, 16-byte-vectorised burst per wavefront.
 #include <hip/hip_runtime.h>
 
-#define RL_FN __host__ __device__ inline
+#define RL_FN __host__ __device__ __forceinline__
 #include "env_aos.h"
 #include "env_terms.h"
 #include "rl_env_host.h"
@@ -26,6 +26,11 @@ __device__ inline float dpp_xor2(float v) {
 }
 
 struct WaveCtx {
+  static constexpr int LS_STRIDE = 64;
+  float* lscratch;
+  __device__ float* lane_scratch() const { return lscratch + lane; }
+  __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+  __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   const Tables* T;
   float* stage[2];
   int dim[2];
@@ -33,6 +38,8 @@ struct WaveCtx {
   __device__ const Tables& tables() const { return *T; }
   __device__ int k() const { return lane & 3; }
   __device__ int env() const { return e0 + (lane >> 2); }
+  __device__ int tile() const { return blockIdx.x; }
+  __device__ int lane_in_tile() const { return lane; }
   __device__ float gsum(float v) const {
     v += dpp_xor1(v);
     v += dpp_xor2(v);
@@ -71,6 +78,7 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const Tables* __restr
   ctx.dim[1] = Tl->critic_dim;
   ctx.stage[0] = smem + TAB_F;
   ctx.stage[1] = ctx.stage[0] + ((ENVS_PER_WAVE * ctx.dim[0] + 3) & ~3);
+  ctx.lscratch = ctx.stage[1] + ((ENVS_PER_WAVE * ctx.dim[1] + 3) & ~3);
   ctx.lane = lane;
   ctx.e0 = blockIdx.x * ENVS_PER_WAVE;
   EnvProgram<WaveCtx, CL> prog(ctx, S);
@@ -126,7 +134,7 @@ struct Backend {
     size_t tab = (sizeof(Tables) + 15) / 16 * 16;
     size_t s0 = ((size_t)ENVS_PER_WAVE * T.policy_dim + 3) / 4 * 16;
     size_t s1 = ((size_t)ENVS_PER_WAVE * T.critic_dim + 3) / 4 * 16;
-    lds_bytes = tab + s0 + s1;
+    lds_bytes = tab + s0 + s1 + (size_t)LS_WORDS * 64 * 4;
     if (lds_bytes > 160 * 1024) {
       err = "observation rows do not fit the 160 KiB LDS";
       return -1;

@@ -217,16 +217,12 @@ struct EnvImpl {
     CL = tables.CL;
     if (be.init(device)) return fail("device init failed: " + be.error());
     if (be.configure(tables)) return fail("kernel configuration failed: " + be.error());
-    const size_t NL = (size_t)NLANE * Npad, Np = Npad;
+    const size_t Np = Npad, ntile = Npad / ENVS_PER_WAVE;
     memset(&S, 0, sizeof(S));
     S.N = N; S.Npad = Npad; S.seed = seed;
-    S.q = alloc<float>(MAX_CL * NL); S.qd = alloc<float>(MAX_CL * NL); S.kp = alloc<float>(MAX_CL * NL);
-    S.kd = alloc<float>(MAX_CL * NL); S.act = alloc<float>(MAX_CL * NL);
-    S.link_inertia = alloc<float>(MAX_CL * INERTIA_NF * NL);
-    S.timers = alloc<float>(NBS * 4 * NL); S.friction = alloc<float>(NBS * 3 * NL);
-    S.root = alloc<float>(13 * Np); S.wrench = alloc<float>(6 * Np); S.base_inertia = alloc<float>(10 * Np);
-    S.base_com = alloc<float>(3 * Np); S.cmd = alloc<float>(CMD_NFIELD * Np); S.flags = alloc<int32_t>(Np);
-    S.level = alloc<int32_t>(Np); S.ttype = alloc<int32_t>(Np); S.origin = alloc<float>(3 * Np);
+    S.lane_state = alloc<float>(ntile * LANE_TILE);
+    S.env_state = alloc<float>(ntile * ENV_TILE);
+    S.flags = alloc<int32_t>(Np); S.level = alloc<int32_t>(Np); S.ttype = alloc<int32_t>(Np);
     S.ep_len = alloc<int64_t>(Np); S.ep_sums = alloc<float>(MAX_T * Np);
     S.obs_policy = alloc<float>(Np * (size_t)std::max(1, tables.policy_dim));
     S.obs_critic = alloc<float>(Np * (size_t)std::max(1, tables.critic_dim));
@@ -261,9 +257,8 @@ struct EnvImpl {
   void startup(const float* terrain_origins, const float* env_origins) {
     const rl_model_desc& m = desc.model;
     const rl_task_desc& t = desc.task;
-    const size_t NL = (size_t)NLANE * Npad, Np = Npad;
-    std::vector<float> link_inertia(MAX_CL * INERTIA_NF * NL, 0.f), friction(NBS * 3 * NL, 0.f), base_inertia(10 * Np, 0.f), base_com(3 * Np, 0.f);
-    std::vector<float> kp(MAX_CL * NL, 0.f), kd(MAX_CL * NL, 0.f), q(MAX_CL * NL, 0.f), origin(3 * Np, 0.f), root(13 * Np, 0.f);
+    const size_t Np = Npad, ntile = Npad / ENVS_PER_WAVE;
+    std::vector<float> lane(ntile * LANE_TILE, 0.f), env(ntile * ENV_TILE, 0.f);
     std::vector<int32_t> level(Np, 0), ttype(Np, 0);
     std::vector<float> bs(64, 1.f), bd(64, 1.f), br(64, 0.f);
     int nb = t.friction_buckets > 0 ? (t.friction_buckets > 64 ? 64 : t.friction_buckets) : 1;
@@ -289,7 +284,7 @@ struct EnvImpl {
         if (t.ev_com && b == t.base_body)
           for (int a = 0; a < 3; ++a) c[a] += uniform_range(seed, e, 0, STREAM_STARTUP, IDX_COM + 3 * b + a, t.com_range[a][0], t.com_range[a][1]);
         if (b == t.base_body)
-          for (int a = 0; a < 3; ++a) base_com[a * Np + e] = (float)c[a];
+          for (int a = 0; a < 3; ++a) env[env_index(e, EF_BASE_COM + a)] = (float)c[a];
         double sc = m.body_mass[b] > 0.f ? mass / m.body_mass[b] : 0.0;
         const float* I6 = m.body_inertia[b];
         double Ic[9] = {sc * I6[0], sc * I6[3], sc * I6[4], sc * I6[3], sc * I6[1], sc * I6[5], sc * I6[4], sc * I6[5], sc * I6[2]};
@@ -311,7 +306,7 @@ struct EnvImpl {
           // base-link bodies may have spheres on other lanes too: replicate their material into slot 0 there
           bool here = kk == k || (s == 0 && tables.lane[kk].base_body_local == tables.lane[k].base_body_local && !tables.lane[kk].owns_base_body);
           if (!here) continue;
-          for (int a = 0; a < 3; ++a) friction[(s * 3 + a) * NL + (size_t)e * NLANE + kk] = mu[a];
+          for (int a = 0; a < 3; ++a) lane[lane_index(e, kk, LF_FRICTION + s * 3 + a)] = mu[a];
         }
       }
       // composite per link -> (mass, com, inertia about com)
@@ -324,38 +319,34 @@ struct EnvImpl {
           for (int bb = 0; bb < 3; ++bb) Ic[a * 3 + bb] = lI[l * 9 + a * 3 + bb] - mass * ((a == bb ? cc : 0.0) - c[a] * c[bb]);
         float rec[10] = {(float)mass, (float)c[0], (float)c[1], (float)c[2], (float)Ic[0], (float)Ic[4], (float)Ic[8], (float)Ic[1], (float)Ic[2], (float)Ic[5]};
         if (l == 0) {
-          for (int f = 0; f < 10; ++f) base_inertia[f * Np + e] = rec[f];
+          for (int f = 0; f < 10; ++f) env[env_index(e, EF_BASE_INERTIA + f)] = rec[f];
         } else {
           int k = (l - 1) / CL, j = (l - 1) % CL;
-          for (int f = 0; f < 10; ++f) link_inertia[((size_t)j * INERTIA_NF + f) * NL + (size_t)e * NLANE + k] = rec[f];
+          for (int f = 0; f < 10; ++f) lane[lane_index(e, k, LF_INERTIA + j * INERTIA_NF + f)] = rec[f];
         }
       }
       for (int k = 0; k < NLANE; ++k)
         for (int j = 0; j < CL; ++j) {
-          kp[j * NL + (size_t)e * NLANE + k] = tables.lane[k].kp0[j];
-          kd[j * NL + (size_t)e * NLANE + k] = tables.lane[k].kd0[j];
-          q[j * NL + (size_t)e * NLANE + k] = tables.lane[k].q0[j];
+          lane[lane_index(e, k, LF_KP + j)] = tables.lane[k].kp0[j];
+          lane[lane_index(e, k, LF_KD + j)] = tables.lane[k].kd0[j];
+          lane[lane_index(e, k, LF_Q + j)] = tables.lane[k].q0[j];
         }
       // terrain level / type / env origin
       if (desc.terrain.is_plane) {
         int ee = e < N ? e : N - 1;
-        for (int a = 0; a < 3; ++a) origin[a * Np + e] = env_origins[ee * 3 + a];
+        for (int a = 0; a < 3; ++a) env[env_index(e, EF_ORIGIN + a)] = env_origins[ee * 3 + a];
       } else {
         int ee = e < N ? e : N - 1;  // padding envs mirror the last real env's cell
         ttype[e] = (int)floor((double)ee / ((double)N / desc.terrain.num_cols));
         int lv = (int)floorf(uniform01(seed, ee, 0, STREAM_STARTUP, IDX_INIT_LEVEL) * (float)(desc.terrain.max_init_level + 1));
         level[e] = lv > desc.terrain.max_init_level ? desc.terrain.max_init_level : lv;
-        for (int a = 0; a < 3; ++a) origin[a * Np + e] = terrain_origins[((size_t)level[e] * desc.terrain.num_cols + ttype[e]) * 3 + a];
+        for (int a = 0; a < 3; ++a) env[env_index(e, EF_ORIGIN + a)] = terrain_origins[((size_t)level[e] * desc.terrain.num_cols + ttype[e]) * 3 + a];
       }
-      root[3 * Np + e] = 1.f;  // identity quaternion until the first reset
-      for (int a = 0; a < 3; ++a) root[a * Np + e] = origin[a * Np + e] + m.default_root_pos[a];
+      env[env_index(e, EF_ROOT + 3)] = 1.f;  // identity quaternion until the first reset
+      for (int a = 0; a < 3; ++a) env[env_index(e, EF_ROOT + a)] = env[env_index(e, EF_ORIGIN + a)] + m.default_root_pos[a];
     }
-    be.h2d(S.link_inertia, link_inertia.data(), link_inertia.size() * 4);
-    be.h2d(S.friction, friction.data(), friction.size() * 4);
-    be.h2d(S.base_inertia, base_inertia.data(), base_inertia.size() * 4);
-    be.h2d(S.base_com, base_com.data(), base_com.size() * 4);
-    be.h2d(S.kp, kp.data(), kp.size() * 4); be.h2d(S.kd, kd.data(), kd.size() * 4); be.h2d(S.q, q.data(), q.size() * 4);
-    be.h2d(S.origin, origin.data(), origin.size() * 4); be.h2d(S.root, root.data(), root.size() * 4);
+    be.h2d(S.lane_state, lane.data(), lane.size() * 4);
+    be.h2d(S.env_state, env.data(), env.size() * 4);
     be.h2d(S.level, level.data(), level.size() * 4); be.h2d(S.ttype, ttype.data(), ttype.size() * 4);
   }
 

@@ -36,12 +36,19 @@ struct Team {
 };
 
 struct HostCtx {
+  static constexpr int LS_STRIDE = 1;
+  float scratch[rl::LS_WORDS];
+  float* lane_scratch() { return scratch; }
+  float uniform(float v) const { return v; }
+  int uniform_i(int v) const { return v; }
   Team* team;
   const rl::Tables* T;
   int k_, e_, sense_ = 0;
   const rl::Tables& tables() const { return *T; }
   int k() const { return k_; }
   int env() const { return e_; }
+  int tile() const { return e_ / rl::ENVS_PER_WAVE; }
+  int lane_in_tile() const { return (e_ % rl::ENVS_PER_WAVE) * rl::NLANE + k_; }
   float gsum(float v) {
     team->slot[k_] = v;
     team->barrier(sense_);
@@ -79,7 +86,8 @@ void run(const rl::KState& S, const rl::Tables* T, int reset) {
   std::vector<std::thread> th;
   for (int k = 0; k < rl::NLANE; ++k)
     th.emplace_back([&, k]() {
-      HostCtx ctx{&team, T, k, 0};
+      HostCtx ctx;
+      ctx.team = &team; ctx.T = T; ctx.k_ = k; ctx.e_ = 0;
       for (int e = 0; e < S.Npad; ++e) {
         ctx.e_ = e;
         rl::EnvProgram<HostCtx, CL> prog(ctx, S);

@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Generate tests/golden/terms_<robot>.npz: outputs of the REFERENCE's own term functions
+(`/root/reference/source/robot_lab/.../velocity/mdp/{rewards,commands,events}.py`, imported unchanged
+through robot_lab_amd.shims) on a recorded simulator state.  The fixtures pin the oracle's
+restatement of those terms (tests/test_terms_golden.py) and travel to the GPU box, where
+/root/reference does not exist.
+
+Run in the build container:  python tools/gen_golden_terms.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from robot_lab_amd import shims  # noqa: E402
+
+shims.install(shims.REFERENCE_SOURCE)
+import robot_lab.tasks  # noqa: E402,F401
+from isaaclab.managers import SceneEntityCfg  # noqa: E402
+from isaaclab.utils import math as mu  # noqa: E402
+from isaaclab_tasks.utils import parse_env_cfg  # noqa: E402
+
+from oracle.env import OracleEnv  # noqa: E402
+from robot_lab_amd.model.build import find_names  # noqa: E402
+from robot_lab_amd.model.cfg_compile import compile_cfg  # noqa: E402
+from robot_lab_amd.scene import build_world  # noqa: E402
+
+T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)  # noqa: E731
+
+
+class Sensor:
+    def __init__(self, ora, body_names):
+        self.body_names = body_names
+        self.data = types.SimpleNamespace(
+            net_forces_w_history=T(ora.force_hist), net_forces_w=T(ora.contact_force),
+            current_air_time=T(ora.timers[..., 0]), current_contact_time=T(ora.timers[..., 1]),
+            last_air_time=T(ora.timers[..., 2]), last_contact_time=T(ora.timers[..., 3]))
+
+    def compute_first_contact(self, dt, abs_tol=1.0e-8):  # [UPSTREAM ContactSensor]
+        c = self.data.current_contact_time
+        return (c > 0.0) & (c < dt + abs_tol)
+
+    def compute_first_air(self, dt, abs_tol=1.0e-8):
+        c = self.data.current_air_time
+        return (c > 0.0) & (c < dt + abs_tol)
+
+    def find_bodies(self, name_keys, preserve_order=False):
+        ids = find_names(list(name_keys) if not isinstance(name_keys, str) else name_keys, self.body_names, preserve_order)
+        return ids, [self.body_names[i] for i in ids]
+
+
+def duck_env(ora, desc):
+    """Duck-typed `env` over the oracle's recorded state; derived articulation data follows SURVEY.md B3
+    using the shim's torch math (independent of oracle/spatial.py)."""
+    st = ora.st
+    quat, pos = T(st["root_quat"]), T(st["root_pos"])
+    ang_w = T(st["root_ang_vel"])
+    com_w = mu.quat_apply(quat, T(st["base_com"]))
+    lin_w = T(st["root_lin_vel"]) + torch.linalg.cross(ang_w, com_w)
+    body_pos, body_vel = ora.phys.body_kinematics(st)
+    fwd = mu.quat_apply(quat, torch.tensor([1.0, 0, 0], dtype=torch.float64).repeat(ora.N, 1))
+    D = ora.D
+    m = desc.model
+    soft = torch.stack([T(list(m.soft_lower)[:D]), T(list(m.soft_upper)[:D])], -1).repeat(ora.N, 1, 1)
+    data = types.SimpleNamespace(
+        root_pos_w=pos, root_quat_w=quat, root_link_pos_w=pos, root_link_quat_w=quat, root_lin_vel_w=lin_w, root_ang_vel_w=ang_w,
+        root_lin_vel_b=mu.quat_apply_inverse(quat, lin_w), root_ang_vel_b=mu.quat_apply_inverse(quat, ang_w),
+        root_com_lin_vel_b=mu.quat_apply_inverse(quat, lin_w),
+        projected_gravity_b=mu.quat_apply_inverse(quat, torch.tensor([0.0, 0, -1.0], dtype=torch.float64).repeat(ora.N, 1)),
+        heading_w=torch.atan2(fwd[:, 1], fwd[:, 0]),
+        joint_pos=T(st["q"]), joint_vel=T(st["qd"]), default_joint_pos=T(ora.q0).repeat(ora.N, 1),
+        default_joint_vel=T(ora.qd0).repeat(ora.N, 1), applied_torque=T(ora.applied_torque), joint_acc=T(ora.joint_acc),
+        soft_joint_pos_limits=soft, body_pos_w=T(body_pos), body_link_pos_w=T(body_pos), body_lin_vel_w=T(body_vel))
+    asset = types.SimpleNamespace(data=data, joint_names=list(desc.joint_names), body_names=list(desc.body_names), device="cpu")
+    asset.find_joints = lambda keys, preserve_order=False: (find_names(keys, asset.joint_names, preserve_order), None)
+    asset.find_bodies = lambda keys, preserve_order=False: (find_names(keys, asset.body_names, preserve_order), None)
+    sensor = Sensor(ora, list(desc.body_names))
+
+    class Scene(dict):
+        pass
+
+    scene = Scene(robot=asset, contact_forces=sensor)
+    scene.sensors = {"contact_forces": sensor}
+    env = types.SimpleNamespace(
+        scene=scene, num_envs=ora.N, device="cpu", step_dt=ora.step_dt, max_episode_length_s=ora.max_episode_length_s,
+        command_manager=types.SimpleNamespace(get_command=lambda name: T(ora.vel_command_b)),
+        action_manager=types.SimpleNamespace(action=T(ora.action), prev_action=T(ora.prev_action)),
+        termination_manager=types.SimpleNamespace(terminated=torch.tensor(ora.terminated)))
+    return env
+
+
+def resolve(params, desc):
+    out = {}
+    for k, v in (params or {}).items():
+        if isinstance(v, SceneEntityCfg):
+            v = v.copy()
+            if v.joint_names is not None:
+                v.joint_ids = find_names(v.joint_names, list(desc.joint_names), v.preserve_order)
+            if v.body_names is not None:
+                v.body_ids = find_names(v.body_names, list(desc.body_names), v.preserve_order)
+        out[k] = v
+    return out
+
+
+def snapshot(ora):
+    keys = ["root_pos", "root_quat", "root_lin_vel", "root_ang_vel", "q", "qd", "base_com"]
+    snap = {"st_" + k: ora.st[k] for k in keys}
+    for k in ("applied_torque", "joint_acc", "force_hist", "contact_force", "timers", "action", "prev_action", "vel_command_b", "terminated"):
+        snap[k] = getattr(ora, k)
+    return snap
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for robot, seed in (("A1", 3), ("Go2", 4)):
+        task = f"RobotLab-Isaac-Velocity-Flat-Unitree-{robot}-v0"
+        cfg = parse_env_cfg(task, device="cpu")
+        desc, spec = compile_cfg(cfg)
+        N = 48
+        h, to, eo = build_world(desc, dict(env_spacing=2.5), N, 0)
+        ora = OracleEnv(desc, h, to, N, seed, eo)
+        ora.reset()
+        rng = np.random.default_rng(seed)
+        for s in range(37):  # long enough for contacts, air phases and a command resample of the standing envs
+            ora.step(rng.uniform(-1, 1, (N, ora.D)))
+        ora.vel_command_b[::5] *= 0.02  # exercise the small-command branches
+        snap = snapshot(ora)
+        env = duck_env(ora, desc)
+        expected = {}
+        for name, term in vars(cfg.rewards).items():
+            if term is None or not hasattr(term, "func") or term.weight == 0:
+                continue
+            f = term.func
+            params = resolve(term.params, desc)
+            if isinstance(f, type):  # class-based term (GaitReward)
+                val = f(term, env)(env, **params)
+            else:
+                val = f(env, **params)
+            expected[name] = val.detach().to(torch.float64).numpy()
+        # command threshold rule: UniformThresholdVelocityCommand._resample_command (VEL/mdp/commands.py:43-47)
+        from robot_lab.tasks.manager_based.locomotion.velocity.mdp.commands import UniformThresholdVelocityCommand
+
+        obj = UniformThresholdVelocityCommand.__new__(UniformThresholdVelocityCommand)
+        cmd_in = T(rng.uniform(-1, 1, (N, 3)) * rng.choice([0.1, 1.0], (N, 1)))
+        obj.vel_command_b = cmd_in.clone()
+        from isaaclab.envs.mdp import UniformVelocityCommand
+
+        orig = UniformVelocityCommand._resample_command
+        UniformVelocityCommand._resample_command = lambda self, ids: None  # parent draw is [UPSTREAM]; pin the subclass rule only
+        obj._resample_command(torch.arange(N))
+        UniformVelocityCommand._resample_command = orig
+        # reset_root_state_uniform (VEL/mdp/events.py:205-271) with injected uniform samples
+        from robot_lab.tasks.manager_based.locomotion.velocity.mdp import events as ref_events
+
+        samples = [T(rng.uniform(-1, 1, (N, 6))), T(rng.uniform(-0.5, 0.5, (N, 6)))]
+        calls = iter(samples)
+        ref_events.math_utils.sample_uniform = lambda lo, hi, size, device: next(calls)
+        written = {}
+        asset = env.scene["robot"]
+        droot = np.zeros((N, 13))
+        droot[:, :3] = list(desc.model.default_root_pos)
+        droot[:, 3:7] = list(desc.model.default_root_quat)
+        asset.data.default_root_state = T(droot)
+        asset.write_root_pose_to_sim = lambda pose, env_ids=None: written.__setitem__("pose", pose.numpy())
+        asset.write_root_velocity_to_sim = lambda vel, env_ids=None: written.__setitem__("vel", vel.numpy())
+        env.scene.env_origins = T(ora.env_origins)
+        env.scene.terrain = None
+        rp = cfg.events.randomize_reset_base.params
+        ref_events.reset_root_state_uniform(env, torch.arange(N), rp["pose_range"], rp["velocity_range"])
+        np.savez_compressed(
+            os.path.join(out_dir, f"terms_{robot.lower()}.npz"), seed=seed, N=N, task=task,
+            term_names=np.array(list(expected.keys())), term_values=np.stack(list(expected.values())),
+            cmd_in=cmd_in.numpy(), cmd_out=obj.vel_command_b.numpy(),
+            reset_pose_samples=samples[0].numpy(), reset_vel_samples=samples[1].numpy(), reset_pose=written["pose"], reset_vel=written["vel"],
+            env_origins=ora.env_origins, **snap)
+        print(robot, "terms:", list(expected.keys()))
+
+
+if __name__ == "__main__":
+    main()
