@@ -410,21 +410,43 @@ struct EnvLane {
         Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad[s], cb[s], cw[s], tp[s]);
         if (c.act) {
           active_mask |= 1u << (g * SPL + s);
-          // Jacobian columns of the point velocity wrt [omega_b, v_b, qd]
-          V3 col[NV];
-          col[0] = cross(unit(0), c.x); col[1] = cross(unit(1), c.x); col[2] = cross(unit(2), c.x);
-          col[3] = unit(0); col[4] = unit(1); col[5] = unit(2);
+          // J = [ [x]x^T | 1 | a_j x (x - p_j) ... ] (point velocity wrt [omega_b, v_b, qd]); add
+          // dt (d_t J^T J + (d_n - d_t) g g^T) with g = J^T n, exploiting the block structure of J
+          const V3 x = c.x, n = c.n;
+          const float kt = dt * c.dt, kn = dt * (c.dn - c.dt), fb = dt * c.bias;
+          const V3 ga = cross(x, n);
+          const float g6[6] = {ga.x, ga.y, ga.z, n.x, n.y, n.z};
+          const float xx = dot(x, x);
+          // base block
+          U[UI::at(0, 0)] += kt * (xx - x.x * x.x); U[UI::at(1, 1)] += kt * (xx - x.y * x.y); U[UI::at(2, 2)] += kt * (xx - x.z * x.z);
+          U[UI::at(0, 1)] -= kt * x.x * x.y; U[UI::at(0, 2)] -= kt * x.x * x.z; U[UI::at(1, 2)] -= kt * x.y * x.z;
+          U[UI::at(0, 4)] -= kt * x.z; U[UI::at(0, 5)] += kt * x.y;
+          U[UI::at(1, 3)] += kt * x.z; U[UI::at(1, 5)] -= kt * x.x;
+          U[UI::at(2, 3)] -= kt * x.y; U[UI::at(2, 4)] += kt * x.x;
+          U[UI::at(3, 3)] += kt; U[UI::at(4, 4)] += kt; U[UI::at(5, 5)] += kt;
 #pragma unroll
-          for (int i = 0; i < CL; ++i) col[6 + i] = i < g ? cross(C.ax[i], c.x - C.p[i]) : V3{0.f, 0.f, 0.f};
-          float gn[NV];
+          for (int i = 0; i < 6; ++i) {
+            rv[i] += fb * g6[i];
+            const float kg = kn * g6[i];
 #pragma unroll
-          for (int i = 0; i < NV; ++i) gn[i] = dot(col[i], c.n);
-          const float kt = dt * c.dt, kn = dt * (c.dn - c.dt);
+            for (int jj = i; jj < 6; ++jj) U[UI::at(i, jj)] += kg * g6[jj];
+          }
+          // chain columns (only the joints between the base and the sphere's link move the point)
+          V3 cj[CL];
+          float gc[CL];
 #pragma unroll
-          for (int i = 0; i < NV; ++i) {
-            rv[i] += dt * c.bias * gn[i];
+          for (int j = 0; j < CL; ++j) {
+            if (j < g) {
+              cj[j] = cross(C.ax[j], x - C.p[j]);
+              gc[j] = dot(cj[j], n);
+              const V3 w = cross(x, cj[j]);
+              const float kg = kn * gc[j];
+              U[UI::at(0, 6 + j)] += kt * w.x + kg * g6[0]; U[UI::at(1, 6 + j)] += kt * w.y + kg * g6[1]; U[UI::at(2, 6 + j)] += kt * w.z + kg * g6[2];
+              U[UI::at(3, 6 + j)] += kt * cj[j].x + kg * g6[3]; U[UI::at(4, 6 + j)] += kt * cj[j].y + kg * g6[4]; U[UI::at(5, 6 + j)] += kt * cj[j].z + kg * g6[5];
+              rv[6 + j] += fb * gc[j];
 #pragma unroll
-            for (int jj = i; jj < NV; ++jj) U[UI::at(i, jj)] += kt * dot(col[i], col[jj]) + kn * gn[i] * gn[jj];
+              for (int i = 0; i <= j; ++i) U[UI::at(6 + i, 6 + j)] += kt * dot(cj[i], cj[j]) + kg * gc[i];
+            }
           }
         }
       }
