@@ -50,6 +50,18 @@ RL_FN Uni make_uni(const Ctx& ctx, const Tables& T) {
 
 // bilinear heightfield (oracle/physics.py TerrainSampler), split so that the 4 corner loads of several
 // query points can be in flight together before any of them is consumed
+struct F2 {
+  float x, y;
+};
+RL_FN F2 ld2(const float* p) {  // 4-byte aligned 8-byte load
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f2v __attribute__((ext_vector_type(2), aligned(4)));
+  f2v v = *reinterpret_cast<const f2v*>(p);
+  return {v.x, v.y};
+#else
+  return {p[0], p[1]};
+#endif
+}
 struct TerrainPatch {
   float h00, h01, h10, h11, fx, fy;
 };
@@ -65,8 +77,10 @@ RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, flo
   int iy = (int)fminf(fmaxf(floorf(gy), 0.f), (float)(u.ny - 2));
   p.fx = clampf(gx - (float)ix, 0.f, 1.f);
   p.fy = clampf(gy - (float)iy, 0.f, 1.f);
-  const float* b = hf + (size_t)ix * u.ny + iy;
-  p.h00 = b[0]; p.h01 = b[1]; p.h10 = b[u.ny]; p.h11 = b[u.ny + 1];
+  // (iy, iy+1) are adjacent in memory: two 8-byte loads per query instead of four 4-byte ones
+  const float* b = hf + (uint32_t)ix * (uint32_t)u.ny + (uint32_t)iy;
+  F2 r0 = ld2(b), r1 = ld2(b + u.ny);
+  p.h00 = r0.x; p.h01 = r0.y; p.h10 = r1.x; p.h11 = r1.y;
   return p;
 }
 RL_FN void terrain_eval(const Uni& u, const TerrainPatch& p, float& h, V3& n) {

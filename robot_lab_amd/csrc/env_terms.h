@@ -210,8 +210,25 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     Chain<CL> C;
     chain_kinematics<CL>(L, q, C);
     float total = 0.f;
-    for (int t = 0; t < T.n_rewards; ++t) {
-      const RewTab& R = T.rew[t];
+    float* rstage = ctx.rew_stage();
+    const int n_rewards = ctx.uniform_i(T.n_rewards);
+    const float step_dt = ctx.uniform(T.step_dt);
+    for (int t = 0; t < n_rewards; ++t) {
+      // the term descriptor is wave-uniform: pin it into SGPRs so that the dispatch below is scalar
+      // branching instead of 28 exec-masked case tests per term
+      const RewTab& Rl = T.rew[t];
+      struct {
+        int kind, n_idx;
+        float weight, p[4];
+        uint32_t joint_mask;
+        uint64_t body_mask;
+        const int32_t *idx_a, *idx_b;
+      } R;
+      R.kind = ctx.uniform_i(Rl.kind); R.n_idx = ctx.uniform_i(Rl.n_idx); R.weight = ctx.uniform(Rl.weight);
+      R.p[0] = ctx.uniform(Rl.p[0]); R.p[1] = ctx.uniform(Rl.p[1]); R.p[2] = ctx.uniform(Rl.p[2]); R.p[3] = ctx.uniform(Rl.p[3]);
+      R.joint_mask = (uint32_t)ctx.uniform_i((int)Rl.joint_mask);
+      R.body_mask = (uint64_t)(uint32_t)ctx.uniform_i((int)(uint32_t)Rl.body_mask) | ((uint64_t)(uint32_t)ctx.uniform_i((int)(uint32_t)(Rl.body_mask >> 32)) << 32);
+      R.idx_a = Rl.idx_a; R.idx_b = Rl.idx_b;
       float f = 0.f;
       switch (R.kind) {
         case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
@@ -357,21 +374,49 @@ struct EnvProgram : EnvLane<Ctx, CL> {
         } break;
         default: break;
       }
-      float val = f * R.weight * T.step_dt;  // RewardManager [UPSTREAM B2]
+      float val = f * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
       total += val;
-      if (k == (t & 3)) {
-        S.rew_terms[(size_t)t * Np + e] = val;
-        S.ep_sums[(size_t)t * Np + e] += val;
+      if (k == 0) rstage[t] = val;
+    }
+    // per-term outputs + episode sums: staged through LDS so that each lane's read-modify-writes of
+    // `ep_sums` (terms t = k, k+4, ...) are issued as one batch instead of one HBM round trip per term
+    ctx.group_sync();
+    {
+      constexpr int NB = (MAX_T + NLANE - 1) / NLANE;
+      float acc[NB];
+      const int nrew = n_rewards;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int t = k + NLANE * i;
+        acc[i] = t < nrew ? S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int t = k + NLANE * i;
+        if (t < nrew) {
+          const float v = rstage[t];
+          S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = v;
+          S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = acc[i] + v;
+        }
       }
     }
+    ctx.group_sync();
     return total;
   }
 
   // ---------------------------------------------------------------- observations [UPSTREAM B2 / B6]
   RL_FN void write_obs(float* stage, const ObsTab* terms, int n, bool corrupt, uint32_t noise_base) {
     const float cy = cosf(heading_w), sy = sinf(heading_w);
+    n = ctx.uniform_i(n);
     for (int i = 0; i < n; ++i) {
-      const ObsTab& O = terms[i];
+      const ObsTab& Ol = terms[i];
+      struct {
+        int kind, has_noise, offset;
+        float scale, clip_lo, clip_hi, noise_lo, noise_hi;
+      } O;
+      O.kind = ctx.uniform_i(Ol.kind); O.has_noise = ctx.uniform_i(Ol.has_noise); O.offset = ctx.uniform_i(Ol.offset);
+      O.scale = ctx.uniform(Ol.scale); O.clip_lo = ctx.uniform(Ol.clip_lo); O.clip_hi = ctx.uniform(Ol.clip_hi);
+      O.noise_lo = ctx.uniform(Ol.noise_lo); O.noise_hi = ctx.uniform(Ol.noise_hi);
       auto put = [&](int col, float v) {
         if (corrupt && O.has_noise) v += U(STREAM_NOISE, noise_base + (uint32_t)col, O.noise_lo, O.noise_hi);
         stage[col] = clampf(v, O.clip_lo, O.clip_hi) * O.scale;
@@ -389,13 +434,14 @@ struct EnvProgram : EnvLane<Ctx, CL> {
             put(O.offset + L.joint_id[j], v);
           }
           break;
-        case OBS_HEIGHT_SCAN: {  // yaw-aligned grid, x fastest; z_base - hit_z - offset.  4 rays per trip so 16 loads overlap
+        case OBS_HEIGHT_SCAN: {  // yaw-aligned grid, x fastest; z_base - hit_z - offset.  12 rays per trip so 24 8-byte loads overlap
           const int nr = T.scan_nx * T.scan_ny, snx = T.scan_nx;
           const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1), soff = T.scan_offset;
-          for (int r0 = k; r0 < nr; r0 += 4 * NLANE) {
-            TerrainPatch tp[4];
+          constexpr int RB = 12;  // rays per lane per trip
+          for (int r0 = k; r0 < nr; r0 += RB * NLANE) {
+            TerrainPatch tp[RB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RB; ++i) {
               int r = r0 + i * NLANE;
               r = r < nr ? r : nr - 1;
               int iy = r / snx, ix = r - iy * snx;
@@ -403,7 +449,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
               tp[i] = terrain_fetch(this->u, S.terrain, pos.x + cy * lx - sy * ly, pos.y + sy * lx + cy * ly);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RB; ++i) {
               int r = r0 + i * NLANE;
               float hz;
               V3 nn;

@@ -48,6 +48,9 @@ struct WaveCtx {
   __device__ float gshfl(float v, int src) const { return __shfl(v, (lane & ~3) | src); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
   __device__ float* obs_stage(int g) const { return stage[g] + (lane >> 2) * dim[g]; }
+  float* rstage;
+  __device__ float* rew_stage() const { return rstage + (lane >> 2) * MAX_T; }
+  __device__ void group_sync() const { __syncthreads(); }
   __device__ void flush_obs(float* out, int d, int g) const {
     __syncthreads();  // single-wave workgroup: orders the LDS writes above before the reads below
     const int n4 = (ENVS_PER_WAVE * d) >> 2;  // 16 rows are contiguous in `out` and 16-byte aligned
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const Tables* __restr
   ctx.stage[0] = smem + TAB_F;
   ctx.stage[1] = ctx.stage[0] + ((ENVS_PER_WAVE * ctx.dim[0] + 3) & ~3);
   ctx.lscratch = ctx.stage[1] + ((ENVS_PER_WAVE * ctx.dim[1] + 3) & ~3);
+  ctx.rstage = ctx.lscratch + LS_WORDS * 64;
   ctx.lane = lane;
   ctx.e0 = blockIdx.x * ENVS_PER_WAVE;
   EnvProgram<WaveCtx, CL> prog(ctx, S);
@@ -134,7 +138,7 @@ struct Backend {
     size_t tab = (sizeof(Tables) + 15) / 16 * 16;
     size_t s0 = ((size_t)ENVS_PER_WAVE * T.policy_dim + 3) / 4 * 16;
     size_t s1 = ((size_t)ENVS_PER_WAVE * T.critic_dim + 3) / 4 * 16;
-    lds_bytes = tab + s0 + s1 + (size_t)LS_WORDS * 64 * 4;
+    lds_bytes = tab + s0 + s1 + (size_t)LS_WORDS * 64 * 4 + (size_t)ENVS_PER_WAVE * MAX_T * 4;
     if (lds_bytes > 160 * 1024) {
       err = "observation rows do not fit the 160 KiB LDS";
       return -1;

@@ -133,7 +133,7 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   const rl_task_desc& t = d.task;
   T.step_dt = s.dt * (float)s.decimation;
   T.max_episode_length_s = t.episode_length_s;
-  T.max_episode_length = (int)ceil((double)t.episode_length_s / ((double)s.dt * s.decimation) - 1e-9);
+  T.max_episode_length = (int)ceil((double)t.episode_length_s / ((double)s.dt * s.decimation) - 1e-4);  // dt is fp32: 20 / (4 * 0.005f) = 1000.00002
   memcpy(T.cmd_range, t.cmd_range, sizeof(T.cmd_range));
   memcpy(T.cmd_resample, t.cmd_resample, sizeof(T.cmd_resample));
   T.cmd_rel_standing = t.cmd_rel_standing; T.cmd_rel_heading = t.cmd_rel_heading; T.cmd_heading_stiffness = t.cmd_heading_stiffness;

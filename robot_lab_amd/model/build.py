@@ -268,4 +268,4 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
 
 
 def max_episode_length(desc: EnvDesc) -> int:
-    return int(math.ceil(desc.task.episode_length_s / (desc.sim.decimation * desc.sim.dt) - 1e-9))
+    return int(math.ceil(desc.task.episode_length_s / (desc.sim.decimation * desc.sim.dt) - 1e-4))

@@ -23,6 +23,6 @@ def import_packages(package_name: str, blacklist_pkgs: list | None = None):
             continue
         try:
             importlib.import_module(name)
-        except Exception as e:  # noqa: BLE001 - optional task families (skrl/AMP/beyondmimic deps)
+        except (Exception, SystemExit) as e:  # noqa: BLE001 - optional task families (skrl/AMP/beyondmimic deps, argparse scripts)
             if os.environ.get("ROBOT_LAB_AMD_VERBOSE_IMPORT"):
                 print(f"[robot_lab_amd] skipped {name}: {type(e).__name__}: {e}")

@@ -22,6 +22,7 @@ struct Team {
   std::atomic<int> count{0};
   std::atomic<int> sense{0};
   float slot[rl::NLANE];
+  float rstage[rl::MAX_T];
   std::vector<float> stage[2];
   void barrier(int& local_sense) {
     local_sense ^= 1;
@@ -71,6 +72,8 @@ struct HostCtx {
     lock.clear(std::memory_order_release);
   }
   float* obs_stage(int g) { return team->stage[g].data(); }
+  float* rew_stage() { return team->rstage; }
+  void group_sync() { team->barrier(sense_); }
   void flush_obs(float* out, int dim, int g) {
     team->barrier(sense_);
     for (int i = k_; i < dim; i += rl::NLANE) out[(size_t)e_ * dim + i] = team->stage[g][i];
@@ -135,3 +138,12 @@ struct Backend {
 }  // namespace
 
 #include "../../robot_lab_amd/csrc/rl_env_capi.inl"
+
+// test hook (emulator library only): the lane program's randomness primitive, for tests/test_philox.py
+extern "C" float rl_test_uniform01(uint64_t seed, uint32_t env, uint32_t counter, uint32_t stream, uint32_t index) {
+  return rl::uniform01(seed, env, counter, stream, index);
+}
+extern "C" void rl_test_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  rl::U4 r = rl::philox4x32_10(rl::U4{ctr[0], ctr[1], ctr[2], ctr[3]}, key[0], key[1]);
+  out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}

@@ -1,0 +1,63 @@
+"""The C-ABI shared library loads and exports every entry point include/rl_env.h declares; the Python
+descriptor mirror has the size the library was built with.  (No compute calls: no GPU here.)"""
+import ctypes
+import os
+import re
+
+import pytest
+
+from robot_lab_amd import capi
+from robot_lab_amd.desc import EnvDesc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "rl_env.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rl_env_[a-z_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(capi.EXPORTS)
+
+
+@pytest.mark.parametrize("which", ["hip", "emu"])
+def test_library_exports(which, emu_lib):
+    path = capi.HIP_LIB if which == "hip" else emu_lib
+    if which == "hip" and not os.path.isfile(path):
+        import __graft_entry__ as g
+
+        g.build()
+    lib = ctypes.CDLL(path)
+    for name in _declared():
+        assert hasattr(lib, name), f"{os.path.basename(path)} does not export {name}"
+    lib.rl_env_desc_size.restype = ctypes.c_uint64
+    assert lib.rl_env_desc_size() == ctypes.sizeof(EnvDesc)
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Without a HIP device the boundary class refuses to construct (it must not route to the oracle/emulator)."""
+    import torch
+
+    from robot_lab_amd.capi import RlEnvError
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RlEnvError):
+        ManagerBasedRLEnv("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", num_envs=16, device="cuda:0")
+    with pytest.raises(RlEnvError):
+        ManagerBasedRLEnv("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", num_envs=16, device="cpu")
+    with pytest.raises(RlEnvError):
+        capi.load_library("/nonexistent/librl_env_hip.so")
+
+
+def test_descriptor_errors_are_reported(emu_lib):
+    from robot_lab_amd.scene import build_world, load_bundle
+
+    desc, extra = load_bundle("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0")
+    h, to, eo = build_world(desc, extra, 16, 0)
+    desc.model.num_chains = 3  # not the star topology the lane program is written for
+    with pytest.raises(capi.RlEnvError, match="star articulation"):
+        capi.NativeEnv(desc, h, to, eo, 16, 1, 0, emu_lib)

@@ -1,0 +1,81 @@
+"""Known-answer facts derivable from the reference (SURVEY.md section 8(c) "KATs") checked on the committed
+descriptor bundles, and - where /root/reference exists - that recompiling the reference's cfg classes
+through the shims reproduces the committed bundles."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from robot_lab_amd.desc import arr, desc_to_json
+from robot_lab_amd.model.build import max_episode_length
+from robot_lab_amd.scene import load_bundle
+
+REF = "/root/reference/source/robot_lab"
+A1R = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
+
+
+def test_a1_census():
+    d, _ = load_bundle(A1R)
+    m = d.model
+    assert (m.num_links, m.num_dof, m.num_bodies, m.num_chains, m.chain_len) == (13, 12, 17, 4, 3)
+    assert abs(float(arr(m.body_mass, 17).sum()) - 13.741) < 1e-4                     # a1.urdf masses
+    assert d.joint_names[:3] == ["FR_hip_joint", "FR_thigh_joint", "FR_calf_joint"]    # rough_env_cfg.py:22-27
+    q0 = arr(m.default_joint_pos, 12)
+    np.testing.assert_allclose(q0.reshape(4, 3), np.tile([0.0, 0.8, -1.5], (4, 1)), atol=1e-6)  # unitree.py:43-50
+    np.testing.assert_allclose(arr(m.default_root_pos), [0, 0, 0.38], atol=1e-6)
+    lo, hi = arr(m.joint_lower, 12).reshape(4, 3), arr(m.joint_upper, 12).reshape(4, 3)
+    np.testing.assert_allclose(lo[0], [-0.802851, -1.047198, -2.696534], atol=1e-5)   # a1.urdf:369,411,439
+    np.testing.assert_allclose(hi[0], [0.802851, 4.188790, -0.916298], atol=1e-5)
+    mid, rng = 0.5 * (lo + hi), hi - lo
+    np.testing.assert_allclose(arr(m.soft_lower, 12).reshape(4, 3), mid - 0.45 * rng, atol=1e-5)  # soft factor 0.9, unitree.py:53
+    np.testing.assert_allclose(arr(m.action_scale, 12).reshape(4, 3), np.tile([0.125, 0.25, 0.25], (4, 1)))  # rough_env_cfg.py:51
+    assert max_episode_length(d) == 1000                                               # ceil(20 / 0.02)
+    assert (d.obs_dim(0), d.obs_dim(1)) == (45, 235) and d.task.scan_nx * d.task.scan_ny == 187
+    assert d.task.n_rewards == 17 and not d.task.term_illegal_contact                  # rough_env_cfg.py:83-153
+    w = {n: d.task.rewards[i].weight for i, n in enumerate(d.reward_names)}
+    assert w["track_lin_vel_xy_exp"] == 3.0 and w["feet_height_body"] == -5.0 and abs(w["joint_torques_l2"] + 2.5e-5) < 1e-12
+    feet = [i for i, n in enumerate(d.body_names) if n.endswith("_foot")]
+    r = d.task.rewards[d.reward_names.index("undesired_contacts")]
+    assert all(not (r.body_mask >> f) & 1 for f in feet) and bin(r.body_mask).count("1") == 13  # "^(?!.*_foot).*"
+
+
+@pytest.mark.parametrize("task,dims,bodies,mass", [
+    ("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", (45, 48), 17, 13.741),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", (45, 235), 19, 16.087),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", (57, 247), 19, 19.523),
+])
+def test_other_bundles(task, dims, bodies, mass):
+    d, _ = load_bundle(task)
+    assert (d.obs_dim(0), d.obs_dim(1)) == dims and d.model.num_bodies == bodies
+    assert abs(float(arr(d.model.body_mass, bodies).sum()) - mass) < 2e-3
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs /root/reference")
+def test_bundles_recompile_from_reference_cfg():
+    from robot_lab_amd import shims
+
+    shims.install(shims.REFERENCE_SOURCE)
+    import gymnasium as gym
+    import robot_lab.tasks  # noqa: F401
+    from isaaclab_tasks.utils import parse_env_cfg
+
+    from robot_lab_amd.model.cfg_compile import compile_cfg
+
+    assert gym.spec(A1R).entry_point == "isaaclab.envs:ManagerBasedRLEnv"
+    for task in (A1R, "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0"):
+        desc, spec = compile_cfg(parse_env_cfg(task, device="cpu", num_envs=8))
+        committed, _ = load_bundle(task)
+        assert json.loads(desc_to_json(desc)) == json.loads(desc_to_json(committed)), task
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs /root/reference")
+def test_entry_point_resolves_to_the_hip_env():
+    from robot_lab_amd import shims
+
+    shims.install(shims.REFERENCE_SOURCE)
+    import isaaclab.envs
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    assert isaaclab.envs.ManagerBasedRLEnv is ManagerBasedRLEnv

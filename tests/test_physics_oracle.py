@@ -1,0 +1,109 @@
+"""Sanity of the physics oracle itself (it is the checker, so it is checked against closed forms):
+free fall, conservation in zero gravity (first-order convergent drift), DC-motor torque-speed clip."""
+import numpy as np
+import pytest
+
+from oracle import spatial as sp
+from oracle.env import OracleEnv
+from oracle.physics import Physics
+from robot_lab_amd.desc import arr
+from robot_lab_amd.scene import build_world, load_bundle
+
+TASK = "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0"
+
+
+def _state(ph, d, N, z=5.0, seed=0):
+    rng = np.random.default_rng(seed)
+    B, D = d.model.num_bodies, d.model.num_dof
+    bm = np.tile(arr(d.model.body_mass, B).astype(float), (N, 1))
+    mass, h, Io = ph.link_inertias(bm, np.zeros((N, 3)))
+    rpy = rng.uniform(-3, 3, (N, 3))
+    return dict(
+        root_pos=np.tile([0, 0, z], (N, 1)).astype(float), root_quat=sp.quat_from_euler_xyz(*rpy.T), root_lin_vel=rng.uniform(-1, 1, (N, 3)),
+        root_ang_vel=rng.uniform(-2, 2, (N, 3)), q=np.tile(arr(d.model.default_joint_pos, D).astype(float), (N, 1)), qd=rng.uniform(-3, 3, (N, D)),
+        link_mass=mass, link_h=h, link_Io=Io, body_mu_s=np.ones((N, B)), body_mu_d=np.ones((N, B)), body_rest=np.zeros((N, B)),
+        ext_force=np.zeros((N, 3)), ext_torque=np.zeros((N, 3)), base_com=np.tile(arr(d.model.body_com, B)[0].astype(float), (N, 1)))
+
+
+def _momentum(ph, st):
+    Rw, ow, X = ph.kinematics(st["root_pos"], st["root_quat"], st["q"])
+    K = ph.link_jacobians(X)
+    nu = ph.gen_vel(st)
+    P = np.zeros((ph.N, 3))
+    Lm = np.zeros((ph.N, 3))
+    E = np.zeros(ph.N)
+    for i in range(ph.L):
+        I = sp.spatial_inertia(st["link_mass"][:, i], st["link_h"][:, i], st["link_Io"][:, i])
+        v = np.einsum("nij,nj->ni", K[:, i], nu)
+        hs = np.einsum("nij,nj->ni", I, v)
+        E += 0.5 * np.einsum("ni,ni->n", v, hs)
+        p = np.einsum("nij,nj->ni", Rw[:, i], hs[:, 3:])
+        P += p
+        Lm += np.einsum("nij,nj->ni", Rw[:, i], hs[:, :3]) + np.cross(ow[:, i], p)
+    return E, P, Lm
+
+
+def _free(d):
+    for a in (d.model.joint_lower, d.model.joint_upper, d.model.joint_vel_limit):
+        pass
+    d.model.joint_lower[:] = [-1e9] * 31
+    d.model.joint_upper[:] = [1e9] * 31
+    d.model.joint_vel_limit[:] = [1e9] * 31
+
+
+def test_free_fall_matches_closed_form():
+    d, _ = load_bundle(TASK)
+    _free(d)
+    N = 4
+    ph = Physics(d, None, N)
+    st = _state(ph, d, N)
+    st["qd"][:] = 0
+    st["root_ang_vel"][:] = 0
+    st["root_lin_vel"][:] = 0
+    z0 = st["root_pos"][:, 2].copy()
+    n = 100
+    for _ in range(n):
+        ph.substep(st, np.zeros((N, 12)))
+    t = n * d.sim.dt
+    # semi-implicit Euler: z_n = z0 - g dt^2 n(n+1)/2 ; nothing else moves (uniform gravity exerts no joint torque in free fall)
+    np.testing.assert_allclose(st["root_pos"][:, 2], z0 - d.sim.gravity * d.sim.dt**2 * n * (n + 1) / 2, rtol=1e-9)
+    np.testing.assert_allclose(st["root_lin_vel"][:, 2], -d.sim.gravity * t, rtol=1e-9)
+    assert np.abs(st["qd"]).max() < 1e-9 and np.abs(st["root_ang_vel"]).max() < 1e-9
+
+
+def test_zero_gravity_conservation_converges_first_order():
+    drifts = []
+    for dt in (1e-3, 5e-4):
+        d, _ = load_bundle(TASK)
+        _free(d)
+        d.sim.gravity = 0.0
+        d.sim.dt = dt
+        N = 4
+        ph = Physics(d, None, N)
+        st = _state(ph, d, N, seed=1)
+        E0, P0, L0 = _momentum(ph, st)
+        for _ in range(int(round(0.5 / dt))):
+            ph.substep(st, np.zeros((N, 12)))
+        E1, P1, L1 = _momentum(ph, st)
+        drifts.append((np.abs(E1 / E0 - 1).max(), np.abs(P1 - P0).max(), np.abs(L1 - L0).max()))
+    for a, b in zip(drifts[0], drifts[1]):
+        assert b < 0.62 * a  # halving dt roughly halves the drift: a consistent first-order integrator
+    assert drifts[1][0] < 0.01
+
+
+def test_dc_motor_torque_speed_clip():
+    """[UPSTREAM B4] DCMotor: A1 saturation = effort = 33.5 N m, velocity limit 21 rad/s (unitree.py:55-63)."""
+    d, extra = load_bundle(TASK)
+    N = 5
+    _, _, eo = build_world(d, extra, N, 0)
+    env = OracleEnv(d, None, None, N, 1, eo)
+    env.kp[:] = 1000.0
+    env.kd[:] = 0.0
+    env.st["q"][:] = 0.0
+    env.st["qd"][:] = np.array([-30.0, -10.5, 0.0, 10.5, 30.0])[:, None]
+    tau, applied, pd = env.actuators(np.full((N, 12), 1.0), np.zeros((N, 12)))
+    want = np.array([33.5, 33.5, 33.5, 16.75, 0.0])  # tau_max = clip(sat (1 - qd / vlim), 0, eff)
+    np.testing.assert_allclose(applied[:, 0], want, atol=1e-5)
+    tau, applied, pd = env.actuators(np.full((N, 12), -1.0), np.zeros((N, 12)))
+    np.testing.assert_allclose(applied[:, 0], -want[::-1], atol=1e-5)
+    assert pd is None
