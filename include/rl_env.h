@@ -106,6 +106,7 @@ typedef struct rl_model_desc {
   int32_t num_spheres;  /* collision spheres */
   int32_t num_chains;   /* star topology: base + num_chains serial chains of chain_len joints */
   int32_t chain_len;
+  int32_t chain_link[4][4];             /* link index of chain k's j-th link (joint index = link - 1) */
   int32_t link_parent[RL_MAX_LINKS];
   float link_origin[RL_MAX_LINKS][3];   /* joint origin in parent link frame (rotations are identity) */
   float link_axis[RL_MAX_LINKS][3];

@@ -312,6 +312,71 @@ struct EnvLane {
     return c;
   }
 
+  // ------------------------------------------------------------------ contact pass 1 for link group G
+  // (compile-time G: the chain joints that move the point, and the link frame, are known statically)
+  template <int G>
+  RL_FN void contact_groups(const Chain<CL>& C, const M3& Rwb, SV V0, uint32_t slot_valid, float (&U)[UI::size], float (&rv)[NV], uint32_t& active_mask) {
+    const float dt = u.dt;
+    constexpr int g = G;
+    if ((slot_valid >> (G * SPL)) & ((1u << SPL) - 1u)) {
+      float rad[SPL];
+      V3 cb[SPL], cw[SPL];
+      TerrainPatch tp[SPL];
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        sphere_center(C, Rwb, g, s, rad[s], cb[s], cw[s]);
+        tp[s] = terrain_fetch(u, S.terrain, cw[s].x, cw[s].y);
+      }
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        if (!((slot_valid >> (G * SPL + s)) & 1u)) continue;
+        Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad[s], cb[s], cw[s], tp[s]);
+        if (c.act) {
+          active_mask |= 1u << (g * SPL + s);
+          // J = [ [x]x^T | 1 | a_j x (x - p_j) ... ] (point velocity wrt [omega_b, v_b, qd]); add
+          // dt (d_t J^T J + (d_n - d_t) g g^T) with g = J^T n, exploiting the block structure of J
+          const V3 x = c.x, n = c.n;
+          const float kt = dt * c.dt, kn = dt * (c.dn - c.dt), fb = dt * c.bias;
+          const V3 ga = cross(x, n);
+          const float g6[6] = {ga.x, ga.y, ga.z, n.x, n.y, n.z};
+          const float xx = dot(x, x);
+          // base block
+          U[UI::at(0, 0)] += kt * (xx - x.x * x.x); U[UI::at(1, 1)] += kt * (xx - x.y * x.y); U[UI::at(2, 2)] += kt * (xx - x.z * x.z);
+          U[UI::at(0, 1)] -= kt * x.x * x.y; U[UI::at(0, 2)] -= kt * x.x * x.z; U[UI::at(1, 2)] -= kt * x.y * x.z;
+          U[UI::at(0, 4)] -= kt * x.z; U[UI::at(0, 5)] += kt * x.y;
+          U[UI::at(1, 3)] += kt * x.z; U[UI::at(1, 5)] -= kt * x.x;
+          U[UI::at(2, 3)] -= kt * x.y; U[UI::at(2, 4)] += kt * x.x;
+          U[UI::at(3, 3)] += kt; U[UI::at(4, 4)] += kt; U[UI::at(5, 5)] += kt;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            rv[i] += fb * g6[i];
+            const float kg = kn * g6[i];
+#pragma unroll
+            for (int jj = i; jj < 6; ++jj) U[UI::at(i, jj)] += kg * g6[jj];
+          }
+          // chain columns (only the joints between the base and the sphere's link move the point)
+          V3 cj[CL];
+          float gc[CL];
+#pragma unroll
+          for (int j = 0; j < CL; ++j) {
+            if (j < g) {
+              cj[j] = cross(C.ax[j], x - C.p[j]);
+              gc[j] = dot(cj[j], n);
+              const V3 w = cross(x, cj[j]);
+              const float kg = kn * gc[j];
+              U[UI::at(0, 6 + j)] += kt * w.x + kg * g6[0]; U[UI::at(1, 6 + j)] += kt * w.y + kg * g6[1]; U[UI::at(2, 6 + j)] += kt * w.z + kg * g6[2];
+              U[UI::at(3, 6 + j)] += kt * cj[j].x + kg * g6[3]; U[UI::at(4, 6 + j)] += kt * cj[j].y + kg * g6[4]; U[UI::at(5, 6 + j)] += kt * cj[j].z + kg * g6[5];
+              rv[6 + j] += fb * gc[j];
+#pragma unroll
+              for (int i = 0; i <= j; ++i) U[UI::at(6 + i, 6 + j)] += kt * dot(cj[i], cj[j]) + kg * gc[i];
+            }
+          }
+        }
+      }
+    }
+    if constexpr (G < CL) contact_groups<G + 1>(C, Rwb, V0, slot_valid, U, rv, active_mask);
+  }
+
   // ------------------------------------------------------------------ one physics substep
   RL_FN void substep(const float (&q_tgt)[CL], const float (&qd_tgt)[CL]) {
     // keep the compiler from hoisting the (loop-invariant) LDS table reads of all four substeps to the
@@ -409,62 +474,8 @@ struct EnvLane {
     // One iteration per link group (base share, then each chain link): the terrain corner loads of the
     // group's SPL sphere slots are issued together, then consumed.
     uint32_t active_mask = 0;
-#pragma unroll 1
-    for (int g = 0; g <= CL; ++g) {
-      float rad[SPL];
-      V3 cb[SPL], cw[SPL];
-      TerrainPatch tp[SPL];
-#pragma unroll
-      for (int s = 0; s < SPL; ++s) {
-        sphere_center(C, Rwb, g, s, rad[s], cb[s], cw[s]);
-        tp[s] = terrain_fetch(u, S.terrain, cw[s].x, cw[s].y);
-      }
-#pragma unroll
-      for (int s = 0; s < SPL; ++s) {
-        Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad[s], cb[s], cw[s], tp[s]);
-        if (c.act) {
-          active_mask |= 1u << (g * SPL + s);
-          // J = [ [x]x^T | 1 | a_j x (x - p_j) ... ] (point velocity wrt [omega_b, v_b, qd]); add
-          // dt (d_t J^T J + (d_n - d_t) g g^T) with g = J^T n, exploiting the block structure of J
-          const V3 x = c.x, n = c.n;
-          const float kt = dt * c.dt, kn = dt * (c.dn - c.dt), fb = dt * c.bias;
-          const V3 ga = cross(x, n);
-          const float g6[6] = {ga.x, ga.y, ga.z, n.x, n.y, n.z};
-          const float xx = dot(x, x);
-          // base block
-          U[UI::at(0, 0)] += kt * (xx - x.x * x.x); U[UI::at(1, 1)] += kt * (xx - x.y * x.y); U[UI::at(2, 2)] += kt * (xx - x.z * x.z);
-          U[UI::at(0, 1)] -= kt * x.x * x.y; U[UI::at(0, 2)] -= kt * x.x * x.z; U[UI::at(1, 2)] -= kt * x.y * x.z;
-          U[UI::at(0, 4)] -= kt * x.z; U[UI::at(0, 5)] += kt * x.y;
-          U[UI::at(1, 3)] += kt * x.z; U[UI::at(1, 5)] -= kt * x.x;
-          U[UI::at(2, 3)] -= kt * x.y; U[UI::at(2, 4)] += kt * x.x;
-          U[UI::at(3, 3)] += kt; U[UI::at(4, 4)] += kt; U[UI::at(5, 5)] += kt;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            rv[i] += fb * g6[i];
-            const float kg = kn * g6[i];
-#pragma unroll
-            for (int jj = i; jj < 6; ++jj) U[UI::at(i, jj)] += kg * g6[jj];
-          }
-          // chain columns (only the joints between the base and the sphere's link move the point)
-          V3 cj[CL];
-          float gc[CL];
-#pragma unroll
-          for (int j = 0; j < CL; ++j) {
-            if (j < g) {
-              cj[j] = cross(C.ax[j], x - C.p[j]);
-              gc[j] = dot(cj[j], n);
-              const V3 w = cross(x, cj[j]);
-              const float kg = kn * gc[j];
-              U[UI::at(0, 6 + j)] += kt * w.x + kg * g6[0]; U[UI::at(1, 6 + j)] += kt * w.y + kg * g6[1]; U[UI::at(2, 6 + j)] += kt * w.z + kg * g6[2];
-              U[UI::at(3, 6 + j)] += kt * cj[j].x + kg * g6[3]; U[UI::at(4, 6 + j)] += kt * cj[j].y + kg * g6[4]; U[UI::at(5, 6 + j)] += kt * cj[j].z + kg * g6[5];
-              rv[6 + j] += fb * gc[j];
-#pragma unroll
-              for (int i = 0; i <= j; ++i) U[UI::at(6 + i, 6 + j)] += kt * dot(cj[i], cj[j]) + kg * gc[i];
-            }
-          }
-        }
-      }
-    }
+    const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
+    contact_groups<0>(C, Rwb, V0, slot_valid, U, rv, active_mask);
 
     // ---- Schur complement of the chain block, 4-lane reduction, 6x6 solve, back substitution
     float Lc[CL][CL];

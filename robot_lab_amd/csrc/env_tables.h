@@ -64,6 +64,7 @@ struct ObsTab {
 struct Tables {
   LaneTab lane[NLANE];
   int32_t CL, D, n_bodies, n_base_bodies;
+  uint32_t slot_valid;  // bit g*SPL+s: some lane has a collision sphere in slot (g, s)
   // sim
   float dt;
   int32_t decimation;

@@ -209,6 +209,24 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     const float bv = fsqrt(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
     Chain<CL> C;
     chain_kinematics<CL>(L, q, C);
+    // per-slot sensor data and per-joint constants: one batch of LDS reads up front instead of dependent
+    // reads inside every term
+    int sbody[NBS], jid[CL];
+    float hmax[NBS], t_ca[NBS], t_cc[NBS], t_la[NBS], t_lc[NBS], q0j[CL], slo[CL], shi[CL];
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {
+      int b = L.slot_body[s];
+      sbody[s] = (s == 0 && !L.owns_base_body) ? -1 : b;
+      hmax[s] = fmaxf(hist_n[s][0], fmaxf(hist_n[s][1], hist_n[s][2]));
+      t_ca[s] = tim[s][0]; t_cc[s] = tim[s][1]; t_la[s] = tim[s][2]; t_lc[s] = tim[s][3];
+    }
+#pragma unroll
+    for (int j = 0; j < CL; ++j) {
+      jid[j] = L.joint_id[j]; q0j[j] = L.q0[j]; slo[j] = L.soft_lo[j]; shi[j] = L.soft_hi[j];
+    }
+    const float fc_hi = T.step_dt + 1e-8f;
+    auto in_mask = [&](uint64_t mask, int s) { return sbody[s] >= 0 && ((mask >> sbody[s]) & 1ull); };
+    auto first_c = [&](int s) { return t_cc[s] > 0.f && t_cc[s] < fc_hi; };
     float total = 0.f;
     float* rstage = ctx.rew_stage();
     const int n_rewards = ctx.uniform_i(T.n_rewards);
@@ -250,16 +268,16 @@ struct EnvProgram : EnvLane<Ctx, CL> {
           float part = 0.f;
 #pragma unroll
           for (int j = 0; j < CL; ++j) {
-            bool in = (R.joint_mask >> L.joint_id[j]) & 1u;
+            bool in = (R.joint_mask >> jid[j]) & 1u;
             float v = 0.f;
             switch (R.kind) {
               case REW_JOINT_TORQUES_L2: v = tau_app[j] * tau_app[j]; break;
               case REW_JOINT_ACC_L2: v = qacc[j] * qacc[j]; break;
               case REW_JOINT_VEL_L2: v = qd[j] * qd[j]; break;
-              case REW_JOINT_POS_LIMITS: v = fmaxf(L.soft_lo[j] - q[j], 0.f) + fmaxf(q[j] - L.soft_hi[j], 0.f); break;
+              case REW_JOINT_POS_LIMITS: v = fmaxf(slo[j] - q[j], 0.f) + fmaxf(q[j] - shi[j], 0.f); break;
               case REW_JOINT_POWER: v = fabsf(qd[j] * tau_app[j]); break;  // rewards.py:81-90
-              case REW_JOINT_DEVIATION_L1: case REW_STAND_STILL: v = fabsf(q[j] - L.q0[j]); break;
-              case REW_JOINT_POS_PENALTY: v = (q[j] - L.q0[j]) * (q[j] - L.q0[j]); break;
+              case REW_JOINT_DEVIATION_L1: case REW_STAND_STILL: v = fabsf(q[j] - q0j[j]); break;
+              case REW_JOINT_POS_PENALTY: v = (q[j] - q0j[j]) * (q[j] - q0j[j]); break;
               case REW_ACTION_RATE_L2: v = (act[j] - prev_act[j]) * (act[j] - prev_act[j]); in = true; break;
               default: break;
             }
@@ -298,13 +316,13 @@ struct EnvProgram : EnvLane<Ctx, CL> {
           float part = 0.f;
 #pragma unroll
           for (int s = 0; s < NBS; ++s) {
-            if (!body_bit(R.body_mask, s)) continue;
-            float hm = hist_max(s);
+            if (!in_mask(R.body_mask, s)) continue;
+            float hm = hmax[s];
             switch (R.kind) {
               case REW_UNDESIRED_CONTACTS: part += hm > R.p[0] ? 1.f : 0.f; break;          // rewards.py:665-675
               case REW_CONTACT_FORCES: part += fmaxf(hm - R.p[0], 0.f); break;              // [UPSTREAM] contact_forces
-              case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT: part += first_contact(s) ? 1.f : 0.f; break;
-              case REW_FEET_AIR_TIME: part += first_contact(s) ? tim[s][2] - R.p[0] : 0.f; break;  // rewards.py:340-360
+              case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT: part += first_c(s) ? 1.f : 0.f; break;
+              case REW_FEET_AIR_TIME: part += first_c(s) ? t_la[s] - R.p[0] : 0.f; break;  // rewards.py:340-360
               case REW_FEET_STUMBLE: {                                                       // rewards.py:428-436
                 float fx = cf[s][0], fy = cf[s][1];
                 part += fsqrt(fx * fx + fy * fy) > 4.f * fabsf(cf[s][2]) ? 1.f : 0.f;
@@ -340,8 +358,8 @@ struct EnvProgram : EnvLane<Ctx, CL> {
           float n = 0.f, sa = 0.f, saa = 0.f, sc = 0.f, scc = 0.f;
 #pragma unroll
           for (int s = 0; s < NBS; ++s) {
-            if (!body_bit(R.body_mask, s)) continue;
-            float la = fminf(tim[s][2], 0.5f), lc = fminf(tim[s][3], 0.5f);
+            if (!in_mask(R.body_mask, s)) continue;
+            float la = fminf(t_la[s], 0.5f), lc = fminf(t_lc[s], 0.5f);
             n += 1.f; sa += la; saa += la * la; sc += lc; scc += lc * lc;
           }
           n = ctx.gsum(n); sa = ctx.gsum(sa); saa = ctx.gsum(saa); sc = ctx.gsum(sc); scc = ctx.gsum(scc);
@@ -355,7 +373,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
             float a = 0.f, c = 0.f;
 #pragma unroll
             for (int s = 0; s < NBS; ++s)
-              if (L.slot_body[s] == R.idx_a[i] && (s != 0 || L.owns_base_body)) { a = tim[s][0]; c = tim[s][1]; }
+              if (sbody[s] == R.idx_a[i]) { a = t_ca[s]; c = t_cc[s]; }
             air[i] = ctx.gsum(a);
             con[i] = ctx.gsum(c);
           }
@@ -435,7 +453,8 @@ struct EnvProgram : EnvLane<Ctx, CL> {
           }
           break;
         case OBS_HEIGHT_SCAN: {  // yaw-aligned grid, x fastest; z_base - hit_z - offset.  12 rays per trip so 24 8-byte loads overlap
-          const int nr = T.scan_nx * T.scan_ny, snx = T.scan_nx;
+          const int nr = ctx.uniform_i(T.scan_nx * T.scan_ny), snx = ctx.uniform_i(T.scan_nx);
+          const float inv_snx = ctx.uniform(1.0f / (float)T.scan_nx);
           const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1), soff = T.scan_offset;
           constexpr int RB = 12;  // rays per lane per trip
           for (int r0 = k; r0 < nr; r0 += RB * NLANE) {
@@ -444,7 +463,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
             for (int i = 0; i < RB; ++i) {
               int r = r0 + i * NLANE;
               r = r < nr ? r : nr - 1;
-              int iy = r / snx, ix = r - iy * snx;
+              int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
               float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
               tp[i] = terrain_fetch(this->u, S.terrain, pos.x + cy * lx - sy * ly, pos.y + sy * lx + cy * ly);
             }

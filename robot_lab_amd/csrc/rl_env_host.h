@@ -35,7 +35,8 @@ inline int obs_term_dim(const rl_env_desc& d, int kind) {
 // ------------------------------------------------------------------------------------------------
 // descriptor -> Tables.  Requires the star topology the lane program is written for.
 // ------------------------------------------------------------------------------------------------
-inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_lane, std::vector<int>& body_slot) {
+inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_lane, std::vector<int>& body_slot, std::vector<int>& link_lane_out,
+                        std::vector<int>& link_pos_out) {
   memset(&T, 0, sizeof(T));
   const rl_model_desc& m = d.model;
   if (m.num_chains != NLANE || m.chain_len < 1 || m.chain_len > MAX_CL)
@@ -47,6 +48,10 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   T.n_bodies = m.num_bodies;
   body_lane.assign(m.num_bodies, -1);
   body_slot.assign(m.num_bodies, -1);
+  std::vector<int>& link_k = link_lane_out;
+  std::vector<int>& link_j = link_pos_out;
+  link_k.assign(m.num_links, -1);
+  link_j.assign(m.num_links, -1);
   int n_base_bodies = 0;
   for (int k = 0; k < NLANE; ++k) {
     LaneTab& L = T.lane[k];
@@ -55,8 +60,9 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       for (int s = 0; s < SPL; ++s) L.sph_r[g][s] = -1.f;
     L.base_body_local = -1;
     for (int j = 0; j < CL; ++j) {
-      int jt = k * CL + j, link = 1 + jt;
-      if (m.link_parent[link] != (j == 0 ? 0 : link - 1)) return fail("links are not in chain-major order");
+      int link = m.chain_link[k][j], jt = link - 1;
+      if (link < 1 || link >= m.num_links || m.link_parent[link] != (j == 0 ? 0 : m.chain_link[k][j - 1])) return fail("chain_link does not describe serial chains off the base");
+      link_k[link] = k; link_j[link] = j;
       for (int c = 0; c < 3; ++c) { L.origin[j][c] = m.link_origin[link][c]; L.axis[j][c] = m.link_axis[link][c]; }
       L.lower[j] = m.joint_lower[jt]; L.upper[j] = m.joint_upper[jt]; L.vel_limit[j] = m.joint_vel_limit[jt];
       L.armature[j] = m.joint_armature[jt]; L.q0[j] = m.default_joint_pos[jt]; L.qd0[j] = m.default_joint_vel[jt];
@@ -80,7 +86,7 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       for (int c = 0; c < 3; ++c) L.slot_pos[0][c] = m.body_pos[b][c];
       body_lane[b] = k; body_slot[b] = 0;
     } else {
-      int k = (link - 1) / CL, j = (link - 1) % CL;
+      int k = link_k[link], j = link_j[link];
       LaneTab& L = T.lane[k];
       int s = next_slot[k]++;
       if (s >= NBS) return fail("too many bodies on one chain");
@@ -113,7 +119,7 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
         if (T.lane[k].base_body_local == -1) T.lane[k].base_body_local = T.lane[body_lane[b]].base_body_local;
       }
     } else {
-      k = (link - 1) / CL; grp = (link - 1) % CL + 1; slot = body_slot[b];
+      k = link_k[link]; grp = link_j[link] + 1; slot = body_slot[b];
     }
     LaneTab& L = T.lane[k];
     if (fill[k][grp] >= SPL) return fail("more than 3 collision spheres on one link group (body " + std::to_string(b) + ")");
@@ -122,6 +128,11 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     L.sph_r[grp][s] = m.sphere_radius[g];
     L.sph_slot[grp][s] = slot;
   }
+  T.slot_valid = 0;
+  for (int k = 0; k < NLANE; ++k)
+    for (int g = 0; g < NGRP; ++g)
+      for (int s2 = 0; s2 < SPL; ++s2)
+        if (T.lane[k].sph_r[g][s2] > 0.f) T.slot_valid |= 1u << (g * SPL + s2);
   // sim / terrain / task scalars
   const rl_sim_desc& s = d.sim;
   T.dt = s.dt; T.decimation = s.decimation; T.gravity = s.gravity; T.contact_k = s.contact_k; T.contact_c = s.contact_c;
@@ -185,7 +196,7 @@ struct EnvImpl {
   int N = 0, Npad = 0, D = 0, B = 0, CL = 0;
   uint64_t seed = 0;
   uint32_t step_counter = 0;
-  std::vector<int> body_lane, body_slot;
+  std::vector<int> body_lane, body_slot, link_lane, link_pos;
   std::vector<void*> allocs;
   // AoS inspection buffers
   float *root_state = nullptr, *joint_pos = nullptr, *joint_vel = nullptr, *cforce = nullptr, *ctimers = nullptr, *action_aos = nullptr;
@@ -213,7 +224,7 @@ struct EnvImpl {
     D = d->model.num_dof;
     B = d->model.num_bodies;
     if (N <= 0) return fail("num_envs must be positive");
-    if (build_tables(*d, tables, body_lane, body_slot)) return -1;
+    if (build_tables(*d, tables, body_lane, body_slot, link_lane, link_pos)) return -1;
     CL = tables.CL;
     if (be.init(device)) return fail("device init failed: " + be.error());
     if (be.configure(tables)) return fail("kernel configuration failed: " + be.error());
@@ -321,7 +332,7 @@ struct EnvImpl {
         if (l == 0) {
           for (int f = 0; f < 10; ++f) env[env_index(e, EF_BASE_INERTIA + f)] = rec[f];
         } else {
-          int k = (l - 1) / CL, j = (l - 1) % CL;
+          int k = link_lane[l], j = link_pos[l];
           for (int f = 0; f < 10; ++f) lane[lane_index(e, k, LF_INERTIA + j * INERTIA_NF + f)] = rec[f];
         }
       }

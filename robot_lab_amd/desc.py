@@ -63,6 +63,7 @@ class ModelDesc(C.Structure):
     _fields_ = [
         ("num_links", i32), ("num_dof", i32), ("num_bodies", i32), ("num_spheres", i32), ("num_chains", i32),
         ("chain_len", i32),
+        ("chain_link", (i32 * 4) * 4),
         ("link_parent", i32 * RL_MAX_LINKS),
         ("link_origin", (f32 * 3) * RL_MAX_LINKS),
         ("link_axis", (f32 * 3) * RL_MAX_LINKS),

@@ -60,15 +60,24 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
     jn, bn = model.joint_names, model.body_names
     d.joint_names, d.body_names = list(jn), list(bn)
     m.num_links, m.num_dof, m.num_bodies, m.num_spheres = L, D, B, G
-    # star topology check: chains hanging off the base
-    roots = [i for i in range(1, L) if model.links[i].parent == 0]
-    clen = D // max(1, len(roots))
-    star = len(roots) * clen == D
-    for c, r in enumerate(roots):
-        for k in range(clen):
-            i = 1 + c * clen + k
-            star = star and i < L and model.links[i].parent == (0 if k == 0 else i - 1)
-    m.num_chains, m.chain_len = (len(roots), clen) if star else (0, 0)
+    # star topology: serial chains hanging off the base (the lane program simulates one chain per lane).
+    # Chains are discovered by following the links, so the task's joint order need not be chain-major
+    # (Go2W lists the 12 leg joints first and the 4 wheel joints last, unitree_go2w/rough_env_cfg.py:25-31).
+    children = {i: [c for c in range(1, L) if model.links[c].parent == i] for i in range(L)}
+    chains = []
+    for r in children[0]:
+        ch, cur = [r], r
+        while len(children[cur]) == 1:
+            cur = children[cur][0]
+            ch.append(cur)
+        chains.append(ch if not children[cur] else None)
+    star = (len(chains) == 4 and all(c is not None for c in chains) and len({len(c) for c in chains}) == 1
+            and len(chains[0]) <= 4 and sum(len(c) for c in chains) == D)
+    m.num_chains, m.chain_len = (4, len(chains[0])) if star else (0, 0)
+    if star:
+        for k, ch in enumerate(chains):
+            for j, l in enumerate(ch):
+                m.chain_link[k][j] = l
     for i, l in enumerate(model.links):
         m.link_parent[i] = l.parent
         set_arr(m.link_origin[i], l.origin)

@@ -124,7 +124,7 @@ class RslRlVecEnvWrapper:
             actions = torch.clamp(actions, -self.clip_actions, self.clip_actions)
         obs, rew, terminated, truncated, extras = self.env.step(actions)
         dones = (terminated | truncated).to(dtype=torch.long)
-        if not self.unwrapped.cfg.is_finite_horizon:
+        if not getattr(self.unwrapped.cfg, "is_finite_horizon", False):
             extras["time_outs"] = truncated
         return self._as_tensordict(obs), rew, dones, extras
 

@@ -9,6 +9,7 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0",
     "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0",
     "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0",
+    "RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0",
 ]
 
 
