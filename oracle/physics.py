@@ -12,7 +12,7 @@ Model (one physics substep of length dt; generalized velocity nu = [omega_b, v_b
 twist in base coordinates at the base-link origin):
 
     (H + A) nu+ = H nu + dt (tau - b) + r                      semi-implicit (symplectic) Euler
-    q+ = q + dt qd+ ;  quat+ = normalize(quat * [1, dt/2 omega_b+]) ;  p+ = p + dt R+ v_b+
+    q+ = q + dt qd+ ;  quat+ = normalize(quat * [1, dt/2 omega_b+]) ;  v_w+ = R (v_b+ + dt omega_b x v_b) ;  p+ = p + dt v_w+
 
     b   : Coriolis/centrifugal/gravity bias  (RNEA with qdd = 0, base acceleration = -g)
     A,r : linearly-implicit contact / joint-limit / implicit-PD terms (all PSD, so the step is
@@ -278,8 +278,13 @@ class Physics:
         quat = sp.quat_mul(st["root_quat"], dq)
         quat /= np.linalg.norm(quat, axis=-1, keepdims=True)
         st["root_quat"] = quat
-        Rn = sp.quat_to_mat(quat)
-        st["root_ang_vel"] = np.einsum("nij,nj->ni", Rn, nu_new[:, :3])
-        st["root_lin_vel"] = np.einsum("nij,nj->ni", Rn, nu_new[:, 3:6])
+        # nu+ is the spatial velocity at t+dt in the (fixed) frame that coincides with the body frame at t,
+        # referred to the OLD origin location: rotate with the OLD orientation, and move the reference
+        # point to the new origin (+ dt omega x v, the classical-vs-spatial acceleration term).  Using the
+        # new orientation here instead integrates v_b' = -omega x v_b explicitly and makes |v| of a fast
+        # spinning robot grow by sqrt(1 + (omega dt)^2) every substep.
+        Ro = Rw[:, 0]
+        st["root_ang_vel"] = np.einsum("nij,nj->ni", Ro, nu_new[:, :3])
+        st["root_lin_vel"] = np.einsum("nij,nj->ni", Ro, nu_new[:, 3:6] + dt * np.cross(nu[:, :3], nu[:, 3:6]))
         st["root_pos"] = st["root_pos"] + dt * st["root_lin_vel"]
         return dict(contact_force=cf, joint_acc=qdd)

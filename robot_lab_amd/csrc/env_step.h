@@ -281,15 +281,16 @@ struct EnvLane {
       if (g == j + 1) cb = C.p[j] + mul(C.R[j], cl);
     cw = pos + mul(Rwb, cb);
   }
-  RL_FN Contact contact_from_patch(const Chain<CL>& C, const M3& Rwb, SV V0, const float (&qdv)[CL], int g, int s, float rad, V3 cb, V3 cw,
-                                   const TerrainPatch& tp) const {
+  // penetration depth and world normal of a fetched patch (straight-line: three of these interleave)
+  RL_FN void patch_phi(const TerrainPatch& tp, float rad, V3 cw, float& phi, V3& nw) const {
+    float hz;
+    terrain_eval(u, tp, hz, nw);
+    phi = rad > 0.f ? rad - (cw.z - hz) * nw.z : -1.f;
+  }
+  RL_FN Contact contact_from_phi(const Chain<CL>& C, const M3& Rwb, SV V0, const float (&qdv)[CL], int g, int s, float rad, V3 cb, float phi, V3 nw) const {
     Contact c;
     c.act = false;
-    float hz;
-    V3 nw;
-    terrain_eval(u, tp, hz, nw);
-    float phi = rad - (cw.z - hz) * nw.z;
-    if (rad > 0.f && phi > 0.f) {
+    if (phi > 0.f) {
       V3 nb = mulT(Rwb, nw);
       V3 x = cb - rad * nb;
       V3 uu = point_velocity<CL>(C, g, x, V0, qdv);
@@ -311,6 +312,13 @@ struct EnvLane {
     }
     return c;
   }
+  RL_FN Contact contact_from_patch(const Chain<CL>& C, const M3& Rwb, SV V0, const float (&qdv)[CL], int g, int s, float rad, V3 cb, V3 cw,
+                                   const TerrainPatch& tp) const {
+    float phi;
+    V3 nw;
+    patch_phi(tp, rad, cw, phi, nw);
+    return contact_from_phi(C, Rwb, V0, qdv, g, s, rad, cb, phi, nw);
+  }
 
   // ------------------------------------------------------------------ contact pass 1 for link group G
   // (compile-time G: the chain joints that move the point, and the link frame, are known statically)
@@ -327,10 +335,19 @@ struct EnvLane {
         sphere_center(C, Rwb, g, s, rad[s], cb[s], cw[s]);
         tp[s] = terrain_fetch(u, S.terrain, cw[s].x, cw[s].y);
       }
+      float phi[SPL];
+      V3 nw[SPL];
+      bool touching = false;
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        patch_phi(tp[s], rad[s], cw[s], phi[s], nw[s]);
+        touching = touching || phi[s] > 0.f;
+      }
+      if (ctx.any(touching))  // most link groups of most wavefronts touch nothing: one uniform branch skips them
 #pragma unroll
       for (int s = 0; s < SPL; ++s) {
         if (!((slot_valid >> (G * SPL + s)) & 1u)) continue;
-        Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad[s], cb[s], cw[s], tp[s]);
+        Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad[s], cb[s], phi[s], nw[s]);
         if (c.act) {
           active_mask |= 1u << (g * SPL + s);
           // J = [ [x]x^T | 1 | a_j x (x - p_j) ... ] (point velocity wrt [omega_b, v_b, qd]); add
@@ -630,9 +647,10 @@ struct EnvLane {
     }
     Q4 dq = quat_normalize(Q4{1.0f, 0.5f * dt * nu0[0], 0.5f * dt * nu0[1], 0.5f * dt * nu0[2]});
     quat = quat_normalize(quat_mul(quat, dq));
-    M3 Rn = quat_to_mat(quat);
-    vang = mul(Rn, V0n.a);
-    vlin = mul(Rn, V0n.l);
+    // nu+ lives in the fixed frame coincident with the body frame at t, referred to the old origin:
+    // rotate with the OLD orientation and shift the reference point (+ dt omega x v) - see oracle/physics.py
+    vang = mul(Rwb, V0n.a);
+    vlin = mul(Rwb, V0n.l + dt * cross(V0.a, V0.l));
     pos = pos + dt * vlin;
   }
 };

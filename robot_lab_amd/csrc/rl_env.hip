@@ -31,6 +31,7 @@ struct WaveCtx {
   __device__ float* lane_scratch() const { return lscratch + lane; }
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+  __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
   const Tables* T;
   float* stage[2];
   int dim[2];

@@ -42,6 +42,7 @@ struct HostCtx {
   float* lane_scratch() { return scratch; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
+  bool any(bool c) const { return c; }
   Team* team;
   const rl::Tables* T;
   int k_, e_, sense_ = 0;

@@ -107,3 +107,24 @@ def test_dc_motor_torque_speed_clip():
     tau, applied, pd = env.actuators(np.full((N, 12), -1.0), np.zeros((N, 12)))
     np.testing.assert_allclose(applied[:, 0], -want[::-1], atol=1e-5)
     assert pd is None
+
+
+def test_fast_spin_does_not_inflate_linear_momentum():
+    """Regression: integrating the base twist in the *rotating* body frame grew |v| by sqrt(1+(w dt)^2) per
+    substep (x1.75 over 1 s at 15 rad/s, x900 over 2 s at 30 rad/s: robots lying on their back were spun up by
+    the persistent reset wrench and then accelerated without bound).  With the fixed-frame update the linear
+    momentum of a free-floating, spinning robot stays put.  Joint limits / velocity limits stay on."""
+    d, _ = load_bundle(TASK)
+    d.sim.gravity = 0.0
+    N = 4
+    ph = Physics(d, None, N)
+    st = _state(ph, d, N, seed=3)
+    st["qd"][:] = 0.0
+    st["root_ang_vel"][:] = np.array([1.0, -0.5, 15.0])
+    st["root_lin_vel"][:] = np.array([3.0, -4.0, 0.5])
+    E0, P0, L0 = _momentum(ph, st)
+    for _ in range(200):
+        ph.substep(st, np.zeros((N, 12)))
+    E1, P1, L1 = _momentum(ph, st)
+    assert np.isfinite(P1).all()
+    assert np.abs(np.linalg.norm(P1, axis=1) / np.linalg.norm(P0, axis=1) - 1).max() < 0.10
