@@ -105,6 +105,14 @@ def main():
     if world > 1:
         dist.all_reduce(log_vec, op=dist.ReduceOp.SUM)
 
+    traffic = None
+    try:  # measured separately with rocprofv3 PMC passes (cannot be collected inside this process)
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tr = json.load(f).get(args.task)
+        if tr and N == 4096:
+            traffic = tr["fetch_bytes"] + tr["write_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
     value = world * N * args.steps / elapsed
     kind = "A1-Flat" if "Flat" in args.task else "A1-Rough"
     algo_bytes = ALGO_BYTES_PER_ENV_STEP[kind] * N
@@ -117,7 +125,7 @@ def main():
         "config": {"workload": f"{args.task}, {N} envs/GPU, random actions U(-1,1), seed 42+rank", "envs_per_gpu": N,
                    "parallelism": f"env-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                     "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "kernel_only_env_steps_per_s": N / (kernel_ms * 1e-3)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
