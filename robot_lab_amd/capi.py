@@ -30,7 +30,7 @@ class RlEnvError(RuntimeError):
 
 
 def load_library(path: str | None = None) -> C.CDLL:
-    path = path or HIP_LIB
+    path = path or os.environ.get("RL_ENV_LIB") or HIP_LIB  # RL_ENV_LIB: alternative HIP build (kernel ablations)
     if path in _libs:
         return _libs[path]
     if not os.path.isfile(path):

@@ -144,6 +144,10 @@ enum { LS_TIM = 0, LS_HIST = LS_TIM + NBS * 4, LS_CF = LS_HIST + NBS * 3, LS_FRI
 template <class Ctx, int CL>
 struct EnvLane {
   static constexpr int LSS = Ctx::LS_STRIDE;
+  static constexpr int SUB = Ctx::SUB;          // sub-lanes per leg (1: one lane per leg; 4: a DPP quad per leg)
+  static constexpr int LPE = NLANE * SUB;       // lanes per environment
+  static constexpr int EPT = 64 / LPE;          // environments per wavefront / tile
+  static constexpr uint32_t ROW = NLANE * EPT;  // entries of a lane-field row
   static constexpr int NV = 6 + CL;
   using UI = SymIdx<NV>;
   static constexpr int NSPH = (CL + 1) * SPL;
@@ -153,9 +157,9 @@ struct EnvLane {
   const Tables& T;
   const LaneTab& L;
   const Uni u;
-  int e, k, Np;
-  float* lt;  // this lane's column of the wave tile:  field f -> lt[f * 64]
-  float* et;  // this env's column of the env tile:    field f -> et[f * 16]
+  int e, k, sub, li, Np;  // env, leg, sub-lane of the leg, lane index inside the env (k * SUB + sub)
+  float* lt;  // this leg's column of the wave tile:   field f -> lt[f * ROW]
+  float* et;  // this env's column of the env tile:    field f -> et[f * EPT]
   // persistent state in registers
   V3 pos, vlin, vang;
   Q4 quat;
@@ -175,12 +179,17 @@ struct EnvLane {
         cf{c.lane_scratch() + LS_CF * LSS}, fric{c.lane_scratch() + LS_FRIC * LSS} {
     e = ctx.env();
     k = ctx.k();
+    sub = ctx.sub();
+    li = k * SUB + sub;
     Np = S.Npad;
-    lt = S.lane_state + (size_t)ctx.tile() * LANE_TILE + (uint32_t)ctx.lane_in_tile();
-    et = S.env_state + (size_t)ctx.tile() * ENV_TILE + (uint32_t)(ctx.lane_in_tile() >> 2);
+    lt = S.lane_state + (size_t)ctx.tile() * ((size_t)NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
+    et = S.env_state + (size_t)ctx.tile() * ((size_t)NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
   }
-  RL_FN float& LF(int f) const { return lt[(uint32_t)f * 64u]; }
-  RL_FN float& EF(int f) const { return et[(uint32_t)f * (uint32_t)ENVS_PER_WAVE]; }
+  RL_FN float& LF(int f) const { return lt[(uint32_t)f * ROW]; }
+  RL_FN float& EF(int f) const { return et[(uint32_t)f * (uint32_t)EPT]; }
+  // link group g (0 = base share, 1.. = chain links) is evaluated by sub-lane g % SUB of the leg
+  RL_FN bool owns_group(int g) const { return SUB == 1 || (g % SUB) == sub; }
+  RL_FN bool owns_slot(int s) const { return owns_group(L.slot_grp[s]); }
 
   // ------------------------------------------------------------------ load / store
   RL_FN void load() {
@@ -213,7 +222,7 @@ struct EnvLane {
   }
 
   RL_FN void store() {
-    if (k == 0) {
+    if (li == 0) {
       EF(EF_ROOT + 0) = pos.x; EF(EF_ROOT + 1) = pos.y; EF(EF_ROOT + 2) = pos.z;
       EF(EF_ROOT + 3) = quat.w; EF(EF_ROOT + 4) = quat.x; EF(EF_ROOT + 5) = quat.y; EF(EF_ROOT + 6) = quat.z;
       EF(EF_ROOT + 7) = vlin.x; EF(EF_ROOT + 8) = vlin.y; EF(EF_ROOT + 9) = vlin.z;
@@ -221,18 +230,22 @@ struct EnvLane {
       EF(EF_WRENCH + 0) = extF.x; EF(EF_WRENCH + 1) = extF.y; EF(EF_WRENCH + 2) = extF.z;
       EF(EF_WRENCH + 3) = extT.x; EF(EF_WRENCH + 4) = extT.y; EF(EF_WRENCH + 5) = extT.z;
     }
+    if (sub == 0) {
 #pragma unroll
-    for (int j = 0; j < CL; ++j) {
-      LF(LF_Q + j) = q[j];
-      LF(LF_QD + j) = qd[j];
-      LF(LF_KP + j) = kp[j];
-      LF(LF_KD + j) = kd[j];
-      LF(LF_ACT + j) = act[j];
+      for (int j = 0; j < CL; ++j) {
+        LF(LF_Q + j) = q[j];
+        LF(LF_QD + j) = qd[j];
+        LF(LF_KP + j) = kp[j];
+        LF(LF_KD + j) = kd[j];
+        LF(LF_ACT + j) = act[j];
+      }
     }
 #pragma unroll
     for (int s = 0; s < NBS; ++s)
+      if (owns_slot(s)) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) LF(LF_TIMERS + s * 4 + t) = tim[s][t];
+        for (int t = 0; t < 4; ++t) LF(LF_TIMERS + s * 4 + t) = tim[s][t];
+      }
   }
 
   // ------------------------------------------------------------------ actuators [UPSTREAM B4]
@@ -320,13 +333,15 @@ struct EnvLane {
     return contact_from_phi(C, Rwb, V0, qdv, g, s, rad, cb, phi, nw);
   }
 
-  // ------------------------------------------------------------------ contact pass 1 for link group G
-  // (compile-time G: the chain joints that move the point, and the link frame, are known statically)
-  template <int G>
-  RL_FN void contact_groups(const Chain<CL>& C, const M3& Rwb, SV V0, uint32_t slot_valid, float (&U)[UI::size], float (&rv)[NV], uint32_t& active_mask) {
+  // ------------------------------------------------------------------ contact pass 1
+  // Adds dt J^T D J / dt J^T n bias of every active sphere of the link groups this lane evaluates to
+  // (U, rv).  With SUB == 4 the four sub-lanes of a leg run this same code on different groups (g is a
+  // per-lane value) and the caller quad-sums the result; with SUB == 1 the lane loops over all groups.
+  RL_FN void contact_pass1(const Chain<CL>& C, const M3& Rwb, SV V0, uint32_t slot_valid, float (&U)[UI::size], float (&rv)[NV], uint32_t& active_mask) {
     const float dt = u.dt;
-    constexpr int g = G;
-    if ((slot_valid >> (G * SPL)) & ((1u << SPL) - 1u)) {
+#pragma unroll 1
+    for (int g = (SUB == 1 ? 0 : sub); g <= CL; g += SUB) {
+      if (!ctx.any(((slot_valid >> (g * SPL)) & ((1u << SPL) - 1u)) != 0u)) continue;
       float rad[SPL];
       V3 cb[SPL], cw[SPL];
       TerrainPatch tp[SPL];
@@ -343,10 +358,9 @@ struct EnvLane {
         patch_phi(tp[s], rad[s], cw[s], phi[s], nw[s]);
         touching = touching || phi[s] > 0.f;
       }
-      if (ctx.any(touching))  // most link groups of most wavefronts touch nothing: one uniform branch skips them
+      if (!ctx.any(touching)) continue;  // most link groups of most wavefronts touch nothing
 #pragma unroll
       for (int s = 0; s < SPL; ++s) {
-        if (!((slot_valid >> (G * SPL + s)) & 1u)) continue;
         Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad[s], cb[s], phi[s], nw[s]);
         if (c.act) {
           active_mask |= 1u << (g * SPL + s);
@@ -391,7 +405,6 @@ struct EnvLane {
         }
       }
     }
-    if constexpr (G < CL) contact_groups<G + 1>(C, Rwb, V0, slot_valid, U, rv, active_mask);
   }
 
   // ------------------------------------------------------------------ one physics substep
@@ -415,6 +428,19 @@ struct EnvLane {
     for (int i = 0; i < UI::size; ++i) U[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) rv[i] = 0.f;
+
+    // ---- contacts first (they only need the kinematics): every sub-lane accumulates the spheres of its
+    // link groups into the zero-initialised (U, rv), the leg's sub-lanes are quad-summed, and the CRBA
+    // terms below are added on top - so only one copy of the 54-entry system is ever live.
+    uint32_t active_mask = 0;
+    const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
+    contact_pass1(C, Rwb, V0, slot_valid, U, rv, active_mask);
+    if (SUB > 1 && ctx.any(active_mask != 0u)) {
+#pragma unroll
+      for (int i = 0; i < UI::size; ++i) U[i] = ctx.leg_sum(U[i]);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) rv[i] = ctx.leg_sum(rv[i]);
+    }
 
     // ---- CRBA + RNEA in base coordinates
     SV Sj[CL];
@@ -458,25 +484,25 @@ struct EnvLane {
       htop = htop + h0;
     }
     {  // 6x6 block from the spatial inertia: [[I, hx],[hx^T, m 1]]
-      U[UI::at(0, 0)] = Itop.I.xx; U[UI::at(1, 1)] = Itop.I.yy; U[UI::at(2, 2)] = Itop.I.zz;
-      U[UI::at(0, 1)] = Itop.I.xy; U[UI::at(0, 2)] = Itop.I.xz; U[UI::at(1, 2)] = Itop.I.yz;
-      U[UI::at(3, 3)] = Itop.m; U[UI::at(4, 4)] = Itop.m; U[UI::at(5, 5)] = Itop.m;
-      U[UI::at(0, 4)] = -Itop.h.z; U[UI::at(0, 5)] = Itop.h.y;
-      U[UI::at(1, 3)] = Itop.h.z;  U[UI::at(1, 5)] = -Itop.h.x;
-      U[UI::at(2, 3)] = -Itop.h.y; U[UI::at(2, 4)] = Itop.h.x;
-      rv[0] = htop.a.x - dt * ftop.a.x; rv[1] = htop.a.y - dt * ftop.a.y; rv[2] = htop.a.z - dt * ftop.a.z;
-      rv[3] = htop.l.x - dt * ftop.l.x; rv[4] = htop.l.y - dt * ftop.l.y; rv[5] = htop.l.z - dt * ftop.l.z;
+      U[UI::at(0, 0)] += Itop.I.xx; U[UI::at(1, 1)] += Itop.I.yy; U[UI::at(2, 2)] += Itop.I.zz;
+      U[UI::at(0, 1)] += Itop.I.xy; U[UI::at(0, 2)] += Itop.I.xz; U[UI::at(1, 2)] += Itop.I.yz;
+      U[UI::at(3, 3)] += Itop.m; U[UI::at(4, 4)] += Itop.m; U[UI::at(5, 5)] += Itop.m;
+      U[UI::at(0, 4)] += -Itop.h.z; U[UI::at(0, 5)] += Itop.h.y;
+      U[UI::at(1, 3)] += Itop.h.z;  U[UI::at(1, 5)] += -Itop.h.x;
+      U[UI::at(2, 3)] += -Itop.h.y; U[UI::at(2, 4)] += Itop.h.x;
+      rv[0] += htop.a.x - dt * ftop.a.x; rv[1] += htop.a.y - dt * ftop.a.y; rv[2] += htop.a.z - dt * ftop.a.z;
+      rv[3] += htop.l.x - dt * ftop.l.x; rv[4] += htop.l.y - dt * ftop.l.y; rv[5] += htop.l.z - dt * ftop.l.z;
     }
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
       SV B = apply(Ic[j], Sj[j]);
-      U[UI::at(0, 6 + j)] = B.a.x; U[UI::at(1, 6 + j)] = B.a.y; U[UI::at(2, 6 + j)] = B.a.z;
-      U[UI::at(3, 6 + j)] = B.l.x; U[UI::at(4, 6 + j)] = B.l.y; U[UI::at(5, 6 + j)] = B.l.z;
+      U[UI::at(0, 6 + j)] += B.a.x; U[UI::at(1, 6 + j)] += B.a.y; U[UI::at(2, 6 + j)] += B.a.z;
+      U[UI::at(3, 6 + j)] += B.l.x; U[UI::at(4, 6 + j)] += B.l.y; U[UI::at(5, 6 + j)] += B.l.z;
 #pragma unroll
-      for (int i = 0; i <= j; ++i) U[UI::at(6 + i, 6 + j)] = dot(Sj[i], B);
+      for (int i = 0; i <= j; ++i) U[UI::at(6 + i, 6 + j)] += dot(Sj[i], B);
       float arm = L.armature[j];
       U[UI::at(6 + j, 6 + j)] += arm;
-      rv[6 + j] = dot(Sj[j], Hs[j]) + arm * qd[j] + dt * (tau_e[j] - dot(Sj[j], Fs[j])) + pd_rhs[j];
+      rv[6 + j] += dot(Sj[j], Hs[j]) + arm * qd[j] + dt * (tau_e[j] - dot(Sj[j], Fs[j])) + pd_rhs[j];
       // joint limits: implicit spring-damper (hard limits in the reference, a1.urdf:369,411,439)
       float below = L.lower[j] - q[j], above = q[j] - L.upper[j];
       float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
@@ -490,10 +516,6 @@ struct EnvLane {
     // kept (12 slots x 10 values would spill) - pass 2 after the solve re-evaluates the active spheres.
     // One iteration per link group (base share, then each chain link): the terrain corner loads of the
     // group's SPL sphere slots are issued together, then consumed.
-    uint32_t active_mask = 0;
-    const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
-    contact_groups<0>(C, Rwb, V0, slot_valid, U, rv, active_mask);
-
     // ---- Schur complement of the chain block, 4-lane reduction, 6x6 solve, back substitution
     float Lc[CL][CL];
 #pragma unroll
@@ -619,7 +641,7 @@ struct EnvLane {
     // base-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes)
     for (int bi = 0; bi < T.n_base_bodies; ++bi) {
       bool mine = L.base_body_local == bi;
-      V3 f{ctx.gsum(mine ? fslot[0].x : 0.f), ctx.gsum(mine ? fslot[0].y : 0.f), ctx.gsum(mine ? fslot[0].z : 0.f)};
+      V3 f{ctx.esum(mine ? fslot[0].x : 0.f), ctx.esum(mine ? fslot[0].y : 0.f), ctx.esum(mine ? fslot[0].z : 0.f)};
       if (mine) fslot[0] = f;
     }
     // [UPSTREAM B5] ContactSensor: history roll + air/contact timers, every physics step

@@ -102,8 +102,8 @@ enum { CMD_VX = 0, CMD_VY, CMD_WZ, CMD_HEADING, CMD_TIME_LEFT, CMD_METRIC_XY, CM
 constexpr int INERTIA_NF = 10;
 
 // ---- HBM state layout: wave-tiled structure-of-arrays -------------------------------------------
-// A tile is the state of one wavefront (16 envs x 4 lanes).  Inside a tile every field is one
-// contiguous row: 64 floats (256 B) for lane fields, 16 floats for env fields.  A wavefront therefore
+// A tile is the state of one wavefront (16 envs, or 4 envs in the 16-lanes-per-env mapping).  Inside a
+// tile every field is one contiguous row: one float per leg for lane fields, one per env for env fields.  A wavefront therefore
 // reads/writes whole coalesced rows, and - the reason for tiling rather than [field][N] planes - every
 // access is `tile base (SGPR) + lane offset (ONE VGPR) + compile-time row offset`; with [field][N]
 // planes hipcc kept ~60 separate 64-bit address pairs live across the kernel (120 VGPRs, profiles/r01).
@@ -123,16 +123,17 @@ enum {  // env fields (rows of 16)
   EF_ORIGIN = EF_CMD + CMD_NFIELD,
   NF_ENV = EF_ORIGIN + 3
 };
-constexpr uint32_t LANE_TILE = (uint32_t)NF_LANE * 64u;          // floats per tile
-constexpr uint32_t ENV_TILE = (uint32_t)NF_ENV * ENVS_PER_WAVE;  // floats per tile
-RL_FN size_t lane_index(int e, int k, int f) { return (size_t)(e / ENVS_PER_WAVE) * LANE_TILE + (size_t)f * 64 + (size_t)(e % ENVS_PER_WAVE) * NLANE + k; }
-RL_FN size_t env_index(int e, int f) { return (size_t)(e / ENVS_PER_WAVE) * ENV_TILE + (size_t)f * ENVS_PER_WAVE + (size_t)(e % ENVS_PER_WAVE); }
+// `ept` = environments per tile (= per wavefront): 16 when one lane simulates a leg, 4 when a leg is
+// spread over 4 sub-lanes.  A lane-field row then has 4*ept entries (one per leg), an env-field row ept.
+RL_FN size_t lane_index(int e, int k, int f, int ept) { return ((size_t)(e / ept) * NF_LANE + (size_t)f) * (size_t)(NLANE * ept) + (size_t)(e % ept) * NLANE + k; }
+RL_FN size_t env_index(int e, int f, int ept) { return ((size_t)(e / ept) * NF_ENV + (size_t)f) * (size_t)ept + (size_t)(e % ept); }
 
 struct KState {
   int32_t N;      // environments the caller sees
   int32_t Npad;   // simulated (multiple of ENVS_PER_WAVE)
-  float* lane_state;  // [Npad/16][NF_LANE][64]
-  float* env_state;   // [Npad/16][NF_ENV][16]
+  int32_t ept;    // environments per tile / wavefront (16 or 4)
+  float* lane_state;  // [Npad/ept][NF_LANE][4*ept]
+  float* env_state;   // [Npad/ept][NF_ENV][ept]
   int32_t* flags;    // [Npad] bit0 is_heading_env, bit1 is_standing_env
   int32_t *level, *ttype;  // [Npad]
   int64_t* ep_len;   // [Npad]   (caller-visible int64 [N])

@@ -9,6 +9,8 @@
 // staged in LDS and written back as one linear, 16-byte-vectorised burst per wavefront.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #define RL_FN __host__ __device__ __forceinline__
 #include "env_aos.h"
 #include "env_terms.h"
@@ -18,75 +20,107 @@ namespace {
 
 using namespace rl;
 
-__device__ inline float dpp_xor1(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm:[1,0,3,2]
+template <int CTRL>
+__device__ inline float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
-__device__ inline float dpp_xor2(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm:[2,3,0,1]
-}
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15 - i of a 16-lane row
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7 - i of each half row
 
+// Wavefront context.  SUB_ = 1: a lane per leg, 4 lanes per env (a DPP quad), 16 envs per wavefront.
+// SUB_ = 4: a DPP quad per leg, 16 lanes per env (a DPP row), 4 envs per wavefront -> 4096 envs fill
+// 1024 wavefronts = one per SIMD of the chip, and each lane's instruction stream is ~half as long.
+template <int SUB_>
 struct WaveCtx {
   static constexpr int LS_STRIDE = 64;
+  static constexpr int SUB = SUB_;
+  static constexpr int LPE = NLANE * SUB_;
+  static constexpr int EPT = 64 / LPE;
   float* lscratch;
+  const Tables* T;
+  float* stage[2];
+  float* rstage;
+  int dim[2];
+  int lane;
   __device__ float* lane_scratch() const { return lscratch + lane; }
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
-  const Tables* T;
-  float* stage[2];
-  int dim[2];
-  int lane, e0;
   __device__ const Tables& tables() const { return *T; }
-  __device__ int k() const { return lane & 3; }
-  __device__ int env() const { return e0 + (lane >> 2); }
+  __device__ int env_in_tile() const { return lane / LPE; }
+  __device__ int k() const { return SUB == 1 ? (lane & 3) : ((lane >> 2) & 3); }
+  __device__ int sub() const { return SUB == 1 ? 0 : (lane & 3); }
   __device__ int tile() const { return blockIdx.x; }
-  __device__ int lane_in_tile() const { return lane; }
+  __device__ int env() const { return blockIdx.x * EPT + env_in_tile(); }
+  // sum over the 4 legs (inputs replicated over a leg's sub-lanes when SUB == 4: the mirrors then pair
+  // lanes of different legs, and a + b == b + a bitwise, so all 16 lanes end with identical bits)
   __device__ float gsum(float v) const {
-    v += dpp_xor1(v);
-    v += dpp_xor2(v);
+    if (SUB == 1) {
+      v += dpp<DPP_QUAD_XOR1>(v);
+      v += dpp<DPP_QUAD_XOR2>(v);
+    } else {
+      v += dpp<DPP_ROW_HALF_MIRROR>(v);
+      v += dpp<DPP_ROW_MIRROR>(v);
+    }
     return v;
   }
-  __device__ float gshfl(float v, int src) const { return __shfl(v, (lane & ~3) | src); }
+  __device__ float leg_sum(float v) const {
+    if (SUB == 1) return v;
+    v += dpp<DPP_QUAD_XOR1>(v);
+    v += dpp<DPP_QUAD_XOR2>(v);
+    return v;
+  }
+  __device__ float esum(float v) const { return gsum(leg_sum(v)); }
+  __device__ float gshfl(float v, int leg) const { return __shfl(v, SUB == 1 ? ((lane & ~3) | leg) : ((lane & ~15) | (leg << 2) | (lane & 3))); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
-  __device__ float* obs_stage(int g) const { return stage[g] + (lane >> 2) * dim[g]; }
-  float* rstage;
-  __device__ float* rew_stage() const { return rstage + (lane >> 2) * MAX_T; }
+  __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }
+  __device__ float* rew_stage() const { return rstage + env_in_tile() * MAX_T; }
   __device__ void group_sync() const { __syncthreads(); }
   __device__ void flush_obs(float* out, int d, int g) const {
     __syncthreads();  // single-wave workgroup: orders the LDS writes above before the reads below
-    const int n4 = (ENVS_PER_WAVE * d) >> 2;  // 16 rows are contiguous in `out` and 16-byte aligned
-    const float4* src = reinterpret_cast<const float4*>(stage[g]);
-    float4* dst = reinterpret_cast<float4*>(out + (size_t)e0 * d);
-    for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+    const int n4 = (EPT * d) >> 2;  // the tile's rows are contiguous in `out`; 16-byte aligned when EPT * d % 4 == 0
+    if (((EPT * d) & 3) == 0) {
+      const float4* src = reinterpret_cast<const float4*>(stage[g]);
+      float4* dst = reinterpret_cast<float4*>(out + (size_t)blockIdx.x * EPT * d);
+      for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+    } else {
+      float* dst = out + (size_t)blockIdx.x * EPT * d;
+      for (int i = lane; i < EPT * d; i += 64) dst[i] = stage[g][i];
+    }
     __syncthreads();
   }
 };
 
 extern __shared__ float4 smem4[];
 
-template <int CL, int RESET>
+template <int CL, int RESET, int SUB>
 __global__ __launch_bounds__(64) void env_kernel(KState S, const Tables* __restrict__ Tg) {
+  using Ctx = WaveCtx<SUB>;
   float* smem = reinterpret_cast<float*>(smem4);
   Tables* Tl = reinterpret_cast<Tables*>(smem);
   const int lane = threadIdx.x;
-  {  // stage the model / term tables into LDS
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(Tg);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(Tl);
-    for (int i = lane; i < (int)(sizeof(Tables) / 4); i += 64) dst[i] = src[i];
+  {  // stage the model / term tables into LDS (16-byte vectors)
+    const float4* src = reinterpret_cast<const float4*>(Tg);
+    float4* dst = reinterpret_cast<float4*>(Tl);
+    for (int i = lane; i < (int)(sizeof(Tables) / 16); i += 64) dst[i] = src[i];
+    const uint32_t* s1 = reinterpret_cast<const uint32_t*>(Tg);
+    uint32_t* d1 = reinterpret_cast<uint32_t*>(Tl);
+    for (int i = (int)(sizeof(Tables) / 16) * 4 + lane; i < (int)(sizeof(Tables) / 4); i += 64) d1[i] = s1[i];
   }
   __syncthreads();
   constexpr int TAB_F = (sizeof(Tables) + 15) / 16 * 4;
-  WaveCtx ctx;
+  Ctx ctx;
   ctx.T = Tl;
   ctx.dim[0] = Tl->policy_dim;
   ctx.dim[1] = Tl->critic_dim;
   ctx.stage[0] = smem + TAB_F;
-  ctx.stage[1] = ctx.stage[0] + ((ENVS_PER_WAVE * ctx.dim[0] + 3) & ~3);
-  ctx.lscratch = ctx.stage[1] + ((ENVS_PER_WAVE * ctx.dim[1] + 3) & ~3);
+  ctx.stage[1] = ctx.stage[0] + ((Ctx::EPT * ctx.dim[0] + 3) & ~3);
+  ctx.lscratch = ctx.stage[1] + ((Ctx::EPT * ctx.dim[1] + 3) & ~3);
   ctx.rstage = ctx.lscratch + LS_WORDS * 64;
   ctx.lane = lane;
-  ctx.e0 = blockIdx.x * ENVS_PER_WAVE;
-  EnvProgram<WaveCtx, CL> prog(ctx, S);
+  EnvProgram<Ctx, CL> prog(ctx, S);
   if (RESET)
     prog.reset_entry();
   else
@@ -125,38 +159,40 @@ struct Backend {
     check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)stream));
     check(hipStreamSynchronize((hipStream_t)stream));  // the host staging vector dies on return
   }
-  template <int CL>
+  int sub = 4;  // lanes per leg; RL_ENV_SUB=1 selects the one-lane-per-leg mapping
+  int envs_per_wave() {
+    if (const char* v = std::getenv("RL_ENV_SUB")) sub = atoi(v) == 1 ? 1 : 4;
+    return 16 / sub;
+  }
+  template <int CL, int SUB>
   int launch_cl(const KState& S, const Tables* T, int reset, size_t lds, hipStream_t st) {
-    dim3 grid(S.Npad / ENVS_PER_WAVE), block(64);
+    dim3 grid(S.Npad / (16 / SUB)), block(64);
     if (reset)
-      hipLaunchKernelGGL((env_kernel<CL, 1>), grid, block, lds, st, S, T);
+      hipLaunchKernelGGL((env_kernel<CL, 1, SUB>), grid, block, lds, st, S, T);
     else
-      hipLaunchKernelGGL((env_kernel<CL, 0>), grid, block, lds, st, S, T);
+      hipLaunchKernelGGL((env_kernel<CL, 0, SUB>), grid, block, lds, st, S, T);
     return check(hipGetLastError());
   }
   size_t lds_bytes = 0;
-  int configure(const Tables& T) {  // dynamic LDS: tables + the two observation staging tiles
+  int configure(const Tables& T) {  // dynamic LDS: tables + observation staging tiles + lane scratchpad + reward stage
+    const size_t ept = 16 / sub;
     size_t tab = (sizeof(Tables) + 15) / 16 * 16;
-    size_t s0 = ((size_t)ENVS_PER_WAVE * T.policy_dim + 3) / 4 * 16;
-    size_t s1 = ((size_t)ENVS_PER_WAVE * T.critic_dim + 3) / 4 * 16;
-    lds_bytes = tab + s0 + s1 + (size_t)LS_WORDS * 64 * 4 + (size_t)ENVS_PER_WAVE * MAX_T * 4;
-    if (lds_bytes > 160 * 1024) {
-      err = "observation rows do not fit the 160 KiB LDS";
-      return -1;
-    }
+    size_t s0 = (ept * T.policy_dim + 3) / 4 * 16;
+    size_t s1 = (ept * T.critic_dim + 3) / 4 * 16;
+    lds_bytes = tab + s0 + s1 + (size_t)LS_WORDS * 64 * 4 + ept * MAX_T * 4;
     if (lds_bytes > 64 * 1024) {
-      if (check(hipFuncSetAttribute((const void*)env_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return -1;
-      if (check(hipFuncSetAttribute((const void*)env_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return -1;
-      if (check(hipFuncSetAttribute((const void*)env_kernel<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return -1;
-      if (check(hipFuncSetAttribute((const void*)env_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes))) return -1;
+      err = "observation rows do not fit the default 64 KiB dynamic LDS";
+      return -1;
     }
     return 0;
   }
   int launch(const KState& S, const Tables* T, int CL, int reset, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    switch (CL) {
-      case 3: return launch_cl<3>(S, T, reset, lds_bytes, st);
-      case 4: return launch_cl<4>(S, T, reset, lds_bytes, st);
+    switch (CL * 10 + sub) {
+      case 31: return launch_cl<3, 1>(S, T, reset, lds_bytes, st);
+      case 41: return launch_cl<4, 1>(S, T, reset, lds_bytes, st);
+      case 34: return launch_cl<3, 4>(S, T, reset, lds_bytes, st);
+      case 44: return launch_cl<4, 4>(S, T, reset, lds_bytes, st);
       default: err = "unsupported chain length"; return -1;
     }
   }

@@ -193,7 +193,7 @@ struct EnvImpl {
   Tables tables;
   Tables* tables_dev = nullptr;
   KState S;
-  int N = 0, Npad = 0, D = 0, B = 0, CL = 0;
+  int N = 0, Npad = 0, D = 0, B = 0, CL = 0, ept = ENVS_PER_WAVE;
   uint64_t seed = 0;
   uint32_t step_counter = 0;
   std::vector<int> body_lane, body_slot, link_lane, link_pos;
@@ -220,7 +220,8 @@ struct EnvImpl {
     desc = *d;
     seed = seed_;
     N = num_envs;
-    Npad = (N + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE * ENVS_PER_WAVE;
+    ept = be.envs_per_wave();
+    Npad = (N + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE * ENVS_PER_WAVE;  // multiple of 16 suits both lane mappings
     D = d->model.num_dof;
     B = d->model.num_bodies;
     if (N <= 0) return fail("num_envs must be positive");
@@ -228,11 +229,11 @@ struct EnvImpl {
     CL = tables.CL;
     if (be.init(device)) return fail("device init failed: " + be.error());
     if (be.configure(tables)) return fail("kernel configuration failed: " + be.error());
-    const size_t Np = Npad, ntile = Npad / ENVS_PER_WAVE;
+    const size_t Np = Npad, ntile = Npad / ept;
     memset(&S, 0, sizeof(S));
-    S.N = N; S.Npad = Npad; S.seed = seed;
-    S.lane_state = alloc<float>(ntile * LANE_TILE);
-    S.env_state = alloc<float>(ntile * ENV_TILE);
+    S.N = N; S.Npad = Npad; S.seed = seed; S.ept = ept;
+    S.lane_state = alloc<float>(ntile * (size_t)NF_LANE * NLANE * ept);
+    S.env_state = alloc<float>(ntile * (size_t)NF_ENV * ept);
     S.flags = alloc<int32_t>(Np); S.level = alloc<int32_t>(Np); S.ttype = alloc<int32_t>(Np);
     S.ep_len = alloc<int64_t>(Np); S.ep_sums = alloc<float>(MAX_T * Np);
     S.obs_policy = alloc<float>(Np * (size_t)std::max(1, tables.policy_dim));
@@ -268,8 +269,8 @@ struct EnvImpl {
   void startup(const float* terrain_origins, const float* env_origins) {
     const rl_model_desc& m = desc.model;
     const rl_task_desc& t = desc.task;
-    const size_t Np = Npad, ntile = Npad / ENVS_PER_WAVE;
-    std::vector<float> lane(ntile * LANE_TILE, 0.f), env(ntile * ENV_TILE, 0.f);
+    const size_t Np = Npad, ntile = Npad / ept;
+    std::vector<float> lane(ntile * (size_t)NF_LANE * NLANE * ept, 0.f), env(ntile * (size_t)NF_ENV * ept, 0.f);
     std::vector<int32_t> level(Np, 0), ttype(Np, 0);
     std::vector<float> bs(64, 1.f), bd(64, 1.f), br(64, 0.f);
     int nb = t.friction_buckets > 0 ? (t.friction_buckets > 64 ? 64 : t.friction_buckets) : 1;
@@ -295,7 +296,7 @@ struct EnvImpl {
         if (t.ev_com && b == t.base_body)
           for (int a = 0; a < 3; ++a) c[a] += uniform_range(seed, e, 0, STREAM_STARTUP, IDX_COM + 3 * b + a, t.com_range[a][0], t.com_range[a][1]);
         if (b == t.base_body)
-          for (int a = 0; a < 3; ++a) env[env_index(e, EF_BASE_COM + a)] = (float)c[a];
+          for (int a = 0; a < 3; ++a) env[env_index(e, EF_BASE_COM + a, ept)] = (float)c[a];
         double sc = m.body_mass[b] > 0.f ? mass / m.body_mass[b] : 0.0;
         const float* I6 = m.body_inertia[b];
         double Ic[9] = {sc * I6[0], sc * I6[3], sc * I6[4], sc * I6[3], sc * I6[1], sc * I6[5], sc * I6[4], sc * I6[5], sc * I6[2]};
@@ -317,7 +318,7 @@ struct EnvImpl {
           // base-link bodies may have spheres on other lanes too: replicate their material into slot 0 there
           bool here = kk == k || (s == 0 && tables.lane[kk].base_body_local == tables.lane[k].base_body_local && !tables.lane[kk].owns_base_body);
           if (!here) continue;
-          for (int a = 0; a < 3; ++a) lane[lane_index(e, kk, LF_FRICTION + s * 3 + a)] = mu[a];
+          for (int a = 0; a < 3; ++a) lane[lane_index(e, kk, LF_FRICTION + s * 3 + a, ept)] = mu[a];
         }
       }
       // composite per link -> (mass, com, inertia about com)
@@ -330,31 +331,31 @@ struct EnvImpl {
           for (int bb = 0; bb < 3; ++bb) Ic[a * 3 + bb] = lI[l * 9 + a * 3 + bb] - mass * ((a == bb ? cc : 0.0) - c[a] * c[bb]);
         float rec[10] = {(float)mass, (float)c[0], (float)c[1], (float)c[2], (float)Ic[0], (float)Ic[4], (float)Ic[8], (float)Ic[1], (float)Ic[2], (float)Ic[5]};
         if (l == 0) {
-          for (int f = 0; f < 10; ++f) env[env_index(e, EF_BASE_INERTIA + f)] = rec[f];
+          for (int f = 0; f < 10; ++f) env[env_index(e, EF_BASE_INERTIA + f, ept)] = rec[f];
         } else {
           int k = link_lane[l], j = link_pos[l];
-          for (int f = 0; f < 10; ++f) lane[lane_index(e, k, LF_INERTIA + j * INERTIA_NF + f)] = rec[f];
+          for (int f = 0; f < 10; ++f) lane[lane_index(e, k, LF_INERTIA + j * INERTIA_NF + f, ept)] = rec[f];
         }
       }
       for (int k = 0; k < NLANE; ++k)
         for (int j = 0; j < CL; ++j) {
-          lane[lane_index(e, k, LF_KP + j)] = tables.lane[k].kp0[j];
-          lane[lane_index(e, k, LF_KD + j)] = tables.lane[k].kd0[j];
-          lane[lane_index(e, k, LF_Q + j)] = tables.lane[k].q0[j];
+          lane[lane_index(e, k, LF_KP + j, ept)] = tables.lane[k].kp0[j];
+          lane[lane_index(e, k, LF_KD + j, ept)] = tables.lane[k].kd0[j];
+          lane[lane_index(e, k, LF_Q + j, ept)] = tables.lane[k].q0[j];
         }
       // terrain level / type / env origin
       if (desc.terrain.is_plane) {
         int ee = e < N ? e : N - 1;
-        for (int a = 0; a < 3; ++a) env[env_index(e, EF_ORIGIN + a)] = env_origins[ee * 3 + a];
+        for (int a = 0; a < 3; ++a) env[env_index(e, EF_ORIGIN + a, ept)] = env_origins[ee * 3 + a];
       } else {
         int ee = e < N ? e : N - 1;  // padding envs mirror the last real env's cell
         ttype[e] = (int)floor((double)ee / ((double)N / desc.terrain.num_cols));
         int lv = (int)floorf(uniform01(seed, ee, 0, STREAM_STARTUP, IDX_INIT_LEVEL) * (float)(desc.terrain.max_init_level + 1));
         level[e] = lv > desc.terrain.max_init_level ? desc.terrain.max_init_level : lv;
-        for (int a = 0; a < 3; ++a) env[env_index(e, EF_ORIGIN + a)] = terrain_origins[((size_t)level[e] * desc.terrain.num_cols + ttype[e]) * 3 + a];
+        for (int a = 0; a < 3; ++a) env[env_index(e, EF_ORIGIN + a, ept)] = terrain_origins[((size_t)level[e] * desc.terrain.num_cols + ttype[e]) * 3 + a];
       }
-      env[env_index(e, EF_ROOT + 3)] = 1.f;  // identity quaternion until the first reset
-      for (int a = 0; a < 3; ++a) env[env_index(e, EF_ROOT + a)] = env[env_index(e, EF_ORIGIN + a)] + m.default_root_pos[a];
+      env[env_index(e, EF_ROOT + 3, ept)] = 1.f;  // identity quaternion until the first reset
+      for (int a = 0; a < 3; ++a) env[env_index(e, EF_ROOT + a, ept)] = env[env_index(e, EF_ORIGIN + a, ept)] + m.default_root_pos[a];
     }
     be.h2d(S.lane_state, lane.data(), lane.size() * 4);
     be.h2d(S.env_state, env.data(), env.size() * 4);

@@ -5,6 +5,8 @@
 // shared slot + spin barrier.  It lets the `-m "not gpu"` tests check the lane program against the fp64
 // oracle without a GPU.  The product path (robot_lab_amd.env) never loads this library: it requires
 // librl_env_hip.so and fails loudly without it.
+#include <pthread.h>
+
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -18,50 +20,72 @@
 
 namespace {
 
+template <int LPE>
 struct Team {
-  std::atomic<int> count{0};
-  std::atomic<int> sense{0};
-  float slot[rl::NLANE];
+  pthread_barrier_t bar;  // blocking barrier: 16 lane threads may outnumber the host cores
+  float slot[LPE];
   float rstage[rl::MAX_T];
   std::vector<float> stage[2];
-  void barrier(int& local_sense) {
-    local_sense ^= 1;
-    if (count.fetch_add(1, std::memory_order_acq_rel) == rl::NLANE - 1) {
-      count.store(0, std::memory_order_relaxed);
-      sense.store(local_sense, std::memory_order_release);
-    } else {
-      while (sense.load(std::memory_order_acquire) != local_sense) {
-      }
-    }
-  }
+  Team() { pthread_barrier_init(&bar, nullptr, LPE); }
+  ~Team() { pthread_barrier_destroy(&bar); }
+  void barrier(int&) { pthread_barrier_wait(&bar); }
 };
 
+// SUB_ sub-lanes per leg: 4 * SUB_ host threads play the lanes of one environment
+template <int SUB_>
 struct HostCtx {
   static constexpr int LS_STRIDE = 1;
+  static constexpr int SUB = SUB_;
+  static constexpr int LPE = rl::NLANE * SUB_;
+  static constexpr int EPT = 64 / LPE;
   float scratch[rl::LS_WORDS];
   float* lane_scratch() { return scratch; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
-  bool any(bool c) const { return c; }
-  Team* team;
+  Team<LPE>* team;
   const rl::Tables* T;
-  int k_, e_, sense_ = 0;
+  int k_, sub_, e_, sense_ = 0;
   const rl::Tables& tables() const { return *T; }
   int k() const { return k_; }
+  int sub() const { return sub_; }
   int env() const { return e_; }
-  int tile() const { return e_ / rl::ENVS_PER_WAVE; }
-  int lane_in_tile() const { return (e_ % rl::ENVS_PER_WAVE) * rl::NLANE + k_; }
+  int tile() const { return e_ / EPT; }
+  int env_in_tile() const { return e_ % EPT; }
+  int li() const { return k_ * SUB + sub_; }
+  // sum over the 4 legs of the values held at the same sub-lane index (replicated inputs -> leg sum)
   float gsum(float v) {
-    team->slot[k_] = v;
+    team->slot[li()] = v;
     team->barrier(sense_);
-    float s = (team->slot[0] + team->slot[1]) + (team->slot[2] + team->slot[3]);
+    const float* p = team->slot;
+    float a = p[0 * SUB + sub_] + p[1 * SUB + sub_], b = p[2 * SUB + sub_] + p[3 * SUB + sub_];
+    float s = k_ < 2 ? a + b : b + a;
     team->barrier(sense_);
     return s;
   }
-  float gshfl(float v, int src) {
-    team->slot[k_] = v;
+  // sum over the SUB sub-lanes of this leg (butterfly order of the DPP quad: (x0+x1)+(x2+x3))
+  float leg_sum(float v) {
+    if (SUB == 1) return v;
+    team->slot[li()] = v;
     team->barrier(sense_);
-    float r = team->slot[src];
+    const float* p = team->slot + k_ * SUB;
+    float s = (p[0] + p[1]) + (p[2 % SUB] + p[3 % SUB]);
+    team->barrier(sense_);
+    return s;
+  }
+  float esum(float v) { return gsum(leg_sum(v)); }
+  // wave-level vote on the GPU; here an env-level OR (it may guard collectives, so it must be uniform)
+  bool any(bool c) {
+    team->slot[li()] = c ? 1.f : 0.f;
+    team->barrier(sense_);
+    bool r = false;
+    for (int i = 0; i < LPE; ++i) r = r || team->slot[i] != 0.f;
+    team->barrier(sense_);
+    return r;
+  }
+  float gshfl(float v, int leg) {
+    team->slot[li()] = v;
+    team->barrier(sense_);
+    float r = team->slot[leg * SUB + sub_];
     team->barrier(sense_);
     return r;
   }
@@ -77,24 +101,25 @@ struct HostCtx {
   void group_sync() { team->barrier(sense_); }
   void flush_obs(float* out, int dim, int g) {
     team->barrier(sense_);
-    for (int i = k_; i < dim; i += rl::NLANE) out[(size_t)e_ * dim + i] = team->stage[g][i];
+    for (int i = li(); i < dim; i += LPE) out[(size_t)e_ * dim + i] = team->stage[g][i];
     team->barrier(sense_);
   }
 };
 
-template <int CL>
+template <int CL, int SUB>
 void run(const rl::KState& S, const rl::Tables* T, int reset) {
-  Team team;
+  using Ctx = HostCtx<SUB>;
+  Team<Ctx::LPE> team;
   team.stage[0].assign(std::max(1, T->policy_dim), 0.f);
   team.stage[1].assign(std::max(1, T->critic_dim), 0.f);
   std::vector<std::thread> th;
-  for (int k = 0; k < rl::NLANE; ++k)
-    th.emplace_back([&, k]() {
-      HostCtx ctx;
-      ctx.team = &team; ctx.T = T; ctx.k_ = k; ctx.e_ = 0;
+  for (int l = 0; l < Ctx::LPE; ++l)
+    th.emplace_back([&, l]() {
+      Ctx ctx;
+      ctx.team = &team; ctx.T = T; ctx.k_ = l / SUB; ctx.sub_ = l % SUB; ctx.e_ = 0;
       for (int e = 0; e < S.Npad; ++e) {
         ctx.e_ = e;
-        rl::EnvProgram<HostCtx, CL> prog(ctx, S);
+        rl::EnvProgram<Ctx, CL> prog(ctx, S);
         if (reset)
           prog.reset_entry();
         else
@@ -107,7 +132,15 @@ void run(const rl::KState& S, const rl::Tables* T, int reset) {
 struct Backend {
   std::string err;
   const std::string& error() const { return err; }
-  int init(int) { return 0; }
+  int sub = 1;  // RL_EMU_SUB=4 selects the 16-lanes-per-env mapping (16 host threads per env: slow)
+  int init(int) {
+    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : 1;
+    return 0;
+  }
+  int envs_per_wave() {
+    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : 1;
+    return 16 / sub;
+  }
   int configure(const rl::Tables&) { return 0; }
   void* alloc(size_t n) { return std::malloc(n ? n : 1); }
   void free(void* p) { std::free(p); }
@@ -115,9 +148,11 @@ struct Backend {
   void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
   void h2d_stream(void* d, const void* s, size_t n, void*) { std::memcpy(d, s, n); }
   int launch(const rl::KState& S, const rl::Tables* T, int CL, int reset, void*) {
-    switch (CL) {
-      case 3: run<3>(S, T, reset); return 0;
-      case 4: run<4>(S, T, reset); return 0;
+    switch (CL * 10 + sub) {
+      case 31: run<3, 1>(S, T, reset); return 0;
+      case 41: run<4, 1>(S, T, reset); return 0;
+      case 34: run<3, 4>(S, T, reset); return 0;
+      case 44: run<4, 4>(S, T, reset); return 0;
       default: err = "unsupported chain length"; return -1;
     }
   }

@@ -72,3 +72,24 @@ def test_resets_and_logs(emu_lib):
     assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
     assert np.array_equal(host_view(nat, "TERRAIN_LEVEL"), ora.terrain_levels)
     nat.close()
+
+
+def test_sixteen_lane_mapping_matches_oracle(emu_lib, monkeypatch):
+    """The 16-lanes-per-env mapping (a DPP quad per leg; the default on the GPU) run by 16 host threads."""
+    monkeypatch.setenv("RL_EMU_SUB", "4")
+    task, N = TASKS[1], 16
+    desc, ora, nat = make_pair(task, N, 21, emu_lib)
+    o = ora.reset()
+    nat.reset()
+    rng = np.random.default_rng(5)
+    for s in range(2):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        o = ora.step(a)
+        nat.step(a.ctypes.data)
+    nat.export_state()
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), 1e-3, 1e-4)
+    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], 2e-3, 2e-3)
+    assert_close("terms", host_view(nat, "REWARD_TERMS")[:, :N], ora.reward_terms, 2e-3, 2e-5)
+    assert_close("timers", host_view(nat, "CONTACT_TIMERS"), ora.timers, 1e-5, 1e-6)
+    assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
+    nat.close()

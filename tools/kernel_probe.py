@@ -10,13 +10,13 @@ from robot_lab_amd.env import ManagerBasedRLEnv
 from robot_lab_amd.scene import load_bundle
 
 
-def run(task, N=4096, decim=None, zero=False, steps=200, mutate=None):
+def run(task, N=4096, decim=None, zero=False, steps=200, mutate=None, lib_path=None):
     desc, extra = load_bundle(task)
     if decim is not None:
         desc.sim.decimation = decim
     if mutate:
         mutate(desc)
-    env = ManagerBasedRLEnv(None, desc=desc, extra=extra, num_envs=N, seed=42, device="cuda:0")
+    env = ManagerBasedRLEnv(None, desc=desc, extra=extra, num_envs=N, seed=42, device="cuda:0", lib_path=lib_path)
     env.reset()
     A = env.num_actions
     ring = [(torch.zeros(N, A, device="cuda") if zero else torch.rand(N, A, device="cuda") * 2 - 1) for _ in range(8)]
