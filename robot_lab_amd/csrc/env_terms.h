@@ -206,7 +206,6 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     return (mask >> b) & 1ull;
   }
   RL_FN float hist_max(int slot) const { return fmaxf(hist_n[slot][0], fmaxf(hist_n[slot][1], hist_n[slot][2])); }
-  RL_FN bool first_contact(int slot) const { return tim[slot][1] > 0.f && tim[slot][1] < T.step_dt + 1e-8f; }
 
   // position (base coords) and velocity relative to the root COM velocity (base coords) of body slot s
   RL_FN void body_rel(const Chain<CL>& C, int s, V3& relp, V3& relv) const {
@@ -454,9 +453,6 @@ struct EnvProgram : EnvLane<Ctx, CL> {
         if (li == 0) rstage[t] = val;
       }
     }
-#ifdef RL_ABLATE_REW_TAIL
-    return total;
-#endif
     // per-term outputs + episode sums: staged through LDS so that each lane's read-modify-writes of
     // `ep_sums` (terms t = k, k+4, ...) are issued as one batch instead of one HBM round trip per term
     ctx.group_sync();
@@ -618,11 +614,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     }
     bool terminated = t_illegal, time_out = t_timeout || t_oob;
     // 5 rewards
-#ifdef RL_ABLATE_REW
-    float rew = 0.f;
-#else
     float rew = compute_rewards(terminated);
-#endif
     if (li == 0) {
       S.reward[e] = rew;
       S.terminated[e] = terminated ? 1 : 0;

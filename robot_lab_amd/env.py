@@ -261,6 +261,7 @@ class ManagerBasedRLEnv(_EnvBase):
     def reset(self, seed: int | None = None, options=None, env_ids=None):
         ids = None if env_ids is None else torch.as_tensor(env_ids).cpu().numpy()
         self._native.reset(ids, self._stream())
+        self._export_stamp = -1  # state changed without a step: exported AoS views are stale
         self.extras = {}
         return self._obs, self.extras
 

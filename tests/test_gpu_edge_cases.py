@@ -1,0 +1,115 @@
+"""`-m gpu`: edge cases of the hot path through the C-ABI - ragged env counts (padding to the wavefront tile),
+partial resets by env id, zero actions, the one-lane-per-leg mapping, and seeds."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_close, oracle_root_state
+from oracle.env import OracleEnv
+from robot_lab_amd.scene import build_world, load_bundle
+
+pytestmark = pytest.mark.gpu
+TASK = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
+
+
+def _pair(N, seed, task=TASK):
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    env = ManagerBasedRLEnv(task, num_envs=N, seed=seed, device="cuda:0")
+    desc, extra = load_bundle(task)
+    h, to, eo = build_world(desc, extra, N, 0)
+    return env, OracleEnv(desc, h, to, N, seed, eo), torch
+
+
+@pytest.mark.parametrize("N", [1, 7, 37])
+def test_ragged_env_counts(N):
+    """num_envs that is not a multiple of the 16-env allocation tile: padded lanes must not leak into results."""
+    env, ora, torch = _pair(N, 3)
+    obs, _ = env.reset()
+    o = ora.reset()
+    assert obs["policy"].shape == (N, 45) and obs["critic"].shape == (N, 235)
+    rng = np.random.default_rng(N)
+    for _ in range(3):
+        a = rng.uniform(-1, 1, (N, 12)).astype(np.float32)
+        obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
+        o = ora.step(a)
+    assert_close("reward", rew.cpu().numpy(), ora.reward, 1e-3, 2e-5)
+    assert_close("critic", obs["critic"].cpu().numpy(), o[1], 5e-3, 5e-3)
+    assert_close("root", env.scene["robot"].data.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4)
+    env.close()
+
+
+def test_partial_reset_by_env_ids():
+    N = 32
+    env, ora, torch = _pair(N, 9)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(2):
+        a = rng.uniform(-1, 1, (N, 12)).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda())
+        ora.step(a)
+    ids = [3, 4, 17, 31]
+    before = env.scene["robot"].data.root_state_w.clone()
+    obs, _ = env.reset(env_ids=ids)
+    o = ora.reset(env_ids=ids)
+    after = env.scene["robot"].data.root_state_w
+    keep = np.setdiff1d(np.arange(N), ids)
+    assert torch.equal(before[keep], after[keep])                       # untouched envs keep their state bit-for-bit
+    assert_close("root", after.cpu().numpy(), oracle_root_state(ora), 1e-4, 1e-5)
+    assert_close("critic", obs["critic"].cpu().numpy(), o[1], 2e-3, 2e-3)
+    assert np.array_equal(env.episode_length_buf.cpu().numpy(), ora.episode_length_buf)
+    with pytest.raises(Exception):
+        env.reset(env_ids=[N])                                          # out of range -> error, not silent corruption
+    env.close()
+
+
+def test_zero_actions_stand_regime():
+    """zero_agent.py:68 regime: joints are held at the default pose by the PD loop."""
+    N = 64
+    env, ora, torch = _pair(N, 2, "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0")
+    env.reset()
+    ora.reset()
+    a = np.zeros((N, 12), dtype=np.float32)
+    for _ in range(8):
+        obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
+        o = ora.step(a)
+    assert_close("reward", rew.cpu().numpy(), ora.reward, 1e-3, 3e-5, 0.97)
+    assert_close("q", env.scene["robot"].data.joint_pos.cpu().numpy(), ora.st["q"], 3e-3, 3e-4, 0.97)
+    env.close()
+
+
+def test_one_lane_per_leg_mapping_matches_too(monkeypatch):
+    """RL_ENV_SUB=1 selects the 4-lanes-per-env kernels; both mappings implement the same step."""
+    monkeypatch.setenv("RL_ENV_SUB", "1")
+    N = 48
+    env, ora, torch = _pair(N, 4)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(1)
+    for _ in range(4):
+        a = rng.uniform(-1, 1, (N, 12)).astype(np.float32)
+        obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
+        o = ora.step(a)
+    assert_close("reward", rew.cpu().numpy(), ora.reward, 1e-3, 2e-5, 0.98)
+    assert_close("root", env.scene["robot"].data.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4, 0.98)
+    env.close()
+
+
+def test_seeds_give_different_but_reproducible_episodes():
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    obs = []
+    for seed in (1, 1, 2):
+        env = ManagerBasedRLEnv(TASK, num_envs=64, seed=seed, device="cuda:0")
+        o, _ = env.reset()
+        for _ in range(3):
+            o, *_ = env.step(torch.zeros(64, 12, device="cuda"))
+        obs.append(o["critic"].clone())
+        env.close()
+    assert torch.equal(obs[0], obs[1]) and not torch.equal(obs[0], obs[2])
