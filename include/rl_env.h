@@ -63,6 +63,9 @@ enum rl_reward_kind {
   RL_REW_FEET_CONTACT = 25,         /* rewards.py:399-413 ; p0 expect_contact_num ; body mask */
   RL_REW_FEET_STUMBLE = 26,         /* rewards.py:428-436 ; body mask */
   RL_REW_FEET_HEIGHT = 27,          /* rewards.py:507-524 ; p0 target_height p1 tanh_mult ; body mask */
+  RL_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP = 28, /* rewards.py:51-66 ; p0 = std^2 (G1) */
+  RL_REW_TRACK_ANG_VEL_Z_WORLD_EXP = 29,      /* rewards.py:69-78 ; p0 = std^2 (G1) */
+  RL_REW_FEET_AIR_TIME_POSITIVE_BIPED = 30,   /* rewards.py:363-383 ; p0 threshold ; body mask (G1) */
   RL_REW_NUM_KINDS
 };
 
@@ -104,11 +107,20 @@ typedef struct rl_model_desc {
   int32_t num_dof;      /* actuated joints, task joint order (A1: 12) */
   int32_t num_bodies;   /* sensor/randomisation bodies (A1: 17) */
   int32_t num_spheres;  /* collision spheres */
-  int32_t num_chains;   /* star topology: base + num_chains serial chains of chain_len joints */
-  int32_t chain_len;
-  int32_t chain_link[4][4];             /* link index of chain k's j-th link (joint index = link - 1) */
+  /* topology the lane program simulates: a serial "trunk" chain of num_trunk joints hanging off the
+     base (G1: the 3 waist joints pelvis -> torso; quadrupeds: none) and num_chains = 4 serial limb
+     chains, chain k hanging off the base (chain_attach = 0) or off the trunk link reached after
+     chain_attach[k] trunk joints (G1 arms: 3 = torso).  0 chains = topology not supported. */
+  int32_t num_chains;
+  int32_t chain_len;                    /* longest chain (A1 3, Go2W 4, G1 7) */
+  int32_t chain_link[4][8];             /* link index of chain k's j-th link (joint index = link - 1), -1 padded */
+  int32_t chain_nj[4];                  /* joints of chain k (G1: legs 6, arms 7) */
+  int32_t chain_attach[4];
+  int32_t num_trunk;
+  int32_t trunk_link[4];
   int32_t link_parent[RL_MAX_LINKS];
-  float link_origin[RL_MAX_LINKS][3];   /* joint origin in parent link frame (rotations are identity) */
+  float link_origin[RL_MAX_LINKS][3];   /* joint origin in parent link frame */
+  float link_quat[RL_MAX_LINKS][4];     /* joint frame orientation in the parent link frame, (w,x,y,z) (URDF joint rpy) */
   float link_axis[RL_MAX_LINKS][3];
   float joint_lower[RL_MAX_DOF], joint_upper[RL_MAX_DOF];
   float joint_vel_limit[RL_MAX_DOF];
@@ -177,6 +189,7 @@ typedef struct rl_task_desc {
   rl_obs_term policy[RL_MAX_OBS_TERMS], critic[RL_MAX_OBS_TERMS];
   int32_t policy_corrupt, critic_corrupt;
   int32_t scan_nx, scan_ny; float scan_res; float scan_offset; /* 17 x 11 @0.1, offset 0.5 */
+  int32_t scan_body;      /* body the RayCaster rides on (velocity_env_cfg.py:71 prim_path; G1: torso_link, unitree_g1/rough_env_cfg.py:55) */
   uint32_t wheel_joint_mask;
   /* rewards */
   int32_t n_rewards;
@@ -195,7 +208,7 @@ typedef struct rl_task_desc {
   float gain_kp_scale[2], gain_kd_scale[2];
   float reset_pose[6][2], reset_vel[6][2];
   float push_interval[2], push_vel[6][2];
-  int32_t base_body;
+  int32_t base_body;      /* body addressed by the mass-add / COM / external-wrench events (base_link_name; G1: torso_link) */
 } rl_task_desc;
 
 typedef struct rl_env_desc {

@@ -77,6 +77,10 @@ class Physics:
         self.parent = arr(m.link_parent, L).astype(int)
         self.origin = arr(m.link_origin, L).astype(np.float64)
         self.axis = arr(m.link_axis, L).astype(np.float64)
+        lq = arr(m.link_quat, L).astype(np.float64)
+        lq[np.abs(lq).sum(1) == 0] = [1.0, 0.0, 0.0, 0.0]  # descriptors written before link_quat existed
+        self.rot0 = sp.quat_to_mat(lq)  # joint frame axes in the parent link frame (URDF joint rpy)
+        self.wrench_link = int(m.body_link[desc.task.base_body])  # link carrying the body the wrench event addresses
         self.body_link = arr(m.body_link, B).astype(int)
         self.sphere_body = arr(m.sphere_body, G).astype(int)
         self.sphere_link = self.body_link[self.sphere_body]
@@ -128,7 +132,7 @@ class Physics:
         ow[:, 0] = root_pos
         for i in range(1, L):
             p = self.parent[i]
-            Rj = sp.axis_angle_mat(self.axis[i], q[:, i - 1])  # child -> parent
+            Rj = self.rot0[i][None] @ sp.axis_angle_mat(self.axis[i], q[:, i - 1])  # child -> parent
             E = np.swapaxes(Rj, 1, 2)
             X[:, i] = sp.xform_motion(E, np.broadcast_to(self.origin[i], (N, 3)))
             Rw[:, i] = Rw[:, p] @ Rj
@@ -197,9 +201,10 @@ class Physics:
         f = np.einsum("nlij,nlj->nli", I, a)
         for i in range(L):
             f[:, i] += np.einsum("nij,nj->ni", sp.crf(v[:, i]), np.einsum("nij,nj->ni", I[:, i], v[:, i]))
-        # persistent external wrench on the base body, body frame, at its COM [UPSTREAM B8]
-        f[:, 0, :3] -= st["ext_torque"] + np.cross(st["base_com"], st["ext_force"])
-        f[:, 0, 3:] -= st["ext_force"]
+        # persistent external wrench on the base body (G1: the torso), body frame, at its COM [UPSTREAM B8]
+        wl = self.wrench_link
+        f[:, wl, :3] -= st["ext_torque"] + np.cross(st["base_com"], st["ext_force"])
+        f[:, wl, 3:] -= st["ext_force"]
         b = np.einsum("nlji,nlj->ni", K, f)
 
         A = np.zeros((N, ND, ND))

@@ -7,12 +7,13 @@
 //   * by g++ for the CPU lane emulator (tests/emu): Ctx = 4 host threads + a barrier.  That build is
 //     test infrastructure for `-m "not gpu"` CI only and is never loaded by the product path.
 //
-// Physics (DESIGN.md "Simulator"): floating-base star articulation; composite-rigid-body inertia
-// and RNEA bias in BASE coordinates; linearly-implicit contact / joint-limit / PD terms; the
-// (6+CL) x (6+CL) per-lane system is reduced by a Schur complement onto the 6 base DoF, the four
-// lanes' 6x6 contributions are summed with wavefront shuffles, every lane solves the 6x6 system
-// redundantly and back-substitutes its own chain.  Same equations as oracle/physics.py, different
-// formulation (that one is generic-tree, dense, fp64, link coordinates).
+// Physics (DESIGN.md "Simulator"): floating-base articulation = a trunk (base + NW serial joints, G1:
+// the waist) carrying 4 limb chains; composite-rigid-body inertia and RNEA bias in BASE coordinates;
+// linearly-implicit contact / joint-limit / PD terms; the (NB+CL) x (NB+CL) per-lane system (NB = 6 +
+// NW trunk DoF) is reduced by a Schur complement onto the trunk DoF, the four limbs' NB x NB
+// contributions are summed with wavefront shuffles, every lane solves the trunk system redundantly
+// and back-substitutes its own chain.  Same equations as oracle/physics.py, different formulation
+// (that one is generic-tree, dense, fp64, link coordinates).
 #pragma once
 #include "env_tables.h"
 
@@ -95,20 +96,47 @@ RL_FN void terrain_sample(const Uni& u, const float* __restrict__ hf, float x, f
   terrain_eval(u, terrain_fetch(u, hf, x, y), h, n);
 }
 
-template <int CL>
-struct Chain {  // kinematics of the lane's chain in base coordinates
+RL_FN M3 ld_m3(const float* p) { return M3{{p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}}; }
+
+template <class TP>
+struct Chain {  // kinematics in base coordinates: the lane's limb (R, p, ax) and the trunk joints (Rw, pw, axw)
+  static constexpr int CL = TP::CL, NW = TP::NW, NWA = TP::NW > 0 ? TP::NW : 1;
   M3 R[CL];
   V3 p[CL], ax[CL];
+  M3 Rw[NWA];
+  V3 pw[NWA], axw[NWA];
+  // frame of the trunk link reached after `depth` trunk joints (0 = the base itself)
+  RL_FN void trunk_frame(int depth, M3& Rf, V3& pf) const {
+    Rf = identity3();
+    pf = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (depth == i + 1) { Rf = Rw[i]; pf = pw[i]; }
+  }
 };
 
-template <int CL>
-RL_FN void chain_kinematics(const LaneTab& L, const float (&q)[CL], Chain<CL>& C) {
+template <class TP>
+RL_FN void chain_kinematics(const LaneTab& L, const float (&q)[TP::JX], Chain<TP>& C) {
+  constexpr int CL = TP::CL, NW = TP::NW;
   M3 Rp = identity3();
   V3 pp{0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {  // trunk joints (same in every lane)
+    const int jx = CL + i;
+    V3 al = ld3(L.axis[jx]);
+    M3 Rj0 = mul(Rp, ld_m3(L.rot0[jx]));
+    C.pw[i] = pp + mul(Rp, ld3(L.origin[jx]));
+    C.axw[i] = mul(Rj0, al);
+    C.Rw[i] = mul(Rj0, rodrigues(al, q[jx]));
+    Rp = C.Rw[i];
+    pp = C.pw[i];
+  }
+  C.trunk_frame(NW > 0 ? L.attach : 0, Rp, pp);
 #pragma unroll
   for (int j = 0; j < CL; ++j) {
     V3 al = ld3(L.axis[j]);
     C.p[j] = pp + mul(Rp, ld3(L.origin[j]));
+    if (TP::ROT) Rp = mul(Rp, ld_m3(L.rot0[j]));
     C.ax[j] = mul(Rp, al);
     C.R[j] = mul(Rp, rodrigues(al, q[j]));
     Rp = C.R[j];
@@ -116,13 +144,17 @@ RL_FN void chain_kinematics(const LaneTab& L, const float (&q)[CL], Chain<CL>& C
   }
 }
 
-// velocity (base coords) of the point x rigidly attached to link group g (0 = base), relative terms selectable
-template <int CL>
-RL_FN V3 point_velocity(const Chain<CL>& C, int g, V3 x, SV V0, const float (&qd)[CL]) {
+// velocity (base coords) of the point x rigidly attached to a link that is moved by the first `wd` trunk
+// joints and the first `lg` limb joints
+template <class TP>
+RL_FN V3 point_velocity(const Chain<TP>& C, int wd, int lg, V3 x, SV V0, const float (&qd)[TP::JX]) {
   V3 u = V0.l + cross(V0.a, x);
 #pragma unroll
-  for (int i = 0; i < CL; ++i)
-    if (i < g) u += qd[i] * cross(C.ax[i], x - C.p[i]);
+  for (int i = 0; i < TP::NW; ++i)
+    if (i < wd) u += qd[TP::CL + i] * cross(C.axw[i], x - C.pw[i]);
+#pragma unroll
+  for (int i = 0; i < TP::CL; ++i)
+    if (i < lg) u += qd[i] * cross(C.ax[i], x - C.p[i]);
   return u;
 }
 
@@ -139,18 +171,22 @@ struct LsMat {
   float* p;
   RL_FN LsRow<STRIDE, W> operator[](int b) const { return {p + b * W * STRIDE}; }
 };
-enum { LS_TIM = 0, LS_HIST = LS_TIM + NBS * 4, LS_CF = LS_HIST + NBS * 3, LS_FRIC = LS_CF + NBS * 3, LS_WORDS = LS_FRIC + NBS * 3 };
+template <int NBS>
+struct LsLayout {
+  enum { TIM = 0, HIST = TIM + NBS * 4, CF = HIST + NBS * 3, FRIC = CF + NBS * 3, WORDS = FRIC + NBS * 3 };
+};
 
-template <class Ctx, int CL>
+template <class Ctx, class TP>
 struct EnvLane {
+  static constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NB = TP::NB, SPL = TP::SPL, NBS = TP::NBS, NGRP = TP::CL + 1;
+  using LS = LsLayout<NBS>;
   static constexpr int LSS = Ctx::LS_STRIDE;
   static constexpr int SUB = Ctx::SUB;          // sub-lanes per leg (1: one lane per leg; 4: a DPP quad per leg)
   static constexpr int LPE = NLANE * SUB;       // lanes per environment
   static constexpr int EPT = 64 / LPE;          // environments per wavefront / tile
   static constexpr uint32_t ROW = NLANE * EPT;  // entries of a lane-field row
-  static constexpr int NV = 6 + CL;
+  static constexpr int NV = NB + CL;  // per-lane system: [omega_b, v_b, trunk joints, limb joints]
   using UI = SymIdx<NV>;
-  static constexpr int NSPH = (CL + 1) * SPL;
 
   Ctx& ctx;
   const KState& S;
@@ -163,11 +199,12 @@ struct EnvLane {
   // persistent state in registers
   V3 pos, vlin, vang;
   Q4 quat;
-  float q[CL], qd[CL], kp[CL], kd[CL], act[CL], prev_act[CL];
-  V3 base_com; // COM of the base body
+  float q[JX], qd[JX], kp[JX], kd[JX], act[JX], prev_act[JX];  // [0, CL) limb, [CL, JX) trunk joints
+  V3 base_com;  // COM of the root body (root COM velocity)
+  V3 wr_com;    // COM of the wrench body in its trunk link frame
   V3 extF, extT;
   // per-step scratch
-  float tau_app[CL], qacc[CL];
+  float tau_app[JX], qacc[JX];
   // contact-sensor state + friction in the lane-private LDS scratchpad
   LsMat<LSS, 4> tim;     // [slot][current_air, current_contact, last_air, last_contact]
   LsMat<LSS, 3> hist_n;  // [slot][|F| of the last three substeps, newest first]
@@ -175,8 +212,8 @@ struct EnvLane {
   LsMat<LSS, 3> fric;    // [slot][mu_s, mu_d, restitution]
 
   RL_FN EnvLane(Ctx& c, const KState& s)
-      : ctx(c), S(s), T(c.tables()), L(c.tables().lane[c.k()]), u(make_uni(c, c.tables())), tim{c.lane_scratch() + LS_TIM * LSS}, hist_n{c.lane_scratch() + LS_HIST * LSS},
-        cf{c.lane_scratch() + LS_CF * LSS}, fric{c.lane_scratch() + LS_FRIC * LSS} {
+      : ctx(c), S(s), T(c.tables()), L(c.tables().lane[c.k()]), u(make_uni(c, c.tables())), tim{c.lane_scratch() + LS::TIM * LSS}, hist_n{c.lane_scratch() + LS::HIST * LSS},
+        cf{c.lane_scratch() + LS::CF * LSS}, fric{c.lane_scratch() + LS::FRIC * LSS} {
     e = ctx.env();
     k = ctx.k();
     sub = ctx.sub();
@@ -200,6 +237,8 @@ struct EnvLane {
     extF = {EF(EF_WRENCH + 0), EF(EF_WRENCH + 1), EF(EF_WRENCH + 2)};
     extT = {EF(EF_WRENCH + 3), EF(EF_WRENCH + 4), EF(EF_WRENCH + 5)};
     base_com = {EF(EF_BASE_COM + 0), EF(EF_BASE_COM + 1), EF(EF_BASE_COM + 2)};
+    if (NW > 0) wr_com = {EF(EF_WR_COM + 0), EF(EF_WR_COM + 1), EF(EF_WR_COM + 2)};
+    else wr_com = base_com;  // quadrupeds: the wrench body is the root body
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
       q[j] = LF(LF_Q + j);
@@ -207,6 +246,17 @@ struct EnvLane {
       kp[j] = LF(LF_KP + j);
       kd[j] = LF(LF_KD + j);
       act[j] = LF(LF_ACT + j);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      q[CL + i] = EF(EF_TQ + i);
+      qd[CL + i] = EF(EF_TQD + i);
+      kp[CL + i] = EF(EF_TKP + i);
+      kd[CL + i] = EF(EF_TKD + i);
+      act[CL + i] = EF(EF_TACT + i);
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
       tau_app[j] = 0.f;
       qacc[j] = 0.f;
     }
@@ -229,6 +279,14 @@ struct EnvLane {
       EF(EF_ROOT + 10) = vang.x; EF(EF_ROOT + 11) = vang.y; EF(EF_ROOT + 12) = vang.z;
       EF(EF_WRENCH + 0) = extF.x; EF(EF_WRENCH + 1) = extF.y; EF(EF_WRENCH + 2) = extF.z;
       EF(EF_WRENCH + 3) = extT.x; EF(EF_WRENCH + 4) = extT.y; EF(EF_WRENCH + 5) = extT.z;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        EF(EF_TQ + i) = q[CL + i];
+        EF(EF_TQD + i) = qd[CL + i];
+        EF(EF_TKP + i) = kp[CL + i];
+        EF(EF_TKD + i) = kd[CL + i];
+        EF(EF_TACT + i) = act[CL + i];
+      }
     }
     if (sub == 0) {
 #pragma unroll
@@ -250,10 +308,10 @@ struct EnvLane {
 
   // ------------------------------------------------------------------ actuators [UPSTREAM B4]
   // returns explicit torque; fills tau_app (applied torque estimate) and the implicit-PD diagonal terms
-  RL_FN void actuators(const float (&q_tgt)[CL], const float (&qd_tgt)[CL], float (&tau_e)[CL], float (&pd_diag)[CL], float (&pd_rhs)[CL]) {
+  RL_FN void actuators(const float (&q_tgt)[JX], const float (&qd_tgt)[JX], float (&tau_e)[JX], float (&pd_diag)[JX], float (&pd_rhs)[JX]) {
     const float dt = u.dt;
 #pragma unroll
-    for (int j = 0; j < CL; ++j) {
+    for (int j = 0; j < JX; ++j) {
       float qt = L.action_is_vel[j] ? q[j] : q_tgt[j];
       float er = qt - q[j], ed = qd_tgt[j] - qd[j];
       float tc = kp[j] * er + kd[j] * ed;
@@ -284,11 +342,19 @@ struct EnvLane {
     V3 x, n;            // contact point and terrain normal, base coordinates
     float bias, dn, dt; // spring bias force, normal / tangential damping
   };
-  // sphere centre in base coordinates (cb) and world (cw); empty slots (radius <= 0) sit at the base origin
-  RL_FN void sphere_center(const Chain<CL>& C, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
+  // joints that move link group g: the first wdepth(g) trunk joints and the first g limb joints
+  RL_FN int wdepth(int g) const { return NW == 0 ? 0 : (g == 0 ? L.grp0_depth : L.attach); }
+  // sphere centre in base coordinates (cb) and world (cw); empty slots (radius <= 0) sit at the group's link origin
+  RL_FN void sphere_center(const Chain<TP>& C, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
     rad = L.sph_r[g][s];
     V3 cl = ld3(L.sph_c[g][s]);
     cb = cl;
+    if (NW > 0) {
+      M3 Rf;
+      V3 pf;
+      C.trunk_frame(L.grp0_depth, Rf, pf);
+      cb = pf + mul(Rf, cl);
+    }
 #pragma unroll
     for (int j = 0; j < CL; ++j)
       if (g == j + 1) cb = C.p[j] + mul(C.R[j], cl);
@@ -300,13 +366,13 @@ struct EnvLane {
     terrain_eval(u, tp, hz, nw);
     phi = rad > 0.f ? rad - (cw.z - hz) * nw.z : -1.f;
   }
-  RL_FN Contact contact_from_phi(const Chain<CL>& C, const M3& Rwb, SV V0, const float (&qdv)[CL], int g, int s, float rad, V3 cb, float phi, V3 nw) const {
+  RL_FN Contact contact_from_phi(const Chain<TP>& C, const M3& Rwb, SV V0, const float (&qdv)[JX], int g, int s, float rad, V3 cb, float phi, V3 nw) const {
     Contact c;
     c.act = false;
     if (phi > 0.f) {
       V3 nb = mulT(Rwb, nw);
       V3 x = cb - rad * nb;
-      V3 uu = point_velocity<CL>(C, g, x, V0, qdv);
+      V3 uu = point_velocity<TP>(C, wdepth(g), g, x, V0, qdv);
       float un = dot(nb, uu);
       V3 ut = uu - un * nb;
       float utn = norm(ut);
@@ -325,7 +391,7 @@ struct EnvLane {
     }
     return c;
   }
-  RL_FN Contact contact_from_patch(const Chain<CL>& C, const M3& Rwb, SV V0, const float (&qdv)[CL], int g, int s, float rad, V3 cb, V3 cw,
+  RL_FN Contact contact_from_patch(const Chain<TP>& C, const M3& Rwb, SV V0, const float (&qdv)[JX], int g, int s, float rad, V3 cb, V3 cw,
                                    const TerrainPatch& tp) const {
     float phi;
     V3 nw;
@@ -337,7 +403,8 @@ struct EnvLane {
   // Adds dt J^T D J / dt J^T n bias of every active sphere of the link groups this lane evaluates to
   // (U, rv).  With SUB == 4 the four sub-lanes of a leg run this same code on different groups (g is a
   // per-lane value) and the caller quad-sums the result; with SUB == 1 the lane loops over all groups.
-  RL_FN void contact_pass1(const Chain<CL>& C, const M3& Rwb, SV V0, uint32_t slot_valid, float (&U)[UI::size], float (&rv)[NV], uint32_t& active_mask) {
+  // Joint columns of the system: 6 + m, m in [0, NW) the trunk joints, m in [NW, NW + CL) the limb joints.
+  RL_FN void contact_pass1(const Chain<TP>& C, const M3& Rwb, SV V0, uint32_t slot_valid, float (&U)[UI::size], float (&rv)[NV], uint32_t& active_mask) {
     const float dt = u.dt;
 #pragma unroll 1
     for (int g = (SUB == 1 ? 0 : sub); g <= CL; g += SUB) {
@@ -359,12 +426,13 @@ struct EnvLane {
         touching = touching || phi[s] > 0.f;
       }
       if (!ctx.any(touching)) continue;  // most link groups of most wavefronts touch nothing
+      const int wd = wdepth(g);
 #pragma unroll
       for (int s = 0; s < SPL; ++s) {
         Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad[s], cb[s], phi[s], nw[s]);
         if (c.act) {
           active_mask |= 1u << (g * SPL + s);
-          // J = [ [x]x^T | 1 | a_j x (x - p_j) ... ] (point velocity wrt [omega_b, v_b, qd]); add
+          // J = [ [x]x^T | 1 | a_m x (x - p_m) ... ] (point velocity wrt [omega_b, v_b, joints]); add
           // dt (d_t J^T J + (d_n - d_t) g g^T) with g = J^T n, exploiting the block structure of J
           const V3 x = c.x, n = c.n;
           const float kt = dt * c.dt, kn = dt * (c.dn - c.dt), fb = dt * c.bias;
@@ -385,21 +453,25 @@ struct EnvLane {
 #pragma unroll
             for (int jj = i; jj < 6; ++jj) U[UI::at(i, jj)] += kg * g6[jj];
           }
-          // chain columns (only the joints between the base and the sphere's link move the point)
-          V3 cj[CL];
-          float gc[CL];
+          // joint columns (only the joints between the base and the sphere's link move the point); columns
+          // of joints that do not move it are zero vectors, so the pair loop needs no second predicate
+          V3 cj[JX];
+          float gc[JX];
 #pragma unroll
-          for (int j = 0; j < CL; ++j) {
-            if (j < g) {
-              cj[j] = cross(C.ax[j], x - C.p[j]);
-              gc[j] = dot(cj[j], n);
-              const V3 w = cross(x, cj[j]);
-              const float kg = kn * gc[j];
-              U[UI::at(0, 6 + j)] += kt * w.x + kg * g6[0]; U[UI::at(1, 6 + j)] += kt * w.y + kg * g6[1]; U[UI::at(2, 6 + j)] += kt * w.z + kg * g6[2];
-              U[UI::at(3, 6 + j)] += kt * cj[j].x + kg * g6[3]; U[UI::at(4, 6 + j)] += kt * cj[j].y + kg * g6[4]; U[UI::at(5, 6 + j)] += kt * cj[j].z + kg * g6[5];
-              rv[6 + j] += fb * gc[j];
+          for (int m = 0; m < JX; ++m) {
+            const bool moves = m < NW ? (m < wd) : (m - NW < g);
+            cj[m] = {0.f, 0.f, 0.f};
+            gc[m] = 0.f;
+            if (moves) {
+              cj[m] = m < NW ? cross(C.axw[m < NW ? m : 0], x - C.pw[m < NW ? m : 0]) : cross(C.ax[m < NW ? 0 : m - NW], x - C.p[m < NW ? 0 : m - NW]);
+              gc[m] = dot(cj[m], n);
+              const V3 w = cross(x, cj[m]);
+              const float kg = kn * gc[m];
+              U[UI::at(0, 6 + m)] += kt * w.x + kg * g6[0]; U[UI::at(1, 6 + m)] += kt * w.y + kg * g6[1]; U[UI::at(2, 6 + m)] += kt * w.z + kg * g6[2];
+              U[UI::at(3, 6 + m)] += kt * cj[m].x + kg * g6[3]; U[UI::at(4, 6 + m)] += kt * cj[m].y + kg * g6[4]; U[UI::at(5, 6 + m)] += kt * cj[m].z + kg * g6[5];
+              rv[6 + m] += fb * gc[m];
 #pragma unroll
-              for (int i = 0; i <= j; ++i) U[UI::at(6 + i, 6 + j)] += kt * dot(cj[i], cj[j]) + kg * gc[i];
+              for (int i = 0; i <= m; ++i) U[UI::at(6 + i, 6 + m)] += kt * dot(cj[i], cj[m]) + kg * gc[i];
             }
           }
         }
@@ -407,20 +479,47 @@ struct EnvLane {
     }
   }
 
+  // U/rv += a rigid composite with spatial inertia I (base coords), momentum h and bias force f that rides
+  // on the trunk link reached after `depth` trunk joints: base block, trunk-joint columns, bias.
+  RL_FN void add_composite(const SI& I, const SV& h, const SV& f, int depth, const SV (&Sw)[TP::NW > 0 ? TP::NW : 1], float (&U)[UI::size], float (&rv)[NV]) const {
+    const float dt = u.dt;
+    // 6x6 block from the spatial inertia: [[I, hx],[hx^T, m 1]]
+    U[UI::at(0, 0)] += I.I.xx; U[UI::at(1, 1)] += I.I.yy; U[UI::at(2, 2)] += I.I.zz;
+    U[UI::at(0, 1)] += I.I.xy; U[UI::at(0, 2)] += I.I.xz; U[UI::at(1, 2)] += I.I.yz;
+    U[UI::at(3, 3)] += I.m; U[UI::at(4, 4)] += I.m; U[UI::at(5, 5)] += I.m;
+    U[UI::at(0, 4)] += -I.h.z; U[UI::at(0, 5)] += I.h.y;
+    U[UI::at(1, 3)] += I.h.z;  U[UI::at(1, 5)] += -I.h.x;
+    U[UI::at(2, 3)] += -I.h.y; U[UI::at(2, 4)] += I.h.x;
+    const SV r = h - f * dt;
+    rv[0] += r.a.x; rv[1] += r.a.y; rv[2] += r.a.z;
+    rv[3] += r.l.x; rv[4] += r.l.y; rv[5] += r.l.z;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      if (i < depth) {
+        const SV B = apply(I, Sw[i]);
+        U[UI::at(0, 6 + i)] += B.a.x; U[UI::at(1, 6 + i)] += B.a.y; U[UI::at(2, 6 + i)] += B.a.z;
+        U[UI::at(3, 6 + i)] += B.l.x; U[UI::at(4, 6 + i)] += B.l.y; U[UI::at(5, 6 + i)] += B.l.z;
+#pragma unroll
+        for (int i2 = 0; i2 <= i; ++i2) U[UI::at(6 + i2, 6 + i)] += dot(Sw[i2], B);
+        rv[6 + i] += dot(Sw[i], r);
+      }
+    }
+  }
+
   // ------------------------------------------------------------------ one physics substep
-  RL_FN void substep(const float (&q_tgt)[CL], const float (&qd_tgt)[CL]) {
+  RL_FN void substep(const float (&q_tgt)[JX], const float (&qd_tgt)[JX]) {
     // keep the compiler from hoisting the (loop-invariant) LDS table reads of all four substeps to the
     // top of the kernel, where ~200 of them stayed live and spilled to scratch
     asm volatile("" ::: "memory");
     const float dt = u.dt;
-    float tau_e[CL], pd_diag[CL], pd_rhs[CL];
+    float tau_e[JX], pd_diag[JX], pd_rhs[JX];
     actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
 
     const M3 Rwb = quat_to_mat(quat);
     SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
     SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
-    Chain<CL> C;
-    chain_kinematics<CL>(L, q, C);
+    Chain<TP> C;
+    chain_kinematics<TP>(L, q, C);
 
     float U[UI::size];
     float rv[NV];
@@ -431,7 +530,7 @@ struct EnvLane {
 
     // ---- contacts first (they only need the kinematics): every sub-lane accumulates the spheres of its
     // link groups into the zero-initialised (U, rv), the leg's sub-lanes are quad-summed, and the CRBA
-    // terms below are added on top - so only one copy of the 54-entry system is ever live.
+    // terms below are added on top - so only one copy of the system is ever live.
     uint32_t active_mask = 0;
     const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
     contact_pass1(C, Rwb, V0, slot_valid, U, rv, active_mask);
@@ -442,12 +541,30 @@ struct EnvLane {
       for (int i = 0; i < NV; ++i) rv[i] = ctx.leg_sum(rv[i]);
     }
 
-    // ---- CRBA + RNEA in base coordinates
+    // ---- trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
+    constexpr int NWA = NW > 0 ? NW : 1;
+    SV Sw[NWA], Vw[NWA], aw[NWA];
+    {
+      SV Vp = V0, ap = a0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        Sw[i] = SV{C.axw[i], cross(C.pw[i], C.axw[i])};
+        SV vj = Sw[i] * qd[CL + i];
+        Vw[i] = Vp + vj;
+        aw[i] = ap + crm(Vw[i], vj);
+        Vp = Vw[i];
+        ap = aw[i];
+      }
+    }
+    // ---- CRBA + RNEA of the limb in base coordinates
     SV Sj[CL];
     SI Ic[CL];
     SV Fs[CL], Hs[CL];
     {
       SV Vp = V0, ap = a0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+        if (L.attach == i + 1) { Vp = Vw[i]; ap = aw[i]; }
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
         Sj[j] = SV{C.ax[j], cross(C.p[j], C.ax[j])};
@@ -470,148 +587,158 @@ struct EnvLane {
         Hs[j] = Hs[j] + Hs[j + 1];
       }
     }
-    SI Itop = Ic[0];
-    SV ftop = Fs[0], htop = Hs[0];
-    if (k == 0) {  // the base link itself, its bias force and the persistent external wrench [UPSTREAM B8]
-      const int bi = EF_BASE_INERTIA;
-      const SI I0 = make_si(EF(bi), V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)}, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)});
-      SV h0 = apply(I0, V0);
-      SV f0 = apply(I0, a0) + crf(V0, h0);
-      f0.a -= extT + cross(base_com, extF);
-      f0.l -= extF;
-      Itop = Itop + I0;
-      ftop = ftop + f0;
-      htop = htop + h0;
+    add_composite(Ic[0], Hs[0], Fs[0], NW > 0 ? L.attach : 0, Sw, U, rv);
+    if (k <= NW) {  // lane group k adds trunk link k (0 = the base link) + the persistent external wrench [UPSTREAM B8]
+      const int bi = EF_BASE_INERTIA + k * INERTIA_NF;
+      M3 Rf;
+      V3 pf;
+      C.trunk_frame(k, Rf, pf);
+      SV Vl = V0, al = a0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+        if (k == i + 1) { Vl = Vw[i]; al = aw[i]; }
+      const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
+      const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
+      SV h0 = apply(I0, Vl);
+      SV f0 = apply(I0, al) + crf(Vl, h0);
+      if (k == (NW > 0 ? T.wrench_depth : 0)) {
+        const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
+        f0.a -= mul(Rf, extT) + cross(xc, Fb);
+        f0.l -= Fb;
+      }
+      add_composite(I0, h0, f0, k, Sw, U, rv);
     }
-    {  // 6x6 block from the spatial inertia: [[I, hx],[hx^T, m 1]]
-      U[UI::at(0, 0)] += Itop.I.xx; U[UI::at(1, 1)] += Itop.I.yy; U[UI::at(2, 2)] += Itop.I.zz;
-      U[UI::at(0, 1)] += Itop.I.xy; U[UI::at(0, 2)] += Itop.I.xz; U[UI::at(1, 2)] += Itop.I.yz;
-      U[UI::at(3, 3)] += Itop.m; U[UI::at(4, 4)] += Itop.m; U[UI::at(5, 5)] += Itop.m;
-      U[UI::at(0, 4)] += -Itop.h.z; U[UI::at(0, 5)] += Itop.h.y;
-      U[UI::at(1, 3)] += Itop.h.z;  U[UI::at(1, 5)] += -Itop.h.x;
-      U[UI::at(2, 3)] += -Itop.h.y; U[UI::at(2, 4)] += Itop.h.x;
-      rv[0] += htop.a.x - dt * ftop.a.x; rv[1] += htop.a.y - dt * ftop.a.y; rv[2] += htop.a.z - dt * ftop.a.z;
-      rv[3] += htop.l.x - dt * ftop.l.x; rv[4] += htop.l.y - dt * ftop.l.y; rv[5] += htop.l.z - dt * ftop.l.z;
+    if (NW > 0 && k == 0) {  // joint-local terms of the trunk joints (armature, actuators, limits): once
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int jx = CL + i;
+        float arm = L.armature[jx];
+        float below = L.lower[jx] - q[jx], above = q[jx] - L.upper[jx];
+        float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
+        bool lim = (below > 0.f) || (above > 0.f);
+        U[UI::at(6 + i, 6 + i)] += arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+        rv[6 + i] += arm * qd[jx] + dt * tau_e[jx] + pd_rhs[jx] + dt * u.limit_k * viol;
+      }
     }
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
       SV B = apply(Ic[j], Sj[j]);
-      U[UI::at(0, 6 + j)] += B.a.x; U[UI::at(1, 6 + j)] += B.a.y; U[UI::at(2, 6 + j)] += B.a.z;
-      U[UI::at(3, 6 + j)] += B.l.x; U[UI::at(4, 6 + j)] += B.l.y; U[UI::at(5, 6 + j)] += B.l.z;
+      U[UI::at(0, NB + j)] += B.a.x; U[UI::at(1, NB + j)] += B.a.y; U[UI::at(2, NB + j)] += B.a.z;
+      U[UI::at(3, NB + j)] += B.l.x; U[UI::at(4, NB + j)] += B.l.y; U[UI::at(5, NB + j)] += B.l.z;
 #pragma unroll
-      for (int i = 0; i <= j; ++i) U[UI::at(6 + i, 6 + j)] += dot(Sj[i], B);
+      for (int i = 0; i < NW; ++i)
+        if (i < L.attach) U[UI::at(6 + i, NB + j)] += dot(Sw[i], B);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) U[UI::at(NB + i, NB + j)] += dot(Sj[i], B);
       float arm = L.armature[j];
-      U[UI::at(6 + j, 6 + j)] += arm;
-      rv[6 + j] += dot(Sj[j], Hs[j]) + arm * qd[j] + dt * (tau_e[j] - dot(Sj[j], Fs[j])) + pd_rhs[j];
+      U[UI::at(NB + j, NB + j)] += arm + ((NW > 0 && j >= L.nj) ? 1.0f : 0.f);  // padding joints of a shorter chain: identity row
+      rv[NB + j] += dot(Sj[j], Hs[j]) + arm * qd[j] + dt * (tau_e[j] - dot(Sj[j], Fs[j])) + pd_rhs[j];
       // joint limits: implicit spring-damper (hard limits in the reference, a1.urdf:369,411,439)
       float below = L.lower[j] - q[j], above = q[j] - L.upper[j];
       float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
       bool lim = (below > 0.f) || (above > 0.f);
-      U[UI::at(6 + j, 6 + j)] += pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
-      rv[6 + j] += dt * u.limit_k * viol;
+      U[UI::at(NB + j, NB + j)] += pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+      rv[NB + j] += dt * u.limit_k * viol;
     }
 
-    // ---- contacts: collision spheres vs heightfield, linearly-implicit (oracle/physics.py header).
-    // Pass 1 adds J^T D J / J^T n bias of every active sphere to the system; the per-sphere data is NOT
-    // kept (12 slots x 10 values would spill) - pass 2 after the solve re-evaluates the active spheres.
-    // One iteration per link group (base share, then each chain link): the terrain corner loads of the
-    // group's SPL sphere slots are issued together, then consumed.
-    // ---- Schur complement of the chain block, 4-lane reduction, 6x6 solve, back substitution
+    // ---- Schur complement of the limb block, cross-limb reduction, NB x NB trunk solve, back substitution
     float Lc[CL][CL];
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
-      float s = U[UI::at(6 + j, 6 + j)];
+      float s = U[UI::at(NB + j, NB + j)];
 #pragma unroll
       for (int m = 0; m < j; ++m) s -= Lc[j][m] * Lc[j][m];
       float inv = frsqrt(s);
       Lc[j][j] = inv;  // the diagonal holds 1 / L_jj
 #pragma unroll
       for (int i = j + 1; i < CL; ++i) {
-        float t = U[UI::at(6 + j, 6 + i)];
+        float t = U[UI::at(NB + j, NB + i)];
 #pragma unroll
         for (int m = 0; m < j; ++m) t -= Lc[i][m] * Lc[j][m];
         Lc[i][j] = t * inv;
       }
     }
-    float Y[6][CL], z[CL];
+    float Y[NB][CL], z[CL];
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < NB; ++r)
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
-        float t = U[UI::at(r, 6 + j)];
+        float t = U[UI::at(r, NB + j)];
 #pragma unroll
         for (int m = 0; m < j; ++m) t -= Lc[j][m] * Y[r][m];
         Y[r][j] = t * Lc[j][j];
       }
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
-      float t = rv[6 + j];
+      float t = rv[NB + j];
 #pragma unroll
       for (int m = 0; m < j; ++m) t -= Lc[j][m] * z[m];
       z[j] = t * Lc[j][j];
     }
-    using BI = SymIdx<6>;
-    float Cb[BI::size], db[6];
+    using BI = SymIdx<NB>;
+    float Cb[BI::size], db[NB];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
+    for (int r = 0; r < NB; ++r) {
       float t = rv[r];
 #pragma unroll
       for (int j = 0; j < CL; ++j) t -= Y[r][j] * z[j];
       db[r] = ctx.gsum(t);
 #pragma unroll
-      for (int c = r; c < 6; ++c) {
+      for (int c = r; c < NB; ++c) {
         float v = U[UI::at(r, c)];
 #pragma unroll
         for (int j = 0; j < CL; ++j) v -= Y[r][j] * Y[c][j];
         Cb[BI::at(r, c)] = ctx.gsum(v);
       }
     }
-    float nu0[6];
-    {  // 6x6 Cholesky solve
-      float G[6][6];
+    float nu0[NB];
+    {  // NB x NB Cholesky solve
+      float G[NB][NB];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
+      for (int j = 0; j < NB; ++j) {
         float s = Cb[BI::at(j, j)];
 #pragma unroll
         for (int m = 0; m < j; ++m) s -= G[j][m] * G[j][m];
         float inv = frsqrt(s);
         G[j][j] = inv;  // 1 / G_jj
 #pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
+        for (int i = j + 1; i < NB; ++i) {
           float t = Cb[BI::at(j, i)];
 #pragma unroll
           for (int m = 0; m < j; ++m) t -= G[i][m] * G[j][m];
           G[i][j] = t * inv;
         }
       }
-      float y6[6];
+      float y6[NB];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
+      for (int j = 0; j < NB; ++j) {
         float t = db[j];
 #pragma unroll
         for (int m = 0; m < j; ++m) t -= G[j][m] * y6[m];
         y6[j] = t * G[j][j];
       }
 #pragma unroll
-      for (int j = 5; j >= 0; --j) {
+      for (int j = NB - 1; j >= 0; --j) {
         float t = y6[j];
 #pragma unroll
-        for (int i = j + 1; i < 6; ++i) t -= G[i][j] * nu0[i];
+        for (int i = j + 1; i < NB; ++i) t -= G[i][j] * nu0[i];
         nu0[j] = t * G[j][j];
       }
     }
-    float qdn[CL];
+    float qdn[JX];
 #pragma unroll
     for (int j = CL - 1; j >= 0; --j) {
       float t = z[j];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) t -= Y[r][j] * nu0[r];
+      for (int r = 0; r < NB; ++r) t -= Y[r][j] * nu0[r];
 #pragma unroll
       for (int i = j + 1; i < CL; ++i) t -= Lc[i][j] * qdn[i];
       qdn[j] = t * Lc[j][j];
     }
 #pragma unroll
-    for (int j = 0; j < CL; ++j) qdn[j] = clampf(qdn[j], -L.vel_limit[j], L.vel_limit[j]);
+    for (int i = 0; i < NW; ++i) qdn[CL + i] = nu0[6 + i];
+#pragma unroll
+    for (int j = 0; j < JX; ++j) qdn[j] = clampf(qdn[j], -L.vel_limit[j], L.vel_limit[j]);
 
     // ---- contact sensor: net contact force per body with the NEW velocities (world frame)
     SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
@@ -628,7 +755,7 @@ struct EnvLane {
       sphere_center(C, Rwb, g, s, rad, cb, cw);
       Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
       if (c.act) {
-        V3 uu = point_velocity<CL>(C, g, c.x, V0n, qdn);
+        V3 uu = point_velocity<TP>(C, wdepth(g), g, c.x, V0n, qdn);
         float un = dot(c.n, uu);
         V3 Fb = (c.bias - (c.dn - c.dt) * un) * c.n - c.dt * uu;
         V3 Fw = mul(Rwb, Fb);
@@ -638,7 +765,7 @@ struct EnvLane {
           if (b == slot) fslot[b] += Fw;
       }
     }
-    // base-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes)
+    // trunk-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes)
     for (int bi = 0; bi < T.n_base_bodies; ++bi) {
       bool mine = L.base_body_local == bi;
       V3 f{ctx.esum(mine ? fslot[0].x : 0.f), ctx.esum(mine ? fslot[0].y : 0.f), ctx.esum(mine ? fslot[0].z : 0.f)};
@@ -662,7 +789,7 @@ struct EnvLane {
     }
     // ---- integrate (semi-implicit Euler: new velocities move the positions)
 #pragma unroll
-    for (int j = 0; j < CL; ++j) {
+    for (int j = 0; j < JX; ++j) {
       qacc[j] = (qdn[j] - qd[j]) * u.inv_dt;
       q[j] += dt * qdn[j];
       qd[j] = qdn[j];

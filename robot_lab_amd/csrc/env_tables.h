@@ -1,8 +1,10 @@
 // env_tables.h - device-side tables and state layout of the env-step lane program.
 //
-// Lane mapping (DESIGN.md "Lane mapping"): an environment is simulated by NLANE = 4 adjacent lanes of
-// a wavefront; lane k owns kinematic chain k (one leg: hip -> thigh -> calf [-> wheel]) and a share of
-// the base link's collision spheres.  16 environments per 64-wide wavefront.
+// Lane mapping (DESIGN.md "Lane mapping"): an environment is simulated by NLANE = 4 lane groups of a
+// wavefront; group k owns limb chain k (a quadruped leg hip -> thigh -> calf [-> wheel]; a G1 leg or
+// arm) and a share of the collision spheres of a trunk link.  The *trunk* is the base link plus an
+// optional serial chain of NW joints hanging off it (G1: waist yaw/roll/pitch -> torso, which carries
+// the arms); its joints are simulated redundantly by all lanes.
 //
 // HBM layout: wave-tiled structure-of-arrays (see "HBM state layout" below).
 #pragma once
@@ -12,11 +14,24 @@
 
 namespace rl {
 
-constexpr int NLANE = 4;    // lanes (= chains) per environment
-constexpr int MAX_CL = 4;   // joints per chain
-constexpr int SPL = 3;      // collision-sphere slots per link group
-constexpr int NGRP = MAX_CL + 1;  // link groups per lane: 0 = share of the base link, 1..CL = chain links
-constexpr int NBS = 6;      // body slots per lane: 0 = a base-link body (or empty), 1.. = chain bodies
+constexpr int NLANE = 4;    // lane groups (= limb chains) per environment
+constexpr int MAX_CL = 7;   // joints per limb chain (A1 3, Go2W 4, G1 arm 7)
+constexpr int MAX_NW = 3;   // trunk joints (G1 waist)
+constexpr int MAX_JX = MAX_CL + MAX_NW;  // per-lane joint arrays: [0, CL) limb joints, [CL, CL+NW) trunk joints
+constexpr int MAX_SPL = 4;  // collision-sphere slots per link group
+constexpr int MAX_NGRP = MAX_CL + 1;  // link groups per lane: 0 = share of a trunk link, 1..CL = limb links
+constexpr int MAX_NBS = 9;  // body slots per lane: 0 = a trunk-link body (or empty), 1.. = limb bodies / sphere-less trunk bodies
+
+// Compile-time shape of a lane program instance: limb chain length, trunk joints, sphere slots per link
+// group, body slots per lane.  Loops are bounded by these (the tables / HBM layout by the MAX_* above).
+template <int CL_, int NW_, int SPL_, int NBS_>
+struct Topo {
+  static constexpr int CL = CL_, NW = NW_, SPL = SPL_, NBS = NBS_, JX = CL_ + NW_, NB = 6 + NW_;
+  static constexpr bool ROT = NW_ > 0;  // joint frames may be rotated w.r.t. the parent link (URDF joint rpy)
+};
+using TopoQuad3 = Topo<3, 0, 3, 6>;  // A1, Go2
+using TopoQuad4 = Topo<4, 0, 3, 6>;  // Go2W
+using TopoG1 = Topo<7, 3, 4, 9>;     // G1 29-DoF
 constexpr int MAX_T = 40;   // reward terms
 constexpr int MAX_OBS = 12;
 constexpr int MAX_BASE_BODIES = 4;
@@ -25,23 +40,29 @@ constexpr int LOG_SIZE = 64;
 // log accumulator slots (device LOG buffer)
 enum { LOG_RESET_COUNT = 0, LOG_TERM_TIMEOUT = 1, LOG_TERM_OOB = 2, LOG_TERM_ILLEGAL = 3, LOG_METRIC_XY = 4, LOG_METRIC_YAW = 5, LOG_EP_SUM0 = 8 };
 
-struct LaneTab {  // one per chain k
-  float origin[MAX_CL][3], axis[MAX_CL][3];
-  float lower[MAX_CL], upper[MAX_CL], vel_limit[MAX_CL], armature[MAX_CL];
-  float q0[MAX_CL], qd0[MAX_CL], soft_lo[MAX_CL], soft_hi[MAX_CL];
-  int32_t act_implicit[MAX_CL];
-  float kp0[MAX_CL], kd0[MAX_CL], eff[MAX_CL], sat[MAX_CL], act_vlim[MAX_CL];
-  int32_t action_is_vel[MAX_CL];
-  float a_scale[MAX_CL], a_off[MAX_CL], a_lo[MAX_CL], a_hi[MAX_CL];
-  int32_t joint_id[MAX_CL];            // task joint index (bit in joint masks, column in action/obs)
-  float sph_c[NGRP][SPL][3];
-  float sph_r[NGRP][SPL];              // <= 0: empty slot
-  int32_t sph_slot[NGRP][SPL];         // body slot the sphere reports to
-  int32_t slot_body[NBS];              // global body index (bit in body masks), -1 = empty
-  int32_t slot_grp[NBS];               // link group the body is attached to
-  float slot_pos[NBS][3];              // body frame origin in its link frame
-  int32_t base_body_local;             // which base-link body (0..n_base_bodies-1) slot 0 / group 0 belongs to, -1 none
-  int32_t owns_base_body;              // 1 if this lane keeps the timers of that base-link body
+struct LaneTab {  // one per limb chain k.  Joint arrays: [0, CL) the limb, [CL, CL+NW) the trunk joints (same in all lanes)
+  float origin[MAX_JX][3], axis[MAX_JX][3];
+  float rot0[MAX_JX][9];               // joint frame axes in the parent link frame, row-major (identity on the quadrupeds)
+  float lower[MAX_JX], upper[MAX_JX], vel_limit[MAX_JX], armature[MAX_JX];
+  float q0[MAX_JX], qd0[MAX_JX], soft_lo[MAX_JX], soft_hi[MAX_JX];
+  int32_t act_implicit[MAX_JX];
+  float kp0[MAX_JX], kd0[MAX_JX], eff[MAX_JX], sat[MAX_JX], act_vlim[MAX_JX];
+  int32_t action_is_vel[MAX_JX];
+  float a_scale[MAX_JX], a_off[MAX_JX], a_lo[MAX_JX], a_hi[MAX_JX];
+  int32_t joint_id[MAX_JX];            // task joint index (bit in joint masks, column in action/obs); -1 = padding (chain shorter than CL)
+  int32_t joint_own[MAX_JX];           // 1: this lane accounts for the joint in reward sums / observation columns / debug views
+                                       //    (limb joints: always; trunk joints: lane 0 only)
+  int32_t nj;                          // joints of this limb (<= CL)
+  int32_t attach;                      // trunk joints that move the limb (0: hangs off the base, NW: off the last trunk link)
+  int32_t grp0_depth;                  // trunk joints that move link group 0 of this lane
+  float sph_c[MAX_NGRP][MAX_SPL][3];
+  float sph_r[MAX_NGRP][MAX_SPL];      // <= 0: empty slot
+  int32_t sph_slot[MAX_NGRP][MAX_SPL]; // body slot the sphere reports to
+  int32_t slot_body[MAX_NBS];          // global body index (bit in body masks), -1 = empty
+  int32_t slot_grp[MAX_NBS];           // link group the body is attached to
+  float slot_pos[MAX_NBS][3];          // body frame origin in its link frame
+  int32_t base_body_local;             // which sphere-carrying trunk body (0..n_base_bodies-1) slot 0 / group 0 belongs to, -1 none
+  int32_t owns_base_body;              // 1 if this lane keeps the timers of that trunk body
 };
 
 struct RewTab {
@@ -63,8 +84,11 @@ struct ObsTab {
 
 struct Tables {
   LaneTab lane[NLANE];
-  int32_t CL, D, n_bodies, n_base_bodies;
+  int32_t CL, NW, SPL, NBS, D, n_bodies, n_base_bodies;
   uint32_t slot_valid;  // bit g*SPL+s: some lane has a collision sphere in slot (g, s)
+  int32_t wrench_depth; // trunk link (0 = base, i = after i trunk joints) carrying the body the wrench / COM events address
+  int32_t scan_depth;   // trunk link carrying the height-scanner body
+  float scan_pos[3];    // scanner body origin in that link's frame
   // sim
   float dt;
   int32_t decimation;
@@ -102,7 +126,8 @@ enum { CMD_VX = 0, CMD_VY, CMD_WZ, CMD_HEADING, CMD_TIME_LEFT, CMD_METRIC_XY, CM
 constexpr int INERTIA_NF = 10;
 
 // ---- HBM state layout: wave-tiled structure-of-arrays -------------------------------------------
-// A tile is the state of one wavefront (16 envs, or 4 envs in the 16-lanes-per-env mapping).  Inside a
+// A tile is the state of one wavefront (16 envs, or 4 envs in the 16-lanes-per-env mapping).  Rows are
+// laid out for the MAX_* shape (unused rows are never touched, so they cost address space only).  Inside a
 // tile every field is one contiguous row: one float per leg for lane fields, one per env for env fields.  A wavefront therefore
 // reads/writes whole coalesced rows, and - the reason for tiling rather than [field][N] planes - every
 // access is `tile base (SGPR) + lane offset (ONE VGPR) + compile-time row offset`; with [field][N]
@@ -110,16 +135,18 @@ constexpr int INERTIA_NF = 10;
 enum {  // lane fields (rows of 64)
   LF_Q = 0, LF_QD = LF_Q + MAX_CL, LF_KP = LF_QD + MAX_CL, LF_KD = LF_KP + MAX_CL, LF_ACT = LF_KD + MAX_CL,
   LF_INERTIA = LF_ACT + MAX_CL,                    // [MAX_CL][10]
-  LF_TIMERS = LF_INERTIA + MAX_CL * INERTIA_NF,    // [NBS][4] current_air, current_contact, last_air, last_contact
-  LF_FRICTION = LF_TIMERS + NBS * 4,               // [NBS][3] mu_s, mu_d, restitution
-  NF_LANE = LF_FRICTION + NBS * 3
+  LF_TIMERS = LF_INERTIA + MAX_CL * INERTIA_NF,    // [MAX_NBS][4] current_air, current_contact, last_air, last_contact
+  LF_FRICTION = LF_TIMERS + MAX_NBS * 4,           // [MAX_NBS][3] mu_s, mu_d, restitution
+  NF_LANE = LF_FRICTION + MAX_NBS * 3
 };
 enum {  // env fields (rows of 16)
   EF_ROOT = 0,                 // pos(3) quat wxyz(4) lin vel (3, world, link origin) ang vel (3, world)
   EF_WRENCH = EF_ROOT + 13,    // force(3) torque(3), base-body frame
-  EF_BASE_INERTIA = EF_WRENCH + 6,
-  EF_BASE_COM = EF_BASE_INERTIA + INERTIA_NF,  // COM of the base *body* in the base frame
-  EF_CMD = EF_BASE_COM + 3,
+  EF_BASE_INERTIA = EF_WRENCH + 6,             // [1 + MAX_NW][10] trunk links: base, then the link after each trunk joint
+  EF_BASE_COM = EF_BASE_INERTIA + (1 + MAX_NW) * INERTIA_NF,  // COM of the root *body* in the base frame (root COM velocity)
+  EF_WR_COM = EF_BASE_COM + 3,                 // COM of the wrench body in its trunk link frame
+  EF_TQ = EF_WR_COM + 3, EF_TQD = EF_TQ + MAX_NW, EF_TKP = EF_TQD + MAX_NW, EF_TKD = EF_TKP + MAX_NW, EF_TACT = EF_TKD + MAX_NW,  // trunk joints
+  EF_CMD = EF_TACT + MAX_NW,
   EF_ORIGIN = EF_CMD + CMD_NFIELD,
   NF_ENV = EF_ORIGIN + 3
 };

@@ -12,7 +12,8 @@ enum RewKind {
   REW_JOINT_ACC_L2, REW_JOINT_POS_LIMITS, REW_JOINT_POWER, REW_STAND_STILL, REW_JOINT_POS_PENALTY, REW_JOINT_MIRROR,
   REW_ACTION_RATE_L2, REW_UNDESIRED_CONTACTS, REW_CONTACT_FORCES, REW_FEET_CONTACT_WITHOUT_CMD, REW_FEET_HEIGHT_BODY,
   REW_UPWARD, REW_FEET_AIR_TIME, REW_FEET_AIR_TIME_VARIANCE, REW_FEET_SLIDE, REW_FEET_GAIT, REW_FLAT_ORIENTATION_L2,
-  REW_IS_TERMINATED, REW_JOINT_DEVIATION_L1, REW_JOINT_VEL_L2, REW_FEET_CONTACT, REW_FEET_STUMBLE, REW_FEET_HEIGHT
+  REW_IS_TERMINATED, REW_JOINT_DEVIATION_L1, REW_JOINT_VEL_L2, REW_FEET_CONTACT, REW_FEET_STUMBLE, REW_FEET_HEIGHT,
+  REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP, REW_TRACK_ANG_VEL_Z_WORLD_EXP, REW_FEET_AIR_TIME_POSITIVE_BIPED
 };
 enum ObsKind {
   OBS_BASE_LIN_VEL = 0, OBS_BASE_ANG_VEL, OBS_PROJECTED_GRAVITY, OBS_VELOCITY_COMMANDS, OBS_JOINT_POS_REL,
@@ -38,15 +39,16 @@ struct GenericSpec {
   static constexpr bool generic = true;
 };
 
-template <class Ctx, int CL, class Spec = GenericSpec>
-struct EnvProgram : EnvLane<Ctx, CL> {
-  using Base = EnvLane<Ctx, CL>;
+template <class Ctx, class TP, class Spec = GenericSpec>
+struct EnvProgram : EnvLane<Ctx, TP> {
+  using Base = EnvLane<Ctx, TP>;
+  static constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NBS = TP::NBS;
   using Base::ctx; using Base::S; using Base::T; using Base::L; using Base::e; using Base::k; using Base::sub; using Base::li; using Base::Np;
   static constexpr int SUB = Base::SUB;
   static constexpr int LPE = Base::LPE;
   using Base::pos; using Base::quat; using Base::vlin; using Base::vang; using Base::q; using Base::qd; using Base::kp; using Base::kd;
   using Base::act; using Base::prev_act; using Base::tim; using Base::cf; using Base::hist_n; using Base::tau_app; using Base::qacc;
-  using Base::extF; using Base::extT; using Base::base_com;
+  using Base::extF; using Base::extT; using Base::base_com; using Base::wr_com;
 
   // command / bookkeeping registers (identical in the 4 lanes of a group)
   V3 cmd;
@@ -148,8 +150,8 @@ struct EnvProgram : EnvLane<Ctx, CL> {
               U(STREAM_RESET, IDX_WRENCH + 5, T.wrench_torque[0], T.wrench_torque[1])};
     }
 #pragma unroll
-    for (int j = 0; j < CL; ++j) {
-      uint32_t ji = (uint32_t)L.joint_id[j];
+    for (int j = 0; j < JX; ++j) {
+      uint32_t ji = (uint32_t)(L.joint_id[j] < 0 ? 0 : L.joint_id[j]);  // padding joints: q0 = qd0 = kp0 = kd0 = 0
       float qn = L.q0[j], qdn = L.qd0[j];
       if (T.ev_reset_joints) {  // reset_joints_by_scale [UPSTREAM B8]
         qn = clampf(L.q0[j] * U(STREAM_RESET, IDX_JPOS + ji, T.reset_jpos[0], T.reset_jpos[1]), L.soft_lo[j], L.soft_hi[j]);
@@ -208,27 +210,29 @@ struct EnvProgram : EnvLane<Ctx, CL> {
   RL_FN float hist_max(int slot) const { return fmaxf(hist_n[slot][0], fmaxf(hist_n[slot][1], hist_n[slot][2])); }
 
   // position (base coords) and velocity relative to the root COM velocity (base coords) of body slot s
-  RL_FN void body_rel(const Chain<CL>& C, int s, V3& relp, V3& relv) const {
+  RL_FN void body_rel(const Chain<TP>& C, int s, V3& relp, V3& relv) const {
     int g = L.slot_grp[s];
     V3 bp = ld3(L.slot_pos[s]);
     V3 x = bp;
+    if (NW > 0) {
+      M3 Rf;
+      V3 pf;
+      C.trunk_frame(L.grp0_depth, Rf, pf);
+      x = pf + mul(Rf, bp);
+    }
 #pragma unroll
     for (int j = 0; j < CL; ++j)
       if (g == j + 1) x = C.p[j] + mul(C.R[j], bp);
     relp = x;
-    V3 v = cross(ang_b, x - base_com);
-#pragma unroll
-    for (int i = 0; i < CL; ++i)
-      if (i < g) v += qd[i] * cross(C.ax[i], x - C.p[i]);
-    relv = v;
+    relv = point_velocity<TP>(C, this->wdepth(g), g, x, SV{ang_b, cross(base_com, ang_b)}, qd);  // relative to the root COM velocity
   }
 
   struct RewCtx {
     float gate, cmd_norm, bv, fc_hi;
     bool terminated;
-    Chain<CL> C;
-    int sbody[NBS], jid[CL];
-    float hmax[NBS], t_ca[NBS], t_cc[NBS], t_la[NBS], t_lc[NBS], q0j[CL], slo[CL], shi[CL];
+    Chain<TP> C;
+    int sbody[NBS], jid[JX];  // jid: task joint index of the joints this lane accounts for, else -1
+    float hmax[NBS], t_ca[NBS], t_cc[NBS], t_la[NBS], t_lc[NBS], q0j[JX], slo[JX], shi[JX];
   };
 
   // one reward term: unweighted value f (all lanes of the env return the same number)
@@ -236,17 +240,17 @@ struct EnvProgram : EnvLane<Ctx, CL> {
   RL_FN float reward_term(const RD& R, const RewCtx& rc) {
     const float gate = rc.gate, cmd_norm = rc.cmd_norm, bv = rc.bv;
     const bool terminated = rc.terminated;
-    const Chain<CL>& C = rc.C;
+    const Chain<TP>& C = rc.C;
     const int(&sbody)[NBS] = rc.sbody;
-    const int(&jid)[CL] = rc.jid;
+    const int(&jid)[JX] = rc.jid;
     const float(&hmax)[NBS] = rc.hmax;
     const float(&t_ca)[NBS] = rc.t_ca;
     const float(&t_cc)[NBS] = rc.t_cc;
     const float(&t_la)[NBS] = rc.t_la;
     const float(&t_lc)[NBS] = rc.t_lc;
-    const float(&q0j)[CL] = rc.q0j;
-    const float(&slo)[CL] = rc.slo;
-    const float(&shi)[CL] = rc.shi;
+    const float(&q0j)[JX] = rc.q0j;
+    const float(&slo)[JX] = rc.slo;
+    const float(&shi)[JX] = rc.shi;
     const float fc_hi = rc.fc_hi;
     auto in_mask = [&](uint64_t mask, int s) { return sbody[s] >= 0 && ((mask >> sbody[s]) & 1ull); };
     auto first_c = [&](int s) { return t_cc[s] > 0.f && t_cc[s] < fc_hi; };
@@ -260,6 +264,28 @@ struct EnvProgram : EnvLane<Ctx, CL> {
           float ez = cmd.z - ang_b.z;
           f = expf(-(ez * ez) / R.p[0]) * gate;
         } break;
+        case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // rewards.py:51-66: root COM velocity in the yaw-only frame
+          const float cy = cosf(heading_w), sy = sinf(heading_w);
+          float ex = cmd.x - (cy * lin_w.x + sy * lin_w.y), ey = cmd.y - (-sy * lin_w.x + cy * lin_w.y);
+          f = expf(-(ex * ex + ey * ey) / R.p[0]) * gate;
+        } break;
+        case REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // rewards.py:69-78
+          float ez = cmd.z - vang.z;
+          f = expf(-(ez * ez) / R.p[0]) * gate;
+        } break;
+        case REW_FEET_AIR_TIME_POSITIVE_BIPED: {  // rewards.py:363-383
+          float nc = 0.f, mn = 1e30f;
+#pragma unroll
+          for (int s = 0; s < NBS; ++s) {
+            if (!in_mask(R.body_mask, s)) continue;
+            bool inc = t_cc[s] > 0.f;
+            nc += inc ? 1.f : 0.f;
+            mn = fminf(mn, inc ? t_cc[s] : t_ca[s]);
+          }
+          nc = ctx.esum(nc);
+          mn = ctx.emin(mn);
+          f = (nc == 1.f ? fminf(mn, R.p[0]) : 0.f) * (cmd_norm > 0.1f ? 1.f : 0.f) * gate;
+        } break;
         case REW_LIN_VEL_Z_L2: f = lin_b.z * lin_b.z * gate; break;                         // rewards.py:647-653
         case REW_ANG_VEL_XY_L2: f = (ang_b.x * ang_b.x + ang_b.y * ang_b.y) * gate; break;  // rewards.py:656-662
         case REW_FLAT_ORIENTATION_L2: f = (grav_b.x * grav_b.x + grav_b.y * grav_b.y) * gate; break;  // rewards.py:678-687
@@ -270,8 +296,8 @@ struct EnvProgram : EnvLane<Ctx, CL> {
         case REW_ACTION_RATE_L2: {
           float part = 0.f;
 #pragma unroll
-          for (int j = 0; j < CL; ++j) {
-            bool in = (R.joint_mask >> jid[j]) & 1u;
+          for (int j = 0; j < JX; ++j) {
+            bool in = jid[j] >= 0 && ((R.joint_mask >> (jid[j] & 31)) & 1u);
             float v = 0.f;
             switch (R.kind) {
               case REW_JOINT_TORQUES_L2: v = tau_app[j] * tau_app[j]; break;
@@ -281,7 +307,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
               case REW_JOINT_POWER: v = fabsf(qd[j] * tau_app[j]); break;  // rewards.py:81-90
               case REW_JOINT_DEVIATION_L1: case REW_STAND_STILL: v = fabsf(q[j] - q0j[j]); break;
               case REW_JOINT_POS_PENALTY: v = (q[j] - q0j[j]) * (q[j] - q0j[j]); break;
-              case REW_ACTION_RATE_L2: v = (act[j] - prev_act[j]) * (act[j] - prev_act[j]); in = true; break;
+              case REW_ACTION_RATE_L2: v = (act[j] - prev_act[j]) * (act[j] - prev_act[j]); in = jid[j] >= 0; break;
               default: break;
             }
             part += in ? v : 0.f;
@@ -404,7 +430,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     rc.cmd_norm = norm(cmd);
     rc.bv = fsqrt(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
     rc.terminated = terminated;
-    chain_kinematics<CL>(L, q, rc.C);
+    chain_kinematics<TP>(L, q, rc.C);
     // per-slot sensor data and per-joint constants: one batch of LDS reads up front instead of dependent
     // reads inside every term
 #pragma unroll
@@ -415,8 +441,8 @@ struct EnvProgram : EnvLane<Ctx, CL> {
       rc.t_ca[s] = tim[s][0]; rc.t_cc[s] = tim[s][1]; rc.t_la[s] = tim[s][2]; rc.t_lc[s] = tim[s][3];
     }
 #pragma unroll
-    for (int j = 0; j < CL; ++j) {
-      rc.jid[j] = L.joint_id[j]; rc.q0j[j] = L.q0[j]; rc.slo[j] = L.soft_lo[j]; rc.shi[j] = L.soft_hi[j];
+    for (int j = 0; j < JX; ++j) {
+      rc.jid[j] = L.joint_own[j] ? L.joint_id[j] : -1; rc.q0j[j] = L.q0[j]; rc.slo[j] = L.soft_lo[j]; rc.shi[j] = L.soft_hi[j];
     }
     rc.fc_hi = T.step_dt + 1e-8f;
     float total = 0.f;
@@ -482,7 +508,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
   // ---------------------------------------------------------------- observations [UPSTREAM B2 / B6]
   // one observation term: value -> +noise -> clip -> scale -> its columns of the LDS-staged row
   template <class OD>
-  RL_FN void obs_term(const OD& O, float* stage, bool corrupt, uint32_t noise_base, float cy, float sy) {
+  RL_FN void obs_term(const OD& O, float* stage, bool corrupt, uint32_t noise_base, float cy, float sy, V3 scan_p) {
     auto put = [&](int col, float v) {
         if (corrupt && O.has_noise) v += U(STREAM_NOISE, noise_base + (uint32_t)col, O.noise_lo, O.noise_hi);
         stage[col] = clampf(v, O.clip_lo, O.clip_hi) * O.scale;
@@ -494,8 +520,9 @@ struct EnvProgram : EnvLane<Ctx, CL> {
         case OBS_VELOCITY_COMMANDS: if (li < 3) put(O.offset + li, comp(cmd, li)); break;
         case OBS_JOINT_POS_REL: case OBS_JOINT_POS_REL_NO_WHEEL: case OBS_JOINT_VEL_REL: case OBS_LAST_ACTION:
 #pragma unroll
-          for (int j = 0; j < CL; ++j) {
+          for (int j = 0; j < JX; ++j) {
             if (SUB > 1 && (j % SUB) != sub) continue;  // the leg's sub-lanes share its joints
+            if (!L.joint_own[j]) continue;              // padding / trunk joints accounted for by lane 0
             float v = O.kind == OBS_JOINT_VEL_REL ? qd[j] - L.qd0[j] : O.kind == OBS_LAST_ACTION ? act[j] : q[j] - L.q0[j];
             if (O.kind == OBS_JOINT_POS_REL_NO_WHEEL && ((T.wheel_joint_mask >> L.joint_id[j]) & 1u)) v = 0.f;
             put(O.offset + L.joint_id[j], v);
@@ -514,7 +541,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
               r = r < nr ? r : nr - 1;
               int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
               float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
-              tp[i] = terrain_fetch(this->u, S.terrain, pos.x + cy * lx - sy * ly, pos.y + sy * lx + cy * ly);
+              tp[i] = terrain_fetch(this->u, S.terrain, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
@@ -522,7 +549,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
               float hz;
               V3 nn;
               terrain_eval(this->u, tp[i], hz, nn);
-              if (r < nr) put(O.offset + r, pos.z - hz - soff);
+              if (r < nr) put(O.offset + r, scan_p.z - hz - soff);
             }
           }
         } break;
@@ -530,8 +557,27 @@ struct EnvProgram : EnvLane<Ctx, CL> {
       }
   }
 
+  // pose of the height scanner: the root link on the quadrupeds, the torso on G1 (rides on trunk link scan_depth)
+  RL_FN void scanner_pose(float& cy, float& sy, V3& scan_p) {
+    if (NW == 0) {
+      cy = cosf(heading_w); sy = sinf(heading_w); scan_p = pos;
+      return;
+    }
+    Chain<TP> C;
+    chain_kinematics<TP>(L, q, C);
+    M3 Rf;
+    V3 pf;
+    C.trunk_frame(T.scan_depth, Rf, pf);
+    const M3 Rs = mul(Rwb, Rf);
+    const float yaw = atan2f(Rs.r1.x, Rs.r0.x);
+    cy = cosf(yaw); sy = sinf(yaw);
+    scan_p = pos + mul(Rwb, pf + mul(Rf, V3{T.scan_pos[0], T.scan_pos[1], T.scan_pos[2]}));
+  }
+
   RL_FN void write_obs(float* stage, const ObsTab* terms, int n, bool corrupt, uint32_t noise_base) {
-    const float cy = cosf(heading_w), sy = sinf(heading_w);
+    float cy, sy;
+    V3 scan_p;
+    scanner_pose(cy, sy, scan_p);
     n = ctx.uniform_i(n);
     for (int i = 0; i < n; ++i) {
       const ObsTab& Ol = terms[i];
@@ -539,7 +585,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
       O.kind = ctx.uniform_i(Ol.kind); O.has_noise = ctx.uniform_i(Ol.has_noise); O.offset = ctx.uniform_i(Ol.offset);
       O.scale = ctx.uniform(Ol.scale); O.clip_lo = ctx.uniform(Ol.clip_lo); O.clip_hi = ctx.uniform(Ol.clip_hi);
       O.noise_lo = ctx.uniform(Ol.noise_lo); O.noise_hi = ctx.uniform(Ol.noise_hi);
-      obs_term(O, stage, corrupt, noise_base, cy, sy);
+      obs_term(O, stage, corrupt, noise_base, cy, sy, scan_p);
     }
   }
 
@@ -551,11 +597,13 @@ struct EnvProgram : EnvLane<Ctx, CL> {
       write_obs(sp, T.policy, T.n_policy, T.policy_corrupt != 0, 0u);
       write_obs(sc, T.critic, T.n_critic, T.critic_corrupt != 0, 1024u);
     } else {
-      const float cy = cosf(heading_w), sy = sinf(heading_w);
+      float cy, sy;
+      V3 scan_p;
+      scanner_pose(cy, sy, scan_p);
 #pragma unroll
-      for (int i = 0; i < Spec::n_policy; ++i) obs_term(Spec::policy[i], sp, Spec::policy_corrupt, 0u, cy, sy);
+      for (int i = 0; i < Spec::n_policy; ++i) obs_term(Spec::policy[i], sp, Spec::policy_corrupt, 0u, cy, sy, scan_p);
 #pragma unroll
-      for (int i = 0; i < Spec::n_critic; ++i) obs_term(Spec::critic[i], sc, Spec::critic_corrupt, 1024u, cy, sy);
+      for (int i = 0; i < Spec::n_critic; ++i) obs_term(Spec::critic[i], sc, Spec::critic_corrupt, 1024u, cy, sy, scan_p);
     }
     ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
     ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
@@ -565,11 +613,11 @@ struct EnvProgram : EnvLane<Ctx, CL> {
   RL_FN void step() {
     this->load();
     // 1 ActionManager.process_action [UPSTREAM B2]; JointPosition/VelocityAction (velocity_env_cfg.py:124-126)
-    float q_tgt[CL], qd_tgt[CL];
+    float q_tgt[JX], qd_tgt[JX];
 #pragma unroll
-    for (int j = 0; j < CL; ++j) {
+    for (int j = 0; j < JX; ++j) {
       prev_act[j] = act[j];
-      float a = e < S.N ? S.action_in[(size_t)e * T.D + L.joint_id[j]] : 0.f;
+      float a = (e < S.N && L.joint_id[j] >= 0) ? S.action_in[(size_t)e * T.D + L.joint_id[j]] : 0.f;
       act[j] = a;
       float pr = clampf(a * L.a_scale[j] + L.a_off[j], L.a_lo[j], L.a_hi[j]);
       q_tgt[j] = L.action_is_vel[j] ? 0.f : pr;
@@ -580,7 +628,8 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     if (S.dbg_torque != nullptr) {
       if (sub == 0)
 #pragma unroll
-      for (int j = 0; j < CL; ++j) {
+      for (int j = 0; j < JX; ++j) {
+        if (!L.joint_own[j]) continue;
         S.dbg_torque[(size_t)e * T.D + L.joint_id[j]] = tau_app[j];
         S.dbg_acc[(size_t)e * T.D + L.joint_id[j]] = qacc[j];
       }
@@ -668,7 +717,7 @@ struct EnvProgram : EnvLane<Ctx, CL> {
     this->load();
     load_task();
 #pragma unroll
-    for (int j = 0; j < CL; ++j) prev_act[j] = act[j];
+    for (int j = 0; j < JX; ++j) prev_act[j] = act[j];
     if (S.reset_mask == nullptr || S.reset_mask[e]) reset_env(false);
     observations();
     this->store();

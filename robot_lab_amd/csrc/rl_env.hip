@@ -73,6 +73,16 @@ struct WaveCtx {
     return v;
   }
   __device__ float esum(float v) const { return gsum(leg_sum(v)); }
+  // min over the lanes of the env
+  __device__ float emin(float v) const {
+    v = fminf(v, dpp<DPP_QUAD_XOR1>(v));
+    v = fminf(v, dpp<DPP_QUAD_XOR2>(v));
+    if (SUB > 1) {
+      v = fminf(v, dpp<DPP_ROW_HALF_MIRROR>(v));
+      v = fminf(v, dpp<DPP_ROW_MIRROR>(v));
+    }
+    return v;
+  }
   __device__ float gshfl(float v, int leg) const { return __shfl(v, SUB == 1 ? ((lane & ~3) | leg) : ((lane & ~15) | (leg << 2) | (lane & 3))); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
   __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }
@@ -95,7 +105,7 @@ struct WaveCtx {
 
 extern __shared__ float4 smem4[];
 
-template <int CL, int RESET, int SUB>
+template <class TP, int RESET, int SUB>
 __global__ __launch_bounds__(64) void env_kernel(KState S, const Tables* __restrict__ Tg) {
   using Ctx = WaveCtx<SUB>;
   float* smem = reinterpret_cast<float*>(smem4);
@@ -118,9 +128,9 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const Tables* __restr
   ctx.stage[0] = smem + TAB_F;
   ctx.stage[1] = ctx.stage[0] + ((Ctx::EPT * ctx.dim[0] + 3) & ~3);
   ctx.lscratch = ctx.stage[1] + ((Ctx::EPT * ctx.dim[1] + 3) & ~3);
-  ctx.rstage = ctx.lscratch + LS_WORDS * 64;
+  ctx.rstage = ctx.lscratch + LsLayout<TP::NBS>::WORDS * 64;
   ctx.lane = lane;
-  EnvProgram<Ctx, CL> prog(ctx, S);
+  EnvProgram<Ctx, TP> prog(ctx, S);
   if (RESET)
     prog.reset_entry();
   else
@@ -164,13 +174,21 @@ struct Backend {
     if (const char* v = std::getenv("RL_ENV_SUB")) sub = atoi(v) == 1 ? 1 : 4;
     return 16 / sub;
   }
-  template <int CL, int SUB>
+  template <class TP, int SUB>
   int launch_cl(const KState& S, const Tables* T, int reset, size_t lds, hipStream_t st) {
     dim3 grid(S.Npad / (16 / SUB)), block(64);
+    if (lds > 64 * 1024) {  // opt in to the large LDS carve-out once per kernel (160 KB per CU on gfx950)
+      static bool done = false;
+      if (!done) {
+        if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 1, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
+        if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 0, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
+        done = true;
+      }
+    }
     if (reset)
-      hipLaunchKernelGGL((env_kernel<CL, 1, SUB>), grid, block, lds, st, S, T);
+      hipLaunchKernelGGL((env_kernel<TP, 1, SUB>), grid, block, lds, st, S, T);
     else
-      hipLaunchKernelGGL((env_kernel<CL, 0, SUB>), grid, block, lds, st, S, T);
+      hipLaunchKernelGGL((env_kernel<TP, 0, SUB>), grid, block, lds, st, S, T);
     return check(hipGetLastError());
   }
   size_t lds_bytes = 0;
@@ -179,9 +197,10 @@ struct Backend {
     size_t tab = (sizeof(Tables) + 15) / 16 * 16;
     size_t s0 = (ept * T.policy_dim + 3) / 4 * 16;
     size_t s1 = (ept * T.critic_dim + 3) / 4 * 16;
-    lds_bytes = tab + s0 + s1 + (size_t)LS_WORDS * 64 * 4 + ept * MAX_T * 4;
-    if (lds_bytes > 64 * 1024) {
-      err = "observation rows do not fit the default 64 KiB dynamic LDS";
+    const size_t ls_words = T.NBS == TopoG1::NBS ? LsLayout<TopoG1::NBS>::WORDS : LsLayout<TopoQuad3::NBS>::WORDS;
+    lds_bytes = tab + s0 + s1 + ls_words * 64 * 4 + ept * MAX_T * 4;
+    if (lds_bytes > 160 * 1024) {
+      err = "observation rows do not fit the 160 KiB LDS of a CU";
       return -1;
     }
     return 0;
@@ -189,10 +208,12 @@ struct Backend {
   int launch(const KState& S, const Tables* T, int CL, int reset, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     switch (CL * 10 + sub) {
-      case 31: return launch_cl<3, 1>(S, T, reset, lds_bytes, st);
-      case 41: return launch_cl<4, 1>(S, T, reset, lds_bytes, st);
-      case 34: return launch_cl<3, 4>(S, T, reset, lds_bytes, st);
-      case 44: return launch_cl<4, 4>(S, T, reset, lds_bytes, st);
+      case 31: return launch_cl<TopoQuad3, 1>(S, T, reset, lds_bytes, st);
+      case 41: return launch_cl<TopoQuad4, 1>(S, T, reset, lds_bytes, st);
+      case 34: return launch_cl<TopoQuad3, 4>(S, T, reset, lds_bytes, st);
+      case 44: return launch_cl<TopoQuad4, 4>(S, T, reset, lds_bytes, st);
+      case 71: return launch_cl<TopoG1, 1>(S, T, reset, lds_bytes, st);
+      case 74: return launch_cl<TopoG1, 4>(S, T, reset, lds_bytes, st);
       default: err = "unsupported chain length"; return -1;
     }
   }

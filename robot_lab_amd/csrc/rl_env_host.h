@@ -33,56 +33,116 @@ inline int obs_term_dim(const rl_env_desc& d, int kind) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// descriptor -> Tables.  Requires the star topology the lane program is written for.
+// descriptor -> Tables.  Requires the trunk + 4 limb chains topology the lane program is written for.
 // ------------------------------------------------------------------------------------------------
+inline void quat_to_rows(const float q[4], float R[9]) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  double n = sqrt(w * w + x * x + y * y + z * z);
+  if (n < 1e-12) { w = 1; x = y = z = 0; n = 1; }
+  w /= n; x /= n; y /= n; z /= n;
+  R[0] = (float)(1 - 2 * (y * y + z * z)); R[1] = (float)(2 * (x * y - w * z)); R[2] = (float)(2 * (x * z + w * y));
+  R[3] = (float)(2 * (x * y + w * z)); R[4] = (float)(1 - 2 * (x * x + z * z)); R[5] = (float)(2 * (y * z - w * x));
+  R[6] = (float)(2 * (x * z - w * y)); R[7] = (float)(2 * (y * z + w * x)); R[8] = (float)(1 - 2 * (x * x + y * y));
+}
+
+// shape of the lane-program instance that simulates this model (env_tables.h Topo<>)
+inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& NBS) {
+  if (m.num_chains != NLANE || m.chain_len < 1 || m.chain_len > MAX_CL || m.num_trunk < 0 || m.num_trunk > MAX_NW)
+    return fail("lane program needs a trunk of <= 3 serial joints carrying 4 limb chains of <= 7 joints (got " + std::to_string(m.num_chains) + " chains x " +
+                std::to_string(m.chain_len) + ", trunk " + std::to_string(m.num_trunk) + ")");
+  if (m.num_trunk == 0 && m.chain_len <= 4) { CL = m.chain_len < 3 ? 3 : m.chain_len; NW = 0; SPL = 3; NBS = 6; }
+  else { CL = 7; NW = 3; SPL = 4; NBS = 9; }
+  if (m.num_trunk != NW && m.num_trunk != 0) return fail("unsupported trunk length " + std::to_string(m.num_trunk));
+  return 0;
+}
+
 inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_lane, std::vector<int>& body_slot, std::vector<int>& link_lane_out,
                         std::vector<int>& link_pos_out) {
   memset(&T, 0, sizeof(T));
   const rl_model_desc& m = d.model;
-  if (m.num_chains != NLANE || m.chain_len < 1 || m.chain_len > MAX_CL)
-    return fail("lane program needs a star articulation with 4 chains of <= 4 joints (got " + std::to_string(m.num_chains) + "x" +
-                std::to_string(m.chain_len) + ")");
-  const int CL = m.chain_len;
-  T.CL = CL;
+  int CL, NW, SPL, NBS;
+  if (topo_shape(m, CL, NW, SPL, NBS)) return -1;
+  const int NGRP = CL + 1;
+  T.CL = CL; T.NW = NW; T.SPL = SPL; T.NBS = NBS;
   T.D = m.num_dof;
   T.n_bodies = m.num_bodies;
   body_lane.assign(m.num_bodies, -1);
   body_slot.assign(m.num_bodies, -1);
-  std::vector<int>& link_k = link_lane_out;
-  std::vector<int>& link_j = link_pos_out;
-  link_k.assign(m.num_links, -1);
+  std::vector<int>& link_k = link_lane_out;   // limb links: lane; trunk links: -1
+  std::vector<int>& link_j = link_pos_out;    // limb links: position in the chain; trunk links: trunk depth (0 = base)
+  link_k.assign(m.num_links, -2);
   link_j.assign(m.num_links, -1);
-  int n_base_bodies = 0;
+  link_k[0] = -1; link_j[0] = 0;
+  for (int i = 0; i < m.num_trunk; ++i) {
+    int link = m.trunk_link[i];
+    if (link < 1 || link >= m.num_links || m.link_parent[link] != (i == 0 ? 0 : m.trunk_link[i - 1])) return fail("trunk_link does not describe a serial chain off the base");
+    link_k[link] = -1; link_j[link] = i + 1;
+  }
+  auto fill_joint = [&](LaneTab& L, int jx, int link) {
+    const int jt = link - 1;
+    for (int c = 0; c < 3; ++c) { L.origin[jx][c] = m.link_origin[link][c]; L.axis[jx][c] = m.link_axis[link][c]; }
+    quat_to_rows(m.link_quat[link], L.rot0[jx]);
+    L.lower[jx] = m.joint_lower[jt]; L.upper[jx] = m.joint_upper[jt]; L.vel_limit[jx] = m.joint_vel_limit[jt];
+    L.armature[jx] = m.joint_armature[jt]; L.q0[jx] = m.default_joint_pos[jt]; L.qd0[jx] = m.default_joint_vel[jt];
+    L.soft_lo[jx] = m.soft_lower[jt]; L.soft_hi[jx] = m.soft_upper[jt];
+    L.act_implicit[jx] = m.act_implicit[jt]; L.kp0[jx] = m.act_kp[jt]; L.kd0[jx] = m.act_kd[jt];
+    L.eff[jx] = m.act_effort_limit[jt]; L.sat[jx] = m.act_saturation[jt]; L.act_vlim[jx] = m.act_vel_limit[jt];
+    L.action_is_vel[jx] = m.action_is_vel[jt]; L.a_scale[jx] = m.action_scale[jt]; L.a_off[jx] = m.action_offset[jt];
+    L.a_lo[jx] = m.action_clip_lo[jt]; L.a_hi[jx] = m.action_clip_hi[jt];
+    L.joint_id[jx] = jt;
+  };
   for (int k = 0; k < NLANE; ++k) {
     LaneTab& L = T.lane[k];
-    for (int s = 0; s < NBS; ++s) { L.slot_body[s] = -1; L.slot_grp[s] = 0; }
-    for (int g = 0; g < NGRP; ++g)
-      for (int s = 0; s < SPL; ++s) L.sph_r[g][s] = -1.f;
+    for (int s = 0; s < MAX_NBS; ++s) { L.slot_body[s] = -1; L.slot_grp[s] = 0; }
+    for (int g = 0; g < MAX_NGRP; ++g)
+      for (int s = 0; s < MAX_SPL; ++s) L.sph_r[g][s] = -1.f;
     L.base_body_local = -1;
-    for (int j = 0; j < CL; ++j) {
-      int link = m.chain_link[k][j], jt = link - 1;
-      if (link < 1 || link >= m.num_links || m.link_parent[link] != (j == 0 ? 0 : m.chain_link[k][j - 1])) return fail("chain_link does not describe serial chains off the base");
+    L.nj = m.chain_nj[k] > 0 ? m.chain_nj[k] : m.chain_len;  // descriptors written before chain_nj existed: equal chains
+    L.attach = m.chain_attach[k];
+    L.grp0_depth = L.attach;  // a lane's link group 0 is a share of the trunk link its limb hangs off
+    if (L.nj > CL || L.attach < 0 || L.attach > m.num_trunk) return fail("bad chain description");
+    for (int jx = 0; jx < MAX_JX; ++jx) {  // padding joints: inert (axis 0, no gains), velocity limit > 0 so clamps are no-ops
+      L.joint_id[jx] = -1; L.joint_own[jx] = 0; L.vel_limit[jx] = 1e9f; L.act_vlim[jx] = 1e9f; L.lower[jx] = -1e9f; L.upper[jx] = 1e9f;
+      L.a_lo[jx] = -1e30f; L.a_hi[jx] = 1e30f; L.act_implicit[jx] = 1;
+      L.rot0[jx][0] = L.rot0[jx][4] = L.rot0[jx][8] = 1.f;
+    }
+    for (int j = 0; j < L.nj; ++j) {
+      int link = m.chain_link[k][j];
+      int parent = j == 0 ? (L.attach == 0 ? 0 : m.trunk_link[L.attach - 1]) : m.chain_link[k][j - 1];
+      if (link < 1 || link >= m.num_links || m.link_parent[link] != parent) return fail("chain_link does not describe serial chains off the trunk");
       link_k[link] = k; link_j[link] = j;
-      for (int c = 0; c < 3; ++c) { L.origin[j][c] = m.link_origin[link][c]; L.axis[j][c] = m.link_axis[link][c]; }
-      L.lower[j] = m.joint_lower[jt]; L.upper[j] = m.joint_upper[jt]; L.vel_limit[j] = m.joint_vel_limit[jt];
-      L.armature[j] = m.joint_armature[jt]; L.q0[j] = m.default_joint_pos[jt]; L.qd0[j] = m.default_joint_vel[jt];
-      L.soft_lo[j] = m.soft_lower[jt]; L.soft_hi[j] = m.soft_upper[jt];
-      L.act_implicit[j] = m.act_implicit[jt]; L.kp0[j] = m.act_kp[jt]; L.kd0[j] = m.act_kd[jt];
-      L.eff[j] = m.act_effort_limit[jt]; L.sat[j] = m.act_saturation[jt]; L.act_vlim[j] = m.act_vel_limit[jt];
-      L.action_is_vel[j] = m.action_is_vel[jt]; L.a_scale[j] = m.action_scale[jt]; L.a_off[j] = m.action_offset[jt];
-      L.a_lo[j] = m.action_clip_lo[jt]; L.a_hi[j] = m.action_clip_hi[jt];
-      L.joint_id[j] = jt;
+      fill_joint(L, j, link);
+      L.joint_own[j] = 1;
+    }
+    for (int i = 0; i < m.num_trunk; ++i) {
+      fill_joint(L, CL + i, m.trunk_link[i]);
+      L.joint_own[CL + i] = k == 0 ? 1 : 0;
     }
   }
-  // bodies -> lane slots.  base-link bodies: one per lane, slot 0; chain bodies: slots 1..
+  for (int l = 0; l < m.num_links; ++l)
+    if (link_k[l] == -2) return fail("link " + std::to_string(l) + " belongs to neither the trunk nor a limb chain");
+  // bodies -> lane slots.  Trunk-link bodies with collision spheres: slot 0 of a lane whose group 0 rides
+  // on that trunk link; limb bodies: slots 1.. of their lane; sphere-less trunk bodies: any free slot.
+  std::vector<int> nsph(m.num_bodies, 0);
+  for (int g = 0; g < m.num_spheres; ++g) nsph[m.sphere_body[g]]++;
+  int n_base_bodies = 0;
   int next_slot[NLANE] = {1, 1, 1, 1};
+  std::vector<int> deferred;
   for (int b = 0; b < m.num_bodies; ++b) {
     int link = m.body_link[b];
-    if (link == 0) {
-      if (n_base_bodies >= NLANE) return fail("more than 4 bodies on the base link");
-      int k = n_base_bodies++;
+    if (link_k[link] == -1) {
+      const int depth = link_j[link];
+      // the first trunk body keeps the pre-trunk behaviour (A1: `base` always takes lane 0, slot 0)
+      if (nsph[b] == 0 && !(NW == 0 && n_base_bodies < NLANE)) { deferred.push_back(b); continue; }
+      int k = -1;
+      for (int kk = 0; kk < NLANE && k < 0; ++kk)
+        if (T.lane[kk].slot_body[0] < 0 && T.lane[kk].grp0_depth == depth) k = kk;
+      if (k < 0) {
+        if (nsph[b] == 0) { deferred.push_back(b); continue; }
+        return fail("no lane left for trunk body " + std::to_string(b));
+      }
       LaneTab& L = T.lane[k];
-      L.slot_body[0] = b; L.slot_grp[0] = 0; L.base_body_local = k; L.owns_base_body = 1;
+      L.slot_body[0] = b; L.slot_grp[0] = 0; L.base_body_local = n_base_bodies++; L.owns_base_body = 1;
       for (int c = 0; c < 3; ++c) L.slot_pos[0][c] = m.body_pos[b][c];
       body_lane[b] = k; body_slot[b] = 0;
     } else {
@@ -95,38 +155,57 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       body_lane[b] = k; body_slot[b] = s;
     }
   }
+  for (int b : deferred) {  // sensor timers only (no spheres report to these slots)
+    int k = -1;
+    for (int kk = 0; kk < NLANE && k < 0; ++kk)
+      if (next_slot[kk] < NBS) k = kk;
+    if (k < 0) return fail("no free body slot for trunk body " + std::to_string(b));
+    LaneTab& L = T.lane[k];
+    int s = next_slot[k]++;
+    L.slot_body[s] = b; L.slot_grp[s] = 0;
+    for (int c = 0; c < 3; ++c) L.slot_pos[s][c] = m.body_pos[b][c];
+    body_lane[b] = k; body_slot[b] = s;
+  }
   T.n_base_bodies = n_base_bodies;
-  // spheres -> lane / group / slot.  Spheres of a base-link body that has more spheres than SPL are
-  // dealt round-robin to the lanes that do not own another base-link body.
-  int fill[NLANE][NGRP];
+  // spheres -> lane / group / slot.  Spheres of a trunk body that has more spheres than its lane has slots
+  // are dealt round-robin to the other lanes riding on the same trunk link that own no other trunk body.
+  int fill[NLANE][MAX_NGRP];
   memset(fill, 0, sizeof(fill));
-  std::vector<int> base_count(m.num_bodies, 0);
-  for (int g = 0; g < m.num_spheres; ++g)
-    if (m.body_link[m.sphere_body[g]] == 0) base_count[m.sphere_body[g]]++;
   int rr = 0;
   for (int g = 0; g < m.num_spheres; ++g) {
     int b = m.sphere_body[g], link = m.body_link[b];
     int k, grp, slot;
-    if (link == 0) {
+    if (link_k[link] == -1) {
       grp = 0; slot = 0;
       k = body_lane[b];
-      if (base_count[b] > SPL) {  // spread (A1 trunk: 8 corner spheres -> 2 per lane)
+      if (nsph[b] > SPL) {  // spread (A1 trunk: 8 corner spheres -> 2 per lane)
+        const int local = T.lane[body_lane[b]].base_body_local, depth = link_j[link];
         for (int tries = 0; tries < NLANE; ++tries, ++rr) {
           int kk = rr % NLANE;
           int other = T.lane[kk].base_body_local;
-          if ((other == -1 || other == T.lane[body_lane[b]].base_body_local) && fill[kk][0] < SPL) { k = kk; ++rr; break; }
+          if ((other == -1 || other == local) && T.lane[kk].grp0_depth == depth && fill[kk][0] < SPL) { k = kk; ++rr; break; }
         }
-        if (T.lane[k].base_body_local == -1) T.lane[k].base_body_local = T.lane[body_lane[b]].base_body_local;
+        if (T.lane[k].base_body_local == -1) T.lane[k].base_body_local = local;
       }
     } else {
       k = link_k[link]; grp = link_j[link] + 1; slot = body_slot[b];
     }
     LaneTab& L = T.lane[k];
-    if (fill[k][grp] >= SPL) return fail("more than 3 collision spheres on one link group (body " + std::to_string(b) + ")");
+    if (fill[k][grp] >= SPL) return fail("too many collision spheres on one link group (body " + std::to_string(b) + ")");
     int s = fill[k][grp]++;
     for (int c = 0; c < 3; ++c) L.sph_c[grp][s][c] = m.sphere_center[g][c];
     L.sph_r[grp][s] = m.sphere_radius[g];
     L.sph_slot[grp][s] = slot;
+  }
+  // bodies the events / the scanner address
+  {
+    const int wl = m.body_link[d.task.base_body], sl = m.body_link[d.task.scan_body];
+    if (link_k[wl] != -1 || link_k[sl] != -1) return fail("the base body and the scanner body must sit on trunk links");
+    if (m.body_link[0] != 0) return fail("body 0 must be the root body");
+    T.wrench_depth = link_j[wl];
+    T.scan_depth = link_j[sl];
+    for (int c = 0; c < 3; ++c) T.scan_pos[c] = m.body_pos[d.task.scan_body][c];
+    if (NW == 0 && d.task.base_body != 0) return fail("quadruped instances need the base body to be the root body");
   }
   T.slot_valid = 0;
   for (int k = 0; k < NLANE; ++k)
@@ -295,8 +374,10 @@ struct EnvImpl {
         double c[3] = {m.body_com[b][0], m.body_com[b][1], m.body_com[b][2]};
         if (t.ev_com && b == t.base_body)
           for (int a = 0; a < 3; ++a) c[a] += uniform_range(seed, e, 0, STREAM_STARTUP, IDX_COM + 3 * b + a, t.com_range[a][0], t.com_range[a][1]);
-        if (b == t.base_body)
+        if (b == 0)  // root body: its COM defines root_com_lin_vel [UPSTREAM B3]
           for (int a = 0; a < 3; ++a) env[env_index(e, EF_BASE_COM + a, ept)] = (float)c[a];
+        if (b == t.base_body)
+          for (int a = 0; a < 3; ++a) env[env_index(e, EF_WR_COM + a, ept)] = (float)c[a];
         double sc = m.body_mass[b] > 0.f ? mass / m.body_mass[b] : 0.0;
         const float* I6 = m.body_inertia[b];
         double Ic[9] = {sc * I6[0], sc * I6[3], sc * I6[4], sc * I6[3], sc * I6[1], sc * I6[5], sc * I6[4], sc * I6[5], sc * I6[2]};
@@ -330,8 +411,8 @@ struct EnvImpl {
         for (int a = 0; a < 3; ++a)
           for (int bb = 0; bb < 3; ++bb) Ic[a * 3 + bb] = lI[l * 9 + a * 3 + bb] - mass * ((a == bb ? cc : 0.0) - c[a] * c[bb]);
         float rec[10] = {(float)mass, (float)c[0], (float)c[1], (float)c[2], (float)Ic[0], (float)Ic[4], (float)Ic[8], (float)Ic[1], (float)Ic[2], (float)Ic[5]};
-        if (l == 0) {
-          for (int f = 0; f < 10; ++f) env[env_index(e, EF_BASE_INERTIA + f, ept)] = rec[f];
+        if (link_lane[l] < 0) {  // trunk link: link_pos = trunk depth
+          for (int f = 0; f < 10; ++f) env[env_index(e, EF_BASE_INERTIA + link_pos[l] * INERTIA_NF + f, ept)] = rec[f];
         } else {
           int k = link_lane[l], j = link_pos[l];
           for (int f = 0; f < 10; ++f) lane[lane_index(e, k, LF_INERTIA + j * INERTIA_NF + f, ept)] = rec[f];
@@ -343,6 +424,11 @@ struct EnvImpl {
           lane[lane_index(e, k, LF_KD + j, ept)] = tables.lane[k].kd0[j];
           lane[lane_index(e, k, LF_Q + j, ept)] = tables.lane[k].q0[j];
         }
+      for (int i = 0; i < tables.NW; ++i) {
+        env[env_index(e, EF_TKP + i, ept)] = tables.lane[0].kp0[CL + i];
+        env[env_index(e, EF_TKD + i, ept)] = tables.lane[0].kd0[CL + i];
+        env[env_index(e, EF_TQ + i, ept)] = tables.lane[0].q0[CL + i];
+      }
       // terrain level / type / env origin
       if (desc.terrain.is_plane) {
         int ee = e < N ? e : N - 1;

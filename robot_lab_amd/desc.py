@@ -27,7 +27,8 @@ REWARD_KINDS = [
     "action_rate_l2", "undesired_contacts", "contact_forces", "feet_contact_without_cmd", "feet_height_body",
     "upward", "feet_air_time", "feet_air_time_variance_penalty", "feet_slide", "GaitReward",
     "flat_orientation_l2", "is_terminated", "joint_deviation_l1", "joint_vel_l2", "feet_contact",
-    "feet_stumble", "feet_height",
+    "feet_stumble", "feet_height", "track_lin_vel_xy_yaw_frame_exp", "track_ang_vel_z_world_exp",
+    "feet_air_time_positive_biped",
 ]
 REW = {n: i for i, n in enumerate(REWARD_KINDS)}
 OBS_KINDS = [
@@ -63,9 +64,11 @@ class ModelDesc(C.Structure):
     _fields_ = [
         ("num_links", i32), ("num_dof", i32), ("num_bodies", i32), ("num_spheres", i32), ("num_chains", i32),
         ("chain_len", i32),
-        ("chain_link", (i32 * 4) * 4),
+        ("chain_link", (i32 * 8) * 4), ("chain_nj", i32 * 4), ("chain_attach", i32 * 4),
+        ("num_trunk", i32), ("trunk_link", i32 * 4),
         ("link_parent", i32 * RL_MAX_LINKS),
         ("link_origin", (f32 * 3) * RL_MAX_LINKS),
+        ("link_quat", (f32 * 4) * RL_MAX_LINKS),
         ("link_axis", (f32 * 3) * RL_MAX_LINKS),
         ("joint_lower", f32 * RL_MAX_DOF), ("joint_upper", f32 * RL_MAX_DOF),
         ("joint_vel_limit", f32 * RL_MAX_DOF),
@@ -117,7 +120,7 @@ class TaskDesc(C.Structure):
         ("n_policy", i32), ("n_critic", i32),
         ("policy", ObsTerm * RL_MAX_OBS_TERMS), ("critic", ObsTerm * RL_MAX_OBS_TERMS),
         ("policy_corrupt", i32), ("critic_corrupt", i32),
-        ("scan_nx", i32), ("scan_ny", i32), ("scan_res", f32), ("scan_offset", f32),
+        ("scan_nx", i32), ("scan_ny", i32), ("scan_res", f32), ("scan_offset", f32), ("scan_body", i32),
         ("wheel_joint_mask", u32),
         ("n_rewards", i32),
         ("rewards", RewardTerm * RL_MAX_REWARD_TERMS),

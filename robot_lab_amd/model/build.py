@@ -44,6 +44,26 @@ def resolve_dict(val, names, default=None):
     return [val] * len(names)
 
 
+def _mat_to_quat(R):
+    """rotation matrix -> (w, x, y, z)"""
+    R = np.asarray(R, dtype=np.float64)
+    t = np.trace(R)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = math.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = [0.0] * 4
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    q = np.array(q)
+    return q / np.linalg.norm(q)
+
+
 DEFAULT_SIM = dict(
     dt=0.005, decimation=4, gravity=9.81,
     contact_k=2.0e4, contact_c=400.0, contact_phi_ref=0.005, contact_ct=4000.0, contact_vdep=1.0,
@@ -60,27 +80,50 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
     jn, bn = model.joint_names, model.body_names
     d.joint_names, d.body_names = list(jn), list(bn)
     m.num_links, m.num_dof, m.num_bodies, m.num_spheres = L, D, B, G
-    # star topology: serial chains hanging off the base (the lane program simulates one chain per lane).
-    # Chains are discovered by following the links, so the task's joint order need not be chain-major
-    # (Go2W lists the 12 leg joints first and the 4 wheel joints last, unitree_go2w/rough_env_cfg.py:25-31).
+    # topology: serial limb chains hanging off the base or off the end of a serial trunk chain (the lane
+    # program simulates one limb per lane group).  Chains are discovered by following the links, so the
+    # task's joint order need not be chain-major (Go2W lists the 12 leg joints first and the 4 wheel
+    # joints last, unitree_go2w/rough_env_cfg.py:25-31; G1 uses the importer's breadth-first order).
     children = {i: [c for c in range(1, L) if model.links[c].parent == i] for i in range(L)}
-    chains = []
-    for r in children[0]:
+
+    def serial(r):
         ch, cur = [r], r
         while len(children[cur]) == 1:
             cur = children[cur][0]
             ch.append(cur)
-        chains.append(ch if not children[cur] else None)
-    star = (len(chains) == 4 and all(c is not None for c in chains) and len({len(c) for c in chains}) == 1
-            and len(chains[0]) <= 4 and sum(len(c) for c in chains) == D)
-    m.num_chains, m.chain_len = (4, len(chains[0])) if star else (0, 0)
-    if star:
-        for k, ch in enumerate(chains):
+        return ch, children[cur]
+
+    limbs, trunk = [], []  # limbs: (attach depth, [links])
+    for r in children[0]:
+        ch, tail = serial(r)
+        if not tail:
+            limbs.append((0, ch))
+        elif not trunk:  # one branching serial chain = the trunk (G1 waist -> torso -> arms)
+            trunk = ch
+            for rr in tail:
+                ch2, tail2 = serial(rr)
+                limbs.append((len(trunk), ch2) if not tail2 else (None, ch2))
+        else:
+            limbs.append((None, ch))
+    ok = (len(limbs) == 4 and all(a is not None for a, _ in limbs) and max(len(c) for _, c in limbs) <= 7 and len(trunk) <= 3
+          and sum(len(c) for _, c in limbs) + len(trunk) == D)
+    if ok and not trunk and len({len(c) for _, c in limbs}) != 1:
+        ok = False
+    m.num_chains, m.chain_len, m.num_trunk = (4, max(len(c) for _, c in limbs), len(trunk)) if ok else (0, 0, 0)
+    for k in range(4):
+        for j in range(8):
+            m.chain_link[k][j] = -1
+    if ok:
+        for k, (a, ch) in enumerate(limbs):
+            m.chain_nj[k], m.chain_attach[k] = len(ch), a
             for j, l in enumerate(ch):
                 m.chain_link[k][j] = l
+        for i, l in enumerate(trunk):
+            m.trunk_link[i] = l
     for i, l in enumerate(model.links):
         m.link_parent[i] = l.parent
         set_arr(m.link_origin[i], l.origin)
+        set_arr(m.link_quat[i], _mat_to_quat(l.rot))
         set_arr(m.link_axis[i], l.axis)
     rob = spec["robot"]
     set_arr(m.joint_lower, [l.lower for l in model.links[1:]])
@@ -191,6 +234,7 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
     t.scan_nx = int(round(sc["size"][0] / sc["resolution"])) + 1
     t.scan_ny = int(round(sc["size"][1] / sc["resolution"])) + 1
     t.scan_offset = sc.get("offset", 0.5)
+    t.scan_body = find_names(sc["body"], bn)[0] if sc.get("body") else 0
     d.reward_names = []
     for i, rt in enumerate(ts["rewards"]):
         r = t.rewards[i]

@@ -121,7 +121,10 @@ def compile_spec(cfg) -> tuple[dict, str]:
     task["observations"] = obs
     hs = getattr(cfg.scene, "height_scanner", None)
     if hs is not None:
-        task["height_scan"] = dict(size=tuple(hs.pattern_cfg.size), resolution=hs.pattern_cfg.resolution, offset=0.5)
+        # the ray caster rides on the body its prim_path names (velocity_env_cfg.py:71; G1 moves it to
+        # the torso, unitree_g1/rough_env_cfg.py:55)
+        task["height_scan"] = dict(size=tuple(hs.pattern_cfg.size), resolution=hs.pattern_cfg.resolution, offset=0.5,
+                                   body=str(hs.prim_path).rsplit("/", 1)[-1])
     # rewards
     rewards = []
     for name, t in _terms(cfg.rewards):
@@ -138,7 +141,7 @@ def compile_spec(cfg) -> tuple[dict, str]:
         bn = (_names(sc, "body_names") if sc is not None else None) or (_names(ac, "body_names") if ac is not None else None)
         if bn is not None:
             e["body_names"] = bn
-        if fn in ("track_lin_vel_xy_exp", "track_ang_vel_z_exp"):
+        if fn in ("track_lin_vel_xy_exp", "track_ang_vel_z_exp", "track_lin_vel_xy_yaw_frame_exp", "track_ang_vel_z_world_exp"):
             e["p"] = [p["std"] ** 2]
         elif fn == "stand_still":
             e["p"] = [p.get("command_threshold", 0.06)]
@@ -146,7 +149,7 @@ def compile_spec(cfg) -> tuple[dict, str]:
             e["p"] = [p["stand_still_scale"], p["velocity_threshold"], p["command_threshold"]]
         elif fn == "joint_mirror":
             e["mirror_joints"] = [list(pair) for pair in p["mirror_joints"]]
-        elif fn in ("undesired_contacts", "contact_forces", "feet_air_time"):
+        elif fn in ("undesired_contacts", "contact_forces", "feet_air_time", "feet_air_time_positive_biped"):
             e["p"] = [p["threshold"]]
         elif fn in ("feet_height_body", "feet_height"):
             e["p"] = [p["target_height"], p["tanh_mult"]]
@@ -206,8 +209,11 @@ def compile_spec(cfg) -> tuple[dict, str]:
     task["events"] = ev
     task["base_body_name"] = base_name or [getattr(cfg, "base_link_name", "base")]
     spec["task"] = task
+    is_regex = lambda n: any(c in n for c in "*()[]|?+^$")
     spec["joint_order"] = list(actions[0]["joint_names"]) if len(actions) == 1 and actions[0]["preserve_order"] else None
-    if spec["joint_order"] is None:
+    if spec["joint_order"] is not None and any(is_regex(n) for n in spec["joint_order"]):
+        spec["joint_order"] = getattr(cfg, "joint_names", None)  # G1: ".*" -> the importer's breadth-first order
+    elif spec["joint_order"] is None:
         jo = []
         for a in actions:
             jo += [n for n in a["joint_names"]]

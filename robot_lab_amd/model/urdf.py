@@ -18,11 +18,18 @@ Two index spaces come out of this:
 
 Collision primitives (``a1.urdf:326-331,379-384,397-404,421-426,449-454``) are converted to a small
 set of collision *spheres* per body (see :func:`_geom_to_spheres`); the simulator's contact model
-is sphere-vs-heightfield.
+is sphere-vs-heightfield.  Mesh collision geometry (G1: ``g1_29dof_rev_1_0.urdf`` STL files under
+``g1_description/meshes``) is replaced by a capsule-like row of <= 3 spheres fitted to the vertex
+cloud (:func:`_mesh_to_spheres`).
+
+Joint frames may be rotated with respect to the parent link (``rpy`` of the joint origin, G1
+``g1_29dof_rev_1_0.urdf:124,182,648,677``): ``Link.rot`` is that fixed rotation.
 """
 from __future__ import annotations
 
 import math
+import os
+import struct
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass, field
 
@@ -59,6 +66,7 @@ class Sphere:
     body: int
     center: np.ndarray  # in LINK frame
     radius: float
+    explicit: bool = False  # a <sphere> primitive of the URDF (kept as is), not a fit of another shape
 
 
 @dataclass
@@ -79,6 +87,7 @@ class Link:
     joint_name: str
     joint_type: str  # "floating" | "revolute" | "continuous"
     origin: np.ndarray  # joint origin in parent link frame
+    rot: np.ndarray  # joint frame axes in the parent link frame (fixed rotation, URDF joint rpy)
     axis: np.ndarray
     lower: float
     upper: float
@@ -105,7 +114,43 @@ class RobotModel:
         return float(sum(b.mass for b in self.bodies))
 
 
-def _geom_to_spheres(geom: ET.Element, T_pos: np.ndarray, T_rot: np.ndarray):
+def _read_stl_vertices(path: str) -> np.ndarray:
+    """Vertices [n, 3] of a binary (or ASCII) STL file."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) >= 84:
+        ntri = struct.unpack_from("<I", data, 80)[0]
+        if 84 + 50 * ntri == len(data):
+            rec = np.frombuffer(data, dtype=np.uint8, count=50 * ntri, offset=84).reshape(ntri, 50)
+            return rec[:, 12:48].copy().view("<f4").reshape(-1, 3).astype(np.float64)
+    verts = [[float(v) for v in line.split()[1:4]] for line in data.decode("ascii", "ignore").splitlines()
+             if line.strip().startswith("vertex")]
+    return np.asarray(verts, dtype=np.float64)
+
+
+def _mesh_to_spheres(verts: np.ndarray, scale: np.ndarray):
+    """Capsule-like sphere row fitted to a vertex cloud: principal axis a (largest variance), half
+    length h, radius r = 90th percentile of the distance from the axis (clamped to [1 cm, h]).
+    h <= 1.5 r -> one sphere of radius max(r, h) at the centre; else 3 spheres at 0, +-(h - r) a."""
+    v = np.unique(np.round(verts * scale[None], 5), axis=0)
+    if len(v) < 4:
+        return []
+    lo, hi = v.min(0), v.max(0)
+    c = 0.5 * (lo + hi)
+    w, vec = np.linalg.eigh(np.cov((v - v.mean(0)).T))
+    a = vec[:, int(np.argmax(w))]
+    t = (v - c) @ a
+    c = c + 0.5 * (t.max() + t.min()) * a - ((c - c) @ a) * a
+    t = (v - c) @ a
+    h = 0.5 * (t.max() - t.min())
+    perp = np.linalg.norm((v - c) - np.outer(t, a), axis=1)
+    r = float(np.clip(np.percentile(perp, 90), 0.01, max(h, 0.01)))
+    if h <= 1.5 * r:
+        return [(c, float(max(r, h)))]
+    return [(c + s * (h - r) * a, r) for s in (-1.0, 0.0, 1.0)]
+
+
+def _geom_to_spheres(geom: ET.Element, T_pos: np.ndarray, T_rot: np.ndarray, mesh_dir: str | None = None):
     """Collision primitive -> list of (center, radius) in the frame T maps into.
 
     sphere   -> itself.
@@ -113,13 +158,18 @@ def _geom_to_spheres(geom: ET.Element, T_pos: np.ndarray, T_rot: np.ndarray):
                 radius = half the smaller cross-section side; otherwise 8 corner spheres inset by
                 r = min(0.02, min_half_extent) (a rounded box).
     cylinder -> length <= 2.5 r: one sphere of the cylinder radius at the centre; else 3 along the axis.
-    mesh     -> ignored (no mesh collision in this simulator).
+    mesh     -> :func:`_mesh_to_spheres` of the STL vertex cloud (file looked up in ``mesh_dir``).
     """
     out = []
     sph = geom.find("sphere")
     box = geom.find("box")
     cyl = geom.find("cylinder")
-    if sph is not None:
+    mesh = geom.find("mesh")
+    if mesh is not None and mesh_dir is not None:
+        fn = os.path.join(mesh_dir, os.path.basename(mesh.get("filename")))
+        if os.path.isfile(fn):
+            out = _mesh_to_spheres(_read_stl_vertices(fn), _vec(mesh.get("scale"), 3, 1.0))
+    elif sph is not None:
         out.append((np.zeros(3), float(sph.get("radius"))))
     elif box is not None:
         size = _vec(box.get("size"))
@@ -148,7 +198,7 @@ def _geom_to_spheres(geom: ET.Element, T_pos: np.ndarray, T_rot: np.ndarray):
         else:
             for t in (-0.5 * length, 0.0, 0.5 * length):
                 out.append((np.array([0.0, 0.0, t]), r))
-    return [(T_pos + T_rot @ c, r) for c, r in out]
+    return [(T_pos + T_rot @ c, r, sph is not None) for c, r in out]
 
 
 def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None = None) -> RobotModel:
@@ -159,6 +209,7 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
     order (link i+1 <-> joint_order[i]).  Default: breadth-first URDF order.
     """
     root = ET.parse(path).getroot()
+    mesh_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(path))), "meshes")
     ulinks = {l.get("name"): l for l in root.findall("link")}
     children: dict[str, list[ET.Element]] = {}
     child_names = set()
@@ -176,7 +227,7 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
 
     model = RobotModel(name=name or root.get("name", "robot"))
     # BFS over moving joints; fixed children are folded into the current link.
-    model.links.append(Link(roots[0], -1, "floating_base", "floating", np.zeros(3), np.array([0, 0, 1.0]), 0, 0, 0, 0))
+    model.links.append(Link(roots[0], -1, "floating_base", "floating", np.zeros(3), np.eye(3), np.array([0, 0, 1.0]), 0, 0, 0, 0))
     pending = [(roots[0], 0, np.zeros(3), np.eye(3), None)]  # (urdf link, link idx, pos, rot in link frame, body idx)
     raw_bodies: list[dict] = []
 
@@ -211,7 +262,7 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
             cpos = _vec(o.get("xyz")) if o is not None else np.zeros(3)
             crot = rpy_to_mat(_vec(o.get("rpy"))) if o is not None and o.get("rpy") else np.eye(3)
             g = col.find("geometry")
-            raw_bodies[bidx]["spheres"] += _geom_to_spheres(g, pos + rot @ cpos, rot @ crot)
+            raw_bodies[bidx]["spheres"] += _geom_to_spheres(g, pos + rot @ cpos, rot @ crot, mesh_dir)
         for j in children.get(uname, []):
             cname = j.find("child").get("link")
             o = j.find("origin")
@@ -222,15 +273,13 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
                 keep = j.get("dont_collapse", "false").lower() == "true"
                 queue.append((cname, lidx, pos + rot @ jpos, rot @ jrot, None if keep else bidx))
             elif jtype in ("revolute", "continuous"):
-                if not np.allclose(jrot, np.eye(3), atol=1e-9) or not np.allclose(rot, np.eye(3), atol=1e-9):
-                    raise NotImplementedError(f"joint {j.get('name')}: rotated joint frames are not supported")
                 lim = j.find("limit")
                 lo = float(lim.get("lower", "-1e9")) if (lim is not None and jtype == "revolute") else -1e9
                 hi = float(lim.get("upper", "1e9")) if (lim is not None and jtype == "revolute") else 1e9
                 vl = float(lim.get("velocity", "1e9")) if lim is not None else 1e9
                 ef = float(lim.get("effort", "1e9")) if lim is not None else 1e9
                 ax = _vec(j.find("axis").get("xyz")) if j.find("axis") is not None else np.array([1.0, 0, 0])
-                model.links.append(Link(cname, lidx, j.get("name"), jtype, pos + rot @ jpos, ax / np.linalg.norm(ax), lo, hi, vl, ef))
+                model.links.append(Link(cname, lidx, j.get("name"), jtype, pos + rot @ jpos, rot @ jrot, ax / np.linalg.norm(ax), lo, hi, vl, ef))
                 queue.append((cname, len(model.links) - 1, np.zeros(3), np.eye(3), None))
             else:
                 raise NotImplementedError(f"joint type {jtype}")
@@ -263,8 +312,8 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
         else:
             com, I = rb["pos"].copy(), np.zeros((3, 3))
         model.bodies.append(Body(rb["name"], rb["link"], rb["pos"], rb["rot"], m, com, I))
-        for c, r in rb["spheres"]:
-            model.spheres.append(Sphere(bi, c, r))
+        for c, r, ex in rb["spheres"]:
+            model.spheres.append(Sphere(bi, c, r, ex))
     _prune_contained_spheres(model)
     _thin_spheres(model)
     return model
@@ -273,8 +322,9 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
 def _thin_spheres(model: RobotModel, min_sep: float = 0.07):
     """Several URDFs tile a slender link with many overlapping primitives (Go2 calf: three cylinders,
     `go2_description.urdf:149-185`).  Per link, keep spheres greedily by descending radius and drop any
-    whose centre is closer than ``min_sep`` to an already kept one - the lane program budgets three
-    collision spheres per link."""
+    whose centre is closer than ``min_sep`` to an already kept one (explicit ``<sphere>`` primitives
+    such as the four r = 5 mm contact points of a G1 foot, `g1_29dof_rev_1_0.urdf:262-283`, are
+    never dropped against each other) - the lane program budgets a few collision spheres per link."""
     by_link: dict[int, list[int]] = {}
     for i, sph in enumerate(model.spheres):
         by_link.setdefault(model.bodies[sph.body].link, []).append(i)
@@ -283,7 +333,8 @@ def _thin_spheres(model: RobotModel, min_sep: float = 0.07):
         kept: list[int] = []
         for i in sorted(ids, key=lambda i: -model.spheres[i].radius):
             c = model.spheres[i].center
-            if all(np.linalg.norm(c - model.spheres[k].center) >= min_sep for k in kept):
+            ex = model.spheres[i].explicit
+            if all((ex and model.spheres[k].explicit) or np.linalg.norm(c - model.spheres[k].center) >= min_sep for k in kept):
                 kept.append(i)
         keep.update(kept)
     model.spheres = [sph for i, sph in enumerate(model.spheres) if i in keep]

@@ -38,7 +38,7 @@ struct HostCtx {
   static constexpr int SUB = SUB_;
   static constexpr int LPE = rl::NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
-  float scratch[rl::LS_WORDS];
+  float scratch[rl::LsLayout<rl::MAX_NBS>::WORDS];
   float* lane_scratch() { return scratch; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
@@ -73,6 +73,15 @@ struct HostCtx {
     return s;
   }
   float esum(float v) { return gsum(leg_sum(v)); }
+  // min over all lanes of the env
+  float emin(float v) {
+    team->slot[li()] = v;
+    team->barrier(sense_);
+    float r = team->slot[0];
+    for (int i = 1; i < LPE; ++i) r = r < team->slot[i] ? r : team->slot[i];
+    team->barrier(sense_);
+    return r;
+  }
   // wave-level vote on the GPU; here an env-level OR (it may guard collectives, so it must be uniform)
   bool any(bool c) {
     team->slot[li()] = c ? 1.f : 0.f;
@@ -106,7 +115,7 @@ struct HostCtx {
   }
 };
 
-template <int CL, int SUB>
+template <class TP, int SUB>
 void run(const rl::KState& S, const rl::Tables* T, int reset) {
   using Ctx = HostCtx<SUB>;
   Team<Ctx::LPE> team;
@@ -119,7 +128,7 @@ void run(const rl::KState& S, const rl::Tables* T, int reset) {
       ctx.team = &team; ctx.T = T; ctx.k_ = l / SUB; ctx.sub_ = l % SUB; ctx.e_ = 0;
       for (int e = 0; e < S.Npad; ++e) {
         ctx.e_ = e;
-        rl::EnvProgram<Ctx, CL> prog(ctx, S);
+        rl::EnvProgram<Ctx, TP> prog(ctx, S);
         if (reset)
           prog.reset_entry();
         else
@@ -149,10 +158,12 @@ struct Backend {
   void h2d_stream(void* d, const void* s, size_t n, void*) { std::memcpy(d, s, n); }
   int launch(const rl::KState& S, const rl::Tables* T, int CL, int reset, void*) {
     switch (CL * 10 + sub) {
-      case 31: run<3, 1>(S, T, reset); return 0;
-      case 41: run<4, 1>(S, T, reset); return 0;
-      case 34: run<3, 4>(S, T, reset); return 0;
-      case 44: run<4, 4>(S, T, reset); return 0;
+      case 31: run<rl::TopoQuad3, 1>(S, T, reset); return 0;
+      case 41: run<rl::TopoQuad4, 1>(S, T, reset); return 0;
+      case 34: run<rl::TopoQuad3, 4>(S, T, reset); return 0;
+      case 44: run<rl::TopoQuad4, 4>(S, T, reset); return 0;
+      case 71: run<rl::TopoG1, 1>(S, T, reset); return 0;
+      case 74: run<rl::TopoG1, 4>(S, T, reset); return 0;
       default: err = "unsupported chain length"; return -1;
     }
   }

@@ -59,5 +59,5 @@ def test_descriptor_errors_are_reported(emu_lib):
     desc, extra = load_bundle("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0")
     h, to, eo = build_world(desc, extra, 16, 0)
     desc.model.num_chains = 3  # not the star topology the lane program is written for
-    with pytest.raises(capi.RlEnvError, match="star articulation"):
+    with pytest.raises(capi.RlEnvError, match="limb chains"):
         capi.NativeEnv(desc, h, to, eo, 16, 1, 0, emu_lib)

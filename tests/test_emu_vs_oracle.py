@@ -10,12 +10,14 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0",
     "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0",
     "RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0",
+    "RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0",
 ]
 
 
 @pytest.mark.parametrize("task", TASKS)
 def test_lane_program_matches_oracle(task, emu_lib):
-    N = 16
+    N = 8 if "G1" in task else 16  # G1: 29 DoF, the fp64 oracle is the slow side
     desc, ora, nat = make_pair(task, N, 42, emu_lib)
     o = ora.reset()
     nat.reset()

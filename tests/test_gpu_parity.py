@@ -15,6 +15,8 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0",
     "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0",
     "RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0",
+    "RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0",
 ]
 
 
@@ -31,7 +33,7 @@ def _pair(task, N, seed):
 
 @pytest.mark.parametrize("task", TASKS)
 def test_short_horizon_parity(task):
-    N = 64
+    N = 32 if "G1" in task else 64
     env, ora, torch = _pair(task, N, 11)
     obs, _ = env.reset()
     o = ora.reset()

@@ -44,11 +44,34 @@ def test_a1_census():
     ("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", (45, 48), 17, 13.741),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", (45, 235), 19, 16.087),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", (57, 247), 19, 19.523),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", (96, 286), 33, 33.341),
+    ("RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0", (96, 99), 33, 33.341),
 ])
 def test_other_bundles(task, dims, bodies, mass):
     d, _ = load_bundle(task)
     assert (d.obs_dim(0), d.obs_dim(1)) == dims and d.model.num_bodies == bodies
     assert abs(float(arr(d.model.body_mass, bodies).sum()) - mass) < 2e-3
+
+
+def test_g1_census():
+    """Known-answer facts of SURVEY.md 8(c): 29 joints, trunk = 3 waist joints carrying the arms, per-joint
+    action scale 0.25 * effort / stiffness (unitree.py:625-636), torso-mounted events and scanner."""
+    d, _ = load_bundle("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0")
+    m, t = d.model, d.task
+    assert (m.num_dof, m.num_links, m.num_chains, m.chain_len, m.num_trunk) == (29, 30, 4, 7, 3)
+    assert list(m.chain_nj) == [6, 6, 7, 7] and list(m.chain_attach) == [0, 0, 3, 3]
+    assert [d.joint_names[m.trunk_link[i] - 1] for i in range(3)] == ["waist_yaw_joint", "waist_roll_joint", "waist_pitch_joint"]
+    j = d.joint_names.index("left_hip_pitch_joint")
+    assert abs(m.action_scale[j] - 0.25 * 88.0 / (0.010177520 * (20 * 3.1415926535) ** 2)) < 1e-6  # = 0.5475
+    assert abs(m.default_root_pos[2] - 0.76) < 1e-6 and abs(m.default_joint_pos[d.joint_names.index("left_knee_joint")] - 0.669) < 1e-6
+    assert d.body_names[t.base_body] == "torso_link" and d.body_names[t.scan_body] == "torso_link"
+    assert t.term_illegal_contact == 1 and t.illegal_body_mask == 1 << d.body_names.index("torso_link")
+    feet = [d.body_names.index(n) for n in ("left_ankle_roll_link", "right_ankle_roll_link")]
+    n_foot_spheres = sum(1 for g in range(m.num_spheres) if m.sphere_body[g] in feet)
+    assert n_foot_spheres == 8  # 4 contact points per foot (g1_29dof_rev_1_0.urdf:262-283)
+    kinds = {d.reward_names[i]: t.rewards[i].kind for i in range(t.n_rewards)}
+    from robot_lab_amd.desc import REW
+    assert kinds["track_lin_vel_xy_exp"] == REW["track_lin_vel_xy_yaw_frame_exp"] and kinds["feet_air_time"] == REW["feet_air_time_positive_biped"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs /root/reference")
@@ -63,7 +86,8 @@ def test_bundles_recompile_from_reference_cfg():
     from robot_lab_amd.model.cfg_compile import compile_cfg
 
     assert gym.spec(A1R).entry_point == "isaaclab.envs:ManagerBasedRLEnv"
-    for task in (A1R, "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0"):
+    for task in (A1R, "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0",
+                 "RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0"):
         desc, spec = compile_cfg(parse_env_cfg(task, device="cpu", num_envs=8))
         committed, _ = load_bundle(task)
         assert json.loads(desc_to_json(desc)) == json.loads(desc_to_json(committed)), task
