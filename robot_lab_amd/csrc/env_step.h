@@ -38,7 +38,7 @@ struct Uni {
   int is_plane, nx, ny;
 };
 template <class Ctx>
-RL_FN Uni make_uni(const Ctx& ctx, const Tables& T) {
+RL_FN Uni make_uni(const Ctx& ctx, const TaskTab& T) {
   Uni u;
   u.dt = ctx.uniform(T.dt); u.inv_dt = ctx.uniform(1.0f / T.dt); u.gravity = ctx.uniform(T.gravity);
   u.contact_k = ctx.uniform(T.contact_k); u.contact_c = ctx.uniform(T.contact_c); u.inv_phi_ref = ctx.uniform(1.0f / T.contact_phi_ref);
@@ -116,7 +116,7 @@ struct Chain {  // kinematics in base coordinates: the lane's limb (R, p, ax) an
 };
 
 template <class TP>
-RL_FN void chain_kinematics(const LaneTab& L, const float (&q)[TP::JX], Chain<TP>& C) {
+RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], Chain<TP>& C) {
   constexpr int CL = TP::CL, NW = TP::NW;
   M3 Rp = identity3();
   V3 pp{0.f, 0.f, 0.f};
@@ -124,7 +124,7 @@ RL_FN void chain_kinematics(const LaneTab& L, const float (&q)[TP::JX], Chain<TP
   for (int i = 0; i < NW; ++i) {  // trunk joints (same in every lane)
     const int jx = CL + i;
     V3 al = ld3(L.axis[jx]);
-    M3 Rj0 = mul(Rp, ld_m3(L.rot0[jx]));
+    M3 Rj0 = mul(Rp, ld_m3(L.rot0[TP::ROT ? jx : 0]));
     C.pw[i] = pp + mul(Rp, ld3(L.origin[jx]));
     C.axw[i] = mul(Rj0, al);
     C.Rw[i] = mul(Rj0, rodrigues(al, q[jx]));
@@ -136,7 +136,7 @@ RL_FN void chain_kinematics(const LaneTab& L, const float (&q)[TP::JX], Chain<TP
   for (int j = 0; j < CL; ++j) {
     V3 al = ld3(L.axis[j]);
     C.p[j] = pp + mul(Rp, ld3(L.origin[j]));
-    if (TP::ROT) Rp = mul(Rp, ld_m3(L.rot0[j]));
+    if (TP::ROT) Rp = mul(Rp, ld_m3(L.rot0[TP::ROT ? j : 0]));
     C.ax[j] = mul(Rp, al);
     C.R[j] = mul(Rp, rodrigues(al, q[j]));
     Rp = C.R[j];
@@ -190,8 +190,8 @@ struct EnvLane {
 
   Ctx& ctx;
   const KState& S;
-  const Tables& T;
-  const LaneTab& L;
+  const TablesT<TP>& T;
+  const LaneTabT<TP>& L;
   const Uni u;
   int e, k, sub, li, Np;  // env, leg, sub-lane of the leg, lane index inside the env (k * SUB + sub)
   float* lt;  // this leg's column of the wave tile:   field f -> lt[f * ROW]
@@ -212,7 +212,7 @@ struct EnvLane {
   LsMat<LSS, 3> fric;    // [slot][mu_s, mu_d, restitution]
 
   RL_FN EnvLane(Ctx& c, const KState& s)
-      : ctx(c), S(s), T(c.tables()), L(c.tables().lane[c.k()]), u(make_uni(c, c.tables())), tim{c.lane_scratch() + LS::TIM * LSS}, hist_n{c.lane_scratch() + LS::HIST * LSS},
+      : ctx(c), S(s), T(c.template tables<TablesT<TP>>()), L(c.template tables<TablesT<TP>>().lane[c.k()]), u(make_uni(c, c.template tables<TablesT<TP>>())), tim{c.lane_scratch() + LS::TIM * LSS}, hist_n{c.lane_scratch() + LS::HIST * LSS},
         cf{c.lane_scratch() + LS::CF * LSS}, fric{c.lane_scratch() + LS::FRIC * LSS} {
     e = ctx.env();
     k = ctx.k();

@@ -40,30 +40,38 @@ constexpr int LOG_SIZE = 64;
 // log accumulator slots (device LOG buffer)
 enum { LOG_RESET_COUNT = 0, LOG_TERM_TIMEOUT = 1, LOG_TERM_OOB = 2, LOG_TERM_ILLEGAL = 3, LOG_METRIC_XY = 4, LOG_METRIC_YAW = 5, LOG_EP_SUM0 = 8 };
 
-struct LaneTab {  // one per limb chain k.  Joint arrays: [0, CL) the limb, [CL, CL+NW) the trunk joints (same in all lanes)
-  float origin[MAX_JX][3], axis[MAX_JX][3];
-  float rot0[MAX_JX][9];               // joint frame axes in the parent link frame, row-major (identity on the quadrupeds)
-  float lower[MAX_JX], upper[MAX_JX], vel_limit[MAX_JX], armature[MAX_JX];
-  float q0[MAX_JX], qd0[MAX_JX], soft_lo[MAX_JX], soft_hi[MAX_JX];
-  int32_t act_implicit[MAX_JX];
-  float kp0[MAX_JX], kd0[MAX_JX], eff[MAX_JX], sat[MAX_JX], act_vlim[MAX_JX];
-  int32_t action_is_vel[MAX_JX];
-  float a_scale[MAX_JX], a_off[MAX_JX], a_lo[MAX_JX], a_hi[MAX_JX];
-  int32_t joint_id[MAX_JX];            // task joint index (bit in joint masks, column in action/obs); -1 = padding (chain shorter than CL)
-  int32_t joint_own[MAX_JX];           // 1: this lane accounts for the joint in reward sums / observation columns / debug views
+using TopoMax = Topo<MAX_CL, MAX_NW, MAX_SPL, MAX_NBS>;  // shape of the host-side (unpacked) tables
+
+// One per limb chain k.  Joint arrays: [0, CL) the limb, [CL, CL+NW) the trunk joints (same in all lanes).
+// Sized by the Topo so that the LDS copy of a quadruped instance stays small: the workgroup's LDS
+// footprint decides whether all 4 SIMDs of a CU get a wavefront (4 x 37 KB fit in 160 KB, 4 x 45 KB do not).
+template <class TP>
+struct LaneTabT {
+  static constexpr int JXA = TP::JX, RXA = TP::ROT ? TP::JX : 1, NG = TP::CL + 1;
+  float origin[JXA][3], axis[JXA][3];
+  float rot0[RXA][9];                  // joint frame axes in the parent link frame, row-major (only read when TP::ROT)
+  float lower[JXA], upper[JXA], vel_limit[JXA], armature[JXA];
+  float q0[JXA], qd0[JXA], soft_lo[JXA], soft_hi[JXA];
+  int32_t act_implicit[JXA];
+  float kp0[JXA], kd0[JXA], eff[JXA], sat[JXA], act_vlim[JXA];
+  int32_t action_is_vel[JXA];
+  float a_scale[JXA], a_off[JXA], a_lo[JXA], a_hi[JXA];
+  int32_t joint_id[JXA];               // task joint index (bit in joint masks, column in action/obs); -1 = padding (chain shorter than CL)
+  int32_t joint_own[JXA];              // 1: this lane accounts for the joint in reward sums / observation columns / debug views
                                        //    (limb joints: always; trunk joints: lane 0 only)
   int32_t nj;                          // joints of this limb (<= CL)
   int32_t attach;                      // trunk joints that move the limb (0: hangs off the base, NW: off the last trunk link)
   int32_t grp0_depth;                  // trunk joints that move link group 0 of this lane
-  float sph_c[MAX_NGRP][MAX_SPL][3];
-  float sph_r[MAX_NGRP][MAX_SPL];      // <= 0: empty slot
-  int32_t sph_slot[MAX_NGRP][MAX_SPL]; // body slot the sphere reports to
-  int32_t slot_body[MAX_NBS];          // global body index (bit in body masks), -1 = empty
-  int32_t slot_grp[MAX_NBS];           // link group the body is attached to
-  float slot_pos[MAX_NBS][3];          // body frame origin in its link frame
+  float sph_c[NG][TP::SPL][3];
+  float sph_r[NG][TP::SPL];            // <= 0: empty slot
+  int32_t sph_slot[NG][TP::SPL];       // body slot the sphere reports to
+  int32_t slot_body[TP::NBS];          // global body index (bit in body masks), -1 = empty
+  int32_t slot_grp[TP::NBS];           // link group the body is attached to
+  float slot_pos[TP::NBS][3];          // body frame origin in its link frame
   int32_t base_body_local;             // which sphere-carrying trunk body (0..n_base_bodies-1) slot 0 / group 0 belongs to, -1 none
   int32_t owns_base_body;              // 1 if this lane keeps the timers of that trunk body
 };
+using LaneTab = LaneTabT<TopoMax>;
 
 struct RewTab {
   int32_t kind;
@@ -82,8 +90,7 @@ struct ObsTab {
   int32_t offset;  // first column of the term in its group
 };
 
-struct Tables {
-  LaneTab lane[NLANE];
+struct TaskTab {  // everything that is not per limb
   int32_t CL, NW, SPL, NBS, D, n_bodies, n_base_bodies;
   uint32_t slot_valid;  // bit g*SPL+s: some lane has a collision sphere in slot (g, s)
   int32_t wrench_depth; // trunk link (0 = base, i = after i trunk joints) carrying the body the wrench / COM events address
@@ -119,6 +126,43 @@ struct Tables {
   float reset_pose[6][2], reset_vel[6][2], push_interval[2], push_vel[6][2];
   float default_root_pos[3], default_root_quat[4];
 };
+
+template <class TP>
+struct TablesT : TaskTab {
+  LaneTabT<TP> lane[NLANE];
+};
+using Tables = TablesT<TopoMax>;  // host side / export-import kernels; env kernels read the packed TablesT<TP>
+
+// host: unpacked -> the instance's compact layout (trunk joints already sit at [CL, CL + NW) of the joint arrays)
+template <class TP>
+inline void pack_tables(const Tables& s, TablesT<TP>& d) {
+  static_cast<TaskTab&>(d) = static_cast<const TaskTab&>(s);
+  for (int k = 0; k < NLANE; ++k) {
+    const LaneTab& a = s.lane[k];
+    LaneTabT<TP>& b = d.lane[k];
+    for (int j = 0; j < TP::JX; ++j) {
+      for (int c = 0; c < 3; ++c) { b.origin[j][c] = a.origin[j][c]; b.axis[j][c] = a.axis[j][c]; }
+      if (TP::ROT) for (int c = 0; c < 9; ++c) b.rot0[TP::ROT ? j : 0][c] = a.rot0[j][c];
+      b.lower[j] = a.lower[j]; b.upper[j] = a.upper[j]; b.vel_limit[j] = a.vel_limit[j]; b.armature[j] = a.armature[j];
+      b.q0[j] = a.q0[j]; b.qd0[j] = a.qd0[j]; b.soft_lo[j] = a.soft_lo[j]; b.soft_hi[j] = a.soft_hi[j];
+      b.act_implicit[j] = a.act_implicit[j]; b.kp0[j] = a.kp0[j]; b.kd0[j] = a.kd0[j]; b.eff[j] = a.eff[j]; b.sat[j] = a.sat[j];
+      b.act_vlim[j] = a.act_vlim[j]; b.action_is_vel[j] = a.action_is_vel[j];
+      b.a_scale[j] = a.a_scale[j]; b.a_off[j] = a.a_off[j]; b.a_lo[j] = a.a_lo[j]; b.a_hi[j] = a.a_hi[j];
+      b.joint_id[j] = a.joint_id[j]; b.joint_own[j] = a.joint_own[j];
+    }
+    b.nj = a.nj; b.attach = a.attach; b.grp0_depth = a.grp0_depth;
+    for (int g = 0; g <= TP::CL; ++g)
+      for (int q = 0; q < TP::SPL; ++q) {
+        for (int c = 0; c < 3; ++c) b.sph_c[g][q][c] = a.sph_c[g][q][c];
+        b.sph_r[g][q] = a.sph_r[g][q]; b.sph_slot[g][q] = a.sph_slot[g][q];
+      }
+    for (int q = 0; q < TP::NBS; ++q) {
+      b.slot_body[q] = a.slot_body[q]; b.slot_grp[q] = a.slot_grp[q];
+      for (int c = 0; c < 3; ++c) b.slot_pos[q][c] = a.slot_pos[q][c];
+    }
+    b.base_body_local = a.base_body_local; b.owns_base_body = a.owns_base_body;
+  }
+}
 
 // fields of the per-env "cmd" record
 enum { CMD_VX = 0, CMD_VY, CMD_WZ, CMD_HEADING, CMD_TIME_LEFT, CMD_METRIC_XY, CMD_METRIC_YAW, CMD_PUSH_LEFT, CMD_NFIELD };

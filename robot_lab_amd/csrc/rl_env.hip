@@ -39,7 +39,7 @@ struct WaveCtx {
   static constexpr int LPE = NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
   float* lscratch;
-  const Tables* T;
+  const void* T;  // TablesT<TP> staged in LDS
   float* stage[2];
   float* rstage;
   int dim[2];
@@ -48,7 +48,8 @@ struct WaveCtx {
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
-  __device__ const Tables& tables() const { return *T; }
+  template <class TT>
+  __device__ const TT& tables() const { return *static_cast<const TT*>(T); }
   __device__ int env_in_tile() const { return lane / LPE; }
   __device__ int k() const { return SUB == 1 ? (lane & 3) : ((lane >> 2) & 3); }
   __device__ int sub() const { return SUB == 1 ? 0 : (lane & 3); }
@@ -106,8 +107,10 @@ struct WaveCtx {
 extern __shared__ float4 smem4[];
 
 template <class TP, int RESET, int SUB>
-__global__ __launch_bounds__(64) void env_kernel(KState S, const Tables* __restrict__ Tg) {
+__global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restrict__ Tgv) {
   using Ctx = WaveCtx<SUB>;
+  using Tables = TablesT<TP>;
+  const Tables* __restrict__ Tg = static_cast<const Tables*>(Tgv);
   float* smem = reinterpret_cast<float*>(smem4);
   Tables* Tl = reinterpret_cast<Tables*>(smem);
   const int lane = threadIdx.x;
@@ -175,7 +178,7 @@ struct Backend {
     return 16 / sub;
   }
   template <class TP, int SUB>
-  int launch_cl(const KState& S, const Tables* T, int reset, size_t lds, hipStream_t st) {
+  int launch_cl(const KState& S, const void* T, int reset, size_t lds, hipStream_t st) {
     dim3 grid(S.Npad / (16 / SUB)), block(64);
     if (lds > 64 * 1024) {  // opt in to the large LDS carve-out once per kernel (160 KB per CU on gfx950)
       static bool done = false;
@@ -194,7 +197,7 @@ struct Backend {
   size_t lds_bytes = 0;
   int configure(const Tables& T) {  // dynamic LDS: tables + observation staging tiles + lane scratchpad + reward stage
     const size_t ept = 16 / sub;
-    size_t tab = (sizeof(Tables) + 15) / 16 * 16;
+    size_t tab = (packed_size(T) + 15) / 16 * 16;
     size_t s0 = (ept * T.policy_dim + 3) / 4 * 16;
     size_t s1 = (ept * T.critic_dim + 3) / 4 * 16;
     const size_t ls_words = T.NBS == TopoG1::NBS ? LsLayout<TopoG1::NBS>::WORDS : LsLayout<TopoQuad3::NBS>::WORDS;
@@ -205,7 +208,7 @@ struct Backend {
     }
     return 0;
   }
-  int launch(const KState& S, const Tables* T, int CL, int reset, void* stream) {
+  int launch(const KState& S, const void* T, int CL, int reset, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     switch (CL * 10 + sub) {
       case 31: return launch_cl<TopoQuad3, 1>(S, T, reset, lds_bytes, st);

@@ -262,6 +262,18 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   return 0;
 }
 
+// packed (per-instance) table image that the env kernels stage into LDS
+inline size_t packed_size(const TaskTab& T) {
+  return T.NW > 0 ? sizeof(TablesT<TopoG1>) : (T.CL == 4 ? sizeof(TablesT<TopoQuad4>) : sizeof(TablesT<TopoQuad3>));
+}
+inline std::vector<uint8_t> pack_image(const Tables& T) {
+  std::vector<uint8_t> img(packed_size(T), 0);
+  if (T.NW > 0) pack_tables<TopoG1>(T, *reinterpret_cast<TablesT<TopoG1>*>(img.data()));
+  else if (T.CL == 4) pack_tables<TopoQuad4>(T, *reinterpret_cast<TablesT<TopoQuad4>*>(img.data()));
+  else pack_tables<TopoQuad3>(T, *reinterpret_cast<TablesT<TopoQuad3>*>(img.data()));
+  return img;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The environment object behind the opaque rl_env*.
 // ------------------------------------------------------------------------------------------------
@@ -270,7 +282,8 @@ struct EnvImpl {
   Backend be;
   rl_env_desc desc;
   Tables tables;
-  Tables* tables_dev = nullptr;
+  Tables* tables_dev = nullptr;   // unpacked (export / import kernels)
+  void* packed_dev = nullptr;     // TablesT<Topo> image the env kernels stage into LDS
   KState S;
   int N = 0, Npad = 0, D = 0, B = 0, CL = 0, ept = ENVS_PER_WAVE;
   uint64_t seed = 0;
@@ -339,6 +352,12 @@ struct EnvImpl {
     S.terrain = terrain_dev;
     S.terrain_origins = terrain_origins_dev;
     be.h2d(tables_dev, &tables, sizeof(Tables));
+    {
+      std::vector<uint8_t> img = pack_image(tables);
+      packed_dev = alloc<uint8_t>(img.size());
+      if (!packed_dev) return fail("device allocation failed: " + be.error());
+      be.h2d(packed_dev, img.data(), img.size());
+    }
     startup(terrain_origins, env_origins);
     return 0;
   }
@@ -462,7 +481,7 @@ struct EnvImpl {
       be.h2d_stream(reset_mask, mask.data(), Npad, stream);
       s.reset_mask = reset_mask;
     }
-    return be.launch(s, tables_dev, CL, /*reset=*/1, stream) ? fail("launch failed: " + be.error()) : 0;
+    return be.launch(s, packed_dev, CL, /*reset=*/1, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 
   int step(const float* action_dev, void* stream) {
@@ -470,7 +489,7 @@ struct EnvImpl {
     KState s = S;
     s.step_counter = ++step_counter;
     s.action_in = action_dev;
-    return be.launch(s, tables_dev, CL, /*reset=*/0, stream) ? fail("launch failed: " + be.error()) : 0;
+    return be.launch(s, packed_dev, CL, /*reset=*/0, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 
   void destroy() {

@@ -43,9 +43,10 @@ struct HostCtx {
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
   Team<LPE>* team;
-  const rl::Tables* T;
+  const void* T;
   int k_, sub_, e_, sense_ = 0;
-  const rl::Tables& tables() const { return *T; }
+  template <class TT>
+  const TT& tables() const { return *static_cast<const TT*>(T); }
   int k() const { return k_; }
   int sub() const { return sub_; }
   int env() const { return e_; }
@@ -116,7 +117,8 @@ struct HostCtx {
 };
 
 template <class TP, int SUB>
-void run(const rl::KState& S, const rl::Tables* T, int reset) {
+void run(const rl::KState& S, const void* Tv, int reset) {
+  const rl::TablesT<TP>* T = static_cast<const rl::TablesT<TP>*>(Tv);
   using Ctx = HostCtx<SUB>;
   Team<Ctx::LPE> team;
   team.stage[0].assign(std::max(1, T->policy_dim), 0.f);
@@ -156,7 +158,7 @@ struct Backend {
   void zero(void* p, size_t n) { std::memset(p, 0, n); }
   void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
   void h2d_stream(void* d, const void* s, size_t n, void*) { std::memcpy(d, s, n); }
-  int launch(const rl::KState& S, const rl::Tables* T, int CL, int reset, void*) {
+  int launch(const rl::KState& S, const void* T, int CL, int reset, void*) {
     switch (CL * 10 + sub) {
       case 31: run<rl::TopoQuad3, 1>(S, T, reset); return 0;
       case 41: run<rl::TopoQuad4, 1>(S, T, reset); return 0;
