@@ -98,65 +98,115 @@ RL_FN void terrain_sample(const Uni& u, const float* __restrict__ hf, float x, f
 
 RL_FN M3 ld_m3(const float* p) { return M3{{p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}}; }
 
-template <class TP>
-struct Chain {  // kinematics in base coordinates: the lane's limb (R, p, ax) and the trunk joints (Rw, pw, axw)
+// Kinematics in base coordinates: the lane's limb (R, p, ax per joint) and the trunk joints (Rw, pw, axw).
+// Two storage modes behind one accessor interface:
+//   * registers (quadrupeds: 3-4 joints, everything stays in VGPRs);
+//   * LDS words shared by the sub-lanes of a limb (G1: 7 + 3 joints = 150 words that the register allocator
+//     otherwise spills to scratch around the 16 x 16 system; the sub-lanes hold identical values, so they
+//     read / write the same word - a broadcast, no bank conflict: word w of limb l sits at b[w * STRIDE]).
+template <class TP, bool LDS, int STRIDE>
+struct ChainT;
+
+template <class TP, int STRIDE>
+struct ChainT<TP, false, STRIDE> {
   static constexpr int CL = TP::CL, NW = TP::NW, NWA = TP::NW > 0 ? TP::NW : 1;
-  M3 R[CL];
-  V3 p[CL], ax[CL];
-  M3 Rw[NWA];
-  V3 pw[NWA], axw[NWA];
-  // frame of the trunk link reached after `depth` trunk joints (0 = the base itself)
-  RL_FN void trunk_frame(int depth, M3& Rf, V3& pf) const {
-    Rf = identity3();
-    pf = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NW; ++i)
-      if (depth == i + 1) { Rf = Rw[i]; pf = pw[i]; }
-  }
+  M3 R_[CL];
+  V3 p_[CL], ax_[CL];
+  M3 Rw_[NWA];
+  V3 pw_[NWA], axw_[NWA];
+  RL_FN explicit ChainT(float*) {}
+  RL_FN M3 R(int j) const { return R_[j]; }
+  RL_FN V3 p(int j) const { return p_[j]; }
+  RL_FN V3 ax(int j) const { return ax_[j]; }
+  RL_FN M3 Rw(int i) const { return Rw_[i]; }
+  RL_FN V3 pw(int i) const { return pw_[i]; }
+  RL_FN V3 axw(int i) const { return axw_[i]; }
+  RL_FN void set(int j, const M3& R, V3 p, V3 ax) { R_[j] = R; p_[j] = p; ax_[j] = ax; }
+  RL_FN void setw(int i, const M3& R, V3 p, V3 ax) { Rw_[i] = R; pw_[i] = p; axw_[i] = ax; }
 };
 
-template <class TP>
-RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], Chain<TP>& C) {
+template <class TP, int STRIDE>
+struct ChainT<TP, true, STRIDE> {
+  static constexpr int CL = TP::CL, NW = TP::NW;
+  static constexpr int WORDS = (CL + NW) * 15;
+  float* b;
+  RL_FN explicit ChainT(float* base) : b(base) {}
+  RL_FN float w(int i) const { return b[i * STRIDE]; }
+  RL_FN V3 v3(int o) const { return {w(o), w(o + 1), w(o + 2)}; }
+  RL_FN M3 m3(int o) const { return M3{v3(o), v3(o + 3), v3(o + 6)}; }
+  RL_FN void put3(int o, V3 v) { b[o * STRIDE] = v.x; b[(o + 1) * STRIDE] = v.y; b[(o + 2) * STRIDE] = v.z; }
+  RL_FN void putj(int o, const M3& R, V3 p, V3 ax) { put3(o, R.r0); put3(o + 3, R.r1); put3(o + 6, R.r2); put3(o + 9, p); put3(o + 12, ax); }
+  RL_FN M3 R(int j) const { return m3(j * 15); }
+  RL_FN V3 p(int j) const { return v3(j * 15 + 9); }
+  RL_FN V3 ax(int j) const { return v3(j * 15 + 12); }
+  RL_FN M3 Rw(int i) const { return m3((CL + i) * 15); }
+  RL_FN V3 pw(int i) const { return v3((CL + i) * 15 + 9); }
+  RL_FN V3 axw(int i) const { return v3((CL + i) * 15 + 12); }
+  RL_FN void set(int j, const M3& R, V3 p, V3 ax) { putj(j * 15, R, p, ax); }
+  RL_FN void setw(int i, const M3& R, V3 p, V3 ax) { putj((CL + i) * 15, R, p, ax); }
+};
+
+// frame of the trunk link reached after `depth` trunk joints (0 = the base itself)
+template <class TP, class CT>
+RL_FN void trunk_frame(const CT& C, int depth, M3& Rf, V3& pf) {
+  Rf = identity3();
+  pf = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TP::NW; ++i)
+    if (depth == i + 1) { Rf = C.Rw(i); pf = C.pw(i); }
+}
+
+template <class TP, class CT>
+RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C) {
   constexpr int CL = TP::CL, NW = TP::NW;
-  M3 Rp = identity3();
-  V3 pp{0.f, 0.f, 0.f};
+  M3 Rp = identity3(), Ra = identity3();
+  V3 pp{0.f, 0.f, 0.f}, pa{0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NW; ++i) {  // trunk joints (same in every lane)
     const int jx = CL + i;
     V3 al = ld3(L.axis[jx]);
     M3 Rj0 = mul(Rp, ld_m3(L.rot0[TP::ROT ? jx : 0]));
-    C.pw[i] = pp + mul(Rp, ld3(L.origin[jx]));
-    C.axw[i] = mul(Rj0, al);
-    C.Rw[i] = mul(Rj0, rodrigues(al, q[jx]));
-    Rp = C.Rw[i];
-    pp = C.pw[i];
+    V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
+    M3 Rj = mul(Rj0, rodrigues(al, q[jx]));
+    C.setw(i, Rj, pj, mul(Rj0, al));
+    Rp = Rj;
+    pp = pj;
+    if (L.attach == i + 1) { Ra = Rj; pa = pj; }
   }
-  C.trunk_frame(NW > 0 ? L.attach : 0, Rp, pp);
+  Rp = Ra;
+  pp = pa;
 #pragma unroll
   for (int j = 0; j < CL; ++j) {
     V3 al = ld3(L.axis[j]);
-    C.p[j] = pp + mul(Rp, ld3(L.origin[j]));
+    V3 pj = pp + mul(Rp, ld3(L.origin[j]));
     if (TP::ROT) Rp = mul(Rp, ld_m3(L.rot0[TP::ROT ? j : 0]));
-    C.ax[j] = mul(Rp, al);
-    C.R[j] = mul(Rp, rodrigues(al, q[j]));
-    Rp = C.R[j];
-    pp = C.p[j];
+    M3 Rj = mul(Rp, rodrigues(al, q[j]));
+    C.set(j, Rj, pj, mul(Rp, al));
+    Rp = Rj;
+    pp = pj;
   }
 }
 
 // velocity (base coords) of the point x rigidly attached to a link that is moved by the first `wd` trunk
 // joints and the first `lg` limb joints
-template <class TP>
-RL_FN V3 point_velocity(const Chain<TP>& C, int wd, int lg, V3 x, SV V0, const float (&qd)[TP::JX]) {
+template <class TP, class CT>
+RL_FN V3 point_velocity(const CT& C, int wd, int lg, V3 x, SV V0, const float (&qd)[TP::JX]) {
   V3 u = V0.l + cross(V0.a, x);
 #pragma unroll
   for (int i = 0; i < TP::NW; ++i)
-    if (i < wd) u += qd[TP::CL + i] * cross(C.axw[i], x - C.pw[i]);
+    if (i < wd) u += qd[TP::CL + i] * cross(C.axw(i), x - C.pw(i));
 #pragma unroll
   for (int i = 0; i < TP::CL; ++i)
-    if (i < lg) u += qd[i] * cross(C.ax[i], x - C.p[i]);
+    if (i < lg) u += qd[i] * cross(C.ax(i), x - C.p(i));
   return u;
 }
+
+// symmetric system / right-hand side stored in limb-shared LDS words (same idea as ChainT<.., true, ..>)
+template <int STRIDE>
+struct LdsVec {
+  float* p;
+  RL_FN float& operator[](int i) const { return p[i * STRIDE]; }
+};
 
 // Lane-private LDS scratchpad: word f of a lane lives at base[f * STRIDE] (STRIDE = 64 on the GPU, so
 // a wavefront access hits 64 different banks).  It holds the per-body contact-sensor state (timers,
@@ -171,6 +221,12 @@ struct LsMat {
   float* p;
   RL_FN LsRow<STRIDE, W> operator[](int b) const { return {p + b * W * STRIDE}; }
 };
+// words of limb-shared LDS an instance needs (0 when it keeps everything in registers)
+template <class TP>
+struct LbLayout {
+  enum { WORDS = TP::NW > 0 ? (TP::JX * 15 + SymIdx<TP::NB + TP::CL>::size + TP::NB + TP::CL) : 0 };
+};
+
 template <int NBS>
 struct LsLayout {
   enum { TIM = 0, HIST = TIM + NBS * 4, CF = HIST + NBS * 3, FRIC = CF + NBS * 3, WORDS = FRIC + NBS * 3 };
@@ -187,6 +243,14 @@ struct EnvLane {
   static constexpr uint32_t ROW = NLANE * EPT;  // entries of a lane-field row
   static constexpr int NV = NB + CL;  // per-lane system: [omega_b, v_b, trunk joints, limb joints]
   using UI = SymIdx<NV>;
+  // G1-sized instances keep the kinematics and the (NV x NV) system in limb-shared LDS words instead of
+  // VGPRs (hipcc otherwise spills ~3.5 KB per lane to scratch: 0.9 GB of HBM traffic per step at 2048 envs)
+  static constexpr Layout LY{CL, NW, NBS};  // field rows of this instance's HBM tiles
+  static constexpr bool LDSU = TP::NW > 0;
+  static constexpr int LBS = Ctx::LB_STRIDE;
+  using ChainTP = ChainT<TP, LDSU, LBS>;
+  enum { LB_CHAIN = 0, LB_U = (CL + NW) * 15, LB_RV = LB_U + UI::size, LB_WORDS = LB_RV + NV };
+  RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_scratch() + LB_CHAIN * LBS : nullptr); }
 
   Ctx& ctx;
   const KState& S;
@@ -219,8 +283,8 @@ struct EnvLane {
     sub = ctx.sub();
     li = k * SUB + sub;
     Np = S.Npad;
-    lt = S.lane_state + (size_t)ctx.tile() * ((size_t)NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
-    et = S.env_state + (size_t)ctx.tile() * ((size_t)NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
+    lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
+    et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
   }
   RL_FN float& LF(int f) const { return lt[(uint32_t)f * ROW]; }
   RL_FN float& EF(int f) const { return et[(uint32_t)f * (uint32_t)EPT]; }
@@ -230,30 +294,30 @@ struct EnvLane {
 
   // ------------------------------------------------------------------ load / store
   RL_FN void load() {
-    pos = {EF(EF_ROOT + 0), EF(EF_ROOT + 1), EF(EF_ROOT + 2)};
-    quat = {EF(EF_ROOT + 3), EF(EF_ROOT + 4), EF(EF_ROOT + 5), EF(EF_ROOT + 6)};
-    vlin = {EF(EF_ROOT + 7), EF(EF_ROOT + 8), EF(EF_ROOT + 9)};
-    vang = {EF(EF_ROOT + 10), EF(EF_ROOT + 11), EF(EF_ROOT + 12)};
-    extF = {EF(EF_WRENCH + 0), EF(EF_WRENCH + 1), EF(EF_WRENCH + 2)};
-    extT = {EF(EF_WRENCH + 3), EF(EF_WRENCH + 4), EF(EF_WRENCH + 5)};
-    base_com = {EF(EF_BASE_COM + 0), EF(EF_BASE_COM + 1), EF(EF_BASE_COM + 2)};
-    if (NW > 0) wr_com = {EF(EF_WR_COM + 0), EF(EF_WR_COM + 1), EF(EF_WR_COM + 2)};
+    pos = {EF(LY.EF_ROOT + 0), EF(LY.EF_ROOT + 1), EF(LY.EF_ROOT + 2)};
+    quat = {EF(LY.EF_ROOT + 3), EF(LY.EF_ROOT + 4), EF(LY.EF_ROOT + 5), EF(LY.EF_ROOT + 6)};
+    vlin = {EF(LY.EF_ROOT + 7), EF(LY.EF_ROOT + 8), EF(LY.EF_ROOT + 9)};
+    vang = {EF(LY.EF_ROOT + 10), EF(LY.EF_ROOT + 11), EF(LY.EF_ROOT + 12)};
+    extF = {EF(LY.EF_WRENCH + 0), EF(LY.EF_WRENCH + 1), EF(LY.EF_WRENCH + 2)};
+    extT = {EF(LY.EF_WRENCH + 3), EF(LY.EF_WRENCH + 4), EF(LY.EF_WRENCH + 5)};
+    base_com = {EF(LY.EF_BASE_COM + 0), EF(LY.EF_BASE_COM + 1), EF(LY.EF_BASE_COM + 2)};
+    if (NW > 0) wr_com = {EF(LY.EF_WR_COM + 0), EF(LY.EF_WR_COM + 1), EF(LY.EF_WR_COM + 2)};
     else wr_com = base_com;  // quadrupeds: the wrench body is the root body
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
-      q[j] = LF(LF_Q + j);
-      qd[j] = LF(LF_QD + j);
-      kp[j] = LF(LF_KP + j);
-      kd[j] = LF(LF_KD + j);
-      act[j] = LF(LF_ACT + j);
+      q[j] = LF(LY.LF_Q + j);
+      qd[j] = LF(LY.LF_QD + j);
+      kp[j] = LF(LY.LF_KP + j);
+      kd[j] = LF(LY.LF_KD + j);
+      act[j] = LF(LY.LF_ACT + j);
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      q[CL + i] = EF(EF_TQ + i);
-      qd[CL + i] = EF(EF_TQD + i);
-      kp[CL + i] = EF(EF_TKP + i);
-      kd[CL + i] = EF(EF_TKD + i);
-      act[CL + i] = EF(EF_TACT + i);
+      q[CL + i] = EF(LY.EF_TQ + i);
+      qd[CL + i] = EF(LY.EF_TQD + i);
+      kp[CL + i] = EF(LY.EF_TKP + i);
+      kd[CL + i] = EF(LY.EF_TKD + i);
+      act[CL + i] = EF(LY.EF_TACT + i);
     }
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
@@ -263,9 +327,9 @@ struct EnvLane {
 #pragma unroll
     for (int s = 0; s < NBS; ++s) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) tim[s][t] = LF(LF_TIMERS + s * 4 + t);
+      for (int t = 0; t < 4; ++t) tim[s][t] = LF(LY.LF_TIMERS + s * 4 + t);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) fric[s][t] = LF(LF_FRICTION + s * 3 + t);
+      for (int t = 0; t < 3; ++t) fric[s][t] = LF(LY.LF_FRICTION + s * 3 + t);
       cf[s][0] = cf[s][1] = cf[s][2] = 0.f;
       hist_n[s][0] = hist_n[s][1] = hist_n[s][2] = 0.f;
     }
@@ -273,36 +337,36 @@ struct EnvLane {
 
   RL_FN void store() {
     if (li == 0) {
-      EF(EF_ROOT + 0) = pos.x; EF(EF_ROOT + 1) = pos.y; EF(EF_ROOT + 2) = pos.z;
-      EF(EF_ROOT + 3) = quat.w; EF(EF_ROOT + 4) = quat.x; EF(EF_ROOT + 5) = quat.y; EF(EF_ROOT + 6) = quat.z;
-      EF(EF_ROOT + 7) = vlin.x; EF(EF_ROOT + 8) = vlin.y; EF(EF_ROOT + 9) = vlin.z;
-      EF(EF_ROOT + 10) = vang.x; EF(EF_ROOT + 11) = vang.y; EF(EF_ROOT + 12) = vang.z;
-      EF(EF_WRENCH + 0) = extF.x; EF(EF_WRENCH + 1) = extF.y; EF(EF_WRENCH + 2) = extF.z;
-      EF(EF_WRENCH + 3) = extT.x; EF(EF_WRENCH + 4) = extT.y; EF(EF_WRENCH + 5) = extT.z;
+      EF(LY.EF_ROOT + 0) = pos.x; EF(LY.EF_ROOT + 1) = pos.y; EF(LY.EF_ROOT + 2) = pos.z;
+      EF(LY.EF_ROOT + 3) = quat.w; EF(LY.EF_ROOT + 4) = quat.x; EF(LY.EF_ROOT + 5) = quat.y; EF(LY.EF_ROOT + 6) = quat.z;
+      EF(LY.EF_ROOT + 7) = vlin.x; EF(LY.EF_ROOT + 8) = vlin.y; EF(LY.EF_ROOT + 9) = vlin.z;
+      EF(LY.EF_ROOT + 10) = vang.x; EF(LY.EF_ROOT + 11) = vang.y; EF(LY.EF_ROOT + 12) = vang.z;
+      EF(LY.EF_WRENCH + 0) = extF.x; EF(LY.EF_WRENCH + 1) = extF.y; EF(LY.EF_WRENCH + 2) = extF.z;
+      EF(LY.EF_WRENCH + 3) = extT.x; EF(LY.EF_WRENCH + 4) = extT.y; EF(LY.EF_WRENCH + 5) = extT.z;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
-        EF(EF_TQ + i) = q[CL + i];
-        EF(EF_TQD + i) = qd[CL + i];
-        EF(EF_TKP + i) = kp[CL + i];
-        EF(EF_TKD + i) = kd[CL + i];
-        EF(EF_TACT + i) = act[CL + i];
+        EF(LY.EF_TQ + i) = q[CL + i];
+        EF(LY.EF_TQD + i) = qd[CL + i];
+        EF(LY.EF_TKP + i) = kp[CL + i];
+        EF(LY.EF_TKD + i) = kd[CL + i];
+        EF(LY.EF_TACT + i) = act[CL + i];
       }
     }
     if (sub == 0) {
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
-        LF(LF_Q + j) = q[j];
-        LF(LF_QD + j) = qd[j];
-        LF(LF_KP + j) = kp[j];
-        LF(LF_KD + j) = kd[j];
-        LF(LF_ACT + j) = act[j];
+        LF(LY.LF_Q + j) = q[j];
+        LF(LY.LF_QD + j) = qd[j];
+        LF(LY.LF_KP + j) = kp[j];
+        LF(LY.LF_KD + j) = kd[j];
+        LF(LY.LF_ACT + j) = act[j];
       }
     }
 #pragma unroll
     for (int s = 0; s < NBS; ++s)
       if (owns_slot(s)) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) LF(LF_TIMERS + s * 4 + t) = tim[s][t];
+        for (int t = 0; t < 4; ++t) LF(LY.LF_TIMERS + s * 4 + t) = tim[s][t];
       }
   }
 
@@ -345,19 +409,19 @@ struct EnvLane {
   // joints that move link group g: the first wdepth(g) trunk joints and the first g limb joints
   RL_FN int wdepth(int g) const { return NW == 0 ? 0 : (g == 0 ? L.grp0_depth : L.attach); }
   // sphere centre in base coordinates (cb) and world (cw); empty slots (radius <= 0) sit at the group's link origin
-  RL_FN void sphere_center(const Chain<TP>& C, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
+  RL_FN void sphere_center(const ChainTP& C, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
     rad = L.sph_r[g][s];
     V3 cl = ld3(L.sph_c[g][s]);
     cb = cl;
     if (NW > 0) {
       M3 Rf;
       V3 pf;
-      C.trunk_frame(L.grp0_depth, Rf, pf);
+      trunk_frame<TP>(C, L.grp0_depth, Rf, pf);
       cb = pf + mul(Rf, cl);
     }
 #pragma unroll
     for (int j = 0; j < CL; ++j)
-      if (g == j + 1) cb = C.p[j] + mul(C.R[j], cl);
+      if (g == j + 1) cb = C.p(j) + mul(C.R(j), cl);
     cw = pos + mul(Rwb, cb);
   }
   // penetration depth and world normal of a fetched patch (straight-line: three of these interleave)
@@ -366,13 +430,13 @@ struct EnvLane {
     terrain_eval(u, tp, hz, nw);
     phi = rad > 0.f ? rad - (cw.z - hz) * nw.z : -1.f;
   }
-  RL_FN Contact contact_from_phi(const Chain<TP>& C, const M3& Rwb, SV V0, const float (&qdv)[JX], int g, int s, float rad, V3 cb, float phi, V3 nw) const {
+  RL_FN Contact contact_from_phi(const ChainTP& C, const M3& Rwb, SV V0, const float (&qdv)[JX], int g, int s, float rad, V3 cb, float phi, V3 nw) const {
     Contact c;
     c.act = false;
     if (phi > 0.f) {
       V3 nb = mulT(Rwb, nw);
       V3 x = cb - rad * nb;
-      V3 uu = point_velocity<TP>(C, wdepth(g), g, x, V0, qdv);
+      V3 uu = point_velocity<TP, ChainTP>(C, wdepth(g), g, x, V0, qdv);
       float un = dot(nb, uu);
       V3 ut = uu - un * nb;
       float utn = norm(ut);
@@ -391,7 +455,7 @@ struct EnvLane {
     }
     return c;
   }
-  RL_FN Contact contact_from_patch(const Chain<TP>& C, const M3& Rwb, SV V0, const float (&qdv)[JX], int g, int s, float rad, V3 cb, V3 cw,
+  RL_FN Contact contact_from_patch(const ChainTP& C, const M3& Rwb, SV V0, const float (&qdv)[JX], int g, int s, float rad, V3 cb, V3 cw,
                                    const TerrainPatch& tp) const {
     float phi;
     V3 nw;
@@ -404,7 +468,7 @@ struct EnvLane {
   // (U, rv).  With SUB == 4 the four sub-lanes of a leg run this same code on different groups (g is a
   // per-lane value) and the caller quad-sums the result; with SUB == 1 the lane loops over all groups.
   // Joint columns of the system: 6 + m, m in [0, NW) the trunk joints, m in [NW, NW + CL) the limb joints.
-  RL_FN void contact_pass1(const Chain<TP>& C, const M3& Rwb, SV V0, uint32_t slot_valid, float (&U)[UI::size], float (&rv)[NV], uint32_t& active_mask) {
+  RL_FN void contact_pass1(const ChainTP& C, const M3& Rwb, SV V0, uint32_t slot_valid, float (&U)[UI::size], float (&rv)[NV], uint32_t& active_mask) {
     const float dt = u.dt;
 #pragma unroll 1
     for (int g = (SUB == 1 ? 0 : sub); g <= CL; g += SUB) {
@@ -463,7 +527,7 @@ struct EnvLane {
             cj[m] = {0.f, 0.f, 0.f};
             gc[m] = 0.f;
             if (moves) {
-              cj[m] = m < NW ? cross(C.axw[m < NW ? m : 0], x - C.pw[m < NW ? m : 0]) : cross(C.ax[m < NW ? 0 : m - NW], x - C.p[m < NW ? 0 : m - NW]);
+              cj[m] = m < NW ? cross(C.axw(m < NW ? m : 0), x - C.pw(m < NW ? m : 0)) : cross(C.ax(m < NW ? 0 : m - NW), x - C.p(m < NW ? 0 : m - NW));
               gc[m] = dot(cj[m], n);
               const V3 w = cross(x, cj[m]);
               const float kg = kn * gc[m];
@@ -481,7 +545,8 @@ struct EnvLane {
 
   // U/rv += a rigid composite with spatial inertia I (base coords), momentum h and bias force f that rides
   // on the trunk link reached after `depth` trunk joints: base block, trunk-joint columns, bias.
-  RL_FN void add_composite(const SI& I, const SV& h, const SV& f, int depth, const SV (&Sw)[TP::NW > 0 ? TP::NW : 1], float (&U)[UI::size], float (&rv)[NV]) const {
+  template <class UT, class RT>
+  RL_FN void add_composite(const SI& I, const SV& h, const SV& f, int depth, const SV (&Sw)[TP::NW > 0 ? TP::NW : 1], UT& U, RT& rv) const {
     const float dt = u.dt;
     // 6x6 block from the spatial inertia: [[I, hx],[hx^T, m 1]]
     U[UI::at(0, 0)] += I.I.xx; U[UI::at(1, 1)] += I.I.yy; U[UI::at(2, 2)] += I.I.zz;
@@ -511,36 +576,51 @@ struct EnvLane {
     // keep the compiler from hoisting the (loop-invariant) LDS table reads of all four substeps to the
     // top of the kernel, where ~200 of them stayed live and spilled to scratch
     asm volatile("" ::: "memory");
-    const float dt = u.dt;
     float tau_e[JX], pd_diag[JX], pd_rhs[JX];
     actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
 
     const M3 Rwb = quat_to_mat(quat);
     SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
     SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
-    Chain<TP> C;
+    ChainTP C = new_chain();
     chain_kinematics<TP>(L, q, C);
 
-    float U[UI::size];
-    float rv[NV];
+    float Uc[UI::size];
+    float rvc[NV];
 #pragma unroll
-    for (int i = 0; i < UI::size; ++i) U[i] = 0.f;
+    for (int i = 0; i < UI::size; ++i) Uc[i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) rv[i] = 0.f;
+    for (int i = 0; i < NV; ++i) rvc[i] = 0.f;
 
     // ---- contacts first (they only need the kinematics): every sub-lane accumulates the spheres of its
     // link groups into the zero-initialised (U, rv), the leg's sub-lanes are quad-summed, and the CRBA
-    // terms below are added on top - so only one copy of the system is ever live.
+    // terms are added on top - so only one copy of the system is ever live.
     uint32_t active_mask = 0;
     const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
-    contact_pass1(C, Rwb, V0, slot_valid, U, rv, active_mask);
+    contact_pass1(C, Rwb, V0, slot_valid, Uc, rvc, active_mask);
     if (SUB > 1 && ctx.any(active_mask != 0u)) {
 #pragma unroll
-      for (int i = 0; i < UI::size; ++i) U[i] = ctx.leg_sum(U[i]);
+      for (int i = 0; i < UI::size; ++i) Uc[i] = ctx.leg_sum(Uc[i]);
 #pragma unroll
-      for (int i = 0; i < NV; ++i) rv[i] = ctx.leg_sum(rv[i]);
+      for (int i = 0; i < NV; ++i) rvc[i] = ctx.leg_sum(rvc[i]);
     }
+    if constexpr (LDSU) {
+      LdsVec<LBS> U{ctx.limb_scratch() + LB_U * LBS}, rv{ctx.limb_scratch() + LB_RV * LBS};
+#pragma unroll
+      for (int i = 0; i < UI::size; ++i) U[i] = Uc[i];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) rv[i] = rvc[i];
+      solve_and_integrate(U, rv, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
+    } else {
+      solve_and_integrate(Uc, rvc, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
+    }
+  }
 
+  // CRBA / RNEA terms on top of the contact terms, Schur complement, trunk solve, contact sensor, integration
+  template <class UT, class RT>
+  RL_FN void solve_and_integrate(UT& U, RT& rv, const ChainTP& C, const M3& Rwb, const SV V0, const SV a0, const float (&tau_e)[JX], const float (&pd_diag)[JX],
+                                 const float (&pd_rhs)[JX], const uint32_t active_mask) {
+    const float dt = u.dt;
     // ---- trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
     constexpr int NWA = NW > 0 ? NW : 1;
     SV Sw[NWA], Vw[NWA], aw[NWA];
@@ -548,7 +628,7 @@ struct EnvLane {
       SV Vp = V0, ap = a0;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
-        Sw[i] = SV{C.axw[i], cross(C.pw[i], C.axw[i])};
+        Sw[i] = SV{C.axw(i), cross(C.pw(i), C.axw(i))};
         SV vj = Sw[i] * qd[CL + i];
         Vw[i] = Vp + vj;
         aw[i] = ap + crm(Vw[i], vj);
@@ -567,14 +647,14 @@ struct EnvLane {
         if (L.attach == i + 1) { Vp = Vw[i]; ap = aw[i]; }
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
-        Sj[j] = SV{C.ax[j], cross(C.p[j], C.ax[j])};
+        Sj[j] = SV{C.ax(j), cross(C.p(j), C.ax(j))};
         SV vj = Sj[j] * qd[j];
         SV Vj = Vp + vj;
         SV aj = ap + crm(Vj, vj);
         // per-env link inertia (mass, com, inertia about com; randomised at startup) straight from HBM/L1
-        const int li = LF_INERTIA + j * INERTIA_NF;
-        V3 cb = C.p[j] + mul(C.R[j], V3{LF(li + 1), LF(li + 2), LF(li + 3)});
-        Ic[j] = make_si(LF(li), cb, rotate(C.R[j], S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
+        const int li = LY.LF_INERTIA + j * INERTIA_NF;
+        V3 cb = C.p(j) + mul(C.R(j), V3{LF(li + 1), LF(li + 2), LF(li + 3)});
+        Ic[j] = make_si(LF(li), cb, rotate(C.R(j), S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
         Hs[j] = apply(Ic[j], Vj);
         Fs[j] = apply(Ic[j], aj) + crf(Vj, Hs[j]);
         Vp = Vj;
@@ -587,26 +667,43 @@ struct EnvLane {
         Hs[j] = Hs[j] + Hs[j + 1];
       }
     }
-    add_composite(Ic[0], Hs[0], Fs[0], NW > 0 ? L.attach : 0, Sw, U, rv);
-    if (k <= NW) {  // lane group k adds trunk link k (0 = the base link) + the persistent external wrench [UPSTREAM B8]
-      const int bi = EF_BASE_INERTIA + k * INERTIA_NF;
-      M3 Rf;
-      V3 pf;
-      C.trunk_frame(k, Rf, pf);
-      SV Vl = V0, al = a0;
-#pragma unroll
-      for (int i = 0; i < NW; ++i)
-        if (k == i + 1) { Vl = Vw[i]; al = aw[i]; }
-      const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
-      const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
-      SV h0 = apply(I0, Vl);
-      SV f0 = apply(I0, al) + crf(Vl, h0);
-      if (k == (NW > 0 ? T.wrench_depth : 0)) {
-        const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
-        f0.a -= mul(Rf, extT) + cross(xc, Fb);
-        f0.l -= Fb;
+    if constexpr (NW == 0) {  // quadrupeds: the base link rides in lane group 0's composite
+      SI Itop = Ic[0];
+      SV ftop = Fs[0], htop = Hs[0];
+      if (k == 0) {  // the base link itself, its bias force and the persistent external wrench [UPSTREAM B8]
+        const int bi = LY.EF_BASE_INERTIA;
+        const SI I0 = make_si(EF(bi), V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)}, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)});
+        SV h0 = apply(I0, V0);
+        SV f0 = apply(I0, a0) + crf(V0, h0);
+        f0.a -= extT + cross(base_com, extF);
+        f0.l -= extF;
+        Itop = Itop + I0;
+        ftop = ftop + f0;
+        htop = htop + h0;
       }
-      add_composite(I0, h0, f0, k, Sw, U, rv);
+      add_composite(Itop, htop, ftop, 0, Sw, U, rv);
+    } else {
+      add_composite(Ic[0], Hs[0], Fs[0], L.attach, Sw, U, rv);
+      if (k <= NW) {  // lane group k adds trunk link k (0 = the base link) + the persistent external wrench [UPSTREAM B8]
+        const int bi = LY.EF_BASE_INERTIA + k * INERTIA_NF;
+        M3 Rf;
+        V3 pf;
+        trunk_frame<TP>(C, k, Rf, pf);
+        SV Vl = V0, al = a0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+          if (k == i + 1) { Vl = Vw[i]; al = aw[i]; }
+        const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
+        const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
+        SV h0 = apply(I0, Vl);
+        SV f0 = apply(I0, al) + crf(Vl, h0);
+        if (k == T.wrench_depth) {
+          const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
+          f0.a -= mul(Rf, extT) + cross(xc, Fb);
+          f0.l -= Fb;
+        }
+        add_composite(I0, h0, f0, k, Sw, U, rv);
+      }
     }
     if (NW > 0 && k == 0) {  // joint-local terms of the trunk joints (armature, actuators, limits): once
 #pragma unroll
@@ -755,7 +852,7 @@ struct EnvLane {
       sphere_center(C, Rwb, g, s, rad, cb, cw);
       Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
       if (c.act) {
-        V3 uu = point_velocity<TP>(C, wdepth(g), g, c.x, V0n, qdn);
+        V3 uu = point_velocity<TP, ChainTP>(C, wdepth(g), g, c.x, V0n, qdn);
         float un = dot(c.n, uu);
         V3 Fb = (c.bias - (c.dn - c.dt) * un) * c.n - c.dt * uu;
         V3 Fw = mul(Rwb, Fb);

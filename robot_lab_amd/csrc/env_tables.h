@@ -176,28 +176,36 @@ constexpr int INERTIA_NF = 10;
 // reads/writes whole coalesced rows, and - the reason for tiling rather than [field][N] planes - every
 // access is `tile base (SGPR) + lane offset (ONE VGPR) + compile-time row offset`; with [field][N]
 // planes hipcc kept ~60 separate 64-bit address pairs live across the kernel (120 VGPRs, profiles/r01).
-enum {  // lane fields (rows of 64)
-  LF_Q = 0, LF_QD = LF_Q + MAX_CL, LF_KP = LF_QD + MAX_CL, LF_KD = LF_KP + MAX_CL, LF_ACT = LF_KD + MAX_CL,
-  LF_INERTIA = LF_ACT + MAX_CL,                    // [MAX_CL][10]
-  LF_TIMERS = LF_INERTIA + MAX_CL * INERTIA_NF,    // [MAX_NBS][4] current_air, current_contact, last_air, last_contact
-  LF_FRICTION = LF_TIMERS + MAX_NBS * 4,           // [MAX_NBS][3] mu_s, mu_d, restitution
-  NF_LANE = LF_FRICTION + MAX_NBS * 3
-};
-enum {  // env fields (rows of 16)
-  EF_ROOT = 0,                 // pos(3) quat wxyz(4) lin vel (3, world, link origin) ang vel (3, world)
-  EF_WRENCH = EF_ROOT + 13,    // force(3) torque(3), base-body frame
-  EF_BASE_INERTIA = EF_WRENCH + 6,             // [1 + MAX_NW][10] trunk links: base, then the link after each trunk joint
-  EF_BASE_COM = EF_BASE_INERTIA + (1 + MAX_NW) * INERTIA_NF,  // COM of the root *body* in the base frame (root COM velocity)
-  EF_WR_COM = EF_BASE_COM + 3,                 // COM of the wrench body in its trunk link frame
-  EF_TQ = EF_WR_COM + 3, EF_TQD = EF_TQ + MAX_NW, EF_TKP = EF_TQD + MAX_NW, EF_TKD = EF_TKP + MAX_NW, EF_TACT = EF_TKD + MAX_NW,  // trunk joints
-  EF_CMD = EF_TACT + MAX_NW,
-  EF_ORIGIN = EF_CMD + CMD_NFIELD,
-  NF_ENV = EF_ORIGIN + 3
+// Field rows of a tile for an instance shape (CL limb joints, NW trunk joints, NBS body slots): only the
+// rows the instance uses exist, so a tile is one dense block of HBM.
+struct Layout {
+  // lane fields (one float per limb)
+  int LF_Q, LF_QD, LF_KP, LF_KD, LF_ACT;
+  int LF_INERTIA;   // [CL][10]
+  int LF_TIMERS;    // [NBS][4] current_air, current_contact, last_air, last_contact
+  int LF_FRICTION;  // [NBS][3] mu_s, mu_d, restitution
+  int NF_LANE;
+  // env fields (one float per env)
+  int EF_ROOT;          // pos(3) quat wxyz(4) lin vel (3, world, link origin) ang vel (3, world)
+  int EF_WRENCH;        // force(3) torque(3), base-body frame
+  int EF_BASE_INERTIA;  // [1 + NW][10] trunk links: base, then the link after each trunk joint
+  int EF_BASE_COM;      // COM of the root *body* in the base frame (root COM velocity)
+  int EF_WR_COM;        // COM of the wrench body in its trunk link frame
+  int EF_TQ, EF_TQD, EF_TKP, EF_TKD, EF_TACT;  // trunk joints
+  int EF_CMD, EF_ORIGIN, NF_ENV;
+  RL_FN constexpr Layout(int CL, int NW, int NBS)
+      : LF_Q(0), LF_QD(CL), LF_KP(2 * CL), LF_KD(3 * CL), LF_ACT(4 * CL), LF_INERTIA(5 * CL), LF_TIMERS(5 * CL + CL * INERTIA_NF),
+        LF_FRICTION(5 * CL + CL * INERTIA_NF + NBS * 4), NF_LANE(5 * CL + CL * INERTIA_NF + NBS * 7),
+        EF_ROOT(0), EF_WRENCH(13), EF_BASE_INERTIA(19), EF_BASE_COM(19 + (1 + NW) * INERTIA_NF), EF_WR_COM(EF_BASE_COM + 3),
+        EF_TQ(EF_WR_COM + 3), EF_TQD(EF_TQ + NW), EF_TKP(EF_TQD + NW), EF_TKD(EF_TKP + NW), EF_TACT(EF_TKD + NW), EF_CMD(EF_TACT + NW),
+        EF_ORIGIN(EF_CMD + CMD_NFIELD), NF_ENV(EF_ORIGIN + 3) {}
 };
 // `ept` = environments per tile (= per wavefront): 16 when one lane simulates a leg, 4 when a leg is
 // spread over 4 sub-lanes.  A lane-field row then has 4*ept entries (one per leg), an env-field row ept.
-RL_FN size_t lane_index(int e, int k, int f, int ept) { return ((size_t)(e / ept) * NF_LANE + (size_t)f) * (size_t)(NLANE * ept) + (size_t)(e % ept) * NLANE + k; }
-RL_FN size_t env_index(int e, int f, int ept) { return ((size_t)(e / ept) * NF_ENV + (size_t)f) * (size_t)ept + (size_t)(e % ept); }
+RL_FN size_t lane_index(const Layout& ly, int e, int k, int f, int ept) {
+  return ((size_t)(e / ept) * ly.NF_LANE + (size_t)f) * (size_t)(NLANE * ept) + (size_t)(e % ept) * NLANE + k;
+}
+RL_FN size_t env_index(const Layout& ly, int e, int f, int ept) { return ((size_t)(e / ept) * ly.NF_ENV + (size_t)f) * (size_t)ept + (size_t)(e % ept); }
 
 struct KState {
   int32_t N;      // environments the caller sees

@@ -42,6 +42,8 @@ struct GenericSpec {
 template <class Ctx, class TP, class Spec = GenericSpec>
 struct EnvProgram : EnvLane<Ctx, TP> {
   using Base = EnvLane<Ctx, TP>;
+  using ChainTP = typename Base::ChainTP;
+  static constexpr Layout LY = Base::LY;
   static constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NBS = TP::NBS;
   using Base::ctx; using Base::S; using Base::T; using Base::L; using Base::e; using Base::k; using Base::sub; using Base::li; using Base::Np;
   static constexpr int SUB = Base::SUB;
@@ -65,28 +67,28 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   RL_FN EnvProgram(Ctx& c, const KState& s) : Base(c, s) {}
 
   RL_FN void load_task() {
-    cmd = {this->EF(EF_CMD + CMD_VX), this->EF(EF_CMD + CMD_VY), this->EF(EF_CMD + CMD_WZ)};
-    heading_target = this->EF(EF_CMD + CMD_HEADING);
-    cmd_time_left = this->EF(EF_CMD + CMD_TIME_LEFT);
-    metric_xy = this->EF(EF_CMD + CMD_METRIC_XY);
-    metric_yaw = this->EF(EF_CMD + CMD_METRIC_YAW);
-    push_left = this->EF(EF_CMD + CMD_PUSH_LEFT);
+    cmd = {this->EF(LY.EF_CMD + CMD_VX), this->EF(LY.EF_CMD + CMD_VY), this->EF(LY.EF_CMD + CMD_WZ)};
+    heading_target = this->EF(LY.EF_CMD + CMD_HEADING);
+    cmd_time_left = this->EF(LY.EF_CMD + CMD_TIME_LEFT);
+    metric_xy = this->EF(LY.EF_CMD + CMD_METRIC_XY);
+    metric_yaw = this->EF(LY.EF_CMD + CMD_METRIC_YAW);
+    push_left = this->EF(LY.EF_CMD + CMD_PUSH_LEFT);
     int f = S.flags[e];
     is_heading = f & 1;
     is_standing = (f >> 1) & 1;
     level = S.level[e];
     ttype = S.ttype[e];
-    origin = {this->EF(EF_ORIGIN + 0), this->EF(EF_ORIGIN + 1), this->EF(EF_ORIGIN + 2)};
+    origin = {this->EF(LY.EF_ORIGIN + 0), this->EF(LY.EF_ORIGIN + 1), this->EF(LY.EF_ORIGIN + 2)};
     ep_len = S.ep_len[e];
   }
   RL_FN void store_task() {
     if (li != 0) return;
-    this->EF(EF_CMD + CMD_VX) = cmd.x; this->EF(EF_CMD + CMD_VY) = cmd.y; this->EF(EF_CMD + CMD_WZ) = cmd.z;
-    this->EF(EF_CMD + CMD_HEADING) = heading_target; this->EF(EF_CMD + CMD_TIME_LEFT) = cmd_time_left;
-    this->EF(EF_CMD + CMD_METRIC_XY) = metric_xy; this->EF(EF_CMD + CMD_METRIC_YAW) = metric_yaw; this->EF(EF_CMD + CMD_PUSH_LEFT) = push_left;
+    this->EF(LY.EF_CMD + CMD_VX) = cmd.x; this->EF(LY.EF_CMD + CMD_VY) = cmd.y; this->EF(LY.EF_CMD + CMD_WZ) = cmd.z;
+    this->EF(LY.EF_CMD + CMD_HEADING) = heading_target; this->EF(LY.EF_CMD + CMD_TIME_LEFT) = cmd_time_left;
+    this->EF(LY.EF_CMD + CMD_METRIC_XY) = metric_xy; this->EF(LY.EF_CMD + CMD_METRIC_YAW) = metric_yaw; this->EF(LY.EF_CMD + CMD_PUSH_LEFT) = push_left;
     S.flags[e] = (is_heading ? 1 : 0) | (is_standing ? 2 : 0);
     S.level[e] = level;
-    this->EF(EF_ORIGIN + 0) = origin.x; this->EF(EF_ORIGIN + 1) = origin.y; this->EF(EF_ORIGIN + 2) = origin.z;
+    this->EF(LY.EF_ORIGIN + 0) = origin.x; this->EF(LY.EF_ORIGIN + 1) = origin.y; this->EF(LY.EF_ORIGIN + 2) = origin.z;
     S.ep_len[e] = ep_len;
     S.command_out[e * 3 + 0] = cmd.x; S.command_out[e * 3 + 1] = cmd.y; S.command_out[e * 3 + 2] = cmd.z;
   }
@@ -151,7 +153,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
-      uint32_t ji = (uint32_t)(L.joint_id[j] < 0 ? 0 : L.joint_id[j]);  // padding joints: q0 = qd0 = kp0 = kd0 = 0
+      uint32_t ji = (uint32_t)((NW > 0 && L.joint_id[j] < 0) ? 0 : L.joint_id[j]);  // padding joints: q0 = qd0 = kp0 = kd0 = 0
       float qn = L.q0[j], qdn = L.qd0[j];
       if (T.ev_reset_joints) {  // reset_joints_by_scale [UPSTREAM B8]
         qn = clampf(L.q0[j] * U(STREAM_RESET, IDX_JPOS + ji, T.reset_jpos[0], T.reset_jpos[1]), L.soft_lo[j], L.soft_hi[j]);
@@ -210,27 +212,27 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   RL_FN float hist_max(int slot) const { return fmaxf(hist_n[slot][0], fmaxf(hist_n[slot][1], hist_n[slot][2])); }
 
   // position (base coords) and velocity relative to the root COM velocity (base coords) of body slot s
-  RL_FN void body_rel(const Chain<TP>& C, int s, V3& relp, V3& relv) const {
+  RL_FN void body_rel(const ChainTP& C, int s, V3& relp, V3& relv) const {
     int g = L.slot_grp[s];
     V3 bp = ld3(L.slot_pos[s]);
     V3 x = bp;
     if (NW > 0) {
       M3 Rf;
       V3 pf;
-      C.trunk_frame(L.grp0_depth, Rf, pf);
+      trunk_frame<TP>(C, L.grp0_depth, Rf, pf);
       x = pf + mul(Rf, bp);
     }
 #pragma unroll
     for (int j = 0; j < CL; ++j)
-      if (g == j + 1) x = C.p[j] + mul(C.R[j], bp);
+      if (g == j + 1) x = C.p(j) + mul(C.R(j), bp);
     relp = x;
-    relv = point_velocity<TP>(C, this->wdepth(g), g, x, SV{ang_b, cross(base_com, ang_b)}, qd);  // relative to the root COM velocity
+    relv = point_velocity<TP, ChainTP>(C, this->wdepth(g), g, x, SV{ang_b, cross(base_com, ang_b)}, qd);  // relative to the root COM velocity
   }
 
   struct RewCtx {
     float gate, cmd_norm, bv, fc_hi;
     bool terminated;
-    Chain<TP> C;
+    ChainTP C;
     int sbody[NBS], jid[JX];  // jid: task joint index of the joints this lane accounts for, else -1
     float hmax[NBS], t_ca[NBS], t_cc[NBS], t_la[NBS], t_lc[NBS], q0j[JX], slo[JX], shi[JX];
   };
@@ -240,7 +242,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   RL_FN float reward_term(const RD& R, const RewCtx& rc) {
     const float gate = rc.gate, cmd_norm = rc.cmd_norm, bv = rc.bv;
     const bool terminated = rc.terminated;
-    const Chain<TP>& C = rc.C;
+    const ChainTP& C = rc.C;
     const int(&sbody)[NBS] = rc.sbody;
     const int(&jid)[JX] = rc.jid;
     const float(&hmax)[NBS] = rc.hmax;
@@ -297,7 +299,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
           float part = 0.f;
 #pragma unroll
           for (int j = 0; j < JX; ++j) {
-            bool in = jid[j] >= 0 && ((R.joint_mask >> (jid[j] & 31)) & 1u);
+            bool in = (NW == 0 || jid[j] >= 0) && ((R.joint_mask >> (jid[j] & 31)) & 1u);
             float v = 0.f;
             switch (R.kind) {
               case REW_JOINT_TORQUES_L2: v = tau_app[j] * tau_app[j]; break;
@@ -307,7 +309,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
               case REW_JOINT_POWER: v = fabsf(qd[j] * tau_app[j]); break;  // rewards.py:81-90
               case REW_JOINT_DEVIATION_L1: case REW_STAND_STILL: v = fabsf(q[j] - q0j[j]); break;
               case REW_JOINT_POS_PENALTY: v = (q[j] - q0j[j]) * (q[j] - q0j[j]); break;
-              case REW_ACTION_RATE_L2: v = (act[j] - prev_act[j]) * (act[j] - prev_act[j]); in = jid[j] >= 0; break;
+              case REW_ACTION_RATE_L2: v = (act[j] - prev_act[j]) * (act[j] - prev_act[j]); in = NW == 0 || jid[j] >= 0; break;
               default: break;
             }
             part += in ? v : 0.f;
@@ -425,7 +427,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   }
 
   RL_FN float compute_rewards(bool terminated) {
-    RewCtx rc;
+    RewCtx rc{0.f, 0.f, 0.f, 0.f, false, this->new_chain()};
     rc.gate = clampf(-grav_b.z, 0.f, 0.7f) / 0.7f;
     rc.cmd_norm = norm(cmd);
     rc.bv = fsqrt(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
@@ -442,7 +444,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
-      rc.jid[j] = L.joint_own[j] ? L.joint_id[j] : -1; rc.q0j[j] = L.q0[j]; rc.slo[j] = L.soft_lo[j]; rc.shi[j] = L.soft_hi[j];
+      rc.jid[j] = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1; rc.q0j[j] = L.q0[j]; rc.slo[j] = L.soft_lo[j]; rc.shi[j] = L.soft_hi[j];
     }
     rc.fc_hi = T.step_dt + 1e-8f;
     float total = 0.f;
@@ -522,7 +524,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #pragma unroll
           for (int j = 0; j < JX; ++j) {
             if (SUB > 1 && (j % SUB) != sub) continue;  // the leg's sub-lanes share its joints
-            if (!L.joint_own[j]) continue;              // padding / trunk joints accounted for by lane 0
+            if (NW > 0 && !L.joint_own[j]) continue;    // padding / trunk joints accounted for by lane 0
             float v = O.kind == OBS_JOINT_VEL_REL ? qd[j] - L.qd0[j] : O.kind == OBS_LAST_ACTION ? act[j] : q[j] - L.q0[j];
             if (O.kind == OBS_JOINT_POS_REL_NO_WHEEL && ((T.wheel_joint_mask >> L.joint_id[j]) & 1u)) v = 0.f;
             put(O.offset + L.joint_id[j], v);
@@ -563,11 +565,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       cy = cosf(heading_w); sy = sinf(heading_w); scan_p = pos;
       return;
     }
-    Chain<TP> C;
+    ChainTP C = this->new_chain();
     chain_kinematics<TP>(L, q, C);
     M3 Rf;
     V3 pf;
-    C.trunk_frame(T.scan_depth, Rf, pf);
+    trunk_frame<TP>(C, T.scan_depth, Rf, pf);
     const M3 Rs = mul(Rwb, Rf);
     const float yaw = atan2f(Rs.r1.x, Rs.r0.x);
     cy = cosf(yaw); sy = sinf(yaw);
@@ -617,7 +619,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       prev_act[j] = act[j];
-      float a = (e < S.N && L.joint_id[j] >= 0) ? S.action_in[(size_t)e * T.D + L.joint_id[j]] : 0.f;
+      float a = (e < S.N && (NW == 0 || L.joint_id[j] >= 0)) ? S.action_in[(size_t)e * T.D + L.joint_id[j]] : 0.f;
       act[j] = a;
       float pr = clampf(a * L.a_scale[j] + L.a_off[j], L.a_lo[j], L.a_hi[j]);
       q_tgt[j] = L.action_is_vel[j] ? 0.f : pr;
@@ -629,7 +631,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       if (sub == 0)
 #pragma unroll
       for (int j = 0; j < JX; ++j) {
-        if (!L.joint_own[j]) continue;
+        if (NW > 0 && !L.joint_own[j]) continue;
         S.dbg_torque[(size_t)e * T.D + L.joint_id[j]] = tau_app[j];
         S.dbg_acc[(size_t)e * T.D + L.joint_id[j]] = qacc[j];
       }

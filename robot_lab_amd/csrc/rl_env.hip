@@ -36,15 +36,18 @@ template <int SUB_>
 struct WaveCtx {
   static constexpr int LS_STRIDE = 64;
   static constexpr int SUB = SUB_;
+  static constexpr int LB_STRIDE = 64 / SUB_;  // limb-shared words: one per limb of the wavefront
   static constexpr int LPE = NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
   float* lscratch;
+  float* lbscratch;
   const void* T;  // TablesT<TP> staged in LDS
   float* stage[2];
   float* rstage;
   int dim[2];
   int lane;
   __device__ float* lane_scratch() const { return lscratch + lane; }
+  __device__ float* limb_scratch() const { return lbscratch + lane / SUB; }
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   ctx.stage[0] = smem + TAB_F;
   ctx.stage[1] = ctx.stage[0] + ((Ctx::EPT * ctx.dim[0] + 3) & ~3);
   ctx.lscratch = ctx.stage[1] + ((Ctx::EPT * ctx.dim[1] + 3) & ~3);
-  ctx.rstage = ctx.lscratch + LsLayout<TP::NBS>::WORDS * 64;
+  ctx.lbscratch = ctx.lscratch + LsLayout<TP::NBS>::WORDS * 64;
+  ctx.rstage = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
   ctx.lane = lane;
   EnvProgram<Ctx, TP> prog(ctx, S);
   if (RESET)
@@ -200,8 +204,9 @@ struct Backend {
     size_t tab = (packed_size(T) + 15) / 16 * 16;
     size_t s0 = (ept * T.policy_dim + 3) / 4 * 16;
     size_t s1 = (ept * T.critic_dim + 3) / 4 * 16;
-    const size_t ls_words = T.NBS == TopoG1::NBS ? LsLayout<TopoG1::NBS>::WORDS : LsLayout<TopoQuad3::NBS>::WORDS;
-    lds_bytes = tab + s0 + s1 + ls_words * 64 * 4 + ept * MAX_T * 4;
+    const size_t ls_words = T.NW > 0 ? LsLayout<TopoG1::NBS>::WORDS : LsLayout<TopoQuad3::NBS>::WORDS;
+    const size_t lb_words = T.NW > 0 ? LbLayout<TopoG1>::WORDS : 0;
+    lds_bytes = tab + s0 + s1 + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + ept * MAX_T * 4;
     if (lds_bytes > 160 * 1024) {
       err = "observation rows do not fit the 160 KiB LDS of a CU";
       return -1;

@@ -322,10 +322,11 @@ struct EnvImpl {
     if (be.init(device)) return fail("device init failed: " + be.error());
     if (be.configure(tables)) return fail("kernel configuration failed: " + be.error());
     const size_t Np = Npad, ntile = Npad / ept;
+    const Layout ly(tables.CL, tables.NW, tables.NBS);
     memset(&S, 0, sizeof(S));
     S.N = N; S.Npad = Npad; S.seed = seed; S.ept = ept;
-    S.lane_state = alloc<float>(ntile * (size_t)NF_LANE * NLANE * ept);
-    S.env_state = alloc<float>(ntile * (size_t)NF_ENV * ept);
+    S.lane_state = alloc<float>(ntile * (size_t)ly.NF_LANE * NLANE * ept);
+    S.env_state = alloc<float>(ntile * (size_t)ly.NF_ENV * ept);
     S.flags = alloc<int32_t>(Np); S.level = alloc<int32_t>(Np); S.ttype = alloc<int32_t>(Np);
     S.ep_len = alloc<int64_t>(Np); S.ep_sums = alloc<float>(MAX_T * Np);
     S.obs_policy = alloc<float>(Np * (size_t)std::max(1, tables.policy_dim));
@@ -368,7 +369,8 @@ struct EnvImpl {
     const rl_model_desc& m = desc.model;
     const rl_task_desc& t = desc.task;
     const size_t Np = Npad, ntile = Npad / ept;
-    std::vector<float> lane(ntile * (size_t)NF_LANE * NLANE * ept, 0.f), env(ntile * (size_t)NF_ENV * ept, 0.f);
+    const Layout ly(tables.CL, tables.NW, tables.NBS);
+    std::vector<float> lane(ntile * (size_t)ly.NF_LANE * NLANE * ept, 0.f), env(ntile * (size_t)ly.NF_ENV * ept, 0.f);
     std::vector<int32_t> level(Np, 0), ttype(Np, 0);
     std::vector<float> bs(64, 1.f), bd(64, 1.f), br(64, 0.f);
     int nb = t.friction_buckets > 0 ? (t.friction_buckets > 64 ? 64 : t.friction_buckets) : 1;
@@ -394,9 +396,9 @@ struct EnvImpl {
         if (t.ev_com && b == t.base_body)
           for (int a = 0; a < 3; ++a) c[a] += uniform_range(seed, e, 0, STREAM_STARTUP, IDX_COM + 3 * b + a, t.com_range[a][0], t.com_range[a][1]);
         if (b == 0)  // root body: its COM defines root_com_lin_vel [UPSTREAM B3]
-          for (int a = 0; a < 3; ++a) env[env_index(e, EF_BASE_COM + a, ept)] = (float)c[a];
+          for (int a = 0; a < 3; ++a) env[env_index(ly, e, ly.EF_BASE_COM + a, ept)] = (float)c[a];
         if (b == t.base_body)
-          for (int a = 0; a < 3; ++a) env[env_index(e, EF_WR_COM + a, ept)] = (float)c[a];
+          for (int a = 0; a < 3; ++a) env[env_index(ly, e, ly.EF_WR_COM + a, ept)] = (float)c[a];
         double sc = m.body_mass[b] > 0.f ? mass / m.body_mass[b] : 0.0;
         const float* I6 = m.body_inertia[b];
         double Ic[9] = {sc * I6[0], sc * I6[3], sc * I6[4], sc * I6[3], sc * I6[1], sc * I6[5], sc * I6[4], sc * I6[5], sc * I6[2]};
@@ -418,7 +420,7 @@ struct EnvImpl {
           // base-link bodies may have spheres on other lanes too: replicate their material into slot 0 there
           bool here = kk == k || (s == 0 && tables.lane[kk].base_body_local == tables.lane[k].base_body_local && !tables.lane[kk].owns_base_body);
           if (!here) continue;
-          for (int a = 0; a < 3; ++a) lane[lane_index(e, kk, LF_FRICTION + s * 3 + a, ept)] = mu[a];
+          for (int a = 0; a < 3; ++a) lane[lane_index(ly, e, kk, ly.LF_FRICTION + s * 3 + a, ept)] = mu[a];
         }
       }
       // composite per link -> (mass, com, inertia about com)
@@ -431,36 +433,36 @@ struct EnvImpl {
           for (int bb = 0; bb < 3; ++bb) Ic[a * 3 + bb] = lI[l * 9 + a * 3 + bb] - mass * ((a == bb ? cc : 0.0) - c[a] * c[bb]);
         float rec[10] = {(float)mass, (float)c[0], (float)c[1], (float)c[2], (float)Ic[0], (float)Ic[4], (float)Ic[8], (float)Ic[1], (float)Ic[2], (float)Ic[5]};
         if (link_lane[l] < 0) {  // trunk link: link_pos = trunk depth
-          for (int f = 0; f < 10; ++f) env[env_index(e, EF_BASE_INERTIA + link_pos[l] * INERTIA_NF + f, ept)] = rec[f];
+          for (int f = 0; f < 10; ++f) env[env_index(ly, e, ly.EF_BASE_INERTIA + link_pos[l] * INERTIA_NF + f, ept)] = rec[f];
         } else {
           int k = link_lane[l], j = link_pos[l];
-          for (int f = 0; f < 10; ++f) lane[lane_index(e, k, LF_INERTIA + j * INERTIA_NF + f, ept)] = rec[f];
+          for (int f = 0; f < 10; ++f) lane[lane_index(ly, e, k, ly.LF_INERTIA + j * INERTIA_NF + f, ept)] = rec[f];
         }
       }
       for (int k = 0; k < NLANE; ++k)
         for (int j = 0; j < CL; ++j) {
-          lane[lane_index(e, k, LF_KP + j, ept)] = tables.lane[k].kp0[j];
-          lane[lane_index(e, k, LF_KD + j, ept)] = tables.lane[k].kd0[j];
-          lane[lane_index(e, k, LF_Q + j, ept)] = tables.lane[k].q0[j];
+          lane[lane_index(ly, e, k, ly.LF_KP + j, ept)] = tables.lane[k].kp0[j];
+          lane[lane_index(ly, e, k, ly.LF_KD + j, ept)] = tables.lane[k].kd0[j];
+          lane[lane_index(ly, e, k, ly.LF_Q + j, ept)] = tables.lane[k].q0[j];
         }
       for (int i = 0; i < tables.NW; ++i) {
-        env[env_index(e, EF_TKP + i, ept)] = tables.lane[0].kp0[CL + i];
-        env[env_index(e, EF_TKD + i, ept)] = tables.lane[0].kd0[CL + i];
-        env[env_index(e, EF_TQ + i, ept)] = tables.lane[0].q0[CL + i];
+        env[env_index(ly, e, ly.EF_TKP + i, ept)] = tables.lane[0].kp0[CL + i];
+        env[env_index(ly, e, ly.EF_TKD + i, ept)] = tables.lane[0].kd0[CL + i];
+        env[env_index(ly, e, ly.EF_TQ + i, ept)] = tables.lane[0].q0[CL + i];
       }
       // terrain level / type / env origin
       if (desc.terrain.is_plane) {
         int ee = e < N ? e : N - 1;
-        for (int a = 0; a < 3; ++a) env[env_index(e, EF_ORIGIN + a, ept)] = env_origins[ee * 3 + a];
+        for (int a = 0; a < 3; ++a) env[env_index(ly, e, ly.EF_ORIGIN + a, ept)] = env_origins[ee * 3 + a];
       } else {
         int ee = e < N ? e : N - 1;  // padding envs mirror the last real env's cell
         ttype[e] = (int)floor((double)ee / ((double)N / desc.terrain.num_cols));
         int lv = (int)floorf(uniform01(seed, ee, 0, STREAM_STARTUP, IDX_INIT_LEVEL) * (float)(desc.terrain.max_init_level + 1));
         level[e] = lv > desc.terrain.max_init_level ? desc.terrain.max_init_level : lv;
-        for (int a = 0; a < 3; ++a) env[env_index(e, EF_ORIGIN + a, ept)] = terrain_origins[((size_t)level[e] * desc.terrain.num_cols + ttype[e]) * 3 + a];
+        for (int a = 0; a < 3; ++a) env[env_index(ly, e, ly.EF_ORIGIN + a, ept)] = terrain_origins[((size_t)level[e] * desc.terrain.num_cols + ttype[e]) * 3 + a];
       }
-      env[env_index(e, EF_ROOT + 3, ept)] = 1.f;  // identity quaternion until the first reset
-      for (int a = 0; a < 3; ++a) env[env_index(e, EF_ROOT + a, ept)] = env[env_index(e, EF_ORIGIN + a, ept)] + m.default_root_pos[a];
+      env[env_index(ly, e, ly.EF_ROOT + 3, ept)] = 1.f;  // identity quaternion until the first reset
+      for (int a = 0; a < 3; ++a) env[env_index(ly, e, ly.EF_ROOT + a, ept)] = env[env_index(ly, e, ly.EF_ORIGIN + a, ept)] + m.default_root_pos[a];
     }
     be.h2d(S.lane_state, lane.data(), lane.size() * 4);
     be.h2d(S.env_state, env.data(), env.size() * 4);

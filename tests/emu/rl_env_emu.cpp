@@ -35,11 +35,14 @@ struct Team {
 template <int SUB_>
 struct HostCtx {
   static constexpr int LS_STRIDE = 1;
+  static constexpr int LB_STRIDE = 1;  // "limb-shared" words are private per lane thread here (the sub-lanes hold identical values)
   static constexpr int SUB = SUB_;
   static constexpr int LPE = rl::NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
   float scratch[rl::LsLayout<rl::MAX_NBS>::WORDS];
   float* lane_scratch() { return scratch; }
+  float lb[rl::LbLayout<rl::TopoG1>::WORDS + 1];
+  float* limb_scratch() { return lb; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
   Team<LPE>* team;
