@@ -62,7 +62,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // derived articulation data [UPSTREAM B3]
   M3 Rwb;
   V3 lin_b, ang_b, grav_b, lin_w;
-  float heading_w;
+  float heading_w, yaw_c, yaw_s;
 
   RL_FN EnvProgram(Ctx& c, const KState& s) : Base(c, s) {}
 
@@ -101,6 +101,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     ang_b = mulT(Rwb, vang);
     grav_b = mulT(Rwb, V3{0.f, 0.f, -1.f});
     heading_w = atan2f(Rwb.r1.x, Rwb.r0.x);
+    const float hn = frsqrt(fmaxf(Rwb.r0.x * Rwb.r0.x + Rwb.r1.x * Rwb.r1.x, 1e-30f));  // cos / sin of the heading without trigonometry
+    yaw_c = Rwb.r0.x * hn;
+    yaw_s = Rwb.r1.x * hn;
   }
 
   RL_FN float U(uint32_t stream, uint32_t idx, float lo, float hi) const {
@@ -237,11 +240,13 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     float hmax[NBS], t_ca[NBS], t_cc[NBS], t_la[NBS], t_lc[NBS], q0j[JX], slo[JX], shi[JX];
   };
 
-  // one reward term: unweighted value f (all lanes of the env return the same number)
+  // one reward term: unweighted value f (all lanes of the env return the same number).  One case per
+  // kind with the per-joint / per-slot loops inside it: with the kinds grouped into shared loops and an
+  // inner switch per joint, a wavefront walked ~30 scalar branches per term and a joint-sum term cost
+  // ~1450 cycles (tools/phase_clock.py) for 3 fused multiply-adds.
   template <class RD>
   RL_FN float reward_term(const RD& R, const RewCtx& rc) {
     const float gate = rc.gate, cmd_norm = rc.cmd_norm, bv = rc.bv;
-    const bool terminated = rc.terminated;
     const ChainTP& C = rc.C;
     const int(&sbody)[NBS] = rc.sbody;
     const int(&jid)[JX] = rc.jid;
@@ -254,181 +259,176 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     const float(&slo)[JX] = rc.slo;
     const float(&shi)[JX] = rc.shi;
     const float fc_hi = rc.fc_hi;
-    auto in_mask = [&](uint64_t mask, int s) { return sbody[s] >= 0 && ((mask >> sbody[s]) & 1ull); };
+    auto in_mask = [&](int s) { return sbody[s] >= 0 && ((R.body_mask >> sbody[s]) & 1ull); };
     auto first_c = [&](int s) { return t_cc[s] > 0.f && t_cc[s] < fc_hi; };
+    // sum over the joints of the term's joint mask / over the body slots of its body mask
+    auto jsum = [&](auto fj) {
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < JX; ++j) {
+        const bool in = (NW == 0 || jid[j] >= 0) && ((R.joint_mask >> (jid[j] & 31)) & 1u);
+        part += in ? fj(j) : 0.f;
+      }
+      return ctx.gsum(part);
+    };
+    auto ssum = [&](auto fs) {
+      float part = 0.f;
+#pragma unroll
+      for (int s = 0; s < NBS; ++s)
+        if (in_mask(s)) part += fs(s);
+      return ctx.esum(part);
+    };
+    const float moving = cmd_norm > 0.1f ? 1.f : 0.f;
     float f = 0.f;
     switch (R.kind) {
-        case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
-          float ex = cmd.x - lin_b.x, ey = cmd.y - lin_b.y;
-          f = expf(-(ex * ex + ey * ey) / R.p[0]) * gate;
-        } break;
-        case REW_TRACK_ANG_VEL_Z_EXP: {  // rewards.py:38-48
-          float ez = cmd.z - ang_b.z;
-          f = expf(-(ez * ez) / R.p[0]) * gate;
-        } break;
-        case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // rewards.py:51-66: root COM velocity in the yaw-only frame
-          const float cy = cosf(heading_w), sy = sinf(heading_w);
-          float ex = cmd.x - (cy * lin_w.x + sy * lin_w.y), ey = cmd.y - (-sy * lin_w.x + cy * lin_w.y);
-          f = expf(-(ex * ex + ey * ey) / R.p[0]) * gate;
-        } break;
-        case REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // rewards.py:69-78
-          float ez = cmd.z - vang.z;
-          f = expf(-(ez * ez) / R.p[0]) * gate;
-        } break;
-        case REW_FEET_AIR_TIME_POSITIVE_BIPED: {  // rewards.py:363-383
-          float nc = 0.f, mn = 1e30f;
+      case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
+        float ex = cmd.x - lin_b.x, ey = cmd.y - lin_b.y;
+        f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
+      } break;
+      case REW_TRACK_ANG_VEL_Z_EXP: {  // rewards.py:38-48
+        float ez = cmd.z - ang_b.z;
+        f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
+      } break;
+      case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // rewards.py:51-66: root COM velocity in the yaw-only frame
+        float ex = cmd.x - (yaw_c * lin_w.x + yaw_s * lin_w.y), ey = cmd.y - (-yaw_s * lin_w.x + yaw_c * lin_w.y);
+        f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
+      } break;
+      case REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // rewards.py:69-78
+        float ez = cmd.z - vang.z;
+        f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
+      } break;
+      case REW_LIN_VEL_Z_L2: f = lin_b.z * lin_b.z * gate; break;                         // rewards.py:647-653
+      case REW_ANG_VEL_XY_L2: f = (ang_b.x * ang_b.x + ang_b.y * ang_b.y) * gate; break;  // rewards.py:656-662
+      case REW_FLAT_ORIENTATION_L2: f = (grav_b.x * grav_b.x + grav_b.y * grav_b.y) * gate; break;  // rewards.py:678-687
+      case REW_UPWARD: f = (1.f - grav_b.z) * (1.f - grav_b.z); break;                     // rewards.py:608-613
+      case REW_IS_TERMINATED: f = rc.terminated ? 1.f : 0.f; break;
+      case REW_JOINT_TORQUES_L2: f = jsum([&](int j) { return tau_app[j] * tau_app[j]; }); break;
+      case REW_JOINT_ACC_L2: f = jsum([&](int j) { return qacc[j] * qacc[j]; }); break;
+      case REW_JOINT_VEL_L2: f = jsum([&](int j) { return qd[j] * qd[j]; }); break;
+      case REW_JOINT_POS_LIMITS: f = jsum([&](int j) { return fmaxf(slo[j] - q[j], 0.f) + fmaxf(q[j] - shi[j], 0.f); }); break;
+      case REW_JOINT_POWER: f = jsum([&](int j) { return fabsf(qd[j] * tau_app[j]); }); break;  // rewards.py:81-90
+      case REW_JOINT_DEVIATION_L1: f = jsum([&](int j) { return fabsf(q[j] - q0j[j]); }); break;
+      case REW_STAND_STILL:  // rewards.py:93-104
+        f = jsum([&](int j) { return fabsf(q[j] - q0j[j]); }) * (cmd_norm < R.p[0] ? 1.f : 0.f) * gate;
+        break;
+      case REW_JOINT_POS_PENALTY: {  // rewards.py:107-129
+        float run = fsqrt(jsum([&](int j) { return (q[j] - q0j[j]) * (q[j] - q0j[j]); }));
+        f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
+      } break;
+      case REW_ACTION_RATE_L2: {
+        float part = 0.f;
 #pragma unroll
-          for (int s = 0; s < NBS; ++s) {
-            if (!in_mask(R.body_mask, s)) continue;
-            bool inc = t_cc[s] > 0.f;
-            nc += inc ? 1.f : 0.f;
-            mn = fminf(mn, inc ? t_cc[s] : t_ca[s]);
-          }
-          nc = ctx.esum(nc);
-          mn = ctx.emin(mn);
-          f = (nc == 1.f ? fminf(mn, R.p[0]) : 0.f) * (cmd_norm > 0.1f ? 1.f : 0.f) * gate;
-        } break;
-        case REW_LIN_VEL_Z_L2: f = lin_b.z * lin_b.z * gate; break;                         // rewards.py:647-653
-        case REW_ANG_VEL_XY_L2: f = (ang_b.x * ang_b.x + ang_b.y * ang_b.y) * gate; break;  // rewards.py:656-662
-        case REW_FLAT_ORIENTATION_L2: f = (grav_b.x * grav_b.x + grav_b.y * grav_b.y) * gate; break;  // rewards.py:678-687
-        case REW_UPWARD: f = (1.f - grav_b.z) * (1.f - grav_b.z); break;                     // rewards.py:608-613
-        case REW_IS_TERMINATED: f = terminated ? 1.f : 0.f; break;
-        case REW_JOINT_TORQUES_L2: case REW_JOINT_ACC_L2: case REW_JOINT_VEL_L2: case REW_JOINT_POS_LIMITS:
-        case REW_JOINT_POWER: case REW_JOINT_DEVIATION_L1: case REW_STAND_STILL: case REW_JOINT_POS_PENALTY:
-        case REW_ACTION_RATE_L2: {
-          float part = 0.f;
+        for (int j = 0; j < JX; ++j) part += (NW == 0 || jid[j] >= 0) ? (act[j] - prev_act[j]) * (act[j] - prev_act[j]) : 0.f;
+        f = ctx.gsum(part);
+      } break;
+      case REW_JOINT_MIRROR: {  // rewards.py:259-278: joint positions staged by task joint index, one pair per lane
+        float* jq = ctx.obs_stage(1);  // the critic row is free until the observations are written
+        ctx.group_sync();
+        if (sub == 0)
 #pragma unroll
-          for (int j = 0; j < JX; ++j) {
-            bool in = (NW == 0 || jid[j] >= 0) && ((R.joint_mask >> (jid[j] & 31)) & 1u);
-            float v = 0.f;
-            switch (R.kind) {
-              case REW_JOINT_TORQUES_L2: v = tau_app[j] * tau_app[j]; break;
-              case REW_JOINT_ACC_L2: v = qacc[j] * qacc[j]; break;
-              case REW_JOINT_VEL_L2: v = qd[j] * qd[j]; break;
-              case REW_JOINT_POS_LIMITS: v = fmaxf(slo[j] - q[j], 0.f) + fmaxf(q[j] - shi[j], 0.f); break;
-              case REW_JOINT_POWER: v = fabsf(qd[j] * tau_app[j]); break;  // rewards.py:81-90
-              case REW_JOINT_DEVIATION_L1: case REW_STAND_STILL: v = fabsf(q[j] - q0j[j]); break;
-              case REW_JOINT_POS_PENALTY: v = (q[j] - q0j[j]) * (q[j] - q0j[j]); break;
-              case REW_ACTION_RATE_L2: v = (act[j] - prev_act[j]) * (act[j] - prev_act[j]); in = NW == 0 || jid[j] >= 0; break;
-              default: break;
-            }
-            part += in ? v : 0.f;
-          }
-          f = ctx.gsum(part);
-          if (R.kind == REW_STAND_STILL) f *= (cmd_norm < R.p[0] ? 1.f : 0.f) * gate;  // rewards.py:93-104
-          if (R.kind == REW_JOINT_POS_PENALTY) {                                        // rewards.py:107-129
-            float run = fsqrt(f);
-            f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
-          }
-        } break;
-        case REW_JOINT_MIRROR: {  // rewards.py:259-278
-          float qa[NLANE][CL];
+          for (int j = 0; j < JX; ++j)
+            if (NW == 0 || jid[j] >= 0) jq[jid[j]] = q[j];
+        ctx.group_sync();
+        float part = 0.f;
+        for (int i = li; i < R.n_idx; i += LPE) {
+          float d = jq[R.idx_a[i]] - jq[R.idx_b[i]];
+          part += d * d;
+        }
+        ctx.group_sync();
+        f = ctx.esum(part) * R.p[0] * gate;
+      } break;
+      case REW_UNDESIRED_CONTACTS: f = ssum([&](int s) { return hmax[s] > R.p[0] ? 1.f : 0.f; }) * gate; break;  // rewards.py:665-675
+      case REW_CONTACT_FORCES: f = ssum([&](int s) { return fmaxf(hmax[s] - R.p[0], 0.f); }); break;           // [UPSTREAM] contact_forces
+      case REW_FEET_CONTACT_WITHOUT_CMD:  // rewards.py:416-425
+        f = ssum([&](int s) { return first_c(s) ? 1.f : 0.f; }) * (cmd_norm < 0.1f ? 1.f : 0.f) * gate;
+        break;
+      case REW_FEET_CONTACT:  // rewards.py:399-413
+        f = (ssum([&](int s) { return first_c(s) ? 1.f : 0.f; }) != R.p[0] ? 1.f : 0.f) * moving * gate;
+        break;
+      case REW_FEET_AIR_TIME: f = ssum([&](int s) { return first_c(s) ? t_la[s] - R.p[0] : 0.f; }) * moving * gate; break;  // rewards.py:340-360
+      case REW_FEET_STUMBLE:  // rewards.py:428-436
+        f = (ssum([&](int s) {
+               float fx = cf[s][0], fy = cf[s][1];
+               return fsqrt(fx * fx + fy * fy) > 4.f * fabsf(cf[s][2]) ? 1.f : 0.f;
+             }) > 0.f ? 1.f : 0.f) * gate;
+        break;
+      case REW_FEET_HEIGHT_BODY:  // rewards.py:527-554
+        f = ssum([&](int s) {
+              V3 relp, relv;
+              body_rel(C, s, relp, relv);
+              float er = relp.z - R.p[0];
+              return er * er * ftanh(R.p[1] * fsqrt(relv.x * relv.x + relv.y * relv.y));
+            }) * moving * gate;
+        break;
+      case REW_FEET_SLIDE:  // rewards.py:557-587
+        f = ssum([&](int s) {
+              V3 relp, relv;
+              body_rel(C, s, relp, relv);
+              return hmax[s] > 1.0f ? fsqrt(relv.x * relv.x + relv.y * relv.y) : 0.f;
+            }) * gate;
+        break;
+      case REW_FEET_HEIGHT:  // feet_height, world frame (rewards.py:507-524)
+        f = ssum([&](int s) {
+              V3 relp, relv;
+              body_rel(C, s, relp, relv);
+              V3 pw = pos + mul(Rwb, relp);
+              V3 vw = lin_w + mul(Rwb, relv);
+              float er = pw.z - R.p[0];
+              return er * er * ftanh(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
+            }) * moving * gate;
+        break;
+      case REW_FEET_AIR_TIME_POSITIVE_BIPED: {  // rewards.py:363-383
+        float nc = 0.f, mn = 1e30f;
 #pragma unroll
-          for (int kk = 0; kk < NLANE; ++kk)
+        for (int s = 0; s < NBS; ++s) {
+          if (!in_mask(s)) continue;
+          bool inc = t_cc[s] > 0.f;
+          nc += inc ? 1.f : 0.f;
+          mn = fminf(mn, inc ? t_cc[s] : t_ca[s]);
+        }
+        nc = ctx.esum(nc);
+        mn = ctx.emin(mn);
+        f = (nc == 1.f ? fminf(mn, R.p[0]) : 0.f) * moving * gate;
+      } break;
+      case REW_FEET_AIR_TIME_VARIANCE: {  // rewards.py:386-397 (torch.var is unbiased)
+        float n = 0.f, sa = 0.f, saa = 0.f, sc = 0.f, scc = 0.f;
 #pragma unroll
-            for (int j = 0; j < CL; ++j) qa[kk][j] = ctx.gshfl(q[j], kk);
-          float s = 0.f;
-          for (int i = 0; i < R.n_idx; ++i) {
-            float va = 0.f, vb = 0.f;
+        for (int s = 0; s < NBS; ++s) {
+          if (!in_mask(s)) continue;
+          float la = fminf(t_la[s], 0.5f), lc = fminf(t_lc[s], 0.5f);
+          n += 1.f; sa += la; saa += la * la; sc += lc; scc += lc * lc;
+        }
+        n = ctx.esum(n); sa = ctx.esum(sa); saa = ctx.esum(saa); sc = ctx.esum(sc); scc = ctx.esum(scc);
+        const float inv_n = frcp(n), inv_den = frcp(fmaxf(n - 1.f, 1.f));
+        f = ((saa - sa * sa * inv_n) + (scc - sc * sc * inv_n)) * inv_den * gate;
+      } break;
+      case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256
+        float air[4], con[4];
 #pragma unroll
-            for (int kk = 0; kk < NLANE; ++kk)
+        for (int i = 0; i < 4; ++i) {
+          float a = 0.f, c = 0.f;
 #pragma unroll
-              for (int j = 0; j < CL; ++j) {
-                int id = T.lane[kk].joint_id[j];
-                va = id == R.idx_a[i] ? qa[kk][j] : va;
-                vb = id == R.idx_b[i] ? qa[kk][j] : vb;
-              }
-            s += (va - vb) * (va - vb);
-          }
-          f = s * R.p[0] * gate;
-        } break;
-        case REW_UNDESIRED_CONTACTS: case REW_CONTACT_FORCES: case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT:
-        case REW_FEET_AIR_TIME: case REW_FEET_HEIGHT_BODY: case REW_FEET_SLIDE: case REW_FEET_HEIGHT: case REW_FEET_STUMBLE: {
-          float part = 0.f;
-#pragma unroll
-          for (int s = 0; s < NBS; ++s) {
-            if (!in_mask(R.body_mask, s)) continue;
-            float hm = hmax[s];
-            switch (R.kind) {
-              case REW_UNDESIRED_CONTACTS: part += hm > R.p[0] ? 1.f : 0.f; break;          // rewards.py:665-675
-              case REW_CONTACT_FORCES: part += fmaxf(hm - R.p[0], 0.f); break;              // [UPSTREAM] contact_forces
-              case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT: part += first_c(s) ? 1.f : 0.f; break;
-              case REW_FEET_AIR_TIME: part += first_c(s) ? t_la[s] - R.p[0] : 0.f; break;  // rewards.py:340-360
-              case REW_FEET_STUMBLE: {                                                       // rewards.py:428-436
-                float fx = cf[s][0], fy = cf[s][1];
-                part += fsqrt(fx * fx + fy * fy) > 4.f * fabsf(cf[s][2]) ? 1.f : 0.f;
-              } break;
-              default: {
-                V3 relp, relv;
-                body_rel(C, s, relp, relv);
-                if (R.kind == REW_FEET_HEIGHT_BODY) {  // rewards.py:527-554
-                  float er = relp.z - R.p[0];
-                  part += er * er * tanhf(R.p[1] * fsqrt(relv.x * relv.x + relv.y * relv.y));
-                } else if (R.kind == REW_FEET_SLIDE) {  // rewards.py:557-587
-                  part += hm > 1.0f ? fsqrt(relv.x * relv.x + relv.y * relv.y) : 0.f;
-                } else {  // feet_height, world frame (rewards.py:507-524)
-                  V3 pw = pos + mul(Rwb, relp);
-                  V3 vw = lin_w + mul(Rwb, relv);
-                  float er = pw.z - R.p[0];
-                  part += er * er * tanhf(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
-                }
-              }
-            }
-          }
-          f = ctx.esum(part);
-          switch (R.kind) {
-            case REW_UNDESIRED_CONTACTS: case REW_FEET_SLIDE: f *= gate; break;
-            case REW_FEET_CONTACT_WITHOUT_CMD: f *= (cmd_norm < 0.1f ? 1.f : 0.f) * gate; break;  // rewards.py:416-425
-            case REW_FEET_CONTACT: f = (f != R.p[0] ? 1.f : 0.f) * (cmd_norm > 0.1f ? 1.f : 0.f) * gate; break;
-            case REW_FEET_AIR_TIME: case REW_FEET_HEIGHT_BODY: case REW_FEET_HEIGHT: f *= (cmd_norm > 0.1f ? 1.f : 0.f) * gate; break;
-            case REW_FEET_STUMBLE: f = (f > 0.f ? 1.f : 0.f) * gate; break;
-            default: break;
-          }
-        } break;
-        case REW_FEET_AIR_TIME_VARIANCE: {  // rewards.py:386-397 (torch.var is unbiased)
-          float n = 0.f, sa = 0.f, saa = 0.f, sc = 0.f, scc = 0.f;
-#pragma unroll
-          for (int s = 0; s < NBS; ++s) {
-            if (!in_mask(R.body_mask, s)) continue;
-            float la = fminf(t_la[s], 0.5f), lc = fminf(t_lc[s], 0.5f);
-            n += 1.f; sa += la; saa += la * la; sc += lc; scc += lc * lc;
-          }
-          n = ctx.esum(n); sa = ctx.esum(sa); saa = ctx.esum(saa); sc = ctx.esum(sc); scc = ctx.esum(scc);
-          float den = fmaxf(n - 1.f, 1.f);
-          f = ((saa - sa * sa / n) / den + (scc - sc * sc / n) / den) * gate;
-        } break;
-        case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256
-          float air[4], con[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float a = 0.f, c = 0.f;
-#pragma unroll
-            for (int s = 0; s < NBS; ++s)
-              if (sbody[s] == R.idx_a[i]) { a = t_ca[s]; c = t_cc[s]; }
-            air[i] = ctx.esum(a);
-            con[i] = ctx.esum(c);
-          }
-          const float std = R.p[0], me2 = R.p[1] * R.p[1];
-          auto sync = [&](int a, int b) {
-            float da = air[a] - air[b], dc = con[a] - con[b];
-            return expf(-(fminf(da * da, me2) + fminf(dc * dc, me2)) / std);
-          };
-          auto asyn = [&](int a, int b) {
-            float d0 = air[a] - con[b], d1 = con[a] - air[b];
-            return expf(-(fminf(d0 * d0, me2) + fminf(d1 * d1, me2)) / std);
-          };
-          float sr = sync(0, 1) * sync(2, 3);
-          float ar = asyn(0, 2) * asyn(1, 3) * asyn(0, 3) * asyn(2, 1);
-          f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? sr * ar : 0.f) * gate;
-        } break;
-        default: break;
-      }
+          for (int s = 0; s < NBS; ++s)
+            if (sbody[s] == R.idx_a[i]) { a = t_ca[s]; c = t_cc[s]; }
+          air[i] = ctx.esum(a);
+          con[i] = ctx.esum(c);
+        }
+        const float inv_std = frcp(R.p[0]), me2 = R.p[1] * R.p[1];
+        auto se = [&](float a, float b) { float d = a - b; return fminf(d * d, me2); };
+        // product of exponentials = exponential of the sum: one v_exp_f32 for the six factors
+        float acc = se(air[0], air[1]) + se(con[0], con[1]) + se(air[2], air[3]) + se(con[2], con[3]);
+        acc += se(air[0], con[2]) + se(con[0], air[2]) + se(air[1], con[3]) + se(con[1], air[3]);
+        acc += se(air[0], con[3]) + se(con[0], air[3]) + se(air[2], con[1]) + se(con[2], air[1]);
+        f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? fexp(-acc * inv_std) : 0.f) * gate;
+      } break;
+      default: break;
+    }
     return f;
   }
 
   RL_FN float compute_rewards(bool terminated) {
     RewCtx rc{0.f, 0.f, 0.f, 0.f, false, this->new_chain()};
-    rc.gate = clampf(-grav_b.z, 0.f, 0.7f) / 0.7f;
+    rc.gate = clampf(-grav_b.z, 0.f, 0.7f) * (1.0f / 0.7f);
     rc.cmd_norm = norm(cmd);
     rc.bv = fsqrt(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
     rc.terminated = terminated;
@@ -450,6 +450,18 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     float total = 0.f;
     float* rstage = ctx.rew_stage();
     const float step_dt = ctx.uniform(T.step_dt);
+    // episode sums of the terms this lane writes back (t = li, li + LPE, ...): loaded now, consumed after the
+    // terms - the HBM round trip overlaps the term arithmetic
+    constexpr int NACC = (MAX_T + LPE - 1) / LPE;
+    float acc[NACC];
+    {
+      const int nrew0 = Spec::generic ? ctx.uniform_i(T.n_rewards) : 0;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+        const int t = li + LPE * i;
+        acc[i] = t < nrew0 ? S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] : 0.f;
+      }
+    }
     int n_rewards;
     if constexpr (Spec::generic) {
       n_rewards = ctx.uniform_i(T.n_rewards);
@@ -485,16 +497,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // `ep_sums` (terms t = k, k+4, ...) are issued as one batch instead of one HBM round trip per term
     ctx.group_sync();
     {
-      constexpr int NB = (MAX_T + LPE - 1) / LPE;
-      float acc[NB];
       const int nrew = n_rewards;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int t = li + LPE * i;
-        acc[i] = t < nrew ? S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
+      for (int i = 0; i < NACC; ++i) {
         const int t = li + LPE * i;
         if (t < nrew) {
           const float v = rstage[t];
@@ -508,13 +513,17 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   }
 
   // ---------------------------------------------------------------- observations [UPSTREAM B2 / B6]
-  // one observation term: value -> +noise -> clip -> scale -> its columns of the LDS-staged row
+  struct ObsCtx {  // per-joint table entries, read from LDS once per step instead of once per term
+    int jid[JX];
+    float q0j[JX], qd0j[JX];
+    uint32_t wheel;
+  };
+  // one observation term: value -> +noise -> clip -> scale -> its columns of the LDS-staged row.  Terms with
+  // noise only stage the raw value here; add_noise() finishes them 4 columns (= one Philox block) per lane.
   template <class OD>
-  RL_FN void obs_term(const OD& O, float* stage, bool corrupt, uint32_t noise_base, float cy, float sy, V3 scan_p) {
-    auto put = [&](int col, float v) {
-        if (corrupt && O.has_noise) v += U(STREAM_NOISE, noise_base + (uint32_t)col, O.noise_lo, O.noise_hi);
-        stage[col] = clampf(v, O.clip_lo, O.clip_hi) * O.scale;
-      };
+  RL_FN void obs_term(const OD& O, const ObsCtx& oc, float* stage, bool corrupt, float cy, float sy, V3 scan_p) {
+    const bool deferred = corrupt && O.has_noise;
+    auto put = [&](int col, float v) { stage[col] = deferred ? v : clampf(v, O.clip_lo, O.clip_hi) * O.scale; };
       switch (O.kind) {
         case OBS_BASE_LIN_VEL: if (li < 3) put(O.offset + li, comp(lin_b, li)); break;
         case OBS_BASE_ANG_VEL: if (li < 3) put(O.offset + li, comp(ang_b, li)); break;
@@ -524,10 +533,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #pragma unroll
           for (int j = 0; j < JX; ++j) {
             if (SUB > 1 && (j % SUB) != sub) continue;  // the leg's sub-lanes share its joints
-            if (NW > 0 && !L.joint_own[j]) continue;    // padding / trunk joints accounted for by lane 0
-            float v = O.kind == OBS_JOINT_VEL_REL ? qd[j] - L.qd0[j] : O.kind == OBS_LAST_ACTION ? act[j] : q[j] - L.q0[j];
-            if (O.kind == OBS_JOINT_POS_REL_NO_WHEEL && ((T.wheel_joint_mask >> L.joint_id[j]) & 1u)) v = 0.f;
-            put(O.offset + L.joint_id[j], v);
+            if (NW > 0 && oc.jid[j] < 0) continue;      // padding / trunk joints accounted for by lane 0
+            float v = O.kind == OBS_JOINT_VEL_REL ? qd[j] - oc.qd0j[j] : O.kind == OBS_LAST_ACTION ? act[j] : q[j] - oc.q0j[j];
+            if (O.kind == OBS_JOINT_POS_REL_NO_WHEEL && ((oc.wheel >> (oc.jid[j] & 31)) & 1u)) v = 0.f;
+            put(O.offset + oc.jid[j], v);
           }
           break;
         case OBS_HEIGHT_SCAN: {  // yaw-aligned grid, x fastest; z_base - hit_z - offset.  12 rays per trip so 24 8-byte loads overlap
@@ -562,7 +571,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // pose of the height scanner: the root link on the quadrupeds, the torso on G1 (rides on trunk link scan_depth)
   RL_FN void scanner_pose(float& cy, float& sy, V3& scan_p) {
     if (NW == 0) {
-      cy = cosf(heading_w); sy = sinf(heading_w); scan_p = pos;
+      cy = yaw_c; sy = yaw_s; scan_p = pos;
       return;
     }
     ChainTP C = this->new_chain();
@@ -571,41 +580,78 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     V3 pf;
     trunk_frame<TP>(C, T.scan_depth, Rf, pf);
     const M3 Rs = mul(Rwb, Rf);
-    const float yaw = atan2f(Rs.r1.x, Rs.r0.x);
-    cy = cosf(yaw); sy = sinf(yaw);
+    const float hn = frsqrt(fmaxf(Rs.r0.x * Rs.r0.x + Rs.r1.x * Rs.r1.x, 1e-30f));
+    cy = Rs.r0.x * hn; sy = Rs.r1.x * hn;
     scan_p = pos + mul(Rwb, pf + mul(Rf, V3{T.scan_pos[0], T.scan_pos[1], T.scan_pos[2]}));
   }
 
-  RL_FN void write_obs(float* stage, const ObsTab* terms, int n, bool corrupt, uint32_t noise_base) {
-    float cy, sy;
-    V3 scan_p;
-    scanner_pose(cy, sy, scan_p);
-    n = ctx.uniform_i(n);
-    for (int i = 0; i < n; ++i) {
-      const ObsTab& Ol = terms[i];
-      ObsDesc O;
-      O.kind = ctx.uniform_i(Ol.kind); O.has_noise = ctx.uniform_i(Ol.has_noise); O.offset = ctx.uniform_i(Ol.offset);
-      O.scale = ctx.uniform(Ol.scale); O.clip_lo = ctx.uniform(Ol.clip_lo); O.clip_hi = ctx.uniform(Ol.clip_hi);
-      O.noise_lo = ctx.uniform(Ol.noise_lo); O.noise_hi = ctx.uniform(Ol.noise_hi);
-      obs_term(O, stage, corrupt, noise_base, cy, sy, scan_p);
+  RL_FN ObsDesc decode_obs(const ObsTab& Ol) const {
+    ObsDesc O;
+    O.kind = ctx.uniform_i(Ol.kind); O.has_noise = ctx.uniform_i(Ol.has_noise); O.offset = ctx.uniform_i(Ol.offset);
+    O.scale = ctx.uniform(Ol.scale); O.clip_lo = ctx.uniform(Ol.clip_lo); O.clip_hi = ctx.uniform(Ol.clip_hi);
+    O.noise_lo = ctx.uniform(Ol.noise_lo); O.noise_hi = ctx.uniform(Ol.noise_hi);
+    return O;
+  }
+
+  // second pass of a corrupted group: lane l finishes columns 4b .. 4b+3 for b = l, l + LPE, ... with the four
+  // uniforms of ONE Philox block (noise index = noise_base + column, so block = index >> 2 as in uniform01);
+  // v_mul_hi/lo_u32 are quarter rate, a Philox call costs ~900 cycles - per value that was the observations' bill
+  RL_FN void add_noise(float* stage, const ObsTab* terms, int n, int dim, uint32_t noise_base) {
+    ctx.group_sync();
+    const int nblk = (dim + 3) >> 2;
+    for (int b = li; b < nblk; b += LPE) {
+      float un[4], v[4];
+      uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_NOISE, (noise_base >> 2) + (uint32_t)b, un);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = 4 * b + c < dim ? stage[4 * b + c] : 0.f;
+      for (int i = 0; i < n; ++i) {
+        const ObsTab& Ol = terms[i];
+        if (!Ol.has_noise) continue;
+        const int lo = Ol.offset, hi = i + 1 < n ? terms[i + 1].offset : dim;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int col = 4 * b + c;
+          if (col >= lo && col < hi) v[c] = clampf(v[c] + Ol.noise_lo + (Ol.noise_hi - Ol.noise_lo) * un[c], Ol.clip_lo, Ol.clip_hi) * Ol.scale;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (4 * b + c < dim) stage[4 * b + c] = v[c];
     }
+  }
+
+  RL_FN void write_obs(float* stage, const ObsCtx& oc, const ObsTab* terms, int n, int dim, bool corrupt, uint32_t noise_base, float cy, float sy, V3 scan_p) {
+    n = ctx.uniform_i(n);
+    bool any_noise = false;
+    for (int i = 0; i < n; ++i) {
+      const ObsDesc O = decode_obs(terms[i]);
+      any_noise = any_noise || (corrupt && O.has_noise);
+      obs_term(O, oc, stage, corrupt, cy, sy, scan_p);
+    }
+    if (any_noise) add_noise(stage, terms, n, dim, noise_base);
   }
 
   RL_FN void observations() {
     derive();
     float* sp = ctx.obs_stage(0);
     float* sc = ctx.obs_stage(1);
+    ObsCtx oc;
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      oc.jid[j] = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1; oc.q0j[j] = L.q0[j]; oc.qd0j[j] = L.qd0[j];
+    }
+    oc.wheel = T.wheel_joint_mask;
+    float cy, sy;
+    V3 scan_p;
+    scanner_pose(cy, sy, scan_p);
     if constexpr (Spec::generic) {
-      write_obs(sp, T.policy, T.n_policy, T.policy_corrupt != 0, 0u);
-      write_obs(sc, T.critic, T.n_critic, T.critic_corrupt != 0, 1024u);
+      write_obs(sp, oc, T.policy, T.n_policy, T.policy_dim, T.policy_corrupt != 0, 0u, cy, sy, scan_p);
+      write_obs(sc, oc, T.critic, T.n_critic, T.critic_dim, T.critic_corrupt != 0, 1024u, cy, sy, scan_p);
     } else {
-      float cy, sy;
-      V3 scan_p;
-      scanner_pose(cy, sy, scan_p);
 #pragma unroll
-      for (int i = 0; i < Spec::n_policy; ++i) obs_term(Spec::policy[i], sp, Spec::policy_corrupt, 0u, cy, sy, scan_p);
+      for (int i = 0; i < Spec::n_policy; ++i) obs_term(Spec::policy[i], oc, sp, Spec::policy_corrupt, cy, sy, scan_p);
 #pragma unroll
-      for (int i = 0; i < Spec::n_critic; ++i) obs_term(Spec::critic[i], sc, Spec::critic_corrupt, 1024u, cy, sy, scan_p);
+      for (int i = 0; i < Spec::n_critic; ++i) obs_term(Spec::critic[i], oc, sc, Spec::critic_corrupt, cy, sy, scan_p);
     }
     ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
     ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
@@ -614,6 +660,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // ---------------------------------------------------------------- step()
   RL_FN void step() {
     this->load();
+    load_task();  // same batch of HBM loads as the state: one round trip instead of a second one after the substeps
     // 1 ActionManager.process_action [UPSTREAM B2]; JointPosition/VelocityAction (velocity_env_cfg.py:124-126)
     float q_tgt[JX], qd_tgt[JX];
 #pragma unroll
@@ -644,8 +691,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         }
       }
     }
-    // 3 counters (the task registers are only loaded now: nothing above needs them)
-    load_task();
+    // 3 counters
     ep_len += 1;
     derive();
     // 4 terminations (velocity_env_cfg.py:648-664)

@@ -23,6 +23,14 @@ RL_FN float fsqrt(float x) { return sqrtf(x); }
 RL_FN float frsqrt(float x) { return 1.0f / sqrtf(x); }
 #endif
 RL_FN float fdiv(float a, float b) { return a * frcp(b); }
+#if defined(__HIP_DEVICE_COMPILE__)
+RL_FN float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }  // v_exp_f32: ~1 ulp, fine at reward tolerances
+#else
+RL_FN float fexp(float x) { return expf(x); }
+#endif
+RL_FN float ftanh(float x) {  // x >= 0 in every use (speed norms); 1 - 2 / (e^{2x} + 1)
+  return 1.0f - 2.0f * frcp(fexp(2.0f * fminf(x, 20.0f)) + 1.0f);
+}
 
 struct V3 {
   float x, y, z;
