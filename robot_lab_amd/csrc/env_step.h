@@ -491,9 +491,8 @@ struct EnvLane {
       }
       if (!ctx.any(touching)) continue;  // most link groups of most wavefronts touch nothing
       const int wd = wdepth(g);
-#pragma unroll
-      for (int s = 0; s < SPL; ++s) {
-        Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad[s], cb[s], phi[s], nw[s]);
+      auto one_slot = [&](const int s, const float rad_s, const V3 cb_s, const float phi_s, const V3 nw_s) __attribute__((always_inline)) {
+        Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad_s, cb_s, phi_s, nw_s);
         if (c.act) {
           active_mask |= 1u << (g * SPL + s);
           // J = [ [x]x^T | 1 | a_m x (x - p_m) ... ] (point velocity wrt [omega_b, v_b, joints]); add
@@ -539,6 +538,26 @@ struct EnvLane {
             }
           }
         }
+      };
+      if constexpr (NW > 0) {
+        // G1-sized instances: each lane walks ITS touching slots (usually one of the SPL) - the trip count is the
+        // maximum over the wavefront of the touching-slot count and the (large) accumulation block exists once
+        uint32_t tm = 0;
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) tm |= phi[s] > 0.f ? (1u << s) : 0u;
+#pragma unroll 1
+        for (; ctx.any(tm != 0u); tm &= tm - 1u) {
+          const int s = tm != 0u ? __builtin_ctz(tm) : 0;
+          float rad_s = rad[0], phi_s = tm != 0u ? phi[0] : -1.f;
+          V3 cb_s = cb[0], nw_s = nw[0];
+#pragma unroll
+          for (int i = 1; i < SPL; ++i)
+            if (s == i) { rad_s = rad[i]; phi_s = tm != 0u ? phi[i] : -1.f; cb_s = cb[i]; nw_s = nw[i]; }
+          one_slot(s, rad_s, cb_s, phi_s, nw_s);
+        }
+      } else {  // quadrupeds: plain unrolled loop over the SPL slots (measured faster there)
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) one_slot(s, rad[s], cb[s], phi[s], nw[s]);
       }
     }
   }

@@ -543,7 +543,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
           const int nr = ctx.uniform_i(T.scan_nx * T.scan_ny), snx = ctx.uniform_i(T.scan_nx);
           const float inv_snx = ctx.uniform(1.0f / (float)T.scan_nx);
           const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1), soff = T.scan_offset;
-          constexpr int RB = 12 / SUB;  // rays per lane per trip
+          constexpr int RB = SUB == 1 ? 12 : 6;  // rays per lane per trip (187 rays: 2 trips of 6 x 16 lanes)
           for (int r0 = li; r0 < nr; r0 += RB * LPE) {
             TerrainPatch tp[RB];
 #pragma unroll
@@ -604,14 +604,15 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_NOISE, (noise_base >> 2) + (uint32_t)b, un);
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = 4 * b + c < dim ? stage[4 * b + c] : 0.f;
-      for (int i = 0; i < n; ++i) {
-        const ObsTab& Ol = terms[i];
-        if (!Ol.has_noise) continue;
-        const int lo = Ol.offset, hi = i + 1 < n ? terms[i + 1].offset : dim;
+      for (int i = 0; i < n; ++i) {  // term descriptors are wave-uniform: SGPRs, scalar branches
+        const ObsDesc O = decode_obs(terms[i]);
+        if (!O.has_noise) continue;
+        const int lo = O.offset, hi = i + 1 < n ? ctx.uniform_i(terms[i + 1 < n ? i + 1 : i].offset) : dim;
+        const float nr = O.noise_hi - O.noise_lo;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int col = 4 * b + c;
-          if (col >= lo && col < hi) v[c] = clampf(v[c] + Ol.noise_lo + (Ol.noise_hi - Ol.noise_lo) * un[c], Ol.clip_lo, Ol.clip_hi) * Ol.scale;
+          if (col >= lo && col < hi) v[c] = clampf(v[c] + O.noise_lo + nr * un[c], O.clip_lo, O.clip_hi) * O.scale;
         }
       }
 #pragma unroll

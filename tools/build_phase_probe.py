@@ -62,13 +62,37 @@ def terms(s):
         s = must(s, "      write_obs(sp, oc, T.policy, T.n_policy, T.policy_dim, T.policy_corrupt != 0, 0u, cy, sy, scan_p);\n",
                  "      write_obs(sp, oc, T.policy, T.n_policy, T.policy_dim, T.policy_corrupt != 0, 0u, cy, sy, scan_p);\n      RL_STAMP(S, 11);\n")
         s = must(s, "    ctx.flush_obs(S.obs_policy, T.policy_dim, 0);", "    RL_STAMP(S, 12);\n    ctx.flush_obs(S.obs_policy, T.policy_dim, 0);")
-    else:
+    elif mode == "obs":
+        s = must(s, "    derive();\n    float* sp = ctx.obs_stage(0);", "    RL_STAMP(S, 0);\n    derive();\n    float* sp = ctx.obs_stage(0);")
+        s = must(s, "    n = ctx.uniform_i(n);\n    bool any_noise = false;", "    n = ctx.uniform_i(n);\n    bool any_noise = false;\n    const int sbase = noise_base == 0u ? 1 : 8;\n    RL_STAMP(S, sbase - 1 + (noise_base == 0u ? 1 : 0));")
+        s = must(s, "      obs_term(O, oc, stage, corrupt, cy, sy, scan_p);\n    }\n    if (any_noise)", "      obs_term(O, oc, stage, corrupt, cy, sy, scan_p);\n      if (noise_base == 0u && i < 6) RL_STAMP(S, 2 + i);\n    }\n    if (any_noise)")
+        s = must(s, "    if (any_noise) add_noise(stage, terms, n, dim, noise_base);", "    if (any_noise) add_noise(stage, terms, n, dim, noise_base);\n    if (noise_base == 0u) RL_STAMP(S, 8);")
+    elif mode == "rewards":
         s = must(s, "    RewCtx rc{", "    RL_STAMP(S, 0);\n    RewCtx rc{")
         s = must(s, "    float total = 0.f;\n    float* rstage = ctx.rew_stage();", "    RL_STAMP(S, 1);\n    float total = 0.f;\n    float* rstage = ctx.rew_stage();")
         s = must(s, "        if (li == 0) rstage[t] = val;\n      }\n    } else {", "        if (li == 0) rstage[t] = val;\n        if (t < 13) RL_STAMP(S, 2 + t);\n      }\n    } else {")
     return s
 
 
+def step_h(s):
+    if mode != "substep":
+        return s
+    s = must(s, '#include "env_tables.h"\n\nnamespace rl {', '#include "env_tables.h"\n#ifndef RL_STAMP\n#define RL_STAMP(S, i)\n#endif\n\nnamespace rl {')
+    s = must(s, "    float tau_e[JX], pd_diag[JX], pd_rhs[JX];\n    actuators(", "    RL_STAMP(S, 0);\n    float tau_e[JX], pd_diag[JX], pd_rhs[JX];\n    actuators(")
+    s = must(s, "    float Uc[UI::size];\n    float rvc[NV];", "    RL_STAMP(S, 1);\n    float Uc[UI::size];\n    float rvc[NV];")
+    s = must(s, "    if (SUB > 1 && ctx.any(active_mask != 0u)) {", "    RL_STAMP(S, 2);\n    if (SUB > 1 && ctx.any(active_mask != 0u)) {")
+    s = must(s, "    if constexpr (LDSU) {\n      LdsVec<LBS> U{", "    RL_STAMP(S, 3);\n    if constexpr (LDSU) {\n      LdsVec<LBS> U{")
+    s = must(s, "    // ---- Schur complement of the limb block", "    RL_STAMP(S, 4);\n    // ---- Schur complement of the limb block")
+    s = must(s, "    float nu0[NB];\n    {  // NB x NB Cholesky solve", "    RL_STAMP(S, 5);\n    float nu0[NB];\n    {  // NB x NB Cholesky solve")
+    s = must(s, "    // ---- contact sensor: net contact force per body with the NEW velocities", "    RL_STAMP(S, 6);\n    // ---- contact sensor: net contact force per body with the NEW velocities")
+    s = must(s, "    // trunk-link bodies can be fed by several lanes", "    RL_STAMP(S, 7);\n    // trunk-link bodies can be fed by several lanes")
+    s = must(s, "    // [UPSTREAM B5] ContactSensor: history roll", "    RL_STAMP(S, 8);\n    // [UPSTREAM B5] ContactSensor: history roll")
+    s = must(s, "    // ---- integrate (semi-implicit Euler", "    RL_STAMP(S, 9);\n    // ---- integrate (semi-implicit Euler")
+    s = must(s, "    pos = pos + dt * vlin;\n  }", "    pos = pos + dt * vlin;\n    RL_STAMP(S, 10);\n  }")
+    return s
+
+
+edit("env_step.h", step_h)
 edit("rl_env.hip", hip)
 edit("rl_env_host.h", host)
 edit("env_terms.h", terms)

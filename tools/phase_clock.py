@@ -21,7 +21,7 @@ env = ManagerBasedRLEnv(task, num_envs=N, seed=42, device="cuda:0")
 env.reset()
 A = env.num_actions
 g = torch.Generator(device="cuda:0").manual_seed(1)
-names = ["tables->LDS", "load+actions", "substep1", "substep2", "substep3", "substep4", "task regs+terminations", "reward terms", "ep_sums epilogue",
+names = os.environ["RL_STAMP_NAMES"].split(",") if os.environ.get("RL_STAMP_NAMES") else ["tables->LDS", "load+actions", "substep1", "substep2", "substep3", "substep4", "task regs+terminations", "reward terms", "ep_sums epilogue",
          "reset+commands+push", "policy obs", "critic obs", "flush obs", "store"]
 acc = np.zeros(14)
 cnt = 0
