@@ -29,7 +29,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = {"A1-Rough": 857 * 4, "A1-Flat": (857 - 2 * 187) * 4}
+# algorithmic bytes per env-step (Rough); Flat drops the 187 scan rays read + written
+ALGO_BYTES_PER_ENV_STEP = {"A1": 857 * 4, "Go2": 3600, "Go2W": 3800, "G1": 5500}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md
 
 
@@ -114,11 +115,11 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     value = world * N * args.steps / elapsed
-    kind = "A1-Flat" if "Flat" in args.task else "A1-Rough"
-    algo_bytes = ALGO_BYTES_PER_ENV_STEP[kind] * N
+    robot = args.task.split("-Unitree-")[1].split("-")[0]
+    algo_bytes = (ALGO_BYTES_PER_ENV_STEP[robot] - (2 * 187 * 4 if "Flat" in args.task else 0)) * N
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     out = {
-        "metric": "env-steps/sec (whole node) at 4096 envs/GPU, A1 Velocity-Rough",
+        "metric": f"env-steps/sec (whole node) at {N} envs/GPU, {robot} Velocity-{'Flat' if 'Flat' in args.task else 'Rough'}",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

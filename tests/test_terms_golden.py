@@ -22,14 +22,15 @@ def _load(robot):
     N = int(g["N"])
     h, to, eo = build_world(desc, extra, N, 0)
     ora = OracleEnv(desc, h, to, N, int(g["seed"]), eo)
-    for k in ("root_pos", "root_quat", "root_lin_vel", "root_ang_vel", "q", "qd", "base_com"):
-        ora.st[k] = g["st_" + k].copy()
+    for k in ("root_pos", "root_quat", "root_lin_vel", "root_ang_vel", "q", "qd", "base_com", "root_com"):
+        if "st_" + k in g:
+            ora.st[k] = g["st_" + k].copy()
     for k in ("applied_torque", "joint_acc", "force_hist", "contact_force", "timers", "action", "prev_action", "vel_command_b", "terminated"):
         setattr(ora, k, g[k].copy())
     return g, desc, ora
 
 
-@pytest.mark.parametrize("robot", ["a1", "go2"])
+@pytest.mark.parametrize("robot", ["a1", "go2", "g1"])
 def test_reward_terms_match_reference_functions(robot):
     g, desc, ora = _load(robot)
     hist = np.linalg.norm(ora.force_hist, axis=-1).max(axis=1)
@@ -41,7 +42,8 @@ def test_reward_terms_match_reference_functions(robot):
         got = ora.reward_terms[i] / (w * ora.step_dt)
         np.testing.assert_allclose(got, g["term_values"][i], rtol=2e-6, atol=1e-7, err_msg=name)  # descriptor parameters are fp32
     # at least the contact / timer driven terms must be exercised by the recorded state
-    for name in ("undesired_contacts", "contact_forces", "feet_height_body", "joint_mirror"):
+    exercised = {"g1": ("track_lin_vel_xy_exp", "track_ang_vel_z_exp", "feet_air_time", "feet_slide", "joint_deviation_arms_l1", "flat_orientation_l2")}
+    for name in exercised.get(robot, ("undesired_contacts", "contact_forces", "feet_height_body", "joint_mirror")):
         assert np.abs(g["term_values"][names.index(name)]).max() > 0, name
 
 
@@ -55,7 +57,7 @@ def test_command_threshold_rule(robot):
     assert (g["cmd_out"][:, :2] == 0).all(axis=1).any()
 
 
-@pytest.mark.parametrize("robot", ["a1", "go2"])
+@pytest.mark.parametrize("robot", ["a1", "go2", "g1"])
 def test_reset_root_state_uniform(robot):
     """VEL/mdp/events.py:205-271 with injected uniform samples == the oracle's reset arithmetic."""
     g, desc, ora = _load(robot)

@@ -59,7 +59,7 @@ def duck_env(ora, desc):
     st = ora.st
     quat, pos = T(st["root_quat"]), T(st["root_pos"])
     ang_w = T(st["root_ang_vel"])
-    com_w = mu.quat_apply(quat, T(st["base_com"]))
+    com_w = mu.quat_apply(quat, T(st["root_com"]))  # COM of the articulation root body
     lin_w = T(st["root_lin_vel"]) + torch.linalg.cross(ang_w, com_w)
     body_pos, body_vel = ora.phys.body_kinematics(st)
     fwd = mu.quat_apply(quat, torch.tensor([1.0, 0, 0], dtype=torch.float64).repeat(ora.N, 1))
@@ -107,7 +107,7 @@ def resolve(params, desc):
 
 
 def snapshot(ora):
-    keys = ["root_pos", "root_quat", "root_lin_vel", "root_ang_vel", "q", "qd", "base_com"]
+    keys = ["root_pos", "root_quat", "root_lin_vel", "root_ang_vel", "q", "qd", "base_com", "root_com"]
     snap = {"st_" + k: ora.st[k] for k in keys}
     for k in ("applied_torque", "joint_acc", "force_hist", "contact_force", "timers", "action", "prev_action", "vel_command_b", "terminated"):
         snap[k] = getattr(ora, k)
@@ -117,7 +117,10 @@ def snapshot(ora):
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
-    for robot, seed in (("A1", 3), ("Go2", 4)):
+    todo = [a for a in sys.argv[1:]] or ["A1", "Go2", "G1"]
+    for robot, seed in (("A1", 3), ("Go2", 4), ("G1", 6)):
+        if robot not in todo:
+            continue
         task = f"RobotLab-Isaac-Velocity-Flat-Unitree-{robot}-v0"
         cfg = parse_env_cfg(task, device="cpu")
         desc, spec = compile_cfg(cfg)
