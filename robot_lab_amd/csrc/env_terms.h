@@ -22,8 +22,9 @@ enum ObsKind {
 
 // Term descriptors as the lane program consumes them: filled from the LDS tables at run time
 // (wave-uniform, pinned into SGPRs).  `Spec` lets a build provide them as `static constexpr` data
-// instead (compile-time term lists); measured on MI355X that bought nothing (85.0 vs 82.9 us per step:
-// the term bodies, not the descriptor decode, are the cost), so only the generic form is instantiated.
+// instead (compile-time term lists: no decode, no dispatch, bodies in execution order).  Measured twice on
+// MI355X for A1 Rough - 85.0 vs 82.9 us (round-1 term code) and 80.4 vs 74.1 us (one-case-per-kind code):
+// the fully unrolled term sequence raises register pressure and LOSES, so only the generic form is instantiated.
 struct RewDesc {
   int kind, n_idx;
   float weight, p[4];
@@ -455,7 +456,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     constexpr int NACC = (MAX_T + LPE - 1) / LPE;
     float acc[NACC];
     {
-      const int nrew0 = Spec::generic ? ctx.uniform_i(T.n_rewards) : 0;
+      const int nrew0 = ctx.uniform_i(T.n_rewards);
 #pragma unroll
       for (int i = 0; i < NACC; ++i) {
         const int t = li + LPE * i;
@@ -649,10 +650,19 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       write_obs(sp, oc, T.policy, T.n_policy, T.policy_dim, T.policy_corrupt != 0, 0u, cy, sy, scan_p);
       write_obs(sc, oc, T.critic, T.n_critic, T.critic_dim, T.critic_corrupt != 0, 1024u, cy, sy, scan_p);
     } else {
+      bool pn = false, cn = false;
 #pragma unroll
-      for (int i = 0; i < Spec::n_policy; ++i) obs_term(Spec::policy[i], oc, sp, Spec::policy_corrupt, cy, sy, scan_p);
+      for (int i = 0; i < Spec::n_policy; ++i) {
+        obs_term(Spec::policy[i], oc, sp, Spec::policy_corrupt, cy, sy, scan_p);
+        pn = pn || (Spec::policy_corrupt && Spec::policy[i].has_noise);
+      }
+      if (pn) add_noise(sp, T.policy, T.n_policy, T.policy_dim, 0u);
 #pragma unroll
-      for (int i = 0; i < Spec::n_critic; ++i) obs_term(Spec::critic[i], oc, sc, Spec::critic_corrupt, cy, sy, scan_p);
+      for (int i = 0; i < Spec::n_critic; ++i) {
+        obs_term(Spec::critic[i], oc, sc, Spec::critic_corrupt, cy, sy, scan_p);
+        cn = cn || (Spec::critic_corrupt && Spec::critic[i].has_noise);
+      }
+      if (cn) add_noise(sc, T.critic, T.n_critic, T.critic_dim, 1024u);
     }
     ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
     ctx.flush_obs(S.obs_critic, T.critic_dim, 1);

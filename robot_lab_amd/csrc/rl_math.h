@@ -79,8 +79,21 @@ RL_FN S3 rotate(const M3& R, const S3& s) {
 }
 
 // rotation about unit axis by angle (child -> parent coordinates)
+#if defined(__HIP_DEVICE_COMPILE__)
+// v_sin_f32 / v_cos_f32 take revolutions; |error| ~1e-6 for the joint-angle range, two instructions each
+// (the libm sinf / cosf expand to ~50 instructions apiece and sat in every substep's kinematics)
+RL_FN void fsincos(float x, float& s, float& c) {
+  const float r = x * 0.15915494309189535f;
+  s = __builtin_amdgcn_sinf(r);
+  c = __builtin_amdgcn_cosf(r);
+}
+#else
+RL_FN void fsincos(float x, float& s, float& c) { s = sinf(x); c = cosf(x); }
+#endif
 RL_FN M3 rodrigues(V3 a, float ang) {
-  float s = sinf(ang), c = cosf(ang), t = 1.0f - c;
+  float s, c;
+  fsincos(ang, s, c);
+  const float t = 1.0f - c;
   return {{c + t * a.x * a.x, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y},
           {t * a.x * a.y + s * a.z, c + t * a.y * a.y, t * a.y * a.z - s * a.x},
           {t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, c + t * a.z * a.z}};
