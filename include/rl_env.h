@@ -232,7 +232,7 @@ enum rl_buffer {
   RL_BUF_REWARD_TERMS = 9, /* float [T, N] per-term weighted value of the last step (parity checks) */
   RL_BUF_EPISODE_SUMS = 10,/* float [T, N] reward_manager._episode_sums (VEL/mdp/curriculums.py:44) */
   RL_BUF_COMMAND = 11,     /* float [N, 3] */
-  RL_BUF_CONTACT_FORCE = 12, /* float [N, B, 3] net_forces_w of the last substep; written by rl_env_export_state */
+  RL_BUF_CONTACT_FORCE = 12, /* float [N, B, 3] net_forces_w of the last substep (inspection view: see rl_env_get_buffer) */
   RL_BUF_CONTACT_TIMERS = 13, /* float [N, B, 4] current_air, current_contact, last_air, last_contact */
   RL_BUF_LOG = 14,         /* float [RL_LOG_SIZE] device-side episode log accumulators */
   RL_BUF_ACTION = 15,      /* float [N, A] last (raw) action */
@@ -262,7 +262,9 @@ int rl_env_reset(rl_env* env, const int32_t* env_ids, int32_t n, void* stream);
  * float [N, A] row-major.  Stream-ordered; no host synchronisation. */
 int rl_env_step(rl_env* env, const float* action_dev, void* stream);
 
-/* Device pointer + shape of one of the env-owned buffers.  shape[] gets up to 3 dims, ndim out. */
+/* Device pointer + shape of one of the env-owned buffers.  shape[] gets up to 3 dims, ndim out.
+ * RL_BUF_CONTACT_FORCE / JOINT_TORQUE / JOINT_ACC are inspection views: they are allocated on the first
+ * request and filled by every step() AFTER that request (the training path never pays for them). */
 int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[3], int32_t* ndim,
                       int32_t* elem_size);
 

@@ -73,15 +73,17 @@ struct LaneTabT {
 };
 using LaneTab = LaneTabT<TopoMax>;
 
-struct RewTab {
+struct RewTab {  // 48 bytes; index lists (joint_mirror pairs, gait feet) live in TaskTab::idx_pool_*
   int32_t kind;
   float weight;
-  float p[8];
+  float p[4];
   uint32_t joint_mask;
-  uint64_t body_mask;
-  int32_t idx_a[16], idx_b[16];
   int32_t n_idx;
+  uint64_t body_mask;
+  int32_t idx_off;  // first entry of this term in the index pools
+  int32_t pad_;
 };
+constexpr int IDX_POOL = 48;
 
 struct ObsTab {
   int32_t kind;
@@ -117,7 +119,7 @@ struct TaskTab {  // everything that is not per limb
   float scan_res, scan_offset;
   uint32_t wheel_joint_mask;
   int32_t n_rewards;
-  RewTab rew[MAX_T];
+  int32_t idx_pool_a[IDX_POOL], idx_pool_b[IDX_POOL];
   int32_t term_time_out, term_oob, term_illegal;
   float oob_buffer, illegal_threshold;
   uint64_t illegal_body_mask;
@@ -130,6 +132,7 @@ struct TaskTab {  // everything that is not per limb
 template <class TP>
 struct TablesT : TaskTab {
   LaneTabT<TP> lane[NLANE];
+  RewTab rew[MAX_T];  // last: only the first n_rewards entries are staged into LDS (KState::table_bytes)
 };
 using Tables = TablesT<TopoMax>;  // host side / export-import kernels; env kernels read the packed TablesT<TP>
 
@@ -137,6 +140,7 @@ using Tables = TablesT<TopoMax>;  // host side / export-import kernels; env kern
 template <class TP>
 inline void pack_tables(const Tables& s, TablesT<TP>& d) {
   static_cast<TaskTab&>(d) = static_cast<const TaskTab&>(s);
+  for (int t = 0; t < MAX_T; ++t) d.rew[t] = s.rew[t];
   for (int k = 0; k < NLANE; ++k) {
     const LaneTab& a = s.lane[k];
     LaneTabT<TP>& b = d.lane[k];
@@ -234,6 +238,7 @@ struct KState {
   const uint8_t* reset_mask;       // [Npad] (reset mode)
   uint64_t seed;
   uint32_t step_counter;
+  uint32_t table_bytes;  // bytes of the packed table image the env kernels stage into LDS (multiple of 16)
 };
 
 }  // namespace rl

@@ -63,7 +63,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // derived articulation data [UPSTREAM B3]
   M3 Rwb;
   V3 lin_b, ang_b, grav_b, lin_w;
-  float heading_w, yaw_c, yaw_s;
+  float yaw_c, yaw_s;  // cos / sin of the heading
 
   RL_FN EnvProgram(Ctx& c, const KState& s) : Base(c, s) {}
 
@@ -101,7 +101,6 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     lin_b = mulT(Rwb, lin_w);
     ang_b = mulT(Rwb, vang);
     grav_b = mulT(Rwb, V3{0.f, 0.f, -1.f});
-    heading_w = atan2f(Rwb.r1.x, Rwb.r0.x);
     const float hn = frsqrt(fmaxf(Rwb.r0.x * Rwb.r0.x + Rwb.r1.x * Rwb.r1.x, 1e-30f));  // cos / sin of the heading without trigonometry
     yaw_c = Rwb.r0.x * hn;
     yaw_s = Rwb.r1.x * hn;
@@ -480,7 +479,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         R.p[0] = ctx.uniform(Rl.p[0]); R.p[1] = ctx.uniform(Rl.p[1]); R.p[2] = ctx.uniform(Rl.p[2]); R.p[3] = ctx.uniform(Rl.p[3]);
         R.joint_mask = (uint32_t)ctx.uniform_i((int)Rl.joint_mask);
         R.body_mask = (uint64_t)(uint32_t)ctx.uniform_i((int)(uint32_t)Rl.body_mask) | ((uint64_t)(uint32_t)ctx.uniform_i((int)(uint32_t)(Rl.body_mask >> 32)) << 32);
-        R.idx_a = Rl.idx_a; R.idx_b = Rl.idx_b;
+        R.idx_a = T.idx_pool_a + Rl.idx_off; R.idx_b = T.idx_pool_b + Rl.idx_off;
         float val = reward_term(R, rc) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
         total += val;
         if (li == 0) rstage[t] = val;
@@ -740,17 +739,19 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     // 7 CommandManager.compute [UPSTREAM B7]
     {
-      float max_step = T.cmd_resample[1] / T.step_dt;
+      const float inv_max_step = T.step_dt * frcp(T.cmd_resample[1]);
       float ex = cmd.x - lin_b.x, ey = cmd.y - lin_b.y;
-      metric_xy += fsqrt(ex * ex + ey * ey) / max_step;
-      metric_yaw += fabsf(cmd.z - ang_b.z) / max_step;
+      metric_xy += fsqrt(ex * ex + ey * ey) * inv_max_step;
+      metric_yaw += fabsf(cmd.z - ang_b.z) * inv_max_step;
       cmd_time_left -= T.step_dt;
       if (cmd_time_left <= 0.f) {
         cmd_time_left = U(STREAM_COMMAND, 6, T.cmd_resample[0], T.cmd_resample[1]);
         resample_command(STREAM_COMMAND, 0);
       }
-      if (T.cmd_heading && is_heading)
+      if (T.cmd_heading && is_heading) {  // the only consumer of the heading angle itself (everything else uses its cos / sin)
+        const float heading_w = atan2f(yaw_s, yaw_c);
         cmd.z = clampf(T.cmd_heading_stiffness * wrap_to_pi(heading_target - heading_w), T.cmd_range[2][0], T.cmd_range[2][1]);
+      }
       if (is_standing) cmd = {0.f, 0.f, 0.f};
       // the "pits" branch of commands.py:61-85 never fires: ROUGH_TERRAINS_CFG has no sub-terrain of that name (utils.py:27-28)
     }

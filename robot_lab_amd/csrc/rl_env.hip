@@ -117,24 +117,22 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   float* smem = reinterpret_cast<float*>(smem4);
   Tables* Tl = reinterpret_cast<Tables*>(smem);
   const int lane = threadIdx.x;
-  {  // stage the model / term tables into LDS (16-byte vectors): all loads in flight before the first LDS write
+  {  // stage the used part of the table image into LDS (16-byte vectors): all loads in flight before the first LDS write
     const float4* src = reinterpret_cast<const float4*>(Tg);
     float4* dst = reinterpret_cast<float4*>(Tl);
-    constexpr int N4 = (int)(sizeof(Tables) / 16), NIT = (N4 + 63) / 64;
+    constexpr int NIT = ((int)(sizeof(Tables) / 16) + 63) / 64;
+    const int n4 = (int)(S.table_bytes >> 4);
     float4 tmp[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = lane + 64 * it;
-      tmp[it] = src[i < N4 ? i : N4 - 1];
+      if (i < n4) tmp[it] = src[i];
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = lane + 64 * it;
-      if (i < N4) dst[i] = tmp[it];
+      if (i < n4) dst[i] = tmp[it];
     }
-    const uint32_t* s1 = reinterpret_cast<const uint32_t*>(Tg);
-    uint32_t* d1 = reinterpret_cast<uint32_t*>(Tl);
-    for (int i = N4 * 4 + lane; i < (int)(sizeof(Tables) / 4); i += 64) d1[i] = s1[i];
   }
   __syncthreads();
   constexpr int TAB_F = (sizeof(Tables) + 15) / 16 * 4;

@@ -36,6 +36,7 @@ int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[
     *dev_ptr = p; *ndim = nd; shape[0] = a; shape[1] = b; shape[2] = c; *elem_size = es;
     return 0;
   };
+  if ((which == RL_BUF_CONTACT_FORCE || which == RL_BUF_JOINT_TORQUE || which == RL_BUF_JOINT_ACC) && I.enable_inspection()) return -1;
   switch (which) {
     case RL_BUF_OBS_POLICY: return set(I.S.obs_policy, 2, N, I.tables.policy_dim, 1, 4);
     case RL_BUF_OBS_CRITIC: return set(I.S.obs_critic, 2, N, I.tables.critic_dim, 1, 4);

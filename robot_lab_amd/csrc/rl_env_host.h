@@ -243,12 +243,17 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   }
   T.scan_nx = t.scan_nx; T.scan_ny = t.scan_ny; T.scan_res = t.scan_res; T.scan_offset = t.scan_offset; T.wheel_joint_mask = t.wheel_joint_mask;
   T.n_rewards = t.n_rewards;
+  int pool_used = 0;
   for (int i = 0; i < t.n_rewards; ++i) {
     const rl_reward_term& r = t.rewards[i];
     if (r.kind < 0 || r.kind >= RL_REW_NUM_KINDS) return fail("unknown reward kind");
     RewTab& R = T.rew[i];
     R.kind = r.kind; R.weight = r.weight; memcpy(R.p, r.p, sizeof(R.p)); R.joint_mask = r.joint_mask; R.body_mask = r.body_mask;
-    memcpy(R.idx_a, r.idx_a, sizeof(R.idx_a)); memcpy(R.idx_b, r.idx_b, sizeof(R.idx_b)); R.n_idx = r.n_idx;
+    R.n_idx = r.n_idx; R.idx_off = pool_used;
+    if (r.n_idx < 0 || r.n_idx > 16 || pool_used + (r.kind == RL_REW_FEET_GAIT ? 4 : r.n_idx) > IDX_POOL) return fail("index lists of the reward terms exceed the pool");
+    const int nidx = r.kind == RL_REW_FEET_GAIT ? 4 : r.n_idx;
+    for (int q = 0; q < nidx; ++q) { T.idx_pool_a[pool_used + q] = r.idx_a[q]; T.idx_pool_b[pool_used + q] = r.idx_b[q]; }
+    pool_used += nidx;
   }
   T.term_time_out = t.term_time_out; T.term_oob = t.term_out_of_bounds; T.term_illegal = t.term_illegal_contact;
   T.oob_buffer = t.oob_buffer; T.illegal_threshold = t.illegal_threshold; T.illegal_body_mask = t.illegal_body_mask;
@@ -265,6 +270,11 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
 // packed (per-instance) table image that the env kernels stage into LDS
 inline size_t packed_size(const TaskTab& T) {
   return T.NW > 0 ? sizeof(TablesT<TopoG1>) : (T.CL == 4 ? sizeof(TablesT<TopoQuad4>) : sizeof(TablesT<TopoQuad3>));
+}
+template <class TP>
+inline size_t staged_bytes_t(const TaskTab& T) { return (offsetof(TablesT<TP>, rew) + (size_t)T.n_rewards * sizeof(RewTab) + 15) / 16 * 16; }
+inline size_t staged_bytes(const TaskTab& T) {
+  return T.NW > 0 ? staged_bytes_t<TopoG1>(T) : (T.CL == 4 ? staged_bytes_t<TopoQuad4>(T) : staged_bytes_t<TopoQuad3>(T));
 }
 inline std::vector<uint8_t> pack_image(const Tables& T) {
   std::vector<uint8_t> img(packed_size(T), 0);
@@ -324,7 +334,7 @@ struct EnvImpl {
     const size_t Np = Npad, ntile = Npad / ept;
     const Layout ly(tables.CL, tables.NW, tables.NBS);
     memset(&S, 0, sizeof(S));
-    S.N = N; S.Npad = Npad; S.seed = seed; S.ept = ept;
+    S.N = N; S.Npad = Npad; S.seed = seed; S.ept = ept; S.table_bytes = (uint32_t)staged_bytes(tables);
     S.lane_state = alloc<float>(ntile * (size_t)ly.NF_LANE * NLANE * ept);
     S.env_state = alloc<float>(ntile * (size_t)ly.NF_ENV * ept);
     S.flags = alloc<int32_t>(Np); S.level = alloc<int32_t>(Np); S.ttype = alloc<int32_t>(Np);
@@ -333,7 +343,6 @@ struct EnvImpl {
     S.obs_critic = alloc<float>(Np * (size_t)std::max(1, tables.critic_dim));
     S.reward = alloc<float>(Np); S.terminated = alloc<uint8_t>(Np); S.time_out = alloc<uint8_t>(Np);
     S.rew_terms = alloc<float>(MAX_T * Np); S.command_out = alloc<float>(3 * Np); S.log = alloc<float>(LOG_SIZE);
-    S.dbg_torque = alloc<float>(Np * D); S.dbg_acc = alloc<float>(Np * D); S.dbg_cforce = alloc<float>(Np * B * 3);
     root_state = alloc<float>(Np * 13); joint_pos = alloc<float>(Np * D); joint_vel = alloc<float>(Np * D);
     ctimers = alloc<float>(Np * B * 4); action_aos = alloc<float>(Np * D); env_origin_aos = alloc<float>(Np * 3);
     reset_mask = alloc<uint8_t>(Np);
@@ -467,6 +476,16 @@ struct EnvImpl {
     be.h2d(S.lane_state, lane.data(), lane.size() * 4);
     be.h2d(S.env_state, env.data(), env.size() * 4);
     be.h2d(S.level, level.data(), level.size() * 4); be.h2d(S.ttype, ttype.data(), ttype.size() * 4);
+  }
+
+  // The inspection views (applied torque, joint acceleration, net contact force per body) cost 75 extra
+  // words per env-step of HBM writes on A1; they are allocated - and from then on written by every step -
+  // when a caller first asks for one of them (rl_env_get_buffer).
+  int enable_inspection() {
+    if (S.dbg_torque) return 0;
+    const size_t Np = Npad;
+    S.dbg_torque = alloc<float>(Np * D); S.dbg_acc = alloc<float>(Np * D); S.dbg_cforce = alloc<float>(Np * B * 3);
+    return (S.dbg_torque && S.dbg_acc && S.dbg_cforce) ? 0 : fail("device allocation failed: " + be.error());
   }
 
   int reset(const int32_t* env_ids, int32_t n, void* stream) {

@@ -148,11 +148,9 @@ RL_FN SI make_si(float m, V3 c, S3 Ic) {
 }
 
 RL_FN float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
-RL_FN float wrap_to_pi(float a) {
+RL_FN float wrap_to_pi(float a) {  // (a + pi) mod 2 pi - pi without fmodf
   const float PI = 3.14159265358979323846f;
-  float w = fmodf(a + PI, 2.0f * PI);
-  if (w < 0.0f) w += 2.0f * PI;
-  return w - PI;
+  return a - 2.0f * PI * floorf((a + PI) * (0.5f / PI));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -43,6 +43,26 @@ class _DevView:
         self._owner = owner
 
 
+_INSPECTION = ("CONTACT_FORCE", "JOINT_TORQUE", "JOINT_ACC")
+
+
+class _Buffers(dict):
+    """name -> torch view of an env-owned device buffer, adopted on first use.  The three inspection views
+    (`data.applied_torque`, `data.joint_acc`, contact forces) are only allocated - and from then on written
+    by every step - when somebody asks for them (`include/rl_env.h: rl_env_get_buffer`)."""
+
+    def __init__(self, env):
+        super().__init__()
+        self._env = env
+
+    def __missing__(self, name):
+        e = self._env
+        ptr, shape, dt = e._native.buffer(name)
+        t = torch.as_tensor(_DevView(ptr, shape, dt, e._native), device=e.device)
+        self[name] = t
+        return t
+
+
 class _LazyLog(dict):
     """`extras["log"]`: per-step episode log [UPSTREAM B1/B2] backed by a device snapshot; entries are
     0-dim device tensors materialised on first access, so a training loop that only reads them at log
@@ -190,7 +210,7 @@ class ManagerBasedRLEnv(_EnvBase):
 
     def __init__(self, cfg=None, render_mode=None, *, desc: EnvDesc | None = None, extra: dict | None = None,
                  num_envs: int | None = None, seed: int | None = None, device: str | None = None, terrain_seed: int = 0,
-                 lib_path: str | None = None, **kwargs):
+                 lib_path: str | None = None, inspection: bool = False, **kwargs):
         if isinstance(cfg, str):  # a compiled descriptor bundle id / path (robot_lab_amd/data)
             desc, extra = load_bundle(cfg)
             cfg = None
@@ -224,12 +244,13 @@ class ManagerBasedRLEnv(_EnvBase):
         self.physics_dt = float(desc.sim.dt)
         self.step_dt = float(desc.sim.dt) * int(desc.sim.decimation)
         self.common_step_counter = 0
-        self._bufs: dict[str, torch.Tensor] = {}
+        self._bufs = _Buffers(self)
         for name in ("OBS_POLICY", "OBS_CRITIC", "REWARD", "TERMINATED", "TIME_OUT", "EPISODE_LENGTH", "ROOT_STATE", "JOINT_POS",
-                     "JOINT_VEL", "REWARD_TERMS", "EPISODE_SUMS", "COMMAND", "CONTACT_FORCE", "CONTACT_TIMERS", "LOG", "ACTION",
-                     "JOINT_TORQUE", "JOINT_ACC", "ENV_ORIGIN", "TERRAIN_LEVEL"):
-            ptr, shape, dt = self._native.buffer(name)
-            self._bufs[name] = torch.as_tensor(_DevView(ptr, shape, dt, self._native), device=self.device)
+                     "JOINT_VEL", "REWARD_TERMS", "EPISODE_SUMS", "COMMAND", "CONTACT_TIMERS", "LOG", "ACTION", "ENV_ORIGIN", "TERRAIN_LEVEL"):
+            self._bufs[name]
+        if inspection:  # applied torque / joint acceleration / contact force views, filled by every step from now on
+            for name in _INSPECTION:
+                self._bufs[name]
         self._terminated = self._bufs["TERMINATED"].view(torch.bool)
         self._time_outs = self._bufs["TIME_OUT"].view(torch.bool)
         self._obs = {"policy": self._bufs["OBS_POLICY"], "critic": self._bufs["OBS_CRITIC"]}

@@ -15,6 +15,8 @@ def make_pair(task, N, seed, lib_path=None, device=0):
     h, to, eo = build_world(desc, extra, N, 0)
     ora = OracleEnv(desc, h, to, N, seed, eo)
     nat = NativeEnv(desc, h, to, eo, N, seed, device, lib_path)
+    for name in ("CONTACT_FORCE", "JOINT_TORQUE", "JOINT_ACC"):  # inspection views: filled by the steps after the first request
+        nat.buffer(name)
     return desc, ora, nat
 
 
