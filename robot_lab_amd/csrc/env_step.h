@@ -258,6 +258,8 @@ struct EnvLane {
   const LaneTabT<TP>& L;
   const Uni u;
   int e, k, sub, li, Np;  // env, leg, sub-lane of the leg, lane index inside the env (k * SUB + sub)
+  static constexpr int MAXOWN = SUB == 1 ? NBS : LaneTabT<TP>::MAXOWN;
+  int own[MAXOWN];        // body slots this lane updates every substep (all of them when a lane is a whole leg)
   float* lt;  // this leg's column of the wave tile:   field f -> lt[f * ROW]
   float* et;  // this env's column of the env tile:    field f -> et[f * EPT]
   // persistent state in registers
@@ -283,6 +285,8 @@ struct EnvLane {
     sub = ctx.sub();
     li = k * SUB + sub;
     Np = S.Npad;
+#pragma unroll
+    for (int i = 0; i < MAXOWN; ++i) own[i] = SUB == 1 ? i : L.own_slot[SUB == 1 ? 0 : sub][SUB == 1 ? 0 : i];
     lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
     et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
   }
@@ -858,9 +862,9 @@ struct EnvLane {
 
     // ---- contact sensor: net contact force per body with the NEW velocities (world frame)
     SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
-    V3 fslot[NBS];
+    V3 fown[MAXOWN];  // per owned slot
 #pragma unroll
-    for (int b = 0; b < NBS; ++b) fslot[b] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < MAXOWN; ++i) fown[i] = {0.f, 0.f, 0.f};
     // pass 2: only the spheres that were active in pass 1 are re-evaluated (same state -> same contact)
 #pragma unroll 1
     for (uint32_t m = active_mask; m != 0; m &= m - 1) {
@@ -877,21 +881,25 @@ struct EnvLane {
         V3 Fw = mul(Rwb, Fb);
         int slot = L.sph_slot[g][s];
 #pragma unroll
-        for (int b = 0; b < NBS; ++b)
-          if (b == slot) fslot[b] += Fw;
+        for (int i = 0; i < MAXOWN; ++i)
+          if (own[i] == slot) fown[i] += Fw;
       }
     }
-    // trunk-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes)
+    // trunk-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes); slot 0,
+    // when a lane has it, is the first entry of its list
     for (int bi = 0; bi < T.n_base_bodies; ++bi) {
-      bool mine = L.base_body_local == bi;
-      V3 f{ctx.esum(mine ? fslot[0].x : 0.f), ctx.esum(mine ? fslot[0].y : 0.f), ctx.esum(mine ? fslot[0].z : 0.f)};
-      if (mine) fslot[0] = f;
+      const bool mine = L.base_body_local == bi && own[0] == 0;
+      V3 f{ctx.esum(mine ? fown[0].x : 0.f), ctx.esum(mine ? fown[0].y : 0.f), ctx.esum(mine ? fown[0].z : 0.f)};
+      if (mine) fown[0] = f;
     }
-    // [UPSTREAM B5] ContactSensor: history roll + air/contact timers, every physics step
+    // [UPSTREAM B5] ContactSensor: history roll + air/contact timers, every physics step - each lane for the
+    // slots it owns (with 16 lanes per env every sub-lane used to update all NBS slots of its private copy)
 #pragma unroll
-    for (int b = 0; b < NBS; ++b) {
-      cf[b][0] = fslot[b].x; cf[b][1] = fslot[b].y; cf[b][2] = fslot[b].z;
-      float fn = norm(fslot[b]);
+    for (int i = 0; i < MAXOWN; ++i) {
+      const int b = own[i];
+      if (b < 0) continue;
+      cf[b][0] = fown[i].x; cf[b][1] = fown[i].y; cf[b][2] = fown[i].z;
+      float fn = norm(fown[i]);
       hist_n[b][2] = hist_n[b][1];
       hist_n[b][1] = hist_n[b][0];
       hist_n[b][0] = fn;

@@ -70,6 +70,8 @@ struct LaneTabT {
   float slot_pos[TP::NBS][3];          // body frame origin in its link frame
   int32_t base_body_local;             // which sphere-carrying trunk body (0..n_base_bodies-1) slot 0 / group 0 belongs to, -1 none
   int32_t owns_base_body;              // 1 if this lane keeps the timers of that trunk body
+  static constexpr int MAXOWN = TP::NBS > 6 ? 4 : 2;
+  int32_t own_slot[4][MAXOWN];         // 16-lanes-per-env mapping: the body slots sub-lane s updates (ascending, -1 padded)
 };
 using LaneTab = LaneTabT<TopoMax>;
 
@@ -165,6 +167,8 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
       for (int c = 0; c < 3; ++c) b.slot_pos[q][c] = a.slot_pos[q][c];
     }
     b.base_body_local = a.base_body_local; b.owns_base_body = a.owns_base_body;
+    for (int q = 0; q < 4; ++q)
+      for (int i = 0; i < LaneTabT<TP>::MAXOWN; ++i) b.own_slot[q][i] = a.own_slot[q][i];
   }
 }
 

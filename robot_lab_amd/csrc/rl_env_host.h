@@ -197,6 +197,21 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     L.sph_r[grp][s] = m.sphere_radius[g];
     L.sph_slot[grp][s] = slot;
   }
+  // 16-lanes-per-env mapping: body slots each sub-lane updates (the slots of the link groups it evaluates)
+  for (int k = 0; k < NLANE; ++k) {
+    LaneTab& L = T.lane[k];
+    const int maxown = NBS > 6 ? 4 : 2;
+    for (int q = 0; q < 4; ++q) {
+      int n = 0;
+      for (int i = 0; i < LaneTab::MAXOWN; ++i) L.own_slot[q][i] = -1;
+      for (int sl = 0; sl < NBS; ++sl) {
+        const bool used = L.slot_body[sl] >= 0 || (sl == 0 && L.base_body_local >= 0);
+        if (!used || (L.slot_grp[sl] % 4) != q) continue;
+        if (n >= maxown) return fail("too many body slots on one sub-lane");
+        L.own_slot[q][n++] = sl;
+      }
+    }
+  }
   // bodies the events / the scanner address
   {
     const int wl = m.body_link[d.task.base_body], sl = m.body_link[d.task.scan_body];
