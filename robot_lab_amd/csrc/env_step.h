@@ -329,7 +329,9 @@ struct EnvLane {
       qacc[j] = 0.f;
     }
 #pragma unroll
-    for (int s = 0; s < NBS; ++s) {
+    for (int i = 0; i < MAXOWN; ++i) {  // sensor state + material of the body slots this lane owns (the others are never read unmasked)
+      const int s = own[i];
+      if (s < 0) continue;
 #pragma unroll
       for (int t = 0; t < 4; ++t) tim[s][t] = LF(LY.LF_TIMERS + s * 4 + t);
 #pragma unroll
@@ -367,11 +369,12 @@ struct EnvLane {
       }
     }
 #pragma unroll
-    for (int s = 0; s < NBS; ++s)
-      if (owns_slot(s)) {
+    for (int i = 0; i < MAXOWN; ++i) {
+      const int s = own[i];
+      if (s < 0 || (s == 0 && SUB > 1 && L.slot_body[0] < 0)) continue;  // slot 0 of a lane that only shares a trunk body's spheres
 #pragma unroll
-        for (int t = 0; t < 4; ++t) LF(LY.LF_TIMERS + s * 4 + t) = tim[s][t];
-      }
+      for (int t = 0; t < 4; ++t) LF(LY.LF_TIMERS + s * 4 + t) = tim[s][t];
+    }
   }
 
   // ------------------------------------------------------------------ actuators [UPSTREAM B4]

@@ -140,7 +140,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     // scene.reset: sensor / wrench buffers
 #pragma unroll
-    for (int b = 0; b < NBS; ++b) {
+    for (int i = 0; i < Base::MAXOWN; ++i) {
+      const int b = this->own[i];
+      if (b < 0) continue;
       tim[b][0] = tim[b][1] = tim[b][2] = tim[b][3] = 0.f;
       cf[b][0] = cf[b][1] = cf[b][2] = 0.f;
       hist_n[b][0] = hist_n[b][1] = hist_n[b][2] = 0.f;
