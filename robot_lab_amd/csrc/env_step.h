@@ -227,15 +227,25 @@ struct LbLayout {
   enum { WORDS = TP::NW > 0 ? (TP::JX * 15 + SymIdx<TP::NB + TP::CL>::size + TP::NB + TP::CL) : 0 };
 };
 
-template <int NBS>
+// STASH > 0: room for the contacts of one link group (x, n, bias, d_n, d_t per sphere slot) so that the sensor
+// pass after the solve does not re-evaluate them (quadrupeds in the 16-lane mapping; 4 workgroups x 40 KB of LDS
+// still share a CU)
+constexpr int CONTACT_WORDS = 10;
+template <int NBS, int STASH = 0>
 struct LsLayout {
-  enum { TIM = 0, HIST = TIM + NBS * 4, CF = HIST + NBS * 3, FRIC = CF + NBS * 3, WORDS = FRIC + NBS * 3 };
+  enum { TIM = 0, HIST = TIM + NBS * 4, CF = HIST + NBS * 3, FRIC = CF + NBS * 3, CT = FRIC + NBS * 3, WORDS = CT + STASH * CONTACT_WORDS };
+};
+template <class TP, int SUB>
+struct LsFor {  // lane scratchpad layout of an instance
+  static constexpr int STASH = (TP::NW == 0 && SUB > 1) ? TP::SPL : 0;
+  using type = LsLayout<TP::NBS, STASH>;
 };
 
 template <class Ctx, class TP>
 struct EnvLane {
   static constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NB = TP::NB, SPL = TP::SPL, NBS = TP::NBS, NGRP = TP::CL + 1;
-  using LS = LsLayout<NBS>;
+  using LS = typename LsFor<TP, Ctx::SUB>::type;
+  static constexpr bool STASH = LsFor<TP, Ctx::SUB>::STASH > 0;
   static constexpr int LSS = Ctx::LS_STRIDE;
   static constexpr int SUB = Ctx::SUB;          // sub-lanes per leg (1: one lane per leg; 4: a DPP quad per leg)
   static constexpr int LPE = NLANE * SUB;       // lanes per environment
@@ -294,6 +304,8 @@ struct EnvLane {
   RL_FN float& EF(int f) const { return et[(uint32_t)f * (uint32_t)EPT]; }
   // link group g (0 = base share, 1.. = chain links) is evaluated by sub-lane g % SUB of the leg
   RL_FN bool owns_group(int g) const { return SUB == 1 || (g % SUB) == sub; }
+  // the link group whose contacts are stashed for the sensor pass: the most distal one this lane evaluates (Go2W: the wheel)
+  RL_FN int stash_group() const { return SUB == 1 ? CL : sub + SUB * ((CL - sub) / SUB); }
   RL_FN bool owns_slot(int s) const { return owns_group(L.slot_grp[s]); }
 
   // ------------------------------------------------------------------ load / store
@@ -502,6 +514,11 @@ struct EnvLane {
         Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad_s, cb_s, phi_s, nw_s);
         if (c.act) {
           active_mask |= 1u << (g * SPL + s);
+          if (STASH && g == stash_group()) {  // keep the contact for the sensor pass
+            float* st = ctx.lane_scratch() + (LS::CT + s * CONTACT_WORDS) * LSS;
+            st[0 * LSS] = c.x.x; st[1 * LSS] = c.x.y; st[2 * LSS] = c.x.z; st[3 * LSS] = c.n.x; st[4 * LSS] = c.n.y; st[5 * LSS] = c.n.z;
+            st[6 * LSS] = c.bias; st[7 * LSS] = c.dn; st[8 * LSS] = c.dt;
+          }
           // J = [ [x]x^T | 1 | a_m x (x - p_m) ... ] (point velocity wrt [omega_b, v_b, joints]); add
           // dt (d_t J^T J + (d_n - d_t) g g^T) with g = J^T n, exploiting the block structure of J
           const V3 x = c.x, n = c.n;
@@ -873,10 +890,19 @@ struct EnvLane {
     for (uint32_t m = active_mask; m != 0; m &= m - 1) {
       const int ci = __builtin_ctz(m);
       const int g = ci / SPL, s = ci - g * SPL;
-      float rad;
-      V3 cb, cw;
-      sphere_center(C, Rwb, g, s, rad, cb, cw);
-      Contact c = contact_from_patch(C, Rwb, V0, qd, g, s, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
+      Contact c;
+      if (STASH && g == stash_group()) {
+        const float* st = ctx.lane_scratch() + (LS::CT + s * CONTACT_WORDS) * LSS;
+        c.act = true;
+        c.x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
+        c.n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
+        c.bias = st[6 * LSS]; c.dn = st[7 * LSS]; c.dt = st[8 * LSS];
+      } else {
+        float rad;
+        V3 cb, cw;
+        sphere_center(C, Rwb, g, s, rad, cb, cw);
+        c = contact_from_patch(C, Rwb, V0, qd, g, s, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
+      }
       if (c.act) {
         V3 uu = point_velocity<TP, ChainTP>(C, wdepth(g), g, c.x, V0n, qdn);
         float un = dot(c.n, uu);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   ctx.stage[0] = smem + TAB_F;
   ctx.stage[1] = ctx.stage[0] + ((Ctx::EPT * ctx.dim[0] + 3) & ~3);
   ctx.lscratch = ctx.stage[1] + ((Ctx::EPT * ctx.dim[1] + 3) & ~3);
-  ctx.lbscratch = ctx.lscratch + LsLayout<TP::NBS>::WORDS * 64;
+  ctx.lbscratch = ctx.lscratch + LsFor<TP, SUB>::type::WORDS * 64;
   ctx.rstage = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
   ctx.lane = lane;
   EnvProgram<Ctx, TP> prog(ctx, S);
@@ -213,7 +213,7 @@ struct Backend {
     size_t tab = (packed_size(T) + 15) / 16 * 16;
     size_t s0 = (ept * T.policy_dim + 3) / 4 * 16;
     size_t s1 = (ept * T.critic_dim + 3) / 4 * 16;
-    const size_t ls_words = T.NW > 0 ? LsLayout<TopoG1::NBS>::WORDS : LsLayout<TopoQuad3::NBS>::WORDS;
+    const size_t ls_words = T.NW > 0 ? LsFor<TopoG1, 4>::type::WORDS : (sub > 1 ? LsFor<TopoQuad3, 4>::type::WORDS : LsFor<TopoQuad3, 1>::type::WORDS);
     const size_t lb_words = T.NW > 0 ? LbLayout<TopoG1>::WORDS : 0;
     lds_bytes = tab + s0 + s1 + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + ept * MAX_T * 4;
     if (lds_bytes > 160 * 1024) {

@@ -39,7 +39,7 @@ struct HostCtx {
   static constexpr int SUB = SUB_;
   static constexpr int LPE = rl::NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
-  float scratch[rl::LsLayout<rl::MAX_NBS>::WORDS];
+  float scratch[rl::LsLayout<rl::MAX_NBS, rl::MAX_SPL>::WORDS];
   float* lane_scratch() { return scratch; }
   float lb[rl::LbLayout<rl::TopoG1>::WORDS + 1];
   float* limb_scratch() { return lb; }
