@@ -428,20 +428,26 @@ struct EnvLane {
   // joints that move link group g: the first wdepth(g) trunk joints and the first g limb joints
   RL_FN int wdepth(int g) const { return NW == 0 ? 0 : (g == 0 ? L.grp0_depth : L.attach); }
   // sphere centre in base coordinates (cb) and world (cw); empty slots (radius <= 0) sit at the group's link origin
-  RL_FN void sphere_center(const ChainTP& C, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
-    rad = L.sph_r[g][s];
-    V3 cl = ld3(L.sph_c[g][s]);
-    cb = cl;
-    if (NW > 0) {
-      M3 Rf;
-      V3 pf;
-      trunk_frame<TP>(C, L.grp0_depth, Rf, pf);
-      cb = pf + mul(Rf, cl);
-    }
+  // frame (base coordinates) of link group g: the trunk link of group 0, else limb link g - 1.  Selected once
+  // per group (12 selects per candidate) instead of one matrix-vector product per candidate per sphere.
+  RL_FN void group_frame(const ChainTP& C, int g, M3& Rg, V3& pg) const {
+    Rg = identity3();
+    pg = {0.f, 0.f, 0.f};
+    if (NW > 0) trunk_frame<TP>(C, L.grp0_depth, Rg, pg);
 #pragma unroll
     for (int j = 0; j < CL; ++j)
-      if (g == j + 1) cb = C.p(j) + mul(C.R(j), cl);
+      if (g == j + 1) { Rg = C.R(j); pg = C.p(j); }
+  }
+  RL_FN void sphere_center_in(const M3& Rg, V3 pg, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
+    rad = L.sph_r[g][s];
+    cb = pg + mul(Rg, ld3(L.sph_c[g][s]));
     cw = pos + mul(Rwb, cb);
+  }
+  RL_FN void sphere_center(const ChainTP& C, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
+    M3 Rg;
+    V3 pg;
+    group_frame(C, g, Rg, pg);
+    sphere_center_in(Rg, pg, Rwb, g, s, rad, cb, cw);
   }
   // penetration depth and world normal of a fetched patch (straight-line: three of these interleave)
   RL_FN void patch_phi(const TerrainPatch& tp, float rad, V3 cw, float& phi, V3& nw) const {
@@ -495,9 +501,12 @@ struct EnvLane {
       float rad[SPL];
       V3 cb[SPL], cw[SPL];
       TerrainPatch tp[SPL];
+      M3 Rg;
+      V3 pg;
+      group_frame(C, g, Rg, pg);
 #pragma unroll
       for (int s = 0; s < SPL; ++s) {
-        sphere_center(C, Rwb, g, s, rad[s], cb[s], cw[s]);
+        sphere_center_in(Rg, pg, Rwb, g, s, rad[s], cb[s], cw[s]);
         tp[s] = terrain_fetch(u, S.terrain, cw[s].x, cw[s].y);
       }
       float phi[SPL];

@@ -75,6 +75,14 @@ def terms(s):
 
 
 def step_h(s):
+    if mode == "contacts":
+        s = must(s, '#include "env_tables.h"\n\nnamespace rl {', '#include "env_tables.h"\n#ifndef RL_STAMP\n#define RL_STAMP(S, i)\n#endif\n\nnamespace rl {')
+        s = must(s, "    const float dt = u.dt;\n#pragma unroll 1\n    for (int g = (SUB == 1 ? 0 : sub); g <= CL; g += SUB) {", "    const float dt = u.dt;\n    RL_STAMP(S, 0);\n#pragma unroll 1\n    for (int g = (SUB == 1 ? 0 : sub); g <= CL; g += SUB) {")
+        s = must(s, "      float phi[SPL];\n      V3 nw[SPL];\n      bool touching = false;", "      RL_STAMP(S, 1);\n      float phi[SPL];\n      V3 nw[SPL];\n      bool touching = false;")
+        s = must(s, "      if (!ctx.any(touching)) continue;  // most link groups", "      RL_STAMP(S, 2);\n      if (!ctx.any(touching)) continue;  // most link groups")
+        s = must(s, "        for (int s = 0; s < SPL; ++s) one_slot(s, rad[s], cb[s], phi[s], nw[s]);", "        for (int s = 0; s < SPL; ++s) { one_slot(s, rad[s], cb[s], phi[s], nw[s]); RL_STAMP(S, 3 + s); }")
+        s = must(s, "        Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad_s, cb_s, phi_s, nw_s);\n        if (c.act) {", "        Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad_s, cb_s, phi_s, nw_s);\n        if (s == 0) RL_STAMP(S, 6);\n        if (c.act) {")
+        return s
     if mode != "substep":
         return s
     s = must(s, '#include "env_tables.h"\n\nnamespace rl {', '#include "env_tables.h"\n#ifndef RL_STAMP\n#define RL_STAMP(S, i)\n#endif\n\nnamespace rl {')
