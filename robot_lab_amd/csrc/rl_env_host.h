@@ -287,7 +287,9 @@ inline size_t packed_size(const TaskTab& T) {
   return T.NW > 0 ? sizeof(TablesT<TopoG1>) : (T.CL == 4 ? sizeof(TablesT<TopoQuad4>) : sizeof(TablesT<TopoQuad3>));
 }
 template <class TP>
-inline size_t staged_bytes_t(const TaskTab& T) { return (offsetof(TablesT<TP>, rew) + (size_t)T.n_rewards * sizeof(RewTab) + 15) / 16 * 16; }
+inline size_t staged_bytes_t(const TaskTab& T) {  // `rew` is the last member: everything up to its first n_rewards entries
+  return (sizeof(TablesT<TP>) - (size_t)(MAX_T - T.n_rewards) * sizeof(RewTab) + 15) / 16 * 16;
+}
 inline size_t staged_bytes(const TaskTab& T) {
   return T.NW > 0 ? staged_bytes_t<TopoG1>(T) : (T.CL == 4 ? staged_bytes_t<TopoQuad4>(T) : staged_bytes_t<TopoQuad3>(T));
 }
