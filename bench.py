@@ -110,7 +110,7 @@ def main():
     try:  # measured separately with rocprofv3 PMC passes (cannot be collected inside this process)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tr = json.load(f).get(args.task)
-        if tr and N == 4096:
+        if tr and N == tr.get("num_envs", 4096):
             traffic = tr["fetch_bytes"] + tr["write_bytes"]
     except (OSError, ValueError, KeyError):
         pass

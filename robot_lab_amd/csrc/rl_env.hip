@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = lane + 64 * it;
-      if (i < n4) tmp[it] = src[i];
+      tmp[it] = src[i < n4 ? i : n4 - 1];  // unconditional (clamped) loads keep tmp[] in registers
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
