@@ -56,9 +56,9 @@ def test_short_horizon_parity(task):
     env.close()
 
 
-def test_time_out_reset_parity():
+@pytest.mark.parametrize("task,N", [(TASKS[1], 64), (TASKS[5], 32)])
+def test_time_out_reset_parity(task, N):
     """Force time-outs through the settable episode_length_buf (rsl_rl init_at_random_ep_len path)."""
-    task, N = TASKS[1], 64
     env, ora, torch = _pair(task, N, 5)
     env.reset()
     ora.reset()
@@ -80,22 +80,24 @@ def test_time_out_reset_parity():
             for name in ("Episode_Reward/track_lin_vel_xy_exp", "Metrics/base_velocity/error_vel_xy"):
                 np.testing.assert_allclose(float(extras["log"][name]), ora.log[name], rtol=2e-3, atol=1e-6)
         assert np.array_equal(env.episode_length_buf.cpu().numpy(), ora.episode_length_buf)
-    assert n_reset == 16
+    assert n_reset >= N // 4  # the forced time-outs (+ any illegal-contact terminations on G1)
     d = env.scene["robot"].data
     assert_close("root", d.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4, 0.98)
     assert_close("critic", obs["critic"].cpu().numpy(), o[1], 5e-3, 5e-3, 0.97)
     env.close()
 
 
-def test_full_size_properties():
-    """BASELINE config 2 at full size (4096 envs): size-independent invariants of step()."""
+@pytest.mark.parametrize("task,N", [(TASKS[1], 4096), (TASKS[5], 2048), (TASKS[3], 4096)])
+def test_full_size_properties(task, N):
+    """BASELINE configs 2 (A1 Rough, 4096 envs), 4 (G1 Rough, 2048) and 5 (Go2W Rough, 4096) at full size:
+    size-independent invariants of step()."""
     import torch
 
     from robot_lab_amd.env import ManagerBasedRLEnv
 
-    N = 4096
-    env = ManagerBasedRLEnv(TASKS[1], num_envs=N, seed=42, device="cuda:0")
-    env2 = ManagerBasedRLEnv(TASKS[1], num_envs=N, seed=42, device="cuda:0")
+    env = ManagerBasedRLEnv(task, num_envs=N, seed=42, device="cuda:0")
+    env2 = ManagerBasedRLEnv(task, num_envs=N, seed=42, device="cuda:0")
+    A, scan0 = env.num_actions, env.get_observations()["critic"].shape[1] - 187
     env.reset()
     env2.reset()
     env.episode_length_buf = torch.randint(0, env.max_episode_length, (N,))
@@ -103,7 +105,7 @@ def test_full_size_properties():
     g = torch.Generator(device="cuda").manual_seed(0)
     total_done = 0
     for s in range(60):
-        a = torch.rand(N, 12, device="cuda", generator=g) * 2 - 1
+        a = torch.rand(N, A, device="cuda", generator=g) * 2 - 1
         ep_before = env.episode_length_buf.clone()
         obs, rew, term, tout, _ = env.step(a)
         obs2, rew2, _, _, _ = env2.step(a)
@@ -118,7 +120,7 @@ def test_full_size_properties():
         ep = env.episode_length_buf
         assert torch.equal(ep[~done], ep_before[~done] + 1) and bool((ep[done] == 0).all())
         # height scan is clipped to [-1, 1] (velocity_env_cfg.py:236-241)
-        assert float(obs["critic"][:, 48:].abs().max()) <= 1.0
+        assert float(obs["critic"][:, scan0:].abs().max()) <= 1.0
     assert total_done > 0
     quat = env.scene["robot"].data.root_quat_w
     torch.testing.assert_close(quat.norm(dim=1), torch.ones(N, device="cuda"), rtol=1e-4, atol=1e-4)
