@@ -224,7 +224,8 @@ struct LsMat {
 // words of limb-shared LDS an instance needs (0 when it keeps everything in registers)
 template <class TP>
 struct LbLayout {
-  enum { WORDS = TP::NW > 0 ? (TP::JX * 15 + SymIdx<TP::NB + TP::CL>::size + TP::NB + TP::CL) : 0 };
+  enum { WORDS = TP::NW > 0 ? (TP::JX * 15 + SymIdx<TP::NB + TP::CL>::size + TP::NB + TP::CL) : 0,
+         AUX_WORDS = TP::NW > 0 ? TP::CL * 12 : 0 };  // streaming CRBA: momentum + bias force per link, in the obs staging rows
 };
 
 // STASH > 0: room for the contacts of one link group (x, n, bias, d_n, d_t per sphere slot) so that the sensor
@@ -688,6 +689,101 @@ struct EnvLane {
         ap = aw[i];
       }
     }
+    if constexpr (LDSU) {
+      // ---- streaming CRBA + RNEA (G1-sized limbs): the forward pass keeps only the running link velocity /
+      // bias acceleration and parks each link's momentum and bias force in LDS (the observation staging rows
+      // are idle during the substeps); the backward pass rebuilds the link inertia, carries ONE running
+      // composite (inertia, force, momentum) and emits the joint's column.  The array form below keeps
+      // 4 x CL spatial quantities live - fine for 3-4 joints, ~200 VGPRs of spills for 7.
+      LdsVec<LBS> W{ctx.aux_limb_scratch()};  // [CL][12]: h_j (6), f_j (6)
+      auto link_inertia = [&](int j) {
+        const int li = LY.LF_INERTIA + j * INERTIA_NF;
+        const M3 Rj = C.R(j);
+        const V3 cb = C.p(j) + mul(Rj, V3{LF(li + 1), LF(li + 2), LF(li + 3)});
+        return make_si(LF(li), cb, rotate(Rj, S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
+      };
+      auto joint_axis = [&](int j) {
+        const V3 ax = C.ax(j);
+        return SV{ax, cross(C.p(j), ax)};
+      };
+      {
+        SV Vp = V0, ap = a0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+          if (L.attach == i + 1) { Vp = Vw[i]; ap = aw[i]; }
+#pragma unroll
+        for (int j = 0; j < CL; ++j) {
+          const SV vj = joint_axis(j) * qd[j];
+          const SV Vj = Vp + vj;
+          const SV aj = ap + crm(Vj, vj);
+          const SI Ij = link_inertia(j);
+          const SV h = apply(Ij, Vj);
+          const SV f = apply(Ij, aj) + crf(Vj, h);
+          const int o = j * 12;
+          W[o + 0] = h.a.x; W[o + 1] = h.a.y; W[o + 2] = h.a.z; W[o + 3] = h.l.x; W[o + 4] = h.l.y; W[o + 5] = h.l.z;
+          W[o + 6] = f.a.x; W[o + 7] = f.a.y; W[o + 8] = f.a.z; W[o + 9] = f.l.x; W[o + 10] = f.l.y; W[o + 11] = f.l.z;
+          Vp = Vj;
+          ap = aj;
+        }
+      }
+      SI Ic{0.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+      SV Fc{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, Hc = Fc;
+#pragma unroll
+      for (int j = CL - 1; j >= 0; --j) {
+        const int o = j * 12;
+        Ic = Ic + link_inertia(j);
+        Hc = Hc + SV{{W[o + 0], W[o + 1], W[o + 2]}, {W[o + 3], W[o + 4], W[o + 5]}};
+        Fc = Fc + SV{{W[o + 6], W[o + 7], W[o + 8]}, {W[o + 9], W[o + 10], W[o + 11]}};
+        const SV Sjj = joint_axis(j);
+        const SV B = apply(Ic, Sjj);
+        U[UI::at(0, NB + j)] += B.a.x; U[UI::at(1, NB + j)] += B.a.y; U[UI::at(2, NB + j)] += B.a.z;
+        U[UI::at(3, NB + j)] += B.l.x; U[UI::at(4, NB + j)] += B.l.y; U[UI::at(5, NB + j)] += B.l.z;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+          if (i < L.attach) U[UI::at(6 + i, NB + j)] += dot(Sw[i], B);
+#pragma unroll
+        for (int i = 0; i <= j; ++i) U[UI::at(NB + i, NB + j)] += dot(i == j ? Sjj : joint_axis(i), B);
+        const float arm = L.armature[j];
+        const float below = L.lower[j] - q[j], above = q[j] - L.upper[j];
+        const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
+        const bool lim = (below > 0.f) || (above > 0.f);
+        U[UI::at(NB + j, NB + j)] += arm + (j >= L.nj ? 1.0f : 0.f) + pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+        rv[NB + j] += dot(Sjj, Hc) + arm * qd[j] + dt * (tau_e[j] - dot(Sjj, Fc)) + pd_rhs[j] + dt * u.limit_k * viol;
+      }
+      add_composite(Ic, Hc, Fc, L.attach, Sw, U, rv);
+      if (k <= NW) {  // lane group k adds trunk link k (0 = the base link) + the persistent external wrench [UPSTREAM B8]
+        const int bi = LY.EF_BASE_INERTIA + k * INERTIA_NF;
+        M3 Rf;
+        V3 pf;
+        trunk_frame<TP>(C, k, Rf, pf);
+        SV Vl = V0, al = a0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+          if (k == i + 1) { Vl = Vw[i]; al = aw[i]; }
+        const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
+        const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
+        SV h0 = apply(I0, Vl);
+        SV f0 = apply(I0, al) + crf(Vl, h0);
+        if (k == T.wrench_depth) {
+          const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
+          f0.a -= mul(Rf, extT) + cross(xc, Fb);
+          f0.l -= Fb;
+        }
+        add_composite(I0, h0, f0, k, Sw, U, rv);
+      }
+      if (k == 0) {  // joint-local terms of the trunk joints (armature, actuators, limits): once
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+          const int jx = CL + i;
+          float arm = L.armature[jx];
+          float below = L.lower[jx] - q[jx], above = q[jx] - L.upper[jx];
+          float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
+          bool lim = (below > 0.f) || (above > 0.f);
+          U[UI::at(6 + i, 6 + i)] += arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+          rv[6 + i] += arm * qd[jx] + dt * tau_e[jx] + pd_rhs[jx] + dt * u.limit_k * viol;
+        }
+      }
+    } else {
     // ---- CRBA + RNEA of the limb in base coordinates
     SV Sj[CL];
     SI Ic[CL];
@@ -788,6 +884,8 @@ struct EnvLane {
       bool lim = (below > 0.f) || (above > 0.f);
       U[UI::at(NB + j, NB + j)] += pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
       rv[NB + j] += dt * u.limit_k * viol;
+    }
+
     }
 
     // ---- Schur complement of the limb block, cross-limb reduction, NB x NB trunk solve, back substitution

@@ -48,6 +48,8 @@ struct WaveCtx {
   int lane;
   __device__ float* lane_scratch() const { return lscratch + lane; }
   __device__ float* limb_scratch() const { return lbscratch + lane / SUB; }
+  // second limb-shared area, valid only while the observation staging rows are idle (inside the substeps)
+  __device__ float* aux_limb_scratch() const { return stage[0] + lane / SUB; }
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
@@ -142,7 +144,12 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   ctx.dim[1] = Tl->critic_dim;
   ctx.stage[0] = smem + TAB_F;
   ctx.stage[1] = ctx.stage[0] + ((Ctx::EPT * ctx.dim[0] + 3) & ~3);
-  ctx.lscratch = ctx.stage[1] + ((Ctx::EPT * ctx.dim[1] + 3) & ~3);
+  {  // the staging rows double as limb-shared scratch inside the substeps (streaming CRBA): at least that big
+    const int s0w = (Ctx::EPT * ctx.dim[0] + 3) & ~3, need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
+    int s1w = (Ctx::EPT * ctx.dim[1] + 3) & ~3;
+    if (s0w + s1w < need) s1w = need - s0w;
+    ctx.lscratch = ctx.stage[1] + s1w;
+  }
   ctx.lbscratch = ctx.lscratch + LsFor<TP, SUB>::type::WORDS * 64;
   ctx.rstage = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
   ctx.lane = lane;
@@ -213,6 +220,8 @@ struct Backend {
     size_t tab = (packed_size(T) + 15) / 16 * 16;
     size_t s0 = (ept * T.policy_dim + 3) / 4 * 16;
     size_t s1 = (ept * T.critic_dim + 3) / 4 * 16;
+    const size_t aux = T.NW > 0 ? (size_t)LbLayout<TopoG1>::AUX_WORDS * (64 / sub) * 4 : 0;
+    if (s0 + s1 < aux) s1 = aux - s0;
     const size_t ls_words = T.NW > 0 ? LsFor<TopoG1, 4>::type::WORDS : (sub > 1 ? LsFor<TopoQuad3, 4>::type::WORDS : LsFor<TopoQuad3, 1>::type::WORDS);
     const size_t lb_words = T.NW > 0 ? LbLayout<TopoG1>::WORDS : 0;
     lds_bytes = tab + s0 + s1 + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + ept * MAX_T * 4;
