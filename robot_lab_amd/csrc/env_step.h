@@ -207,6 +207,18 @@ struct LdsVec {
   float* p;
   RL_FN float& operator[](int i) const { return p[i * STRIDE]; }
 };
+// accumulate-only view of the same words for contributions that DIFFER between the sub-lanes of a limb (contacts):
+// ds_add_f32 into the shared word instead of a private register copy + quad sum
+template <class Ctx, int STRIDE>
+struct LdsAcc {
+  float* p;
+  struct Ref {
+    float* q;
+    RL_FN void operator+=(float v) const { Ctx::limb_atomic_add(q, v); }
+    RL_FN void operator-=(float v) const { Ctx::limb_atomic_add(q, -v); }
+  };
+  RL_FN Ref operator[](int i) const { return Ref{p + i * STRIDE}; }
+};
 
 // Lane-private LDS scratchpad: word f of a lane lives at base[f * STRIDE] (STRIDE = 64 on the GPU, so
 // a wavefront access hits 64 different banks).  It holds the per-body contact-sensor state (timers,
@@ -494,7 +506,8 @@ struct EnvLane {
   // (U, rv).  With SUB == 4 the four sub-lanes of a leg run this same code on different groups (g is a
   // per-lane value) and the caller quad-sums the result; with SUB == 1 the lane loops over all groups.
   // Joint columns of the system: 6 + m, m in [0, NW) the trunk joints, m in [NW, NW + CL) the limb joints.
-  RL_FN void contact_pass1(const ChainTP& C, const M3& Rwb, SV V0, uint32_t slot_valid, float (&U)[UI::size], float (&rv)[NV], uint32_t& active_mask) {
+  template <class UA, class RA>
+  RL_FN void contact_pass1(const ChainTP& C, const M3& Rwb, SV V0, uint32_t slot_valid, UA& U, RA& rv, uint32_t& active_mask) {
     const float dt = u.dt;
 #pragma unroll 1
     for (int g = (SUB == 1 ? 0 : sub); g <= CL; g += SUB) {
@@ -638,34 +651,46 @@ struct EnvLane {
     ChainTP C = new_chain();
     chain_kinematics<TP>(L, q, C);
 
-    float Uc[UI::size];
-    float rvc[NV];
-#pragma unroll
-    for (int i = 0; i < UI::size; ++i) Uc[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) rvc[i] = 0.f;
-
     // ---- contacts first (they only need the kinematics): every sub-lane accumulates the spheres of its
-    // link groups into the zero-initialised (U, rv), the leg's sub-lanes are quad-summed, and the CRBA
-    // terms are added on top - so only one copy of the system is ever live.
+    // link groups into the zero-initialised (U, rv), the leg's sub-lanes are summed, and the CRBA terms are
+    // added on top - so only one copy of the system is ever live.
     uint32_t active_mask = 0;
     const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
-    contact_pass1(C, Rwb, V0, slot_valid, Uc, rvc, active_mask);
-    if (SUB > 1 && ctx.any(active_mask != 0u)) {
-#pragma unroll
-      for (int i = 0; i < UI::size; ++i) Uc[i] = ctx.leg_sum(Uc[i]);
-#pragma unroll
-      for (int i = 0; i < NV; ++i) rvc[i] = ctx.leg_sum(rvc[i]);
-    }
-    if constexpr (LDSU) {
+    if constexpr (LDSU && Ctx::LIMB_ATOMICS) {
+      // G1-sized system on the GPU: ds_add_f32 straight into the limb-shared LDS words (no 152-register private
+      // copy, no quad sum of 152 values)
       LdsVec<LBS> U{ctx.limb_scratch() + LB_U * LBS}, rv{ctx.limb_scratch() + LB_RV * LBS};
 #pragma unroll
-      for (int i = 0; i < UI::size; ++i) U[i] = Uc[i];
+      for (int i = 0; i < UI::size; ++i) U[i] = 0.f;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) rv[i] = rvc[i];
+      for (int i = 0; i < NV; ++i) rv[i] = 0.f;
+      LdsAcc<Ctx, LBS> Ua{U.p}, ra{rv.p};
+      contact_pass1(C, Rwb, V0, slot_valid, Ua, ra, active_mask);
       solve_and_integrate(U, rv, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
     } else {
-      solve_and_integrate(Uc, rvc, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
+      float Uc[UI::size];
+      float rvc[NV];
+#pragma unroll
+      for (int i = 0; i < UI::size; ++i) Uc[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) rvc[i] = 0.f;
+      contact_pass1(C, Rwb, V0, slot_valid, Uc, rvc, active_mask);
+      if (SUB > 1 && ctx.any(active_mask != 0u)) {
+#pragma unroll
+        for (int i = 0; i < UI::size; ++i) Uc[i] = ctx.leg_sum(Uc[i]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) rvc[i] = ctx.leg_sum(rvc[i]);
+      }
+      if constexpr (LDSU) {
+        LdsVec<LBS> U{ctx.limb_scratch() + LB_U * LBS}, rv{ctx.limb_scratch() + LB_RV * LBS};
+#pragma unroll
+        for (int i = 0; i < UI::size; ++i) U[i] = Uc[i];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) rv[i] = rvc[i];
+        solve_and_integrate(U, rv, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
+      } else {
+        solve_and_integrate(Uc, rvc, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
+      }
     }
   }
 

@@ -37,6 +37,8 @@ struct WaveCtx {
   static constexpr int LS_STRIDE = 64;
   static constexpr int SUB = SUB_;
   static constexpr int LB_STRIDE = 64 / SUB_;  // limb-shared words: one per limb of the wavefront
+  static constexpr bool LIMB_ATOMICS = true;   // limb-shared words are real shared LDS: sub-lanes can ds_add into them
+  __device__ static void limb_atomic_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   static constexpr int LPE = NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
   float* lscratch;

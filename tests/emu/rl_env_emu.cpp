@@ -35,6 +35,8 @@ struct Team {
 template <int SUB_>
 struct HostCtx {
   static constexpr int LS_STRIDE = 1;
+  static constexpr bool LIMB_ATOMICS = false;  // per-thread copies: the register accumulation + leg_sum path is emulated
+  static void limb_atomic_add(float* p, float v) { *p += v; }
   static constexpr int LB_STRIDE = 1;  // "limb-shared" words are private per lane thread here (the sub-lanes hold identical values)
   static constexpr int SUB = SUB_;
   static constexpr int LPE = rl::NLANE * SUB_;
