@@ -545,7 +545,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
           const int nr = ctx.uniform_i(T.scan_nx * T.scan_ny), snx = ctx.uniform_i(T.scan_nx);
           const float inv_snx = ctx.uniform(1.0f / (float)T.scan_nx);
           const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1), soff = T.scan_offset;
-          constexpr int RB = SUB == 1 ? 12 : 6;  // rays per lane per trip (187 rays: 2 trips of 6 x 16 lanes)
+          constexpr int RB = 12;  // rays per lane per trip (187 rays = one trip of 12 x 16 lanes: all 187 loads in flight together)
           for (int r0 = li; r0 < nr; r0 += RB * LPE) {
             TerrainPatch tp[RB];
 #pragma unroll

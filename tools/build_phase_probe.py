@@ -87,9 +87,10 @@ def step_h(s):
         return s
     s = must(s, '#include "env_tables.h"\n\nnamespace rl {', '#include "env_tables.h"\n#ifndef RL_STAMP\n#define RL_STAMP(S, i)\n#endif\n\nnamespace rl {')
     s = must(s, "    float tau_e[JX], pd_diag[JX], pd_rhs[JX];\n    actuators(", "    RL_STAMP(S, 0);\n    float tau_e[JX], pd_diag[JX], pd_rhs[JX];\n    actuators(")
-    s = must(s, "    float Uc[UI::size];\n    float rvc[NV];", "    RL_STAMP(S, 1);\n    float Uc[UI::size];\n    float rvc[NV];")
-    s = must(s, "    if (SUB > 1 && ctx.any(active_mask != 0u)) {", "    RL_STAMP(S, 2);\n    if (SUB > 1 && ctx.any(active_mask != 0u)) {")
-    s = must(s, "    if constexpr (LDSU) {\n      LdsVec<LBS> U{", "    RL_STAMP(S, 3);\n    if constexpr (LDSU) {\n      LdsVec<LBS> U{")
+    s = must(s, "    // ---- contacts first (they only need the kinematics)", "    RL_STAMP(S, 1);\n    // ---- contacts first (they only need the kinematics)")
+    s = must(s, "      contact_pass1(C, Rwb, V0, slot_valid, Ua, ra, active_mask);\n", "      contact_pass1(C, Rwb, V0, slot_valid, Ua, ra, active_mask);\n      RL_STAMP(S, 2);\n      RL_STAMP(S, 3);\n")
+    s = must(s, "      contact_pass1(C, Rwb, V0, slot_valid, Uc, rvc, active_mask);\n", "      contact_pass1(C, Rwb, V0, slot_valid, Uc, rvc, active_mask);\n      RL_STAMP(S, 2);\n")
+    s = must(s, "      if constexpr (LDSU) {\n        LdsVec<LBS> U{", "      RL_STAMP(S, 3);\n      if constexpr (LDSU) {\n        LdsVec<LBS> U{")
     s = must(s, "    // ---- Schur complement of the limb block", "    RL_STAMP(S, 4);\n    // ---- Schur complement of the limb block")
     s = must(s, "    float nu0[NB];\n    {  // NB x NB Cholesky solve", "    RL_STAMP(S, 5);\n    float nu0[NB];\n    {  // NB x NB Cholesky solve")
     s = must(s, "    // ---- contact sensor: net contact force per body with the NEW velocities", "    RL_STAMP(S, 6);\n    // ---- contact sensor: net contact force per body with the NEW velocities")
