@@ -15,6 +15,8 @@
 // and back-substitutes its own chain.  Same equations as oracle/physics.py, different formulation
 // (that one is generic-tree, dense, fp64, link coordinates).
 #pragma once
+#include <type_traits>
+
 #include "env_tables.h"
 
 namespace rl {
@@ -813,7 +815,61 @@ struct EnvLane {
     SV Sj[CL];
     SI Ic[CL];
     SV Fs[CL], Hs[CL];
-    {
+    if constexpr (SUB == 4 && NW == 0 && CL <= 4) {
+      // 16-lane mapping: the four sub-lanes of a leg used to repeat the whole pass.  Now every sub-lane runs
+      // the (cheap) velocity recursion, builds the inertia / momentum / bias force of ONE link - link `sub` -
+      // and the three or four records are exchanged with DPP quad broadcasts (22 values per link).
+      SV Vl[CL], al[CL];
+      {
+        SV Vp = V0, ap = a0;
+#pragma unroll
+        for (int j = 0; j < CL; ++j) {
+          Sj[j] = SV{C.ax(j), cross(C.p(j), C.ax(j))};
+          const SV vj = Sj[j] * qd[j];
+          Vl[j] = Vp + vj;
+          al[j] = ap + crm(Vl[j], vj);
+          Vp = Vl[j];
+          ap = al[j];
+        }
+      }
+      const int m = sub < CL ? sub : CL - 1;  // my link (the spare sub-lane of a 3-joint leg repeats the last one)
+      // my link's frame / velocity / bias acceleration as a 0-1 weighted blend: a chain of selects on `m` is
+      // rewritten by the compiler into an indexed load from a scratch copy of the arrays (a trip to memory)
+      M3 Rm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      V3 pm{0.f, 0.f, 0.f};
+      SV Vm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, am = Vm;
+#pragma unroll
+      for (int j = 0; j < CL; ++j) {
+        const float w = m == j ? 1.f : 0.f;
+        const M3 Rj = C.R(j);
+        Rm.r0 += w * Rj.r0; Rm.r1 += w * Rj.r1; Rm.r2 += w * Rj.r2;
+        pm += w * C.p(j);
+        Vm.a += w * Vl[j].a; Vm.l += w * Vl[j].l;
+        am.a += w * al[j].a; am.l += w * al[j].l;
+      }
+      const uint32_t li = (uint32_t)(LY.LF_INERTIA + m * INERTIA_NF);
+      const V3 cb = pm + mul(Rm, V3{LF(li + 1), LF(li + 2), LF(li + 3)});
+      const SI Im = make_si(LF(li), cb, rotate(Rm, S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
+      const SV hm = apply(Im, Vm);
+      const SV fm = apply(Im, am) + crf(Vm, hm);
+      auto bc = [&](auto tag, int j) {
+        constexpr int J = decltype(tag)::value;
+        auto b = [&](float v) { return ctx.template leg_bcast<J>(v); };
+        Ic[j] = SI{b(Im.m), {b(Im.h.x), b(Im.h.y), b(Im.h.z)}, {b(Im.I.xx), b(Im.I.yy), b(Im.I.zz), b(Im.I.xy), b(Im.I.xz), b(Im.I.yz)}};
+        Hs[j] = SV{{b(hm.a.x), b(hm.a.y), b(hm.a.z)}, {b(hm.l.x), b(hm.l.y), b(hm.l.z)}};
+        Fs[j] = SV{{b(fm.a.x), b(fm.a.y), b(fm.a.z)}, {b(fm.l.x), b(fm.l.y), b(fm.l.z)}};
+      };
+      bc(std::integral_constant<int, 0>{}, 0);
+      if constexpr (CL > 1) bc(std::integral_constant<int, 1>{}, 1);
+      if constexpr (CL > 2) bc(std::integral_constant<int, 2>{}, 2);
+      if constexpr (CL > 3) bc(std::integral_constant<int, 3>{}, 3);
+#pragma unroll
+      for (int j = CL - 2; j >= 0; --j) {  // suffix sums: composite inertia / force / momentum
+        Ic[j] = Ic[j] + Ic[j + 1];
+        Fs[j] = Fs[j] + Fs[j + 1];
+        Hs[j] = Hs[j] + Hs[j + 1];
+      }
+    } else {
       SV Vp = V0, ap = a0;
 #pragma unroll
       for (int i = 0; i < NW; ++i)

@@ -91,6 +91,9 @@ struct WaveCtx {
     }
     return v;
   }
+  // value held by sub-lane J of this lane's leg (DPP quad_perm broadcast; SUB == 4)
+  template <int J>
+  __device__ float leg_bcast(float v) const { return dpp<J | (J << 2) | (J << 4) | (J << 6)>(v); }
   __device__ float gshfl(float v, int leg) const { return __shfl(v, SUB == 1 ? ((lane & ~3) | leg) : ((lane & ~15) | (leg << 2) | (lane & 3))); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
   __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }

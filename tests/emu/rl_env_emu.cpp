@@ -99,6 +99,14 @@ struct HostCtx {
     team->barrier(sense_);
     return r;
   }
+  template <int J>
+  float leg_bcast(float v) {
+    team->slot[li()] = v;
+    team->barrier(sense_);
+    float r = team->slot[k_ * SUB + (J < SUB ? J : 0)];
+    team->barrier(sense_);
+    return r;
+  }
   float gshfl(float v, int leg) {
     team->slot[li()] = v;
     team->barrier(sense_);
