@@ -551,27 +551,33 @@ struct EnvLane {
           const V3 ga = cross(x, n);
           const float g6[6] = {ga.x, ga.y, ga.z, n.x, n.y, n.z};
           const float xx = dot(x, x);
-          // base block
-          U[UI::at(0, 0)] += kt * (xx - x.x * x.x); U[UI::at(1, 1)] += kt * (xx - x.y * x.y); U[UI::at(2, 2)] += kt * (xx - x.z * x.z);
-          U[UI::at(0, 1)] -= kt * x.x * x.y; U[UI::at(0, 2)] -= kt * x.x * x.z; U[UI::at(1, 2)] -= kt * x.y * x.z;
-          U[UI::at(0, 4)] -= kt * x.z; U[UI::at(0, 5)] += kt * x.y;
-          U[UI::at(1, 3)] += kt * x.z; U[UI::at(1, 5)] -= kt * x.x;
-          U[UI::at(2, 3)] -= kt * x.y; U[UI::at(2, 4)] += kt * x.x;
-          U[UI::at(3, 3)] += kt; U[UI::at(4, 4)] += kt; U[UI::at(5, 5)] += kt;
+          // base block: kt [x]x^T [x]x  /  kt [x]x^T  /  kt 1   plus the rank-1 normal term - one update per entry
+          float b6[SymIdx<6>::size];
+#pragma unroll
+          for (int i = 0; i < SymIdx<6>::size; ++i) b6[i] = 0.f;
+          using B6 = SymIdx<6>;
+          b6[B6::at(0, 0)] = kt * (xx - x.x * x.x); b6[B6::at(1, 1)] = kt * (xx - x.y * x.y); b6[B6::at(2, 2)] = kt * (xx - x.z * x.z);
+          b6[B6::at(0, 1)] = -kt * x.x * x.y; b6[B6::at(0, 2)] = -kt * x.x * x.z; b6[B6::at(1, 2)] = -kt * x.y * x.z;
+          b6[B6::at(0, 4)] = -kt * x.z; b6[B6::at(0, 5)] = kt * x.y;
+          b6[B6::at(1, 3)] = kt * x.z; b6[B6::at(1, 5)] = -kt * x.x;
+          b6[B6::at(2, 3)] = -kt * x.y; b6[B6::at(2, 4)] = kt * x.x;
+          b6[B6::at(3, 3)] = kt; b6[B6::at(4, 4)] = kt; b6[B6::at(5, 5)] = kt;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
             rv[i] += fb * g6[i];
             const float kg = kn * g6[i];
 #pragma unroll
-            for (int jj = i; jj < 6; ++jj) U[UI::at(i, jj)] += kg * g6[jj];
+            for (int jj = i; jj < 6; ++jj) U[UI::at(i, jj)] += b6[B6::at(i, jj)] + kg * g6[jj];
           }
           // joint columns (only the joints between the base and the sphere's link move the point); columns
           // of joints that do not move it are zero vectors, so the pair loop needs no second predicate
           V3 cj[JX];
           float gc[JX];
+          bool mv[JX];
 #pragma unroll
           for (int m = 0; m < JX; ++m) {
             const bool moves = m < NW ? (m < wd) : (m - NW < g);
+            mv[m] = moves;
             cj[m] = {0.f, 0.f, 0.f};
             gc[m] = 0.f;
             if (moves) {
@@ -583,7 +589,8 @@ struct EnvLane {
               U[UI::at(3, 6 + m)] += kt * cj[m].x + kg * g6[3]; U[UI::at(4, 6 + m)] += kt * cj[m].y + kg * g6[4]; U[UI::at(5, 6 + m)] += kt * cj[m].z + kg * g6[5];
               rv[6 + m] += fb * gc[m];
 #pragma unroll
-              for (int i = 0; i <= m; ++i) U[UI::at(6 + i, 6 + m)] += kt * dot(cj[i], cj[m]) + kg * gc[i];
+              for (int i = 0; i <= m; ++i)
+                if (NW == 0 || mv[i]) U[UI::at(6 + i, 6 + m)] += kt * dot(cj[i], cj[m]) + kg * gc[i];  // (adds of an exact 0 are LDS atomics on G1)
             }
           }
         }
