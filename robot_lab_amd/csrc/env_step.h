@@ -252,7 +252,7 @@ struct LsLayout {
 };
 template <class TP, int SUB>
 struct LsFor {  // lane scratchpad layout of an instance
-  static constexpr int STASH = (TP::NW == 0 && SUB > 1) ? TP::SPL : 0;
+  static constexpr int STASH = SUB > 1 ? TP::SPL : 0;
   using type = LsLayout<TP::NBS, STASH>;
 };
 
