@@ -239,7 +239,7 @@ struct LsMat {
 template <class TP>
 struct LbLayout {
   enum { WORDS = TP::NW > 0 ? (TP::JX * 15 + SymIdx<TP::NB + TP::CL>::size + TP::NB + TP::CL) : 0,
-         AUX_WORDS = TP::NW > 0 ? TP::CL * 12 : 0 };  // streaming CRBA: momentum + bias force per link, in the obs staging rows
+         AUX_WORDS = TP::NW > 0 ? TP::CL * 22 : 0 };  // streaming CRBA: momentum, bias force, inertia per link, in the obs staging rows
 };
 
 // STASH > 0: room for the contacts of one link group (x, n, bias, d_n, d_t per sphere slot) so that the sensor
@@ -252,7 +252,7 @@ struct LsLayout {
 };
 template <class TP, int SUB>
 struct LsFor {  // lane scratchpad layout of an instance
-  static constexpr int STASH = SUB > 1 ? TP::SPL : 0;
+  static constexpr int STASH = (TP::NW == 0 && SUB > 1) ? TP::SPL : 0;  // (G1: the LDS goes to the per-link CRBA records instead)
   using type = LsLayout<TP::NBS, STASH>;
 };
 
@@ -729,9 +729,11 @@ struct EnvLane {
       // are idle during the substeps); the backward pass rebuilds the link inertia, carries ONE running
       // composite (inertia, force, momentum) and emits the joint's column.  The array form below keeps
       // 4 x CL spatial quantities live - fine for 3-4 joints, ~200 VGPRs of spills for 7.
-      LdsVec<LBS> W{ctx.aux_limb_scratch()};  // [CL][12]: h_j (6), f_j (6)
+      // W[j]: 22 limb-shared words per link: momentum h_j (6), bias force f_j (6), spatial inertia I_j (10)
+      constexpr int WL = 22;
+      LdsVec<LBS> W{ctx.aux_limb_scratch()};
       auto link_inertia = [&](int j) {
-        const int li = LY.LF_INERTIA + j * INERTIA_NF;
+        const uint32_t li = (uint32_t)(LY.LF_INERTIA + j * INERTIA_NF);
         const M3 Rj = C.R(j);
         const V3 cb = C.p(j) + mul(Rj, V3{LF(li + 1), LF(li + 2), LF(li + 3)});
         return make_si(LF(li), cb, rotate(Rj, S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
@@ -740,34 +742,61 @@ struct EnvLane {
         const V3 ax = C.ax(j);
         return SV{ax, cross(C.p(j), ax)};
       };
+      auto put_sv = [&](int o, const SV& v) { W[o] = v.a.x; W[o + 1] = v.a.y; W[o + 2] = v.a.z; W[o + 3] = v.l.x; W[o + 4] = v.l.y; W[o + 5] = v.l.z; };
+      auto get_sv = [&](int o) { return SV{{W[o], W[o + 1], W[o + 2]}, {W[o + 3], W[o + 4], W[o + 5]}}; };
+      auto heavy = [&](int j, const SV& Vj, const SV& aj) {  // link j: inertia, momentum, bias force -> W[j]
+        const SI Ij = link_inertia(j);
+        const SV h = apply(Ij, Vj);
+        const SV f = apply(Ij, aj) + crf(Vj, h);
+        const int o = j * WL;
+        put_sv(o, h);
+        put_sv(o + 6, f);
+        W[o + 12] = Ij.m; W[o + 13] = Ij.h.x; W[o + 14] = Ij.h.y; W[o + 15] = Ij.h.z;
+        W[o + 16] = Ij.I.xx; W[o + 17] = Ij.I.yy; W[o + 18] = Ij.I.zz; W[o + 19] = Ij.I.xy; W[o + 20] = Ij.I.xz; W[o + 21] = Ij.I.yz;
+      };
       {
         SV Vp = V0, ap = a0;
 #pragma unroll
         for (int i = 0; i < NW; ++i)
           if (L.attach == i + 1) { Vp = Vw[i]; ap = aw[i]; }
+        if constexpr (Ctx::LIMB_ATOMICS && SUB == 4) {
+          // the limb words are real shared LDS: all sub-lanes run the (cheap) velocity recursion and park V_j, a_j
+          // in W[j]; then sub-lane s does the heavy part of links s and s + 4 only and overwrites them with h, f, I
 #pragma unroll
-        for (int j = 0; j < CL; ++j) {
-          const SV vj = joint_axis(j) * qd[j];
-          const SV Vj = Vp + vj;
-          const SV aj = ap + crm(Vj, vj);
-          const SI Ij = link_inertia(j);
-          const SV h = apply(Ij, Vj);
-          const SV f = apply(Ij, aj) + crf(Vj, h);
-          const int o = j * 12;
-          W[o + 0] = h.a.x; W[o + 1] = h.a.y; W[o + 2] = h.a.z; W[o + 3] = h.l.x; W[o + 4] = h.l.y; W[o + 5] = h.l.z;
-          W[o + 6] = f.a.x; W[o + 7] = f.a.y; W[o + 8] = f.a.z; W[o + 9] = f.l.x; W[o + 10] = f.l.y; W[o + 11] = f.l.z;
-          Vp = Vj;
-          ap = aj;
+          for (int j = 0; j < CL; ++j) {
+            const SV vj = joint_axis(j) * qd[j];
+            const SV Vj = Vp + vj;
+            const SV aj = ap + crm(Vj, vj);
+            put_sv(j * WL, Vj);
+            put_sv(j * WL + 6, aj);
+            Vp = Vj;
+            ap = aj;
+          }
+#pragma unroll
+          for (int t = 0; t < (CL + 3) / 4; ++t) {
+            const int j = sub + 4 * t;  // per-lane link index: LDS / HBM addressing only, no register arrays
+            if (j < CL) heavy(j, get_sv(j * WL), get_sv(j * WL + 6));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CL; ++j) {
+            const SV vj = joint_axis(j) * qd[j];
+            const SV Vj = Vp + vj;
+            const SV aj = ap + crm(Vj, vj);
+            heavy(j, Vj, aj);
+            Vp = Vj;
+            ap = aj;
+          }
         }
       }
       SI Ic{0.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
       SV Fc{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, Hc = Fc;
 #pragma unroll
       for (int j = CL - 1; j >= 0; --j) {
-        const int o = j * 12;
-        Ic = Ic + link_inertia(j);
-        Hc = Hc + SV{{W[o + 0], W[o + 1], W[o + 2]}, {W[o + 3], W[o + 4], W[o + 5]}};
-        Fc = Fc + SV{{W[o + 6], W[o + 7], W[o + 8]}, {W[o + 9], W[o + 10], W[o + 11]}};
+        const int o = j * WL;
+        Ic = Ic + SI{W[o + 12], {W[o + 13], W[o + 14], W[o + 15]}, {W[o + 16], W[o + 17], W[o + 18], W[o + 19], W[o + 20], W[o + 21]}};
+        Hc = Hc + get_sv(o);
+        Fc = Fc + get_sv(o + 6);
         const SV Sjj = joint_axis(j);
         const SV B = apply(Ic, Sjj);
         U[UI::at(0, NB + j)] += B.a.x; U[UI::at(1, NB + j)] += B.a.y; U[UI::at(2, NB + j)] += B.a.z;

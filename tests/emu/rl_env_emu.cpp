@@ -45,7 +45,7 @@ struct HostCtx {
   float* lane_scratch() { return scratch; }
   float lb[rl::LbLayout<rl::TopoG1>::WORDS + 1];
   float* limb_scratch() { return lb; }
-  float aux[rl::MAX_CL * 12];
+  float aux[rl::MAX_CL * 22];
   float* aux_limb_scratch() { return aux; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
