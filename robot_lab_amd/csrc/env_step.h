@@ -1,10 +1,11 @@
 // env_step.h - the env-step lane program: ONE function that advances an environment by one
-// `ManagerBasedRLEnv.step()` (stages 1-9), written for one lane of a 4-lane group.
+// `ManagerBasedRLEnv.step()` (stages 1-9), written for one lane of the 4 x SUB lanes that
+// simulate an environment (SUB sub-lanes per limb: 4 on the GPU by default, 1 in the older mapping).
 //
 // It is compiled twice from this single source:
 //   * by hipcc for gfx950 (rl_env.hip): Ctx = wavefront context, group ops are DPP/ds_swizzle
 //     shuffles, tables live in LDS;
-//   * by g++ for the CPU lane emulator (tests/emu): Ctx = 4 host threads + a barrier.  That build is
+//   * by g++ for the CPU lane emulator (tests/emu): Ctx = 4 x SUB host threads + a barrier.  That build is
 //     test infrastructure for `-m "not gpu"` CI only and is never loaded by the product path.
 //
 // Physics (DESIGN.md "Simulator"): floating-base articulation = a trunk (base + NW serial joints, G1:

@@ -53,7 +53,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   using Base::act; using Base::prev_act; using Base::tim; using Base::cf; using Base::hist_n; using Base::tau_app; using Base::qacc;
   using Base::extF; using Base::extT; using Base::base_com; using Base::wr_com;
 
-  // command / bookkeeping registers (identical in the 4 lanes of a group)
+  // command / bookkeeping registers (identical in all lanes of an env)
   V3 cmd;
   float heading_target, cmd_time_left, metric_xy, metric_yaw, push_left;
   bool is_heading, is_standing;
@@ -124,7 +124,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     is_standing = is;
   }
 
-  // ---------------------------------------------------------------- reset of one env (all 4 lanes) [UPSTREAM B1]
+  // ---------------------------------------------------------------- reset of one env (all its lanes) [UPSTREAM B1]
   RL_FN void reset_env(bool log_episode) {
     // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671)
     if (T.curriculum && !T.is_plane) {

@@ -1,12 +1,13 @@
 // rl_env.hip - gfx950 (MI355X, CDNA4) build of the env-step lane program + the C-ABI of include/rl_env.h.
 //
-// Launch geometry: one 64-lane wavefront per workgroup = 16 environments x 4 lanes; Npad/16 workgroups
-// (4096 envs -> 256 workgroups -> one wavefront on every one of the 256 CUs, dealt round-robin over the
-// 8 XCDs by the dispatcher).  The path has no dense contraction -> no MFMA; it is latency bound at this
-// size, so a wavefront gets a whole CU's register file (no occupancy pressure) and
-// every cross-lane reduction is a DPP quad_perm move (4-lane groups are exactly DPP quads - no LDS
-// round trip).  The model / term tables are staged once per workgroup into LDS; observation rows are
-// staged in LDS and written back as one linear, 16-byte-vectorised burst per wavefront.
+// Launch geometry: one 64-lane wavefront per workgroup = 4 environments x 16 lanes (a DPP row per env, a DPP
+// quad per limb); Npad/4 workgroups (4096 envs -> 1024 workgroups -> one wavefront on every SIMD of the 256
+// CUs, dealt round-robin over the 8 XCDs by the dispatcher; RL_ENV_SUB=1 selects the older 16 envs x 4 lanes
+// mapping).  The path has no dense contraction -> no MFMA; it is latency bound at this size,
+// so a wavefront gets a SIMD's whole register file and every cross-lane reduction is a DPP move (quad_perm
+// inside a limb, row mirrors across limbs - no LDS round trip).  The packed model / term tables are staged
+// once per workgroup into LDS; observation rows are staged in LDS and written back as one linear,
+// 16-byte-vectorised burst per wavefront.  DESIGN.md section 3 has the LDS budget (4 workgroups x <= 40 KB per CU).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -1,8 +1,8 @@
 // rl_env_emu.cpp - CPU lane emulator of the env-step lane program.  TEST INFRASTRUCTURE ONLY.
 //
 // Runs the *same* source (robot_lab_amd/csrc/env_step.h, env_terms.h) that hipcc compiles for gfx950,
-// with the 4 lanes of an environment group played by 4 host threads and the wavefront shuffles by a
-// shared slot + spin barrier.  It lets the `-m "not gpu"` tests check the lane program against the fp64
+// with the 4 x SUB lanes of an environment played by host threads and the wavefront shuffles by a shared
+// slot + pthread barrier ("limb-shared" LDS words are per-thread copies: see Ctx::LIMB_ATOMICS).  It lets the `-m "not gpu"` tests check the lane program against the fp64
 // oracle without a GPU.  The product path (robot_lab_amd.env) never loads this library: it requires
 // librl_env_hip.so and fails loudly without it.
 #include <pthread.h>
