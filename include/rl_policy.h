@@ -1,0 +1,48 @@
+/* rl_policy.h - C-ABI of the fused policy / value MLP inference kernel (the
+ * component next to the env in the rollout loop).
+ *
+ * Replaces (reference call sites; the arithmetic itself lives in the third-party rsl_rl `ActorCritic`):
+ *   - `policy = runner.get_inference_policy(device=...)`; `actions = policy(obs)`
+ *        scripts/reinforcement_learning/rsl_rl/play.py:207,246
+ *   - the actor / critic forward inside `runner.learn()` rollouts, scripts/reinforcement_learning/rsl_rl/train.py:206-224
+ *   - network shape: `RslRlPpoActorCriticCfg(actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128],
+ *        activation="elu")`, .../unitree_a1/agents/rsl_rl_ppo_cfg.py:15-22  (A1: 45 -> 512 -> 256 -> 128 -> 12 and
+ *        235 -> 512 -> 256 -> 128 -> 1; the last layer is linear)
+ *
+ * y = W_L act(... act(W_1 x + b_1) ...) + b_L in fp32 (exact-f32 MFMA, v_mfma_f32_16x16x4_f32), one kernel launch
+ * for the whole network.  All pointers passed to rl_mlp_forward are DEVICE pointers; weights are given once, on the
+ * host, in the torch.nn.Linear layout ([out_features][in_features] row-major).  Only inference is provided
+ * (no autograd, no rollout storage / GAE - out of scope this round). */
+#ifndef RL_POLICY_H
+#define RL_POLICY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RL_MLP_MAX_LAYERS 8
+#define RL_MLP_MAX_WIDTH 512 /* widest layer input / output */
+
+enum rl_mlp_activation { RL_ACT_ELU = 0, RL_ACT_RELU = 1, RL_ACT_TANH = 2 };
+
+typedef struct rl_mlp rl_mlp;
+
+/* dims[0] = input width, dims[1..n_layers] = layer output widths (n_layers Linear layers; the activation follows
+ * every layer but the last).  weights[l] / biases[l]: HOST pointers, nn.Linear layout [dims[l+1]][dims[l]] / [dims[l+1]]. */
+int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, const float* const* weights,
+                  const float* const* biases, int32_t device, rl_mlp** out);
+
+/* y[n_rows][dims[n_layers]] = MLP(x[n_rows][dims[0]]); x, y: device pointers, row-major; stream-ordered. */
+int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream);
+
+int32_t rl_mlp_in_dim(const rl_mlp* m);
+int32_t rl_mlp_out_dim(const rl_mlp* m);
+int rl_mlp_destroy(rl_mlp* m);
+const char* rl_mlp_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

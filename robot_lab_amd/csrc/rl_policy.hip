@@ -1,0 +1,210 @@
+// rl_policy.hip - fused MLP inference for gfx950 (MI355X): the actor / critic networks of the reference's PPO
+// configs (.../unitree_a1/agents/rsl_rl_ppo_cfg.py:15-22: 45 -> 512 -> 256 -> 128 -> 12, ELU) evaluated in ONE
+// kernel launch.  C-ABI: include/rl_policy.h.
+//
+// Mapping: a workgroup (4 wavefronts) owns a tile of 16 rows (environments): 4096 envs -> 256 workgroups -> one
+// per CU.  Activations never leave the CU: the 16 x K tile of a layer's input sits in LDS, the layer's output is
+// written to the other LDS buffer.  The contraction runs on the matrix cores in exact fp32
+// (v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] B[4x16]; result = a k-ordered fmaf chain, so parity with an fp32
+// reference is round-off only).  Wavefront w accumulates the 16-column output tiles w, w + 4, ... (up to 8
+// independent accumulators -> the 40-cycle dependent MFMA latency is hidden).  Both operands are kept in
+// FRAGMENT-MAJOR order, so a 16-deep k block costs a lane ONE ds_read_b128 (A: its four k-steps, conflict-free) and
+// one global_load_dwordx4 per output tile (B: the host pre-arranges the weights as [k block][tile][lane][4 k-steps],
+// 1 KB contiguous per wavefront load, L2-resident: the whole actor is 0.75 MB) for 4 MFMAs per tile.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rl_policy.h"
+
+namespace {
+
+constexpr int MT = 16;                              // rows per workgroup
+constexpr int KMAX = RL_MLP_MAX_WIDTH;              // widest layer
+constexpr int MAX_TPW = RL_MLP_MAX_WIDTH / 16 / 4;  // output tiles per wavefront
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpParams {
+  int n_layers, act;
+  int in_dim, out_dim;
+  int KB[RL_MLP_MAX_LAYERS];   // 16-deep k blocks of the layer's input (input width padded to 16)
+  int N[RL_MLP_MAX_LAYERS];    // true output width
+  int TPW[RL_MLP_MAX_LAYERS];  // output tiles per wavefront (output width padded to 64 columns = 4 wavefronts x 16)
+  const float* W[RL_MLP_MAX_LAYERS];  // fragment-major weight image [KB][4 * TPW tiles][64 lanes][4 k-steps]
+  const float* b[RL_MLP_MAX_LAYERS];  // [64 * TPW]
+};
+
+__device__ inline float activate(float v, int act) {
+  switch (act) {
+    case RL_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case RL_ACT_RELU: return fmaxf(v, 0.f);
+    default: return tanhf(v);
+  }
+}
+
+// LDS activation tile, "fragment-major": element (row, k) of the 16 x K tile sits where the A operand of
+// v_mfma_f32_16x16x4_f32 wants it - lane (row = lane & 15, ak = lane >> 4) reads the four k-steps of a 16-deep k
+// block (k = 16 kb + 4 s + ak, s = 0..3) as ONE aligned ds_read_b128, and consecutive lanes read consecutive
+// 16-byte slots (conflict-free).
+__device__ inline int lds_index(int row, int k) { return ((((k >> 4) * 4 + (k & 3)) * 16 + row) << 2) + ((k >> 2) & 3); }  // [kb][ak][row][s]
+
+template <int TPW>
+__device__ inline void layer(const MlpParams& P, int l, const float* __restrict__ xin, float* __restrict__ xout, float* __restrict__ y, int row0,
+                             int n_rows, int lane, int wave) {
+  const int KB = P.KB[l];
+  constexpr int NT = 4 * TPW;
+  const bool last = l == P.n_layers - 1;
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;                                    // + kb * 64
+  const f32x4* wb = reinterpret_cast<const f32x4*>(P.W[l]) + (size_t)wave * 64 + lane;            // + (kb * NT + 4 t) * 64
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    const f32x4 a = xa[kb * 64];
+    f32x4 b[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) b[t] = wb[((size_t)kb * NT + 4 * t) * 64];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+  }
+  // epilogue: D[row = (lane >> 4) * 4 + reg][col = lane & 15] -> bias, activation -> next LDS tile / global
+  const int col = lane & 15, rbase = (lane >> 4) * 4;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int n = (wave + 4 * t) * 16 + col;
+    const float bias = P.b[l][n];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc[t][r] + bias;
+      if (!last) {
+        xout[lds_index(rbase + r, n)] = n < P.N[l] ? activate(v, P.act) : 0.f;  // padded columns feed zeros into the next layer
+      } else if (n < P.N[l] && row0 + rbase + r < n_rows) {
+        y[(size_t)(row0 + rbase + r) * P.out_dim + n] = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpParams P, const float* __restrict__ x, float* __restrict__ y, int n_rows) {
+  extern __shared__ float4 smem4[];  // two [16 x KMAX] fragment-major activation tiles: 64 KB
+  float* buf0 = reinterpret_cast<float*>(smem4);
+  float* buf1 = buf0 + MT * KMAX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * MT;
+  const int K0 = P.KB[0] * 16;
+  for (int i = tid; i < MT * K0; i += 256) {  // input tile -> LDS (zero fill of the k padding and of rows past the end)
+    const int r = i / K0, c = i - r * K0;
+    buf0[lds_index(r, c)] = (row0 + r < n_rows && c < P.in_dim) ? x[(size_t)(row0 + r) * P.in_dim + c] : 0.f;
+  }
+  __syncthreads();
+  float *cur = buf0, *nxt = buf1;
+  for (int l = 0; l < P.n_layers; ++l) {
+    switch (P.TPW[l]) {
+      case 1: layer<1>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      case 2: layer<2>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      case 3: layer<3>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      case 4: layer<4>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      case 5: layer<5>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      case 6: layer<6>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      case 7: layer<7>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      default: layer<8>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+    }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+}
+
+std::string& err() {
+  static thread_local std::string e;
+  return e;
+}
+int fail(const std::string& m) {
+  err() = m;
+  return -1;
+}
+
+}  // namespace
+
+struct rl_mlp {
+  MlpParams P;
+  std::vector<void*> allocs;
+};
+
+extern "C" {
+
+int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, const float* const* weights, const float* const* biases,
+                  int32_t device, rl_mlp** out) {
+  if (!dims || !weights || !biases || !out) return fail("null argument");
+  if (n_layers < 1 || n_layers > RL_MLP_MAX_LAYERS) return fail("unsupported layer count");
+  for (int l = 0; l <= n_layers; ++l)
+    if (dims[l] < 1 || dims[l] > RL_MLP_MAX_WIDTH) return fail("layer width out of range (1.." + std::to_string(RL_MLP_MAX_WIDTH) + ")");
+  if (activation < RL_ACT_ELU || activation > RL_ACT_TANH) return fail("unknown activation");
+  if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
+  rl_mlp* m = new rl_mlp();
+  memset(&m->P, 0, sizeof(m->P));
+  m->P.n_layers = n_layers; m->P.act = activation; m->P.in_dim = dims[0]; m->P.out_dim = dims[n_layers];
+  for (int l = 0; l < n_layers; ++l) {
+    const int K = dims[l], N = dims[l + 1];
+    // layer l contracts over the 16-padded width of its input; its output is padded to 64 columns (4 wavefronts x 16).
+    // For l > 0 the input's padding columns were written as zeros by layer l-1 (64-padded >= 16-padded).
+    const int KB = (K + 15) / 16, TPW = (N + 63) / 64, NT = 4 * TPW;
+    m->P.KB[l] = KB; m->P.N[l] = N; m->P.TPW[l] = TPW;
+    std::vector<float> Wf((size_t)KB * NT * 64 * 4, 0.f), bp((size_t)NT * 16, 0.f);
+    for (int n = 0; n < N; ++n) bp[n] = biases[l][n];
+    for (int kb = 0; kb < KB; ++kb)
+      for (int t = 0; t < NT; ++t)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int sI = 0; sI < 4; ++sI) {
+            const int k = kb * 16 + 4 * sI + (ln >> 4), n = t * 16 + (ln & 15);  // B[k][n] = W[n][k] (nn.Linear: [out][in])
+            if (k < K && n < N) Wf[(((size_t)kb * NT + t) * 64 + ln) * 4 + sI] = weights[l][(size_t)n * K + k];
+          }
+    void *dW = nullptr, *db = nullptr;
+    if (hipMalloc(&dW, Wf.size() * 4) != hipSuccess || hipMalloc(&db, bp.size() * 4) != hipSuccess) {
+      rl_mlp_destroy(m);
+      return fail("device allocation failed");
+    }
+    m->allocs.push_back(dW); m->allocs.push_back(db);
+    (void)hipMemcpy(dW, Wf.data(), Wf.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+    m->P.W[l] = (const float*)dW; m->P.b[l] = (const float*)db;
+  }
+  *out = m;
+  return 0;
+}
+
+int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream) {
+  if (!m || !x_dev || !y_dev) return fail("null argument");
+  if (n_rows <= 0) return 0;
+  constexpr size_t lds = sizeof(float) * 2 * MT * KMAX;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail("cannot reserve 64 KB of LDS");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((n_rows + MT - 1) / MT), dim3(256), lds, (hipStream_t)stream, m->P, x_dev, y_dev, n_rows);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
+}
+
+int32_t rl_mlp_in_dim(const rl_mlp* m) { return m ? m->P.in_dim : 0; }
+int32_t rl_mlp_out_dim(const rl_mlp* m) { return m ? m->P.out_dim : 0; }
+
+int rl_mlp_destroy(rl_mlp* m) {
+  if (!m) return 0;
+  for (void* p : m->allocs) (void)hipFree(p);
+  delete m;
+  return 0;
+}
+
+const char* rl_mlp_last_error(void) { return err().c_str(); }
+
+}  // extern "C"
