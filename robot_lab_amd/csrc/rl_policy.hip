@@ -64,16 +64,34 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
   for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;                                    // + kb * 64
   const f32x4* wb = reinterpret_cast<const f32x4*>(P.W[l]) + (size_t)wave * 64 + lane;            // + (kb * NT + 4 t) * 64
-#pragma unroll 2
-  for (int kb = 0; kb < KB; ++kb) {
-    const f32x4 a = xa[kb * 64];
-    f32x4 b[TPW];
+  // software pipeline, two k blocks deep: the operands of blocks kb + 1 and kb + 2 are in flight while block kb's 4 x TPW
+  // MFMAs issue (an L2 hit is ~600-800 cycles, a block's MFMAs are 128 x TPW cycles)
+  auto load_b = [&](int kb, f32x4 (&b)[TPW]) {
+    const int kc = kb < KB ? kb : KB - 1;  // clamped: the tail re-reads the last block instead of branching
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) b[t] = wb[((size_t)kb * NT + 4 * t) * 64];
+    for (int t = 0; t < TPW; ++t) b[t] = wb[((size_t)kc * NT + 4 * t) * 64];
+  };
+  f32x4 b0[TPW], b1[TPW], b2[TPW];
+  load_b(0, b0);
+  load_b(1, b1);
+  auto mma = [&](const f32x4& a, const f32x4 (&b)[TPW]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+  };
+  int kb = 0;
+  for (; kb + 3 <= KB; kb += 3) {  // rotate the three buffers by unrolling three blocks
+    load_b(kb + 2, b2);
+    mma(xa[kb * 64], b0);
+    load_b(kb + 3, b0);
+    mma(xa[(kb + 1) * 64], b1);
+    load_b(kb + 4, b1);
+    mma(xa[(kb + 2) * 64], b2);
+  }
+  if (kb < KB) {
+    mma(xa[kb * 64], b0);
+    if (kb + 1 < KB) mma(xa[(kb + 1) * 64], b1);
   }
   // epilogue: D[row = (lane >> 4) * 4 + reg][col = lane & 15] -> bias, activation -> next LDS tile / global
   const int col = lane & 15, rbase = (lane >> 4) * 4;
