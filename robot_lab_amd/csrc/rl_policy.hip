@@ -41,7 +41,7 @@ struct MlpParams {
 
 __device__ inline float activate(float v, int act) {
   switch (act) {
-    case RL_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case RL_ACT_ELU: return v > 0.f ? v : __expf(v) - 1.0f;  // |abs error| ~1e-7: inside the fp32 round-off of the layer
     case RL_ACT_RELU: return fmaxf(v, 0.f);
     default: return tanhf(v);
   }
@@ -95,16 +95,19 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
   }
   // epilogue: D[row = (lane >> 4) * 4 + reg][col = lane & 15] -> bias, activation -> next LDS tile / global
   const int col = lane & 15, rbase = (lane >> 4) * 4;
+  // lds_index(rbase + r, (wave + 4 t) * 16 + col) = lane-constant + 1024 t + 4 r
+  const int obase = wave * 256 + (col & 3) * 64 + rbase * 4 + ((col >> 2) & 3);
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int n = (wave + 4 * t) * 16 + col;
     const float bias = P.b[l][n];
+    const bool valid = n < P.N[l];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = acc[t][r] + bias;
       if (!last) {
-        xout[lds_index(rbase + r, n)] = n < P.N[l] ? activate(v, P.act) : 0.f;  // padded columns feed zeros into the next layer
-      } else if (n < P.N[l] && row0 + rbase + r < n_rows) {
+        xout[obase + 1024 * t + 4 * r] = valid ? activate(v, P.act) : 0.f;  // padded columns feed zeros into the next layer
+      } else if (valid && row0 + rbase + r < n_rows) {
         y[(size_t)(row0 + rbase + r) * P.out_dim + n] = v;
       }
     }
