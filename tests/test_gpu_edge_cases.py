@@ -42,14 +42,15 @@ def test_ragged_env_counts(N):
     env.close()
 
 
-def test_partial_reset_by_env_ids():
+@pytest.mark.parametrize("task", [TASK, "RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0"])
+def test_partial_reset_by_env_ids(task):
     N = 32
-    env, ora, torch = _pair(N, 9)
+    env, ora, torch = _pair(N, 9, task)
     env.reset()
     ora.reset()
     rng = np.random.default_rng(0)
     for _ in range(2):
-        a = rng.uniform(-1, 1, (N, 12)).astype(np.float32)
+        a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
         env.step(torch.from_numpy(a).cuda())
         ora.step(a)
     ids = [3, 4, 17, 31]
@@ -59,7 +60,8 @@ def test_partial_reset_by_env_ids():
     after = env.scene["robot"].data.root_state_w
     keep = np.setdiff1d(np.arange(N), ids)
     assert torch.equal(before[keep], after[keep])                       # untouched envs keep their state bit-for-bit
-    assert_close("root", after.cpu().numpy(), oracle_root_state(ora), 1e-4, 1e-5)
+    tol = (1e-4, 1e-5) if task == TASK else (2e-3, 2e-4)  # the untouched envs carry two steps of fp32 drift (29 DoF on G1)
+    assert_close("root", after.cpu().numpy(), oracle_root_state(ora), *tol)
     assert_close("critic", obs["critic"].cpu().numpy(), o[1], 2e-3, 2e-3)
     assert np.array_equal(env.episode_length_buf.cpu().numpy(), ora.episode_length_buf)
     with pytest.raises(Exception):
