@@ -115,8 +115,9 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     value = world * N * args.steps / elapsed
-    robot = args.task.split("-Unitree-")[1].split("-")[0]
-    algo_bytes = (ALGO_BYTES_PER_ENV_STEP[robot] - (2 * 187 * 4 if "Flat" in args.task else 0)) * N
+    robot = args.task.replace("RobotLab-Isaac-Velocity-", "").replace("-v0", "").split("-", 1)[1].replace("Unitree-", "")
+    per_step = ALGO_BYTES_PER_ENV_STEP.get(robot, ALGO_BYTES_PER_ENV_STEP["Go2W" if A == 16 else "A1"])  # other quadrupeds: as their Unitree twin
+    algo_bytes = (per_step - (2 * 187 * 4 if "Flat" in args.task else 0)) * N
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     out = {
         "metric": f"env-steps/sec (whole node) at {N} envs/GPU, {robot} Velocity-{'Flat' if 'Flat' in args.task else 'Rough'}",

@@ -13,7 +13,7 @@ import re
 import numpy as np
 
 from ..desc import EnvDesc, OBS, REW, RL_MAX_BODIES, RL_MAX_DOF, RL_MAX_LINKS, RL_MAX_SPHERES, mask_of, set_arr
-from .urdf import RobotModel
+from .urdf import RobotModel, cap_spheres
 
 
 def find_names(patterns, names, preserve_order=False):
@@ -74,12 +74,12 @@ DEFAULT_SIM = dict(
 def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
     d = EnvDesc()
     m = d.model
-    L, D, B, G = len(model.links), len(model.links) - 1, len(model.bodies), len(model.spheres)
-    if L > RL_MAX_LINKS or D > RL_MAX_DOF or B > RL_MAX_BODIES or G > RL_MAX_SPHERES:
+    L, D, B = len(model.links), len(model.links) - 1, len(model.bodies)
+    if L > RL_MAX_LINKS or D > RL_MAX_DOF or B > RL_MAX_BODIES:
         raise ValueError("model exceeds descriptor capacity")
     jn, bn = model.joint_names, model.body_names
     d.joint_names, d.body_names = list(jn), list(bn)
-    m.num_links, m.num_dof, m.num_bodies, m.num_spheres = L, D, B, G
+    m.num_links, m.num_dof, m.num_bodies = L, D, B
     # topology: serial limb chains hanging off the base or off the end of a serial trunk chain (the lane
     # program simulates one limb per lane group).  Chains are discovered by following the links, so the
     # task's joint order need not be chain-major (Go2W lists the 12 leg joints first and the 4 wheel
@@ -120,6 +120,13 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
                 m.chain_link[k][j] = l
         for i, l in enumerate(trunk):
             m.trunk_link[i] = l
+    # collision-sphere budget of the lane-program instance that will simulate this topology
+    if ok:
+        cap_spheres(model, [0] + list(trunk), per_link=4 if trunk else 3)
+    G = len(model.spheres)
+    if G > RL_MAX_SPHERES:
+        raise ValueError("model exceeds descriptor capacity (collision spheres)")
+    m.num_spheres = G
     for i, l in enumerate(model.links):
         m.link_parent[i] = l.parent
         set_arr(m.link_origin[i], l.origin)

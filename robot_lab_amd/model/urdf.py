@@ -319,6 +319,30 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
     return model
 
 
+def cap_spheres(model: RobotModel, trunk_links, per_link: int, per_trunk_body: int = 8):
+    """The lane program budgets `per_link` collision spheres per limb link (3 on the quadruped instances, 4 on G1)
+    and up to `per_trunk_body` per body of a trunk link (spread over the lanes).  Links that still exceed it after
+    thinning (Unitree B2 trunk, ZSL1 calves) keep a farthest-point subset: the largest sphere first, then
+    repeatedly the one farthest from those kept.  Called by `build_desc` once the topology is known."""
+    trunk_links = set(trunk_links)
+    groups: dict[tuple[int, int], list[int]] = {}
+    for i, sph in enumerate(model.spheres):
+        link = model.bodies[sph.body].link
+        groups.setdefault((link, sph.body if link in trunk_links else -1), []).append(i)
+    keep = set()
+    for (link, _), ids in groups.items():
+        budget = per_trunk_body if link in trunk_links else per_link
+        if len(ids) <= budget:
+            keep.update(ids)
+            continue
+        kept = [max(ids, key=lambda i: model.spheres[i].radius)]
+        while len(kept) < budget:
+            rest = [i for i in ids if i not in kept]
+            kept.append(max(rest, key=lambda i: min(np.linalg.norm(model.spheres[i].center - model.spheres[k].center) for k in kept)))
+        keep.update(kept)
+    model.spheres = [sph for i, sph in enumerate(model.spheres) if i in keep]
+
+
 def _thin_spheres(model: RobotModel, min_sep: float = 0.07):
     """Several URDFs tile a slender link with many overlapping primitives (Go2 calf: three cylinders,
     `go2_description.urdf:149-185`).  Per link, keep spheres greedily by descending radius and drop any

@@ -12,6 +12,12 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0",
     "RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0",
     "RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0",
+    # more quadrupeds of the reference, supported as data
+    "RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0",
+    "RobotLab-Isaac-Velocity-Rough-Deeprobotics-Lite3-v0",
+    "RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0",
+    "RobotLab-Isaac-Velocity-Rough-Zsibot-ZSL1-v0",
+    "RobotLab-Isaac-Velocity-Flat-Zsibot-ZSL1W-v0",
 ]
 
 

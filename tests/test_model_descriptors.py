@@ -46,11 +46,18 @@ def test_a1_census():
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", (57, 247), 19, 19.523),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", (96, 286), 33, 33.341),
     ("RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0", (96, 99), 33, 33.341),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0", (45, 235), 17, None),
+    ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-Lite3-v0", (45, 235), 17, None),
+    ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", (57, 247), 17, None),
+    ("RobotLab-Isaac-Velocity-Rough-Zsibot-ZSL1-v0", (45, 235), 17, None),
+    ("RobotLab-Isaac-Velocity-Flat-Zsibot-ZSL1W-v0", (57, 60), 17, None),
 ])
 def test_other_bundles(task, dims, bodies, mass):
     d, _ = load_bundle(task)
     assert (d.obs_dim(0), d.obs_dim(1)) == dims and d.model.num_bodies == bodies
-    assert abs(float(arr(d.model.body_mass, bodies).sum()) - mass) < 2e-3
+    if mass is not None:
+        assert abs(float(arr(d.model.body_mass, bodies).sum()) - mass) < 2e-3
+    assert d.model.num_chains == 4 and d.model.chain_len in (3, 4, 7)
 
 
 def test_g1_census():

@@ -17,8 +17,11 @@ from isaaclab_tasks.utils import parse_env_cfg  # noqa: E402
 from robot_lab_amd.model.cfg_compile import UnsupportedTerm, compile_cfg  # noqa: E402
 from robot_lab_amd.scene import DATA_DIR, save_bundle  # noqa: E402
 
-TASKS = sys.argv[1:] or [
-    f"RobotLab-Isaac-Velocity-{t}-Unitree-{r}-v0" for r in ("A1", "Go2", "Go2W", "G1") for t in ("Flat", "Rough")]
+# the BASELINE.json robots + the other quadrupeds of the reference whose cfg compiles to the same lane-program
+# instances as data: 3-joint legs -> Topo<3,0,3,6>, wheeled 4-joint legs -> Topo<4,0,3,6>
+ROBOTS = ("Unitree-A1", "Unitree-Go2", "Unitree-Go2W", "Unitree-G1", "Unitree-B2", "Deeprobotics-Lite3", "Deeprobotics-M20",
+          "Zsibot-ZSL1", "Zsibot-ZSL1W")
+TASKS = sys.argv[1:] or [f"RobotLab-Isaac-Velocity-{t}-{r}-v0" for r in ROBOTS for t in ("Flat", "Rough")]
 os.makedirs(DATA_DIR, exist_ok=True)
 for task in TASKS:
     try:
