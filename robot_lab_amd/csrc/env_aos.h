@@ -21,7 +21,7 @@ RL_FN void export_env(const KState& S, const Tables& T, const AosPtrs& A, int e)
       A.joint_vel[e * T.D + L.joint_id[j]] = S.lane_state[lane_index(ly, e, k, ly.LF_QD + j, S.ept)];
       A.action[e * T.D + L.joint_id[j]] = S.lane_state[lane_index(ly, e, k, ly.LF_ACT + j, S.ept)];
     }
-    for (int i = 0; k == 0 && i < T.NW; ++i) {  // trunk joints live in the env record
+    for (int i = 0; k == 0 && i < T.nw_used; ++i) {  // trunk joints live in the env record
       const int jt = L.joint_id[T.CL + i];
       A.joint_pos[e * T.D + jt] = S.env_state[env_index(ly, e, ly.EF_TQ + i, S.ept)];
       A.joint_vel[e * T.D + jt] = S.env_state[env_index(ly, e, ly.EF_TQD + i, S.ept)];
@@ -46,7 +46,7 @@ RL_FN void import_env(const KState& S, const Tables& T, const float* root_state,
       if (joint_pos) S.lane_state[lane_index(ly, e, k, ly.LF_Q + j, S.ept)] = joint_pos[e * T.D + L.joint_id[j]];
       if (joint_vel) S.lane_state[lane_index(ly, e, k, ly.LF_QD + j, S.ept)] = joint_vel[e * T.D + L.joint_id[j]];
     }
-    for (int i = 0; k == 0 && i < T.NW; ++i) {
+    for (int i = 0; k == 0 && i < T.nw_used; ++i) {
       const int jt = L.joint_id[T.CL + i];
       if (joint_pos) S.env_state[env_index(ly, e, ly.EF_TQ + i, S.ept)] = joint_pos[e * T.D + jt];
       if (joint_vel) S.env_state[env_index(ly, e, ly.EF_TQD + i, S.ept)] = joint_vel[e * T.D + jt];

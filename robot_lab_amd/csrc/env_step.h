@@ -843,7 +843,7 @@ struct EnvLane {
           float below = L.lower[jx] - q[jx], above = q[jx] - L.upper[jx];
           float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
           bool lim = (below > 0.f) || (above > 0.f);
-          U[UI::at(6 + i, 6 + i)] += arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+          U[UI::at(6 + i, 6 + i)] += arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f) + (i >= T.nw_used ? 1.0f : 0.f);  // padding trunk joint: identity row
           rv[6 + i] += arm * qd[jx] + dt * tau_e[jx] + pd_rhs[jx] + dt * u.limit_k * viol;
         }
       }
@@ -979,7 +979,7 @@ struct EnvLane {
         float below = L.lower[jx] - q[jx], above = q[jx] - L.upper[jx];
         float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
         bool lim = (below > 0.f) || (above > 0.f);
-        U[UI::at(6 + i, 6 + i)] += arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+        U[UI::at(6 + i, 6 + i)] += arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f) + (i >= T.nw_used ? 1.0f : 0.f);
         rv[6 + i] += arm * qd[jx] + dt * tau_e[jx] + pd_rhs[jx] + dt * u.limit_k * viol;
       }
     }

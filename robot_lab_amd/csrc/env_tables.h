@@ -96,6 +96,7 @@ struct ObsTab {
 
 struct TaskTab {  // everything that is not per limb
   int32_t CL, NW, SPL, NBS, D, n_bodies, n_base_bodies;
+  int32_t nw_used;      // trunk joints the model really has (<= NW; the rest are inert padding)
   uint32_t slot_valid;  // bit g*SPL+s: some lane has a collision sphere in slot (g, s)
   int32_t wrench_depth; // trunk link (0 = base, i = after i trunk joints) carrying the body the wrench / COM events address
   int32_t scan_depth;   // trunk link carrying the height-scanner body

@@ -50,9 +50,11 @@ inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& N
   if (m.num_chains != NLANE || m.chain_len < 1 || m.chain_len > MAX_CL || m.num_trunk < 0 || m.num_trunk > MAX_NW)
     return fail("lane program needs a trunk of <= 3 serial joints carrying 4 limb chains of <= 7 joints (got " + std::to_string(m.num_chains) + " chains x " +
                 std::to_string(m.chain_len) + ", trunk " + std::to_string(m.num_trunk) + ")");
-  if (m.num_trunk == 0 && m.chain_len <= 4) { CL = m.chain_len < 3 ? 3 : m.chain_len; NW = 0; SPL = 3; NBS = 6; }
+  bool equal = true;
+  for (int k = 1; k < NLANE; ++k) equal = equal && m.chain_nj[k] == m.chain_nj[0];
+  if (m.num_trunk == 0 && m.chain_len <= 4 && equal && m.chain_len >= 3) { CL = m.chain_len; NW = 0; SPL = 3; NBS = 6; }
   else { CL = 7; NW = 3; SPL = 4; NBS = 9; }
-  if (m.num_trunk != NW && m.num_trunk != 0) return fail("unsupported trunk length " + std::to_string(m.num_trunk));
+  // a shorter trunk (ATOM01: one waist joint) or none runs on the NW = 3 instance with inert padding trunk joints
   return 0;
 }
 
@@ -63,7 +65,7 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   int CL, NW, SPL, NBS;
   if (topo_shape(m, CL, NW, SPL, NBS)) return -1;
   const int NGRP = CL + 1;
-  T.CL = CL; T.NW = NW; T.SPL = SPL; T.NBS = NBS;
+  T.CL = CL; T.NW = NW; T.SPL = SPL; T.NBS = NBS; T.nw_used = m.num_trunk;
   T.D = m.num_dof;
   T.n_bodies = m.num_bodies;
   body_lane.assign(m.num_bodies, -1);
@@ -97,7 +99,7 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     for (int g = 0; g < MAX_NGRP; ++g)
       for (int s = 0; s < MAX_SPL; ++s) L.sph_r[g][s] = -1.f;
     L.base_body_local = -1;
-    L.nj = m.chain_nj[k] > 0 ? m.chain_nj[k] : m.chain_len;  // descriptors written before chain_nj existed: equal chains
+    L.nj = m.chain_nj[k];
     L.attach = m.chain_attach[k];
     L.grp0_depth = L.attach;  // a lane's link group 0 is a share of the trunk link its limb hangs off
     if (L.nj > CL || L.attach < 0 || L.attach > m.num_trunk) return fail("bad chain description");

@@ -105,10 +105,9 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
                 limbs.append((len(trunk), ch2) if not tail2 else (None, ch2))
         else:
             limbs.append((None, ch))
-    ok = (len(limbs) == 4 and all(a is not None for a, _ in limbs) and max(len(c) for _, c in limbs) <= 7 and len(trunk) <= 3
+    ok = (1 <= len(limbs) <= 4 and all(a is not None for a, _ in limbs) and max(len(c) for _, c in limbs) <= 7 and len(trunk) <= 3
           and sum(len(c) for _, c in limbs) + len(trunk) == D)
-    if ok and not trunk and len({len(c) for _, c in limbs}) != 1:
-        ok = False
+    # fewer than 4 limbs (bipeds without arms): the spare lane groups simulate empty chains
     m.num_chains, m.chain_len, m.num_trunk = (4, max(len(c) for _, c in limbs), len(trunk)) if ok else (0, 0, 0)
     for k in range(4):
         for j in range(8):
@@ -120,9 +119,12 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
                 m.chain_link[k][j] = l
         for i, l in enumerate(trunk):
             m.trunk_link[i] = l
+    # quadruped instances (Topo<3|4,0,3,6>) need 4 equal chains of <= 4 joints and no trunk; everything else that fits
+    # runs on the trunk + limbs instance (Topo<7,3,4,9>) with inert padding joints (rl_env_host.h: topo_shape)
+    quad = ok and not trunk and len(limbs) == 4 and len({len(c) for _, c in limbs}) == 1 and len(limbs[0][1]) <= 4
     # collision-sphere budget of the lane-program instance that will simulate this topology
     if ok:
-        cap_spheres(model, [0] + list(trunk), per_link=4 if trunk else 3)
+        cap_spheres(model, [0] + list(trunk), per_link=3 if quad else 4)
     G = len(model.spheres)
     if G > RL_MAX_SPHERES:
         raise ValueError("model exceeds descriptor capacity (collision spheres)")

@@ -132,6 +132,8 @@ def _mesh_to_spheres(verts: np.ndarray, scale: np.ndarray):
     """Capsule-like sphere row fitted to a vertex cloud: principal axis a (largest variance), half
     length h, radius r = 90th percentile of the distance from the axis (clamped to [1 cm, h]).
     h <= 1.5 r -> one sphere of radius max(r, h) at the centre; else 3 spheres at 0, +-(h - r) a."""
+    if verts.ndim != 2 or len(verts) < 4:  # not an STL file (.dae / .obj collision meshes are not parsed): no spheres
+        return []
     v = np.unique(np.round(verts * scale[None], 5), axis=0)
     if len(v) < 4:
         return []

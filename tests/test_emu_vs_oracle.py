@@ -18,12 +18,17 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0",
     "RobotLab-Isaac-Velocity-Rough-Zsibot-ZSL1-v0",
     "RobotLab-Isaac-Velocity-Flat-Zsibot-ZSL1W-v0",
+    # humanoids / bipeds on the G1 instance with padding (shorter trunk, fewer or shorter limbs)
+    "RobotLab-Isaac-Velocity-Flat-RoboParty-ATOM01-v0",
+    "RobotLab-Isaac-Velocity-Flat-RobotEra-Xbot-v0",
+    "RobotLab-Isaac-Velocity-Flat-MagicLab-Bot-Gen1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Openloong-Loong-v0",
 ]
 
 
 @pytest.mark.parametrize("task", TASKS)
 def test_lane_program_matches_oracle(task, emu_lib):
-    N = 8 if "G1" in task else 16  # G1: 29 DoF, the fp64 oracle is the slow side
+    N = 8 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong")) else 16  # big models: the fp64 oracle is the slow side
     desc, ora, nat = make_pair(task, N, 42, emu_lib)
     o = ora.reset()
     nat.reset()

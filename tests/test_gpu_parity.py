@@ -22,6 +22,10 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0",
     "RobotLab-Isaac-Velocity-Rough-Zsibot-ZSL1-v0",
     "RobotLab-Isaac-Velocity-Rough-Zsibot-ZSL1W-v0",
+    "RobotLab-Isaac-Velocity-Rough-RoboParty-ATOM01-v0",
+    "RobotLab-Isaac-Velocity-Rough-RobotEra-Xbot-v0",
+    "RobotLab-Isaac-Velocity-Rough-MagicLab-Bot-Gen1-v0",
+    "RobotLab-Isaac-Velocity-Flat-Openloong-Loong-v0",
 ]
 
 
@@ -38,7 +42,7 @@ def _pair(task, N, seed):
 
 @pytest.mark.parametrize("task", TASKS)
 def test_short_horizon_parity(task):
-    N = 32 if "G1" in task else 64
+    N = 32 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong")) else 64
     env, ora, torch = _pair(task, N, 11)
     obs, _ = env.reset()
     o = ora.reset()
@@ -49,7 +53,7 @@ def test_short_horizon_parity(task):
         a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
         obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
         o = ora.step(a)
-        assert_close(f"reward[{s}]", rew.cpu().numpy(), ora.reward, 1e-3, 2e-5, 0.98)
+        assert_close(f"reward[{s}]", rew.cpu().numpy(), ora.reward, 1e-3, 2e-5, 0.98 if N >= 64 else 0.96)  # N = 32: one contact-switch outlier allowed
         assert np.array_equal((term | tout).cpu().numpy(), ora.terminated | ora.time_outs)
     d = env.scene["robot"].data
     assert_close("root", d.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4, 0.98)

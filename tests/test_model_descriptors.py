@@ -51,6 +51,10 @@ def test_a1_census():
     ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", (57, 247), 17, None),
     ("RobotLab-Isaac-Velocity-Rough-Zsibot-ZSL1-v0", (45, 235), 17, None),
     ("RobotLab-Isaac-Velocity-Flat-Zsibot-ZSL1W-v0", (57, 60), 17, None),
+    ("RobotLab-Isaac-Velocity-Rough-RoboParty-ATOM01-v0", (78, 268), 24, None),
+    ("RobotLab-Isaac-Velocity-Rough-RobotEra-Xbot-v0", (93, 283), 29, None),
+    ("RobotLab-Isaac-Velocity-Flat-MagicLab-Bot-Gen1-v0", (51, 54), 15, None),
+    ("RobotLab-Isaac-Velocity-Rough-Openloong-Loong-v0", (45, 235), 13, None),
 ])
 def test_other_bundles(task, dims, bodies, mass):
     d, _ = load_bundle(task)

@@ -19,8 +19,11 @@ from robot_lab_amd.scene import DATA_DIR, save_bundle  # noqa: E402
 
 # the BASELINE.json robots + the other quadrupeds of the reference whose cfg compiles to the same lane-program
 # instances as data: 3-joint legs -> Topo<3,0,3,6>, wheeled 4-joint legs -> Topo<4,0,3,6>
+# humanoids / bipeds that fit "trunk of <= 3 joints + <= 4 limb chains of <= 7 joints" run on the G1 instance
+# (Topo<7,3,4,9>) with inert padding joints / empty limbs: ATOM01 (23 DoF, 1 waist joint), Xbot (28 DoF, legs hang off
+# a 2-joint trunk), MagicLab Bot-Gen1 (14 DoF), Openloong Loong (12-DoF biped, two empty limbs)
 ROBOTS = ("Unitree-A1", "Unitree-Go2", "Unitree-Go2W", "Unitree-G1", "Unitree-B2", "Deeprobotics-Lite3", "Deeprobotics-M20",
-          "Zsibot-ZSL1", "Zsibot-ZSL1W")
+          "Zsibot-ZSL1", "Zsibot-ZSL1W", "RoboParty-ATOM01", "RobotEra-Xbot", "MagicLab-Bot-Gen1", "Openloong-Loong")
 TASKS = sys.argv[1:] or [f"RobotLab-Isaac-Velocity-{t}-{r}-v0" for r in ROBOTS for t in ("Flat", "Rough")]
 os.makedirs(DATA_DIR, exist_ok=True)
 for task in TASKS:
