@@ -61,7 +61,7 @@ def test_other_bundles(task, dims, bodies, mass):
     assert (d.obs_dim(0), d.obs_dim(1)) == dims and d.model.num_bodies == bodies
     if mass is not None:
         assert abs(float(arr(d.model.body_mass, bodies).sum()) - mass) < 2e-3
-    assert d.model.num_chains == 4 and d.model.chain_len in (3, 4, 7)
+    assert d.model.num_chains == 4 and 3 <= d.model.chain_len <= 7
 
 
 def test_g1_census():
