@@ -66,6 +66,16 @@ enum rl_reward_kind {
   RL_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP = 28, /* rewards.py:51-66 ; p0 = std^2 (G1) */
   RL_REW_TRACK_ANG_VEL_Z_WORLD_EXP = 29,      /* rewards.py:69-78 ; p0 = std^2 (G1) */
   RL_REW_FEET_AIR_TIME_POSITIVE_BIPED = 30,   /* rewards.py:363-383 ; p0 threshold ; body mask (G1) */
+  RL_REW_HANDSTAND_FEET_HEIGHT_EXP = 31,      /* config/others/unitree_a1_handstand/env/rewards.py:18-28 ; p0 std^2 p1 target_height ; body mask */
+  RL_REW_HANDSTAND_FEET_ON_AIR = 32,          /* .../env/rewards.py:31-37 ; body mask */
+  RL_REW_HANDSTAND_FEET_AIR_TIME = 33,        /* .../env/rewards.py:40-47 ; p0 threshold ; body mask */
+  RL_REW_HANDSTAND_ORIENTATION_L2 = 34,       /* .../env/rewards.py:50-59 ; p0..p2 target gravity */
+  RL_REW_BASE_HEIGHT_L2 = 35,                 /* rewards.py:616-644 ; p0 target_height p1 = 1: target follows the mean hit height of the
+                                                 3 x 3 base ray caster (velocity_env_cfg.py:78-85), 0: world height */
+  RL_REW_WHEEL_VEL_PENALTY = 36,              /* rewards.py:132-153 ; p0 velocity_threshold p1 command_threshold ;
+                                                 pairs (idx_a = wheel body, idx_b = wheel joint), n_idx of them */
+  RL_REW_FEET_DISTANCE_Y_EXP = 37,            /* rewards.py:439-461 ; p0 std^2 p1 stance_width ; idx_a = feet in asset_cfg order */
+  RL_REW_FEET_DISTANCE_XY_EXP = 38,           /* rewards.py:464-505 ; p0 std^2 p1 stance_width p2 stance_length ; idx_a = the 4 feet */
   RL_REW_NUM_KINDS
 };
 

@@ -75,6 +75,14 @@ class Physics:
         self.L, self.D, self.B, self.G = m.num_links, m.num_dof, m.num_bodies, m.num_spheres
         L, D, B, G = self.L, self.D, self.B, self.G
         self.parent = arr(m.link_parent, L).astype(int)
+        # link index = 1 + task joint index, which need not be topological (MagicLab Z1 lists hip roll before the hip
+        # pitch it hangs from): walk the tree parents first
+        self.order, done = [], {0}
+        while len(self.order) < L - 1:
+            for i in range(1, L):
+                if i not in done and self.parent[i] in done:
+                    self.order.append(i)
+                    done.add(i)
         self.origin = arr(m.link_origin, L).astype(np.float64)
         self.axis = arr(m.link_axis, L).astype(np.float64)
         lq = arr(m.link_quat, L).astype(np.float64)
@@ -130,7 +138,7 @@ class Physics:
         X = np.zeros((N, L, 6, 6))
         Rw[:, 0] = sp.quat_to_mat(root_quat)
         ow[:, 0] = root_pos
-        for i in range(1, L):
+        for i in self.order:
             p = self.parent[i]
             Rj = self.rot0[i][None] @ sp.axis_angle_mat(self.axis[i], q[:, i - 1])  # child -> parent
             E = np.swapaxes(Rj, 1, 2)
@@ -143,7 +151,7 @@ class Physics:
         N, L, D = self.N, self.L, self.D
         K = np.zeros((N, L, 6, 6 + D))
         K[:, 0, :, :6] = np.eye(6)
-        for i in range(1, L):
+        for i in self.order:
             K[:, i] = X[:, i] @ K[:, self.parent[i]]
             K[:, i, :, 6 + i - 1] += self.S[i]
         return K
@@ -195,7 +203,7 @@ class Physics:
         v = np.einsum("nlij,nj->nli", K, nu)
         a = np.zeros((N, L, 6))
         a[:, 0, 3:] = np.einsum("nji,j->ni", Rw[:, 0], np.array([0.0, 0.0, g]))
-        for i in range(1, L):
+        for i in self.order:
             vj = self.S[i][None] * st["qd"][:, i - 1, None]
             a[:, i] = np.einsum("nij,nj->ni", X[:, i], a[:, self.parent[i]]) + np.einsum("nij,nj->ni", sp.crm(v[:, i]), vj)
         f = np.einsum("nlij,nlj->nli", I, a)

@@ -13,7 +13,9 @@ enum RewKind {
   REW_ACTION_RATE_L2, REW_UNDESIRED_CONTACTS, REW_CONTACT_FORCES, REW_FEET_CONTACT_WITHOUT_CMD, REW_FEET_HEIGHT_BODY,
   REW_UPWARD, REW_FEET_AIR_TIME, REW_FEET_AIR_TIME_VARIANCE, REW_FEET_SLIDE, REW_FEET_GAIT, REW_FLAT_ORIENTATION_L2,
   REW_IS_TERMINATED, REW_JOINT_DEVIATION_L1, REW_JOINT_VEL_L2, REW_FEET_CONTACT, REW_FEET_STUMBLE, REW_FEET_HEIGHT,
-  REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP, REW_TRACK_ANG_VEL_Z_WORLD_EXP, REW_FEET_AIR_TIME_POSITIVE_BIPED
+  REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP, REW_TRACK_ANG_VEL_Z_WORLD_EXP, REW_FEET_AIR_TIME_POSITIVE_BIPED,
+  REW_HANDSTAND_FEET_HEIGHT_EXP, REW_HANDSTAND_FEET_ON_AIR, REW_HANDSTAND_FEET_AIR_TIME, REW_HANDSTAND_ORIENTATION_L2, REW_BASE_HEIGHT_L2, REW_WHEEL_VEL_PENALTY,
+  REW_FEET_DISTANCE_Y_EXP, REW_FEET_DISTANCE_XY_EXP
 };
 enum ObsKind {
   OBS_BASE_LIN_VEL = 0, OBS_BASE_ANG_VEL, OBS_PROJECTED_GRAVITY, OBS_VELOCITY_COMMANDS, OBS_JOINT_POS_REL,
@@ -392,6 +394,80 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         mn = ctx.emin(mn);
         f = (nc == 1.f ? fminf(mn, R.p[0]) : 0.f) * moving * gate;
       } break;
+      case REW_WHEEL_VEL_PENALTY: {  // rewards.py:132-153: |wheel speed| by task joint index and the wheels' first-air flags by
+                                     // body index are staged in the (still unwritten) critic row, one pair per lane
+        float* jq = ctx.obs_stage(1);
+        ctx.group_sync();
+        if (sub == 0)
+#pragma unroll
+          for (int j = 0; j < JX; ++j)
+            if (NW == 0 || jid[j] >= 0) jq[jid[j]] = fabsf(qd[j]);
+#pragma unroll
+        for (int s = 0; s < NBS; ++s)
+          if (sbody[s] >= 0) jq[T.D + sbody[s]] = (t_ca[s] > 0.f && t_ca[s] < fc_hi) ? 1.f : 0.f;
+        ctx.group_sync();
+        const bool running = cmd_norm > R.p[1] || bv > R.p[0];
+        float part = 0.f;
+        for (int i = li; i < R.n_idx; i += LPE) part += (running ? jq[T.D + R.idx_a[i]] : 1.f) * jq[R.idx_b[i]];
+        ctx.group_sync();
+        f = ctx.esum(part);
+      } break;
+      case REW_FEET_DISTANCE_Y_EXP:
+      case REW_FEET_DISTANCE_XY_EXP: {  // rewards.py:439-461, 464-505: feet (link frames) against a stance rectangle in the base frame
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < NBS; ++s) {
+          int at = -1;
+          for (int i = 0; i < R.n_idx; ++i) at = (sbody[s] == R.idx_a[i]) ? i : at;
+          if (at < 0) continue;
+          V3 relp, relv;
+          body_rel(C, s, relp, relv);
+          const float ey = ((at & 1) ? -0.5f : 0.5f) * R.p[1] - relp.y;
+          const float ex = R.kind == REW_FEET_DISTANCE_XY_EXP ? (at < 2 ? 0.5f : -0.5f) * R.p[2] - relp.x : 0.f;
+          part += ex * ex + ey * ey;
+        }
+        f = fexp(-ctx.esum(part) * frcp(R.p[0])) * gate;
+      } break;
+      case REW_HANDSTAND_FEET_HEIGHT_EXP: {  // config/others/unitree_a1_handstand/env/rewards.py:18-28
+        const float err = ssum([&](int s) {
+          V3 relp, relv;
+          body_rel(C, s, relp, relv);
+          const float dz = pos.z + dot(Rwb.r2, relp) - R.p[1];
+          return dz * dz;
+        });
+        f = fexp(-err * frcp(R.p[0]));
+      } break;
+      case REW_HANDSTAND_FEET_ON_AIR: {  // .../env/rewards.py:31-37: every selected foot has just left the ground
+        float n = 0.f, na = 0.f;
+#pragma unroll
+        for (int s = 0; s < NBS; ++s) {
+          if (!in_mask(s)) continue;
+          n += 1.f;
+          na += (t_ca[s] > 0.f && t_ca[s] < fc_hi) ? 1.f : 0.f;
+        }
+        f = ctx.esum(n - na) == 0.f ? 1.f : 0.f;
+      } break;
+      case REW_HANDSTAND_FEET_AIR_TIME: f = ssum([&](int s) { return first_c(s) ? t_la[s] - R.p[0] : 0.f; }); break;  // .../env/rewards.py:40-47
+      case REW_HANDSTAND_ORIENTATION_L2: {  // .../env/rewards.py:50-59
+        const float dx = grav_b.x - R.p[0], dy = grav_b.y - R.p[1], dz = grav_b.z - R.p[2];
+        f = dx * dx + dy * dy + dz * dz;
+      } break;
+      case REW_BASE_HEIGHT_L2: {  // rewards.py:616-644; the 3 x 3 base ray caster (velocity_env_cfg.py:78-85)
+        float tgt = R.p[0];
+        if (R.p[1] > 0.5f) {
+          float hsum = 0.f;
+          for (int r = li; r < 9; r += LPE) {  // 9 rays over the env's lanes (LPE = 16 or 4)
+            const int iy = r / 3, ix = r - 3 * iy;
+            const float lx = (float)(ix - 1) * 0.05f, ly = (float)(iy - 1) * 0.05f;
+            float hz;
+            V3 nn;
+            terrain_sample(this->u, S.terrain, pos.x + yaw_c * lx - yaw_s * ly, pos.y + yaw_s * lx + yaw_c * ly, hz, nn);
+            hsum += hz;
+          }
+          tgt += ctx.esum(hsum) * (1.0f / 9.0f);
+        }
+        f = (pos.z - tgt) * (pos.z - tgt) * gate;
+      } break;
       case REW_FEET_AIR_TIME_VARIANCE: {  // rewards.py:386-397 (torch.var is unbiased)
         float n = 0.f, sa = 0.f, saa = 0.f, sc = 0.f, scc = 0.f;
 #pragma unroll
@@ -686,23 +762,6 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     // 2 decimation loop: actuators -> physics -> contact sensor
     for (int s = 0; s < T.decimation; ++s) this->substep(q_tgt, qd_tgt);
-    if (S.dbg_torque != nullptr) {
-      if (sub == 0)
-#pragma unroll
-      for (int j = 0; j < JX; ++j) {
-        if (NW > 0 && !L.joint_own[j]) continue;
-        S.dbg_torque[(size_t)e * T.D + L.joint_id[j]] = tau_app[j];
-        S.dbg_acc[(size_t)e * T.D + L.joint_id[j]] = qacc[j];
-      }
-#pragma unroll
-      for (int s = 0; s < NBS; ++s) {
-        int b = L.slot_body[s];
-        if (b >= 0 && (s != 0 || L.owns_base_body) && this->owns_slot(s)) {
-          float* o = S.dbg_cforce + ((size_t)e * T.n_bodies + b) * 3;
-          o[0] = cf[s][0]; o[1] = cf[s][1]; o[2] = cf[s][2];
-        }
-      }
-    }
     // 3 counters
     ep_len += 1;
     derive();
@@ -738,6 +797,24 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       }
       reset_env(true);
       derive();
+    }
+    if (S.dbg_torque != nullptr) {  // inspection views as a reader sees them after step(): zeroed by the reset of a done env
+      const float live = (terminated || time_out) ? 0.f : 1.f;
+      if (sub == 0)
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+          if (NW > 0 && !L.joint_own[j]) continue;
+          S.dbg_torque[(size_t)e * T.D + L.joint_id[j]] = live * tau_app[j];
+          S.dbg_acc[(size_t)e * T.D + L.joint_id[j]] = live * qacc[j];
+        }
+#pragma unroll
+      for (int s = 0; s < NBS; ++s) {
+        int b = L.slot_body[s];
+        if (b >= 0 && (s != 0 || L.owns_base_body) && this->owns_slot(s)) {
+          float* o = S.dbg_cforce + ((size_t)e * T.n_bodies + b) * 3;
+          o[0] = cf[s][0]; o[1] = cf[s][1]; o[2] = cf[s][2];
+        }
+      }
     }
     // 7 CommandManager.compute [UPSTREAM B7]
     {

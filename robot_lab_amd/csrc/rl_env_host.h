@@ -169,10 +169,28 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     body_lane[b] = k; body_slot[b] = s;
   }
   T.n_base_bodies = n_base_bodies;
-  // spheres -> lane / group / slot.  Spheres of a trunk body that has more spheres than its lane has slots
-  // are dealt round-robin to the other lanes riding on the same trunk link that own no other trunk body.
+  // spheres -> lane / group / slot.  A trunk body with more spheres than its lane has slots also uses the lanes
+  // riding on the same trunk link that own no trunk body: first every such body reserves the lanes it needs
+  // (MagicLab Dog-W: 6-sphere base + 4-sphere head), then the lanes still free go to the first of them in body
+  // order (A1 trunk: 8 corner spheres -> 2 per lane); the spheres are dealt round-robin over a body's lanes.
   int fill[NLANE][MAX_NGRP];
   memset(fill, 0, sizeof(fill));
+  std::vector<uint32_t> lanes_of(m.num_bodies, 0u);
+  for (int pass = 0; pass < 2; ++pass)
+    for (int b = 0; b < m.num_bodies; ++b) {
+      const int link = m.body_link[b];
+      if (link_k[link] != -1 || nsph[b] <= SPL) continue;
+      if (pass == 0) lanes_of[b] = 1u << body_lane[b];
+      int have = 0;
+      for (int kk = 0; kk < NLANE; ++kk) have += (lanes_of[b] >> kk) & 1u;
+      const int want = pass == 0 ? (nsph[b] + SPL - 1) / SPL : NLANE;
+      for (int kk = 0; kk < NLANE && have < want; ++kk)
+        if (T.lane[kk].base_body_local == -1 && T.lane[kk].grp0_depth == link_j[link]) {
+          T.lane[kk].base_body_local = T.lane[body_lane[b]].base_body_local;
+          lanes_of[b] |= 1u << kk;
+          ++have;
+        }
+    }
   int rr = 0;
   for (int g = 0; g < m.num_spheres; ++g) {
     int b = m.sphere_body[g], link = m.body_link[b];
@@ -180,15 +198,11 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     if (link_k[link] == -1) {
       grp = 0; slot = 0;
       k = body_lane[b];
-      if (nsph[b] > SPL) {  // spread (A1 trunk: 8 corner spheres -> 2 per lane)
-        const int local = T.lane[body_lane[b]].base_body_local, depth = link_j[link];
+      if (nsph[b] > SPL)
         for (int tries = 0; tries < NLANE; ++tries, ++rr) {
           int kk = rr % NLANE;
-          int other = T.lane[kk].base_body_local;
-          if ((other == -1 || other == local) && T.lane[kk].grp0_depth == depth && fill[kk][0] < SPL) { k = kk; ++rr; break; }
+          if (((lanes_of[b] >> kk) & 1u) && fill[kk][0] < SPL) { k = kk; ++rr; break; }
         }
-        if (T.lane[k].base_body_local == -1) T.lane[k].base_body_local = local;
-      }
     } else {
       k = link_k[link]; grp = link_j[link] + 1; slot = body_slot[b];
     }
@@ -268,6 +282,8 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     R.kind = r.kind; R.weight = r.weight; memcpy(R.p, r.p, sizeof(R.p)); R.joint_mask = r.joint_mask; R.body_mask = r.body_mask;
     R.n_idx = r.n_idx; R.idx_off = pool_used;
     if (r.n_idx < 0 || r.n_idx > 16 || pool_used + (r.kind == RL_REW_FEET_GAIT ? 4 : r.n_idx) > IDX_POOL) return fail("index lists of the reward terms exceed the pool");
+    if ((r.kind == RL_REW_WHEEL_VEL_PENALTY && m.num_dof + m.num_bodies > T.critic_dim) || (r.kind == RL_REW_JOINT_MIRROR && m.num_dof > T.critic_dim))
+      return fail("joint_mirror / wheel_vel_penalty stage per-joint (and per-body) values in the critic row, which is too short");
     const int nidx = r.kind == RL_REW_FEET_GAIT ? 4 : r.n_idx;
     for (int q = 0; q < nidx; ++q) { T.idx_pool_a[pool_used + q] = r.idx_a[q]; T.idx_pool_b[pool_used + q] = r.idx_b[q]; }
     pool_used += nidx;

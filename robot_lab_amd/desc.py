@@ -28,7 +28,9 @@ REWARD_KINDS = [
     "upward", "feet_air_time", "feet_air_time_variance_penalty", "feet_slide", "GaitReward",
     "flat_orientation_l2", "is_terminated", "joint_deviation_l1", "joint_vel_l2", "feet_contact",
     "feet_stumble", "feet_height", "track_lin_vel_xy_yaw_frame_exp", "track_ang_vel_z_world_exp",
-    "feet_air_time_positive_biped",
+    "feet_air_time_positive_biped", "handstand_feet_height_exp", "handstand_feet_on_air", "handstand_feet_air_time",
+    "handstand_orientation_l2", "base_height_l2", "wheel_vel_penalty", "feet_distance_y_exp",
+    "feet_distance_xy_exp",
 ]
 REW = {n: i for i, n in enumerate(REWARD_KINDS)}
 OBS_KINDS = [

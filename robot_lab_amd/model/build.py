@@ -176,6 +176,13 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
             m.act_implicit[i] = 1 if act["type"] == "implicit" else 0
             arm[i] = v
             assigned[i] = True
+    if not all(assigned) and rob.get("unactuated_passive"):
+        for i in range(D):
+            if not assigned[i]:  # passive hinge: no drive, no torque
+                m.act_kp[i] = m.act_kd[i] = m.act_effort_limit[i] = m.act_saturation[i] = 0.0
+                m.act_vel_limit[i] = 1e9
+                m.act_implicit[i] = 1
+                assigned[i] = True
     if not all(assigned):
         raise ValueError(f"joints without actuator: {[n for n, a in zip(jn, assigned) if not a]}")
     set_arr(m.joint_armature, arm)
@@ -268,6 +275,19 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
             set_arr(r.idx_b, ib)
             r.n_idx = len(ia)
             r.p[0] = 1.0 / len(rt["mirror_joints"]) if rt["mirror_joints"] else 0.0
+        if rt["func"] == "wheel_vel_penalty":  # in_air[:, body_ids] * joint_vel[:, joint_ids], elementwise (rewards.py:146)
+            ia, ib = find_names(rt["body_names"], bn), find_names(rt["joint_names"], jn)
+            if len(ia) != len(ib):
+                raise ValueError("wheel_vel_penalty pairs one wheel body with one wheel joint")
+            set_arr(r.idx_a, ia)
+            set_arr(r.idx_b, ib)
+            r.n_idx = len(ia)
+        if rt["func"] in ("feet_distance_y_exp", "feet_distance_xy_exp"):  # the foot's place in body_ids picks its side
+            ia = find_names(rt["body_names"], bn)
+            if rt["func"] == "feet_distance_xy_exp" and len(ia) != 4:
+                raise ValueError("feet_distance_xy_exp is written for 4 feet")
+            set_arr(r.idx_a, ia)
+            r.n_idx = len(ia)
         if rt["func"] == "GaitReward":
             pairs = rt["synced_feet_pair_names"]
             feet = [find_names(list(pairs[0]), bn, True), find_names(list(pairs[1]), bn, True)]

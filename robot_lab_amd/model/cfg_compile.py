@@ -67,6 +67,10 @@ def compile_spec(cfg) -> tuple[dict, str]:
         init_pos=tuple(robot.init_state.pos), init_rot=tuple(robot.init_state.rot or (1.0, 0.0, 0.0, 0.0)),
         init_joint_pos=dict(robot.init_state.joint_pos), init_joint_vel=dict(robot.init_state.joint_vel or {".*": 0.0}),
         soft_joint_pos_limit_factor=robot.soft_joint_pos_limit_factor or 1.0, actuators=actuators))
+    # joints no actuator group names keep the importer's drive gains; with the assets' `PDGainsCfg(stiffness=0, damping=0)`
+    # (assets/booster.py:29-31) they are passive hinges whose action-vector entries have no effect
+    gains = getattr(getattr(robot.spawn, "joint_drive", None), "gains", None)
+    spec["robot"]["unactuated_passive"] = bool(gains is not None and gains.stiffness == 0 and gains.damping == 0)
     # actions
     actions = []
     for name, a in vars(cfg.actions).items():
@@ -149,7 +153,25 @@ def compile_spec(cfg) -> tuple[dict, str]:
             e["p"] = [p["stand_still_scale"], p["velocity_threshold"], p["command_threshold"]]
         elif fn == "joint_mirror":
             e["mirror_joints"] = [list(pair) for pair in p["mirror_joints"]]
-        elif fn in ("undesired_contacts", "contact_forces", "feet_air_time", "feet_air_time_positive_biped"):
+        elif fn == "wheel_vel_penalty":
+            e["p"] = [p["velocity_threshold"], p["command_threshold"]]
+        elif fn == "feet_distance_y_exp":
+            e["p"] = [p["std"] ** 2, p["stance_width"]]
+        elif fn == "feet_distance_xy_exp":
+            e["p"] = [p["std"] ** 2, p["stance_width"], p["stance_length"]]
+        elif fn == "handstand_feet_height_exp":
+            e["p"] = [p["std"] ** 2, p["target_height"]]
+        elif fn == "handstand_orientation_l2":
+            e["p"] = list(p["target_gravity"])
+        elif fn == "base_height_l2":
+            sensor = p.get("sensor_cfg")
+            if sensor is not None:  # the 3 x 3 `height_scanner_base` ray caster (velocity_env_cfg.py:78-85)
+                hb = getattr(cfg.scene, getattr(sensor, "name", "height_scanner_base"), None)
+                if hb is None or tuple(hb.pattern_cfg.size) != (0.1, 0.1) or hb.pattern_cfg.resolution != 0.05:
+                    raise UnsupportedTerm("base_height_l2 with a ray caster other than the 0.1 x 0.1 @ 0.05 grid")
+            e["p"] = [p["target_height"], 1.0 if sensor is not None else 0.0]
+            e.pop("body_names", None)
+        elif fn in ("undesired_contacts", "contact_forces", "feet_air_time", "feet_air_time_positive_biped", "handstand_feet_air_time"):
             e["p"] = [p["threshold"]]
         elif fn in ("feet_height_body", "feet_height"):
             e["p"] = [p["target_height"], p["tanh_mult"]]

@@ -298,9 +298,6 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
             l.parent = inv[l.parent]
         for b in raw_bodies:
             b["link"] = inv[b["link"]]
-        for i, l in enumerate(model.links[1:], 1):
-            if l.parent >= i:
-                raise ValueError("joint_order must be topological (parents before children)")
 
     # finalise bodies: composite inertial per body, expressed in the link frame
     for bi, rb in enumerate(raw_bodies):
@@ -331,9 +328,18 @@ def cap_spheres(model: RobotModel, trunk_links, per_link: int, per_trunk_body: i
     for i, sph in enumerate(model.spheres):
         link = model.bodies[sph.body].link
         groups.setdefault((link, sph.body if link in trunk_links else -1), []).append(i)
+    budgets = {key: (per_trunk_body if key[0] in trunk_links else per_link) for key in groups}
+    if len(trunk_links) == 1:
+        # no trunk joints: the bodies of the base link share the 4 lanes' base groups, one body per lane and
+        # `per_link` spheres per lane (MagicLab Dog-W: an 8-sphere base and a 4-sphere head are 5 lanes' worth)
+        base = [key for key in groups if key[0] in trunk_links]
+        lanes = lambda: sum(-(-min(len(groups[k]), budgets[k]) // per_link) for k in base)
+        while base and lanes() > 4:
+            big = max(base, key=lambda k: min(len(groups[k]), budgets[k]))
+            budgets[big] = min(len(groups[big]), budgets[big]) - 1
     keep = set()
-    for (link, _), ids in groups.items():
-        budget = per_trunk_body if link in trunk_links else per_link
+    for key, ids in groups.items():
+        link, budget = key[0], budgets[key]
         if len(ids) <= budget:
             keep.update(ids)
             continue

@@ -26,6 +26,12 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Rough-RobotEra-Xbot-v0",
     "RobotLab-Isaac-Velocity-Rough-MagicLab-Bot-Gen1-v0",
     "RobotLab-Isaac-Velocity-Flat-Openloong-Loong-v0",
+    "RobotLab-Isaac-Velocity-Flat-DDTRobot-Tita-v0",
+    "RobotLab-Isaac-Velocity-Rough-MagicLab-Bot-Z1-v0",
+    "RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Unitree-B2W-v0",
+    "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-W-v0",
+    "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-v0",
 ]
 
 
@@ -42,7 +48,7 @@ def _pair(task, N, seed):
 
 @pytest.mark.parametrize("task", TASKS)
 def test_short_horizon_parity(task):
-    N = 32 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong")) else 64
+    N = 32 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1")) else 64
     env, ora, torch = _pair(task, N, 11)
     obs, _ = env.reset()
     o = ora.reset()

@@ -30,7 +30,7 @@ def _load(robot):
     return g, desc, ora
 
 
-@pytest.mark.parametrize("robot", ["a1", "go2", "g1"])
+@pytest.mark.parametrize("robot", ["a1", "go2", "g1", "a1_handstand", "tita"])
 def test_reward_terms_match_reference_functions(robot):
     g, desc, ora = _load(robot)
     hist = np.linalg.norm(ora.force_hist, axis=-1).max(axis=1)
@@ -42,7 +42,11 @@ def test_reward_terms_match_reference_functions(robot):
         got = ora.reward_terms[i] / (w * ora.step_dt)
         np.testing.assert_allclose(got, g["term_values"][i], rtol=2e-6, atol=1e-7, err_msg=name)  # descriptor parameters are fp32
     # at least the contact / timer driven terms must be exercised by the recorded state
-    exercised = {"g1": ("track_lin_vel_xy_exp", "track_ang_vel_z_exp", "feet_air_time", "feet_slide", "joint_deviation_arms_l1", "flat_orientation_l2")}
+    exercised = {"g1": ("track_lin_vel_xy_exp", "track_ang_vel_z_exp", "feet_air_time", "feet_slide", "joint_deviation_arms_l1", "flat_orientation_l2"),
+                 # config/others/unitree_a1_handstand/env/rewards.py:18-59
+                 "a1_handstand": ("handstand_feet_height_exp", "handstand_feet_on_air", "handstand_feet_air_time", "handstand_orientation_l2"),
+                 # rewards.py:616-644 (ray caster branch), 132-153, 439-461
+                 "tita": ("base_height_l2", "wheel_vel_penalty", "feet_distance_y_exp", "feet_slide", "contact_forces")}
     for name in exercised.get(robot, ("undesired_contacts", "contact_forces", "feet_height_body", "joint_mirror")):
         assert np.abs(g["term_values"][names.index(name)]).max() > 0, name
 

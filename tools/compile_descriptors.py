@@ -22,8 +22,12 @@ from robot_lab_amd.scene import DATA_DIR, save_bundle  # noqa: E402
 # humanoids / bipeds that fit "trunk of <= 3 joints + <= 4 limb chains of <= 7 joints" run on the G1 instance
 # (Topo<7,3,4,9>) with inert padding joints / empty limbs: ATOM01 (23 DoF, 1 waist joint), Xbot (28 DoF, legs hang off
 # a 2-joint trunk), MagicLab Bot-Gen1 (14 DoF), Openloong Loong (12-DoF biped, two empty limbs)
+# ... MagicLab Z1 (14 DoF, hip joints listed out of tree order), DDT Tita (2 wheeled legs, 2 empty limbs)
 ROBOTS = ("Unitree-A1", "Unitree-Go2", "Unitree-Go2W", "Unitree-G1", "Unitree-B2", "Deeprobotics-Lite3", "Deeprobotics-M20",
-          "Zsibot-ZSL1", "Zsibot-ZSL1W", "RoboParty-ATOM01", "RobotEra-Xbot", "MagicLab-Bot-Gen1", "Openloong-Loong")
+          "Zsibot-ZSL1", "Zsibot-ZSL1W", "RoboParty-ATOM01", "RobotEra-Xbot", "MagicLab-Bot-Gen1", "Openloong-Loong",
+          "Unitree-B2W", "MagicLab-Dog-W", "MagicLab-Dog", "MagicLab-Bot-Z1", "DDTRobot-Tita", "HandStand-Unitree-A1")
+# not compiled: Unitree-H1 (asset lives in isaaclab_assets, not in the reference), Booster-T1 (5 limbs: head + arms + legs),
+# FFTAI GR1T1/T2 (more links than the descriptor holds), MagicLab-Dog Rough (its registration names a class that does not exist)
 TASKS = sys.argv[1:] or [f"RobotLab-Isaac-Velocity-{t}-{r}-v0" for r in ROBOTS for t in ("Flat", "Rough")]
 os.makedirs(DATA_DIR, exist_ok=True)
 for task in TASKS:
@@ -32,6 +36,9 @@ for task in TASKS:
         desc, spec = compile_cfg(cfg)
     except (UnsupportedTerm, NotImplementedError) as e:
         print(f"{task}: NOT COMPILED ({e})")
+        continue
+    if desc.model.num_chains == 0:
+        print(f"{task}: NOT COMPILED (topology is not a trunk of <= 3 joints + <= 4 serial limbs of <= 7 joints)")
         continue
     save_bundle(os.path.join(DATA_DIR, task + ".json"), desc, spec)
     m = desc.model

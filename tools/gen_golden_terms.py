@@ -27,7 +27,7 @@ from isaaclab_tasks.utils import parse_env_cfg  # noqa: E402
 from oracle.env import OracleEnv  # noqa: E402
 from robot_lab_amd.model.build import find_names  # noqa: E402
 from robot_lab_amd.model.cfg_compile import compile_cfg  # noqa: E402
-from robot_lab_amd.scene import build_world  # noqa: E402
+from robot_lab_amd.scene import build_world, load_bundle  # noqa: E402
 
 T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)  # noqa: E731
 
@@ -85,6 +85,14 @@ def duck_env(ora, desc):
 
     scene = Scene(robot=asset, contact_forces=sensor)
     scene.sensors = {"contact_forces": sensor}
+    # `height_scanner_base` (velocity_env_cfg.py:78-85): 3 x 3 yaw-aligned rays, 0.05 m apart, under the root link.  The ray /
+    # mesh intersection itself is upstream; the hit heights are the bilinear heightfield at the ray positions.
+    gx, gy = torch.meshgrid(torch.tensor([-0.05, 0.0, 0.05], dtype=torch.float64), torch.tensor([-0.05, 0.0, 0.05], dtype=torch.float64), indexing="xy")
+    rays = torch.stack([gx.reshape(-1), gy.reshape(-1), torch.zeros(9, dtype=torch.float64)], -1)
+    hit = pos[:, None, :] + mu.quat_apply_yaw(quat[:, None, :].repeat(1, 9, 1), rays[None].repeat(ora.N, 1, 1))
+    hz, _ = ora.phys.terrain.sample(hit[..., 0].numpy(), hit[..., 1].numpy())
+    hit[..., 2] = T(hz)
+    scene["height_scanner_base"] = types.SimpleNamespace(data=types.SimpleNamespace(ray_hits_w=hit))
     env = types.SimpleNamespace(
         scene=scene, num_envs=ora.N, device="cpu", step_dt=ora.step_dt, max_episode_length_s=ora.max_episode_length_s,
         command_manager=types.SimpleNamespace(get_command=lambda name: T(ora.vel_command_b)),
@@ -117,21 +125,28 @@ def snapshot(ora):
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
-    todo = [a for a in sys.argv[1:]] or ["A1", "Go2", "G1"]
-    for robot, seed in (("A1", 3), ("Go2", 4), ("G1", 6)):
+    todo = [a for a in sys.argv[1:]] or ["A1", "Go2", "G1", "A1_HandStand", "Tita"]
+    for robot, seed, task in (("A1", 3, None), ("Go2", 4, None), ("G1", 6, None),
+                              # the hand-stand terms (config/others/unitree_a1_handstand/env/rewards.py) and, on rough terrain,
+                              # base_height_l2 with its ray caster, wheel_vel_penalty, feet_distance_y_exp
+                              ("A1_HandStand", 7, "RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0"),
+                              ("Tita", 8, "RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0")):
         if robot not in todo:
             continue
-        task = f"RobotLab-Isaac-Velocity-Flat-Unitree-{robot}-v0"
+        task = task or f"RobotLab-Isaac-Velocity-Flat-Unitree-{robot}-v0"
         cfg = parse_env_cfg(task, device="cpu")
         desc, spec = compile_cfg(cfg)
         N = 48
-        h, to, eo = build_world(desc, dict(env_spacing=2.5), N, 0)
+        h, to, eo = build_world(desc, load_bundle(task)[1] if "Rough" in task else dict(env_spacing=2.5), N, 0)
         ora = OracleEnv(desc, h, to, N, seed, eo)
         ora.reset()
         rng = np.random.default_rng(seed)
         for s in range(37):  # long enough for contacts, air phases and a command resample of the standing envs
             ora.step(rng.uniform(-1, 1, (N, ora.D)))
         ora.vel_command_b[::5] *= 0.02  # exercise the small-command branches
+        if robot in ("A1_HandStand", "Tita"):  # every body just left the ground: the first-air branches (all feet at once is rare)
+            ora.timers[::7, :, 0] = ora.step_dt
+            ora.timers[::7, :, 1] = 0.0
         snap = snapshot(ora)
         env = duck_env(ora, desc)
         expected = {}
