@@ -23,7 +23,7 @@ class UnsupportedTerm(ValueError):
 def _terms(cfg_group):
     """(name, term_cfg) of a cfg container in declaration order, skipping deleted (None) terms."""
     out = []
-    for k, v in vars(cfg_group).items():
+    for k, v in (vars(cfg_group) if hasattr(cfg_group, "__dict__") else {}).items():
         if k.startswith("_") or v is None or not hasattr(v, "func"):
             continue
         out.append((k, v))
@@ -85,6 +85,12 @@ def compile_spec(cfg) -> tuple[dict, str]:
     spec["actions"] = actions
     spec["sim"] = dict(dt=cfg.sim.dt, decimation=cfg.decimation)
     # terrain
+    # curricula: terrain_levels_vel is built in; the command_levels_* terms (mdp/curriculums.py:21-94) rescale the
+    # global command ranges from a mean over the envs reset in one step - every cfg of the reference deletes them
+    # (e.g. unitree_a1/rough_env_cfg.py:158-159) and the lane program has no such grid-wide step: refuse, do not ignore
+    for name, t in _terms(getattr(cfg, "curriculum", None) or object()):
+        if _fname(t) != "terrain_levels_vel":
+            raise UnsupportedTerm(f"curriculum term {_fname(t)} ({name})")
     ter = cfg.scene.terrain
     if ter.terrain_type == "plane":
         spec["terrain"] = dict(is_plane=1)
