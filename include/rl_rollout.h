@@ -1,0 +1,80 @@
+/* rl_rollout.h - C-ABI of the on-policy rollout storage: stochastic policy head, transition record, GAE
+ * (second half: what sits between `policy(obs)` and `env.step()` in the rollout loop).
+ *
+ * Replaces (reference call sites; the arithmetic lives in the third-party `rsl-rl-lib`, pinned to 3.0.1 by
+ * scripts/reinforcement_learning/rsl_rl/train.py:65-75 and absent from the reference tree):
+ *   - `runner.learn(num_learning_iterations=..., init_at_random_ep_len=True)`, train.py:224 - per iteration
+ *        `num_steps_per_env` (= 24, .../unitree_a1/agents/rsl_rl_ppo_cfg.py:11) times
+ *            actions = alg.act(obs)                      -> rl_rollout_act
+ *            obs, rewards, dones, extras = env.step(...)    (include/rl_env.h)
+ *            alg.process_env_step(obs, rewards, dones, extras) -> rl_rollout_record
+ *        then  alg.compute_returns(obs)                  -> rl_rollout_compute_returns
+ *   - `gamma=0.99, lam=0.95`, rsl_rl_ppo_cfg.py:33-34; `init_noise_std=1.0`, :16 (the `std` vector passed to act)
+ *
+ * Published algorithm restated (rsl_rl/algorithms/ppo.py `act` / `process_env_step`, rsl_rl/storage/rollout_storage.py
+ * `add_transitions` / `compute_returns`):
+ *   act:      a = mu + sigma * eps, eps ~ N(0, 1);  log_prob = sum_j( -((a_j - mu_j)/sigma_j)^2 / 2 - log sigma_j - log sqrt(2 pi) )
+ *   record:   r_t += gamma * V_t * time_out  (bootstrapping on time outs);  done_t = terminated | time_out
+ *   returns:  for t = T-1 .. 0:  nt = 1 - done_t;  delta = r_t + nt * gamma * V_{t+1} - V_t;
+ *             A = delta + nt * gamma * lam * A;  R_t = A + V_t;   adv = R - V;
+ *             normalize: adv = (adv - mean(adv)) / (std(adv) + 1e-8)   (unbiased std over all T * N entries)
+ * The random stream is this library's own (Philox4x32-10 keyed by the seed, counter = transitions recorded so far,
+ * Box-Muller): torch's generator is not reproduced.
+ *
+ * All array arguments are DEVICE pointers (fp32 unless noted); work is stream-ordered on `stream` (a hipStream_t, or
+ * NULL for the default stream).  Storage layout: [num_steps][num_envs][dim], i.e. a flat [T * N, dim] batch. */
+#ifndef RL_ROLLOUT_H
+#define RL_ROLLOUT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rl_rollout rl_rollout;
+
+enum rl_rollout_buffer {
+  RL_RO_OBS = 0,        /* f32 [T][N][obs_dim] */
+  RL_RO_CRITIC_OBS = 1, /* f32 [T][N][critic_dim] */
+  RL_RO_ACTIONS = 2,    /* f32 [T][N][act_dim] */
+  RL_RO_MU = 3,         /* f32 [T][N][act_dim] */
+  RL_RO_SIGMA = 4,      /* f32 [T][N][act_dim] */
+  RL_RO_LOG_PROB = 5,   /* f32 [T][N] */
+  RL_RO_VALUES = 6,     /* f32 [T][N] */
+  RL_RO_REWARDS = 7,    /* f32 [T][N] */
+  RL_RO_DONES = 8,      /* u8  [T][N] */
+  RL_RO_RETURNS = 9,    /* f32 [T][N] */
+  RL_RO_ADVANTAGES = 10,/* f32 [T][N] */
+  RL_RO_NUM_BUFFERS
+};
+
+int rl_rollout_create(int32_t num_envs, int32_t num_steps, int32_t obs_dim, int32_t critic_dim, int32_t act_dim, uint64_t seed,
+                      int32_t device, rl_rollout** out);
+
+/* PPO.act + the first half of RolloutStorage.add_transitions, for the current step t:
+ *   obs [N][obs_dim], critic_obs [N][critic_dim], mean [N][act_dim] (actor output), std [act_dim] (the policy's noise std),
+ *   values [N] (critic output)  ->  actions_out [N][act_dim] (what env.step consumes); everything is copied into slot t.
+ * Fails when the storage is full (num_steps transitions recorded and not cleared). */
+int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, const float* mean, const float* std, const float* values,
+                   float* actions_out, void* stream);
+
+/* PPO.process_env_step + the second half of add_transitions: rewards [N] f32, terminated / time_outs [N] u8 (the
+ * env's RL_BUF_TERMINATED / RL_BUF_TIME_OUT); closes step t and advances to t + 1. */
+int rl_rollout_record(rl_rollout* r, const float* rewards, const uint8_t* terminated, const uint8_t* time_outs, float gamma, void* stream);
+
+/* RolloutStorage.compute_returns(last_values [N], gamma, lam, normalize_advantage); needs a full storage. */
+int rl_rollout_compute_returns(rl_rollout* r, const float* last_values, float gamma, float lam, int32_t normalize_advantage, void* stream);
+
+/* RolloutStorage.clear(): back to step 0 (the random counter keeps running). */
+int rl_rollout_clear(rl_rollout* r);
+
+int rl_rollout_get_buffer(rl_rollout* r, int32_t which, void** dev_ptr, int64_t* count);
+int32_t rl_rollout_step(const rl_rollout* r); /* transitions recorded since the last clear */
+int rl_rollout_destroy(rl_rollout* r);
+const char* rl_rollout_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,330 @@
+// rl_rollout.hip - on-policy rollout storage for gfx950 (MI355X): stochastic policy head, transition record and
+// GAE.  C-ABI: include/rl_rollout.h (which restates the rsl-rl-lib 3.0.1 arithmetic this follows).
+//
+// Everything here is HBM-bound byte / element work (per rollout step ~1.4 KB per env: 45 + 235 observation columns,
+// 3 x 12 action-sized rows, 5 scalars), so the kernels are plain coalesced streams:
+//   act      one launch: the first blocks copy the two observation batches into slot t as flat 16-byte streams, the
+//            rest draw the actions (one thread per env x 4-action Philox block: 4 uniforms -> 4 normals by Box-Muller)
+//            and one thread per env reduces the log-probability
+//   record   one thread per env
+//   returns  one thread per env walks its T values backwards ([T][N] arrays: every step is a coalesced row), block
+//            partial sums feed the advantage normalisation; the partials are summed in a fixed order by every block
+//            of the next kernel (no atomics: bit-reproducible)
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/rl_rollout.h"
+#define RL_FN __host__ __device__ __forceinline__
+#include "rl_math.h"
+
+namespace {
+
+constexpr uint32_t STREAM_POLICY = 7;  // Philox stream of the action noise (the env uses streams 1..6)
+constexpr int BLOCK = 256;
+constexpr int MAX_PARTIALS = 4096;
+
+thread_local std::string g_err;
+int fail(const std::string& m) {
+  g_err = m;
+  return -1;
+}
+#define HIP_OK(x)                                                                  \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) return fail(std::string(#x ": ") + hipGetErrorString(e_)); \
+  } while (0)
+
+struct ActArgs {
+  const float *obs, *critic_obs, *mean, *std, *values;
+  float *actions_out, *s_obs, *s_critic, *s_actions, *s_mu, *s_sigma, *s_logp, *s_values;
+  int N, obs_dim, critic_dim, act_dim;
+  int copy_blocks_obs, copy_blocks_critic, sample_blocks;
+  uint64_t seed;
+  uint32_t counter;
+};
+
+__device__ inline void stream_copy(const float* __restrict__ src, float* __restrict__ dst, size_t n, int block, int nblocks) {
+  // n floats, both 16-byte aligned at the base (hipMalloc / torch allocations): float4 body + scalar tail
+  const size_t n4 = n >> 2;
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (size_t i = (size_t)block * BLOCK + threadIdx.x; i < n4; i += (size_t)nblocks * BLOCK) d4[i] = s4[i];
+  if (block == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+}
+
+// standard normals of one Philox block: (u0, u1) and (u2, u3) -> two Box-Muller pairs; u in [0, 1) -> 1 - u in (0, 1]
+__device__ inline void normal4(uint64_t seed, uint32_t env, uint32_t counter, uint32_t blk, float (&z)[4]) {
+  float u[4];
+  rl::uniform01x4(seed, env, counter, STREAM_POLICY, blk, u);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float r = sqrtf(-2.0f * logf(1.0f - u[2 * p]));
+    float s, c;
+    sincosf(6.28318530717958647692f * u[2 * p + 1], &s, &c);
+    z[2 * p] = r * c;
+    z[2 * p + 1] = r * s;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
+  int b = blockIdx.x;
+  if (b < a.copy_blocks_obs) {
+    stream_copy(a.obs, a.s_obs, (size_t)a.N * a.obs_dim, b, a.copy_blocks_obs);
+    return;
+  }
+  b -= a.copy_blocks_obs;
+  if (b < a.copy_blocks_critic) {
+    stream_copy(a.critic_obs, a.s_critic, (size_t)a.N * a.critic_dim, b, a.copy_blocks_critic);
+    return;
+  }
+  b -= a.copy_blocks_critic;
+  // one thread per env: act_dim is 12 .. 29, a row of mean is 48 .. 116 contiguous bytes
+  const int e = b * BLOCK + threadIdx.x;
+  if (e >= a.N) return;
+  const int A = a.act_dim;
+  const float* mu = a.mean + (size_t)e * A;
+  float logp = 0.f;
+  for (int j0 = 0; j0 < A; j0 += 4) {
+    float z[4];
+    normal4(a.seed, (uint32_t)e, a.counter, (uint32_t)(j0 >> 2), z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + i;
+      if (j >= A) break;
+      const float m = mu[j], sd = a.std[j];
+      const float act = m + sd * z[i];
+      const float q = (act - m) / sd;  // as the reference evaluates Normal.log_prob on the sampled action
+      logp += -0.5f * q * q - logf(sd) - 0.91893853320467274178f;
+      const size_t o = (size_t)e * A + j;
+      a.actions_out[o] = act;
+      a.s_actions[o] = act;
+      a.s_mu[o] = m;
+      a.s_sigma[o] = sd;
+    }
+  }
+  a.s_logp[e] = logp;
+  a.s_values[e] = a.values[e];
+}
+
+__global__ __launch_bounds__(BLOCK) void record_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
+                                                       const uint8_t* __restrict__ time_outs, const float* __restrict__ s_values,
+                                                       float* __restrict__ s_rewards, uint8_t* __restrict__ s_dones, float gamma, int N) {
+  const int e = blockIdx.x * BLOCK + threadIdx.x;
+  if (e >= N) return;
+  const bool to = time_outs[e] != 0;
+  s_rewards[e] = rewards[e] + (to ? gamma * s_values[e] : 0.f);  // bootstrapping on time outs
+  s_dones[e] = (terminated[e] != 0 || to) ? 1 : 0;
+}
+
+__device__ inline double block_sum(double v, double* sh) {
+  // fixed-order tree over the 256 threads
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(BLOCK) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                                                    const uint8_t* __restrict__ dones, const float* __restrict__ last_values,
+                                                    float* __restrict__ returns, float* __restrict__ adv, double* __restrict__ partial, float gamma,
+                                                    float lam, int T, int N) {
+  __shared__ double sh[BLOCK];
+  const int e = blockIdx.x * BLOCK + threadIdx.x;
+  double sum = 0.0;
+  if (e < N) {
+    float a = 0.f, next_v = last_values[e];
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t i = (size_t)t * N + e;
+      const float v = values[i];
+      const float nt = dones[i] ? 0.f : 1.f;
+      const float delta = rewards[i] + nt * gamma * next_v - v;
+      a = delta + nt * gamma * lam * a;
+      const float ret = a + v;
+      returns[i] = ret;
+      const float ad = ret - v;  // "advantages = returns - values", not the running a (they differ by one rounding)
+      adv[i] = ad;
+      sum += (double)ad;
+      next_v = v;
+    }
+  }
+  const double s = block_sum(sum, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__device__ inline double sum_partials(const double* __restrict__ p, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += p[i];  // same order in every thread of every block
+  return s;
+}
+
+__global__ __launch_bounds__(BLOCK) void var_kernel(const float* __restrict__ adv, const double* __restrict__ partial_sum, double* __restrict__ partial_sq,
+                                                    int nb_gae, size_t count) {
+  __shared__ double sh[BLOCK];
+  const double mean = sum_partials(partial_sum, nb_gae) / (double)count;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (size_t)gridDim.x * BLOCK) {
+    const double d = (double)adv[i] - mean;
+    acc += d * d;
+  }
+  const double s = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial_sq[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(BLOCK) void norm_kernel(float* __restrict__ adv, const double* __restrict__ partial_sum, const double* __restrict__ partial_sq,
+                                                     int nb_gae, int nb_var, size_t count) {
+  const double mean = sum_partials(partial_sum, nb_gae) / (double)count;
+  const double var = sum_partials(partial_sq, nb_var) / (double)(count > 1 ? count - 1 : 1);  // torch.std: unbiased
+  const float m = (float)mean, inv = 1.0f / ((float)sqrt(var) + 1e-8f);
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (size_t)gridDim.x * BLOCK) adv[i] = (adv[i] - m) * inv;
+}
+
+}  // namespace
+
+struct rl_rollout {
+  int N, T, obs_dim, critic_dim, act_dim, device;
+  uint64_t seed;
+  uint32_t counter = 0;  // transitions drawn so far (Philox counter)
+  int step = 0;
+  bool acted = false;    // rl_rollout_act done for the current step, rl_rollout_record pending
+  void* buf[RL_RO_NUM_BUFFERS] = {};
+  int64_t count[RL_RO_NUM_BUFFERS] = {};
+  double *partial_sum = nullptr, *partial_sq = nullptr;
+};
+
+namespace {
+int dim_of(const rl_rollout* r, int which) {
+  switch (which) {
+    case RL_RO_OBS: return r->obs_dim;
+    case RL_RO_CRITIC_OBS: return r->critic_dim;
+    case RL_RO_ACTIONS: case RL_RO_MU: case RL_RO_SIGMA: return r->act_dim;
+    default: return 1;
+  }
+}
+template <class Tp>
+Tp* slot(const rl_rollout* r, int which, int t) {
+  return static_cast<Tp*>(r->buf[which]) + (size_t)t * r->N * dim_of(r, which);
+}
+int blocks_for(size_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
+}  // namespace
+
+extern "C" {
+
+const char* rl_rollout_last_error(void) { return g_err.c_str(); }
+
+int rl_rollout_create(int32_t num_envs, int32_t num_steps, int32_t obs_dim, int32_t critic_dim, int32_t act_dim, uint64_t seed, int32_t device,
+                      rl_rollout** out) {
+  if (!out) return fail("out is NULL");
+  if (num_envs < 1 || num_steps < 1 || obs_dim < 1 || critic_dim < 1 || act_dim < 1) return fail("sizes must be positive");
+  if (blocks_for((size_t)num_envs) > MAX_PARTIALS) return fail("num_envs too large for the reduction scratch");
+  HIP_OK(hipSetDevice(device));
+  rl_rollout* r = new rl_rollout();
+  r->N = num_envs; r->T = num_steps; r->obs_dim = obs_dim; r->critic_dim = critic_dim; r->act_dim = act_dim; r->device = device; r->seed = seed;
+  for (int w = 0; w < RL_RO_NUM_BUFFERS; ++w) {
+    r->count[w] = (int64_t)num_steps * num_envs * dim_of(r, w);
+    const size_t bytes = (size_t)r->count[w] * (w == RL_RO_DONES ? 1 : 4);
+    if (hipMalloc(&r->buf[w], bytes) != hipSuccess || hipMemset(r->buf[w], 0, bytes) != hipSuccess) {
+      rl_rollout_destroy(r);
+      return fail("hipMalloc of the rollout storage failed");
+    }
+  }
+  if (hipMalloc(&r->partial_sum, MAX_PARTIALS * sizeof(double)) != hipSuccess || hipMalloc(&r->partial_sq, MAX_PARTIALS * sizeof(double)) != hipSuccess) {
+    rl_rollout_destroy(r);
+    return fail("hipMalloc of the reduction scratch failed");
+  }
+  *out = r;
+  return 0;
+}
+
+int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, const float* mean, const float* std, const float* values,
+                   float* actions_out, void* stream) {
+  if (!r || !obs || !critic_obs || !mean || !std || !values || !actions_out) return fail("NULL argument");
+  if (r->step >= r->T) return fail("rollout storage overflow: call rl_rollout_clear after num_steps transitions");
+  if (r->acted) return fail("rl_rollout_act called twice without rl_rollout_record");
+  HIP_OK(hipSetDevice(r->device));
+  ActArgs a;
+  const int t = r->step;
+  a.obs = obs; a.critic_obs = critic_obs; a.mean = mean; a.std = std; a.values = values; a.actions_out = actions_out;
+  a.s_obs = slot<float>(r, RL_RO_OBS, t); a.s_critic = slot<float>(r, RL_RO_CRITIC_OBS, t); a.s_actions = slot<float>(r, RL_RO_ACTIONS, t);
+  a.s_mu = slot<float>(r, RL_RO_MU, t); a.s_sigma = slot<float>(r, RL_RO_SIGMA, t); a.s_logp = slot<float>(r, RL_RO_LOG_PROB, t);
+  a.s_values = slot<float>(r, RL_RO_VALUES, t);
+  a.N = r->N; a.obs_dim = r->obs_dim; a.critic_dim = r->critic_dim; a.act_dim = r->act_dim; a.seed = r->seed; a.counter = r->counter;
+  // 4 float4 per thread of the copy blocks
+  a.copy_blocks_obs = std::max(1, blocks_for(((size_t)r->N * r->obs_dim) >> 4));
+  a.copy_blocks_critic = std::max(1, blocks_for(((size_t)r->N * r->critic_dim) >> 4));
+  a.sample_blocks = blocks_for((size_t)r->N);
+  hipLaunchKernelGGL(act_kernel, dim3(a.copy_blocks_obs + a.copy_blocks_critic + a.sample_blocks), dim3(BLOCK), 0, (hipStream_t)stream, a);
+  HIP_OK(hipGetLastError());
+  r->acted = true;
+  return 0;
+}
+
+int rl_rollout_record(rl_rollout* r, const float* rewards, const uint8_t* terminated, const uint8_t* time_outs, float gamma, void* stream) {
+  if (!r || !rewards || !terminated || !time_outs) return fail("NULL argument");
+  if (!r->acted) return fail("rl_rollout_record needs rl_rollout_act for this step first");
+  HIP_OK(hipSetDevice(r->device));
+  const int t = r->step;
+  hipLaunchKernelGGL(record_kernel, dim3(blocks_for((size_t)r->N)), dim3(BLOCK), 0, (hipStream_t)stream, rewards, terminated, time_outs,
+                     slot<float>(r, RL_RO_VALUES, t), slot<float>(r, RL_RO_REWARDS, t), slot<uint8_t>(r, RL_RO_DONES, t), gamma, r->N);
+  HIP_OK(hipGetLastError());
+  r->acted = false;
+  r->step += 1;
+  r->counter += 1;
+  return 0;
+}
+
+int rl_rollout_compute_returns(rl_rollout* r, const float* last_values, float gamma, float lam, int32_t normalize_advantage, void* stream) {
+  if (!r || !last_values) return fail("NULL argument");
+  if (r->step != r->T || r->acted) return fail("compute_returns needs a full storage (num_steps recorded transitions)");
+  HIP_OK(hipSetDevice(r->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = blocks_for((size_t)r->N);
+  const size_t count = (size_t)r->T * r->N;
+  hipLaunchKernelGGL(gae_kernel, dim3(nb), dim3(BLOCK), 0, s, (const float*)r->buf[RL_RO_REWARDS], (const float*)r->buf[RL_RO_VALUES],
+                     (const uint8_t*)r->buf[RL_RO_DONES], last_values, (float*)r->buf[RL_RO_RETURNS], (float*)r->buf[RL_RO_ADVANTAGES], r->partial_sum,
+                     gamma, lam, r->T, r->N);
+  if (normalize_advantage) {
+    const int nbv = std::min(256, std::max(1, blocks_for(count >> 2)));  // every thread re-sums the partials: keep them few
+    hipLaunchKernelGGL(var_kernel, dim3(nbv), dim3(BLOCK), 0, s, (const float*)r->buf[RL_RO_ADVANTAGES], r->partial_sum, r->partial_sq, nb, count);
+    hipLaunchKernelGGL(norm_kernel, dim3(nbv), dim3(BLOCK), 0, s, (float*)r->buf[RL_RO_ADVANTAGES], r->partial_sum, r->partial_sq, nb, nbv, count);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int rl_rollout_clear(rl_rollout* r) {
+  if (!r) return fail("NULL handle");
+  r->step = 0;
+  r->acted = false;
+  return 0;
+}
+
+int rl_rollout_get_buffer(rl_rollout* r, int32_t which, void** dev_ptr, int64_t* count) {
+  if (!r || which < 0 || which >= RL_RO_NUM_BUFFERS) return fail("unknown buffer");
+  if (dev_ptr) *dev_ptr = r->buf[which];
+  if (count) *count = r->count[which];
+  return 0;
+}
+
+int32_t rl_rollout_step(const rl_rollout* r) { return r ? r->step : -1; }
+
+int rl_rollout_destroy(rl_rollout* r) {
+  if (!r) return 0;
+  for (void* p : r->buf)
+    if (p) (void)hipFree(p);
+  if (r->partial_sum) (void)hipFree(r->partial_sum);
+  if (r->partial_sq) (void)hipFree(r->partial_sq);
+  delete r;
+  return 0;
+}
+
+}  // extern "C"
