@@ -37,6 +37,12 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
 /* y[n_rows][dims[n_layers]] = MLP(x[n_rows][dims[0]]); x, y: device pointers, row-major; stream-ordered. */
 int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream);
 
+/* Two networks over the same n_rows rows in one launch (the actor and the critic of a rollout step,
+ * train.py:206-224 -> rsl_rl PPO.act: `policy.act(obs)` and `policy.evaluate(privileged_obs)` back to back):
+ * ya = A(xa), yb = B(xb).  Same results as two rl_mlp_forward calls; the two networks' workgroups share the CUs. */
+int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b, const float* xb_dev, float* yb_dev, int32_t n_rows,
+                        void* stream);
+
 int32_t rl_mlp_in_dim(const rl_mlp* m);
 int32_t rl_mlp_out_dim(const rl_mlp* m);
 int rl_mlp_destroy(rl_mlp* m);

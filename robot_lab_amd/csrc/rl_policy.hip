@@ -114,12 +114,12 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpParams P, const float* __restrict__ x, float* __restrict__ y, int n_rows) {
+__device__ __forceinline__ void mlp_tile(const MlpParams& P, const float* __restrict__ x, float* __restrict__ y, int n_rows, int tile) {
   extern __shared__ float4 smem4[];  // two [16 x KMAX] fragment-major activation tiles: 64 KB
   float* buf0 = reinterpret_cast<float*>(smem4);
   float* buf1 = buf0 + MT * KMAX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * MT;
+  const int row0 = tile * MT;
   const int K0 = P.KB[0] * 16;
   for (int i = tid; i < MT * K0; i += 256) {  // input tile -> LDS (zero fill of the k padding and of rows past the end)
     const int r = i / K0, c = i - r * K0;
@@ -143,6 +143,25 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpParams P, const flo
   }
 }
 
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpParams P, const float* __restrict__ x, float* __restrict__ y, int n_rows) {
+  mlp_tile(P, x, y, n_rows, blockIdx.x);
+}
+
+// Two networks over the same rows in ONE launch (actor + critic of a rollout step): workgroup 2 i runs network A on
+// row tile i, workgroup 2 i + 1 network B.  A 4096-row call of one network is 256 workgroups = one per CU = one
+// wavefront per SIMD, which cannot hide the L2 latency of the weight stream behind its own MFMAs (the 65536-row call
+// runs 1.55x faster per row with two workgroups resident per CU); the pair puts 512 workgroups on the chip.
+struct MlpPair {
+  const MlpParams *a, *b;  // device copies
+  const float *xa, *xb;
+  float *ya, *yb;
+};
+__global__ __launch_bounds__(256) void mlp_forward_pair_kernel(MlpPair q, int n_rows) {
+  const bool second = blockIdx.x & 1;
+  const MlpParams& P = *(second ? q.b : q.a);  // workgroup-uniform address: the fields arrive by scalar loads
+  mlp_tile(P, second ? q.xb : q.xa, second ? q.yb : q.ya, n_rows, blockIdx.x >> 1);
+}
+
 std::string& err() {
   static thread_local std::string e;
   return e;
@@ -156,6 +175,7 @@ int fail(const std::string& m) {
 
 struct rl_mlp {
   MlpParams P;
+  MlpParams* dP = nullptr;  // device copy (rl_mlp_forward_pair)
   std::vector<void*> allocs;
 };
 
@@ -197,8 +217,32 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
     (void)hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
     m->P.W[l] = (const float*)dW; m->P.b[l] = (const float*)db;
   }
+  void* dP = nullptr;
+  if (hipMalloc(&dP, sizeof(MlpParams)) != hipSuccess) {
+    rl_mlp_destroy(m);
+    return fail("device allocation failed");
+  }
+  m->allocs.push_back(dP);
+  (void)hipMemcpy(dP, &m->P, sizeof(MlpParams), hipMemcpyHostToDevice);
+  m->dP = (MlpParams*)dP;
   *out = m;
   return 0;
+}
+
+int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b, const float* xb_dev, float* yb_dev, int32_t n_rows, void* stream) {
+  if (!a || !b || !xa_dev || !ya_dev || !xb_dev || !yb_dev) return fail("null argument");
+  if (n_rows <= 0) return 0;
+  constexpr size_t lds = sizeof(float) * 2 * MT * KMAX;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail("cannot reserve 64 KB of LDS");
+    attr_done = true;
+  }
+  MlpPair q{a->dP, b->dP, xa_dev, xb_dev, ya_dev, yb_dev};
+  hipLaunchKernelGGL(mlp_forward_pair_kernel, dim3(2 * ((n_rows + MT - 1) / MT)), dim3(256), lds, (hipStream_t)stream, q, n_rows);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
 }
 
 int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream) {

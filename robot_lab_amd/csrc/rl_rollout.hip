@@ -5,7 +5,7 @@
 // 3 x 12 action-sized rows, 5 scalars), so the kernels are plain coalesced streams:
 //   act      one launch: the first blocks copy the two observation batches into slot t as flat 16-byte streams, the
 //            rest draw the actions (one thread per env x 4-action Philox block: 4 uniforms -> 4 normals by Box-Muller)
-//            and one thread per env reduces the log-probability
+//            and reduce the log-probability of an env through LDS
 //   record   one thread per env
 //   returns  one thread per env walks its T values backwards ([T][N] arrays: every step is a coalesced row), block
 //            partial sums feed the advantage normalisation; the partials are summed in a fixed order by every block
@@ -83,18 +83,21 @@ __global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
     return;
   }
   b -= a.copy_blocks_critic;
-  // one thread per env: act_dim is 12 .. 29, a row of mean is 48 .. 116 contiguous bytes
-  const int e = b * BLOCK + threadIdx.x;
-  if (e >= a.N) return;
-  const int A = a.act_dim;
-  const float* mu = a.mean + (size_t)e * A;
+  // one thread per (env, Philox block of 4 actions): a block of 256 threads covers 256 / nblk envs; the log-probability
+  // partials of an env meet in LDS (one thread per env alone left 16 workgroups walking 3 Philox blocks each: 9.7 us)
+  __shared__ float part[BLOCK];
+  const int A = a.act_dim, nblk = (A + 3) >> 2, epb = BLOCK / nblk;
+  const int el = threadIdx.x / nblk, blk = threadIdx.x - el * nblk;
+  const int e = b * epb + el;
+  const bool live = el < epb && e < a.N;
   float logp = 0.f;
-  for (int j0 = 0; j0 < A; j0 += 4) {
+  if (live) {
+    const float* mu = a.mean + (size_t)e * A;
     float z[4];
-    normal4(a.seed, (uint32_t)e, a.counter, (uint32_t)(j0 >> 2), z);
+    normal4(a.seed, (uint32_t)e, a.counter, (uint32_t)blk, z);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = j0 + i;
+      const int j = 4 * blk + i;
       if (j >= A) break;
       const float m = mu[j], sd = a.std[j];
       const float act = m + sd * z[i];
@@ -107,8 +110,14 @@ __global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
       a.s_sigma[o] = sd;
     }
   }
-  a.s_logp[e] = logp;
-  a.s_values[e] = a.values[e];
+  part[threadIdx.x] = logp;
+  __syncthreads();
+  if (live && blk == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nblk; ++i) s += part[threadIdx.x + i];  // fixed order: blocks 0, 1, ...
+    a.s_logp[e] = s;
+    a.s_values[e] = a.values[e];
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void record_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
@@ -225,6 +234,7 @@ int rl_rollout_create(int32_t num_envs, int32_t num_steps, int32_t obs_dim, int3
                       rl_rollout** out) {
   if (!out) return fail("out is NULL");
   if (num_envs < 1 || num_steps < 1 || obs_dim < 1 || critic_dim < 1 || act_dim < 1) return fail("sizes must be positive");
+  if (act_dim > 4 * BLOCK) return fail("act_dim above 1024");
   if (blocks_for((size_t)num_envs) > MAX_PARTIALS) return fail("num_envs too large for the reduction scratch");
   HIP_OK(hipSetDevice(device));
   rl_rollout* r = new rl_rollout();
@@ -261,7 +271,8 @@ int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, con
   // 4 float4 per thread of the copy blocks
   a.copy_blocks_obs = std::max(1, blocks_for(((size_t)r->N * r->obs_dim) >> 4));
   a.copy_blocks_critic = std::max(1, blocks_for(((size_t)r->N * r->critic_dim) >> 4));
-  a.sample_blocks = blocks_for((size_t)r->N);
+  const int envs_per_block = BLOCK / ((r->act_dim + 3) / 4);
+  a.sample_blocks = (r->N + envs_per_block - 1) / envs_per_block;
   hipLaunchKernelGGL(act_kernel, dim3(a.copy_blocks_obs + a.copy_blocks_critic + a.sample_blocks), dim3(BLOCK), 0, (hipStream_t)stream, a);
   HIP_OK(hipGetLastError());
   r->acted = true;

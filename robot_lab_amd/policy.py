@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 POLICY_LIB = os.path.join(_HERE, "csrc", "librl_policy_hip.so")
-POLICY_EXPORTS = ["rl_mlp_create", "rl_mlp_forward", "rl_mlp_in_dim", "rl_mlp_out_dim", "rl_mlp_destroy", "rl_mlp_last_error"]
+POLICY_EXPORTS = ["rl_mlp_create", "rl_mlp_forward", "rl_mlp_forward_pair", "rl_mlp_in_dim", "rl_mlp_out_dim", "rl_mlp_destroy", "rl_mlp_last_error"]
 ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2}
 _lib = None
 
@@ -36,6 +36,7 @@ def load_policy_library(path: str | None = None) -> C.CDLL:
     fpp = C.POINTER(C.POINTER(C.c_float))
     lib.rl_mlp_create.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, fpp, fpp, C.c_int32, C.POINTER(C.c_void_p)]
     lib.rl_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rl_mlp_forward_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rl_mlp_in_dim.argtypes = [C.c_void_p]
     lib.rl_mlp_out_dim.argtypes = [C.c_void_p]
     lib.rl_mlp_destroy.argtypes = [C.c_void_p]
@@ -78,11 +79,8 @@ class MlpPolicy:
         to_np = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)  # noqa: E731
         return cls([to_np(sd[f"{prefix}.{i}.weight"]) for i in idx], [to_np(sd[f"{prefix}.{i}.bias"]) for i in idx], activation, **kw)
 
-    def __call__(self, obs):
-        """obs: float32 device tensor [N, in_dim] (or a dict / TensorDict with a "policy" entry, as rsl_rl passes)."""
+    def _prepare(self, obs):
         torch = self._torch
-        if not torch.is_tensor(obs):
-            obs = obs["policy"]
         if obs.device != self.device or obs.dtype != torch.float32 or not obs.is_contiguous():
             obs = obs.to(device=self.device, dtype=torch.float32).contiguous()
         if obs.ndim != 2 or obs.shape[1] != self.in_dim:
@@ -90,6 +88,27 @@ class MlpPolicy:
         n = obs.shape[0]
         if self._out is None or self._out.shape[0] != n:
             self._out = torch.empty(n, self.out_dim, device=self.device, dtype=torch.float32)
+        return obs, n
+
+    def forward_pair(self, obs, other: "MlpPolicy", other_obs):
+        """(self(obs), other(other_obs)) from ONE kernel launch - the actor and the critic of a rollout step
+        (rsl_rl PPO.act: `policy.act(obs)` then `policy.evaluate(privileged_obs)`); both batches have the same row count."""
+        obs, n = self._prepare(obs)
+        other_obs, n2 = other._prepare(other_obs)
+        if n != n2 or other.device != self.device:
+            raise ValueError("forward_pair needs two batches of the same row count on the same device")
+        stream = self._torch.cuda.current_stream(self.device).cuda_stream
+        if self.lib.rl_mlp_forward_pair(self.handle, C.c_void_p(obs.data_ptr()), C.c_void_p(self._out.data_ptr()), other.handle,
+                                        C.c_void_p(other_obs.data_ptr()), C.c_void_p(other._out.data_ptr()), n, C.c_void_p(stream)) != 0:
+            raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
+        return self._out, other._out
+
+    def __call__(self, obs):
+        """obs: float32 device tensor [N, in_dim] (or a dict / TensorDict with a "policy" entry, as rsl_rl passes)."""
+        torch = self._torch
+        if not torch.is_tensor(obs):
+            obs = obs["policy"]
+        obs, n = self._prepare(obs)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.lib.rl_mlp_forward(self.handle, C.c_void_p(obs.data_ptr()), C.c_void_p(self._out.data_ptr()), n, C.c_void_p(stream)) != 0:
             raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())

@@ -89,3 +89,25 @@ def test_hip_mlp_from_rsl_rl_state_dict_and_env_obs():
         obs, *_ = env.step(act.clamp(-1, 1))
     env.close()
     pol.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [4096, 37])
+def test_hip_mlp_pair_is_bitwise_the_two_single_launches(N):
+    """rl_mlp_forward_pair (actor + critic in one launch) = the same row tiles through the same code: identical bits."""
+    import torch
+
+    from robot_lab_amd.policy import MlpPolicy
+
+    wa, ba = _net([45, 512, 256, 128, 12], 5)
+    wc, bc = _net([235, 512, 256, 128, 1], 6)
+    actor, critic = MlpPolicy(wa, ba, "elu", device="cuda:0"), MlpPolicy(wc, bc, "elu", device="cuda:0")
+    rng = np.random.default_rng(7)
+    xo = torch.from_numpy(rng.uniform(-2, 2, (N, 45)).astype(np.float32)).cuda()
+    xc = torch.from_numpy(rng.uniform(-2, 2, (N, 235)).astype(np.float32)).cuda()
+    ya, yc = actor(xo).clone(), critic(xc).clone()
+    pa, pc = actor.forward_pair(xo, critic, xc)
+    assert torch.equal(pa, ya) and torch.equal(pc, yc)
+    np.testing.assert_allclose(pc.cpu().numpy(), mlp_forward(xc.cpu().numpy(), wc, bc, "elu"), rtol=2e-5, atol=2e-5)
+    actor.close()
+    critic.close()

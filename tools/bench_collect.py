@@ -22,6 +22,7 @@ task = sys.argv[1] if len(sys.argv) > 1 else "RobotLab-Isaac-Velocity-Rough-Unit
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 T, GAMMA, LAM = 24, 0.99, 0.95  # rsl_rl_ppo_cfg.py:11,33-34
+PAIR = os.environ.get("RL_PAIR", "1") == "1"  # actor + critic in one launch (rl_mlp_forward_pair)
 env = ManagerBasedRLEnv(task, num_envs=N, seed=42, device="cuda:0")
 obs, _ = env.reset()
 od, cd, A = obs["policy"].shape[1], obs["critic"].shape[1], env.num_actions
@@ -41,7 +42,8 @@ storage = RolloutStorage(N, T, od, cd, A, seed=1, device="cuda:0")
 def iteration(obs):
     storage.clear()
     for _ in range(T):
-        actions = storage.act(obs["policy"], obs["critic"], actor(obs["policy"]), std, critic(obs["critic"]))
+        mean, values = actor.forward_pair(obs["policy"], critic, obs["critic"]) if PAIR else (actor(obs["policy"]), critic(obs["critic"]))
+        actions = storage.act(obs["policy"], obs["critic"], mean, std, values)
         obs, rew, term, tout, extras = env.step(actions)
         storage.process_env_step(rew, term, tout, GAMMA)
     storage.compute_returns(critic(obs["critic"]), GAMMA, LAM)
