@@ -102,7 +102,7 @@ def main():
     kernel_ms = e0.elapsed_time(e1) / KREP
 
     # the one collective of the path: packed episode-metric vector, off the timed region
-    log_vec = env._bufs["LOG"].clone()
+    log_vec = env._bufs["LOG"][native.log_slot()].clone()  # the last step's ring slot
     if world > 1:
         dist.all_reduce(log_vec, op=dist.ReduceOp.SUM)
 

@@ -244,7 +244,8 @@ enum rl_buffer {
   RL_BUF_COMMAND = 11,     /* float [N, 3] */
   RL_BUF_CONTACT_FORCE = 12, /* float [N, B, 3] net_forces_w of the last substep (inspection view: see rl_env_get_buffer) */
   RL_BUF_CONTACT_TIMERS = 13, /* float [N, B, 4] current_air, current_contact, last_air, last_contact */
-  RL_BUF_LOG = 14,         /* float [RL_LOG_SIZE] device-side episode log accumulators */
+  RL_BUF_LOG = 14,         /* float [RL_LOG_RING][RL_LOG_SIZE] device-side episode log: step k accumulates into slot
+                              k % RL_LOG_RING, which step k - 1 zeroed (see rl_env_log_slot) */
   RL_BUF_ACTION = 15,      /* float [N, A] last (raw) action */
   RL_BUF_JOINT_TORQUE = 16,/* float [N, D] applied torque of the last substep */
   RL_BUF_JOINT_ACC = 17,   /* float [N, D] */
@@ -254,6 +255,7 @@ enum rl_buffer {
 };
 
 #define RL_LOG_SIZE 64
+#define RL_LOG_RING 64 /* a step's log stays readable until RL_LOG_RING - 2 further steps have been launched */
 
 typedef struct rl_env rl_env; /* opaque */
 
@@ -288,8 +290,11 @@ int rl_env_export_state(rl_env* env, void* stream);
 int rl_env_import_state(rl_env* env, const float* root_state, const float* joint_pos,
                         const float* joint_vel, void* stream);
 
-/* Copies the RL_LOG_SIZE episode-log accumulators to host and zeroes them (synchronises `stream`). */
+/* Copies the RL_LOG_SIZE episode-log accumulators of the LAST step (what the reference rebuilds as extras["log"] on
+ * every step() that resets an env: manager_based_rl_env.py [UPSTREAM B1]) to host and zeroes them (synchronises `stream`). */
 int rl_env_read_log(rl_env* env, float* out_host, void* stream);
+/* Ring slot of RL_BUF_LOG the last step() wrote (= steps so far % RL_LOG_RING); device readers use it to avoid the copy. */
+int32_t rl_env_log_slot(const rl_env* env);
 
 int32_t rl_env_num_envs(const rl_env* env);
 int32_t rl_env_num_actions(const rl_env* env);

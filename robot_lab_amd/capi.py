@@ -18,7 +18,7 @@ HIP_LIB = os.path.join(_HERE, "csrc", "librl_env_hip.so")
 
 EXPORTS = [
     "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_get_buffer", "rl_env_export_state", "rl_env_import_state",
-    "rl_env_read_log", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length",
+    "rl_env_read_log", "rl_env_log_slot", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length",
     "rl_env_destroy", "rl_env_last_error", "rl_env_desc_size",
 ]
 
@@ -46,6 +46,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rl_env_export_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.rl_env_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rl_env_read_log.argtypes = [C.c_void_p, fp, C.c_void_p]
+    lib.rl_env_log_slot.argtypes = [C.c_void_p]
+    lib.rl_env_log_slot.restype = C.c_int32
     for n in ("rl_env_num_envs", "rl_env_num_actions", "rl_env_max_episode_length"):
         getattr(lib, n).argtypes = [C.c_void_p]
         getattr(lib, n).restype = C.c_int32
@@ -125,6 +127,9 @@ class NativeEnv:
         out = np.zeros(RL_LOG_SIZE, dtype=np.float32)
         self._check(self.lib.rl_env_read_log(self.handle, out.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(stream)))
         return out
+
+    def log_slot(self) -> int:
+        return int(self.lib.rl_env_log_slot(self.handle))
 
     def close(self):
         if self.handle:

@@ -37,6 +37,7 @@ constexpr int MAX_OBS = 12;
 constexpr int MAX_BASE_BODIES = 4;
 constexpr int ENVS_PER_WAVE = 16;
 constexpr int LOG_SIZE = 64;
+constexpr int LOG_RING = 64;  // step k logs into slot k % LOG_RING (one slot = one step's extras["log"]); power of two
 // log accumulator slots (device LOG buffer)
 enum { LOG_RESET_COUNT = 0, LOG_TERM_TIMEOUT = 1, LOG_TERM_OOB = 2, LOG_TERM_ILLEGAL = 3, LOG_METRIC_XY = 4, LOG_METRIC_YAW = 5, LOG_EP_SUM0 = 8 };
 
@@ -232,7 +233,7 @@ struct KState {
   uint8_t *terminated, *time_out;  // [Npad]
   float* rew_terms;                // [MAX_T][Npad]
   float* command_out;              // [Npad][3]
-  float* log;                      // [LOG_SIZE]
+  float* log;                      // [LOG_RING][LOG_SIZE]
   // optional inspection buffers (nullptr = skip)
   float *dbg_torque, *dbg_acc;     // [Npad][D]
   float* dbg_cforce;               // [Npad][B][3]

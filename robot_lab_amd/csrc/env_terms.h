@@ -193,13 +193,13 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // manager resets: episode-sum log + zero, command metrics log + resample, interval timer
     for (int t = li; t < T.n_rewards; t += LPE) {
       float* p = S.ep_sums + (size_t)t * Np + e;
-      if (log_episode && e < S.N) ctx.atomic_add(S.log + LOG_EP_SUM0 + t, *p);
+      if (log_episode && e < S.N) ctx.atomic_add(log_slot() + LOG_EP_SUM0 + t, *p);
       *p = 0.f;
     }
     if (li == 0 && log_episode && e < S.N) {
-      ctx.atomic_add(S.log + LOG_RESET_COUNT, 1.0f);
-      ctx.atomic_add(S.log + LOG_METRIC_XY, metric_xy);
-      ctx.atomic_add(S.log + LOG_METRIC_YAW, metric_yaw);
+      ctx.atomic_add(log_slot() + LOG_RESET_COUNT, 1.0f);
+      ctx.atomic_add(log_slot() + LOG_METRIC_XY, metric_xy);
+      ctx.atomic_add(log_slot() + LOG_METRIC_YAW, metric_yaw);
     }
     metric_xy = 0.f;
     metric_yaw = 0.f;
@@ -745,8 +745,16 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
   }
 
+  // episode log of THIS step: slot step_counter % LOG_RING.  Every step starts from a slot the previous step zeroed, so a
+  // slot is what the reference rebuilds as extras["log"] on every call - no snapshot + memset between steps on the host
+  RL_FN float* log_slot() const { return S.log + (S.step_counter & (uint32_t)(LOG_RING - 1)) * LOG_SIZE; }
+
   // ---------------------------------------------------------------- step()
   RL_FN void step() {
+    if (e == 0) {  // the lanes of env 0 clear the next step's slot (nobody writes it during this launch)
+      float* nx = S.log + ((S.step_counter + 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SIZE;
+      for (int i = li; i < LOG_SIZE; i += LPE) nx[i] = 0.f;
+    }
     this->load();
     load_task();  // same batch of HBM loads as the state: one round trip instead of a second one after the substeps
     // 1 ActionManager.process_action [UPSTREAM B2]; JointPosition/VelocityAction (velocity_env_cfg.py:124-126)
@@ -791,9 +799,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // 6 reset done envs
     if (terminated || time_out) {
       if (li == 0 && e < S.N) {
-        if (t_timeout) ctx.atomic_add(S.log + LOG_TERM_TIMEOUT, 1.f);
-        if (t_oob) ctx.atomic_add(S.log + LOG_TERM_OOB, 1.f);
-        if (t_illegal) ctx.atomic_add(S.log + LOG_TERM_ILLEGAL, 1.f);
+        if (t_timeout) ctx.atomic_add(log_slot() + LOG_TERM_TIMEOUT, 1.f);
+        if (t_oob) ctx.atomic_add(log_slot() + LOG_TERM_OOB, 1.f);
+        if (t_illegal) ctx.atomic_add(log_slot() + LOG_TERM_ILLEGAL, 1.f);
       }
       reset_env(true);
       derive();

@@ -52,7 +52,7 @@ int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[
     case RL_BUF_COMMAND: return set(I.S.command_out, 2, N, 3, 1, 4);
     case RL_BUF_CONTACT_FORCE: return set(I.S.dbg_cforce, 3, N, B, 3, 4);
     case RL_BUF_CONTACT_TIMERS: return set(I.ctimers, 3, N, B, 4, 4);
-    case RL_BUF_LOG: return set(I.S.log, 1, RL_LOG_SIZE, 1, 1, 4);
+    case RL_BUF_LOG: return set(I.S.log, 2, RL_LOG_RING, RL_LOG_SIZE, 1, 4);
     case RL_BUF_ACTION: return set(I.action_aos, 2, N, D, 1, 4);
     case RL_BUF_JOINT_TORQUE: return set(I.S.dbg_torque, 2, N, D, 1, 4);
     case RL_BUF_JOINT_ACC: return set(I.S.dbg_acc, 2, N, D, 1, 4);
@@ -78,7 +78,12 @@ int rl_env_import_state(rl_env* env, const float* root_state, const float* joint
 int rl_env_read_log(rl_env* env, float* out_host, void* stream) {
   if (!env || !out_host) return rl::fail("null argument");
   Impl& I = *reinterpret_cast<Impl*>(env);
-  return I.be.read_and_zero(out_host, I.S.log, RL_LOG_SIZE * sizeof(float), stream) ? rl::fail("log read failed: " + I.be.error()) : 0;
+  float* slot = I.S.log + (size_t)(I.step_counter & (uint32_t)(RL_LOG_RING - 1)) * RL_LOG_SIZE;  // the last step's slot
+  return I.be.read_and_zero(out_host, slot, RL_LOG_SIZE * sizeof(float), stream) ? rl::fail("log read failed: " + I.be.error()) : 0;
+}
+
+int32_t rl_env_log_slot(const rl_env* env) {
+  return env ? (int32_t)(reinterpret_cast<const Impl*>(env)->step_counter & (uint32_t)(RL_LOG_RING - 1)) : -1;
 }
 
 int32_t rl_env_num_envs(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->N; }

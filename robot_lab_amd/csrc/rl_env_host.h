@@ -377,7 +377,7 @@ struct EnvImpl {
     S.obs_policy = alloc<float>(Np * (size_t)std::max(1, tables.policy_dim));
     S.obs_critic = alloc<float>(Np * (size_t)std::max(1, tables.critic_dim));
     S.reward = alloc<float>(Np); S.terminated = alloc<uint8_t>(Np); S.time_out = alloc<uint8_t>(Np);
-    S.rew_terms = alloc<float>(MAX_T * Np); S.command_out = alloc<float>(3 * Np); S.log = alloc<float>(LOG_SIZE);
+    S.rew_terms = alloc<float>(MAX_T * Np); S.command_out = alloc<float>(3 * Np); S.log = alloc<float>(LOG_RING * LOG_SIZE);
     root_state = alloc<float>(Np * 13); joint_pos = alloc<float>(Np * D); joint_vel = alloc<float>(Np * D);
     ctimers = alloc<float>(Np * B * 4); action_aos = alloc<float>(Np * D); env_origin_aos = alloc<float>(Np * 3);
     reset_mask = alloc<uint8_t>(Np);

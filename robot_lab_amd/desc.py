@@ -20,6 +20,7 @@ RL_MAX_REWARD_TERMS = 40
 RL_MAX_OBS_TERMS = 12
 RL_TERM_NPARAM = 8
 RL_LOG_SIZE = 64
+RL_LOG_RING = 64
 
 REWARD_KINDS = [
     "track_lin_vel_xy_exp", "track_ang_vel_z_exp", "lin_vel_z_l2", "ang_vel_xy_l2", "joint_torques_l2",

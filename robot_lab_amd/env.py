@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from .capi import NativeEnv, RlEnvError
-from .desc import RL_LOG_SIZE, EnvDesc
+from .desc import RL_LOG_RING, RL_LOG_SIZE, EnvDesc
 from .scene import build_world, load_bundle
 
 try:  # gymnasium (or the shim in robot_lab_amd/shims) supplies Env / spaces when available
@@ -68,15 +68,21 @@ class _LazyLog(dict):
     0-dim device tensors materialised on first access, so a training loop that only reads them at log
     time never forces a host sync inside `step()`."""
 
-    def __init__(self, env, snap):
+    def __init__(self, env, slot, step):
         super().__init__()
-        self._env, self._snap, self._done = env, snap, False
+        self._env, self._slot, self._step, self._done = env, slot, step, False
 
     def _fill(self):
         if self._done:
             return
+        e = self._env
+        # the kernel logs step k into ring slot k % RL_LOG_RING and clears the slot of step k + 1 (include/rl_env.h):
+        # this step's numbers are on the device, untouched, until RL_LOG_RING - 2 further steps have been launched
+        if e.common_step_counter - self._step > RL_LOG_RING - 2:
+            raise RuntimeError(f'extras["log"] of step {self._step} was read {e.common_step_counter - self._step} steps later: '
+                               f"the device keeps the last {RL_LOG_RING - 2} steps")
         self._done = True
-        e, s = self._env, self._snap
+        s = self._slot.clone()
         cnt = torch.clamp(s[0], min=1.0)
         for i, name in enumerate(e.desc.reward_names):
             dict.__setitem__(self, "Episode_Reward/" + name, s[8 + i] / cnt / e.max_episode_length_s)
@@ -293,10 +299,8 @@ class ManagerBasedRLEnv(_EnvBase):
             raise ValueError(f"action shape {tuple(action.shape)} != {(self.num_envs, self.num_actions)}")
         self._native.step(action.data_ptr(), self._stream())
         self.common_step_counter += 1
-        if self.log_episodes:
-            snap = self._bufs["LOG"].clone()
-            self._bufs["LOG"].zero_()
-            self.extras = {"log": _LazyLog(self, snap)}
+        if self.log_episodes:  # no snapshot, no memset: a view of this step's ring slot, cloned only if somebody reads it
+            self.extras = {"log": _LazyLog(self, self._bufs["LOG"][self._native.log_slot()], self.common_step_counter)}
         else:
             self.extras = {}
         return self._obs, self._bufs["REWARD"], self._terminated, self._time_outs, self.extras

@@ -115,3 +115,38 @@ def test_seeds_give_different_but_reproducible_episodes():
         obs.append(o["critic"].clone())
         env.close()
     assert torch.equal(obs[0], obs[1]) and not torch.equal(obs[0], obs[2])
+
+
+def test_episode_log_ring_keeps_a_step_readable_and_then_expires():
+    """extras["log"] is a view of the step's slot in the device-side log ring (include/rl_env.h RL_LOG_RING): it can
+    be read many steps later (rsl_rl keeps the dicts of an iteration and reads them at its end), it holds that
+    step's numbers only, and a read after the ring has wrapped fails instead of returning another step's log."""
+    from robot_lab_amd.desc import RL_LOG_RING
+
+    N = 64
+    env, ora, torch = _pair(N, 11)
+    env.reset()
+    ora.reset()
+    ep = np.zeros(N, dtype=np.int64)
+    ep[::4] = ora.max_episode_length - 2  # 16 envs time out at the second step
+    ora.episode_length_buf[:] = ep
+    env.episode_length_buf = torch.as_tensor(ep)
+    rng = np.random.default_rng(5)
+    kept, want = [], []
+    for s in range(RL_LOG_RING + 8):
+        a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
+        _, _, term, tout, extras = env.step(torch.from_numpy(a).cuda())
+        if s < 3:
+            ora.step(a)
+            kept.append(extras["log"])
+            want.append((int((ora.terminated | ora.time_outs).sum()), dict(ora.log) if (ora.terminated | ora.time_outs).any() else None))
+        if s == 30:  # 28-30 steps later: still this step's numbers
+            for lg, (ndone, olog) in zip(kept[:2], want[:2]):
+                if olog is not None:
+                    for name in ("Episode_Reward/track_lin_vel_xy_exp", "Episode_Reward/action_rate_l2"):
+                        np.testing.assert_allclose(float(lg[name]), olog[name], rtol=2e-3, atol=1e-6)
+            assert want[1][0] >= 16 and float(kept[1]["Episode_Termination/time_out"]) == 16.0
+    with pytest.raises(RuntimeError, match="steps later"):
+        kept[2]["Episode_Termination/time_out"]  # never read inside the window: gone
+    assert float(kept[1]["Episode_Termination/time_out"]) == 16.0  # materialised at step 30: stays
+    env.close()
