@@ -231,10 +231,26 @@ struct LsRow {
   float* p;
   RL_FN float& operator[](int t) const { return p[t * STRIDE]; }
 };
-template <int STRIDE, int W>
+// Rows are indexed by BODY SLOT.  In the 16-lane mapping a lane only ever touches the <= NOWN slots it owns (the
+// slots of the link groups it evaluates), so the scratchpad holds NOWN rows and `at` turns a slot into its place in
+// the lane's ascending `own[]` list (rows of slots the lane does not own alias row 0: they are only read under a mask).
+// NOWN == 0: one row per slot (a lane is a whole leg).
+template <int STRIDE, int W, int NOWN>
 struct LsMat {
   float* p;
-  RL_FN LsRow<STRIDE, W> operator[](int b) const { return {p + b * W * STRIDE}; }
+  int own[NOWN > 0 ? NOWN : 1];  // copy of the lane's own[] (by value: a pointer into the lane object would pin it in memory)
+  RL_FN void set_own(const int* o) {
+#pragma unroll
+    for (int j = 0; j < (NOWN > 0 ? NOWN : 1); ++j) own[j] = NOWN > 0 ? o[j] : 0;
+  }
+  RL_FN int at(int b) const {
+    if (NOWN == 0) return b;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < NOWN; ++j) i += (own[j] == b) ? j : 0;
+    return i;
+  }
+  RL_FN LsRow<STRIDE, W> operator[](int b) const { return {p + at(b) * W * STRIDE}; }
 };
 // words of limb-shared LDS an instance needs (0 when it keeps everything in registers)
 template <class TP>
@@ -247,14 +263,15 @@ struct LbLayout {
 // pass after the solve does not re-evaluate them (quadrupeds in the 16-lane mapping; 4 workgroups x 40 KB of LDS
 // still share a CU)
 constexpr int CONTACT_WORDS = 10;
-template <int NBS, int STASH = 0>
-struct LsLayout {
-  enum { TIM = 0, HIST = TIM + NBS * 4, CF = HIST + NBS * 3, FRIC = CF + NBS * 3, CT = FRIC + NBS * 3, WORDS = CT + STASH * CONTACT_WORDS };
+template <int ROWS, int STASH = 0>
+struct LsLayout {  // ROWS sensor rows (timers 4, force history 3, last force 3, friction 3 words each) + the contact stash
+  enum { TIM = 0, HIST = TIM + ROWS * 4, CF = HIST + ROWS * 3, FRIC = CF + ROWS * 3, CT = FRIC + ROWS * 3, WORDS = CT + STASH * CONTACT_WORDS };
 };
 template <class TP, int SUB>
 struct LsFor {  // lane scratchpad layout of an instance
   static constexpr int STASH = (TP::NW == 0 && SUB > 1) ? TP::SPL : 0;  // (G1: the LDS goes to the per-link CRBA records instead)
-  using type = LsLayout<TP::NBS, STASH>;
+  static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::MAXOWN;      // 16-lane mapping: rows for the owned slots only
+  using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::MAXOWN), STASH>;
 };
 
 template <class Ctx, class TP>
@@ -298,14 +315,15 @@ struct EnvLane {
   // per-step scratch
   float tau_app[JX], qacc[JX];
   // contact-sensor state + friction in the lane-private LDS scratchpad
-  LsMat<LSS, 4> tim;     // [slot][current_air, current_contact, last_air, last_contact]
-  LsMat<LSS, 3> hist_n;  // [slot][|F| of the last three substeps, newest first]
-  LsMat<LSS, 3> cf;      // [slot][net contact force of the last substep, world]
-  LsMat<LSS, 3> fric;    // [slot][mu_s, mu_d, restitution]
+  static constexpr int NOWN = LsFor<TP, Ctx::SUB>::NOWN;
+  LsMat<LSS, 4, NOWN> tim;     // [slot][current_air, current_contact, last_air, last_contact]
+  LsMat<LSS, 3, NOWN> hist_n;  // [slot][|F| of the last three substeps, newest first]
+  LsMat<LSS, 3, NOWN> cf;      // [slot][net contact force of the last substep, world]
+  LsMat<LSS, 3, NOWN> fric;    // [slot][mu_s, mu_d, restitution]
 
   RL_FN EnvLane(Ctx& c, const KState& s)
-      : ctx(c), S(s), T(c.template tables<TablesT<TP>>()), L(c.template tables<TablesT<TP>>().lane[c.k()]), u(make_uni(c, c.template tables<TablesT<TP>>())), tim{c.lane_scratch() + LS::TIM * LSS}, hist_n{c.lane_scratch() + LS::HIST * LSS},
-        cf{c.lane_scratch() + LS::CF * LSS}, fric{c.lane_scratch() + LS::FRIC * LSS} {
+      : ctx(c), S(s), T(c.template tables<TablesT<TP>>()), L(c.template tables<TablesT<TP>>().lane[c.k()]), u(make_uni(c, c.template tables<TablesT<TP>>())), tim{c.lane_scratch() + LS::TIM * LSS, {}}, hist_n{c.lane_scratch() + LS::HIST * LSS, {}},
+        cf{c.lane_scratch() + LS::CF * LSS, {}}, fric{c.lane_scratch() + LS::FRIC * LSS, {}} {
     e = ctx.env();
     k = ctx.k();
     sub = ctx.sub();
@@ -313,6 +331,7 @@ struct EnvLane {
     Np = S.Npad;
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) own[i] = SUB == 1 ? i : L.own_slot[SUB == 1 ? 0 : sub][SUB == 1 ? 0 : i];
+    tim.set_own(own); hist_n.set_own(own); cf.set_own(own); fric.set_own(own);
     lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
     et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
   }

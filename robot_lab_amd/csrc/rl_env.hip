@@ -143,21 +143,31 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
     }
   }
   __syncthreads();
-  constexpr int TAB_F = (sizeof(Tables) + 15) / 16 * 4;
+  // LDS after the tables (only the staged bytes take room: the unused tail of the reward table is never touched):
+  //   lane scratchpad | limb-shared words | observation staging rows | reward stage
+  // On the instances with a contact stash (quadrupeds, 16 lanes per env) the staging rows and the reward stage live ON the
+  // stash words of the scratchpad when they fit: the stash is dead once the substeps are over and nothing before them
+  // touches the rows.  26 KB -> 20 KB per workgroup = 8 instead of 6 workgroups per CU.
+  const int TAB_F = (int)(S.table_bytes >> 2);
+  using LS = typename LsFor<TP, SUB>::type;
+  constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
   Ctx ctx;
   ctx.T = Tl;
   ctx.dim[0] = Tl->policy_dim;
   ctx.dim[1] = Tl->critic_dim;
-  ctx.stage[0] = smem + TAB_F;
-  ctx.stage[1] = ctx.stage[0] + ((Ctx::EPT * ctx.dim[0] + 3) & ~3);
+  const int s0w = (Ctx::EPT * ctx.dim[0] + 3) & ~3;
+  int s1w = (Ctx::EPT * ctx.dim[1] + 3) & ~3;
   {  // the staging rows double as limb-shared scratch inside the substeps (streaming CRBA): at least that big
-    const int s0w = (Ctx::EPT * ctx.dim[0] + 3) & ~3, need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
-    int s1w = (Ctx::EPT * ctx.dim[1] + 3) & ~3;
+    const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
     if (s0w + s1w < need) s1w = need - s0w;
-    ctx.lscratch = ctx.stage[1] + s1w;
   }
-  ctx.lbscratch = ctx.lscratch + LsFor<TP, SUB>::type::WORDS * 64;
-  ctx.rstage = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
+  ctx.lscratch = smem + TAB_F;
+  ctx.lbscratch = ctx.lscratch + LS::WORDS * 64;
+  float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
+  const bool alias = STASH_WORDS > 0 && s0w + s1w + Ctx::EPT * MAX_T <= STASH_WORDS;  // same rule as Backend::configure
+  ctx.stage[0] = alias ? ctx.lscratch + LS::CT * 64 : tail;
+  ctx.stage[1] = ctx.stage[0] + s0w;
+  ctx.rstage = ctx.stage[1] + s1w;
   ctx.lane = lane;
   EnvProgram<Ctx, TP> prog(ctx, S);
   if (RESET)
@@ -223,14 +233,17 @@ struct Backend {
   size_t lds_bytes = 0;
   int configure(const Tables& T) {  // dynamic LDS: tables + observation staging tiles + lane scratchpad + reward stage
     const size_t ept = 16 / sub;
-    size_t tab = (packed_size(T) + 15) / 16 * 16;
+    const size_t tab = staged_bytes(T);
     size_t s0 = (ept * T.policy_dim + 3) / 4 * 16;
     size_t s1 = (ept * T.critic_dim + 3) / 4 * 16;
     const size_t aux = T.NW > 0 ? (size_t)LbLayout<TopoG1>::AUX_WORDS * (64 / sub) * 4 : 0;
     if (s0 + s1 < aux) s1 = aux - s0;
     const size_t ls_words = T.NW > 0 ? LsFor<TopoG1, 4>::type::WORDS : (sub > 1 ? LsFor<TopoQuad3, 4>::type::WORDS : LsFor<TopoQuad3, 1>::type::WORDS);
     const size_t lb_words = T.NW > 0 ? LbLayout<TopoG1>::WORDS : 0;
-    lds_bytes = tab + s0 + s1 + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + ept * MAX_T * 4;
+    const size_t stash = (T.NW == 0 && sub > 1) ? (size_t)LsFor<TopoQuad3, 4>::STASH * CONTACT_WORDS * 64 * 4 : 0;
+    size_t rows = s0 + s1 + ept * MAX_T * 4;  // staging rows + reward stage: on the contact stash when they fit (env_kernel)
+    if (stash > 0 && rows <= stash) rows = 0;
+    lds_bytes = tab + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + rows;
     if (lds_bytes > 160 * 1024) {
       err = "observation rows do not fit the 160 KiB LDS of a CU";
       return -1;
