@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--task", type=str, default="RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=512)
-    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-steps", type=int, default=30)
     args = ap.parse_args()
 
     import torch
