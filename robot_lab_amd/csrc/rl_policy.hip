@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -25,7 +26,6 @@ namespace {
 
 constexpr int MT = 16;                              // rows per workgroup
 constexpr int KMAX = RL_MLP_MAX_WIDTH;              // widest layer
-constexpr int MAX_TPW = RL_MLP_MAX_WIDTH / 16 / 4;  // output tiles per wavefront
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,9 +34,9 @@ struct MlpParams {
   int in_dim, out_dim;
   int KB[RL_MLP_MAX_LAYERS];   // 16-deep k blocks of the layer's input (input width padded to 16)
   int N[RL_MLP_MAX_LAYERS];    // true output width
-  int TPW[RL_MLP_MAX_LAYERS];  // output tiles per wavefront (output width padded to 64 columns = 4 wavefronts x 16)
-  const float* W[RL_MLP_MAX_LAYERS];  // fragment-major weight image [KB][4 * TPW tiles][64 lanes][4 k-steps]
-  const float* b[RL_MLP_MAX_LAYERS];  // [64 * TPW]
+  int NT8[RL_MLP_MAX_LAYERS];  // groups of 8 output tiles (output width padded to 128 columns: 4 wavefronts x 2 or 8 x 1 tiles per group)
+  const float* W[RL_MLP_MAX_LAYERS];  // fragment-major weight image [KB][8 * NT8 tiles][64 lanes][4 k-steps]
+  const float* b[RL_MLP_MAX_LAYERS];  // [128 * NT8]
 };
 
 __device__ inline float activate(float v, int act) {
@@ -53,90 +53,116 @@ __device__ inline float activate(float v, int act) {
 // 16-byte slots (conflict-free).
 __device__ inline int lds_index(int row, int k) { return ((((k >> 4) * 4 + (k & 3)) * 16 + row) << 2) + ((k >> 2) & 3); }  // [kb][ak][row][s]
 
-template <int TPW>
+// TPW output tiles per wavefront, RT 16-row tiles per workgroup, WAVES wavefronts per workgroup (tile index of wavefront
+// w: w, w + WAVES, ...).  <RT 1, WAVES 4> is the 16-row kernel.  <RT 2, WAVES 8> reuses every weight fragment for two row
+// tiles with the same two wavefronts per SIMD as two resident 16-row workgroups: half the L2 -> CU weight stream per flop
+// (at 16 rows per workgroup every CU pulls ~32 B / cycle of weights at full MFMA rate, ~20 TB/s of L2 reads chip-wide).
+template <int TPW, int RT, int WAVES>
 __device__ inline void layer(const MlpParams& P, int l, const float* __restrict__ xin, float* __restrict__ xout, float* __restrict__ y, int row0,
                              int n_rows, int lane, int wave) {
   const int KB = P.KB[l];
-  constexpr int NT = 4 * TPW;
+  const int NT = 8 * P.NT8[l];     // tiles per k block in the weight image (>= WAVES * TPW: only the tiles that carry
+                                   // real or next-layer-padding columns are computed)
+  constexpr int TILE = MT * KMAX;  // floats of one 16-row LDS tile
   const bool last = l == P.n_layers - 1;
-  f32x4 acc[TPW];
+  f32x4 acc[RT][TPW];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;                                    // + kb * 64
-  const f32x4* wb = reinterpret_cast<const f32x4*>(P.W[l]) + (size_t)wave * 64 + lane;            // + (kb * NT + 4 t) * 64
-  // software pipeline, two k blocks deep: the operands of blocks kb + 1 and kb + 2 are in flight while block kb's 4 x TPW
-  // MFMAs issue (an L2 hit is ~600-800 cycles, a block's MFMAs are 128 x TPW cycles)
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;                                    // + kb * 64 (+ r * TILE / 4)
+  const f32x4* wb = reinterpret_cast<const f32x4*>(P.W[l]) + (size_t)wave * 64 + lane;            // + (kb * NT + WAVES t) * 64
+  // software pipeline, two k blocks deep: the operands of blocks kb + 1 and kb + 2 are in flight while block kb's
+  // 4 x TPW x RT MFMAs issue (an L2 hit is ~600-800 cycles, a block's MFMAs are 128 x TPW x RT cycles)
   auto load_b = [&](int kb, f32x4 (&b)[TPW]) {
     const int kc = kb < KB ? kb : KB - 1;  // clamped: the tail re-reads the last block instead of branching
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) b[t] = wb[((size_t)kc * NT + 4 * t) * 64];
+    for (int t = 0; t < TPW; ++t) b[t] = wb[((size_t)kc * NT + WAVES * t) * 64];
   };
   f32x4 b0[TPW], b1[TPW], b2[TPW];
   load_b(0, b0);
   load_b(1, b1);
-  auto mma = [&](const f32x4& a, const f32x4 (&b)[TPW]) {
+  auto mma = [&](int kb, const f32x4 (&b)[TPW]) {
+    f32x4 a[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) a[r] = xa[kb * 64 + r * (TILE / 4)];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][s], b[t][s], acc[r][t], 0, 0, 0);
   };
   int kb = 0;
   for (; kb + 3 <= KB; kb += 3) {  // rotate the three buffers by unrolling three blocks
     load_b(kb + 2, b2);
-    mma(xa[kb * 64], b0);
+    mma(kb, b0);
     load_b(kb + 3, b0);
-    mma(xa[(kb + 1) * 64], b1);
+    mma(kb + 1, b1);
     load_b(kb + 4, b1);
-    mma(xa[(kb + 2) * 64], b2);
+    mma(kb + 2, b2);
   }
   if (kb < KB) {
-    mma(xa[kb * 64], b0);
-    if (kb + 1 < KB) mma(xa[(kb + 1) * 64], b1);
+    mma(kb, b0);
+    if (kb + 1 < KB) mma(kb + 1, b1);
   }
   // epilogue: D[row = (lane >> 4) * 4 + reg][col = lane & 15] -> bias, activation -> next LDS tile / global
   const int col = lane & 15, rbase = (lane >> 4) * 4;
-  // lds_index(rbase + r, (wave + 4 t) * 16 + col) = lane-constant + 1024 t + 4 r
+  // lds_index(rbase + r, (wave + WAVES t) * 16 + col) = lane-constant + 256 WAVES t + 4 r
   const int obase = wave * 256 + (col & 3) * 64 + rbase * 4 + ((col >> 2) & 3);
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    const int n = (wave + 4 * t) * 16 + col;
+    const int n = (wave + WAVES * t) * 16 + col;
     const float bias = P.b[l][n];
     const bool valid = n < P.N[l];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = acc[t][r] + bias;
-      if (!last) {
-        xout[obase + 1024 * t + 4 * r] = valid ? activate(v, P.act) : 0.f;  // padded columns feed zeros into the next layer
-      } else if (valid && row0 + rbase + r < n_rows) {
-        y[(size_t)(row0 + rbase + r) * P.out_dim + n] = v;
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[rt][t][r] + bias;
+        if (!last) {
+          xout[rt * TILE + obase + 256 * WAVES * t + 4 * r] = valid ? activate(v, P.act) : 0.f;  // padded columns feed zeros into the next layer
+        } else if (valid && row0 + rt * MT + rbase + r < n_rows) {
+          y[(size_t)(row0 + rt * MT + rbase + r) * P.out_dim + n] = v;
+        }
       }
-    }
   }
 }
 
+template <int RT, int WAVES>
 __device__ __forceinline__ void mlp_tile(const MlpParams& P, const float* __restrict__ x, float* __restrict__ y, int n_rows, int tile) {
-  extern __shared__ float4 smem4[];  // two [16 x KMAX] fragment-major activation tiles: 64 KB
+  extern __shared__ float4 smem4[];  // two buffers of RT [16 x KMAX] fragment-major activation tiles: RT x 64 KB
   float* buf0 = reinterpret_cast<float*>(smem4);
-  float* buf1 = buf0 + MT * KMAX;
+  float* buf1 = buf0 + RT * MT * KMAX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = tile * MT;
+  const int row0 = tile * (RT * MT);
   const int K0 = P.KB[0] * 16;
-  for (int i = tid; i < MT * K0; i += 256) {  // input tile -> LDS (zero fill of the k padding and of rows past the end)
+  for (int i = tid; i < RT * MT * K0; i += 64 * WAVES) {  // input tile -> LDS (zero fill of the k padding and of rows past the end)
     const int r = i / K0, c = i - r * K0;
-    buf0[lds_index(r, c)] = (row0 + r < n_rows && c < P.in_dim) ? x[(size_t)(row0 + r) * P.in_dim + c] : 0.f;
+    buf0[(r >> 4) * (MT * KMAX) + lds_index(r & 15, c)] = (row0 + r < n_rows && c < P.in_dim) ? x[(size_t)(row0 + r) * P.in_dim + c] : 0.f;
   }
   __syncthreads();
   float *cur = buf0, *nxt = buf1;
   for (int l = 0; l < P.n_layers; ++l) {
-    switch (P.TPW[l]) {
-      case 1: layer<1>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-      case 2: layer<2>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-      case 3: layer<3>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-      case 4: layer<4>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-      case 5: layer<5>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-      case 6: layer<6>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-      case 7: layer<7>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-      default: layer<8>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+    const int tpw = ((P.N[l] + 15) / 16 + WAVES - 1) / WAVES;  // 16-column tiles per wavefront that carry output columns
+    if constexpr (WAVES == 4) {
+      switch (tpw) {
+        case 1: layer<1, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        case 2: layer<2, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        case 3: layer<3, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        case 4: layer<4, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        case 5: layer<5, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        case 6: layer<6, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        case 7: layer<7, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        default: layer<8, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      }
+    } else {
+      switch (tpw) {
+        case 1: layer<1, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        case 2: layer<2, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        case 3: layer<3, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+        default: layer<4, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+      }
     }
     __syncthreads();
     float* t = cur; cur = nxt; nxt = t;
@@ -144,22 +170,23 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& P, const float* __rest
 }
 
 __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpParams P, const float* __restrict__ x, float* __restrict__ y, int n_rows) {
-  mlp_tile(P, x, y, n_rows, blockIdx.x);
+  mlp_tile<1, 4>(P, x, y, n_rows, blockIdx.x);
 }
 
-// Two networks over the same rows in ONE launch (actor + critic of a rollout step): workgroup 2 i runs network A on
-// row tile i, workgroup 2 i + 1 network B.  A 4096-row call of one network is 256 workgroups = one per CU = one
+// Two networks over the same rows in ONE launch (actor + critic of a rollout step): even workgroups run network A, odd
+// ones network B on the same row tile.  A 4096-row call of one network is 256 16-row workgroups = one per CU = one
 // wavefront per SIMD, which cannot hide the L2 latency of the weight stream behind its own MFMAs (the 65536-row call
-// runs 1.55x faster per row with two workgroups resident per CU); the pair puts 512 workgroups on the chip.
+// runs 1.55x faster per row with two workgroups resident per CU); the pair puts two wavefronts on every SIMD.
 struct MlpPair {
   const MlpParams *a, *b;  // device copies
   const float *xa, *xb;
   float *ya, *yb;
 };
-__global__ __launch_bounds__(256) void mlp_forward_pair_kernel(MlpPair q, int n_rows) {
+template <int RT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mlp_forward_pair_kernel(MlpPair q, int n_rows) {
   const bool second = blockIdx.x & 1;
   const MlpParams& P = *(second ? q.b : q.a);  // workgroup-uniform address: the fields arrive by scalar loads
-  mlp_tile(P, second ? q.xb : q.xa, second ? q.yb : q.ya, n_rows, blockIdx.x >> 1);
+  mlp_tile<RT, WAVES>(P, second ? q.xb : q.xa, second ? q.yb : q.ya, n_rows, blockIdx.x >> 1);
 }
 
 std::string& err() {
@@ -194,10 +221,10 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
   m->P.n_layers = n_layers; m->P.act = activation; m->P.in_dim = dims[0]; m->P.out_dim = dims[n_layers];
   for (int l = 0; l < n_layers; ++l) {
     const int K = dims[l], N = dims[l + 1];
-    // layer l contracts over the 16-padded width of its input; its output is padded to 64 columns (4 wavefronts x 16).
-    // For l > 0 the input's padding columns were written as zeros by layer l-1 (64-padded >= 16-padded).
-    const int KB = (K + 15) / 16, TPW = (N + 63) / 64, NT = 4 * TPW;
-    m->P.KB[l] = KB; m->P.N[l] = N; m->P.TPW[l] = TPW;
+    // layer l contracts over the 16-padded width of its input; its output is padded to 128 columns (groups of 8 tiles).
+    // For l > 0 the input's padding columns were written as zeros by layer l-1 (128-padded >= 16-padded).
+    const int KB = (K + 15) / 16, NT8 = (N + 127) / 128, NT = 8 * NT8;
+    m->P.KB[l] = KB; m->P.N[l] = N; m->P.NT8[l] = NT8;
     std::vector<float> Wf((size_t)KB * NT * 64 * 4, 0.f), bp((size_t)NT * 16, 0.f);
     for (int n = 0; n < N; ++n) bp[n] = biases[l][n];
     for (int kb = 0; kb < KB; ++kb)
@@ -232,15 +259,23 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
 int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b, const float* xb_dev, float* yb_dev, int32_t n_rows, void* stream) {
   if (!a || !b || !xa_dev || !ya_dev || !xb_dev || !yb_dev) return fail("null argument");
   if (n_rows <= 0) return 0;
-  constexpr size_t lds = sizeof(float) * 2 * MT * KMAX;
+  // 32-row, 8-wavefront workgroups once they fill the chip (2 networks x n_rows / 32 >= 256 CUs); RL_MLP_PAIR_RT overrides (1 | 2)
+  static const int forced = [] { const char* e = getenv("RL_MLP_PAIR_RT"); return e ? atoi(e) : 0; }();
+  const int RT = forced == 1 || forced == 2 ? forced : (n_rows >= 4096 ? 2 : 1);
+  const size_t lds = sizeof(float) * 2 * MT * KMAX * RT;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail("cannot reserve 64 KB of LDS");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 2 * MT * KMAX)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * MT * KMAX)) != hipSuccess)
+      return fail("cannot reserve the LDS of the paired kernel");
     attr_done = true;
   }
   MlpPair q{a->dP, b->dP, xa_dev, xb_dev, ya_dev, yb_dev};
-  hipLaunchKernelGGL(mlp_forward_pair_kernel, dim3(2 * ((n_rows + MT - 1) / MT)), dim3(256), lds, (hipStream_t)stream, q, n_rows);
+  const int tiles = (n_rows + RT * MT - 1) / (RT * MT);
+  if (RT == 2)
+    hipLaunchKernelGGL((mlp_forward_pair_kernel<2, 8>), dim3(2 * tiles), dim3(512), lds, (hipStream_t)stream, q, n_rows);
+  else
+    hipLaunchKernelGGL((mlp_forward_pair_kernel<1, 4>), dim3(2 * tiles), dim3(256), lds, (hipStream_t)stream, q, n_rows);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
 }

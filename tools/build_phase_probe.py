@@ -42,7 +42,7 @@ def hip(s):
     s = must(s, '#include "env_aos.h"', STAMP + '#include "env_aos.h"')
     if mode == "phases":
         s = must(s, "  const int lane = threadIdx.x;\n  {  // stage", "  const int lane = threadIdx.x;\n  RL_STAMP(S, 0);\n  {  // stage")
-        s = must(s, "  __syncthreads();\n  constexpr int TAB_F", "  __syncthreads();\n  RL_STAMP(S, 1);\n  constexpr int TAB_F")
+        s = must(s, "  __syncthreads();\n  // LDS after the tables", "  __syncthreads();\n  RL_STAMP(S, 1);\n  // LDS after the tables")
     return s
 
 
