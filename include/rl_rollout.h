@@ -74,6 +74,21 @@ int32_t rl_rollout_step(const rl_rollout* r); /* transitions recorded since the 
 int rl_rollout_destroy(rl_rollout* r);
 const char* rl_rollout_last_error(void);
 
+/* ---- symmetry data augmentation -------------------------------------------------
+ * Replaces `compute_symmetric_states(env, obs, actions)`,
+ * source/robot_lab/robot_lab/tasks/manager_based/locomotion/velocity/mdp/symmetry/anymal.py:27-87, which rsl_rl's PPO
+ * calls on every mini-batch when `RslRlSymmetryCfg(use_data_augmentation=True, data_augmentation_func=...)` is set
+ * (.../config/quadruped/anymal_d/agents/rsl_rl_ppo_cfg.py:100-105): the batch is replicated n_sym (= 4: identity,
+ * left-right, front-back, diagonal) times and copy s has its columns permuted and sign-flipped,
+ *     out[s * n_rows + r][c] = sign[s][c] * in[r][perm[s][c]]          (anymal.py:97-171 for the policy observation,
+ *                                                                        :179-212 for the actions, tables :232-259)
+ * One kernel launch for all copies; `perm` / `sign` are given once on the host. */
+typedef struct rl_symmetry rl_symmetry;
+int rl_symmetry_create(int32_t n_sym, int32_t dim, const int32_t* perm, const float* sign, int32_t device, rl_symmetry** out);
+/* in [n_rows][dim] -> out [n_sym * n_rows][dim]; device pointers, stream-ordered. */
+int rl_symmetry_apply(rl_symmetry* s, const float* in_dev, float* out_dev, int32_t n_rows, void* stream);
+int rl_symmetry_destroy(rl_symmetry* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,7 +197,27 @@ __global__ __launch_bounds__(BLOCK) void norm_kernel(float* __restrict__ adv, co
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (size_t)gridDim.x * BLOCK) adv[i] = (adv[i] - m) * inv;
 }
 
+// out[s * n_rows + r][c] = sign[s][c] * in[r][perm[s][c]]: blockIdx.y = copy s, one thread per element of a copy (32-bit
+// index math); the rows of `in` are re-read by the n_sym copies out of L2, writes are fully coalesced
+__global__ __launch_bounds__(BLOCK) void symmetry_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ perm,
+                                                         const float* __restrict__ sign, uint32_t per, uint32_t dim) {
+  const uint32_t s = blockIdx.y;
+  const int32_t* __restrict__ pm = perm + s * dim;
+  const float* __restrict__ sg = sign + s * dim;
+  float* __restrict__ o = out + (size_t)s * per;
+  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < per; i += gridDim.x * BLOCK) {
+    const uint32_t r = i / dim, c = i - r * dim;
+    o[i] = sg[c] * in[r * dim + (uint32_t)pm[c]];
+  }
+}
+
 }  // namespace
+
+struct rl_symmetry {
+  int n_sym, dim, device;
+  int32_t* perm = nullptr;
+  float* sign = nullptr;
+};
 
 struct rl_rollout {
   int N, T, obs_dim, critic_dim, act_dim, device;
@@ -327,6 +347,44 @@ int rl_rollout_get_buffer(rl_rollout* r, int32_t which, void** dev_ptr, int64_t*
 }
 
 int32_t rl_rollout_step(const rl_rollout* r) { return r ? r->step : -1; }
+
+int rl_symmetry_create(int32_t n_sym, int32_t dim, const int32_t* perm, const float* sign, int32_t device, rl_symmetry** out) {
+  if (!perm || !sign || !out) return fail("NULL argument");
+  if (n_sym < 1 || dim < 1) return fail("sizes must be positive");
+  for (int i = 0; i < n_sym * dim; ++i)
+    if (perm[i] < 0 || perm[i] >= dim) return fail("perm entry out of range");
+  HIP_OK(hipSetDevice(device));
+  rl_symmetry* s = new rl_symmetry{n_sym, dim, device};
+  if (hipMalloc(&s->perm, sizeof(int32_t) * n_sym * dim) != hipSuccess || hipMalloc(&s->sign, sizeof(float) * n_sym * dim) != hipSuccess) {
+    rl_symmetry_destroy(s);
+    return fail("hipMalloc of the symmetry tables failed");
+  }
+  HIP_OK(hipMemcpy(s->perm, perm, sizeof(int32_t) * n_sym * dim, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(s->sign, sign, sizeof(float) * n_sym * dim, hipMemcpyHostToDevice));
+  *out = s;
+  return 0;
+}
+
+int rl_symmetry_apply(rl_symmetry* s, const float* in_dev, float* out_dev, int32_t n_rows, void* stream) {
+  if (!s || !in_dev || !out_dev) return fail("NULL argument");
+  if (n_rows <= 0) return 0;
+  HIP_OK(hipSetDevice(s->device));
+  const size_t per = (size_t)n_rows * s->dim;
+  if (per >= (1ull << 31)) return fail("batch too large for the 32-bit index math of the symmetry kernel");
+  const int blocks = (int)std::min<size_t>((per + BLOCK - 1) / BLOCK, 4096);
+  hipLaunchKernelGGL(symmetry_kernel, dim3(blocks, s->n_sym), dim3(BLOCK), 0, (hipStream_t)stream, in_dev, out_dev, s->perm, s->sign, (uint32_t)per,
+                     (uint32_t)s->dim);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int rl_symmetry_destroy(rl_symmetry* s) {
+  if (!s) return 0;
+  if (s->perm) (void)hipFree(s->perm);
+  if (s->sign) (void)hipFree(s->sign);
+  delete s;
+  return 0;
+}
 
 int rl_rollout_destroy(rl_rollout* r) {
   if (!r) return 0;
