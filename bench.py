@@ -52,12 +52,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # RL_BENCH_SHARE_GPU=1 (self-test of the N > 1 control flow on a 1-GPU box): every rank uses cuda:0 and the two tiny
+    # collectives run over gloo on host tensors (RCCL refuses two ranks on one device).  Never set by the driver.
+    share = os.environ.get("RL_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    coll = "cpu" if share else dev  # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # RCCL on ROCm
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # RCCL on ROCm
 
     from robot_lab_amd.env import ManagerBasedRLEnv
 
@@ -82,7 +91,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -102,7 +111,7 @@ def main():
     kernel_ms = e0.elapsed_time(e1) / KREP
 
     # the one collective of the path: packed episode-metric vector, off the timed region
-    log_vec = env._bufs["LOG"][native.log_slot()].clone()  # the last step's ring slot
+    log_vec = env._bufs["LOG"][native.log_slot()].clone().to(coll)  # the last step's ring slot
     if world > 1:
         dist.all_reduce(log_vec, op=dist.ReduceOp.SUM)
 
