@@ -543,9 +543,24 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     int n_rewards;
     if constexpr (Spec::generic) {
       n_rewards = ctx.uniform_i(T.n_rewards);
+      // the descriptor of term t + 1 is read from LDS (into VGPRs) before term t runs, so its round trip hides behind
+      // that term instead of opening the next one; it is pinned into SGPRs (readfirstlane) only when its turn comes
+      struct Raw {
+        int kind, n_idx, idx_off;
+        float weight, p[4];
+        uint32_t joint_mask, bm_lo, bm_hi;
+      };
+      auto fetch = [&](int t) {
+        const RewTab& Rl = T.rew[t < n_rewards ? t : n_rewards - 1];
+        Raw r;
+        r.kind = Rl.kind; r.n_idx = Rl.n_idx; r.idx_off = Rl.idx_off; r.weight = Rl.weight;
+        r.p[0] = Rl.p[0]; r.p[1] = Rl.p[1]; r.p[2] = Rl.p[2]; r.p[3] = Rl.p[3];
+        r.joint_mask = Rl.joint_mask; r.bm_lo = (uint32_t)Rl.body_mask; r.bm_hi = (uint32_t)(Rl.body_mask >> 32);
+        return r;
+      };
+      Raw nxt = fetch(0);
       for (int t = 0; t < n_rewards; ++t) {
         // the term descriptor is wave-uniform: pin it into SGPRs so that the dispatch is scalar branching
-        const RewTab& Rl = T.rew[t];
         struct {
           int kind, n_idx;
           float weight, p[4];
@@ -553,11 +568,13 @@ struct EnvProgram : EnvLane<Ctx, TP> {
           uint64_t body_mask;
           const int32_t *idx_a, *idx_b;
         } R;
-        R.kind = ctx.uniform_i(Rl.kind); R.n_idx = ctx.uniform_i(Rl.n_idx); R.weight = ctx.uniform(Rl.weight);
-        R.p[0] = ctx.uniform(Rl.p[0]); R.p[1] = ctx.uniform(Rl.p[1]); R.p[2] = ctx.uniform(Rl.p[2]); R.p[3] = ctx.uniform(Rl.p[3]);
-        R.joint_mask = (uint32_t)ctx.uniform_i((int)Rl.joint_mask);
-        R.body_mask = (uint64_t)(uint32_t)ctx.uniform_i((int)(uint32_t)Rl.body_mask) | ((uint64_t)(uint32_t)ctx.uniform_i((int)(uint32_t)(Rl.body_mask >> 32)) << 32);
-        R.idx_a = T.idx_pool_a + Rl.idx_off; R.idx_b = T.idx_pool_b + Rl.idx_off;
+        R.kind = ctx.uniform_i(nxt.kind); R.n_idx = ctx.uniform_i(nxt.n_idx); R.weight = ctx.uniform(nxt.weight);
+        R.p[0] = ctx.uniform(nxt.p[0]); R.p[1] = ctx.uniform(nxt.p[1]); R.p[2] = ctx.uniform(nxt.p[2]); R.p[3] = ctx.uniform(nxt.p[3]);
+        R.joint_mask = (uint32_t)ctx.uniform_i((int)nxt.joint_mask);
+        R.body_mask = (uint64_t)(uint32_t)ctx.uniform_i((int)nxt.bm_lo) | ((uint64_t)(uint32_t)ctx.uniform_i((int)nxt.bm_hi) << 32);
+        const int off = ctx.uniform_i(nxt.idx_off);
+        R.idx_a = T.idx_pool_a + off; R.idx_b = T.idx_pool_b + off;
+        nxt = fetch(t + 1);
         float val = reward_term(R, rc) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
         total += val;
         if (li == 0) rstage[t] = val;
@@ -663,11 +680,20 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     scan_p = pos + mul(Rwb, pf + mul(Rf, V3{T.scan_pos[0], T.scan_pos[1], T.scan_pos[2]}));
   }
 
-  RL_FN ObsDesc decode_obs(const ObsTab& Ol) const {
+  // descriptor of term i read from LDS into VGPRs (no wait); pin_obs() turns it into SGPRs when its turn comes, so that
+  // the LDS round trip of term i + 1 hides behind term i
+  RL_FN ObsDesc fetch_obs(const ObsTab* terms, int i, int n) const {
+    const ObsTab& Ol = terms[i < n ? i : n - 1];
     ObsDesc O;
-    O.kind = ctx.uniform_i(Ol.kind); O.has_noise = ctx.uniform_i(Ol.has_noise); O.offset = ctx.uniform_i(Ol.offset);
-    O.scale = ctx.uniform(Ol.scale); O.clip_lo = ctx.uniform(Ol.clip_lo); O.clip_hi = ctx.uniform(Ol.clip_hi);
-    O.noise_lo = ctx.uniform(Ol.noise_lo); O.noise_hi = ctx.uniform(Ol.noise_hi);
+    O.kind = Ol.kind; O.has_noise = Ol.has_noise; O.offset = Ol.offset;
+    O.scale = Ol.scale; O.clip_lo = Ol.clip_lo; O.clip_hi = Ol.clip_hi; O.noise_lo = Ol.noise_lo; O.noise_hi = Ol.noise_hi;
+    return O;
+  }
+  RL_FN ObsDesc pin_obs(const ObsDesc& R) const {
+    ObsDesc O;
+    O.kind = ctx.uniform_i(R.kind); O.has_noise = ctx.uniform_i(R.has_noise); O.offset = ctx.uniform_i(R.offset);
+    O.scale = ctx.uniform(R.scale); O.clip_lo = ctx.uniform(R.clip_lo); O.clip_hi = ctx.uniform(R.clip_hi);
+    O.noise_lo = ctx.uniform(R.noise_lo); O.noise_hi = ctx.uniform(R.noise_hi);
     return O;
   }
 
@@ -682,10 +708,12 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_NOISE, (noise_base >> 2) + (uint32_t)b, un);
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = 4 * b + c < dim ? stage[4 * b + c] : 0.f;
+      ObsDesc nxt = fetch_obs(terms, 0, n);
       for (int i = 0; i < n; ++i) {  // term descriptors are wave-uniform: SGPRs, scalar branches
-        const ObsDesc O = decode_obs(terms[i]);
+        const ObsDesc O = pin_obs(nxt);
+        nxt = fetch_obs(terms, i + 1, n);
         if (!O.has_noise) continue;
-        const int lo = O.offset, hi = i + 1 < n ? ctx.uniform_i(terms[i + 1 < n ? i + 1 : i].offset) : dim;
+        const int lo = O.offset, hi = i + 1 < n ? ctx.uniform_i(nxt.offset) : dim;
         const float nr = O.noise_hi - O.noise_lo;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -702,8 +730,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   RL_FN void write_obs(float* stage, const ObsCtx& oc, const ObsTab* terms, int n, int dim, bool corrupt, uint32_t noise_base, float cy, float sy, V3 scan_p) {
     n = ctx.uniform_i(n);
     bool any_noise = false;
+    ObsDesc nxt = fetch_obs(terms, 0, n);
     for (int i = 0; i < n; ++i) {
-      const ObsDesc O = decode_obs(terms[i]);
+      const ObsDesc O = pin_obs(nxt);
+      nxt = fetch_obs(terms, i + 1, n);
       any_noise = any_noise || (corrupt && O.has_noise);
       obs_term(O, oc, stage, corrupt, cy, sy, scan_p);
     }

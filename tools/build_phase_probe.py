@@ -69,7 +69,7 @@ def terms(s):
         s = must(s, "    if (any_noise) add_noise(stage, terms, n, dim, noise_base);", "    if (any_noise) add_noise(stage, terms, n, dim, noise_base);\n    if (noise_base == 0u) RL_STAMP(S, 8);")
     elif mode == "obsfine":
         s = must(s, "    n = ctx.uniform_i(n);\n    bool any_noise = false;", "    n = ctx.uniform_i(n);\n    bool any_noise = false;\n    if (noise_base == 0u) RL_STAMP(S, 0);")
-        s = must(s, "      const ObsDesc O = decode_obs(terms[i]);\n      any_noise", "      const ObsDesc O = decode_obs(terms[i]);\n      if (noise_base == 0u && i < 5) RL_STAMP(S, 1 + 3 * i);\n      any_noise")
+        s = must(s, "      nxt = fetch_obs(terms, i + 1, n);\n      any_noise", "      nxt = fetch_obs(terms, i + 1, n);\n      if (noise_base == 0u && i < 5) RL_STAMP(S, 1 + 3 * i);\n      any_noise")
         s = must(s, "      obs_term(O, oc, stage, corrupt, cy, sy, scan_p);\n    }\n    if (any_noise)", "      if (noise_base == 0u && i < 5) RL_STAMP(S, 2 + 3 * i);\n      obs_term(O, oc, stage, corrupt, cy, sy, scan_p);\n      if (noise_base == 0u && i < 5) RL_STAMP(S, 3 + 3 * i);\n    }\n    if (any_noise)")
     elif mode == "rewards":
         s = must(s, "    RewCtx rc{", "    RL_STAMP(S, 0);\n    RewCtx rc{")
