@@ -71,7 +71,10 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;                                    // + kb * 64 (+ r * TILE / 4)
-  const f32x4* wb = reinterpret_cast<const f32x4*>(P.W[l]) + (size_t)wave * 64 + lane;            // + (kb * NT + WAVES t) * 64
+  // the weight pointer is loaded from the parameter block, so the compiler would fall back to FLAT loads (they count on
+  // vmcnt AND lgkmcnt: every wait for an LDS operand then drains the whole weight pipeline) - say that it is global memory
+  typedef const f32x4 __attribute__((address_space(1))) * GlobalV4;
+  const GlobalV4 wb = (GlobalV4)(uintptr_t)P.W[l] + (size_t)wave * 64 + lane;                       // + (kb * NT + WAVES t) * 64
   // software pipeline, two k blocks deep: the operands of blocks kb + 1 and kb + 2 are in flight while block kb's
   // 4 x TPW x RT MFMAs issue (an L2 hit is ~600-800 cycles, a block's MFMAs are 128 x TPW x RT cycles)
   auto load_b = [&](int kb, f32x4 (&b)[TPW]) {
@@ -113,7 +116,7 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int n = (wave + WAVES * t) * 16 + col;
-    const float bias = P.b[l][n];
+    const float bias = ((const float __attribute__((address_space(1)))*)(uintptr_t)P.b[l])[n];
     const bool valid = n < P.N[l];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
