@@ -274,6 +274,15 @@ int rl_env_reset(rl_env* env, const int32_t* env_ids, int32_t n, void* stream);
  * float [N, A] row-major.  Stream-ordered; no host synchronisation. */
 int rl_env_step(rl_env* env, const float* action_dev, void* stream);
 
+/* rl_env_step fused with what rsl_rl's PPO.process_env_step stores for the transition (train.py:224 -> OnPolicyRunner.learn;
+ * include/rl_rollout.h): besides everything rl_env_step does, the same kernel writes
+ *     rewards_out[e] = reward[e] + gamma * values[e] * time_out[e]      (bootstrapping on time outs)
+ *     dones_out[e]   = terminated[e] | time_out[e]
+ * for e < N - normally straight into the current slot of an rl_rollout (rl_rollout_record_slots), which saves the
+ * separate record launch.  values_dev: float [N] (the critic's V(s_t)); all three are device pointers. */
+int rl_env_step_record(rl_env* env, const float* action_dev, const float* values_dev, float* rewards_out_dev, uint8_t* dones_out_dev,
+                       float gamma, void* stream);
+
 /* Device pointer + shape of one of the env-owned buffers.  shape[] gets up to 3 dims, ndim out.
  * RL_BUF_CONTACT_FORCE / JOINT_TORQUE / JOINT_ACC are inspection views: they are allocated on the first
  * request and filled by every step() AFTER that request (the training path never pays for them). */

@@ -63,6 +63,11 @@ int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, con
  * env's RL_BUF_TERMINATED / RL_BUF_TIME_OUT); closes step t and advances to t + 1. */
 int rl_rollout_record(rl_rollout* r, const float* rewards, const uint8_t* terminated, const uint8_t* time_outs, float gamma, void* stream);
 
+/* The same second half without a launch of its own: hands out the current step's slots (values [N] as stored by
+ * rl_rollout_act, rewards [N], dones [N] u8) for a producer that writes them itself - rl_env_step_record
+ * (include/rl_env.h) does it inside the env kernel - and closes the step like rl_rollout_record. */
+int rl_rollout_record_slots(rl_rollout* r, const float** values, float** rewards, uint8_t** dones);
+
 /* RolloutStorage.compute_returns(last_values [N], gamma, lam, normalize_advantage); needs a full storage. */
 int rl_rollout_compute_returns(rl_rollout* r, const float* last_values, float gamma, float lam, int32_t normalize_advantage, void* stream);
 

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, "csrc", "librl_env_hip.so")
 
 EXPORTS = [
-    "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_get_buffer", "rl_env_export_state", "rl_env_import_state",
+    "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_step_record", "rl_env_get_buffer", "rl_env_export_state", "rl_env_import_state",
     "rl_env_read_log", "rl_env_log_slot", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length",
     "rl_env_destroy", "rl_env_last_error", "rl_env_desc_size",
 ]
@@ -42,6 +42,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rl_env_create.argtypes = [C.POINTER(EnvDesc), fp, fp, fp, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]
     lib.rl_env_reset.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]
     lib.rl_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rl_env_step_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.rl_env_get_buffer.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.rl_env_export_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.rl_env_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -106,6 +107,10 @@ class NativeEnv:
 
     def step(self, action_ptr: int, stream: int = 0):
         self._check(self.lib.rl_env_step(self.handle, C.c_void_p(action_ptr), C.c_void_p(stream)))
+
+    def step_record(self, action_ptr: int, values_ptr: int, rewards_ptr: int, dones_ptr: int, gamma: float, stream: int = 0):
+        self._check(self.lib.rl_env_step_record(self.handle, C.c_void_p(action_ptr), C.c_void_p(values_ptr), C.c_void_p(rewards_ptr),
+                                                C.c_void_p(dones_ptr), gamma, C.c_void_p(stream)))
 
     def buffer(self, name: str):
         """-> (address, shape tuple, numpy dtype)"""

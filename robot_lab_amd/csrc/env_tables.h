@@ -242,6 +242,11 @@ struct KState {
   const float* terrain_origins;    // [rows][cols][3]
   const float* action_in;          // [N][D]
   const uint8_t* reset_mask;       // [Npad] (reset mode)
+  // optional rollout sink of rl_env_step_record (all NULL for a plain step): what PPO.process_env_step stores for this step
+  const float* ro_values;          // [N] V(s_t) of the critic
+  float* ro_rewards;               // [N] <- reward + gamma * V * time_out
+  uint8_t* ro_dones;               // [N] <- terminated | time_out
+  float ro_gamma;
   uint64_t seed;
   uint32_t step_counter;
   uint32_t table_bytes;  // bytes of the packed table image the env kernels stage into LDS (multiple of 16)

@@ -825,6 +825,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       S.reward[e] = rew;
       S.terminated[e] = terminated ? 1 : 0;
       S.time_out[e] = time_out ? 1 : 0;
+      if (S.ro_rewards != nullptr && e < S.N) {  // rl_env_step_record: the transition's second half goes straight into the rollout storage
+        S.ro_rewards[e] = rew + (time_out ? S.ro_gamma * S.ro_values[e] : 0.f);  // bootstrapping on time outs (rsl_rl PPO.process_env_step)
+        S.ro_dones[e] = (terminated || time_out) ? 1 : 0;
+      }
     }
     // 6 reset done envs
     if (terminated || time_out) {

@@ -28,6 +28,13 @@ int rl_env_step(rl_env* env, const float* action_dev, void* stream) {
   return reinterpret_cast<Impl*>(env)->step(action_dev, stream);
 }
 
+int rl_env_step_record(rl_env* env, const float* action_dev, const float* values_dev, float* rewards_out_dev, uint8_t* dones_out_dev, float gamma,
+                       void* stream) {
+  if (!env) return rl::fail("null env");
+  if (!values_dev || !rewards_out_dev || !dones_out_dev) return rl::fail("rollout sink needs values, rewards and dones");
+  return reinterpret_cast<Impl*>(env)->step(action_dev, stream, values_dev, rewards_out_dev, dones_out_dev, gamma);
+}
+
 int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[3], int32_t* ndim, int32_t* elem_size) {
   if (!env || !dev_ptr || !shape || !ndim || !elem_size) return rl::fail("null argument");
   Impl& I = *reinterpret_cast<Impl*>(env);

@@ -540,11 +540,14 @@ struct EnvImpl {
     return be.launch(s, packed_dev, CL, /*reset=*/1, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 
-  int step(const float* action_dev, void* stream) {
+  int step(const float* action_dev, void* stream, const float* ro_values = nullptr, float* ro_rewards = nullptr, uint8_t* ro_dones = nullptr,
+           float ro_gamma = 0.f) {
     if (!action_dev) return fail("action pointer is null");
+    if ((ro_values || ro_rewards || ro_dones) && !(ro_values && ro_rewards && ro_dones)) return fail("rollout sink needs values, rewards and dones");
     KState s = S;
     s.step_counter = ++step_counter;
     s.action_in = action_dev;
+    s.ro_values = ro_values; s.ro_rewards = ro_rewards; s.ro_dones = ro_dones; s.ro_gamma = ro_gamma;
     return be.launch(s, packed_dev, CL, /*reset=*/0, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 

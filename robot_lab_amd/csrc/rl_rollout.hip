@@ -313,6 +313,19 @@ int rl_rollout_record(rl_rollout* r, const float* rewards, const uint8_t* termin
   return 0;
 }
 
+int rl_rollout_record_slots(rl_rollout* r, const float** values, float** rewards, uint8_t** dones) {
+  if (!r || !values || !rewards || !dones) return fail("NULL argument");
+  if (!r->acted) return fail("rl_rollout_record_slots needs rl_rollout_act for this step first");
+  const int t = r->step;
+  *values = slot<float>(r, RL_RO_VALUES, t);
+  *rewards = slot<float>(r, RL_RO_REWARDS, t);
+  *dones = slot<uint8_t>(r, RL_RO_DONES, t);
+  r->acted = false;
+  r->step += 1;
+  r->counter += 1;
+  return 0;
+}
+
 int rl_rollout_compute_returns(rl_rollout* r, const float* last_values, float gamma, float lam, int32_t normalize_advantage, void* stream) {
   if (!r || !last_values) return fail("NULL argument");
   if (r->step != r->T || r->acted) return fail("compute_returns needs a full storage (num_steps recorded transitions)");

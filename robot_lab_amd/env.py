@@ -292,12 +292,19 @@ class ManagerBasedRLEnv(_EnvBase):
         self.extras = {}
         return self._obs, self.extras
 
-    def step(self, action: torch.Tensor):
+    def step(self, action: torch.Tensor, rollout=None, gamma: float = 0.99):
+        """`rollout`: a `robot_lab_amd.rollout.RolloutStorage` whose `act()` produced `action` - the env kernel then also
+        writes the transition's rewards (+ time-out bootstrap) and dones into its current slot (`rl_env_step_record`), i.e.
+        `rollout.process_env_step(...)` without a launch of its own."""
         if action.device != self._bufs["REWARD"].device or action.dtype != torch.float32 or not action.is_contiguous():
             action = action.to(device=self.device, dtype=torch.float32).contiguous()
         if action.shape != (self.num_envs, self.num_actions):
             raise ValueError(f"action shape {tuple(action.shape)} != {(self.num_envs, self.num_actions)}")
-        self._native.step(action.data_ptr(), self._stream())
+        if rollout is None:
+            self._native.step(action.data_ptr(), self._stream())
+        else:
+            v, r, d = rollout.record_slots()
+            self._native.step_record(action.data_ptr(), v, r, d, gamma, self._stream())
         self.common_step_counter += 1
         if self.log_episodes:  # no snapshot, no memset: a view of this step's ring slot, cloned only if somebody reads it
             self.extras = {"log": _LazyLog(self, self._bufs["LOG"][self._native.log_slot()], self.common_step_counter)}

@@ -17,7 +17,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROLLOUT_LIB = os.path.join(_HERE, "csrc", "librl_rollout_hip.so")
-ROLLOUT_EXPORTS = ["rl_rollout_create", "rl_rollout_act", "rl_rollout_record", "rl_rollout_compute_returns", "rl_rollout_clear",
+ROLLOUT_EXPORTS = ["rl_rollout_create", "rl_rollout_act", "rl_rollout_record", "rl_rollout_record_slots", "rl_rollout_compute_returns", "rl_rollout_clear",
                    "rl_rollout_get_buffer", "rl_rollout_step", "rl_rollout_destroy", "rl_rollout_last_error"]
 # name -> (rl_rollout_buffer id, dtype, has a trailing feature dim)
 BUFFERS = dict(observations=(0, np.float32, True), privileged_observations=(1, np.float32, True), actions=(2, np.float32, True),
@@ -43,6 +43,7 @@ def load_rollout_library(path: str | None = None) -> C.CDLL:
     lib.rl_rollout_create.argtypes = [C.c_int32] * 5 + [C.c_uint64, C.c_int32, C.POINTER(vp)]
     lib.rl_rollout_act.argtypes = [vp] * 8
     lib.rl_rollout_record.argtypes = [vp, vp, vp, vp, C.c_float, vp]
+    lib.rl_rollout_record_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.rl_rollout_compute_returns.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int32, vp]
     lib.rl_rollout_clear.argtypes = [vp]
     lib.rl_rollout_get_buffer.argtypes = [vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]
@@ -124,6 +125,14 @@ class RolloutStorage:
                 raise RlRolloutError("terminated / time_outs must be contiguous uint8 or bool tensors of num_envs entries")
         if self.lib.rl_rollout_record(self.handle, self._f32(rewards.view(-1), (N,)), self._p(terminated), self._p(time_outs), gamma, self._stream()) != 0:
             raise RlRolloutError(self._err())
+
+    def record_slots(self):
+        """(values, rewards, dones) device addresses of the current step's slots, closing the step: for a producer that writes
+        the transition's second half itself (`ManagerBasedRLEnv.step(actions, rollout=storage)` -> `rl_env_step_record`)."""
+        v, r, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if self.lib.rl_rollout_record_slots(self.handle, C.byref(v), C.byref(r), C.byref(d)) != 0:
+            raise RlRolloutError(self._err())
+        return v.value, r.value, d.value
 
     # -- PPO.compute_returns / RolloutStorage.compute_returns
     def compute_returns(self, last_values, gamma: float, lam: float, normalize_advantage: bool = True):

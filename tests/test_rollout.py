@@ -173,3 +173,43 @@ def test_hip_rollout_is_reproducible_and_checks_order():
     with pytest.raises(RlRolloutError, match="full storage"):
         st.compute_returns(torch.zeros(N).cuda(), GAMMA, LAM)
     st.close()
+
+
+@pytest.mark.gpu
+def test_fused_step_record_equals_the_separate_record_kernel():
+    """rl_env_step_record (the env kernel writes rewards + time-out bootstrap and dones into the storage slot) against
+    rl_env_step followed by rl_rollout_record on a twin env: identical bits, including envs that time out."""
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+    from robot_lab_amd.rollout import RolloutStorage
+
+    task, N, T = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 256, 4
+    envs = [ManagerBasedRLEnv(task, num_envs=N, seed=9, device="cuda:0") for _ in range(2)]
+    sts = [RolloutStorage(N, T, 45, 235, 12, seed=3, device="cuda:0") for _ in range(2)]
+    ep = torch.zeros(N, dtype=torch.int64)
+    ep[::5] = envs[0].max_episode_length - 2  # a fifth of the envs time out at the second step
+    obs = []
+    for e in envs:
+        o, _ = e.reset()
+        e.episode_length_buf = ep
+        obs.append(o)
+    g = torch.Generator().manual_seed(1)
+    std = torch.full((12,), 0.8, device="cuda:0")
+    for t in range(T):
+        mean, values = torch.randn(N, 12, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+        acts = [st.act(o["policy"], o["critic"], mean, std, values) for st, o in zip(sts, obs)]
+        assert torch.equal(acts[0], acts[1])
+        o0, rew, term, tout, _ = envs[0].step(acts[0], rollout=sts[0], gamma=GAMMA)       # fused
+        o1, rew1, term1, tout1, _ = envs[1].step(acts[1])                                 # separate
+        sts[1].process_env_step(rew1, term1, tout1, GAMMA)
+        obs = [o0, o1]
+        assert torch.equal(rew, rew1) and torch.equal(tout, tout1)
+        assert sts[0].step == sts[1].step == t + 1
+    torch.cuda.synchronize()
+    assert torch.equal(sts[0].rewards, sts[1].rewards) and torch.equal(sts[0].dones, sts[1].dones)
+    assert bool(sts[0].dones.any()) and not torch.equal(sts[0].rewards[1], torch.zeros(N, device="cuda:0"))
+    boot = sts[0].dones[1] & ~torch.zeros(N, dtype=torch.bool, device="cuda:0")
+    assert int(boot.sum()) >= N // 5
+    for x in sts + envs:
+        x.close()

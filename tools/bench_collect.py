@@ -22,6 +22,7 @@ task = sys.argv[1] if len(sys.argv) > 1 else "RobotLab-Isaac-Velocity-Rough-Unit
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 T, GAMMA, LAM = 24, 0.99, 0.95  # rsl_rl_ppo_cfg.py:11,33-34
+FUSED = os.environ.get("RL_FUSED_RECORD", "1") == "1"
 PAIR = os.environ.get("RL_PAIR", "1") == "1"  # actor + critic in one launch (rl_mlp_forward_pair)
 env = ManagerBasedRLEnv(task, num_envs=N, seed=42, device="cuda:0")
 obs, _ = env.reset()
@@ -44,8 +45,11 @@ def iteration(obs):
     for _ in range(T):
         mean, values = actor.forward_pair(obs["policy"], critic, obs["critic"]) if PAIR else (actor(obs["policy"]), critic(obs["critic"]))
         actions = storage.act(obs["policy"], obs["critic"], mean, std, values)
-        obs, rew, term, tout, extras = env.step(actions)
-        storage.process_env_step(rew, term, tout, GAMMA)
+        if FUSED:  # the env kernel writes the transition's rewards / dones into the storage slot (rl_env_step_record)
+            obs, rew, term, tout, extras = env.step(actions, rollout=storage, gamma=GAMMA)
+        else:
+            obs, rew, term, tout, extras = env.step(actions)
+            storage.process_env_step(rew, term, tout, GAMMA)
     storage.compute_returns(critic(obs["critic"]), GAMMA, LAM)
     return obs
 
