@@ -115,12 +115,13 @@ def main():
     if world > 1:
         dist.all_reduce(log_vec, op=dist.ReduceOp.SUM)
 
-    traffic = None
+    traffic = sq = None
     try:  # measured separately with rocprofv3 PMC passes (cannot be collected inside this process)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tr = json.load(f).get(args.task)
         if tr and N == tr.get("num_envs", 4096):
             traffic = tr["fetch_bytes"] + tr["write_bytes"]
+            sq = tr.get("sq")  # where a wavefront's cycles go (SQ counters, same offline pass): the kernel is issue / latency bound
     except (OSError, ValueError, KeyError):
         pass
     value = world * N * args.steps / elapsed
@@ -137,7 +138,7 @@ def main():
                    "parallelism": f"env-shard x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                     "kernel_only_env_steps_per_s": N / (kernel_ms * 1e-3)},
+                     "kernel_only_env_steps_per_s": N / (kernel_ms * 1e-3), "wavefront_cycle_breakdown": sq},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.task, args.cpu_envs, args.cpu_steps)
