@@ -111,6 +111,7 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
   }
   // epilogue: D[row = (lane >> 4) * 4 + reg][col = lane & 15] -> bias, activation -> next LDS tile / global
   const int col = lane & 15, rbase = (lane >> 4) * 4;
+  const int act = P.act;  // wave-uniform: the selects below become scalar branches around straight-line code
   // lds_index(rbase + r, (wave + WAVES t) * 16 + col) = lane-constant + 256 WAVES t + 4 r
   const int obase = wave * 256 + (col & 3) * 64 + rbase * 4 + ((col >> 2) & 3);
 #pragma unroll
@@ -124,7 +125,8 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
       for (int r = 0; r < 4; ++r) {
         const float v = acc[rt][t][r] + bias;
         if (!last) {
-          xout[rt * TILE + obase + 256 * WAVES * t + 4 * r] = valid ? activate(v, P.act) : 0.f;  // padded columns feed zeros into the next layer
+          const float av = act == RL_ACT_ELU ? (v > 0.f ? v : __expf(v) - 1.0f) : act == RL_ACT_RELU ? fmaxf(v, 0.f) : tanhf(v);
+          xout[rt * TILE + obase + 256 * WAVES * t + 4 * r] = valid ? av : 0.f;  // padded columns feed zeros into the next layer
         } else if (valid && row0 + rt * MT + rbase + r < n_rows) {
           y[(size_t)(row0 + rt * MT + rbase + r) * P.out_dim + n] = v;
         }
@@ -140,9 +142,12 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& P, const float* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = tile * (RT * MT);
   const int K0 = P.KB[0] * 16;
-  for (int i = tid; i < RT * MT * K0; i += 64 * WAVES) {  // input tile -> LDS (zero fill of the k padding and of rows past the end)
-    const int r = i / K0, c = i - r * K0;
-    buf0[(r >> 4) * (MT * KMAX) + lds_index(r & 15, c)] = (row0 + r < n_rows && c < P.in_dim) ? x[(size_t)(row0 + r) * P.in_dim + c] : 0.f;
+  // input tile -> LDS (zero fill of the k padding and of rows past the end): a wavefront per row, lanes over the columns
+  for (int r = wave; r < RT * MT; r += WAVES) {
+    const bool live = row0 + r < n_rows;
+    const float* __restrict__ xr = x + (size_t)(row0 + r) * P.in_dim;
+    float* __restrict__ dst = buf0 + (r >> 4) * (MT * KMAX);
+    for (int c = lane; c < K0; c += 64) dst[lds_index(r & 15, c)] = (live && c < P.in_dim) ? xr[c] : 0.f;
   }
   __syncthreads();
   float *cur = buf0, *nxt = buf1;

@@ -27,7 +27,7 @@ class RlPolicyError(RuntimeError):
 
 def load_policy_library(path: str | None = None) -> C.CDLL:
     global _lib
-    path = path or POLICY_LIB
+    path = path or os.environ.get("RL_POLICY_LIB") or POLICY_LIB  # RL_POLICY_LIB: alternative build (kernel ablations)
     if _lib is not None and path == POLICY_LIB:
         return _lib
     if not os.path.isfile(path):
