@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: needs /root/reference (skipped where it is absent)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The suites need the in-tree libraries (HIP product libraries + the CPU lane emulator): build whatever is missing or
+    stale - a no-op after `__graft_entry__.build()`, ~2 minutes of hipcc / g++ on a fresh checkout."""
+    import __graft_entry__ as g
+
+    g.build()
+
+
 @pytest.fixture(scope="session")
 def emu_lib():
     """CPU lane emulator (test infrastructure): same lane-program source as the HIP kernel, built with g++."""
