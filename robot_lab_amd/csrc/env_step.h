@@ -269,7 +269,7 @@ struct LsLayout {  // ROWS sensor rows (timers 4, force history 3, last force 3,
 };
 template <class TP, int SUB>
 struct LsFor {  // lane scratchpad layout of an instance
-  static constexpr int STASH = (TP::NW == 0 && SUB > 1) ? TP::SPL : 0;  // (G1: the LDS goes to the per-link CRBA records instead)
+  static constexpr int STASH = SUB > 1 ? TP::SPL : 0;  // contacts of the most distal link group a sub-lane evaluates (feet, wheels, hands)
   static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::MAXOWN;      // 16-lane mapping: rows for the owned slots only
   using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::MAXOWN), STASH>;
 };

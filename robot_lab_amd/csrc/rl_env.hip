@@ -164,7 +164,8 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   ctx.lscratch = smem + TAB_F;
   ctx.lbscratch = ctx.lscratch + LS::WORDS * 64;
   float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
-  const bool alias = STASH_WORDS > 0 && s0w + s1w + Ctx::EPT * MAX_T <= STASH_WORDS;  // same rule as Backend::configure
+  // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
+  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && s0w + s1w + Ctx::EPT * MAX_T <= STASH_WORDS;  // same rule as Backend::configure
   ctx.stage[0] = alias ? ctx.lscratch + LS::CT * 64 : tail;
   ctx.stage[1] = ctx.stage[0] + s0w;
   ctx.rstage = ctx.stage[1] + s1w;
