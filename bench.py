@@ -2,27 +2,32 @@
 """bench.py - env-steps/sec of `ManagerBasedRLEnv.step()` on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 1000 --warmup 100
+    python bench.py --gpus 8 --steps 1000 --warmup 100          # spawns 8 ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                   # or is launched as a rank (the reference's contract:
+                                                                  # scripts/reinforcement_learning/rsl_rl/train.py:143-150, README.md:323-337)
 
 A "step" is one `env.step(actions)` over all environments of the rank: one pass of the hot path
 (action processing, 4 physics substeps, term stack, resets, observations) = one HIP kernel launch.
 Workload at N=1: BASELINE.json configs[1] = Unitree-A1 Velocity-Rough, 4096 envs, random actions
 ~U(-1,1) (the `scripts/tools/random_agent.py:68` distribution) already resident in HBM.  Environments
-shard embarrassingly: every rank owns its own 4096 envs, seed = 42 + rank (as
-`scripts/reinforcement_learning/rsl_rl/train.py:148`); the only collective is one RCCL all-reduce of
-the packed episode-metric vector after the timed region ("weak" scaling).
+shard embarrassingly: every rank owns its own 4096 envs, seed = 42 + rank (as `train.py:148`); the only
+collective is one RCCL all-reduce of the packed episode-metric vector after the timed region ("weak" scaling).
+`--gpus N` must equal the number of ranks that actually run: without WORLD_SIZE in the environment the script
+re-executes itself under `torch.distributed.run` with N ranks; with it, a mismatch is an error.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch
 (3.4 KB per env-step x 4096 envs) / mean kernel duration measured with HIP events
-on the launch stream; `cpu_baseline` = the fp64 numpy oracle timed on a bounded sample on this
-box's host cores (rank 0, N=1 only).
+on the launch stream; `cpu_baseline` = the same lane program compiled for the host (tests/emu: the source
+hipcc compiles, g++ -O3 -march=native) run by a thread pool over the box's host cores on a bounded sample
+(rank 0, N=1 only), with the fp64 numpy oracle's figure next to it.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,7 +39,7 @@ ALGO_BYTES_PER_ENV_STEP = {"A1": 857 * 4, "Go2": 3600, "Go2W": 3800, "G1": 5500}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -42,9 +47,40 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--task", type=str, default="RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=512)
-    ap.add_argument("--cpu-steps", type=int, default=30)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work the baseline leg may spend on the lane-program port")
+    ap.add_argument("--cpu-oracle-envs", type=int, default=256)
+    ap.add_argument("--cpu-oracle-steps", type=int, default=10)
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no rank environment: become the launcher of N ranks (one per GPU)."""
+    import socket
+
+    share = os.environ.get("RL_BENCH_SHARE_GPU") == "1"
+    if not share:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible; refusing to run a {args.gpus}-GPU "
+                  f"benchmark on fewer GPUs", file=sys.stderr)
+            return 2
+    with socket.socket() as s:  # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -52,11 +88,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the number of ranks must match the flag")
     # RL_BENCH_SHARE_GPU=1 (self-test of the N > 1 control flow on a 1-GPU box): every rank uses cuda:0 and the two tiny
     # collectives run over gloo on host tensors (RCCL refuses two ranks on one device).  Never set by the driver.
     share = os.environ.get("RL_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} HIP device(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     coll = "cpu" if share else dev  # where the collectives' tensors live
@@ -67,6 +107,7 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device(dev))  # RCCL on ROCm
+        assert dist.get_world_size() == world
 
     from robot_lab_amd.env import ManagerBasedRLEnv
 
@@ -84,16 +125,28 @@ def main():
 
     for i in range(args.warmup):
         env.step(ring[i % 32])
+    ep_before = env.episode_length_buf.clone()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         env.step(ring[i % 32])
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = elapsed_rank
+    per_rank = [N * args.steps / elapsed_rank]
     if world > 1:
-        t = torch.tensor([elapsed], device=coll, dtype=torch.float64)
+        t = torch.tensor([elapsed_rank], device=coll, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [N * args.steps / float(x.item()) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # what the timed window held (a cold 20-step window after reset looks different from steady state: robots still
+    # falling, no resets): envs that were reset inside it, and how many bodies touch the ground at its end
+    envs_reset = int((env.episode_length_buf < ep_before + args.steps).sum())
+    env._export_stamp = -1
+    env._export()
+    bodies_in_contact = float((env._bufs["CONTACT_TIMERS"][: N, :, 1] > 0).sum(dim=1).float().mean())
 
     # kernel duration with HIP events on the launch stream (no Python-side extras in the loop)
     native, stream = env._native, env._stream()
@@ -111,17 +164,21 @@ def main():
     kernel_ms = e0.elapsed_time(e1) / KREP
 
     # the one collective of the path: packed episode-metric vector, off the timed region
-    log_vec = env._bufs["LOG"][native.log_slot()].clone().to(coll)  # the last step's ring slot
+    k = native.log_slot()
+    log = env._bufs["LOG"]
+    log_vec = torch.where(log[k][0] > 0, log[k], log[(k - 1) % log.shape[0]]).clone().to(coll)  # most recent step that reset an env
+    log_vec[7] = float(N)  # spare slot: envs behind this vector, so the reduced vector carries the global env count
     if world > 1:
         dist.all_reduce(log_vec, op=dist.ReduceOp.SUM)
 
-    traffic = sq = None
+    traffic = sq = prof_src = None
     try:  # measured separately with rocprofv3 PMC passes (cannot be collected inside this process)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tr = json.load(f).get(args.task)
         if tr and N == tr.get("num_envs", 4096):
             traffic = tr["fetch_bytes"] + tr["write_bytes"]
             sq = tr.get("sq")  # where a wavefront's cycles go (SQ counters, same offline pass): the kernel is issue / latency bound
+            prof_src = tr.get("source", "profiles/traffic.json")
     except (OSError, ValueError, KeyError):
         pass
     value = world * N * args.steps / elapsed
@@ -136,12 +193,19 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.task}, {N} envs/GPU, random actions U(-1,1), seed 42+rank", "envs_per_gpu": N,
                    "parallelism": f"env-shard x{world}"},
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "collective_backend": ("gloo (RL_BENCH_SHARE_GPU self-test)" if share else "nccl (RCCL)") if world > 1 else None,
+        "per_rank_env_steps_per_s": per_rank, "envs_behind_reduced_log": float(log_vec[7]),
+        "window": {"envs_reset_in_window": envs_reset, "mean_bodies_in_contact_at_end": bodies_in_contact,
+                   "note": "rank 0; episodes last 1000 steps, so a short window right after reset() is a cold one"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                     "kernel_only_env_steps_per_s": N / (kernel_ms * 1e-3), "wavefront_cycle_breakdown": sq},
+                     "kernel_only_env_steps_per_s": N / (kernel_ms * 1e-3), "wavefront_cycle_breakdown": sq,
+                     # `achieved` / `kernel_ms` are measured live in this run; `traffic` and the cycle breakdown are NOT: they are the
+                     # rocprofv3 PMC passes of an earlier run of the same command, read from the file named here
+                     "offline": {"fields": ["traffic", "wavefront_cycle_breakdown"], "source": prof_src} if traffic is not None else None},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.task, args.cpu_envs, args.cpu_steps)
+        out["cpu_baseline"] = cpu_baseline(args.task, N, args.cpu_seconds, args.cpu_oracle_envs, args.cpu_oracle_steps)
     env.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -149,27 +213,76 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(task, n_envs, steps):
-    """fp64 numpy oracle (the CPU restatement of the same step) on a bounded sample of the same workload."""
+def build_host_port() -> str:
+    """The lane program (robot_lab_amd/csrc/env_step.h + env_terms.h, the source hipcc compiles) built for THIS box's CPU:
+    g++ -O3 -march=native of tests/emu/rl_env_emu.cpp into a per-box cache (a -march=native object must not travel)."""
+    import hashlib
+
+    src = os.path.join(ROOT, "tests", "emu", "rl_env_emu.cpp")
+    csrc = os.path.join(ROOT, "robot_lab_amd", "csrc")
+    h = hashlib.sha1()
+    for p in [src] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".inl"))) + [os.path.join(ROOT, "include", "rl_env.h")]:
+        h.update(open(p, "rb").read())
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rl_env_host_port_{h.hexdigest()[:12]}.so")
+    if not os.path.isfile(cache):
+        subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", cache + ".tmp", src], check=True)
+        os.replace(cache + ".tmp", cache)
+    return cache
+
+
+def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
+    """Two CPU figures on this box's host cores, same task and env count as the GPU line:
+    (i) `value`: the lane program compiled for the host (kind "port": tests/emu, 4 lane threads per environment in lock
+        step, one team of 4 per 4 host cores, every core busy) - the "tuned CPU" number SURVEY.md 8(d) asks for;
+    (ii) `oracle`: the fp64 numpy oracle (oracle/env.py, single process) on a smaller sample."""
     import numpy as np
 
     from oracle.env import OracleEnv
+    from robot_lab_amd.capi import NativeEnv
     from robot_lab_amd.scene import build_world, load_bundle
 
+    cores = os.cpu_count() or 4
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    teams = max(1, cores // 4)
+    os.environ["RL_EMU_TEAMS"] = str(teams)
     desc, extra = load_bundle(task)
+    D = desc.model.num_dof
+    lib = build_host_port()
     h, to, eo = build_world(desc, extra, n_envs, 0)
-    ora = OracleEnv(desc, h, to, n_envs, 42, eo)
-    ora.reset()
+    nat = NativeEnv(desc, h, to, eo, n_envs, 42, 0, lib)
+    nat.reset()
     rng = np.random.default_rng(0)
-    acts = rng.uniform(-1, 1, (steps + 2, n_envs, desc.model.num_dof))
-    ora.step(acts[0])
+    acts = rng.uniform(-1, 1, (8, n_envs, D)).astype(np.float32)
+    nat.step(acts[0].ctypes.data)  # warm-up (thread pool, page faults)
+    t0 = time.perf_counter()
+    nat.step(acts[1].ctypes.data)
+    one = time.perf_counter() - t0
+    steps = int(max(3, min(200, budget_s / max(one, 1e-6))))
     t0 = time.perf_counter()
     for s in range(steps):
-        ora.step(acts[s + 1])
+        nat.step(acts[s % 8].ctypes.data)
     dt = time.perf_counter() - t0
-    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n_envs} envs x {steps} steps of the same task, fp64 numpy oracle (oracle/env.py), single process",
-            "host_cores_available": os.cpu_count()}
+    nat.close()
+    port = n_envs * steps / dt
+    # fp64 numpy oracle, as in round 1 (one process; numpy's own threading aside)
+    h, to, eo = build_world(desc, extra, oracle_envs, 0)
+    ora = OracleEnv(desc, h, to, oracle_envs, 42, eo)
+    ora.reset()
+    oa = rng.uniform(-1, 1, (oracle_steps + 1, oracle_envs, D))
+    ora.step(oa[0])
+    t0 = time.perf_counter()
+    for s in range(oracle_steps):
+        ora.step(oa[s + 1])
+    odt = time.perf_counter() - t0
+    return {"value": port, "unit": "env-steps/s", "cores": teams * 4, "kind": "port", "per_core": port / (teams * 4),
+            "sample": f"{n_envs} envs x {steps} steps of the same task ({dt:.1f} s): the env-step lane program compiled for the host "
+                      f"(g++ -O3 -march=native), {teams} teams x 4 lane threads",
+            "host_cores_available": cores,
+            "oracle": {"value": oracle_envs * oracle_steps / odt, "unit": "env-steps/s", "cores": 1, "kind": "oracle",
+                       "sample": f"{oracle_envs} envs x {oracle_steps} steps, fp64 numpy oracle (oracle/env.py), single process"}}
 
 
 if __name__ == "__main__":

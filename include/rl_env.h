@@ -10,9 +10,12 @@
  * The Python class `robot_lab_amd.env.ManagerBasedRLEnv` is the binding; INTEGRATION.md shows it.
  *
  * All device buffers are env-owned, device-resident, valid until rl_env_destroy, and are
- * rewritten in place by every rl_env_step (callers get the same pointer every time - the reference
- * returns its tensors by reference too, SURVEY.md 8(b) "Ownership").  All calls are stream-ordered
- * on the hipStream_t passed in; no call synchronises the host except rl_env_read_log.
+ * rewritten in place by every rl_env_step - EXCEPT the two observation groups, which alternate between
+ * two HBM buffers: the observations returned by step t stay untouched until step t + 2 is launched
+ * (the reference builds fresh observation tensors on every step - ObservationManager.compute ->
+ * torch.cat - and rsl_rl's PPO.act keeps a reference to them across the following env.step;
+ * SURVEY.md 8(b) "Ownership").  All calls are stream-ordered on the hipStream_t passed in; no call
+ * synchronises the host except rl_env_read_log and rl_env_import_state.
  *
  * Return value: 0 on success, negative on error; rl_env_last_error() gives the message.
  */
@@ -230,8 +233,8 @@ typedef struct rl_env_desc {
 
 /* ---- buffers a caller may look at (device pointers) -------------------------------------- */
 enum rl_buffer {
-  RL_BUF_OBS_POLICY = 0,   /* float [N, obs_policy_dim]  */
-  RL_BUF_OBS_CRITIC = 1,   /* float [N, obs_critic_dim]  */
+  RL_BUF_OBS_POLICY = 0,   /* float [N, obs_policy_dim]: the buffer the LAST step()/reset() wrote (slot rl_env_obs_slot of the ring below) */
+  RL_BUF_OBS_CRITIC = 1,   /* float [N, obs_critic_dim]: likewise */
   RL_BUF_REWARD = 2,       /* float [N] */
   RL_BUF_TERMINATED = 3,   /* uint8 [N] */
   RL_BUF_TIME_OUT = 4,     /* uint8 [N] */
@@ -245,13 +248,29 @@ enum rl_buffer {
   RL_BUF_CONTACT_FORCE = 12, /* float [N, B, 3] net_forces_w of the last substep (inspection view: see rl_env_get_buffer) */
   RL_BUF_CONTACT_TIMERS = 13, /* float [N, B, 4] current_air, current_contact, last_air, last_contact */
   RL_BUF_LOG = 14,         /* float [RL_LOG_RING][RL_LOG_SIZE] device-side episode log: step k accumulates into slot
-                              k % RL_LOG_RING, which step k - 1 zeroed (see rl_env_log_slot) */
+                              k % RL_LOG_RING, which step k - 1 zeroed (see rl_env_log_slot); step k + 1 then lets a slot whose
+                              reset count (entry 0) is 0 inherit slot k - 1, so every slot but the newest reads as "the log of
+                              the most recent step that reset an env"; for the newest, a reader does that select itself */
   RL_BUF_ACTION = 15,      /* float [N, A] last (raw) action */
   RL_BUF_JOINT_TORQUE = 16,/* float [N, D] applied torque of the last substep */
   RL_BUF_JOINT_ACC = 17,   /* float [N, D] */
   RL_BUF_ENV_ORIGIN = 18,  /* float [N, 3] */
   RL_BUF_TERRAIN_LEVEL = 19, /* int32 [N] */
+  RL_BUF_TASK_STATE = 20,  /* float [N, RL_TASK_STATE_NF] command / event state carried between steps (rl_task_state_field);
+                              written by rl_env_export_state, read by rl_env_commit_state */
+  RL_BUF_GAINS = 21,       /* float [N, 2, D] per-env actuator stiffness / damping (randomize_actuator_gains, velocity_env_cfg.py:337-347) */
+  RL_BUF_OBS_POLICY_RING = 22, /* float [2, Npad, obs_policy_dim] both observation buffers; step()/reset() alternate between them */
+  RL_BUF_OBS_CRITIC_RING = 23, /* float [2, Npad, obs_critic_dim] */
   RL_BUF_COUNT
+};
+
+/* fields of one RL_BUF_TASK_STATE row: UniformVelocityCommand state [UPSTREAM B7] (command, heading target, resampling
+ * timer, the two metric accumulators, the two per-env flags), the interval-event timer of push_robot [UPSTREAM B2] and the
+ * persistent external wrench of apply_external_force_torque [UPSTREAM B8] */
+enum rl_task_state_field {
+  RL_TS_CMD_VX = 0, RL_TS_CMD_VY, RL_TS_CMD_WZ, RL_TS_HEADING_TARGET, RL_TS_CMD_TIME_LEFT, RL_TS_METRIC_XY, RL_TS_METRIC_YAW,
+  RL_TS_PUSH_TIME_LEFT, RL_TS_IS_HEADING_ENV, RL_TS_IS_STANDING_ENV, RL_TS_EXT_FORCE, RL_TS_EXT_TORQUE = RL_TS_EXT_FORCE + 3,
+  RL_TASK_STATE_NF = RL_TS_EXT_TORQUE + 3
 };
 
 #define RL_LOG_SIZE 64
@@ -289,21 +308,36 @@ int rl_env_step_record(rl_env* env, const float* action_dev, const float* values
 int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[3], int32_t* ndim,
                       int32_t* elem_size);
 
-/* Gathers the SoA simulator state into the AoS debug/inspection buffers (ROOT_STATE, JOINT_*,
- * CONTACT_*).  Not part of step(); callers such as rl_utils.py:12-13 (camera follow) use it. */
+/* Gathers the SoA simulator state into the AoS debug/inspection buffers.  Not part of step(); callers such as
+ * rl_utils.py:12-13 (camera follow) use it.  The set it writes is everything step() carries from one call to the next
+ * besides the directly addressable buffers (EPISODE_LENGTH, EPISODE_SUMS, TERRAIN_LEVEL): ROOT_STATE, JOINT_POS, JOINT_VEL,
+ * ACTION (= last action), GAINS, CONTACT_TIMERS, TASK_STATE, ENV_ORIGIN. */
 int rl_env_export_state(rl_env* env, void* stream);
 
-/* Overwrites simulator state from AoS host arrays (teacher-forced parity tests, and
- * write_root_state_to_sim-style callers).  Any pointer may be NULL to leave that part as is.
- * root_state [N,13], joint_pos [N,D], joint_vel [N,D]. */
+/* The inverse of rl_env_export_state: scatters those AoS device buffers back into the simulator state (the reference's
+ * `scene.write_data_to_sim()` / `write_root_state_to_sim` / `write_joint_state_to_sim` direction [UPSTREAM B1]).  A caller edits
+ * the buffers (they are plain device pointers) after an export and commits.  Used by the teacher-forced parity tests
+ * (tests/test_gpu_teacher_forced.py): HIP and oracle are stepped ONCE from a shared state. */
+int rl_env_commit_state(rl_env* env, void* stream);
+
+/* Convenience form for HOST arrays: export, overwrite the given parts (any pointer may be NULL to leave that part as is;
+ * root_state [N,13], joint_pos [N,D], joint_vel [N,D]), commit.  Synchronises `stream`. */
 int rl_env_import_state(rl_env* env, const float* root_state, const float* joint_pos,
                         const float* joint_vel, void* stream);
 
-/* Copies the RL_LOG_SIZE episode-log accumulators of the LAST step (what the reference rebuilds as extras["log"] on
- * every step() that resets an env: manager_based_rl_env.py [UPSTREAM B1]) to host and zeroes them (synchronises `stream`). */
+/* Copies the RL_LOG_SIZE episode-log accumulators of the most recent step that reset an environment to host (what a caller of
+ * the reference finds in extras["log"], which is rebuilt inside _reset_idx only: manager_based_rl_env.py [UPSTREAM B1]).
+ * Synchronises `stream`. */
 int rl_env_read_log(rl_env* env, float* out_host, void* stream);
 /* Ring slot of RL_BUF_LOG the last step() wrote (= steps so far % RL_LOG_RING); device readers use it to avoid the copy. */
 int32_t rl_env_log_slot(const rl_env* env);
+
+/* Which of the two observation buffers (RL_BUF_OBS_*_RING) the last step()/reset() wrote: 0 or 1. */
+int32_t rl_env_obs_slot(const rl_env* env);
+/* ManagerBasedRLEnv.common_step_counter [UPSTREAM B1]: steps taken so far.  It keys the counter-based random streams
+ * (resets, command resampling, pushes, observation noise), so a state moved between two envs moves together with it. */
+int64_t rl_env_step_count(const rl_env* env);
+int rl_env_set_step_count(rl_env* env, int64_t count);
 
 int32_t rl_env_num_envs(const rl_env* env);
 int32_t rl_env_num_actions(const rl_env* env);

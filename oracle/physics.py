@@ -98,6 +98,17 @@ class Physics:
         self.S = np.zeros((L, 6))
         self.S[:, :3] = self.axis
         self.S[0] = 0.0
+        # Optional record of how close each env came to one of the model's DISCONTINUITIES during the substeps run since
+        # it was set (tests/helpers.py switch_mask): dict of per-env minima, filled by substep() when not None.
+        #   phi    [m]   |penetration| of the sphere nearest to touching / leaving (contact on-off: the damping force jumps)
+        #   fn0    [N]   |lagged normal force| of a penetrating sphere nearest to its activation threshold 0
+        #   stick  [m/s] ||u_t| - v_stick| of an active contact (mu_s <-> mu_d)
+        #   limit  [rad] distance of a joint to a limit it is about to cross (the limit damper switches on)
+        self.margins = None
+
+    def _margin(self, key, val):
+        m = self.margins
+        m[key] = np.minimum(m[key], val) if key in m else np.asarray(val, dtype=np.float64).copy()
 
     # ------------------------------------------------------------------ per-env inertial tables
     def link_inertias(self, body_mass, base_com_shift):
@@ -225,6 +236,8 @@ class Physics:
         hi = arr(self.desc.model.joint_upper, D).astype(np.float64)
         kl, cl = float(sim.limit_k), float(sim.limit_c)
         below, above = st["q"] < lo, st["q"] > hi
+        if self.margins is not None:
+            self._margin("limit", np.minimum(np.abs(st["q"] - lo), np.abs(st["q"] - hi)).min(axis=1))
         viol = np.where(below, lo - st["q"], 0.0) - np.where(above, st["q"] - hi, 0.0)
         act = below | above
         A[:, 6 + idx, 6 + idx] += np.where(act, dt * (kl * dt + cl), 0.0)
@@ -244,6 +257,8 @@ class Physics:
             cw[:, gi] = ow[:, l] + np.einsum("nij,j->ni", Rw[:, l], self.sphere_center[gi])
         hz, nrm = self.terrain.sample(cw[..., 0], cw[..., 1])
         phi = self.sphere_radius[None] - (cw[..., 2] - hz) * nrm[..., 2]
+        if self.margins is not None and G > 0:
+            self._margin("phi", np.abs(phi).min(axis=1))
         contacts = []
         for gi in range(G):
             if not np.any(phi[:, gi] > 0):
@@ -267,6 +282,11 @@ class Physics:
             active = (ph > 0) & (fn0 > 0)
             mu = np.where(utn < vstick, st["body_mu_s"][:, bdy], st["body_mu_d"][:, bdy])
             dtan = np.minimum(ct, mu * np.maximum(fn0, 0.0) / np.maximum(utn, 1e-6))
+            if self.margins is not None:
+                self._margin("fn0", np.where(ph > 0, np.abs(fn0), np.inf))
+                # the friction coefficient only matters where the Coulomb bound (not the stick damping c_t) is the smaller one
+                coulomb = active & (np.maximum(st["body_mu_s"][:, bdy], st["body_mu_d"][:, bdy]) * np.maximum(fn0, 0.0) / np.maximum(utn, 1e-6) < ct)
+                self._margin("stick", np.where(coulomb, np.abs(utn - vstick), np.inf))
             Dm = dtan[:, None, None] * np.eye(3) + (dn - dtan)[:, None, None] * (n[:, :, None] * n[:, None, :])
             w = active.astype(np.float64)
             A += dt * w[:, None, None] * (np.swapaxes(J, 1, 2) @ Dm @ J)

@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, "csrc", "librl_env_hip.so")
 
 EXPORTS = [
-    "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_step_record", "rl_env_get_buffer", "rl_env_export_state", "rl_env_import_state",
-    "rl_env_read_log", "rl_env_log_slot", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length",
+    "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_step_record", "rl_env_get_buffer", "rl_env_export_state", "rl_env_commit_state",
+    "rl_env_import_state", "rl_env_read_log", "rl_env_log_slot", "rl_env_obs_slot", "rl_env_step_count", "rl_env_set_step_count", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length",
     "rl_env_destroy", "rl_env_last_error", "rl_env_desc_size",
 ]
 
@@ -45,6 +45,12 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rl_env_step_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.rl_env_get_buffer.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.rl_env_export_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rl_env_commit_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rl_env_obs_slot.argtypes = [C.c_void_p]
+    lib.rl_env_obs_slot.restype = C.c_int32
+    lib.rl_env_step_count.argtypes = [C.c_void_p]
+    lib.rl_env_step_count.restype = C.c_int64
+    lib.rl_env_set_step_count.argtypes = [C.c_void_p, C.c_int64]
     lib.rl_env_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rl_env_read_log.argtypes = [C.c_void_p, fp, C.c_void_p]
     lib.rl_env_log_slot.argtypes = [C.c_void_p]
@@ -124,6 +130,21 @@ class NativeEnv:
 
     def export_state(self, stream: int = 0):
         self._check(self.lib.rl_env_export_state(self.handle, C.c_void_p(stream)))
+
+    def commit_state(self, stream: int = 0):
+        """AoS state buffers (ROOT_STATE, JOINT_*, ACTION, GAINS, CONTACT_TIMERS, TASK_STATE, ENV_ORIGIN) -> simulator state."""
+        self._check(self.lib.rl_env_commit_state(self.handle, C.c_void_p(stream)))
+
+    def obs_slot(self) -> int:
+        return int(self.lib.rl_env_obs_slot(self.handle))
+
+    @property
+    def step_count(self) -> int:
+        return int(self.lib.rl_env_step_count(self.handle))
+
+    @step_count.setter
+    def step_count(self, n: int):
+        self._check(self.lib.rl_env_set_step_count(self.handle, int(n)))
 
     def import_state(self, root_ptr=0, qpos_ptr=0, qvel_ptr=0, stream: int = 0):
         self._check(self.lib.rl_env_import_state(self.handle, C.c_void_p(root_ptr), C.c_void_p(qpos_ptr), C.c_void_p(qvel_ptr), C.c_void_p(stream)))

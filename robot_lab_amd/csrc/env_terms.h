@@ -781,9 +781,20 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 
   // ---------------------------------------------------------------- step()
   RL_FN void step() {
-    if (e == 0) {  // the lanes of env 0 clear the next step's slot (nobody writes it during this launch)
-      float* nx = S.log + ((S.step_counter + 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SIZE;
-      for (int i = li; i < LOG_SIZE; i += LPE) nx[i] = 0.f;
+    {  // episode-log ring upkeep by the lanes of env 0 (nobody else touches these two slots during this launch)
+      // (a) the previous step's slot is final now: if that step reset nobody, it inherits its predecessor, so that every
+      //     slot reads as "the log of the most recent step that reset an env" - what a caller of the reference sees, which
+      //     rebuilds extras["log"] only inside _reset_idx [UPSTREAM B1];  (b) clear the next step's slot.
+      float* pv = S.log + ((S.step_counter - 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SIZE;
+      const float* pp = S.log + ((S.step_counter - 2u) & (uint32_t)(LOG_RING - 1)) * LOG_SIZE;
+      const bool inherit = pv[LOG_RESET_COUNT] == 0.f;
+      ctx.group_sync();  // every lane has read the count before lane 0 overwrites it
+      if (e == 0) {
+        if (inherit)
+          for (int i = li; i < LOG_SIZE; i += LPE) pv[i] = pp[i];
+        float* nx = S.log + ((S.step_counter + 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SIZE;
+        for (int i = li; i < LOG_SIZE; i += LPE) nx[i] = 0.f;
+      }
     }
     this->load();
     load_task();  // same batch of HBM loads as the state: one round trip instead of a second one after the substeps

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 
 #define RL_FN __host__ __device__ __forceinline__
 #include "env_aos.h"
@@ -181,9 +182,9 @@ __global__ void export_kernel(KState S, const Tables* __restrict__ T, AosPtrs A)
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < S.Npad) export_env(S, *T, A, e);
 }
-__global__ void import_kernel(KState S, const Tables* __restrict__ T, const float* r, const float* q, const float* qd, int N) {
+__global__ void commit_kernel(KState S, const Tables* __restrict__ T, AosPtrs A) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < N) import_env(S, *T, r, q, qd, e);
+  if (e < S.Npad) commit_env(S, *T, A, e);
 }
 
 struct Backend {
@@ -196,7 +197,13 @@ struct Backend {
     }
     return 0;
   }
-  int init(int device) { return check(hipSetDevice(device)); }
+  int device = 0;
+  int init(int dev) {
+    device = dev;
+    return check(hipSetDevice(dev));
+  }
+  // every entry point runs on the env's device, whatever the calling thread's current device is
+  int activate() { return check(hipSetDevice(device)); }
   void* alloc(size_t n) {
     void* p = nullptr;
     if (check(hipMalloc(&p, n ? n : 16))) return nullptr;
@@ -217,12 +224,17 @@ struct Backend {
   template <class TP, int SUB>
   int launch_cl(const KState& S, const void* T, int reset, size_t lds, hipStream_t st) {
     dim3 grid(S.Npad / (16 / SUB)), block(64);
-    if (lds > 64 * 1024) {  // opt in to the large LDS carve-out once per kernel (160 KB per CU on gfx950)
-      static bool done = false;
-      if (!done) {
+    if (lds > 64 * 1024) {
+      // opt in to the large LDS carve-out (160 KB per CU on gfx950).  The attribute belongs to the (kernel, device) pair and
+      // must cover the LARGEST request: remember per device what was configured and raise it when an env needs more.
+      static size_t configured[64] = {};
+      static std::mutex mu;
+      std::lock_guard<std::mutex> lock(mu);
+      size_t& have = configured[device & 63];
+      if (lds > have) {
         if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 1, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
         if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 0, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
-        done = true;
+        have = lds;
       }
     }
     if (reset)
@@ -267,23 +279,13 @@ struct Backend {
     hipLaunchKernelGGL(export_kernel, dim3((S.Npad + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, T, A);
     return check(hipGetLastError());
   }
-  int launch_import(const KState& S, const Tables* T, const float* r, const float* q, const float* qd, int N, int D, void* stream) {
-    // r/q/qd are HOST arrays (include/rl_env.h): stage them through temporary device buffers
-    hipStream_t st = (hipStream_t)stream;
-    float *dr = nullptr, *dq = nullptr, *dqd = nullptr;
-    if (r) { if (check(hipMalloc(&dr, (size_t)N * 13 * 4))) return -1; check(hipMemcpyAsync(dr, r, (size_t)N * 13 * 4, hipMemcpyHostToDevice, st)); }
-    if (q) { if (check(hipMalloc(&dq, (size_t)N * D * 4))) return -1; check(hipMemcpyAsync(dq, q, (size_t)N * D * 4, hipMemcpyHostToDevice, st)); }
-    if (qd) { if (check(hipMalloc(&dqd, (size_t)N * D * 4))) return -1; check(hipMemcpyAsync(dqd, qd, (size_t)N * D * 4, hipMemcpyHostToDevice, st)); }
-    hipLaunchKernelGGL(import_kernel, dim3((N + 63) / 64), dim3(64), 0, st, S, T, dr, dq, dqd, N);
-    int rc = check(hipGetLastError());
-    rc |= check(hipStreamSynchronize(st));
-    (void)hipFree(dr); (void)hipFree(dq); (void)hipFree(dqd);
-    return rc;
+  int launch_commit(const KState& S, const Tables* T, const AosPtrs& A, void* stream) {
+    hipLaunchKernelGGL(commit_kernel, dim3((S.Npad + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, T, A);
+    return check(hipGetLastError());
   }
-  int read_and_zero(void* out, void* src, size_t n, void* stream) {
+  int d2h_sync(void* out, const void* src, size_t n, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (check(hipMemcpyAsync(out, src, n, hipMemcpyDeviceToHost, st))) return -1;
-    if (check(hipMemsetAsync(src, 0, n, st))) return -1;
     return check(hipStreamSynchronize(st));
   }
 };

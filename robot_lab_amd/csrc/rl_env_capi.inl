@@ -45,8 +45,12 @@ int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[
   };
   if ((which == RL_BUF_CONTACT_FORCE || which == RL_BUF_JOINT_TORQUE || which == RL_BUF_JOINT_ACC) && I.enable_inspection()) return -1;
   switch (which) {
-    case RL_BUF_OBS_POLICY: return set(I.S.obs_policy, 2, N, I.tables.policy_dim, 1, 4);
+    case RL_BUF_OBS_POLICY: return set(I.S.obs_policy, 2, N, I.tables.policy_dim, 1, 4);  // the slot the last step()/reset() wrote
     case RL_BUF_OBS_CRITIC: return set(I.S.obs_critic, 2, N, I.tables.critic_dim, 1, 4);
+    case RL_BUF_OBS_POLICY_RING: return set(I.obs_ring[0][0], 3, 2, Np, I.tables.policy_dim, 4);
+    case RL_BUF_OBS_CRITIC_RING: return set(I.obs_ring[1][0], 3, 2, Np, I.tables.critic_dim, 4);
+    case RL_BUF_TASK_STATE: return set(I.task_state, 2, N, RL_TASK_STATE_NF, 1, 4);
+    case RL_BUF_GAINS: return set(I.gains, 3, N, 2, D, 4);
     case RL_BUF_REWARD: return set(I.S.reward, 1, N, 1, 1, 4);
     case RL_BUF_TERMINATED: return set(I.S.terminated, 1, N, 1, 1, 1);
     case RL_BUF_TIME_OUT: return set(I.S.time_out, 1, N, 1, 1, 1);
@@ -71,26 +75,44 @@ int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[
 
 int rl_env_export_state(rl_env* env, void* stream) {
   if (!env) return rl::fail("null env");
-  Impl& I = *reinterpret_cast<Impl*>(env);
-  rl::AosPtrs A{I.root_state, I.joint_pos, I.joint_vel, I.ctimers, I.action_aos, I.env_origin_aos};
-  return I.be.launch_export(I.S, I.tables_dev, A, stream) ? rl::fail("export launch failed: " + I.be.error()) : 0;
+  return reinterpret_cast<Impl*>(env)->export_state(stream);
+}
+
+int rl_env_commit_state(rl_env* env, void* stream) {
+  if (!env) return rl::fail("null env");
+  return reinterpret_cast<Impl*>(env)->commit_state(stream);
 }
 
 int rl_env_import_state(rl_env* env, const float* root_state, const float* joint_pos, const float* joint_vel, void* stream) {
   if (!env) return rl::fail("null env");
-  Impl& I = *reinterpret_cast<Impl*>(env);
-  return I.be.launch_import(I.S, I.tables_dev, root_state, joint_pos, joint_vel, I.N, I.D, stream) ? rl::fail("import failed: " + I.be.error()) : 0;
+  return reinterpret_cast<Impl*>(env)->import_state(root_state, joint_pos, joint_vel, stream);
 }
 
 int rl_env_read_log(rl_env* env, float* out_host, void* stream) {
   if (!env || !out_host) return rl::fail("null argument");
   Impl& I = *reinterpret_cast<Impl*>(env);
-  float* slot = I.S.log + (size_t)(I.step_counter & (uint32_t)(RL_LOG_RING - 1)) * RL_LOG_SIZE;  // the last step's slot
-  return I.be.read_and_zero(out_host, slot, RL_LOG_SIZE * sizeof(float), stream) ? rl::fail("log read failed: " + I.be.error()) : 0;
+  if (I.be.activate()) return rl::fail("device activation failed: " + I.be.error());
+  // the last step's slot, or - if that step reset nobody - its predecessor, which the kernel has resolved the same way
+  float two[2][RL_LOG_SIZE];
+  for (int i = 0; i < 2; ++i) {
+    float* slot = I.S.log + (size_t)((I.step_counter - (uint32_t)i) & (uint32_t)(RL_LOG_RING - 1)) * RL_LOG_SIZE;
+    if (I.be.d2h_sync(two[i], slot, RL_LOG_SIZE * sizeof(float), stream)) return rl::fail("log read failed: " + I.be.error());
+  }
+  memcpy(out_host, two[0][0] > 0.f ? two[0] : two[1], RL_LOG_SIZE * sizeof(float));
+  return 0;
 }
 
 int32_t rl_env_log_slot(const rl_env* env) {
   return env ? (int32_t)(reinterpret_cast<const Impl*>(env)->step_counter & (uint32_t)(RL_LOG_RING - 1)) : -1;
+}
+
+int32_t rl_env_obs_slot(const rl_env* env) { return env ? reinterpret_cast<const Impl*>(env)->obs_slot : -1; }
+int64_t rl_env_step_count(const rl_env* env) { return env ? (int64_t) reinterpret_cast<const Impl*>(env)->step_counter : -1; }
+int rl_env_set_step_count(rl_env* env, int64_t count) {
+  if (!env) return rl::fail("null env");
+  if (count < 0 || count > 0xffffffffll) return rl::fail("step count out of range");
+  reinterpret_cast<Impl*>(env)->step_counter = (uint32_t)count;
+  return 0;
 }
 
 int32_t rl_env_num_envs(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->N; }

@@ -11,9 +11,12 @@
 #include <vector>
 
 #include "../../include/rl_env.h"
+#include "env_aos.h"
 #include "env_tables.h"
 
 namespace rl {
+
+static_assert((int)TASK_NF == (int)RL_TASK_STATE_NF && (int)TS_EXT_F == (int)RL_TS_EXT_FORCE && (int)TS_PUSH == (int)RL_TS_PUSH_TIME_LEFT, "RL_BUF_TASK_STATE row layout");
 
 inline std::string& last_error() {
   static thread_local std::string e;
@@ -337,7 +340,11 @@ struct EnvImpl {
   std::vector<void*> allocs;
   // AoS inspection buffers
   float *root_state = nullptr, *joint_pos = nullptr, *joint_vel = nullptr, *cforce = nullptr, *ctimers = nullptr, *action_aos = nullptr;
-  float *env_origin_aos = nullptr;
+  float *env_origin_aos = nullptr, *task_state = nullptr, *gains = nullptr;
+  // the two observation groups alternate between two HBM buffers (include/rl_env.h "Ownership"): obs_slot = the one last written
+  float* obs_ring[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [group][slot]
+  int obs_slot = 0;
+  bool alloc_failed = false;
   uint8_t* reset_mask = nullptr;
   float* terrain_dev = nullptr;
   float* terrain_origins_dev = nullptr;
@@ -348,6 +355,8 @@ struct EnvImpl {
     if (p) {
       be.zero(p, n * sizeof(Tp));
       allocs.push_back(p);
+    } else {
+      alloc_failed = true;  // checked once at the end of create(): a kernel must never see a null buffer
     }
     return (Tp*)p;
   }
@@ -374,21 +383,28 @@ struct EnvImpl {
     S.env_state = alloc<float>(ntile * (size_t)ly.NF_ENV * ept);
     S.flags = alloc<int32_t>(Np); S.level = alloc<int32_t>(Np); S.ttype = alloc<int32_t>(Np);
     S.ep_len = alloc<int64_t>(Np); S.ep_sums = alloc<float>(MAX_T * Np);
-    S.obs_policy = alloc<float>(Np * (size_t)std::max(1, tables.policy_dim));
-    S.obs_critic = alloc<float>(Np * (size_t)std::max(1, tables.critic_dim));
+    for (int g = 0; g < 2; ++g) {  // one allocation per group: [2][Npad][dim] (RL_BUF_OBS_*_RING)
+      const size_t row = Np * (size_t)std::max(1, g == 0 ? tables.policy_dim : tables.critic_dim);
+      obs_ring[g][0] = alloc<float>(2 * row);
+      obs_ring[g][1] = obs_ring[g][0] ? obs_ring[g][0] + row : nullptr;
+    }
+    obs_slot = 0;
+    S.obs_policy = obs_ring[0][0];
+    S.obs_critic = obs_ring[1][0];
     S.reward = alloc<float>(Np); S.terminated = alloc<uint8_t>(Np); S.time_out = alloc<uint8_t>(Np);
     S.rew_terms = alloc<float>(MAX_T * Np); S.command_out = alloc<float>(3 * Np); S.log = alloc<float>(LOG_RING * LOG_SIZE);
     root_state = alloc<float>(Np * 13); joint_pos = alloc<float>(Np * D); joint_vel = alloc<float>(Np * D);
     ctimers = alloc<float>(Np * B * 4); action_aos = alloc<float>(Np * D); env_origin_aos = alloc<float>(Np * 3);
+    task_state = alloc<float>(Np * TASK_NF); gains = alloc<float>(Np * 2 * D);
     reset_mask = alloc<uint8_t>(Np);
     tables_dev = alloc<Tables>(1);
-    if (!tables_dev) return fail("device allocation failed: " + be.error());
+    if (alloc_failed) return fail("device allocation failed: " + be.error());
     if (!desc.terrain.is_plane) {
       if (!terrain_heights || !terrain_origins) return fail("heightfield terrain needs heights and sub-terrain origins");
       size_t nh = (size_t)desc.terrain.nx * desc.terrain.ny;
       terrain_dev = alloc<float>(nh);
       terrain_origins_dev = alloc<float>((size_t)desc.terrain.num_rows * desc.terrain.num_cols * 3);
-      if (!terrain_dev) return fail("device allocation failed (terrain)");
+      if (alloc_failed) return fail("device allocation failed (terrain): " + be.error());
       be.h2d(terrain_dev, terrain_heights, nh * 4);
       be.h2d(terrain_origins_dev, terrain_origins, (size_t)desc.terrain.num_rows * desc.terrain.num_cols * 12);
     } else if (!env_origins) {
@@ -400,7 +416,7 @@ struct EnvImpl {
     {
       std::vector<uint8_t> img = pack_image(tables);
       packed_dev = alloc<uint8_t>(img.size());
-      if (!packed_dev) return fail("device allocation failed: " + be.error());
+      if (alloc_failed) return fail("device allocation failed: " + be.error());
       be.h2d(packed_dev, img.data(), img.size());
     }
     startup(terrain_origins, env_origins);
@@ -519,11 +535,24 @@ struct EnvImpl {
   int enable_inspection() {
     if (S.dbg_torque) return 0;
     const size_t Np = Npad;
-    S.dbg_torque = alloc<float>(Np * D); S.dbg_acc = alloc<float>(Np * D); S.dbg_cforce = alloc<float>(Np * B * 3);
-    return (S.dbg_torque && S.dbg_acc && S.dbg_cforce) ? 0 : fail("device allocation failed: " + be.error());
+    if (be.activate()) return fail("device activation failed: " + be.error());
+    float *t = alloc<float>(Np * D), *a = alloc<float>(Np * D), *c = alloc<float>(Np * B * 3);
+    if (!(t && a && c)) return fail("device allocation failed: " + be.error());
+    S.dbg_torque = t; S.dbg_acc = a; S.dbg_cforce = c;
+    return 0;
+  }
+
+  AosPtrs aos() const { return AosPtrs{root_state, joint_pos, joint_vel, ctimers, action_aos, env_origin_aos, task_state, gains}; }
+
+  // next observation buffers: the ones the previous call wrote stay untouched during this one
+  void flip_obs(KState& s) {
+    obs_slot ^= 1;
+    S.obs_policy = s.obs_policy = obs_ring[0][obs_slot];
+    S.obs_critic = s.obs_critic = obs_ring[1][obs_slot];
   }
 
   int reset(const int32_t* env_ids, int32_t n, void* stream) {
+    if (be.activate()) return fail("device activation failed: " + be.error());
     KState s = S;
     s.step_counter = step_counter;
     if (env_ids == nullptr) {
@@ -537,6 +566,7 @@ struct EnvImpl {
       be.h2d_stream(reset_mask, mask.data(), Npad, stream);
       s.reset_mask = reset_mask;
     }
+    flip_obs(s);
     return be.launch(s, packed_dev, CL, /*reset=*/1, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 
@@ -544,14 +574,34 @@ struct EnvImpl {
            float ro_gamma = 0.f) {
     if (!action_dev) return fail("action pointer is null");
     if ((ro_values || ro_rewards || ro_dones) && !(ro_values && ro_rewards && ro_dones)) return fail("rollout sink needs values, rewards and dones");
+    if (be.activate()) return fail("device activation failed: " + be.error());
     KState s = S;
     s.step_counter = ++step_counter;
+    flip_obs(s);
     s.action_in = action_dev;
     s.ro_values = ro_values; s.ro_rewards = ro_rewards; s.ro_dones = ro_dones; s.ro_gamma = ro_gamma;
     return be.launch(s, packed_dev, CL, /*reset=*/0, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 
+  int export_state(void* stream) {
+    if (be.activate()) return fail("device activation failed: " + be.error());
+    return be.launch_export(S, tables_dev, aos(), stream) ? fail("export launch failed: " + be.error()) : 0;
+  }
+  int commit_state(void* stream) {
+    if (be.activate()) return fail("device activation failed: " + be.error());
+    return be.launch_commit(S, tables_dev, aos(), stream) ? fail("commit launch failed: " + be.error()) : 0;
+  }
+  // host arrays -> export, overwrite the given parts, commit (include/rl_env.h rl_env_import_state)
+  int import_state(const float* r, const float* q, const float* qd, void* stream) {
+    if (export_state(stream)) return -1;
+    if (r) be.h2d_stream(root_state, r, (size_t)N * 13 * 4, stream);
+    if (q) be.h2d_stream(joint_pos, q, (size_t)N * D * 4, stream);
+    if (qd) be.h2d_stream(joint_vel, qd, (size_t)N * D * 4, stream);
+    return commit_state(stream);
+  }
+
   void destroy() {
+    (void)be.activate();
     for (void* p : allocs) be.free(p);
     allocs.clear();
   }

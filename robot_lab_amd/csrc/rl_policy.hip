@@ -211,6 +211,7 @@ int fail(const std::string& m) {
 struct rl_mlp {
   MlpParams P;
   MlpParams* dP = nullptr;  // device copy (rl_mlp_forward_pair)
+  int device = 0;
   std::vector<void*> allocs;
 };
 
@@ -225,6 +226,7 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
   if (activation < RL_ACT_ELU || activation > RL_ACT_TANH) return fail("unknown activation");
   if (hipSetDevice(device) != hipSuccess) return fail("hipSetDevice failed");
   rl_mlp* m = new rl_mlp();
+  m->device = device;
   memset(&m->P, 0, sizeof(m->P));
   m->P.n_layers = n_layers; m->P.act = activation; m->P.in_dim = dims[0]; m->P.out_dim = dims[n_layers];
   for (int l = 0; l < n_layers; ++l) {
@@ -271,12 +273,14 @@ int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b
   static const int forced = [] { const char* e = getenv("RL_MLP_PAIR_RT"); return e ? atoi(e) : 0; }();
   const int RT = forced == 1 || forced == 2 ? forced : (n_rows >= 4096 ? 2 : 1);
   const size_t lds = sizeof(float) * 2 * MT * KMAX * RT;
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (a->device != b->device) return fail("the two networks live on different devices");
+  if (hipSetDevice(a->device) != hipSuccess) return fail("hipSetDevice failed");
+  static bool attr_done[64] = {};  // the LDS opt-in belongs to the (kernel, device) pair
+  if (!attr_done[a->device & 63]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 2 * MT * KMAX)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * MT * KMAX)) != hipSuccess)
       return fail("cannot reserve the LDS of the paired kernel");
-    attr_done = true;
+    attr_done[a->device & 63] = true;
   }
   MlpPair q{a->dP, b->dP, xa_dev, xb_dev, ya_dev, yb_dev};
   const int tiles = (n_rows + RT * MT - 1) / (RT * MT);
@@ -292,11 +296,12 @@ int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, 
   if (!m || !x_dev || !y_dev) return fail("null argument");
   if (n_rows <= 0) return 0;
   constexpr size_t lds = sizeof(float) * 2 * MT * KMAX;
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (hipSetDevice(m->device) != hipSuccess) return fail("hipSetDevice failed");
+  static bool attr_done[64] = {};
+  if (!attr_done[m->device & 63]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail("cannot reserve 64 KB of LDS");
-    attr_done = true;
+    attr_done[m->device & 63] = true;
   }
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((n_rows + MT - 1) / MT), dim3(256), lds, (hipStream_t)stream, m->P, x_dev, y_dev, n_rows);
   hipError_t e = hipGetLastError();
@@ -308,6 +313,7 @@ int32_t rl_mlp_out_dim(const rl_mlp* m) { return m ? m->P.out_dim : 0; }
 
 int rl_mlp_destroy(rl_mlp* m) {
   if (!m) return 0;
+  (void)hipSetDevice(m->device);
   for (void* p : m->allocs) (void)hipFree(p);
   delete m;
   return 0;

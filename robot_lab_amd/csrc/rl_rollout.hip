@@ -49,7 +49,12 @@ struct ActArgs {
 };
 
 __device__ inline void stream_copy(const float* __restrict__ src, float* __restrict__ dst, size_t n, int block, int nblocks) {
-  // n floats, both 16-byte aligned at the base (hipMalloc / torch allocations): float4 body + scalar tail
+  // n floats: float4 body + scalar tail when both ends are 16-byte aligned.  The destination is slot t of a [T][N][dim]
+  // array, i.e. base + t * N * dim floats - only 4-byte aligned when N * dim is not a multiple of 4 (N = 37, dim = 45): scalar copy
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) != 0) {
+    for (size_t i = (size_t)block * BLOCK + threadIdx.x; i < n; i += (size_t)nblocks * BLOCK) dst[i] = src[i];
+    return;
+  }
   const size_t n4 = n >> 2;
   const float4* s4 = reinterpret_cast<const float4*>(src);
   float4* d4 = reinterpret_cast<float4*>(dst);

@@ -11,8 +11,12 @@ Same construction and call surface as the class the reference registers as its g
 but `step()` is ONE hand-written HIP kernel launch on the MI355X (through the C-ABI of
 `include/rl_env.h`) instead of PhysX + a few hundred torch kernels.  PyTorch is only the owner of
 device memory handed in (actions) and the view type handed out; every returned tensor is a zero-copy
-view of an env-owned HBM buffer that the next `step()` overwrites (the reference returns its buffers
-by reference as well).
+view of an env-owned HBM buffer.  Rewards, dones and the inspection views are rewritten in place by the
+next `step()` (the reference's `reward_buf` / `reset_buf` are too).  The observation groups are NOT: the
+reference builds fresh observation tensors on every step (`ObservationManager.compute` -> `torch.cat`) and
+rsl_rl's `PPO.act` keeps a reference to them across the following `env.step()`, so the kernel alternates
+between two HBM buffers per group - the tensors returned by step t stay intact until step t + 2 is launched
+(no copy, no extra traffic; `include/rl_env.h` "Ownership").
 
 There is no CPU path: without `librl_env_hip.so` or without a GPU the constructor raises.
 """
@@ -64,13 +68,15 @@ class _Buffers(dict):
 
 
 class _LazyLog(dict):
-    """`extras["log"]`: per-step episode log [UPSTREAM B1/B2] backed by a device snapshot; entries are
-    0-dim device tensors materialised on first access, so a training loop that only reads them at log
-    time never forces a host sync inside `step()`."""
+    """`extras["log"]`: the episode log of the most recent step that reset an environment [UPSTREAM B1/B2] - the
+    reference rebuilds `extras["log"]` inside `_reset_idx` only, so on a step without resets a caller still sees the
+    previous one (rsl_rl appends it once per step and averages).  Backed by the device-side ring (the kernel resolves
+    an empty slot to its predecessor, `csrc/env_terms.h step()`); entries are 0-dim device tensors materialised on
+    first access, so a training loop that only reads them at log time never forces a host sync inside `step()`."""
 
-    def __init__(self, env, slot, step):
+    def __init__(self, env, slot, prev, step):
         super().__init__()
-        self._env, self._slot, self._step, self._done = env, slot, step, False
+        self._env, self._slot, self._prev, self._step, self._done = env, slot, prev, step, False
 
     def _fill(self):
         if self._done:
@@ -82,7 +88,9 @@ class _LazyLog(dict):
             raise RuntimeError(f'extras["log"] of step {self._step} was read {e.common_step_counter - self._step} steps later: '
                                f"the device keeps the last {RL_LOG_RING - 2} steps")
         self._done = True
-        s = self._slot.clone()
+        # this step's slot if it reset an env, else its predecessor (which the kernel has already resolved the same way)
+        s = torch.where(self._slot[0] > 0, self._slot, self._prev)
+        self._slot = self._prev = None
         cnt = torch.clamp(s[0], min=1.0)
         for i, name in enumerate(e.desc.reward_names):
             dict.__setitem__(self, "Episode_Reward/" + name, s[8 + i] / cnt / e.max_episode_length_s)
@@ -251,15 +259,19 @@ class ManagerBasedRLEnv(_EnvBase):
         self.step_dt = float(desc.sim.dt) * int(desc.sim.decimation)
         self.common_step_counter = 0
         self._bufs = _Buffers(self)
-        for name in ("OBS_POLICY", "OBS_CRITIC", "REWARD", "TERMINATED", "TIME_OUT", "EPISODE_LENGTH", "ROOT_STATE", "JOINT_POS",
-                     "JOINT_VEL", "REWARD_TERMS", "EPISODE_SUMS", "COMMAND", "CONTACT_TIMERS", "LOG", "ACTION", "ENV_ORIGIN", "TERRAIN_LEVEL"):
+        for name in ("OBS_POLICY_RING", "OBS_CRITIC_RING", "REWARD", "TERMINATED", "TIME_OUT", "EPISODE_LENGTH", "ROOT_STATE", "JOINT_POS",
+                     "JOINT_VEL", "REWARD_TERMS", "EPISODE_SUMS", "COMMAND", "CONTACT_TIMERS", "LOG", "ACTION", "ENV_ORIGIN", "TERRAIN_LEVEL",
+                     "TASK_STATE", "GAINS"):
             self._bufs[name]
         if inspection:  # applied torque / joint acceleration / contact force views, filled by every step from now on
             for name in _INSPECTION:
                 self._bufs[name]
         self._terminated = self._bufs["TERMINATED"].view(torch.bool)
         self._time_outs = self._bufs["TIME_OUT"].view(torch.bool)
-        self._obs = {"policy": self._bufs["OBS_POLICY"], "critic": self._bufs["OBS_CRITIC"]}
+        # the two observation groups alternate between two HBM buffers: views of both, picked after every step / reset
+        n = self.num_envs
+        self._obs_slots = [{"policy": self._bufs["OBS_POLICY_RING"][s, :n], "critic": self._bufs["OBS_CRITIC_RING"][s, :n]} for s in (0, 1)]
+        self._obs = self._obs_slots[self._native.obs_slot()]
         self._export_stamp = -1
         self.scene = _Scene(self)
         self.command_manager = _CommandManager(self)
@@ -289,6 +301,7 @@ class ManagerBasedRLEnv(_EnvBase):
         ids = None if env_ids is None else torch.as_tensor(env_ids).cpu().numpy()
         self._native.reset(ids, self._stream())
         self._export_stamp = -1  # state changed without a step: exported AoS views are stale
+        self._obs = self._obs_slots[self._native.obs_slot()]
         self.extras = {}
         return self._obs, self.extras
 
@@ -306,8 +319,10 @@ class ManagerBasedRLEnv(_EnvBase):
             v, r, d = rollout.record_slots()
             self._native.step_record(action.data_ptr(), v, r, d, gamma, self._stream())
         self.common_step_counter += 1
-        if self.log_episodes:  # no snapshot, no memset: a view of this step's ring slot, cloned only if somebody reads it
-            self.extras = {"log": _LazyLog(self, self._bufs["LOG"][self._native.log_slot()], self.common_step_counter)}
+        self._obs = self._obs_slots[self._native.obs_slot()]
+        if self.log_episodes:  # no snapshot, no memset: views of this step's ring slot and its predecessor, read only if somebody asks
+            k = self._native.log_slot()
+            self.extras = {"log": _LazyLog(self, self._bufs["LOG"][k], self._bufs["LOG"][(k - 1) % RL_LOG_RING], self.common_step_counter)}
         else:
             self.extras = {}
         return self._obs, self._bufs["REWARD"], self._terminated, self._time_outs, self.extras
@@ -354,8 +369,42 @@ class ManagerBasedRLEnv(_EnvBase):
             self._native.export_state(self._stream())
             self._export_stamp = self.common_step_counter
 
+    # the state step() carries between calls, as torch views of the AoS buffers `rl_env_export_state` fills
+    STATE_BUFFERS = ("ROOT_STATE", "JOINT_POS", "JOINT_VEL", "ACTION", "GAINS", "CONTACT_TIMERS", "TASK_STATE", "ENV_ORIGIN")
+
+    def read_state(self) -> dict:
+        """Full carried state as a dict of host arrays: the AoS buffers above plus episode length, episode sums, terrain
+        levels and the step counter (tests/test_gpu_teacher_forced.py; `rl_env_export_state`)."""
+        self._export_stamp = -1
+        self._export()
+        out = {k.lower(): self._bufs[k].cpu().numpy().copy() for k in self.STATE_BUFFERS}
+        out["episode_length"] = self._bufs["EPISODE_LENGTH"].cpu().numpy().copy()
+        out["episode_sums"] = self._bufs["EPISODE_SUMS"][:, : self.num_envs].cpu().numpy().copy()
+        out["terrain_level"] = self._bufs["TERRAIN_LEVEL"].cpu().numpy().copy()
+        out["step_count"] = self._native.step_count
+        return out
+
+    def load_state(self, state: dict):
+        """Inverse of `read_state` (`rl_env_commit_state`): any subset of its keys."""
+        self._export_stamp = -1
+        self._export()  # parts that are not given keep their current values
+        for k in self.STATE_BUFFERS:
+            if k.lower() in state:
+                self._bufs[k].copy_(torch.as_tensor(np.asarray(state[k.lower()]), device=self.device).reshape(self._bufs[k].shape))
+        if "episode_length" in state:
+            self.episode_length_buf = state["episode_length"]
+        if "episode_sums" in state:
+            self._bufs["EPISODE_SUMS"][:, : self.num_envs].copy_(torch.as_tensor(np.asarray(state["episode_sums"]), device=self.device))
+        if "terrain_level" in state:
+            self._bufs["TERRAIN_LEVEL"].copy_(torch.as_tensor(np.asarray(state["terrain_level"]), device=self.device).to(torch.int32))
+        if "step_count" in state:
+            self._native.step_count = int(state["step_count"])
+            self.common_step_counter = int(state["step_count"])
+        self._native.commit_state(self._stream())
+        self._export_stamp = -1
+
     def write_state(self, root_state=None, joint_pos=None, joint_vel=None):
-        """Overwrite simulator state (host arrays); used by teacher-forced parity tests."""
+        """Overwrite root / joint state from host arrays (`rl_env_import_state`: export, overwrite, commit)."""
         keep = []
         ptrs = []
         for a in (root_state, joint_pos, joint_vel):

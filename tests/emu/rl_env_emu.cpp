@@ -8,8 +8,12 @@
 #include <pthread.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -20,15 +24,93 @@
 
 namespace {
 
+// Sense-reversing barrier of the LPE lane threads of one environment: spins (the lanes meet every few hundred
+// instructions), yields once the wait gets long - 16 lane threads may outnumber the host cores in the test tier.
+struct LaneBarrier {
+  std::atomic<int> count{0}, gen{0};
+  int n = 1;
+  void wait() {
+    const int g = gen.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+      count.store(0, std::memory_order_relaxed);
+      gen.store(g + 1, std::memory_order_release);
+    } else {
+      for (int spins = 0; gen.load(std::memory_order_acquire) == g; ++spins) {
+        if (spins < 2000) __builtin_ia32_pause();
+        else std::this_thread::yield();
+      }
+    }
+  }
+};
+
 template <int LPE>
-struct Team {
-  pthread_barrier_t bar;  // blocking barrier: 16 lane threads may outnumber the host cores
-  float slot[LPE];
+struct alignas(64) Team {
+  LaneBarrier bar;
+  alignas(64) float slot[LPE];
   float rstage[rl::MAX_T];
   std::vector<float> stage[2];
-  Team() { pthread_barrier_init(&bar, nullptr, LPE); }
-  ~Team() { pthread_barrier_destroy(&bar); }
-  void barrier(int&) { pthread_barrier_wait(&bar); }
+  Team() { bar.n = LPE; }
+  void barrier(int&) { bar.wait(); }
+};
+
+// Persistent worker pool: RL_EMU_TEAMS teams (default 1) of LPE lane threads; team t simulates the environments
+// e = t, t + teams, ...  bench.py's cpu_baseline leg sets RL_EMU_TEAMS = host cores / 4 to time the lane program on the
+// whole box; the tests use one team.
+class Pool {
+ public:
+  static Pool& get() {
+    static Pool p;
+    return p;
+  }
+  void run(int n_threads, const std::function<void(int)>& job) {
+    std::unique_lock<std::mutex> lk(m_);
+    while ((int)th_.size() < n_threads) {
+      const int id = (int)th_.size();
+      seen_.push_back(gen_);
+      th_.emplace_back([this, id] { worker(id); });
+    }
+    job_ = &job;
+    active_ = n_threads;
+    pending_ = n_threads;
+    ++gen_;
+    cv_.notify_all();
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+  ~Pool() {
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      stop_ = true;
+      cv_.notify_all();
+    }
+    for (auto& t : th_) t.join();
+  }
+
+ private:
+  void worker(int id) {
+    for (;;) {
+      const std::function<void(int)>* job;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || seen_[id] != gen_; });
+        if (stop_) return;
+        seen_[id] = gen_;
+        if (id >= active_) continue;
+        job = job_;
+      }
+      (*job)(id);
+      std::unique_lock<std::mutex> lk(m_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::vector<uint64_t> seen_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* job_ = nullptr;
+  uint64_t gen_ = 0;
+  int active_ = 0, pending_ = 0;
+  bool stop_ = false;
 };
 
 // SUB_ sub-lanes per leg: 4 * SUB_ host threads play the lanes of one environment
@@ -135,30 +217,36 @@ template <class TP, int SUB>
 void run(const rl::KState& S, const void* Tv, int reset) {
   const rl::TablesT<TP>* T = static_cast<const rl::TablesT<TP>*>(Tv);
   using Ctx = HostCtx<SUB>;
-  Team<Ctx::LPE> team;
-  team.stage[0].assign(std::max(1, T->policy_dim), 0.f);
-  team.stage[1].assign(std::max(1, T->critic_dim), 0.f);
-  std::vector<std::thread> th;
-  for (int l = 0; l < Ctx::LPE; ++l)
-    th.emplace_back([&, l]() {
-      Ctx ctx;
-      ctx.team = &team; ctx.T = T; ctx.k_ = l / SUB; ctx.sub_ = l % SUB; ctx.e_ = 0;
-      for (int e = 0; e < S.Npad; ++e) {
-        ctx.e_ = e;
-        rl::EnvProgram<Ctx, TP> prog(ctx, S);
-        if (reset)
-          prog.reset_entry();
-        else
-          prog.step();
-      }
-    });
-  for (auto& t : th) t.join();
+  int teams = 1;
+  if (const char* v = std::getenv("RL_EMU_TEAMS")) teams = std::max(1, std::atoi(v));
+  teams = std::min(teams, (int)S.Npad);
+  std::vector<std::unique_ptr<Team<Ctx::LPE>>> team(teams);
+  for (auto& t : team) {
+    t.reset(new Team<Ctx::LPE>());
+    t->stage[0].assign(std::max(1, T->policy_dim), 0.f);
+    t->stage[1].assign(std::max(1, T->critic_dim), 0.f);
+  }
+  const std::function<void(int)> job = [&](int id) {
+    const int tm = id / Ctx::LPE, l = id % Ctx::LPE;
+    Ctx ctx;
+    ctx.team = team[tm].get(); ctx.T = T; ctx.k_ = l / SUB; ctx.sub_ = l % SUB; ctx.e_ = 0;
+    for (int e = tm; e < S.Npad; e += teams) {
+      ctx.e_ = e;
+      rl::EnvProgram<Ctx, TP> prog(ctx, S);
+      if (reset)
+        prog.reset_entry();
+      else
+        prog.step();
+    }
+  };
+  Pool::get().run(teams * Ctx::LPE, job);
 }
 
 struct Backend {
   std::string err;
   const std::string& error() const { return err; }
   int sub = 1;  // RL_EMU_SUB=4 selects the 16-lanes-per-env mapping (16 host threads per env: slow)
+  int activate() { return 0; }
   int init(int) {
     if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : 1;
     return 0;
@@ -188,13 +276,12 @@ struct Backend {
     for (int e = 0; e < S.Npad; ++e) rl::export_env(S, *T, A, e);
     return 0;
   }
-  int launch_import(const rl::KState& S, const rl::Tables* T, const float* r, const float* q, const float* qd, int N, int D, void*) {
-    for (int e = 0; e < N; ++e) rl::import_env(S, *T, r, q, qd, e);
+  int launch_commit(const rl::KState& S, const rl::Tables* T, const rl::AosPtrs& A, void*) {
+    for (int e = 0; e < S.Npad; ++e) rl::commit_env(S, *T, A, e);
     return 0;
   }
-  int read_and_zero(void* out, void* src, size_t n, void*) {
+  int d2h_sync(void* out, const void* src, size_t n, void*) {
     std::memcpy(out, src, n);
-    std::memset(src, 0, n);
     return 0;
   }
 };

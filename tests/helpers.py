@@ -41,3 +41,132 @@ def assert_close(name, got, want, rtol, atol, frac_ok=1.0):
     ok = np.abs(got - want) <= atol + rtol * np.abs(want)
     frac = ok.mean() if ok.size else 1.0
     assert frac >= frac_ok, f"{name}: only {frac:.4f} within tol (need {frac_ok}); max abs err {np.abs(got - want).max():.3e}"
+
+
+# ------------------------------------------------------------------------------------------------
+# teacher-forced parity: both sides step ONCE from a shared state (SURVEY.md 8(c) last row)
+# ------------------------------------------------------------------------------------------------
+STATE_BUFFERS = ("ROOT_STATE", "JOINT_POS", "JOINT_VEL", "ACTION", "GAINS", "CONTACT_TIMERS", "TASK_STATE", "ENV_ORIGIN")
+
+
+def emu_read_state(nat):
+    """`ManagerBasedRLEnv.read_state()` for a NativeEnv of the CPU lane emulator (host pointers)."""
+    nat.export_state()
+    out = {k.lower(): host_view(nat, k).copy() for k in STATE_BUFFERS}
+    out["episode_length"] = host_view(nat, "EPISODE_LENGTH").copy()
+    out["episode_sums"] = host_view(nat, "EPISODE_SUMS")[:, : nat.num_envs].copy()
+    out["terrain_level"] = host_view(nat, "TERRAIN_LEVEL").copy()
+    out["step_count"] = nat.step_count
+    return out
+
+
+def emu_load_state(nat, s):
+    nat.export_state()
+    for k in STATE_BUFFERS:
+        host_view(nat, k)[...] = np.asarray(s[k.lower()], dtype=np.float32).reshape(host_view(nat, k).shape)
+    host_view(nat, "EPISODE_LENGTH")[...] = s["episode_length"]
+    host_view(nat, "EPISODE_SUMS")[:, : nat.num_envs] = s["episode_sums"]
+    host_view(nat, "TERRAIN_LEVEL")[...] = s["terrain_level"]
+    nat.step_count = int(s["step_count"])
+    nat.commit_state()
+
+
+# Margins (oracle/physics.py Physics.margins) below which an env counts as sitting ON one of the model's discontinuities,
+# where fp32 and fp64 may legitimately land on different sides: contact on/off (penetration, lagged normal force),
+# static/dynamic friction, joint-limit damper, implicit-actuator saturation, contact-sensor force threshold.
+SWITCH_EPS = dict(phi=2e-5, fn0=2e-2, stick=2e-4, limit=2e-5, saturation=2e-3, force=2e-2)
+
+
+def switch_mask(margins, eps=SWITCH_EPS):
+    """bool [N]: envs within `eps` of a switch during the step the margins were recorded over."""
+    mask = None
+    for k, v in margins.items():
+        m = np.asarray(v) < eps[k]
+        mask = m if mask is None else (mask | m)
+    return mask
+
+
+def rel_err(got, want, floor):
+    """max over the trailing axes of |got - want| / max(|want|, floor): one number per env."""
+    got = np.asarray(got, dtype=np.float64).reshape(len(got), -1)
+    want = np.asarray(want, dtype=np.float64).reshape(len(want), -1)
+    return (np.abs(got - want) / np.maximum(np.abs(want), floor)).max(axis=1)
+
+
+def teacher_forced_check(ora, state, action, got, n_twins=2, gain=16.0, base=1e-5, seed=0, max_mask=0.015):
+    """One step of the fp64 oracle from the SHARED `state` (a read_state() dict of the HIP / emulator env, i.e. fp32 values)
+    against what the fp32 side produced from that same state (`got`: dict with the read_state() keys after the step plus
+    reward, reward_terms [T, N], done [N] bool, obs_policy, obs_critic).
+
+    Tolerance, per env and per field:   err <= base + gain * s,   err = max |got - want| / max(|want|, 1)
+    where s is the oracle's OWN response (same metric) to a random relative perturbation of 1e-6 (16 fp32 ulp) of the shared
+    root / joint state, maximum over `n_twins` perturbed twins.  Why not a flat 1e-5: the step map of a robot in stiff
+    contact amplifies an input perturbation of 1e-6 by 30x (median) to 2000x (joint velocities; measured),
+    so fp32 round-off inside 4 substeps necessarily shows up at 1e-5 .. 1e-3 there, while airborne envs agree to < 1e-5.
+    A kernel bug (wrong lane, wrong slot, wrong term) produces errors orders of magnitude above its env's own sensitivity.
+    Envs within SWITCH_EPS of a discontinuity of the model (contact on/off, stick/slip, limit damper, actuator saturation,
+    sensor threshold) are excluded - and counted: the test fails if they exceed `max_mask` of the batch.
+    Returns a report dict; raises AssertionError listing the offending envs otherwise."""
+    N = ora.N
+    ora.load_state(state)
+    ora.phys.margins = {}
+    o = ora.step(action)
+    want = ora.read_state()
+    want.update(reward=ora.reward.copy(), reward_terms=ora.reward_terms.copy(), done=(ora.terminated | ora.time_outs).copy(),
+                obs_policy=o[0].copy(), obs_critic=o[1].copy())
+    mask = switch_mask(ora.phys.margins)
+    margins, ora.phys.margins = ora.phys.margins, None
+    rng = np.random.default_rng(seed)
+    fields = ("root_state", "joint_pos", "joint_vel", "task_state", "obs_policy", "obs_critic")
+    sens = {f: np.zeros(N) for f in fields}
+    sens["reward"] = np.zeros(N)
+    sens["reward_terms"] = np.zeros((len(want["reward_terms"]), N))
+    for _ in range(n_twins):
+        tw = dict(state)
+        for k in ("root_state", "joint_pos", "joint_vel"):
+            tw[k] = np.asarray(state[k], dtype=np.float64) * (1.0 + 1e-6 * rng.uniform(-1, 1, np.shape(state[k])))
+        ora.load_state(tw)
+        ot = ora.step(action)
+        t = ora.read_state()
+        t.update(obs_policy=ot[0], obs_critic=ot[1])
+        for f in fields:
+            sens[f] = np.maximum(sens[f], rel_err(t[f], want[f], 1.0))
+        sens["reward"] = np.maximum(sens["reward"], np.abs(ora.reward - want["reward"]))
+        sens["reward_terms"] = np.maximum(sens["reward_terms"], np.abs(ora.reward_terms - want["reward_terms"]))
+    ok = ~mask
+    report = dict(n=N, masked=int(mask.sum()), masked_frac=float(mask.mean()), margins_min={k: float(np.min(v)) for k, v in margins.items()})
+    bad = {}
+    for f in fields:
+        err = rel_err(got[f], want[f], 1.0)
+        tol = base + gain * sens[f]
+        report[f] = dict(max_err=float(err[ok].max()), p50=float(np.median(err)), frac_within_base=float(np.mean(err[ok] <= base)), max_tol=float(tol[ok].max()))
+        b = np.nonzero((err > tol) & ok)[0]
+        if len(b):
+            bad[f] = [(int(i), float(err[i]), float(tol[i])) for i in b[:8]]
+    # rewards: absolute, base scaled by the term weights (reward = sum of w * f * dt)
+    w = np.abs(np.array([ora.desc.task.rewards[i].weight for i in range(ora.desc.task.n_rewards)], dtype=np.float64))
+    err_t = np.abs(np.asarray(got["reward_terms"], dtype=np.float64) - want["reward_terms"])
+    tol_t = base * np.maximum(np.maximum(w[:, None], np.abs(want["reward_terms"])), 1e-3) + gain * sens["reward_terms"]
+    bt = np.argwhere((err_t > tol_t) & ok[None])
+    if len(bt):
+        bad["reward_terms"] = [(int(t), int(i), float(err_t[t, i]), float(tol_t[t, i])) for t, i in bt[:8]]
+    err_r = np.abs(np.asarray(got["reward"], dtype=np.float64) - want["reward"])
+    tol_r = base * np.maximum(w.sum(), 1.0) * ora.step_dt + base * np.abs(want["reward"]) + gain * sens["reward"]
+    br = np.nonzero((err_r > tol_r) & ok)[0]
+    if len(br):
+        bad["reward"] = [(int(i), float(err_r[i]), float(tol_r[i])) for i in br[:8]]
+    report["reward"] = dict(max_err=float(err_r[ok].max()), frac_within_base=float(np.mean(err_r[ok] <= base * np.maximum(w.sum(), 1.0) * ora.step_dt)))
+    # discrete outputs: exact
+    if not np.array_equal(np.asarray(got["done"])[ok], want["done"][ok]):
+        bad["done"] = np.nonzero((np.asarray(got["done"]) != want["done"]) & ok)[0][:8].tolist()
+    for f in ("episode_length", "terrain_level"):
+        if not np.array_equal(np.asarray(got[f])[ok], np.asarray(want[f])[ok]):
+            bad[f] = np.nonzero((np.asarray(got[f]) != np.asarray(want[f])) & ok)[0][:8].tolist()
+    te = np.abs(np.asarray(got["contact_timers"], dtype=np.float64) - want["contact_timers"]).reshape(N, -1).max(axis=1)
+    if (te[ok] > 1e-6).any():
+        bad["contact_timers"] = np.nonzero((te > 1e-6) & ok)[0][:8].tolist()
+    report["done_count"] = int(want["done"].sum())
+    report["bad"] = bad
+    assert report["masked_frac"] <= max_mask, f"{report['masked']} of {N} envs sit on a switch (> {max_mask:.1%}): {report}"
+    assert not bad, f"teacher-forced parity violated outside the switch mask: {bad}\nreport: {report}"
+    return report

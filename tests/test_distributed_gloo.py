@@ -36,7 +36,7 @@ def _shard(rank, emu_lib):
     for _ in range(STEPS):
         a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
         nat.step(a.ctypes.data)
-        log += nat.read_log()
+        log += host_view(nat, "LOG")[nat.log_slot()]  # this step's own accumulators (rl_env_read_log would repeat the last reset's)
         rew += float(host_view(nat, "REWARD").sum())
     nat.close()
     return log, rew
@@ -74,3 +74,43 @@ def test_env_shards_and_metric_allreduce(emu_lib):
         np.testing.assert_allclose(reduced, total, rtol=1e-6)    # all-reduce == sum over shards
     assert total[0] == world * N // 2                            # every forced time-out was counted exactly once
     assert not np.array_equal(ref[0][0], ref[1][0])              # different seeds -> different shards
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py --gpus N: the flag decides how many ranks run (train.py:143-150 launch contract)
+# ------------------------------------------------------------------------------------------------
+def _bench(args, env_extra=None, timeout=300):
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="box has >= 2 GPUs: the launch would succeed")
+def test_bench_refuses_more_gpus_than_the_box_has():
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 2 and "--gpus 2" in r.stderr and "HIP device" in r.stderr
+    assert r.stdout.strip() == ""  # no JSON line that could be mistaken for a 2-GPU result
+
+
+def test_bench_rejects_a_rank_count_that_differs_from_the_flag():
+    r = _bench(["--gpus", "4", "--steps", "2", "--warmup", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_spawns_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus 2` with no rank environment re-executes itself under torch.distributed.run with 2 ranks: checked
+    through the launcher's command line (the ranks themselves need GPUs)."""
+    import bench
+
+    seen = {}
+    monkeypatch.setenv("RL_BENCH_SHARE_GPU", "1")  # skips the device-count check of the launcher
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    assert bench.spawn_ranks(bench.parse_args(["--gpus", "2", "--steps", "3"])) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "3"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -5,12 +5,13 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_close, oracle_root_state
+from helpers import SWITCH_EPS, assert_close, oracle_root_state, switch_mask
 from oracle.env import OracleEnv
 from robot_lab_amd.scene import build_world, load_bundle
 
 pytestmark = pytest.mark.gpu
 TASK = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
+FREE_RUN_EPS = {k: 10.0 * v for k, v in SWITCH_EPS.items()}  # as in test_gpu_parity.py
 
 
 def _pair(N, seed, task=TASK):
@@ -76,11 +77,14 @@ def test_zero_actions_stand_regime():
     env.reset()
     ora.reset()
     a = np.zeros((N, 12), dtype=np.float32)
+    ora.phys.margins = {}
     for _ in range(8):
         obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
         o = ora.step(a)
-    assert_close("reward", rew.cpu().numpy(), ora.reward, 1e-3, 3e-5, 0.97)
-    assert_close("q", env.scene["robot"].data.joint_pos.cpu().numpy(), ora.st["q"], 3e-3, 3e-4, 0.97)
+    ok = ~switch_mask(ora.phys.margins, FREE_RUN_EPS)  # free run: envs that came near a contact switch are excluded, the rest must agree 100 %
+    assert ok.mean() >= 0.6
+    assert_close("reward", rew.cpu().numpy()[ok], ora.reward[ok], 1e-3, 3e-5)
+    assert_close("q", env.scene["robot"].data.joint_pos.cpu().numpy()[ok], ora.st["q"][ok], 3e-3, 3e-4)
     env.close()
 
 
@@ -92,12 +96,15 @@ def test_one_lane_per_leg_mapping_matches_too(monkeypatch):
     env.reset()
     ora.reset()
     rng = np.random.default_rng(1)
+    ora.phys.margins = {}
     for _ in range(4):
         a = rng.uniform(-1, 1, (N, 12)).astype(np.float32)
         obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
         o = ora.step(a)
-    assert_close("reward", rew.cpu().numpy(), ora.reward, 1e-3, 2e-5, 0.98)
-    assert_close("root", env.scene["robot"].data.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4, 0.98)
+    ok = ~switch_mask(ora.phys.margins, FREE_RUN_EPS)
+    assert ok.mean() >= 0.75
+    assert_close("reward", rew.cpu().numpy()[ok], ora.reward[ok], 1e-3, 2e-5)
+    assert_close("root", env.scene["robot"].data.root_state_w.cpu().numpy()[ok], oracle_root_state(ora)[ok], 2e-3, 2e-4)
     env.close()
 
 

@@ -1,10 +1,15 @@
 """`-m gpu`: the HIP path, called through the C-ABI (robot_lab_amd.env -> librl_env_hip.so), against the
-fp64 oracle on identical seeds and actions.  fp32 tolerance: root/joint state rtol 2e-3 (atol 2e-4) after
-5 env steps (20 physics substeps with contacts), rewards atol 2e-5, dones exact."""
+fp64 oracle on identical seeds and actions, over FREE-RUNNING 5-step trajectories (20 physics substeps with contacts) of
+21 task ids.  A free run diverges wherever one side crosses a contact switch the other does not, so the comparison is
+explicit about that: the oracle records how close every env came to a discontinuity of the model on every step
+(Physics.margins; helpers.switch_mask with 10x the one-step margins, because the two trajectories drift apart by
+round-off amplification before they reach the switch), those envs are excluded and counted, and 100 % of the entries of
+the remaining envs must agree: state rtol 2e-3 (atol 2e-4), rewards atol 2e-5, dones exact.  The tight, single-step form
+of this comparison at the BASELINE sizes is tests/test_gpu_teacher_forced.py."""
 import numpy as np
 import pytest
 
-from helpers import assert_close, oracle_root_state
+from helpers import SWITCH_EPS, assert_close, oracle_root_state, switch_mask
 from oracle.env import OracleEnv
 from robot_lab_amd.scene import build_world, load_bundle
 
@@ -46,6 +51,9 @@ def _pair(task, N, seed):
     return env, OracleEnv(desc, h, to, N, seed, eo), torch
 
 
+FREE_RUN_EPS = {k: 10.0 * v for k, v in SWITCH_EPS.items()}
+
+
 @pytest.mark.parametrize("task", TASKS)
 def test_short_horizon_parity(task):
     N = 32 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1")) else 64
@@ -55,19 +63,25 @@ def test_short_horizon_parity(task):
     assert_close("obs0", obs["policy"].cpu().numpy(), o[0], 1e-4, 1e-5)
     assert_close("critic0", obs["critic"].cpu().numpy(), o[1], 1e-3, 1e-4)
     rng = np.random.default_rng(3)
+    ora.phys.margins = {}  # minima over the whole trajectory: an env that touched a switch at step s stays excluded afterwards
+    on_switch = np.zeros(N, dtype=bool)
     for s in range(5):
         a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
         obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
         o = ora.step(a)
-        assert_close(f"reward[{s}]", rew.cpu().numpy(), ora.reward, 1e-3, 2e-5, 0.98 if N >= 64 else 0.96)  # N = 32: one contact-switch outlier allowed
-        assert np.array_equal((term | tout).cpu().numpy(), ora.terminated | ora.time_outs)
+        on_switch |= switch_mask(ora.phys.margins, FREE_RUN_EPS)
+        ok = ~on_switch
+        assert_close(f"reward[{s}]", rew.cpu().numpy()[ok], ora.reward[ok], 1e-3, 2e-5)
+        assert np.array_equal((term | tout).cpu().numpy()[ok], (ora.terminated | ora.time_outs)[ok])
+    ok = ~on_switch
+    assert on_switch.mean() <= 0.25, f"{on_switch.sum()} of {N} envs came within the switch margins over 5 steps"
     d = env.scene["robot"].data
-    assert_close("root", d.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4, 0.98)
-    assert_close("q", d.joint_pos.cpu().numpy(), ora.st["q"], 2e-3, 2e-4, 0.98)
-    assert_close("qd", d.joint_vel.cpu().numpy(), ora.st["qd"], 5e-3, 5e-3, 0.97)
-    assert_close("rew_terms", env.reward_terms().cpu().numpy(), ora.reward_terms, 2e-3, 2e-5, 0.98)
-    assert_close("policy", obs["policy"].cpu().numpy(), o[0], 5e-3, 5e-3, 0.97)
-    assert_close("critic", obs["critic"].cpu().numpy(), o[1], 5e-3, 5e-3, 0.97)
+    assert_close("root", d.root_state_w.cpu().numpy()[ok], oracle_root_state(ora)[ok], 2e-3, 2e-4)
+    assert_close("q", d.joint_pos.cpu().numpy()[ok], ora.st["q"][ok], 2e-3, 2e-4)
+    assert_close("qd", d.joint_vel.cpu().numpy()[ok], ora.st["qd"][ok], 5e-3, 5e-3)
+    assert_close("rew_terms", env.reward_terms().cpu().numpy()[:, ok], ora.reward_terms[:, ok], 2e-3, 2e-5)
+    assert_close("policy", obs["policy"].cpu().numpy()[ok], o[0][ok], 5e-3, 5e-3)
+    assert_close("critic", obs["critic"].cpu().numpy()[ok], o[1][ok], 5e-3, 5e-3)
     env.close()
 
 
@@ -83,10 +97,13 @@ def test_time_out_reset_parity(task, N):
     ora.episode_length_buf[:] = ep
     rng = np.random.default_rng(0)
     n_reset = 0
+    ora.phys.margins = {}
+    on_switch = np.zeros(N, dtype=bool)
     for s in range(3):
         a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
         obs, rew, term, tout, extras = env.step(torch.from_numpy(a).cuda())
         o = ora.step(a)
+        on_switch |= switch_mask(ora.phys.margins, FREE_RUN_EPS)
         done = (term | tout).cpu().numpy()
         assert np.array_equal(done, ora.terminated | ora.time_outs)
         n_reset += int(done.sum())
@@ -97,15 +114,16 @@ def test_time_out_reset_parity(task, N):
         assert np.array_equal(env.episode_length_buf.cpu().numpy(), ora.episode_length_buf)
     assert n_reset >= N // 4  # the forced time-outs (+ any illegal-contact terminations on G1)
     d = env.scene["robot"].data
-    assert_close("root", d.root_state_w.cpu().numpy(), oracle_root_state(ora), 2e-3, 2e-4, 0.98)
-    assert_close("critic", obs["critic"].cpu().numpy(), o[1], 5e-3, 5e-3, 0.97)
+    ok = ~on_switch
+    assert_close("root", d.root_state_w.cpu().numpy()[ok], oracle_root_state(ora)[ok], 2e-3, 2e-4)
+    assert_close("critic", obs["critic"].cpu().numpy()[ok], o[1][ok], 5e-3, 5e-3)
     env.close()
 
 
-@pytest.mark.parametrize("task,N", [(TASKS[1], 4096), (TASKS[5], 2048), (TASKS[3], 4096)])
+@pytest.mark.parametrize("task,N", [(TASKS[1], 4096), (TASKS[2], 4096), (TASKS[5], 2048), (TASKS[3], 4096)])
 def test_full_size_properties(task, N):
-    """BASELINE configs 2 (A1 Rough, 4096 envs), 4 (G1 Rough, 2048) and 5 (Go2W Rough, 4096) at full size:
-    size-independent invariants of step()."""
+    """BASELINE configs 2 (A1 Rough, 4096 envs), 3 (Go2 Rough, 4096 per GPU), 4 (G1 Rough, 2048) and 5 (Go2W Rough, 4096) at
+    full size: size-independent invariants of step() over 60 steps (oracle parity at these sizes: test_gpu_teacher_forced.py)."""
     import torch
 
     from robot_lab_amd.env import ManagerBasedRLEnv

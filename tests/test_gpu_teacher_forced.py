@@ -1,0 +1,101 @@
+"""`-m gpu`: teacher-forced one-step parity at the BASELINE.json sizes (configs 2 - 5: A1 Rough 4096, Go2 Rough 4096, G1 Rough
+2048, Go2W Rough 4096), HIP through the C-ABI vs the fp64 oracle (SURVEY.md 8(c) last row, section 7 "Chaotic divergence").
+
+The HIP env runs K random-action steps (so the batch holds every phase of contact, commands and resets), its full carried
+state is exported (rl_env_export_state), the oracle adopts it, and BOTH take one step from that shared state.  100 % of the
+envs outside the explicitly computed switch mask must agree within the per-env bound of helpers.teacher_forced_check
+(1e-5 + 16 x the oracle's own response to a 1e-6 input perturbation); dones, episode lengths, terrain levels and contact
+timers exactly; the mask itself must stay below 1.5 % of the batch.  A second HIP env takes the same step from the state
+committed back through rl_env_commit_state and must reproduce the first one bit for bit (the exchange carries everything)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import teacher_forced_check
+from oracle.env import OracleEnv
+from robot_lab_amd.scene import build_world, load_bundle
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 4096),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", 4096),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 2048),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 4096),
+]
+
+
+def _outputs(env, obs, rew, term, tout):
+    got = env.read_state()
+    got.update(reward=rew.cpu().numpy(), reward_terms=env.reward_terms().cpu().numpy(), done=(term | tout).cpu().numpy(),
+               obs_policy=obs["policy"].cpu().numpy(), obs_critic=obs["critic"].cpu().numpy())
+    return got
+
+
+@pytest.mark.parametrize("task,N", CONFIGS)
+def test_one_step_from_shared_state_full_size(task, N):
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    K, seed = 30, 42
+    env = ManagerBasedRLEnv(task, num_envs=N, seed=seed, device="cuda:0")
+    env2 = ManagerBasedRLEnv(task, num_envs=N, seed=seed, device="cuda:0")
+    env.reset()
+    env2.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ep = torch.randint(0, env.max_episode_length, (N,), generator=torch.Generator().manual_seed(5))
+    ep[::7] = env.max_episode_length - 1 - (torch.arange(len(ep[::7])) % (K + 2))  # time-outs during the warm-up and on the compared step
+    env.episode_length_buf = ep
+    for _ in range(K):
+        env.step(torch.rand(N, env.num_actions, device="cuda", generator=g) * 2 - 1)
+    state = env.read_state()
+    assert state["step_count"] == K
+    a = torch.rand(N, env.num_actions, device="cuda", generator=g) * 2 - 1
+    out1 = env.step(a)
+    # --- the C-ABI state exchange carries everything: a second env continues bit-identically from the committed state
+    env2.load_state(state)
+    out2 = env2.step(a)
+    for x, y in zip((out1[0]["policy"], out1[0]["critic"], out1[1], out1[2], out1[3]), (out2[0]["policy"], out2[0]["critic"], out2[1], out2[2], out2[3])):
+        assert torch.equal(x, y)
+    s1, s2 = env.read_state(), env2.read_state()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k]), k
+    # --- HIP vs oracle from the shared state
+    desc, extra = load_bundle(task)
+    h, to, eo = build_world(desc, extra, N, 0)
+    ora = OracleEnv(desc, h, to, N, seed, eo)
+    rep = teacher_forced_check(ora, state, a.cpu().numpy(), _outputs(env, *out1[:4]), n_twins=2, max_mask=0.015)
+    assert rep["done_count"] > 0
+    rep["task"], rep["warmup_steps"] = task, K
+    print("\n[teacher-forced]", json.dumps(rep))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "teacher_forced_" + task.split("Unitree-")[1].replace("-v0", "") + ".json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    env.close()
+    env2.close()
+
+
+def test_observations_survive_the_next_step():
+    """rsl_rl's PPO.act keeps `obs` by reference across env.step(); the tensors returned by step t must still
+    hold s_t after step t + 1 (two alternating HBM buffers, no copy)."""
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    N = 256
+    env = ManagerBasedRLEnv(CONFIGS[0][0], num_envs=N, seed=1, device="cuda:0")
+    obs, _ = env.reset()
+    keep, snap = obs, {k: v.clone() for k, v in obs.items()}
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(4):
+        obs, *_ = env.step(torch.rand(N, env.num_actions, device="cuda", generator=g) * 2 - 1)
+        for k in keep:
+            assert torch.equal(keep[k], snap[k]), (t, k)         # what the previous call returned is intact ...
+            assert keep[k].data_ptr() != obs[k].data_ptr()       # ... because this call wrote the other buffer
+            assert not torch.equal(keep[k], obs[k])
+        keep, snap = obs, {k: v.clone() for k, v in obs.items()}
+    env.close()

@@ -93,6 +93,7 @@ def test_rollout_library_exports():
     (4096, 24, 45, 235, 12),  # A1 rough: rsl_rl_ppo_cfg.py:11, obs / critic widths of the A1 bundles
     (2048, 24, 96, 310, 29),  # G1-sized action rows (29 is not a multiple of the 4-wide Philox block)
     (37, 3, 5, 7, 1),         # ragged everything
+    (37, 3, 45, 235, 12),     # A1 widths on a ragged env count: slots of the [T][N][dim] storage are only 4-byte aligned
 ])
 def test_hip_rollout_matches_oracle(N, T, obs, critic, A):
     import torch

@@ -1,0 +1,111 @@
+"""CPU tier of the teacher-forced parity check (SURVEY.md 8(c) last row): the lane program (CPU lane emulator, the source
+hipcc compiles) and the fp64 oracle take ONE step from a SHARED state that the lane program itself reached after a few
+random-action steps (contacts, resets, commands in every phase).  Also covers the C-ABI state round trip
+(rl_env_export_state / rl_env_commit_state / rl_env_import_state, rl_env_step_count) that the GPU tier uses at the
+BASELINE sizes (tests/test_gpu_teacher_forced.py)."""
+import numpy as np
+import pytest
+
+from helpers import emu_load_state, emu_read_state, host_view, make_pair, teacher_forced_check
+
+CASES = [
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 48, 8),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", 32, 6),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 32, 6),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 8, 6),
+]
+
+
+def _outputs(nat, N):
+    got = emu_read_state(nat)
+    got.update(reward=host_view(nat, "REWARD").copy(), reward_terms=host_view(nat, "REWARD_TERMS")[:, :N].copy(),
+               done=host_view(nat, "TERMINATED").astype(bool) | host_view(nat, "TIME_OUT").astype(bool),
+               obs_policy=host_view(nat, "OBS_POLICY").copy(), obs_critic=host_view(nat, "OBS_CRITIC").copy())
+    return got
+
+
+@pytest.mark.parametrize("task,N,K", CASES)
+def test_one_step_from_shared_state(task, N, K, emu_lib):
+    desc, ora, nat = make_pair(task, N, 42, emu_lib)
+    nat.reset()
+    rng = np.random.default_rng(1)
+    ep = rng.integers(0, nat.max_episode_length, N)
+    ep[::5] = nat.max_episode_length - 1 - (np.arange(len(ep[::5])) % (K + 2))  # time-outs during the warm-up ...
+    ep[1:4] = nat.max_episode_length - 1 - K                                     # ... and on the compared step
+    host_view(nat, "EPISODE_LENGTH")[:] = ep
+    for _ in range(K):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        nat.step(a.ctypes.data)
+    state = emu_read_state(nat)
+    assert state["step_count"] == K
+    a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+    nat.step(a.ctypes.data)
+    # small batches: one env on a switch is already 2 - 12 % of the batch, so the mask-size bound is checked at full size only
+    rep = teacher_forced_check(ora, state, a, _outputs(nat, N), max_mask=0.25)
+    assert rep["done_count"] > 0  # the compared step itself resets somebody
+    nat.close()
+
+
+def test_state_round_trip_is_exact(emu_lib):
+    """export -> commit into a second env -> both step bit-identically (every carried field is in the exchange)."""
+    task, N = CASES[0][0], 16
+    desc, _, nat = make_pair(task, N, 7, emu_lib)
+    _, _, nat2 = make_pair(task, N, 7, emu_lib)
+    nat.reset()
+    nat2.reset()
+    rng = np.random.default_rng(2)
+    host_view(nat, "EPISODE_LENGTH")[:] = rng.integers(0, nat.max_episode_length, N)
+    for _ in range(5):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        nat.step(a.ctypes.data)
+    emu_load_state(nat2, emu_read_state(nat))
+    assert nat2.step_count == nat.step_count == 5
+    for _ in range(2):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        nat.step(a.ctypes.data)
+        nat2.step(a.ctypes.data)
+        for name in ("OBS_POLICY", "OBS_CRITIC", "REWARD", "TERMINATED", "TIME_OUT", "EPISODE_LENGTH", "EPISODE_SUMS", "COMMAND"):
+            assert np.array_equal(host_view(nat, name), host_view(nat2, name)), name
+    s1, s2 = emu_read_state(nat), emu_read_state(nat2)
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k]), k
+    nat.close()
+    nat2.close()
+
+
+def test_import_state_host_arrays(emu_lib):
+    """rl_env_import_state (host arrays; any part may be NULL) overwrites exactly the given parts."""
+    task, N = CASES[0][0], 16
+    desc, _, nat = make_pair(task, N, 3, emu_lib)
+    nat.reset()
+    before = emu_read_state(nat)
+    q = (before["joint_pos"] + 0.01).astype(np.float32)
+    nat.import_state(0, q.ctypes.data, 0)
+    after = emu_read_state(nat)
+    assert np.array_equal(after["joint_pos"], q)
+    for k in before:
+        if k != "joint_pos":
+            assert np.array_equal(before[k], after[k]), k
+    nat.close()
+
+
+def test_observation_buffers_alternate(emu_lib):
+    """The observations returned by step t are not touched by step t + 1 (include/rl_env.h "Ownership": rsl_rl's PPO.act keeps
+    a reference to them across env.step)."""
+    task, N = CASES[0][0], 16
+    desc, _, nat = make_pair(task, N, 3, emu_lib)
+    nat.reset()
+    rng = np.random.default_rng(0)
+    views, snaps = [], []
+    for t in range(3):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        nat.step(a.ctypes.data)
+        assert nat.obs_slot() == (t + 1 + 1) % 2  # reset() wrote slot 1, the steps alternate from there
+        views.append(host_view(nat, "OBS_CRITIC"))  # a VIEW of the buffer step t wrote
+        snaps.append(views[-1].copy())
+        if t >= 1:
+            assert np.array_equal(views[t - 1], snaps[t - 1])  # step t did not overwrite what step t - 1 returned
+            assert not np.array_equal(views[t], views[t - 1])
+    ring = host_view(nat, "OBS_CRITIC_RING")
+    assert ring.shape[0] == 2 and np.array_equal(ring[nat.obs_slot(), :N], views[-1])
+    nat.close()
