@@ -20,6 +20,15 @@
 
 #include "env_tables.h"
 
+// RL_PHASE("name"): with -DRL_PHASE_MARKS the device build plants a `; PHASE name` comment in the assembly so that
+// tools/isa_profile.py can attribute the static instruction mix to the phases of the lane program (analysis builds only:
+// an asm volatile statement is also a scheduling barrier).
+#if defined(RL_PHASE_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define RL_PHASE(name) asm volatile("; PHASE " name)
+#else
+#define RL_PHASE(name) ((void)0)
+#endif
+
 namespace rl {
 
 template <int N>
@@ -671,6 +680,7 @@ struct EnvLane {
     // keep the compiler from hoisting the (loop-invariant) LDS table reads of all four substeps to the
     // top of the kernel, where ~200 of them stayed live and spilled to scratch
     asm volatile("" ::: "memory");
+    RL_PHASE("sub.actuators+kinematics");
     float tau_e[JX], pd_diag[JX], pd_rhs[JX];
     actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
 
@@ -703,7 +713,9 @@ struct EnvLane {
       for (int i = 0; i < UI::size; ++i) Uc[i] = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) rvc[i] = 0.f;
+      RL_PHASE("sub.contact_pass1");
       contact_pass1(C, Rwb, V0, slot_valid, Uc, rvc, active_mask);
+      RL_PHASE("sub.leg_sum");
       if (SUB > 1 && ctx.any(active_mask != 0u)) {
 #pragma unroll
         for (int i = 0; i < UI::size; ++i) Uc[i] = ctx.leg_sum(Uc[i]);
@@ -728,6 +740,7 @@ struct EnvLane {
   RL_FN void solve_and_integrate(UT& U, RT& rv, const ChainTP& C, const M3& Rwb, const SV V0, const SV a0, const float (&tau_e)[JX], const float (&pd_diag)[JX],
                                  const float (&pd_rhs)[JX], const uint32_t active_mask) {
     const float dt = u.dt;
+    RL_PHASE("sub.crba");
     // ---- trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
     constexpr int NWA = NW > 0 ? NW : 1;
     SV Sw[NWA], Vw[NWA], aw[NWA];
@@ -1026,6 +1039,7 @@ struct EnvLane {
     }
 
     // ---- Schur complement of the limb block, cross-limb reduction, NB x NB trunk solve, back substitution
+    RL_PHASE("sub.schur");
     float Lc[CL][CL];
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
@@ -1059,6 +1073,7 @@ struct EnvLane {
       for (int m = 0; m < j; ++m) t -= Lc[j][m] * z[m];
       z[j] = t * Lc[j][j];
     }
+    RL_PHASE("sub.cross_leg_sum");
     using BI = SymIdx<NB>;
     float Cb[BI::size], db[NB];
 #pragma unroll
@@ -1075,6 +1090,7 @@ struct EnvLane {
         Cb[BI::at(r, c)] = ctx.gsum(v);
       }
     }
+    RL_PHASE("sub.trunk_solve");
     float nu0[NB];
     {  // NB x NB Cholesky solve
       float G[NB][NB];
@@ -1109,6 +1125,7 @@ struct EnvLane {
         nu0[j] = t * G[j][j];
       }
     }
+    RL_PHASE("sub.back_subst");
     float qdn[JX];
 #pragma unroll
     for (int j = CL - 1; j >= 0; --j) {
@@ -1125,6 +1142,7 @@ struct EnvLane {
     for (int j = 0; j < JX; ++j) qdn[j] = clampf(qdn[j], -L.vel_limit[j], L.vel_limit[j]);
 
     // ---- contact sensor: net contact force per body with the NEW velocities (world frame)
+    RL_PHASE("sub.contact_pass2");
     SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
     V3 fown[MAXOWN];  // per owned slot
 #pragma unroll
@@ -1158,6 +1176,7 @@ struct EnvLane {
           if (own[i] == slot) fown[i] += Fw;
       }
     }
+    RL_PHASE("sub.sensor+integrate");
     // trunk-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes); slot 0,
     // when a lane has it, is the first entry of its list
     for (int bi = 0; bi < T.n_base_bodies; ++bi) {

@@ -559,6 +559,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         return r;
       };
       Raw nxt = fetch(0);
+      RL_PHASE("rewards.terms");
       for (int t = 0; t < n_rewards; ++t) {
         // the term descriptor is wave-uniform: pin it into SGPRs so that the dispatch is scalar branching
         struct {
@@ -588,6 +589,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         if (li == 0) rstage[t] = val;
       }
     }
+    RL_PHASE("rewards.writeback");
     // per-term outputs + episode sums: staged through LDS so that each lane's read-modify-writes of
     // `ep_sums` (terms t = k, k+4, ...) are issued as one batch instead of one HBM round trip per term
     ctx.group_sync();
@@ -796,8 +798,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         for (int i = li; i < LOG_SIZE; i += LPE) nx[i] = 0.f;
       }
     }
+    RL_PHASE("load");
     this->load();
     load_task();  // same batch of HBM loads as the state: one round trip instead of a second one after the substeps
+    RL_PHASE("action");
     // 1 ActionManager.process_action [UPSTREAM B2]; JointPosition/VelocityAction (velocity_env_cfg.py:124-126)
     float q_tgt[JX], qd_tgt[JX];
 #pragma unroll
@@ -811,6 +815,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     // 2 decimation loop: actuators -> physics -> contact sensor
     for (int s = 0; s < T.decimation; ++s) this->substep(q_tgt, qd_tgt);
+    RL_PHASE("terminations");
     // 3 counters
     ep_len += 1;
     derive();
@@ -831,7 +836,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     bool terminated = t_illegal, time_out = t_timeout || t_oob;
     // 5 rewards
+    RL_PHASE("rewards");
     float rew = compute_rewards(terminated);
+    RL_PHASE("resets+commands+push");
     if (li == 0) {
       S.reward[e] = rew;
       S.terminated[e] = terminated ? 1 : 0;
@@ -899,7 +906,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       }
     }
     // 9 observations
+    RL_PHASE("observations");
     observations();
+    RL_PHASE("store");
     this->store();
     store_task();
   }

@@ -265,14 +265,30 @@ struct Backend {
   }
   int launch(const KState& S, const void* T, int CL, int reset, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    // RL_ENV_ONLY=<CL * 10 + SUB> (e.g. 34): build that one instance only - kernel experiments compile in 15 s instead of 80
+#ifndef RL_ENV_ONLY
+#define RL_ENV_ONLY 0
+#endif
     switch (CL * 10 + sub) {
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 31
       case 31: return launch_cl<TopoQuad3, 1>(S, T, reset, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 41
       case 41: return launch_cl<TopoQuad4, 1>(S, T, reset, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 34
       case 34: return launch_cl<TopoQuad3, 4>(S, T, reset, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 44
       case 44: return launch_cl<TopoQuad4, 4>(S, T, reset, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 71
       case 71: return launch_cl<TopoG1, 1>(S, T, reset, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 74
       case 74: return launch_cl<TopoG1, 4>(S, T, reset, lds_bytes, st);
-      default: err = "unsupported chain length"; return -1;
+#endif
+      default: err = "this build does not carry the lane-program instance for chain length " + std::to_string(CL) + " / " + std::to_string(sub) + " lanes per limb"; return -1;
     }
   }
   int launch_export(const KState& S, const Tables* T, const AosPtrs& A, void* stream) {
