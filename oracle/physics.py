@@ -105,6 +105,10 @@ class Physics:
         #   stick  [m/s] ||u_t| - v_stick| of an active contact (mu_s <-> mu_d)
         #   limit  [rad] distance of a joint to a limit it is about to cross (the limit damper switches on)
         self.margins = None
+        # np.float32: the linear solve of every substep is done in single precision (everything else stays fp64).  Used by the
+        # "twins" of tests/helpers.py teacher_forced_check to measure how much an fp32 solve of THIS env's system moves the
+        # result (conditioning of H + A: light distal links next to a heavy trunk, stiff contacts) - never by the checker itself.
+        self.solve_dtype = None
 
     def _margin(self, key, val):
         m = self.margins
@@ -293,7 +297,10 @@ class Physics:
             r += dt * (w * bias)[:, None] * np.einsum("nij,ni->nj", J, n)
             contacts.append((bdy, J, n, bias, Dm, w))
         rhs = np.einsum("nij,nj->ni", H, nu) + dt * (np.concatenate([np.zeros((N, 6)), tau], -1) - b) + r
-        nu_new = np.linalg.solve(H + A, rhs[..., None])[..., 0]
+        if self.solve_dtype is None:
+            nu_new = np.linalg.solve(H + A, rhs[..., None])[..., 0]
+        else:
+            nu_new = np.linalg.solve((H + A).astype(self.solve_dtype), rhs[..., None].astype(self.solve_dtype))[..., 0].astype(np.float64)
         vlim = arr(self.desc.model.joint_vel_limit, D).astype(np.float64)
         nu_new[:, 6:] = np.clip(nu_new[:, 6:], -vlim, vlim)
         # contact sensor: net contact force per body, world frame

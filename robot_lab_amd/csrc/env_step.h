@@ -20,14 +20,23 @@
 
 #include "env_tables.h"
 
-// RL_PHASE("name"): with -DRL_PHASE_MARKS the device build plants a `; PHASE name` comment in the assembly so that
-// tools/isa_profile.py can attribute the static instruction mix to the phases of the lane program (analysis builds only:
-// an asm volatile statement is also a scheduling barrier).
+// RL_PHASE(id, "name") marks a phase boundary of the lane program.  Product builds: nothing.  Analysis builds of the device code:
+//   -DRL_PHASE_MARKS  plants a `; PHASE name` comment in the assembly: tools/isa_profile.py attributes the static instruction mix
+//                     to the phases (an asm volatile statement is also a scheduling barrier, so such a build is for reading only);
+//   -DRL_PHASE_CLOCK  lane 0 of every wavefront accumulates the shader-clock ticks it spends in each phase into float row
+//                     [wavefront][id] behind the reward-term rows (tools/phase_clock.py reads them): s_waitcnt 0, read the clock,
+//                     add the interval to the phase that ends, read the clock again - the bookkeeping itself is not counted.
+// The ids index tools/phase_clock.py PHASES.
 #if defined(RL_PHASE_MARKS) && defined(__HIP_DEVICE_COMPILE__)
-#define RL_PHASE(name) asm volatile("; PHASE " name)
+#define RL_PHASE(id, name) asm volatile("; PHASE " name)
+#elif defined(RL_PHASE_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
+#define RL_PHASE(id, name) this->phase_stamp(id)
+#define RL_PHASE_CLOCK_ON 1
 #else
-#define RL_PHASE(name) ((void)0)
+#define RL_PHASE(id, name) ((void)0)
 #endif
+constexpr int RL_PHASE_ROW0 = 24;   // first reward-term row the clock build borrows (A1 .. G1 tasks have <= 22 reward terms)
+constexpr int RL_PHASE_SLOTS = 32;
 
 namespace rl {
 
@@ -36,6 +45,22 @@ struct SymIdx {  // upper-triangular packed index of an N x N symmetric matrix
   static constexpr int size = N * (N + 1) / 2;
   static constexpr int at(int i, int j) { return i <= j ? i * N - i * (i - 1) / 2 + (j - i) : j * N - j * (j - 1) / 2 + (i - j); }
 };
+
+// compile-time loops whose index is needed as a constant expression (DPP controls, array slots that must stay registers)
+template <int I, int N, class F>
+RL_FN void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <int I, class F>
+RL_FN void static_for_down(F&& f) {  // I, I - 1, ..., 0
+  if constexpr (I >= 0) {
+    f(std::integral_constant<int, I>{});
+    static_for_down<I - 1>(f);
+  }
+}
 
 RL_FN float comp(V3 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : v.z; }
 RL_FN V3 unit(int i) { return {i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f}; }
@@ -103,6 +128,10 @@ RL_FN void terrain_eval(const Uni& u, const TerrainPatch& p, float& h, V3& n) {
   float dzdy = ((1.f - p.fx) * (p.h01 - p.h00) + p.fx * (p.h11 - p.h10)) * u.inv_hscale;
   float inv = frsqrt(dzdx * dzdx + dzdy * dzdy + 1.0f);
   n = {-dzdx * inv, -dzdy * inv, inv};
+}
+RL_FN float terrain_height(const TerrainPatch& p) {  // the height alone (ray casters)
+  const float hx0 = p.h00 + p.fx * (p.h10 - p.h00), hx1 = p.h01 + p.fx * (p.h11 - p.h01);
+  return hx0 + p.fy * (hx1 - hx0);
 }
 RL_FN void terrain_sample(const Uni& u, const float* __restrict__ hf, float x, float y, float& h, V3& n) {
   terrain_eval(u, terrain_fetch(u, hf, x, y), h, n);
@@ -344,6 +373,21 @@ struct EnvLane {
     lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
     et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
   }
+#ifdef RL_PHASE_CLOCK_ON
+  long long ph_t0 = 0;
+  int ph_cur = 0;
+  __device__ void phase_stamp(int id) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long t = (long long)__builtin_readcyclecounter();
+    if (ctx.lane == 0) {
+      float* row = S.rew_terms + (size_t)RL_PHASE_ROW0 * (size_t)S.Npad + (size_t)blockIdx.x * RL_PHASE_SLOTS;
+      row[ph_cur] += (float)(t - ph_t0);
+    }
+    ph_cur = id;
+    __builtin_amdgcn_s_waitcnt(0);
+    ph_t0 = (long long)__builtin_readcyclecounter();
+  }
+#endif
   RL_FN float& LF(int f) const { return lt[(uint32_t)f * ROW]; }
   RL_FN float& EF(int f) const { return et[(uint32_t)f * (uint32_t)EPT]; }
   // link group g (0 = base share, 1.. = chain links) is evaluated by sub-lane g % SUB of the leg
@@ -675,12 +719,360 @@ struct EnvLane {
     }
   }
 
+  // ================================================================== quadruped instances: articulated-body form
+  // (H + A) nu+ = rhs is tree structured: every limb is a serial chain hanging off the base.  Instead of assembling the limb's
+  // (6 + CL)^2 block and taking its Schur complement onto the base (the form the trunk + limbs instance still uses, below), the
+  // limb is eliminated joint by joint from the tip - the articulated-body recursion applied to the velocity-level system:
+  //     I^A_j = I_j + C_j + I^a_{j+1}                 6 x 6 symmetric, in BASE coordinates (no transforms between links)
+  //     U = I^A_j S_j,   D = S_j^T U + d_j,   u = t_j + S_j^T rho^A_j
+  //     I^a_j = I^A_j - U U^T / D,   rho^a_j = rho^A_j - U u / D
+  // with I_j the link's rigid spatial inertia, C_j = dt sum P^T D_c P the implicit damping of the contacts on that link (one
+  // 6 x 6 block per contact: no joint columns), rho_j = h_j - dt f_j + dt sum bias P^T n, and d_j / t_j the joint-local terms
+  // (armature, implicit PD, limit spring-damper).  The base receives sum_limbs (I^a_0, rho^a_0), its 6 x 6 system is solved as
+  // before and the joint velocities follow going outwards: qd_j = (u - U^T v_parent) / D.  Same linear system as the Schur form
+  // (oracle/physics.py solves it densely), same solution up to round-off; a contact costs ~3x fewer operations and no
+  // (6 + CL)^2 system is live in registers.
+  //
+  // Work split over the SUB sub-lanes of a limb: link group g = sub + SUB * it (it < NIT) - group 0 is the lane's share of the
+  // base link's spheres, group j + 1 is limb link j.  The owner of a group evaluates its contacts AND builds its link's rigid
+  // record, adds the two, and the 27 numbers travel to the other sub-lanes with DPP quad broadcasts when the recursion gets there.
+  static constexpr bool ABA = NW == 0;
+  static constexpr int NIT = (CL + SUB) / SUB;  // ceil((CL + 1) / SUB) link groups per sub-lane
+  using B6 = SymIdx<6>;
+  struct LinkRec {
+    float A[B6::size];  // 6 x 6 symmetric, [omega; v] order
+    float r[6];
+  };
+  struct GroupFetch {
+    float rad[SPL];
+    V3 cb[SPL], cw[SPL];
+    TerrainPatch tp[SPL];
+  };
+
+  // stage A of a link group: sphere centres, terrain loads issued (consumed by group_contacts after unrelated work)
+  template <int IT>
+  RL_FN bool group_fetch(const ChainTP& C, const M3& Rwb, uint32_t slot_valid, GroupFetch& gf) {
+    const int g = sub + SUB * IT;
+    const bool mine = g <= CL;
+    const int gi = mine ? g : CL;  // lanes without a group in this iteration index the last one and evaluate nothing
+    if (!ctx.any(mine && ((slot_valid >> (gi * SPL)) & ((1u << SPL) - 1u)) != 0u)) return false;
+    M3 Rg;
+    V3 pg;
+    group_frame(C, gi, Rg, pg);
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+      sphere_center_in(Rg, pg, Rwb, gi, s, gf.rad[s], gf.cb[s], gf.cw[s]);
+      if (!mine) gf.rad[s] = -1.f;
+      gf.tp[s] = terrain_fetch(u, S.terrain, gf.cw[s].x, gf.cw[s].y);
+    }
+    return true;
+  }
+
+  // stage B: penetration, contact activation, and the contact's 6 x 6 block / bias onto the group's link record
+  template <int IT>
+  RL_FN void group_contacts(const ChainTP& C, const M3& Rwb, SV V0, const GroupFetch& gf, LinkRec& acc, uint32_t& active_mask) {
+    const float dt = u.dt;
+    const int g = sub + SUB * IT;
+    const int gi = g <= CL ? g : CL;
+    float phi[SPL];
+    V3 nw[SPL];
+    bool touching = false;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+      patch_phi(gf.tp[s], gf.rad[s], gf.cw[s], phi[s], nw[s]);
+      touching = touching || phi[s] > 0.f;
+    }
+    if (!ctx.any(touching)) return;  // most link groups of most wavefronts touch nothing
+    // every lane walks ITS touching slots (usually one of the SPL): the trip count is the maximum over the wavefront of the
+    // touching-slot count and the contact code exists once, instead of SPL predicated copies that all get executed because
+    // SOME lane of the wavefront touches with each slot (RL_CONTACT_UNROLLED selects the old form for A/B runs)
+    auto one_slot = [&](const int s, const float rad_s, const V3 cb_s, const float phi_s, const V3 nw_s) __attribute__((always_inline)) {
+      Contact c = contact_from_phi(C, Rwb, V0, qd, gi, s, rad_s, cb_s, phi_s, nw_s);
+      if (c.act) {
+        active_mask |= 1u << (gi * SPL + s);
+        if (STASH && gi == stash_group()) {  // keep the contact for the sensor pass
+          float* st = ctx.lane_scratch() + (LS::CT + s * CONTACT_WORDS) * LSS;
+          st[0 * LSS] = c.x.x; st[1 * LSS] = c.x.y; st[2 * LSS] = c.x.z; st[3 * LSS] = c.n.x; st[4 * LSS] = c.n.y; st[5 * LSS] = c.n.z;
+          st[6 * LSS] = c.bias; st[7 * LSS] = c.dn; st[8 * LSS] = c.dt;
+        }
+        // point velocity = P [omega; v] of the link, P = [ [x]x^T | 1 ]:  dt (d_t P^T P + (d_n - d_t) g g^T), g = P^T n = [x x n; n]
+        const V3 x = c.x, n = c.n;
+        const float kt = dt * c.dt, kn = dt * (c.dn - c.dt), fb = dt * c.bias;
+        const V3 ga = cross(x, n);
+        const float g6[6] = {ga.x, ga.y, ga.z, n.x, n.y, n.z};
+        const float xx = dot(x, x);
+        float b6[B6::size];
+#pragma unroll
+        for (int i = 0; i < B6::size; ++i) b6[i] = 0.f;
+        b6[B6::at(0, 0)] = kt * (xx - x.x * x.x); b6[B6::at(1, 1)] = kt * (xx - x.y * x.y); b6[B6::at(2, 2)] = kt * (xx - x.z * x.z);
+        b6[B6::at(0, 1)] = -kt * x.x * x.y; b6[B6::at(0, 2)] = -kt * x.x * x.z; b6[B6::at(1, 2)] = -kt * x.y * x.z;
+        b6[B6::at(0, 4)] = -kt * x.z; b6[B6::at(0, 5)] = kt * x.y;
+        b6[B6::at(1, 3)] = kt * x.z; b6[B6::at(1, 5)] = -kt * x.x;
+        b6[B6::at(2, 3)] = -kt * x.y; b6[B6::at(2, 4)] = kt * x.x;
+        b6[B6::at(3, 3)] = kt; b6[B6::at(4, 4)] = kt; b6[B6::at(5, 5)] = kt;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          acc.r[i] += fb * g6[i];
+          const float kg = kn * g6[i];
+#pragma unroll
+          for (int jj = i; jj < 6; ++jj) acc.A[B6::at(i, jj)] += b6[B6::at(i, jj)] + kg * g6[jj];
+        }
+      }
+    };
+#ifdef RL_CONTACT_UNROLLED
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) one_slot(s, gf.rad[s], gf.cb[s], phi[s], nw[s]);
+#else
+    uint32_t tm = 0;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) tm |= phi[s] > 0.f ? (1u << s) : 0u;
+#pragma unroll 1
+    for (; ctx.any(tm != 0u); tm &= tm - 1u) {
+      const int s = tm != 0u ? __builtin_ctz(tm) : 0;
+      float rad_s = gf.rad[0], phi_s = tm != 0u ? phi[0] : -1.f;
+      V3 cb_s = gf.cb[0], nw_s = nw[0];
+#pragma unroll
+      for (int i = 1; i < SPL; ++i)
+        if (s == i) { rad_s = gf.rad[i]; phi_s = tm != 0u ? phi[i] : -1.f; cb_s = gf.cb[i]; nw_s = nw[i]; }
+      one_slot(s, rad_s, cb_s, phi_s, nw_s);
+    }
+#endif
+  }
+
+  // rec += rigid spatial inertia (base coordinates) and rho = h - dt f of a body with inertia I moving with V under the bias
+  // acceleration a, minus dt x an extra force `fx`
+  RL_FN void add_rigid(LinkRec& rec, const SI& I, const SV& V, const SV& a, const SV& fx) const {
+    const SV h = apply(I, V);
+    const SV f = apply(I, a) + crf(V, h) + fx;
+    const SV rho = h - f * u.dt;
+    rec.A[B6::at(0, 0)] += I.I.xx; rec.A[B6::at(1, 1)] += I.I.yy; rec.A[B6::at(2, 2)] += I.I.zz;
+    rec.A[B6::at(0, 1)] += I.I.xy; rec.A[B6::at(0, 2)] += I.I.xz; rec.A[B6::at(1, 2)] += I.I.yz;
+    rec.A[B6::at(3, 3)] += I.m; rec.A[B6::at(4, 4)] += I.m; rec.A[B6::at(5, 5)] += I.m;
+    rec.A[B6::at(0, 4)] += -I.h.z; rec.A[B6::at(0, 5)] += I.h.y;
+    rec.A[B6::at(1, 3)] += I.h.z;  rec.A[B6::at(1, 5)] += -I.h.x;
+    rec.A[B6::at(2, 3)] += -I.h.y; rec.A[B6::at(2, 4)] += I.h.x;
+    rec.r[0] += rho.a.x; rec.r[1] += rho.a.y; rec.r[2] += rho.a.z;
+    rec.r[3] += rho.l.x; rec.r[4] += rho.l.y; rec.r[5] += rho.l.z;
+  }
+
+  // rigid record of the limb link this lane owns in iteration IT (link sub + SUB * IT - 1, if the limb has it)
+  template <int IT>
+  RL_FN void link_rigid(const ChainTP& C, const SV (&Vl)[CL], const SV (&al)[CL], LinkRec& rec) const {
+    const int l = sub + SUB * IT - 1;
+    const bool has = l >= 0 && l < CL;
+    // the link's frame / velocity / bias acceleration as a 0-1 weighted blend over the links an owner of this iteration can
+    // have (a chain of selects on a per-lane index turns into an indexed load from a scratch copy of the arrays)
+    M3 Rm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    V3 pm{0.f, 0.f, 0.f};
+    SV Vm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, am = Vm;
+#pragma unroll
+    for (int j = 0; j < CL; ++j) {
+      if (j < SUB * IT - 1 || j > SUB * IT + SUB - 2) continue;
+      const float w = l == j ? 1.f : 0.f;
+      const M3 Rj = C.R(j);
+      Rm.r0 += w * Rj.r0; Rm.r1 += w * Rj.r1; Rm.r2 += w * Rj.r2;
+      pm += w * C.p(j);
+      Vm.a += w * Vl[j].a; Vm.l += w * Vl[j].l;
+      am.a += w * al[j].a; am.l += w * al[j].l;
+    }
+    const uint32_t li = (uint32_t)(LY.LF_INERTIA + (has ? l : 0) * INERTIA_NF);
+    const float mass = has ? LF(li) : 0.f;
+    const V3 cb = pm + mul(Rm, V3{LF(li + 1), LF(li + 2), LF(li + 3)});
+    const SI Im = make_si(mass, cb, rotate(Rm, S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
+    add_rigid(rec, Im, Vm, am, SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
+  }
+
+  RL_FN void fetch_all(const ChainTP& C, const M3& Rwb, uint32_t slot_valid, GroupFetch (&gf)[NIT], bool (&fetched)[NIT]) {
+    RL_PHASE(3, "sub.contact_fetch");
+    static_for<0, NIT>([&](auto it) { fetched[it.value] = group_fetch<it.value>(C, Rwb, slot_valid, gf[it.value]); });
+  }
+
+  // The decimation loop of the quadruped instances, software-pipelined over the terrain loads: the kinematics of substep s + 1
+  // are computed right after substep s has moved the joints, its sphere centres follow and the heightfield loads are issued -
+  // they fly (L2 / MALL: 300 - 900 cycles) while the sensor timers, the actuators and the rigid link records are worked on.
+  RL_FN void substeps_aba(const float (&q_tgt)[JX], const float (&qd_tgt)[JX], int n) {
+    const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
+    ChainTP C = new_chain();
+    chain_kinematics<TP>(L, q, C);
+    M3 Rwb = quat_to_mat(quat);
+    GroupFetch gf[NIT];
+    bool fetched[NIT];
+    fetch_all(C, Rwb, slot_valid, gf, fetched);
+    for (int s = 0; s < n; ++s) {
+      // keep the compiler from hoisting the (loop-invariant) LDS table reads of all substeps to the top of the kernel
+      asm volatile("" ::: "memory");
+      RL_PHASE(2, "sub.actuators+kinematics");
+      float tau_e[JX], pd_diag[JX], pd_rhs[JX];
+      actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
+      const SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
+      const SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
+      float nu0[NB], qdn[JX];
+      uint32_t active_mask = 0;
+      aba_solve(C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, gf, fetched, nu0, qdn, active_mask);
+      V3 fown[MAXOWN];
+      sensor_forces(C, Rwb, V0, nu0, qdn, active_mask, fown);
+      integrate(Rwb, V0, nu0, qdn);
+      if (s + 1 < n) {
+        RL_PHASE(2, "sub.actuators+kinematics");
+        chain_kinematics<TP>(L, q, C);
+        Rwb = quat_to_mat(quat);
+        fetch_all(C, Rwb, slot_valid, gf, fetched);
+      }
+      RL_PHASE(14, "sub.sensor+integrate");
+      sensor_timers(fown);
+    }
+  }
+
+  RL_FN void aba_solve(const ChainTP& C, const M3& Rwb, const SV V0, const SV a0, const float (&tau_e)[JX], const float (&pd_diag)[JX],
+                       const float (&pd_rhs)[JX], const GroupFetch (&gf)[NIT], const bool (&fetched)[NIT], float (&nu0)[NB], float (&qdn)[JX],
+                       uint32_t& active_mask) {
+    const float dt = u.dt;
+    // ---- link velocities / bias accelerations (every sub-lane: cheap), rigid record of the owned link(s)
+    RL_PHASE(4, "sub.link_records");
+    SV Sj[CL], Vl[CL], al[CL];
+    {
+      SV Vp = V0, ap = a0;
+#pragma unroll
+      for (int j = 0; j < CL; ++j) {
+        Sj[j] = SV{C.ax(j), cross(C.p(j), C.ax(j))};
+        const SV vj = Sj[j] * qd[j];
+        Vl[j] = Vp + vj;
+        al[j] = ap + crm(Vl[j], vj);
+        Vp = Vl[j];
+        ap = al[j];
+      }
+    }
+    LinkRec rec[NIT];
+    static_for<0, NIT>([&](auto it) {
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) rec[it.value].A[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rec[it.value].r[i] = 0.f;
+      link_rigid<it.value>(C, Vl, al, rec[it.value]);
+    });
+    // ---- contacts, stage B
+    RL_PHASE(5, "sub.contact_pass1");
+    static_for<0, NIT>([&](auto it) {
+      if (fetched[it.value]) group_contacts<it.value>(C, Rwb, V0, gf[it.value], rec[it.value], active_mask);
+    });
+    // ---- articulated-body recursion, tip -> base (every sub-lane; the records come from their owners)
+    RL_PHASE(9, "sub.aba");
+    LinkRec P;  // what hangs below the current joint, as seen from its parent
+#pragma unroll
+    for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
+    float Uh[CL][6], ui[CL];
+    static_for_down<CL - 1>([&](auto jc) {
+      constexpr int j = jc.value, g = j + 1, so = g % SUB, io = g / SUB;
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) P.A[i] += ctx.template leg_bcast<so>(rec[io].A[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<so>(rec[io].r[i]);
+      const float s6[6] = {Sj[j].a.x, Sj[j].a.y, Sj[j].a.z, Sj[j].l.x, Sj[j].l.y, Sj[j].l.z};
+      // joint-local terms: armature, implicit PD, limit spring-damper (hard limits in the reference, a1.urdf:369,411,439)
+      const float arm = L.armature[j];
+      const float below = L.lower[j] - q[j], above = q[j] - L.upper[j];
+      const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
+      const bool lim = (below > 0.f) || (above > 0.f);
+      float D = arm + pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+      float uu = arm * qd[j] + dt * tau_e[j] + pd_rhs[j] + dt * u.limit_k * viol;
+      float U6[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) t += P.A[B6::at(r, c)] * s6[c];
+        U6[r] = t;
+        D += s6[r] * t;
+        uu += s6[r] * P.r[r];
+      }
+      const float inv = frcp(D);
+      ui[j] = uu * inv;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Uh[j][r] = U6[r] * inv;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        P.r[r] -= U6[r] * ui[j];
+#pragma unroll
+        for (int c = r; c < 6; ++c) P.A[B6::at(r, c)] -= U6[r] * Uh[j][c];
+      }
+    });
+    // the lane's share of the base link's contacts (group 0, owned by sub-lane 0 in iteration 0), when anybody has one
+    if (ctx.any(sub == 0 && (active_mask & ((1u << SPL) - 1u)) != 0u)) {
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) P.A[i] += ctx.template leg_bcast<0>(rec[0].A[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<0>(rec[0].r[i]);
+    }
+    if (k == 0) {  // the base link itself and the persistent external wrench [UPSTREAM B8]: rides with limb 0
+      const int bi = LY.EF_BASE_INERTIA;
+      const SI I0 = make_si(EF(bi), V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)}, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)});
+      add_rigid(P, I0, V0, a0, SV{-(extT + cross(base_com, extF)), -extF});
+    }
+    // ---- cross-limb reduction, 6 x 6 base solve
+    RL_PHASE(10, "sub.cross_leg_sum");
+    float Cb[B6::size], db[6];
+#pragma unroll
+    for (int i = 0; i < B6::size; ++i) Cb[i] = ctx.gsum(P.A[i]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) db[i] = ctx.gsum(P.r[i]);
+    RL_PHASE(11, "sub.trunk_solve");
+    {
+      float G[6][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float sacc = Cb[B6::at(j, j)];
+#pragma unroll
+        for (int m = 0; m < j; ++m) sacc -= G[j][m] * G[j][m];
+        const float inv = frsqrt(sacc);
+        G[j][j] = inv;  // 1 / G_jj
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          float t = Cb[B6::at(j, i)];
+#pragma unroll
+          for (int m = 0; m < j; ++m) t -= G[i][m] * G[j][m];
+          G[i][j] = t * inv;
+        }
+      }
+      float y6[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float t = db[j];
+#pragma unroll
+        for (int m = 0; m < j; ++m) t -= G[j][m] * y6[m];
+        y6[j] = t * G[j][j];
+      }
+#pragma unroll
+      for (int j = 5; j >= 0; --j) {
+        float t = y6[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) t -= G[i][j] * nu0[i];
+        nu0[j] = t * G[j][j];
+      }
+    }
+    // ---- joint velocities, base -> tip
+    RL_PHASE(12, "sub.back_subst");
+    {
+      float vp[6] = {nu0[0], nu0[1], nu0[2], nu0[3], nu0[4], nu0[5]};
+#pragma unroll
+      for (int j = 0; j < CL; ++j) {
+        float t = ui[j];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t -= Uh[j][r] * vp[r];
+        qdn[j] = t;
+        vp[0] += Sj[j].a.x * t; vp[1] += Sj[j].a.y * t; vp[2] += Sj[j].a.z * t;
+        vp[3] += Sj[j].l.x * t; vp[4] += Sj[j].l.y * t; vp[5] += Sj[j].l.z * t;
+      }
+    }
+  }
+
   // ------------------------------------------------------------------ one physics substep
   RL_FN void substep(const float (&q_tgt)[JX], const float (&qd_tgt)[JX]) {
     // keep the compiler from hoisting the (loop-invariant) LDS table reads of all four substeps to the
     // top of the kernel, where ~200 of them stayed live and spilled to scratch
     asm volatile("" ::: "memory");
-    RL_PHASE("sub.actuators+kinematics");
+    RL_PHASE(2, "sub.actuators+kinematics");
     float tau_e[JX], pd_diag[JX], pd_rhs[JX];
     actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
 
@@ -713,9 +1105,9 @@ struct EnvLane {
       for (int i = 0; i < UI::size; ++i) Uc[i] = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) rvc[i] = 0.f;
-      RL_PHASE("sub.contact_pass1");
+      RL_PHASE(5, "sub.contact_pass1");
       contact_pass1(C, Rwb, V0, slot_valid, Uc, rvc, active_mask);
-      RL_PHASE("sub.leg_sum");
+      RL_PHASE(6, "sub.leg_sum");
       if (SUB > 1 && ctx.any(active_mask != 0u)) {
 #pragma unroll
         for (int i = 0; i < UI::size; ++i) Uc[i] = ctx.leg_sum(Uc[i]);
@@ -740,7 +1132,7 @@ struct EnvLane {
   RL_FN void solve_and_integrate(UT& U, RT& rv, const ChainTP& C, const M3& Rwb, const SV V0, const SV a0, const float (&tau_e)[JX], const float (&pd_diag)[JX],
                                  const float (&pd_rhs)[JX], const uint32_t active_mask) {
     const float dt = u.dt;
-    RL_PHASE("sub.crba");
+    RL_PHASE(7, "sub.crba");
     // ---- trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
     constexpr int NWA = NW > 0 ? NW : 1;
     SV Sw[NWA], Vw[NWA], aw[NWA];
@@ -1039,7 +1431,7 @@ struct EnvLane {
     }
 
     // ---- Schur complement of the limb block, cross-limb reduction, NB x NB trunk solve, back substitution
-    RL_PHASE("sub.schur");
+    RL_PHASE(8, "sub.schur");
     float Lc[CL][CL];
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
@@ -1073,7 +1465,7 @@ struct EnvLane {
       for (int m = 0; m < j; ++m) t -= Lc[j][m] * z[m];
       z[j] = t * Lc[j][j];
     }
-    RL_PHASE("sub.cross_leg_sum");
+    RL_PHASE(10, "sub.cross_leg_sum");
     using BI = SymIdx<NB>;
     float Cb[BI::size], db[NB];
 #pragma unroll
@@ -1090,7 +1482,7 @@ struct EnvLane {
         Cb[BI::at(r, c)] = ctx.gsum(v);
       }
     }
-    RL_PHASE("sub.trunk_solve");
+    RL_PHASE(11, "sub.trunk_solve");
     float nu0[NB];
     {  // NB x NB Cholesky solve
       float G[NB][NB];
@@ -1125,7 +1517,7 @@ struct EnvLane {
         nu0[j] = t * G[j][j];
       }
     }
-    RL_PHASE("sub.back_subst");
+    RL_PHASE(12, "sub.back_subst");
     float qdn[JX];
 #pragma unroll
     for (int j = CL - 1; j >= 0; --j) {
@@ -1138,72 +1530,137 @@ struct EnvLane {
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) qdn[CL + i] = nu0[6 + i];
+    sensor_and_integrate(C, Rwb, V0, nu0, qdn, active_mask);
+  }
+
+  // The tail of a substep (both formulations): contact-sensor forces with the new velocities, integration, sensor timers.
+  RL_FN void sensor_and_integrate(const ChainTP& C, const M3& Rwb, const SV V0, const float (&nu0)[NB], float (&qdn)[JX], const uint32_t active_mask) {
+    V3 fown[MAXOWN];
+    sensor_forces(C, Rwb, V0, nu0, qdn, active_mask, fown);
+    sensor_timers(fown);
+    integrate(Rwb, V0, nu0, qdn);
+  }
+
+  // net contact force per owned body slot with the NEW velocities (world frame): what was actually applied
+  RL_FN void sensor_forces(const ChainTP& C, const M3& Rwb, const SV V0, const float (&nu0)[NB], float (&qdn)[JX], const uint32_t active_mask, V3 (&fown)[MAXOWN]) {
 #pragma unroll
     for (int j = 0; j < JX; ++j) qdn[j] = clampf(qdn[j], -L.vel_limit[j], L.vel_limit[j]);
-
-    // ---- contact sensor: net contact force per body with the NEW velocities (world frame)
-    RL_PHASE("sub.contact_pass2");
+    RL_PHASE(13, "sub.contact_pass2");
     SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
-    V3 fown[MAXOWN];  // per owned slot
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) fown[i] = {0.f, 0.f, 0.f};
-    // pass 2: only the spheres that were active in pass 1 are re-evaluated (same state -> same contact)
-#pragma unroll 1
-    for (uint32_t m = active_mask; m != 0; m &= m - 1) {
-      const int ci = __builtin_ctz(m);
-      const int g = ci / SPL, s = ci - g * SPL;
-      Contact c;
-      if (STASH && g == stash_group()) {
-        const float* st = ctx.lane_scratch() + (LS::CT + s * CONTACT_WORDS) * LSS;
-        c.act = true;
-        c.x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
-        c.n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
-        c.bias = st[6 * LSS]; c.dn = st[7 * LSS]; c.dt = st[8 * LSS];
-      } else {
-        float rad;
-        V3 cb, cw;
-        sphere_center(C, Rwb, g, s, rad, cb, cw);
-        c = contact_from_patch(C, Rwb, V0, qd, g, s, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
-      }
-      if (c.act) {
-        V3 uu = point_velocity<TP, ChainTP>(C, wdepth(g), g, c.x, V0n, qdn);
-        float un = dot(c.n, uu);
-        V3 Fb = (c.bias - (c.dn - c.dt) * un) * c.n - c.dt * uu;
-        V3 Fw = mul(Rwb, Fb);
-        int slot = L.sph_slot[g][s];
+    auto apply = [&](const Contact& c, int g, int slot) __attribute__((always_inline)) {
+      V3 uu = point_velocity<TP, ChainTP>(C, wdepth(g), g, c.x, V0n, qdn);
+      float un = dot(c.n, uu);
+      V3 Fb = (c.bias - (c.dn - c.dt) * un) * c.n - c.dt * uu;
+      V3 Fw = mul(Rwb, Fb);
 #pragma unroll
-        for (int i = 0; i < MAXOWN; ++i)
-          if (own[i] == slot) fown[i] += Fw;
+      for (int i = 0; i < MAXOWN; ++i)
+        if (own[i] == slot) fown[i] += Fw;
+    };
+    if constexpr (ABA && STASH) {
+      // static structure: the SPL slots of every link group the lane evaluates, masked by the pass-1 activity bits - the
+      // stash words of the distal group are read in one batch (no per-contact loop with its LDS round trips)
+      static_for<0, NIT>([&](auto it) {
+        const int g = sub + SUB * it.value;
+        const int gi = g <= CL ? g : CL;
+        const uint32_t bits = g <= CL ? (active_mask >> (gi * SPL)) & ((1u << SPL) - 1u) : 0u;
+        if (!ctx.any(bits != 0u)) return;
+        if (gi == stash_group()) {
+          Contact c[SPL];
+          int slot[SPL];
+#pragma unroll
+          for (int s2 = 0; s2 < SPL; ++s2) {
+            const float* st = ctx.lane_scratch() + (LS::CT + s2 * CONTACT_WORDS) * LSS;
+            c[s2].act = (bits >> s2) & 1u;
+            c[s2].x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
+            c[s2].n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
+            c[s2].bias = st[6 * LSS]; c[s2].dn = st[7 * LSS]; c[s2].dt = st[8 * LSS];
+            slot[s2] = L.sph_slot[gi][s2];
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < SPL; ++s2)
+            if (c[s2].act) apply(c[s2], gi, slot[s2]);
+        } else {  // not stashed (the base-link share of a lane that also carries a distal group): evaluate again
+#pragma unroll 1
+          for (uint32_t m = bits; m != 0; m &= m - 1) {
+            const int s2 = __builtin_ctz(m);
+            float rad;
+            V3 cb, cw;
+            sphere_center(C, Rwb, gi, s2, rad, cb, cw);
+            Contact c = contact_from_patch(C, Rwb, V0, qd, gi, s2, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
+            if (c.act) apply(c, gi, L.sph_slot[gi][s2]);
+          }
+        }
+      });
+    } else {
+      // pass 2: only the spheres that were active in pass 1 are re-evaluated (same state -> same contact)
+#pragma unroll 1
+      for (uint32_t m = active_mask; m != 0; m &= m - 1) {
+        const int ci = __builtin_ctz(m);
+        const int g = ci / SPL, s2 = ci - g * SPL;
+        Contact c;
+        if (STASH && g == stash_group()) {
+          const float* st = ctx.lane_scratch() + (LS::CT + s2 * CONTACT_WORDS) * LSS;
+          c.act = true;
+          c.x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
+          c.n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
+          c.bias = st[6 * LSS]; c.dn = st[7 * LSS]; c.dt = st[8 * LSS];
+        } else {
+          float rad;
+          V3 cb, cw;
+          sphere_center(C, Rwb, g, s2, rad, cb, cw);
+          c = contact_from_patch(C, Rwb, V0, qd, g, s2, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
+        }
+        if (c.act) apply(c, g, L.sph_slot[g][s2]);
       }
     }
-    RL_PHASE("sub.sensor+integrate");
+    RL_PHASE(14, "sub.sensor+integrate");
     // trunk-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes); slot 0,
-    // when a lane has it, is the first entry of its list
-    for (int bi = 0; bi < T.n_base_bodies; ++bi) {
-      const bool mine = L.base_body_local == bi && own[0] == 0;
-      V3 f{ctx.esum(mine ? fown[0].x : 0.f), ctx.esum(mine ? fown[0].y : 0.f), ctx.esum(mine ? fown[0].z : 0.f)};
-      if (mine) fown[0] = f;
+    // when a lane has it, is the first entry of its list.  Nothing to sum when no lane of the wavefront touches with group 0.
+    if (ctx.any((active_mask & ((1u << SPL) - 1u)) != 0u)) {
+      for (int bi = 0; bi < T.n_base_bodies; ++bi) {
+        const bool mine = L.base_body_local == bi && own[0] == 0;
+        V3 f{ctx.esum(mine ? fown[0].x : 0.f), ctx.esum(mine ? fown[0].y : 0.f), ctx.esum(mine ? fown[0].z : 0.f)};
+        if (mine) fown[0] = f;
+      }
     }
-    // [UPSTREAM B5] ContactSensor: history roll + air/contact timers, every physics step - each lane for the
-    // slots it owns (with 16 lanes per env every sub-lane used to update all NBS slots of its private copy)
+  }
+
+  // [UPSTREAM B5] ContactSensor: history roll + air/contact timers, every physics step - each lane for the slots it owns.
+  // All scratchpad reads first, then the arithmetic, then the writes: the rows are addressed through computed indices, so the
+  // compiler cannot move a read above an earlier write on its own and every read-modify-write became its own LDS round trip.
+  RL_FN void sensor_timers(const V3 (&fown)[MAXOWN]) {
+    const float dt = u.dt;
+    float h0[MAXOWN], h1[MAXOWN], t0[MAXOWN], t1[MAXOWN], t2[MAXOWN], t3[MAXOWN];
+#pragma unroll
+    for (int i = 0; i < MAXOWN; ++i) {
+      const int b = own[i] < 0 ? 0 : own[i];
+      h0[i] = hist_n[b][0]; h1[i] = hist_n[b][1];
+      t0[i] = tim[b][0]; t1[i] = tim[b][1]; t2[i] = tim[b][2]; t3[i] = tim[b][3];
+    }
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) {
       const int b = own[i];
       if (b < 0) continue;
       cf[b][0] = fown[i].x; cf[b][1] = fown[i].y; cf[b][2] = fown[i].z;
-      float fn = norm(fown[i]);
-      hist_n[b][2] = hist_n[b][1];
-      hist_n[b][1] = hist_n[b][0];
+      const float fn = norm(fown[i]);
+      hist_n[b][2] = h1[i];
+      hist_n[b][1] = h0[i];
       hist_n[b][0] = fn;
-      bool contact = fn > u.force_threshold;
-      float ca = tim[b][0], cc = tim[b][1];
-      bool first_contact = (ca > 0.f) && contact, first_detach = (cc > 0.f) && !contact;
-      tim[b][2] = first_contact ? ca + dt : tim[b][2];
+      const bool contact = fn > u.force_threshold;
+      const float ca = t0[i], cc = t1[i];
+      const bool first_contact = (ca > 0.f) && contact, first_detach = (cc > 0.f) && !contact;
+      tim[b][2] = first_contact ? ca + dt : t2[i];
       tim[b][0] = contact ? 0.f : ca + dt;
-      tim[b][3] = first_detach ? cc + dt : tim[b][3];
+      tim[b][3] = first_detach ? cc + dt : t3[i];
       tim[b][1] = contact ? cc + dt : 0.f;
     }
-    // ---- integrate (semi-implicit Euler: new velocities move the positions)
+  }
+
+  // semi-implicit Euler: the new velocities move the positions
+  RL_FN void integrate(const M3& Rwb, const SV V0, const float (&nu0)[NB], const float (&qdn)[JX]) {
+    const float dt = u.dt;
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       qacc[j] = (qdn[j] - qd[j]) * u.inv_dt;
@@ -1214,8 +1671,8 @@ struct EnvLane {
     quat = quat_normalize(quat_mul(quat, dq));
     // nu+ lives in the fixed frame coincident with the body frame at t, referred to the old origin:
     // rotate with the OLD orientation and shift the reference point (+ dt omega x v) - see oracle/physics.py
-    vang = mul(Rwb, V0n.a);
-    vlin = mul(Rwb, V0n.l + dt * cross(V0.a, V0.l));
+    vang = mul(Rwb, V3{nu0[0], nu0[1], nu0[2]});
+    vlin = mul(Rwb, V3{nu0[3], nu0[4], nu0[5]} + dt * cross(V0.a, V0.l));
     pos = pos + dt * vlin;
   }
 };

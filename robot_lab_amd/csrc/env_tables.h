@@ -15,6 +15,7 @@
 namespace rl {
 
 constexpr int NLANE = 4;    // lane groups (= limb chains) per environment
+constexpr int NLANE_ = 4;
 constexpr int MAX_CL = 7;   // joints per limb chain (A1 3, Go2W 4, G1 arm 7)
 constexpr int MAX_NW = 3;   // trunk joints (G1 waist)
 constexpr int MAX_JX = MAX_CL + MAX_NW;  // per-lane joint arrays: [0, CL) limb joints, [CL, CL+NW) trunk joints
@@ -28,6 +29,8 @@ template <int CL_, int NW_, int SPL_, int NBS_>
 struct Topo {
   static constexpr int CL = CL_, NW = NW_, SPL = SPL_, NBS = NBS_, JX = CL_ + NW_, NB = 6 + NW_;
   static constexpr bool ROT = NW_ > 0;  // joint frames may be rotated w.r.t. the parent link (URDF joint rpy)
+  static constexpr int DMAX = NLANE_ * CL_ + NW_;  // joints a model of this shape can have
+  static constexpr int OBS_NC = 12 + 3 * DMAX;     // non-scan columns of an observation group (ObsGroupTabT)
 };
 using TopoQuad3 = Topo<3, 0, 3, 6>;  // A1, Go2
 using TopoQuad4 = Topo<4, 0, 3, 6>;  // Go2W
@@ -95,6 +98,27 @@ struct ObsTab {
   int32_t offset;  // first column of the term in its group
 };
 
+// Observation groups as per-COLUMN descriptors: the host expands the term list (rl_env_host.h build_tables), so the lane program
+// never dispatches on observation terms.  A column reads one entry of the env's feature vector (layout below), optionally adds
+// uniform noise, clips, scales [UPSTREAM B2: noise -> clip -> scale].  The height scan (at most one per group) is ONE descriptor
+// for its scan_n consecutive columns.
+struct ObsColTab {  // 24 bytes
+  float scale, clip_lo, clip_hi, noise_lo, noise_rng;  // noise_rng = noise_hi - noise_lo; both 0 when the column gets no noise
+  int32_t src;                                         // feature index
+};
+template <int NC>
+struct ObsGroupTabT {
+  int32_t n_cols;           // non-scan columns, in row order
+  int32_t scan_off, scan_n; // the scan occupies columns [scan_off, scan_off + scan_n) of the row (scan_n = 0: no scan)
+  int32_t dim, corrupt, pad_[3];
+  ObsColTab scan;
+  ObsColTab col[NC];
+};
+// feature vector of an env (LDS, rebuilt by every step): base linear velocity, base angular velocity, projected gravity, velocity
+// command, then per task joint index q - q0 | qd - qd0 | last action | q - q0 with the wheel joints zeroed (observations.py:17-27)
+enum { FEAT_LIN = 0, FEAT_ANG = 3, FEAT_GRAV = 6, FEAT_CMD = 9, FEAT_JOINT = 12 };
+RL_FN constexpr int feat_count(int D) { return FEAT_JOINT + 4 * D; }
+
 struct TaskTab {  // everything that is not per limb
   int32_t CL, NW, SPL, NBS, D, n_bodies, n_base_bodies;
   int32_t nw_used;      // trunk joints the model really has (<= NW; the rest are inert padding)
@@ -136,6 +160,7 @@ struct TaskTab {  // everything that is not per limb
 template <class TP>
 struct TablesT : TaskTab {
   LaneTabT<TP> lane[NLANE];
+  ObsGroupTabT<TP::OBS_NC> obs[2];  // policy, critic
   RewTab rew[MAX_T];  // last: only the first n_rewards entries are staged into LDS (KState::table_bytes)
 };
 using Tables = TablesT<TopoMax>;  // host side / export-import kernels; env kernels read the packed TablesT<TP>
@@ -145,6 +170,11 @@ template <class TP>
 inline void pack_tables(const Tables& s, TablesT<TP>& d) {
   static_cast<TaskTab&>(d) = static_cast<const TaskTab&>(s);
   for (int t = 0; t < MAX_T; ++t) d.rew[t] = s.rew[t];
+  for (int g = 0; g < 2; ++g) {
+    d.obs[g].n_cols = s.obs[g].n_cols; d.obs[g].scan_off = s.obs[g].scan_off; d.obs[g].scan_n = s.obs[g].scan_n;
+    d.obs[g].dim = s.obs[g].dim; d.obs[g].corrupt = s.obs[g].corrupt; d.obs[g].scan = s.obs[g].scan;
+    for (int c = 0; c < TP::OBS_NC && c < s.obs[g].n_cols; ++c) d.obs[g].col[c] = s.obs[g].col[c];
+  }
   for (int k = 0; k < NLANE; ++k) {
     const LaneTab& a = s.lane[k];
     LaneTabT<TP>& b = d.lane[k];

@@ -34,10 +34,6 @@ struct RewDesc {
   uint64_t body_mask;
   int idx_a[16], idx_b[16];
 };
-struct ObsDesc {
-  int kind, has_noise, offset;
-  float scale, clip_lo, clip_hi, noise_lo, noise_hi;
-};
 struct GenericSpec {
   static constexpr bool generic = true;
 };
@@ -559,7 +555,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         return r;
       };
       Raw nxt = fetch(0);
-      RL_PHASE("rewards.terms");
+      RL_PHASE(17, "rewards.terms");
       for (int t = 0; t < n_rewards; ++t) {
         // the term descriptor is wave-uniform: pin it into SGPRs so that the dispatch is scalar branching
         struct {
@@ -576,9 +572,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         const int off = ctx.uniform_i(nxt.idx_off);
         R.idx_a = T.idx_pool_a + off; R.idx_b = T.idx_pool_b + off;
         nxt = fetch(t + 1);
+        RL_PHASE(25, "rewards.term_body");
         float val = reward_term(R, rc) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
         total += val;
         if (li == 0) rstage[t] = val;
+        RL_PHASE(17, "rewards.terms");
       }
     } else {
       n_rewards = Spec::n_rewards;
@@ -589,7 +587,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         if (li == 0) rstage[t] = val;
       }
     }
-    RL_PHASE("rewards.writeback");
+    RL_PHASE(18, "rewards.writeback");
     // per-term outputs + episode sums: staged through LDS so that each lane's read-modify-writes of
     // `ep_sums` (terms t = k, k+4, ...) are issued as one batch instead of one HBM round trip per term
     ctx.group_sync();
@@ -610,61 +608,6 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   }
 
   // ---------------------------------------------------------------- observations [UPSTREAM B2 / B6]
-  struct ObsCtx {  // per-joint table entries, read from LDS once per step instead of once per term
-    int jid[JX];
-    float q0j[JX], qd0j[JX];
-    uint32_t wheel;
-  };
-  // one observation term: value -> +noise -> clip -> scale -> its columns of the LDS-staged row.  Terms with
-  // noise only stage the raw value here; add_noise() finishes them 4 columns (= one Philox block) per lane.
-  template <class OD>
-  RL_FN void obs_term(const OD& O, const ObsCtx& oc, float* stage, bool corrupt, float cy, float sy, V3 scan_p) {
-    const bool deferred = corrupt && O.has_noise;
-    auto put = [&](int col, float v) { stage[col] = deferred ? v : clampf(v, O.clip_lo, O.clip_hi) * O.scale; };
-      switch (O.kind) {
-        case OBS_BASE_LIN_VEL: if (li < 3) put(O.offset + li, comp(lin_b, li)); break;
-        case OBS_BASE_ANG_VEL: if (li < 3) put(O.offset + li, comp(ang_b, li)); break;
-        case OBS_PROJECTED_GRAVITY: if (li < 3) put(O.offset + li, comp(grav_b, li)); break;
-        case OBS_VELOCITY_COMMANDS: if (li < 3) put(O.offset + li, comp(cmd, li)); break;
-        case OBS_JOINT_POS_REL: case OBS_JOINT_POS_REL_NO_WHEEL: case OBS_JOINT_VEL_REL: case OBS_LAST_ACTION:
-#pragma unroll
-          for (int j = 0; j < JX; ++j) {
-            if (SUB > 1 && (j % SUB) != sub) continue;  // the leg's sub-lanes share its joints
-            if (NW > 0 && oc.jid[j] < 0) continue;      // padding / trunk joints accounted for by lane 0
-            float v = O.kind == OBS_JOINT_VEL_REL ? qd[j] - oc.qd0j[j] : O.kind == OBS_LAST_ACTION ? act[j] : q[j] - oc.q0j[j];
-            if (O.kind == OBS_JOINT_POS_REL_NO_WHEEL && ((oc.wheel >> (oc.jid[j] & 31)) & 1u)) v = 0.f;
-            put(O.offset + oc.jid[j], v);
-          }
-          break;
-        case OBS_HEIGHT_SCAN: {  // yaw-aligned grid, x fastest; z_base - hit_z - offset.  12 rays per trip so 24 8-byte loads overlap
-          const int nr = ctx.uniform_i(T.scan_nx * T.scan_ny), snx = ctx.uniform_i(T.scan_nx);
-          const float inv_snx = ctx.uniform(1.0f / (float)T.scan_nx);
-          const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1), soff = T.scan_offset;
-          constexpr int RB = 12;  // rays per lane per trip (187 rays = one trip of 12 x 16 lanes: all 187 loads in flight together)
-          for (int r0 = li; r0 < nr; r0 += RB * LPE) {
-            TerrainPatch tp[RB];
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-              int r = r0 + i * LPE;
-              r = r < nr ? r : nr - 1;
-              int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
-              float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
-              tp[i] = terrain_fetch(this->u, S.terrain, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
-            }
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-              int r = r0 + i * LPE;
-              float hz;
-              V3 nn;
-              terrain_eval(this->u, tp[i], hz, nn);
-              if (r < nr) put(O.offset + r, scan_p.z - hz - soff);
-            }
-          }
-        } break;
-        default: break;
-      }
-  }
-
   // pose of the height scanner: the root link on the quadrupeds, the torso on G1 (rides on trunk link scan_depth)
   RL_FN void scanner_pose(float& cy, float& sy, V3& scan_p) {
     if (NW == 0) {
@@ -682,97 +625,108 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     scan_p = pos + mul(Rwb, pf + mul(Rf, V3{T.scan_pos[0], T.scan_pos[1], T.scan_pos[2]}));
   }
 
-  // descriptor of term i read from LDS into VGPRs (no wait); pin_obs() turns it into SGPRs when its turn comes, so that
-  // the LDS round trip of term i + 1 hides behind term i
-  RL_FN ObsDesc fetch_obs(const ObsTab* terms, int i, int n) const {
-    const ObsTab& Ol = terms[i < n ? i : n - 1];
-    ObsDesc O;
-    O.kind = Ol.kind; O.has_noise = Ol.has_noise; O.offset = Ol.offset;
-    O.scale = Ol.scale; O.clip_lo = Ol.clip_lo; O.clip_hi = Ol.clip_hi; O.noise_lo = Ol.noise_lo; O.noise_hi = Ol.noise_hi;
-    return O;
-  }
-  RL_FN ObsDesc pin_obs(const ObsDesc& R) const {
-    ObsDesc O;
-    O.kind = ctx.uniform_i(R.kind); O.has_noise = ctx.uniform_i(R.has_noise); O.offset = ctx.uniform_i(R.offset);
-    O.scale = ctx.uniform(R.scale); O.clip_lo = ctx.uniform(R.clip_lo); O.clip_hi = ctx.uniform(R.clip_hi);
-    O.noise_lo = ctx.uniform(R.noise_lo); O.noise_hi = ctx.uniform(R.noise_hi);
-    return O;
-  }
-
-  // second pass of a corrupted group: lane l finishes columns 4b .. 4b+3 for b = l, l + LPE, ... with the four
-  // uniforms of ONE Philox block (noise index = noise_base + column, so block = index >> 2 as in uniform01);
-  // v_mul_hi/lo_u32 are quarter rate, a Philox call costs ~900 cycles - per value that was the observations' bill
-  RL_FN void add_noise(float* stage, const ObsTab* terms, int n, int dim, uint32_t noise_base) {
-    ctx.group_sync();
-    const int nblk = (dim + 3) >> 2;
-    for (int b = li; b < nblk; b += LPE) {
-      float un[4], v[4];
-      uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_NOISE, (noise_base >> 2) + (uint32_t)b, un);
+  // One observation group -> its LDS-staged row.  No dispatch on terms: the host expanded the term list into per-column
+  // descriptors (ObsGroupTabT); a column is a gather from the env's feature vector F, [+ noise], clip, scale.  Groups that
+  // corrupt stage the raw value first and finish in a second pass, 4 consecutive columns (= one Philox block: noise index =
+  // noise_base + column, block = index >> 2 as in uniform01) per lane - a Philox4x32-10 call is ~900 cycles (v_mul_hi/lo_u32 are
+  // quarter rate), so it must not be paid per column.
+  template <class GT>
+  RL_FN void write_group(const GT& G, const float* F, float* stage, uint32_t noise_base, float cy, float sy, V3 scan_p) {
+    constexpr int NITC = (TP::OBS_NC + LPE - 1) / LPE;
+    const int n_cols = ctx.uniform_i(G.n_cols), scan_off = ctx.uniform_i(G.scan_off), scan_n = ctx.uniform_i(G.scan_n);
+    const int dim = ctx.uniform_i(G.dim);
+    const bool corrupt = ctx.uniform_i(G.corrupt) != 0;
+    {  // non-scan columns: ordinal n = li, li + LPE, ...; all descriptor reads, then all feature reads, then the arithmetic
+      ObsColTab d[NITC];
+      float f[NITC];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = 4 * b + c < dim ? stage[4 * b + c] : 0.f;
-      ObsDesc nxt = fetch_obs(terms, 0, n);
-      for (int i = 0; i < n; ++i) {  // term descriptors are wave-uniform: SGPRs, scalar branches
-        const ObsDesc O = pin_obs(nxt);
-        nxt = fetch_obs(terms, i + 1, n);
-        if (!O.has_noise) continue;
-        const int lo = O.offset, hi = i + 1 < n ? ctx.uniform_i(nxt.offset) : dim;
-        const float nr = O.noise_hi - O.noise_lo;
+      for (int i = 0; i < NITC; ++i) {
+        const int n = li + LPE * i;
+        d[i] = G.col[n < n_cols ? n : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < NITC; ++i) f[i] = F[d[i].src];
+#pragma unroll
+      for (int i = 0; i < NITC; ++i) {
+        const int n = li + LPE * i;
+        if (n < n_cols) stage[n < scan_off ? n : n + scan_n] = corrupt ? f[i] : clampf(f[i], d[i].clip_lo, d[i].clip_hi) * d[i].scale;
+      }
+    }
+    if (scan_n > 0) {  // yaw-aligned grid, x fastest; z_sensor - hit_z - offset.  12 rays per trip so 24 8-byte loads overlap
+      const float s_scale = ctx.uniform(G.scan.scale), s_lo = ctx.uniform(G.scan.clip_lo), s_hi = ctx.uniform(G.scan.clip_hi);
+      const int snx = ctx.uniform_i(T.scan_nx);
+      const float inv_snx = ctx.uniform(1.0f / (float)T.scan_nx);
+      const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1), soff = T.scan_offset;
+      constexpr int RB = 12;  // rays per lane per trip (187 rays = one trip of 12 x 16 lanes: all 187 loads in flight together)
+      for (int r0 = li; r0 < scan_n; r0 += RB * LPE) {
+        TerrainPatch tp[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          int r = r0 + i * LPE;
+          r = r < scan_n ? r : scan_n - 1;
+          int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
+          float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
+          tp[i] = terrain_fetch(this->u, S.terrain, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int r = r0 + i * LPE;
+          const float v = scan_p.z - terrain_height(tp[i]) - soff;
+          if (r < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
+        }
+      }
+    }
+    if (corrupt) {
+      ctx.group_sync();
+      const int nblk = (dim + 3) >> 2;
+      for (int b = li; b < nblk; b += LPE) {
+        float un[4];
+        uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_NOISE, (noise_base >> 2) + (uint32_t)b, un);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int col = 4 * b + c;
-          if (col >= lo && col < hi) v[c] = clampf(v[c] + O.noise_lo + nr * un[c], O.clip_lo, O.clip_hi) * O.scale;
+          if (col >= dim) continue;
+          const bool in_scan = col >= scan_off && col < scan_off + scan_n;
+          const int n = col < scan_off ? col : col - scan_n;
+          const ObsColTab& dc = in_scan ? G.scan : G.col[in_scan ? 0 : n];
+          stage[col] = clampf(stage[col] + dc.noise_lo + dc.noise_rng * un[c], dc.clip_lo, dc.clip_hi) * dc.scale;
         }
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (4 * b + c < dim) stage[4 * b + c] = v[c];
     }
-  }
-
-  RL_FN void write_obs(float* stage, const ObsCtx& oc, const ObsTab* terms, int n, int dim, bool corrupt, uint32_t noise_base, float cy, float sy, V3 scan_p) {
-    n = ctx.uniform_i(n);
-    bool any_noise = false;
-    ObsDesc nxt = fetch_obs(terms, 0, n);
-    for (int i = 0; i < n; ++i) {
-      const ObsDesc O = pin_obs(nxt);
-      nxt = fetch_obs(terms, i + 1, n);
-      any_noise = any_noise || (corrupt && O.has_noise);
-      obs_term(O, oc, stage, corrupt, cy, sy, scan_p);
-    }
-    if (any_noise) add_noise(stage, terms, n, dim, noise_base);
   }
 
   RL_FN void observations() {
     derive();
-    float* sp = ctx.obs_stage(0);
-    float* sc = ctx.obs_stage(1);
-    ObsCtx oc;
-#pragma unroll
-    for (int j = 0; j < JX; ++j) {
-      oc.jid[j] = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1; oc.q0j[j] = L.q0[j]; oc.qd0j[j] = L.qd0[j];
+    // the env's feature vector -> LDS (env_tables.h FEAT_*): lane 0 the base block, the first sub-lane of a limb its joints
+    float* F = ctx.feat_stage();
+    const int D = ctx.uniform_i(T.D);
+    if (li == 0) {
+      F[FEAT_LIN + 0] = lin_b.x; F[FEAT_LIN + 1] = lin_b.y; F[FEAT_LIN + 2] = lin_b.z;
+      F[FEAT_ANG + 0] = ang_b.x; F[FEAT_ANG + 1] = ang_b.y; F[FEAT_ANG + 2] = ang_b.z;
+      F[FEAT_GRAV + 0] = grav_b.x; F[FEAT_GRAV + 1] = grav_b.y; F[FEAT_GRAV + 2] = grav_b.z;
+      F[FEAT_CMD + 0] = cmd.x; F[FEAT_CMD + 1] = cmd.y; F[FEAT_CMD + 2] = cmd.z;
     }
-    oc.wheel = T.wheel_joint_mask;
+    if (sub == 0) {
+      const uint32_t wheel = T.wheel_joint_mask;
+#pragma unroll
+      for (int j = 0; j < JX; ++j) {
+        const int jid = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1;
+        if (jid < 0) continue;  // padding / trunk joints accounted for by limb 0
+        const float qr = q[j] - L.q0[j];
+        F[FEAT_JOINT + jid] = qr;
+        F[FEAT_JOINT + D + jid] = qd[j] - L.qd0[j];
+        F[FEAT_JOINT + 2 * D + jid] = act[j];
+        F[FEAT_JOINT + 3 * D + jid] = ((wheel >> (jid & 31)) & 1u) ? 0.f : qr;
+      }
+    }
     float cy, sy;
     V3 scan_p;
     scanner_pose(cy, sy, scan_p);
-    if constexpr (Spec::generic) {
-      write_obs(sp, oc, T.policy, T.n_policy, T.policy_dim, T.policy_corrupt != 0, 0u, cy, sy, scan_p);
-      write_obs(sc, oc, T.critic, T.n_critic, T.critic_dim, T.critic_corrupt != 0, 1024u, cy, sy, scan_p);
-    } else {
-      bool pn = false, cn = false;
-#pragma unroll
-      for (int i = 0; i < Spec::n_policy; ++i) {
-        obs_term(Spec::policy[i], oc, sp, Spec::policy_corrupt, cy, sy, scan_p);
-        pn = pn || (Spec::policy_corrupt && Spec::policy[i].has_noise);
-      }
-      if (pn) add_noise(sp, T.policy, T.n_policy, T.policy_dim, 0u);
-#pragma unroll
-      for (int i = 0; i < Spec::n_critic; ++i) {
-        obs_term(Spec::critic[i], oc, sc, Spec::critic_corrupt, cy, sy, scan_p);
-        cn = cn || (Spec::critic_corrupt && Spec::critic[i].has_noise);
-      }
-      if (cn) add_noise(sc, T.critic, T.n_critic, T.critic_dim, 1024u);
-    }
+    ctx.group_sync();
+    write_group(T.obs[0], F, ctx.obs_stage(0), 0u, cy, sy, scan_p);
+    RL_PHASE(21, "obs.policy_done");
+    write_group(T.obs[1], F, ctx.obs_stage(1), 1024u, cy, sy, scan_p);
+    RL_PHASE(22, "obs.flush");
     ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
     ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
   }
@@ -798,10 +752,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         for (int i = li; i < LOG_SIZE; i += LPE) nx[i] = 0.f;
       }
     }
-    RL_PHASE("load");
+    RL_PHASE(0, "load");
     this->load();
     load_task();  // same batch of HBM loads as the state: one round trip instead of a second one after the substeps
-    RL_PHASE("action");
+    RL_PHASE(1, "action");
     // 1 ActionManager.process_action [UPSTREAM B2]; JointPosition/VelocityAction (velocity_env_cfg.py:124-126)
     float q_tgt[JX], qd_tgt[JX];
 #pragma unroll
@@ -814,8 +768,12 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       qd_tgt[j] = L.action_is_vel[j] ? pr : 0.f;
     }
     // 2 decimation loop: actuators -> physics -> contact sensor
-    for (int s = 0; s < T.decimation; ++s) this->substep(q_tgt, qd_tgt);
-    RL_PHASE("terminations");
+    if constexpr (Base::ABA) {
+      this->substeps_aba(q_tgt, qd_tgt, T.decimation);
+    } else {
+      for (int s = 0; s < T.decimation; ++s) this->substep(q_tgt, qd_tgt);
+    }
+    RL_PHASE(15, "terminations");
     // 3 counters
     ep_len += 1;
     derive();
@@ -836,9 +794,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     bool terminated = t_illegal, time_out = t_timeout || t_oob;
     // 5 rewards
-    RL_PHASE("rewards");
+    RL_PHASE(16, "rewards");
     float rew = compute_rewards(terminated);
-    RL_PHASE("resets+commands+push");
+    RL_PHASE(19, "resets+commands+push");
     if (li == 0) {
       S.reward[e] = rew;
       S.terminated[e] = terminated ? 1 : 0;
@@ -906,11 +864,12 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       }
     }
     // 9 observations
-    RL_PHASE("observations");
+    RL_PHASE(20, "observations");
     observations();
-    RL_PHASE("store");
+    RL_PHASE(23, "store");
     this->store();
     store_task();
+    RL_PHASE(24, "end");
   }
 
   // ---------------------------------------------------------------- reset() entry: reset masked envs, recompute obs

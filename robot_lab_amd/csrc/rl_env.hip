@@ -48,7 +48,8 @@ struct WaveCtx {
   const void* T;  // TablesT<TP> staged in LDS
   float* stage[2];
   float* rstage;
-  int dim[2];
+  float* fstage;  // feature vectors of the tile's envs (observations)
+  int dim[2], fdim;
   int lane;
   __device__ float* lane_scratch() const { return lscratch + lane; }
   __device__ float* limb_scratch() const { return lbscratch + lane / SUB; }
@@ -95,11 +96,15 @@ struct WaveCtx {
   }
   // value held by sub-lane J of this lane's leg (DPP quad_perm broadcast; SUB == 4)
   template <int J>
-  __device__ float leg_bcast(float v) const { return dpp<J | (J << 2) | (J << 4) | (J << 6)>(v); }
+  __device__ float leg_bcast(float v) const {
+    if constexpr (SUB == 1) return v;  // a lane is the whole leg
+    else return dpp<J | (J << 2) | (J << 4) | (J << 6)>(v);
+  }
   __device__ float gshfl(float v, int leg) const { return __shfl(v, SUB == 1 ? ((lane & ~3) | leg) : ((lane & ~15) | (leg << 2) | (lane & 3))); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
   __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }
   __device__ float* rew_stage() const { return rstage + env_in_tile() * MAX_T; }
+  __device__ float* feat_stage() const { return fstage + env_in_tile() * fdim; }
   __device__ void group_sync() const { __syncthreads(); }
   __device__ void flush_obs(float* out, int d, int g) const {
     __syncthreads();  // single-wave workgroup: orders the LDS writes above before the reads below
@@ -166,10 +171,12 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   ctx.lbscratch = ctx.lscratch + LS::WORDS * 64;
   float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
   // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
-  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && s0w + s1w + Ctx::EPT * MAX_T <= STASH_WORDS;  // same rule as Backend::configure
+  ctx.fdim = feat_count(Tl->D);
+  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && s0w + s1w + Ctx::EPT * (MAX_T + ctx.fdim) <= STASH_WORDS;  // same rule as Backend::configure
   ctx.stage[0] = alias ? ctx.lscratch + LS::CT * 64 : tail;
   ctx.stage[1] = ctx.stage[0] + s0w;
   ctx.rstage = ctx.stage[1] + s1w;
+  ctx.fstage = ctx.rstage + Ctx::EPT * MAX_T;
   ctx.lane = lane;
   EnvProgram<Ctx, TP> prog(ctx, S);
   if (RESET)
@@ -254,7 +261,7 @@ struct Backend {
     const size_t ls_words = T.NW > 0 ? LsFor<TopoG1, 4>::type::WORDS : (sub > 1 ? LsFor<TopoQuad3, 4>::type::WORDS : LsFor<TopoQuad3, 1>::type::WORDS);
     const size_t lb_words = T.NW > 0 ? LbLayout<TopoG1>::WORDS : 0;
     const size_t stash = (T.NW == 0 && sub > 1) ? (size_t)LsFor<TopoQuad3, 4>::STASH * CONTACT_WORDS * 64 * 4 : 0;
-    size_t rows = s0 + s1 + ept * MAX_T * 4;  // staging rows + reward stage: on the contact stash when they fit (env_kernel)
+    size_t rows = s0 + s1 + ept * (MAX_T + feat_count(T.D)) * 4;  // staging rows + reward stage + feature vectors: on the contact stash when they fit (env_kernel)
     if (stash > 0 && rows <= stash) rows = 0;
     lds_bytes = tab + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + rows;
     if (lds_bytes > 160 * 1024) {

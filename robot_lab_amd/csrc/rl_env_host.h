@@ -274,6 +274,37 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       off += obs_term_dim(d, src[i].kind);
     }
     (grp == 0 ? T.policy_dim : T.critic_dim) = off;
+    // per-column descriptors (env_tables.h ObsGroupTabT): what the lane program reads
+    auto& G = T.obs[grp];
+    const int corrupt = grp == 0 ? t.policy_corrupt : t.critic_corrupt;
+    const int NCmax = 12 + 3 * (NLANE * CL + NW);
+    G.n_cols = 0; G.scan_off = 0; G.scan_n = 0; G.dim = off; G.corrupt = corrupt ? 1 : 0;
+    for (int i = 0; i < n; ++i) {
+      const bool noisy = corrupt && src[i].has_noise;
+      ObsColTab c{src[i].scale, src[i].clip_lo, src[i].clip_hi, noisy ? src[i].noise_lo : 0.f, noisy ? src[i].noise_hi - src[i].noise_lo : 0.f, 0};
+      const int w = obs_term_dim(d, src[i].kind);
+      if (src[i].kind == RL_OBS_HEIGHT_SCAN) {
+        if (G.scan_n > 0) return fail("an observation group can hold one height scan");
+        G.scan = c; G.scan_off = dst[i].offset; G.scan_n = w;
+        continue;
+      }
+      if (G.n_cols + w > NCmax) return fail("observation group has more columns than the lane program's column table (" + std::to_string(NCmax) + ")");
+      for (int q = 0; q < w; ++q) {
+        switch (src[i].kind) {
+          case RL_OBS_BASE_LIN_VEL: c.src = FEAT_LIN + q; break;
+          case RL_OBS_BASE_ANG_VEL: c.src = FEAT_ANG + q; break;
+          case RL_OBS_PROJECTED_GRAVITY: c.src = FEAT_GRAV + q; break;
+          case RL_OBS_VELOCITY_COMMANDS: c.src = FEAT_CMD + q; break;
+          case RL_OBS_JOINT_POS_REL: c.src = FEAT_JOINT + q; break;
+          case RL_OBS_JOINT_VEL_REL: c.src = FEAT_JOINT + m.num_dof + q; break;
+          case RL_OBS_LAST_ACTION: c.src = FEAT_JOINT + 2 * m.num_dof + q; break;
+          case RL_OBS_JOINT_POS_REL_NO_WHEEL: c.src = FEAT_JOINT + 3 * m.num_dof + q; break;
+          default: return fail("unknown observation kind");
+        }
+        G.col[G.n_cols++] = c;
+      }
+    }
+    // the non-scan columns are stored densely: column of ordinal n is n (before the scan) or n + scan_n (after it)
   }
   T.scan_nx = t.scan_nx; T.scan_ny = t.scan_ny; T.scan_res = t.scan_res; T.scan_offset = t.scan_offset; T.wheel_joint_mask = t.wheel_joint_mask;
   T.n_rewards = t.n_rewards;

@@ -48,6 +48,7 @@ struct alignas(64) Team {
   LaneBarrier bar;
   alignas(64) float slot[LPE];
   float rstage[rl::MAX_T];
+  float feat[rl::feat_count(rl::TopoMax::DMAX)];
   std::vector<float> stage[2];
   Team() { bar.n = LPE; }
   void barrier(int&) { bar.wait(); }
@@ -183,6 +184,7 @@ struct HostCtx {
   }
   template <int J>
   float leg_bcast(float v) {
+    if (SUB == 1) return v;  // a lane is the whole leg
     team->slot[li()] = v;
     team->barrier(sense_);
     float r = team->slot[k_ * SUB + (J < SUB ? J : 0)];
@@ -205,6 +207,7 @@ struct HostCtx {
   }
   float* obs_stage(int g) { return team->stage[g].data(); }
   float* rew_stage() { return team->rstage; }
+  float* feat_stage() { return team->feat; }
   void group_sync() { team->barrier(sense_); }
   void flush_obs(float* out, int dim, int g) {
     team->barrier(sense_);

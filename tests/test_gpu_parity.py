@@ -1,15 +1,19 @@
 """`-m gpu`: the HIP path, called through the C-ABI (robot_lab_amd.env -> librl_env_hip.so), against the
-fp64 oracle on identical seeds and actions, over FREE-RUNNING 5-step trajectories (20 physics substeps with contacts) of
-21 task ids.  A free run diverges wherever one side crosses a contact switch the other does not, so the comparison is
-explicit about that: the oracle records how close every env came to a discontinuity of the model on every step
-(Physics.margins; helpers.switch_mask with 10x the one-step margins, because the two trajectories drift apart by
-round-off amplification before they reach the switch), those envs are excluded and counted, and 100 % of the entries of
-the remaining envs must agree: state rtol 2e-3 (atol 2e-4), rewards atol 2e-5, dones exact.  The tight, single-step form
-of this comparison at the BASELINE sizes is tests/test_gpu_teacher_forced.py."""
+fp64 oracle on identical seeds and actions, for 21 task ids, in two forms:
+
+* FREE RUN of 5 steps (20 physics substeps with contacts).  A free run diverges wherever the step map is ill conditioned or one
+  side crosses a contact switch the other does not, so the tolerance is per entry: helpers.OracleWithTwin runs a twin of
+  the oracle that is disturbed like an fp32 implementation (1e-6 relative input perturbation, single-precision solves) and
+  100 % of the entries must satisfy |got - want| <= atol + rtol |want| + 32 |twin - want| (state rtol 2e-3 / atol 2e-4,
+  rewards atol 2e-5); dones exact wherever the twin takes the oracle's decision.
+* TEACHER FORCED: the oracle then adopts the state the HIP env reached (robots in contact, commands and timers mid-episode)
+  and both take ONE more step from it - helpers.teacher_forced_check, the per-env conditioning-aware bound.
+
+The teacher-forced form at the BASELINE sizes is tests/test_gpu_teacher_forced.py."""
 import numpy as np
 import pytest
 
-from helpers import SWITCH_EPS, assert_close, oracle_root_state, switch_mask
+from helpers import OracleWithTwin, assert_close, oracle_root_state, teacher_forced_check
 from oracle.env import OracleEnv
 from robot_lab_amd.scene import build_world, load_bundle
 
@@ -48,75 +52,76 @@ def _pair(task, N, seed):
     env = ManagerBasedRLEnv(task, num_envs=N, seed=seed, device="cuda:0")
     desc, extra = load_bundle(task)
     h, to, eo = build_world(desc, extra, N, 0)
-    return env, OracleEnv(desc, h, to, N, seed, eo), torch
-
-
-FREE_RUN_EPS = {k: 10.0 * v for k, v in SWITCH_EPS.items()}
+    return env, OracleWithTwin(lambda: OracleEnv(desc, h, to, N, seed, eo)), torch
 
 
 @pytest.mark.parametrize("task", TASKS)
 def test_short_horizon_parity(task):
     N = 32 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1")) else 64
-    env, ora, torch = _pair(task, N, 11)
+    env, two, torch = _pair(task, N, 11)
+    ora = two.ora
     obs, _ = env.reset()
-    o = ora.reset()
+    o = two.reset()
     assert_close("obs0", obs["policy"].cpu().numpy(), o[0], 1e-4, 1e-5)
     assert_close("critic0", obs["critic"].cpu().numpy(), o[1], 1e-3, 1e-4)
     rng = np.random.default_rng(3)
-    ora.phys.margins = {}  # minima over the whole trajectory: an env that touched a switch at step s stays excluded afterwards
-    on_switch = np.zeros(N, dtype=bool)
     for s in range(5):
         a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
         obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
-        o = ora.step(a)
-        on_switch |= switch_mask(ora.phys.margins, FREE_RUN_EPS)
-        ok = ~on_switch
-        assert_close(f"reward[{s}]", rew.cpu().numpy()[ok], ora.reward[ok], 1e-3, 2e-5)
+        o = two.step(a)
+        two.close(f"reward[{s}]", rew.cpu().numpy(), lambda e: e.reward, 1e-3, 2e-5)
+        ok = ~two.done_differs
         assert np.array_equal((term | tout).cpu().numpy()[ok], (ora.terminated | ora.time_outs)[ok])
-    ok = ~on_switch
-    assert on_switch.mean() <= 0.25, f"{on_switch.sum()} of {N} envs came within the switch margins over 5 steps"
+    assert two.done_differs.mean() <= 0.15
     d = env.scene["robot"].data
-    assert_close("root", d.root_state_w.cpu().numpy()[ok], oracle_root_state(ora)[ok], 2e-3, 2e-4)
-    assert_close("q", d.joint_pos.cpu().numpy()[ok], ora.st["q"][ok], 2e-3, 2e-4)
-    assert_close("qd", d.joint_vel.cpu().numpy()[ok], ora.st["qd"][ok], 5e-3, 5e-3)
-    assert_close("rew_terms", env.reward_terms().cpu().numpy()[:, ok], ora.reward_terms[:, ok], 2e-3, 2e-5)
-    assert_close("policy", obs["policy"].cpu().numpy()[ok], o[0][ok], 5e-3, 5e-3)
-    assert_close("critic", obs["critic"].cpu().numpy()[ok], o[1][ok], 5e-3, 5e-3)
+    two.close("root", d.root_state_w.cpu().numpy(), oracle_root_state, 2e-3, 2e-4)
+    two.close("q", d.joint_pos.cpu().numpy(), lambda e: e.st["q"], 2e-3, 2e-4)
+    two.close("qd", d.joint_vel.cpu().numpy(), lambda e: e.st["qd"], 5e-3, 5e-3)
+    two.close("rew_terms", env.reward_terms().cpu().numpy(), lambda e: e.reward_terms, 2e-3, 2e-5)
+    two.close("policy", obs["policy"].cpu().numpy(), lambda e: e.obs_policy, 5e-3, 5e-3)
+    two.close("critic", obs["critic"].cpu().numpy(), lambda e: e.obs_critic, 5e-3, 5e-3)
+    # teacher forced: one more step, both from the state the HIP env is in now
+    state = env.read_state()
+    a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
+    obs, rew, term, tout, _ = env.step(torch.from_numpy(a).cuda())
+    got = env.read_state()
+    got.update(reward=rew.cpu().numpy(), reward_terms=env.reward_terms().cpu().numpy(), done=(term | tout).cpu().numpy(),
+               obs_policy=obs["policy"].cpu().numpy(), obs_critic=obs["critic"].cpu().numpy())
+    teacher_forced_check(ora, state, a, got, max_mask=0.35)  # small batch: a few envs on a switch are already > 1.5 %
     env.close()
 
 
 @pytest.mark.parametrize("task,N", [(TASKS[1], 64), (TASKS[5], 32)])
 def test_time_out_reset_parity(task, N):
     """Force time-outs through the settable episode_length_buf (rsl_rl init_at_random_ep_len path)."""
-    env, ora, torch = _pair(task, N, 5)
+    env, two, torch = _pair(task, N, 5)
+    ora = two.ora
     env.reset()
-    ora.reset()
+    two.reset()
     ep = np.zeros(N, dtype=np.int64)
     ep[::4] = env.max_episode_length - 2
     env.episode_length_buf = torch.from_numpy(ep)
     ora.episode_length_buf[:] = ep
+    two.twin.episode_length_buf[:] = ep
     rng = np.random.default_rng(0)
     n_reset = 0
-    ora.phys.margins = {}
-    on_switch = np.zeros(N, dtype=bool)
     for s in range(3):
         a = rng.uniform(-1, 1, (N, env.num_actions)).astype(np.float32)
         obs, rew, term, tout, extras = env.step(torch.from_numpy(a).cuda())
-        o = ora.step(a)
-        on_switch |= switch_mask(ora.phys.margins, FREE_RUN_EPS)
+        o = two.step(a)
         done = (term | tout).cpu().numpy()
-        assert np.array_equal(done, ora.terminated | ora.time_outs)
+        ok = ~two.done_differs
+        assert np.array_equal(done[ok], (ora.terminated | ora.time_outs)[ok])
         n_reset += int(done.sum())
-        if done.any():
+        if done.any() and ok.all():
             assert float(extras["log"]["Episode_Termination/time_out"]) == float(ora.time_outs_terms[0].sum())
             for name in ("Episode_Reward/track_lin_vel_xy_exp", "Metrics/base_velocity/error_vel_xy"):
                 np.testing.assert_allclose(float(extras["log"][name]), ora.log[name], rtol=2e-3, atol=1e-6)
-        assert np.array_equal(env.episode_length_buf.cpu().numpy(), ora.episode_length_buf)
+        assert np.array_equal(env.episode_length_buf.cpu().numpy()[ok], ora.episode_length_buf[ok])
     assert n_reset >= N // 4  # the forced time-outs (+ any illegal-contact terminations on G1)
     d = env.scene["robot"].data
-    ok = ~on_switch
-    assert_close("root", d.root_state_w.cpu().numpy()[ok], oracle_root_state(ora)[ok], 2e-3, 2e-4)
-    assert_close("critic", obs["critic"].cpu().numpy()[ok], o[1][ok], 5e-3, 5e-3)
+    two.close("root", d.root_state_w.cpu().numpy(), oracle_root_state, 2e-3, 2e-4)
+    two.close("critic", obs["critic"].cpu().numpy(), lambda e: e.obs_critic, 5e-3, 5e-3)
     env.close()
 
 

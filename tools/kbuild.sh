@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build ONE lane-program instance of the env kernel into a scratch directory and print its resource usage + static
+# instruction profile:   tools/kbuild.sh <outdir> <CL*10+SUB, e.g. 34 | 44 | 74> [extra hipcc flags]
+OUT=$1; INST=${2:-34}; shift; shift
+mkdir -p $OUT && cd $OUT
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DRL_ENV_ONLY=$INST -DRL_PHASE_MARKS -save-temps -o lib_marks.so /root/repo/robot_lab_amd/csrc/rl_env.hip "$@" 2>&1 | grep -E "error" -A6 | head -40
+python - <<PY
+import re
+s=open('$OUT/rl_env-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+for m in re.finditer(r'^(_ZN12_GLOBAL__N_110env_kernel[^:\n]*Li0ELi\dEEEvNS1_6KStateEPKv):', s, flags=re.M):
+    i=m.start(); j=s.index('s_endpgm', i)
+    open('$OUT/step.s','w').write(s[i:j+10])
+    tail=s[j:j+4000]
+    print(m.group(1)[:70], [x for x in re.findall(r'; (NumVgprs: \d+|NumAgprs: \d+|ScratchSize: \d+|codeLenInByte = \d+)', tail)][:4])
+PY
+python /root/repo/tools/isa_profile.py $OUT/step.s 2>/dev/null | sed -n 1,28p
