@@ -783,9 +783,9 @@ struct EnvLane {
       touching = touching || phi[s] > 0.f;
     }
     if (!ctx.any(touching)) return;  // most link groups of most wavefronts touch nothing
-    // every lane walks ITS touching slots (usually one of the SPL): the trip count is the maximum over the wavefront of the
-    // touching-slot count and the contact code exists once, instead of SPL predicated copies that all get executed because
-    // SOME lane of the wavefront touches with each slot (RL_CONTACT_UNROLLED selects the old form for A/B runs)
+    // SPL predicated copies of the contact code (RL_CONTACT_LOOP: every lane walks ITS touching slots instead - the trip count is
+    // the maximum over the wavefront of the touching-slot count and the code exists once; measured 3.5 us SLOWER on A1 Rough,
+    // 56.6 vs 53.0 us in one gpurun call: the select chain per trip and the ballot per trip cost more than the skipped copies)
     auto one_slot = [&](const int s, const float rad_s, const V3 cb_s, const float phi_s, const V3 nw_s) __attribute__((always_inline)) {
       Contact c = contact_from_phi(C, Rwb, V0, qd, gi, s, rad_s, cb_s, phi_s, nw_s);
       if (c.act) {
@@ -819,7 +819,7 @@ struct EnvLane {
         }
       }
     };
-#ifdef RL_CONTACT_UNROLLED
+#ifndef RL_CONTACT_LOOP
 #pragma unroll
     for (int s = 0; s < SPL; ++s) one_slot(s, gf.rad[s], gf.cb[s], phi[s], nw[s]);
 #else
@@ -884,6 +884,9 @@ struct EnvLane {
 
   RL_FN void fetch_all(const ChainTP& C, const M3& Rwb, uint32_t slot_valid, GroupFetch (&gf)[NIT], bool (&fetched)[NIT]) {
     RL_PHASE(3, "sub.contact_fetch");
+#ifdef RL_ABL_NO_CONTACTS  // analysis builds (tools/ablate.sh)
+    slot_valid = 0u;
+#endif
     static_for<0, NIT>([&](auto it) { fetched[it.value] = group_fetch<it.value>(C, Rwb, slot_valid, gf[it.value]); });
   }
 

@@ -87,8 +87,11 @@ struct RewTab {  // 48 bytes; index lists (joint_mirror pairs, gait feet) live i
   int32_t n_idx;
   uint64_t body_mask;
   int32_t idx_off;  // first entry of this term in the index pools
-  int32_t pad_;
+  int32_t row;      // joint-sum kinds: row of the env's joint-statistics table the term sums over its joint mask; else -1
 };
+// per-env reward tables in LDS (env_terms.h compute_rewards): REW_JS_ROWS statistics per task joint, REW_BT_NF words per body
+constexpr int REW_JS_ROWS = 10, REW_BT_NF = 14;
+RL_FN constexpr int rew_tab_words(int D, int n_bodies) { return REW_JS_ROWS * D + REW_BT_NF * n_bodies; }
 constexpr int IDX_POOL = 48;
 
 struct ObsTab {
@@ -147,6 +150,7 @@ struct TaskTab {  // everything that is not per limb
   float scan_res, scan_offset;
   uint32_t wheel_joint_mask;
   int32_t n_rewards;
+  uint64_t rew_rel_mask;  // bodies whose position / velocity relative to the root some reward term reads
   int32_t idx_pool_a[IDX_POOL], idx_pool_b[IDX_POOL];
   int32_t term_time_out, term_oob, term_illegal;
   float oob_buffer, illegal_threshold;

@@ -22,23 +22,7 @@ enum ObsKind {
   OBS_JOINT_VEL_REL, OBS_LAST_ACTION, OBS_HEIGHT_SCAN, OBS_JOINT_POS_REL_NO_WHEEL
 };
 
-// Term descriptors as the lane program consumes them: filled from the LDS tables at run time
-// (wave-uniform, pinned into SGPRs).  `Spec` lets a build provide them as `static constexpr` data
-// instead (compile-time term lists: no decode, no dispatch, bodies in execution order).  Measured twice on
-// MI355X for A1 Rough - 85.0 vs 82.9 us (round-1 term code) and 80.4 vs 74.1 us (one-case-per-kind code):
-// the fully unrolled term sequence raises register pressure and LOSES, so only the generic form is instantiated.
-struct RewDesc {
-  int kind, n_idx;
-  float weight, p[4];
-  uint32_t joint_mask;
-  uint64_t body_mask;
-  int idx_a[16], idx_b[16];
-};
-struct GenericSpec {
-  static constexpr bool generic = true;
-};
-
-template <class Ctx, class TP, class Spec = GenericSpec>
+template <class Ctx, class TP>
 struct EnvProgram : EnvLane<Ctx, TP> {
   using Base = EnvLane<Ctx, TP>;
   using ChainTP = typename Base::ChainTP;
@@ -232,53 +216,47 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     relv = point_velocity<TP, ChainTP>(C, this->wdepth(g), g, x, SV{ang_b, cross(base_com, ang_b)}, qd);  // relative to the root COM velocity
   }
 
-  struct RewCtx {
-    float gate, cmd_norm, bv, fc_hi;
+  // Reward evaluation: LANE PER TERM.  The lanes that own joints / body slots first publish two small per-env tables in LDS -
+  // joint statistics (one row per statistic, one column per task joint) and a body table (contact sensor state, net force,
+  // foot position / velocity relative to the root) - and then lane l of the env evaluates terms l, l + LPE, ... completely:
+  // it reads its term's descriptor from the LDS table image, sums over the joints of its joint mask / the bodies of its body
+  // mask from the tables and applies the term's own arithmetic.  The terms of an env are thus evaluated side by side (the wavefront
+  // executes each reward KIND that occurs once, for all environments and all terms of that kind), instead of one after the other
+  // with a descriptor pinned into SGPRs, a scalar dispatch and a cross-lane reduction per term (round 1: ~1100 cycles per term,
+  // 20 k of a 125 k-cycle step).  Every term cites the reference function it restates; oracle/env.py has the same arithmetic in fp64.
+  enum { JS_TAU2 = 0, JS_ACC2, JS_QD2, JS_LIMIT, JS_POWER, JS_DEV1, JS_DEV2, JS_DA2, JS_Q, JS_ABSQD, JS_ROWS };  // = env_tables.h REW_JS_ROWS
+  enum { BT_HMAX = 0, BT_CA, BT_CC, BT_LA, BT_LC, BT_FX, BT_FY, BT_FZ, BT_PX, BT_PY, BT_PZ, BT_VX, BT_VY, BT_VZ, BT_NF };  // = REW_BT_NF
+  static_assert(JS_ROWS == REW_JS_ROWS && BT_NF == REW_BT_NF, "reward tables: LDS sizing in env_tables.h");
+
+  struct RewEnv {
+    float gate, cmd_norm, bv, fc_hi, moving;
     bool terminated;
-    ChainTP C;
-    int sbody[NBS], jid[JX];  // jid: task joint index of the joints this lane accounts for, else -1
-    float hmax[NBS], t_ca[NBS], t_cc[NBS], t_la[NBS], t_lc[NBS], q0j[JX], slo[JX], shi[JX];
+    const float* JT;  // [JS_ROWS][D]
+    const float* BT;  // [n_bodies][BT_NF]
+    int D;
   };
 
-  // one reward term: unweighted value f (all lanes of the env return the same number).  One case per
-  // kind with the per-joint / per-slot loops inside it: with the kinds grouped into shared loops and an
-  // inner switch per joint, a wavefront walked ~30 scalar branches per term and a joint-sum term cost
-  // ~1450 cycles (tools/phase_clock.py) for 3 fused multiply-adds.
-  template <class RD>
-  RL_FN float reward_term(const RD& R, const RewCtx& rc) {
-    const float gate = rc.gate, cmd_norm = rc.cmd_norm, bv = rc.bv;
-    const ChainTP& C = rc.C;
-    const int(&sbody)[NBS] = rc.sbody;
-    const int(&jid)[JX] = rc.jid;
-    const float(&hmax)[NBS] = rc.hmax;
-    const float(&t_ca)[NBS] = rc.t_ca;
-    const float(&t_cc)[NBS] = rc.t_cc;
-    const float(&t_la)[NBS] = rc.t_la;
-    const float(&t_lc)[NBS] = rc.t_lc;
-    const float(&q0j)[JX] = rc.q0j;
-    const float(&slo)[JX] = rc.slo;
-    const float(&shi)[JX] = rc.shi;
-    const float fc_hi = rc.fc_hi;
-    auto in_mask = [&](int s) { return sbody[s] >= 0 && ((R.body_mask >> sbody[s]) & 1ull); };
-    auto first_c = [&](int s) { return t_cc[s] > 0.f && t_cc[s] < fc_hi; };
-    // sum over the joints of the term's joint mask / over the body slots of its body mask
-    auto jsum = [&](auto fj) {
-      float part = 0.f;
+  // unweighted value of one term, evaluated by ONE lane
+  RL_FN float term_value(const RewTab& R, const RewEnv& E) {
+    const float gate = E.gate, cmd_norm = E.cmd_norm, bv = E.bv, moving = E.moving;
+    const float* BT = E.BT;
+    const int32_t* ia = T.idx_pool_a + R.idx_off;
+    const int32_t* ib = T.idx_pool_b + R.idx_off;
+    auto first_c = [&](const float* r) { return r[BT_CC] > 0.f && r[BT_CC] < E.fc_hi; };   // ContactSensor.compute_first_contact(step_dt)
+    auto first_a = [&](const float* r) { return r[BT_CA] > 0.f && r[BT_CA] < E.fc_hi; };   // compute_first_air(step_dt)
+    // joint-sum kinds share one loop: R.row = row of the joint-statistics table (host: rl_env_host.h), -1 for every other kind
+    // (8 columns per trip, all LDS reads of a trip in flight together: a lone wavefront cannot hide a round trip per joint)
+    float js = 0.f;
+    if (R.row >= 0) {
+      const float* g = E.JT + R.row * E.D;
+      for (int j0 = 0; j0 < E.D; j0 += 8) {
+        float v[8];
 #pragma unroll
-      for (int j = 0; j < JX; ++j) {
-        const bool in = (NW == 0 || jid[j] >= 0) && ((R.joint_mask >> (jid[j] & 31)) & 1u);
-        part += in ? fj(j) : 0.f;
+        for (int w = 0; w < 8; ++w) v[w] = g[j0 + w];  // columns >= D: reads inside the tables, dropped by the mask (the host keeps joint masks below 1 << D)
+#pragma unroll
+        for (int w = 0; w < 8; ++w) js += ((R.joint_mask >> (j0 + w)) & 1u) ? v[w] : 0.f;
       }
-      return ctx.gsum(part);
-    };
-    auto ssum = [&](auto fs) {
-      float part = 0.f;
-#pragma unroll
-      for (int s = 0; s < NBS; ++s)
-        if (in_mask(s)) part += fs(s);
-      return ctx.esum(part);
-    };
-    const float moving = cmd_norm > 0.1f ? 1.f : 0.f;
+    }
     float f = 0.f;
     switch (R.kind) {
       case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
@@ -301,150 +279,69 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       case REW_ANG_VEL_XY_L2: f = (ang_b.x * ang_b.x + ang_b.y * ang_b.y) * gate; break;  // rewards.py:656-662
       case REW_FLAT_ORIENTATION_L2: f = (grav_b.x * grav_b.x + grav_b.y * grav_b.y) * gate; break;  // rewards.py:678-687
       case REW_UPWARD: f = (1.f - grav_b.z) * (1.f - grav_b.z); break;                     // rewards.py:608-613
-      case REW_IS_TERMINATED: f = rc.terminated ? 1.f : 0.f; break;
-      case REW_JOINT_TORQUES_L2: f = jsum([&](int j) { return tau_app[j] * tau_app[j]; }); break;
-      case REW_JOINT_ACC_L2: f = jsum([&](int j) { return qacc[j] * qacc[j]; }); break;
-      case REW_JOINT_VEL_L2: f = jsum([&](int j) { return qd[j] * qd[j]; }); break;
-      case REW_JOINT_POS_LIMITS: f = jsum([&](int j) { return fmaxf(slo[j] - q[j], 0.f) + fmaxf(q[j] - shi[j], 0.f); }); break;
-      case REW_JOINT_POWER: f = jsum([&](int j) { return fabsf(qd[j] * tau_app[j]); }); break;  // rewards.py:81-90
-      case REW_JOINT_DEVIATION_L1: f = jsum([&](int j) { return fabsf(q[j] - q0j[j]); }); break;
-      case REW_STAND_STILL:  // rewards.py:93-104
-        f = jsum([&](int j) { return fabsf(q[j] - q0j[j]); }) * (cmd_norm < R.p[0] ? 1.f : 0.f) * gate;
+      case REW_IS_TERMINATED: f = E.terminated ? 1.f : 0.f; break;
+      // joint sums [UPSTREAM isaaclab.envs.mdp] + rewards.py:81-90: the statistic is in the table, the mask picked the joints
+      case REW_JOINT_TORQUES_L2: case REW_JOINT_ACC_L2: case REW_JOINT_VEL_L2: case REW_JOINT_POS_LIMITS: case REW_JOINT_POWER:
+      case REW_JOINT_DEVIATION_L1: case REW_ACTION_RATE_L2:
+        f = js;
         break;
+      case REW_STAND_STILL: f = js * (cmd_norm < R.p[0] ? 1.f : 0.f) * gate; break;  // rewards.py:93-104
       case REW_JOINT_POS_PENALTY: {  // rewards.py:107-129
-        float run = fsqrt(jsum([&](int j) { return (q[j] - q0j[j]) * (q[j] - q0j[j]); }));
+        float run = fsqrt(js);
         f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
       } break;
-      case REW_ACTION_RATE_L2: {
+      case REW_JOINT_MIRROR: {  // rewards.py:259-278
+        const float* qt = E.JT + JS_Q * E.D;
         float part = 0.f;
+        for (int i0 = 0; i0 < R.n_idx; i0 += 4) {  // 4 pairs per trip: index reads, then the 8 position reads, in flight together
+          int a4[4], b4[4];
 #pragma unroll
-        for (int j = 0; j < JX; ++j) part += (NW == 0 || jid[j] >= 0) ? (act[j] - prev_act[j]) * (act[j] - prev_act[j]) : 0.f;
-        f = ctx.gsum(part);
-      } break;
-      case REW_JOINT_MIRROR: {  // rewards.py:259-278: joint positions staged by task joint index, one pair per lane
-        float* jq = ctx.obs_stage(1);  // the critic row is free until the observations are written
-        ctx.group_sync();
-        if (sub == 0)
+          for (int w = 0; w < 4; ++w) { a4[w] = ia[i0 + w < R.n_idx ? i0 + w : i0]; b4[w] = ib[i0 + w < R.n_idx ? i0 + w : i0]; }
+          float qa[4], qb[4];
 #pragma unroll
-          for (int j = 0; j < JX; ++j)
-            if (NW == 0 || jid[j] >= 0) jq[jid[j]] = q[j];
-        ctx.group_sync();
-        float part = 0.f;
-        for (int i = li; i < R.n_idx; i += LPE) {
-          float d = jq[R.idx_a[i]] - jq[R.idx_b[i]];
-          part += d * d;
+          for (int w = 0; w < 4; ++w) { qa[w] = qt[a4[w]]; qb[w] = qt[b4[w]]; }
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float d = qa[w] - qb[w];
+            part += i0 + w < R.n_idx ? d * d : 0.f;
+          }
         }
-        ctx.group_sync();
-        f = ctx.esum(part) * R.p[0] * gate;
+        f = part * R.p[0] * gate;
       } break;
-      case REW_UNDESIRED_CONTACTS: f = ssum([&](int s) { return hmax[s] > R.p[0] ? 1.f : 0.f; }) * gate; break;  // rewards.py:665-675
-      case REW_CONTACT_FORCES: f = ssum([&](int s) { return fmaxf(hmax[s] - R.p[0], 0.f); }); break;           // [UPSTREAM] contact_forces
-      case REW_FEET_CONTACT_WITHOUT_CMD:  // rewards.py:416-425
-        f = ssum([&](int s) { return first_c(s) ? 1.f : 0.f; }) * (cmd_norm < 0.1f ? 1.f : 0.f) * gate;
-        break;
-      case REW_FEET_CONTACT:  // rewards.py:399-413
-        f = (ssum([&](int s) { return first_c(s) ? 1.f : 0.f; }) != R.p[0] ? 1.f : 0.f) * moving * gate;
-        break;
-      case REW_FEET_AIR_TIME: f = ssum([&](int s) { return first_c(s) ? t_la[s] - R.p[0] : 0.f; }) * moving * gate; break;  // rewards.py:340-360
-      case REW_FEET_STUMBLE:  // rewards.py:428-436
-        f = (ssum([&](int s) {
-               float fx = cf[s][0], fy = cf[s][1];
-               return fsqrt(fx * fx + fy * fy) > 4.f * fabsf(cf[s][2]) ? 1.f : 0.f;
-             }) > 0.f ? 1.f : 0.f) * gate;
-        break;
-      case REW_FEET_HEIGHT_BODY:  // rewards.py:527-554
-        f = ssum([&](int s) {
-              V3 relp, relv;
-              body_rel(C, s, relp, relv);
-              float er = relp.z - R.p[0];
-              return er * er * ftanh(R.p[1] * fsqrt(relv.x * relv.x + relv.y * relv.y));
-            }) * moving * gate;
-        break;
-      case REW_FEET_SLIDE:  // rewards.py:557-587
-        f = ssum([&](int s) {
-              V3 relp, relv;
-              body_rel(C, s, relp, relv);
-              return hmax[s] > 1.0f ? fsqrt(relv.x * relv.x + relv.y * relv.y) : 0.f;
-            }) * gate;
-        break;
-      case REW_FEET_HEIGHT:  // feet_height, world frame (rewards.py:507-524)
-        f = ssum([&](int s) {
-              V3 relp, relv;
-              body_rel(C, s, relp, relv);
-              V3 pw = pos + mul(Rwb, relp);
-              V3 vw = lin_w + mul(Rwb, relv);
-              float er = pw.z - R.p[0];
-              return er * er * ftanh(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
-            }) * moving * gate;
-        break;
-      case REW_FEET_AIR_TIME_POSITIVE_BIPED: {  // rewards.py:363-383
-        float nc = 0.f, mn = 1e30f;
-#pragma unroll
-        for (int s = 0; s < NBS; ++s) {
-          if (!in_mask(s)) continue;
-          bool inc = t_cc[s] > 0.f;
-          nc += inc ? 1.f : 0.f;
-          mn = fminf(mn, inc ? t_cc[s] : t_ca[s]);
-        }
-        nc = ctx.esum(nc);
-        mn = ctx.emin(mn);
-        f = (nc == 1.f ? fminf(mn, R.p[0]) : 0.f) * moving * gate;
-      } break;
-      case REW_WHEEL_VEL_PENALTY: {  // rewards.py:132-153: |wheel speed| by task joint index and the wheels' first-air flags by
-                                     // body index are staged in the (still unwritten) critic row, one pair per lane
-        float* jq = ctx.obs_stage(1);
-        ctx.group_sync();
-        if (sub == 0)
-#pragma unroll
-          for (int j = 0; j < JX; ++j)
-            if (NW == 0 || jid[j] >= 0) jq[jid[j]] = fabsf(qd[j]);
-#pragma unroll
-        for (int s = 0; s < NBS; ++s)
-          if (sbody[s] >= 0) jq[T.D + sbody[s]] = (t_ca[s] > 0.f && t_ca[s] < fc_hi) ? 1.f : 0.f;
-        ctx.group_sync();
+      case REW_WHEEL_VEL_PENALTY: {  // rewards.py:132-153: pairs (wheel body, wheel joint)
+        const float* aq = E.JT + JS_ABSQD * E.D;
         const bool running = cmd_norm > R.p[1] || bv > R.p[0];
         float part = 0.f;
-        for (int i = li; i < R.n_idx; i += LPE) part += (running ? jq[T.D + R.idx_a[i]] : 1.f) * jq[R.idx_b[i]];
-        ctx.group_sync();
-        f = ctx.esum(part);
+        for (int i = 0; i < R.n_idx; ++i) part += (running ? (first_a(BT + ia[i] * BT_NF) ? 1.f : 0.f) : 1.f) * aq[ib[i]];
+        f = part;
+      } break;
+      case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256: product of exponentials = exponential of the sum
+        float air[4], con[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float* r = BT + ia[i] * BT_NF;
+          air[i] = r[BT_CA];
+          con[i] = r[BT_CC];
+        }
+        const float inv_std = frcp(R.p[0]), me2 = R.p[1] * R.p[1];
+        auto se = [&](float a, float b) { float d = a - b; return fminf(d * d, me2); };
+        float acc = se(air[0], air[1]) + se(con[0], con[1]) + se(air[2], air[3]) + se(con[2], con[3]);
+        acc += se(air[0], con[2]) + se(con[0], air[2]) + se(air[1], con[3]) + se(con[1], air[3]);
+        acc += se(air[0], con[3]) + se(con[0], air[3]) + se(air[2], con[1]) + se(con[2], air[1]);
+        f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? fexp(-acc * inv_std) : 0.f) * gate;
       } break;
       case REW_FEET_DISTANCE_Y_EXP:
       case REW_FEET_DISTANCE_XY_EXP: {  // rewards.py:439-461, 464-505: feet (link frames) against a stance rectangle in the base frame
         float part = 0.f;
-#pragma unroll
-        for (int s = 0; s < NBS; ++s) {
-          int at = -1;
-          for (int i = 0; i < R.n_idx; ++i) at = (sbody[s] == R.idx_a[i]) ? i : at;
-          if (at < 0) continue;
-          V3 relp, relv;
-          body_rel(C, s, relp, relv);
-          const float ey = ((at & 1) ? -0.5f : 0.5f) * R.p[1] - relp.y;
-          const float ex = R.kind == REW_FEET_DISTANCE_XY_EXP ? (at < 2 ? 0.5f : -0.5f) * R.p[2] - relp.x : 0.f;
+        for (int i = 0; i < R.n_idx; ++i) {
+          const float* r = BT + ia[i] * BT_NF;
+          const float ey = ((i & 1) ? -0.5f : 0.5f) * R.p[1] - r[BT_PY];
+          const float ex = R.kind == REW_FEET_DISTANCE_XY_EXP ? (i < 2 ? 0.5f : -0.5f) * R.p[2] - r[BT_PX] : 0.f;
           part += ex * ex + ey * ey;
         }
-        f = fexp(-ctx.esum(part) * frcp(R.p[0])) * gate;
+        f = fexp(-part * frcp(R.p[0])) * gate;
       } break;
-      case REW_HANDSTAND_FEET_HEIGHT_EXP: {  // config/others/unitree_a1_handstand/env/rewards.py:18-28
-        const float err = ssum([&](int s) {
-          V3 relp, relv;
-          body_rel(C, s, relp, relv);
-          const float dz = pos.z + dot(Rwb.r2, relp) - R.p[1];
-          return dz * dz;
-        });
-        f = fexp(-err * frcp(R.p[0]));
-      } break;
-      case REW_HANDSTAND_FEET_ON_AIR: {  // .../env/rewards.py:31-37: every selected foot has just left the ground
-        float n = 0.f, na = 0.f;
-#pragma unroll
-        for (int s = 0; s < NBS; ++s) {
-          if (!in_mask(s)) continue;
-          n += 1.f;
-          na += (t_ca[s] > 0.f && t_ca[s] < fc_hi) ? 1.f : 0.f;
-        }
-        f = ctx.esum(n - na) == 0.f ? 1.f : 0.f;
-      } break;
-      case REW_HANDSTAND_FEET_AIR_TIME: f = ssum([&](int s) { return first_c(s) ? t_la[s] - R.p[0] : 0.f; }); break;  // .../env/rewards.py:40-47
-      case REW_HANDSTAND_ORIENTATION_L2: {  // .../env/rewards.py:50-59
+      case REW_HANDSTAND_ORIENTATION_L2: {  // config/others/unitree_a1_handstand/env/rewards.py:50-59
         const float dx = grav_b.x - R.p[0], dy = grav_b.y - R.p[1], dz = grav_b.z - R.p[2];
         f = dx * dx + dy * dy + dz * dz;
       } break;
@@ -452,158 +349,219 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         float tgt = R.p[0];
         if (R.p[1] > 0.5f) {
           float hsum = 0.f;
-          for (int r = li; r < 9; r += LPE) {  // 9 rays over the env's lanes (LPE = 16 or 4)
-            const int iy = r / 3, ix = r - 3 * iy;
+          for (int r9 = 0; r9 < 9; ++r9) {
+            const int iy = r9 / 3, ix = r9 - 3 * iy;
             const float lx = (float)(ix - 1) * 0.05f, ly = (float)(iy - 1) * 0.05f;
             float hz;
             V3 nn;
             terrain_sample(this->u, S.terrain, pos.x + yaw_c * lx - yaw_s * ly, pos.y + yaw_s * lx + yaw_c * ly, hz, nn);
             hsum += hz;
           }
-          tgt += ctx.esum(hsum) * (1.0f / 9.0f);
+          tgt += hsum * (1.0f / 9.0f);
         }
         f = (pos.z - tgt) * (pos.z - tgt) * gate;
       } break;
-      case REW_FEET_AIR_TIME_VARIANCE: {  // rewards.py:386-397 (torch.var is unbiased)
-        float n = 0.f, sa = 0.f, saa = 0.f, sc = 0.f, scc = 0.f;
+      default: {  // sums over the bodies of the term's body mask
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, mn = 1e30f;
+        // 4 bodies per trip, their table rows read together (a lone wavefront cannot hide an LDS round trip per body)
+        for (uint64_t m = R.body_mask; m != 0ull;) {
+          const float* rr[4];
+          bool on[4];
 #pragma unroll
-        for (int s = 0; s < NBS; ++s) {
-          if (!in_mask(s)) continue;
-          float la = fminf(t_la[s], 0.5f), lc = fminf(t_lc[s], 0.5f);
-          n += 1.f; sa += la; saa += la * la; sc += lc; scc += lc * lc;
+          for (int w = 0; w < 4; ++w) {
+            on[w] = m != 0ull;
+            rr[w] = BT + (on[w] ? __builtin_ctzll(m) : 0) * BT_NF;
+            m &= m - 1ull;  // (0 stays 0)
+          }
+          float hm[4], ca[4], cc[4], la[4], lc[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { hm[w] = rr[w][BT_HMAX]; ca[w] = rr[w][BT_CA]; cc[w] = rr[w][BT_CC]; la[w] = rr[w][BT_LA]; lc[w] = rr[w][BT_LC]; }
+          switch (R.kind) {
+            case REW_UNDESIRED_CONTACTS:  // rewards.py:665-675
+#pragma unroll
+              for (int w = 0; w < 4; ++w) a0 += on[w] && hm[w] > R.p[0] ? 1.f : 0.f;
+              break;
+            case REW_CONTACT_FORCES:  // [UPSTREAM] contact_forces
+#pragma unroll
+              for (int w = 0; w < 4; ++w) a0 += on[w] ? fmaxf(hm[w] - R.p[0], 0.f) : 0.f;
+              break;
+            case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT:  // rewards.py:416-425, 399-413
+#pragma unroll
+              for (int w = 0; w < 4; ++w) a0 += on[w] && cc[w] > 0.f && cc[w] < E.fc_hi ? 1.f : 0.f;
+              break;
+            case REW_FEET_AIR_TIME: case REW_HANDSTAND_FEET_AIR_TIME:  // rewards.py:340-360
+#pragma unroll
+              for (int w = 0; w < 4; ++w) a0 += on[w] && cc[w] > 0.f && cc[w] < E.fc_hi ? la[w] - R.p[0] : 0.f;
+              break;
+            case REW_FEET_AIR_TIME_POSITIVE_BIPED:  // rewards.py:363-383
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const bool inc = cc[w] > 0.f;
+                a0 += on[w] && inc ? 1.f : 0.f;
+                mn = on[w] ? fminf(mn, inc ? cc[w] : ca[w]) : mn;
+              }
+              break;
+            case REW_HANDSTAND_FEET_ON_AIR:  // .../env/rewards.py:31-37: counts the feet that have NOT just lifted
+#pragma unroll
+              for (int w = 0; w < 4; ++w) a0 += on[w] && !(ca[w] > 0.f && ca[w] < E.fc_hi) ? 1.f : 0.f;
+              break;
+            case REW_FEET_AIR_TIME_VARIANCE:  // rewards.py:386-397 (torch.var is unbiased)
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const float xa = fminf(la[w], 0.5f), xc = fminf(lc[w], 0.5f), o = on[w] ? 1.f : 0.f;
+                a0 += o; a1 += o * xa; a2 += o * xa * xa; a3 += o * xc; a4 += o * xc * xc;
+              }
+              break;
+            case REW_FEET_STUMBLE:  // rewards.py:428-436
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const float fx = rr[w][BT_FX], fy = rr[w][BT_FY], fz = rr[w][BT_FZ];
+                a0 += on[w] && fsqrt(fx * fx + fy * fy) > 4.f * fabsf(fz) ? 1.f : 0.f;
+              }
+              break;
+            default: {  // the kinds that look at a foot's position / velocity relative to the root
+              V3 relp[4], relv[4];
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                relp[w] = {rr[w][BT_PX], rr[w][BT_PY], rr[w][BT_PZ]};
+                relv[w] = {rr[w][BT_VX], rr[w][BT_VY], rr[w][BT_VZ]};
+              }
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                float v = 0.f;
+                if (R.kind == REW_FEET_HEIGHT_BODY) {  // rewards.py:527-554
+                  const float er = relp[w].z - R.p[0];
+                  v = er * er * ftanh(R.p[1] * fsqrt(relv[w].x * relv[w].x + relv[w].y * relv[w].y));
+                } else if (R.kind == REW_FEET_SLIDE) {  // rewards.py:557-587
+                  v = hm[w] > 1.0f ? fsqrt(relv[w].x * relv[w].x + relv[w].y * relv[w].y) : 0.f;
+                } else if (R.kind == REW_FEET_HEIGHT) {  // feet_height, world frame (rewards.py:507-524)
+                  const V3 vw = lin_w + mul(Rwb, relv[w]);
+                  const float er = pos.z + dot(Rwb.r2, relp[w]) - R.p[0];
+                  v = er * er * ftanh(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
+                } else if (R.kind == REW_HANDSTAND_FEET_HEIGHT_EXP) {  // .../env/rewards.py:18-28
+                  const float dz = pos.z + dot(Rwb.r2, relp[w]) - R.p[1];
+                  v = dz * dz;
+                }
+                a0 += on[w] ? v : 0.f;
+              }
+            } break;
+          }
         }
-        n = ctx.esum(n); sa = ctx.esum(sa); saa = ctx.esum(saa); sc = ctx.esum(sc); scc = ctx.esum(scc);
-        const float inv_n = frcp(n), inv_den = frcp(fmaxf(n - 1.f, 1.f));
-        f = ((saa - sa * sa * inv_n) + (scc - sc * sc * inv_n)) * inv_den * gate;
-      } break;
-      case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256
-        float air[4], con[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float a = 0.f, c = 0.f;
-#pragma unroll
-          for (int s = 0; s < NBS; ++s)
-            if (sbody[s] == R.idx_a[i]) { a = t_ca[s]; c = t_cc[s]; }
-          air[i] = ctx.esum(a);
-          con[i] = ctx.esum(c);
+        switch (R.kind) {
+          case REW_UNDESIRED_CONTACTS: f = a0 * gate; break;
+          case REW_CONTACT_FORCES: f = a0; break;
+          case REW_FEET_CONTACT_WITHOUT_CMD: f = a0 * (cmd_norm < 0.1f ? 1.f : 0.f) * gate; break;
+          case REW_FEET_CONTACT: f = (a0 != R.p[0] ? 1.f : 0.f) * moving * gate; break;
+          case REW_FEET_AIR_TIME: f = a0 * moving * gate; break;
+          case REW_HANDSTAND_FEET_AIR_TIME: f = a0; break;
+          case REW_FEET_STUMBLE: f = (a0 > 0.f ? 1.f : 0.f) * gate; break;
+          case REW_FEET_HEIGHT_BODY: case REW_FEET_HEIGHT: f = a0 * moving * gate; break;
+          case REW_FEET_SLIDE: f = a0 * gate; break;
+          case REW_FEET_AIR_TIME_POSITIVE_BIPED: f = (a0 == 1.f ? fminf(mn, R.p[0]) : 0.f) * moving * gate; break;
+          case REW_HANDSTAND_FEET_HEIGHT_EXP: f = fexp(-a0 * frcp(R.p[0])); break;
+          case REW_HANDSTAND_FEET_ON_AIR: f = a0 == 0.f ? 1.f : 0.f; break;
+          case REW_FEET_AIR_TIME_VARIANCE: {
+            const float inv_n = frcp(a0), inv_den = frcp(fmaxf(a0 - 1.f, 1.f));
+            f = ((a2 - a1 * a1 * inv_n) + (a4 - a3 * a3 * inv_n)) * inv_den * gate;
+          } break;
+          default: break;
         }
-        const float inv_std = frcp(R.p[0]), me2 = R.p[1] * R.p[1];
-        auto se = [&](float a, float b) { float d = a - b; return fminf(d * d, me2); };
-        // product of exponentials = exponential of the sum: one v_exp_f32 for the six factors
-        float acc = se(air[0], air[1]) + se(con[0], con[1]) + se(air[2], air[3]) + se(con[2], con[3]);
-        acc += se(air[0], con[2]) + se(con[0], air[2]) + se(air[1], con[3]) + se(con[1], air[3]);
-        acc += se(air[0], con[3]) + se(con[0], air[3]) + se(air[2], con[1]) + se(con[2], air[1]);
-        f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? fexp(-acc * inv_std) : 0.f) * gate;
       } break;
-      default: break;
     }
     return f;
   }
 
   RL_FN float compute_rewards(bool terminated) {
-    RewCtx rc{0.f, 0.f, 0.f, 0.f, false, this->new_chain()};
-    rc.gate = clampf(-grav_b.z, 0.f, 0.7f) * (1.0f / 0.7f);
-    rc.cmd_norm = norm(cmd);
-    rc.bv = fsqrt(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
-    rc.terminated = terminated;
-    chain_kinematics<TP>(L, q, rc.C);
-    // per-slot sensor data and per-joint constants: one batch of LDS reads up front instead of dependent
-    // reads inside every term
-#pragma unroll
-    for (int s = 0; s < NBS; ++s) {
-      int b = L.slot_body[s];
-      rc.sbody[s] = ((s == 0 && !L.owns_base_body) || !this->owns_slot(s)) ? -1 : b;
-      rc.hmax[s] = fmaxf(hist_n[s][0], fmaxf(hist_n[s][1], hist_n[s][2]));
-      rc.t_ca[s] = tim[s][0]; rc.t_cc[s] = tim[s][1]; rc.t_la[s] = tim[s][2]; rc.t_lc[s] = tim[s][3];
-    }
-#pragma unroll
-    for (int j = 0; j < JX; ++j) {
-      rc.jid[j] = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1; rc.q0j[j] = L.q0[j]; rc.slo[j] = L.soft_lo[j]; rc.shi[j] = L.soft_hi[j];
-    }
-    rc.fc_hi = T.step_dt + 1e-8f;
-    float total = 0.f;
-    float* rstage = ctx.rew_stage();
-    const float step_dt = ctx.uniform(T.step_dt);
+    const int D = ctx.uniform_i(T.D), n_rewards = ctx.uniform_i(T.n_rewards);
+    float* JT = ctx.rew_tab();
+    float* BT = JT + JS_ROWS * D;
     // episode sums of the terms this lane writes back (t = li, li + LPE, ...): loaded now, consumed after the
     // terms - the HBM round trip overlaps the term arithmetic
     constexpr int NACC = (MAX_T + LPE - 1) / LPE;
     float acc[NACC];
-    {
-      const int nrew0 = ctx.uniform_i(T.n_rewards);
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) {
-        const int t = li + LPE * i;
-        acc[i] = t < nrew0 ? S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] : 0.f;
+    for (int i = 0; i < NACC; ++i) {
+      const int t = li + LPE * i;
+      acc[i] = t < n_rewards ? S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] : 0.f;
+    }
+    // ---- publish the joint statistics (first sub-lane of a limb: its joints; limb 0 also the trunk joints) ...
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < JX; ++j) {
+        const int jid = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1;
+        if (jid < 0) continue;
+        const float dq = q[j] - L.q0[j], da = act[j] - prev_act[j];
+        JT[JS_TAU2 * D + jid] = tau_app[j] * tau_app[j];
+        JT[JS_ACC2 * D + jid] = qacc[j] * qacc[j];
+        JT[JS_QD2 * D + jid] = qd[j] * qd[j];
+        JT[JS_LIMIT * D + jid] = fmaxf(L.soft_lo[j] - q[j], 0.f) + fmaxf(q[j] - L.soft_hi[j], 0.f);
+        JT[JS_POWER * D + jid] = fabsf(qd[j] * tau_app[j]);
+        JT[JS_DEV1 * D + jid] = fabsf(dq);
+        JT[JS_DEV2 * D + jid] = dq * dq;
+        JT[JS_DA2 * D + jid] = da * da;
+        JT[JS_Q * D + jid] = q[j];
+        JT[JS_ABSQD * D + jid] = fabsf(qd[j]);
       }
     }
-    int n_rewards;
-    if constexpr (Spec::generic) {
-      n_rewards = ctx.uniform_i(T.n_rewards);
-      // the descriptor of term t + 1 is read from LDS (into VGPRs) before term t runs, so its round trip hides behind
-      // that term instead of opening the next one; it is pinned into SGPRs (readfirstlane) only when its turn comes
-      struct Raw {
-        int kind, n_idx, idx_off;
-        float weight, p[4];
-        uint32_t joint_mask, bm_lo, bm_hi;
-      };
-      auto fetch = [&](int t) {
-        const RewTab& Rl = T.rew[t < n_rewards ? t : n_rewards - 1];
-        Raw r;
-        r.kind = Rl.kind; r.n_idx = Rl.n_idx; r.idx_off = Rl.idx_off; r.weight = Rl.weight;
-        r.p[0] = Rl.p[0]; r.p[1] = Rl.p[1]; r.p[2] = Rl.p[2]; r.p[3] = Rl.p[3];
-        r.joint_mask = Rl.joint_mask; r.bm_lo = (uint32_t)Rl.body_mask; r.bm_hi = (uint32_t)(Rl.body_mask >> 32);
-        return r;
-      };
-      Raw nxt = fetch(0);
-      RL_PHASE(17, "rewards.terms");
-      for (int t = 0; t < n_rewards; ++t) {
-        // the term descriptor is wave-uniform: pin it into SGPRs so that the dispatch is scalar branching
-        struct {
-          int kind, n_idx;
-          float weight, p[4];
-          uint32_t joint_mask;
-          uint64_t body_mask;
-          const int32_t *idx_a, *idx_b;
-        } R;
-        R.kind = ctx.uniform_i(nxt.kind); R.n_idx = ctx.uniform_i(nxt.n_idx); R.weight = ctx.uniform(nxt.weight);
-        R.p[0] = ctx.uniform(nxt.p[0]); R.p[1] = ctx.uniform(nxt.p[1]); R.p[2] = ctx.uniform(nxt.p[2]); R.p[3] = ctx.uniform(nxt.p[3]);
-        R.joint_mask = (uint32_t)ctx.uniform_i((int)nxt.joint_mask);
-        R.body_mask = (uint64_t)(uint32_t)ctx.uniform_i((int)nxt.bm_lo) | ((uint64_t)(uint32_t)ctx.uniform_i((int)nxt.bm_hi) << 32);
-        const int off = ctx.uniform_i(nxt.idx_off);
-        R.idx_a = T.idx_pool_a + off; R.idx_b = T.idx_pool_b + off;
-        nxt = fetch(t + 1);
-        RL_PHASE(25, "rewards.term_body");
-        float val = reward_term(R, rc) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
-        total += val;
-        if (li == 0) rstage[t] = val;
-        RL_PHASE(17, "rewards.terms");
-      }
-    } else {
-      n_rewards = Spec::n_rewards;
-#pragma unroll
-      for (int t = 0; t < Spec::n_rewards; ++t) {  // fully unrolled: every descriptor is a compile-time constant
-        float val = reward_term(Spec::rewards[t], rc) * Spec::rewards[t].weight * step_dt;
-        total += val;
-        if (li == 0) rstage[t] = val;
-      }
-    }
-    RL_PHASE(18, "rewards.writeback");
-    // per-term outputs + episode sums: staged through LDS so that each lane's read-modify-writes of
-    // `ep_sums` (terms t = k, k+4, ...) are issued as one batch instead of one HBM round trip per term
-    ctx.group_sync();
+    // ---- ... and the body table (the lane that owns a body slot: sensor state; position / velocity relative to the root for
+    // the bodies some term looks at that way - T.rew_rel_mask)
     {
-      const int nrew = n_rewards;
+      const uint64_t rel_mask = T.rew_rel_mask;
+      const bool any_rel = ctx.uniform_i((int)(rel_mask != 0ull)) != 0;
+      ChainTP C = this->new_chain();
+      if (any_rel) chain_kinematics<TP>(L, q, C);
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) {
-        const int t = li + LPE * i;
-        if (t < nrew) {
-          const float v = rstage[t];
-          S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = v;
-          S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = acc[i] + v;
+      for (int i = 0; i < Base::MAXOWN; ++i) {
+        const int s = this->own[i];
+        if (s < 0) continue;
+        const int b = L.slot_body[s];
+        if (b < 0 || (s == 0 && !L.owns_base_body)) continue;
+        float* r = BT + b * BT_NF;
+        r[BT_HMAX] = fmaxf(hist_n[s][0], fmaxf(hist_n[s][1], hist_n[s][2]));
+        r[BT_CA] = tim[s][0]; r[BT_CC] = tim[s][1]; r[BT_LA] = tim[s][2]; r[BT_LC] = tim[s][3];
+        r[BT_FX] = cf[s][0]; r[BT_FY] = cf[s][1]; r[BT_FZ] = cf[s][2];
+        if (any_rel && ((rel_mask >> b) & 1ull)) {
+          V3 relp, relv;
+          body_rel(C, s, relp, relv);
+          r[BT_PX] = relp.x; r[BT_PY] = relp.y; r[BT_PZ] = relp.z;
+          r[BT_VX] = relv.x; r[BT_VY] = relv.y; r[BT_VZ] = relv.z;
         }
       }
     }
     ctx.group_sync();
+    // ---- lane per term
+    RL_PHASE(17, "rewards.terms");
+    RewEnv E;
+    E.gate = clampf(-grav_b.z, 0.f, 0.7f) * (1.0f / 0.7f);
+    E.cmd_norm = norm(cmd);
+    E.bv = fsqrt(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
+    E.fc_hi = T.step_dt + 1e-8f;
+    E.moving = E.cmd_norm > 0.1f ? 1.f : 0.f;
+    E.terminated = terminated;
+    E.JT = JT; E.BT = BT; E.D = D;
+    const float step_dt = ctx.uniform(T.step_dt);
+    float* rstage = ctx.rew_stage();
+    float mine = 0.f;
+    for (int t = li; t < n_rewards; t += LPE) {
+      const RewTab& R = T.rew[t];
+      const float val = term_value(R, E) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
+      rstage[t] = val;
+      mine += val;
+    }
+    const float total = ctx.esum(mine);
+    // per-term outputs + episode sums: staged through LDS so that each lane's read-modify-writes of
+    // `ep_sums` (terms t = li, li + LPE, ...) are issued as one batch instead of one HBM round trip per term
+    RL_PHASE(18, "rewards.writeback");
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const int t = li + LPE * i;
+      if (t < n_rewards) {
+        const float v = rstage[t];
+        S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = v;
+        S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = acc[i] + v;
+      }
+    }
+    ctx.group_sync();  // the tables share LDS with the observation rows written next
     return total;
   }
 
@@ -630,10 +588,45 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // corrupt stage the raw value first and finish in a second pass, 4 consecutive columns (= one Philox block: noise index =
   // noise_base + column, block = index >> 2 as in uniform01) per lane - a Philox4x32-10 call is ~900 cycles (v_mul_hi/lo_u32 are
   // quarter rate), so it must not be paid per column.
+  // Height-scan rays of this lane: yaw-aligned grid, x fastest [UPSTREAM B6]; SCAN_RB rays per lane per trip so that all their
+  // 8-byte loads overlap (187 rays = ONE trip of 12 x 16 lanes).  The gather costs ~5 us of the A1 Rough step at 4096 envs
+  // (tools/ablate.sh): two cache lines per ray through the CU's vector L1, 6 k line requests per CU and step.
+  static constexpr int SCAN_RB = 12;
+  struct ScanPatches {
+    TerrainPatch tp[SCAN_RB];
+    bool single_trip;
+  };
+  RL_FN void scan_fetch_trip(int r0, int scan_n, float cy, float sy, V3 scan_p, ScanPatches& sp) const {
+    const int snx = ctx.uniform_i(T.scan_nx);
+    const float inv_snx = ctx.uniform(1.0f / (float)T.scan_nx);
+    const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1);
+#pragma unroll
+    for (int i = 0; i < SCAN_RB; ++i) {
+      int r = r0 + i * LPE;
+      r = r < scan_n ? r : scan_n - 1;
+      int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
+      float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
+      sp.tp[i] = terrain_fetch(this->u, S.terrain, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
+    }
+  }
+  RL_FN void scan_fetch(float cy, float sy, V3 scan_p, ScanPatches& sp) const {
+    const int scan_n = ctx.uniform_i(T.scan_nx * T.scan_ny);
+    const bool wanted = ctx.uniform_i(T.obs[0].scan_n + T.obs[1].scan_n) > 0;
+    sp.single_trip = wanted && scan_n <= SCAN_RB * LPE;
+#ifdef RL_ABL_NO_SCAN
+    sp.single_trip = false;
+#endif
+    if (sp.single_trip) scan_fetch_trip(li, scan_n, cy, sy, scan_p, sp);
+  }
+
   template <class GT>
-  RL_FN void write_group(const GT& G, const float* F, float* stage, uint32_t noise_base, float cy, float sy, V3 scan_p) {
+  RL_FN void write_group(const GT& G, const float* F, float* stage, uint32_t noise_base, float cy, float sy, V3 scan_p, const ScanPatches& sp) {
     constexpr int NITC = (TP::OBS_NC + LPE - 1) / LPE;
+#ifdef RL_ABL_NO_SCAN
+    const int n_cols = ctx.uniform_i(G.n_cols), scan_off = ctx.uniform_i(G.scan_off), scan_n = 0;
+#else
     const int n_cols = ctx.uniform_i(G.n_cols), scan_off = ctx.uniform_i(G.scan_off), scan_n = ctx.uniform_i(G.scan_n);
+#endif
     const int dim = ctx.uniform_i(G.dim);
     const bool corrupt = ctx.uniform_i(G.corrupt) != 0;
     {  // non-scan columns: ordinal n = li, li + LPE, ...; all descriptor reads, then all feature reads, then the arithmetic
@@ -652,27 +645,26 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         if (n < n_cols) stage[n < scan_off ? n : n + scan_n] = corrupt ? f[i] : clampf(f[i], d[i].clip_lo, d[i].clip_hi) * d[i].scale;
       }
     }
-    if (scan_n > 0) {  // yaw-aligned grid, x fastest; z_sensor - hit_z - offset.  12 rays per trip so 24 8-byte loads overlap
+    if (scan_n > 0) {  // z_sensor - hit_z - offset per ray; the heightfield patches were fetched by scan_fetch()
       const float s_scale = ctx.uniform(G.scan.scale), s_lo = ctx.uniform(G.scan.clip_lo), s_hi = ctx.uniform(G.scan.clip_hi);
-      const int snx = ctx.uniform_i(T.scan_nx);
-      const float inv_snx = ctx.uniform(1.0f / (float)T.scan_nx);
-      const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1), soff = T.scan_offset;
-      constexpr int RB = 12;  // rays per lane per trip (187 rays = one trip of 12 x 16 lanes: all 187 loads in flight together)
-      for (int r0 = li; r0 < scan_n; r0 += RB * LPE) {
-        TerrainPatch tp[RB];
+      const float soff = T.scan_offset;
+      if (sp.single_trip) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-          int r = r0 + i * LPE;
-          r = r < scan_n ? r : scan_n - 1;
-          int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
-          float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
-          tp[i] = terrain_fetch(this->u, S.terrain, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-          const int r = r0 + i * LPE;
-          const float v = scan_p.z - terrain_height(tp[i]) - soff;
+        for (int i = 0; i < SCAN_RB; ++i) {
+          const int r = li + i * LPE;
+          const float v = scan_p.z - terrain_height(sp.tp[i]) - soff;
           if (r < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
+        }
+      } else {
+        for (int r0 = li; r0 < scan_n; r0 += SCAN_RB * LPE) {
+          ScanPatches one;
+          scan_fetch_trip(r0, scan_n, cy, sy, scan_p, one);
+#pragma unroll
+          for (int i = 0; i < SCAN_RB; ++i) {
+            const int r = r0 + i * LPE;
+            const float v = scan_p.z - terrain_height(one.tp[i]) - soff;
+            if (r < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
+          }
         }
       }
     }
@@ -697,6 +689,14 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 
   RL_FN void observations() {
     derive();
+    // the height-scan loads go out first and are consumed by the group(s) that carry the scan, after the feature vector and the
+    // non-scan columns.  (Issuing them before the reward stage was tried: the 72 patch registers do not survive it - the compiler
+    // parks them in AGPRs, which needs the data, i.e. waits for the loads on the spot: 52.6 us either way.)
+    ScanPatches sp;
+    float cy, sy;
+    V3 scan_p;
+    scanner_pose(cy, sy, scan_p);
+    scan_fetch(cy, sy, scan_p, sp);
     // the env's feature vector -> LDS (env_tables.h FEAT_*): lane 0 the base block, the first sub-lane of a limb its joints
     float* F = ctx.feat_stage();
     const int D = ctx.uniform_i(T.D);
@@ -719,13 +719,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         F[FEAT_JOINT + 3 * D + jid] = ((wheel >> (jid & 31)) & 1u) ? 0.f : qr;
       }
     }
-    float cy, sy;
-    V3 scan_p;
-    scanner_pose(cy, sy, scan_p);
     ctx.group_sync();
-    write_group(T.obs[0], F, ctx.obs_stage(0), 0u, cy, sy, scan_p);
+    write_group(T.obs[0], F, ctx.obs_stage(0), 0u, cy, sy, scan_p, sp);
     RL_PHASE(21, "obs.policy_done");
-    write_group(T.obs[1], F, ctx.obs_stage(1), 1024u, cy, sy, scan_p);
+    write_group(T.obs[1], F, ctx.obs_stage(1), 1024u, cy, sy, scan_p, sp);
     RL_PHASE(22, "obs.flush");
     ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
     ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
@@ -768,6 +765,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       qd_tgt[j] = L.action_is_vel[j] ? pr : 0.f;
     }
     // 2 decimation loop: actuators -> physics -> contact sensor
+#ifdef RL_ABL_SUBSTEPS
+    if constexpr (Base::ABA) {
+      this->substeps_aba(q_tgt, qd_tgt, RL_ABL_SUBSTEPS);
+    } else
+#endif
     if constexpr (Base::ABA) {
       this->substeps_aba(q_tgt, qd_tgt, T.decimation);
     } else {
@@ -777,6 +779,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // 3 counters
     ep_len += 1;
     derive();
+
     // 4 terminations (velocity_env_cfg.py:648-664)
     bool t_timeout = T.term_time_out && ep_len >= (long long)T.max_episode_length;
     bool t_oob = false;
@@ -795,7 +798,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     bool terminated = t_illegal, time_out = t_timeout || t_oob;
     // 5 rewards
     RL_PHASE(16, "rewards");
+#ifdef RL_ABL_NO_REWARDS  // analysis builds: what the kernel costs without this stage (tools/ablate.sh)
+    float rew = 0.f;
+#else
     float rew = compute_rewards(terminated);
+#endif
     RL_PHASE(19, "resets+commands+push");
     if (li == 0) {
       S.reward[e] = rew;
@@ -865,7 +872,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     // 9 observations
     RL_PHASE(20, "observations");
+#ifndef RL_ABL_NO_OBS
     observations();
+#endif
     RL_PHASE(23, "store");
     this->store();
     store_task();

@@ -49,7 +49,7 @@ struct WaveCtx {
   float* stage[2];
   float* rstage;
   float* fstage;  // feature vectors of the tile's envs (observations)
-  int dim[2], fdim;
+  int dim[2], fdim, rtdim;  // rtdim: words of an env's reward tables (they share LDS with the observation rows + features)
   int lane;
   __device__ float* lane_scratch() const { return lscratch + lane; }
   __device__ float* limb_scratch() const { return lbscratch + lane / SUB; }
@@ -105,9 +105,23 @@ struct WaveCtx {
   __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }
   __device__ float* rew_stage() const { return rstage + env_in_tile() * MAX_T; }
   __device__ float* feat_stage() const { return fstage + env_in_tile() * fdim; }
-  __device__ void group_sync() const { __syncthreads(); }
+  __device__ float* rew_tab() const { return stage[0] + env_in_tile() * rtdim; }
+  // Ordering point for LDS traffic between the lanes of the workgroup.  The workgroup IS one wavefront, and a wavefront's LDS
+  // instructions execute in issue order, so a later ds_read of any lane sees an earlier ds_write of any lane without a hardware
+  // barrier: all that is needed is that the COMPILER keeps the accesses on their side of this point.  __syncthreads() would add
+  // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier - draining every global load in flight (the terrain and height-scan gathers that
+  // are deliberately issued early) ~20 times per step.
+  __device__ static void wave_sync() {
+#ifdef RL_SYNCTHREADS  // the old form, for A/B runs
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+  }
+  __device__ void group_sync() const { wave_sync(); }
   __device__ void flush_obs(float* out, int d, int g) const {
-    __syncthreads();  // single-wave workgroup: orders the LDS writes above before the reads below
+    wave_sync();  // orders the LDS writes above before the reads below
     const int n4 = (EPT * d) >> 2;  // the tile's rows are contiguous in `out`; 16-byte aligned when EPT * d % 4 == 0
     if (((EPT * d) & 3) == 0) {
       const float4* src = reinterpret_cast<const float4*>(stage[g]);
@@ -117,7 +131,7 @@ struct WaveCtx {
       float* dst = out + (size_t)blockIdx.x * EPT * d;
       for (int i = lane; i < EPT * d; i += 64) dst[i] = stage[g][i];
     }
-    __syncthreads();
+    wave_sync();
   }
 };
 
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
       if (i < n4) dst[i] = tmp[it];
     }
   }
-  __syncthreads();
+  Ctx::wave_sync();
   // LDS after the tables (only the staged bytes take room: the unused tail of the reward table is never touched):
   //   lane scratchpad | limb-shared words | observation staging rows | reward stage
   // On the instances with a contact stash (quadrupeds, 16 lanes per env) the staging rows and the reward stage live ON the
@@ -172,11 +186,16 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
   // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
   ctx.fdim = feat_count(Tl->D);
-  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && s0w + s1w + Ctx::EPT * (MAX_T + ctx.fdim) <= STASH_WORDS;  // same rule as Backend::configure
-  ctx.stage[0] = alias ? ctx.lscratch + LS::CT * 64 : tail;
+  ctx.rtdim = rew_tab_words(Tl->D, Tl->n_bodies);
+  // reward stage | [ observation rows + feature vectors ] = [ reward tables ] (the tables die before the rows are written)
+  int region = s0w + s1w + Ctx::EPT * ctx.fdim;
+  if (region < Ctx::EPT * ctx.rtdim) s1w += Ctx::EPT * ctx.rtdim - region, region = Ctx::EPT * ctx.rtdim;
+  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;  // same rule as Backend::configure
+  float* base = alias ? ctx.lscratch + LS::CT * 64 : tail;
+  ctx.rstage = base;
+  ctx.stage[0] = base + Ctx::EPT * MAX_T;
   ctx.stage[1] = ctx.stage[0] + s0w;
-  ctx.rstage = ctx.stage[1] + s1w;
-  ctx.fstage = ctx.rstage + Ctx::EPT * MAX_T;
+  ctx.fstage = ctx.stage[1] + s1w;
   ctx.lane = lane;
   EnvProgram<Ctx, TP> prog(ctx, S);
   if (RESET)
@@ -261,7 +280,10 @@ struct Backend {
     const size_t ls_words = T.NW > 0 ? LsFor<TopoG1, 4>::type::WORDS : (sub > 1 ? LsFor<TopoQuad3, 4>::type::WORDS : LsFor<TopoQuad3, 1>::type::WORDS);
     const size_t lb_words = T.NW > 0 ? LbLayout<TopoG1>::WORDS : 0;
     const size_t stash = (T.NW == 0 && sub > 1) ? (size_t)LsFor<TopoQuad3, 4>::STASH * CONTACT_WORDS * 64 * 4 : 0;
-    size_t rows = s0 + s1 + ept * (MAX_T + feat_count(T.D)) * 4;  // staging rows + reward stage + feature vectors: on the contact stash when they fit (env_kernel)
+    // reward stage + max(observation rows + feature vectors, reward tables): on the contact stash when they fit (env_kernel)
+    size_t region = s0 + s1 + ept * feat_count(T.D) * 4;
+    region = std::max(region, ept * (size_t)rew_tab_words(T.D, T.n_bodies) * 4);
+    size_t rows = ept * MAX_T * 4 + region;
     if (stash > 0 && rows <= stash) rows = 0;
     lds_bytes = tab + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + rows;
     if (lds_bytes > 160 * 1024) {

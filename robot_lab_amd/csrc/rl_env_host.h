@@ -316,11 +316,30 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     R.kind = r.kind; R.weight = r.weight; memcpy(R.p, r.p, sizeof(R.p)); R.joint_mask = r.joint_mask; R.body_mask = r.body_mask;
     R.n_idx = r.n_idx; R.idx_off = pool_used;
     if (r.n_idx < 0 || r.n_idx > 16 || pool_used + (r.kind == RL_REW_FEET_GAIT ? 4 : r.n_idx) > IDX_POOL) return fail("index lists of the reward terms exceed the pool");
-    if ((r.kind == RL_REW_WHEEL_VEL_PENALTY && m.num_dof + m.num_bodies > T.critic_dim) || (r.kind == RL_REW_JOINT_MIRROR && m.num_dof > T.critic_dim))
-      return fail("joint_mirror / wheel_vel_penalty stage per-joint (and per-body) values in the critic row, which is too short");
     const int nidx = r.kind == RL_REW_FEET_GAIT ? 4 : r.n_idx;
     for (int q = 0; q < nidx; ++q) { T.idx_pool_a[pool_used + q] = r.idx_a[q]; T.idx_pool_b[pool_used + q] = r.idx_b[q]; }
     pool_used += nidx;
+    // how the lane that evaluates the term finds its inputs (env_terms.h term_value): joint-sum kinds name a row of the
+    // joint-statistics table (same order as the JS_* enum there); kinds that read a body's position / velocity relative
+    // to the root add their bodies to rew_rel_mask
+    switch (r.kind) {
+      case RL_REW_JOINT_TORQUES_L2: R.row = 0; break;
+      case RL_REW_JOINT_ACC_L2: R.row = 1; break;
+      case RL_REW_JOINT_VEL_L2: R.row = 2; break;
+      case RL_REW_JOINT_POS_LIMITS: R.row = 3; break;
+      case RL_REW_JOINT_POWER: R.row = 4; break;
+      case RL_REW_JOINT_DEVIATION_L1: case RL_REW_STAND_STILL: R.row = 5; break;
+      case RL_REW_JOINT_POS_PENALTY: R.row = 6; break;
+      case RL_REW_ACTION_RATE_L2: R.row = 7; R.joint_mask = 0xffffffffu; break;  // every action dimension (cut to D below)
+      default: R.row = -1; break;
+    }
+    R.joint_mask &= m.num_dof >= 32 ? 0xffffffffu : ((1u << m.num_dof) - 1u);  // the lane that sums a row reads 8 columns per trip
+    if (r.kind == RL_REW_FEET_HEIGHT_BODY || r.kind == RL_REW_FEET_SLIDE || r.kind == RL_REW_FEET_HEIGHT || r.kind == RL_REW_HANDSTAND_FEET_HEIGHT_EXP)
+      T.rew_rel_mask |= r.body_mask;
+    if (r.kind == RL_REW_FEET_DISTANCE_Y_EXP || r.kind == RL_REW_FEET_DISTANCE_XY_EXP)
+      for (int q = 0; q < r.n_idx; ++q) T.rew_rel_mask |= 1ull << r.idx_a[q];
+    for (int q = 0; q < nidx; ++q)  // index lists address the tables directly: validate them here, not in the kernel
+      if (r.idx_a[q] < 0 || r.idx_a[q] >= RL_MAX_BODIES || r.idx_b[q] < 0 || r.idx_b[q] >= RL_MAX_BODIES) return fail("reward term index list out of range");
   }
   T.term_time_out = t.term_time_out; T.term_oob = t.term_out_of_bounds; T.term_illegal = t.term_illegal_contact;
   T.oob_buffer = t.oob_buffer; T.illegal_threshold = t.illegal_threshold; T.illegal_body_mask = t.illegal_body_mask;

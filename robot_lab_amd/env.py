@@ -278,8 +278,14 @@ class ManagerBasedRLEnv(_EnvBase):
         self.reward_manager = _RewardManager(self)
         self.extras: dict = {}
         self.log_episodes = True
-        if gym is not None:
-            sp = gym.spaces
+        g = gym
+        if g is None:  # gymnasium (or its shim) may have become importable after this module was first imported
+            try:
+                import gymnasium as g
+            except Exception:  # noqa: BLE001
+                g = None
+        if g is not None:
+            sp = g.spaces
             inf = float("inf")
             self.single_observation_space = sp.Dict({k: sp.Box(-inf, inf, (v.shape[1],)) for k, v in self._obs.items()})
             self.single_action_space = sp.Box(-inf, inf, (self.num_actions,))

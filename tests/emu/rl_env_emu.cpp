@@ -49,6 +49,7 @@ struct alignas(64) Team {
   alignas(64) float slot[LPE];
   float rstage[rl::MAX_T];
   float feat[rl::feat_count(rl::TopoMax::DMAX)];
+  float rtab[rl::rew_tab_words(RL_MAX_DOF, RL_MAX_BODIES)];
   std::vector<float> stage[2];
   Team() { bar.n = LPE; }
   void barrier(int&) { bar.wait(); }
@@ -208,6 +209,7 @@ struct HostCtx {
   float* obs_stage(int g) { return team->stage[g].data(); }
   float* rew_stage() { return team->rstage; }
   float* feat_stage() { return team->feat; }
+  float* rew_tab() { return team->rtab; }
   void group_sync() { team->barrier(sense_); }
   void flush_obs(float* out, int dim, int g) {
     team->barrier(sense_);
