@@ -104,6 +104,8 @@ class Physics:
         #   fn0    [N]   |lagged normal force| of a penetrating sphere nearest to its activation threshold 0
         #   stick  [m/s] ||u_t| - v_stick| of an active contact (mu_s <-> mu_d)
         #   limit  [rad] distance of a joint to a limit it is about to cross (the limit damper switches on)
+        #   cell   0 / inf: a touching sphere sits within 2e-5 m (fp32 resolution of world coordinates at +-60 m) of a heightfield
+        #          cell edge across which the bilinear patch's NORMAL jumps (the height is continuous there, its gradient is not)
         self.margins = None
         # np.float32: the linear solve of every substep is done in single precision (everything else stays fp64).  Used by the
         # "twins" of tests/helpers.py teacher_forced_check to measure how much an fp32 solve of THIS env's system moves the
@@ -263,6 +265,13 @@ class Physics:
         phi = self.sphere_radius[None] - (cw[..., 2] - hz) * nrm[..., 2]
         if self.margins is not None and G > 0:
             self._margin("phi", np.abs(phi).min(axis=1))
+            if not self.desc.terrain.is_plane:
+                near = phi > -1e-4  # touching, or about to
+                jump = np.zeros_like(phi)
+                for dx, dy in ((2e-5, 0.0), (-2e-5, 0.0), (0.0, 2e-5), (0.0, -2e-5)):
+                    _, n2 = self.terrain.sample(cw[..., 0] + dx, cw[..., 1] + dy)
+                    jump = np.maximum(jump, np.abs(n2 - nrm).max(axis=-1))
+                self._margin("cell", np.where(near & (jump > 1e-3), 0.0, np.inf).min(axis=1))
         contacts = []
         for gi in range(G):
             if not np.any(phi[:, gi] > 0):

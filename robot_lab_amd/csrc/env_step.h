@@ -242,25 +242,6 @@ RL_FN V3 point_velocity(const CT& C, int wd, int lg, V3 x, SV V0, const float (&
   return u;
 }
 
-// symmetric system / right-hand side stored in limb-shared LDS words (same idea as ChainT<.., true, ..>)
-template <int STRIDE>
-struct LdsVec {
-  float* p;
-  RL_FN float& operator[](int i) const { return p[i * STRIDE]; }
-};
-// accumulate-only view of the same words for contributions that DIFFER between the sub-lanes of a limb (contacts):
-// ds_add_f32 into the shared word instead of a private register copy + quad sum
-template <class Ctx, int STRIDE>
-struct LdsAcc {
-  float* p;
-  struct Ref {
-    float* q;
-    RL_FN void operator+=(float v) const { Ctx::limb_atomic_add(q, v); }
-    RL_FN void operator-=(float v) const { Ctx::limb_atomic_add(q, -v); }
-  };
-  RL_FN Ref operator[](int i) const { return Ref{p + i * STRIDE}; }
-};
-
 // Lane-private LDS scratchpad: word f of a lane lives at base[f * STRIDE] (STRIDE = 64 on the GPU, so
 // a wavefront access hits 64 different banks).  It holds the per-body contact-sensor state (timers,
 // force history, last force) and friction - ~80 values that would otherwise sit in VGPRs all step.
@@ -291,10 +272,16 @@ struct LsMat {
   RL_FN LsRow<STRIDE, W> operator[](int b) const { return {p + at(b) * W * STRIDE}; }
 };
 // words of limb-shared LDS an instance needs (0 when it keeps everything in registers)
+// Trunk + limbs instance (articulated-body form, substeps_aba_trunk): per limb the kinematics (15 words per joint), one 27-word
+// record per link group (rigid inertia + contact damping of a link, as seen in base coordinates) and 12 words per limb joint
+// that first hold the link velocity / bias acceleration and later the elimination's U / D and u / D; per ENV one 27-word
+// accumulator per trunk link (base, waist links, torso) that the limbs and the trunk links' owners ds_add into.
+constexpr int LINK_REC = 27;  // 21 (6 x 6 symmetric) + 6
 template <class TP>
 struct LbLayout {
-  enum { WORDS = TP::NW > 0 ? (TP::JX * 15 + SymIdx<TP::NB + TP::CL>::size + TP::NB + TP::CL) : 0,
-         AUX_WORDS = TP::NW > 0 ? TP::CL * 22 : 0 };  // streaming CRBA: momentum, bias force, inertia per link, in the obs staging rows
+  enum { CHAIN = 0, REC = TP::JX * 15, VA = REC + (TP::CL + 1) * LINK_REC, WORDS = TP::NW > 0 ? VA + TP::CL * 12 : 0,
+         AUX_WORDS = 0,
+         ENV_WORDS = TP::NW > 0 ? (TP::NW + 1) * LINK_REC : 0 };
 };
 
 // STASH > 0: room for the contacts of one link group (x, n, bias, d_n, d_t per sphere slot) so that the sensor
@@ -330,7 +317,7 @@ struct EnvLane {
   static constexpr bool LDSU = TP::NW > 0;
   static constexpr int LBS = Ctx::LB_STRIDE;
   using ChainTP = ChainT<TP, LDSU, LBS>;
-  enum { LB_CHAIN = 0, LB_U = (CL + NW) * 15, LB_RV = LB_U + UI::size, LB_WORDS = LB_RV + NV };
+  enum { LB_CHAIN = LbLayout<TP>::CHAIN, LB_REC = LbLayout<TP>::REC, LB_VA = LbLayout<TP>::VA, LB_WORDS = LbLayout<TP>::WORDS };
   RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_scratch() + LB_CHAIN * LBS : nullptr); }
 
   Ctx& ctx;
@@ -576,149 +563,6 @@ struct EnvLane {
     return contact_from_phi(C, Rwb, V0, qdv, g, s, rad, cb, phi, nw);
   }
 
-  // ------------------------------------------------------------------ contact pass 1
-  // Adds dt J^T D J / dt J^T n bias of every active sphere of the link groups this lane evaluates to
-  // (U, rv).  With SUB == 4 the four sub-lanes of a leg run this same code on different groups (g is a
-  // per-lane value) and the caller quad-sums the result; with SUB == 1 the lane loops over all groups.
-  // Joint columns of the system: 6 + m, m in [0, NW) the trunk joints, m in [NW, NW + CL) the limb joints.
-  template <class UA, class RA>
-  RL_FN void contact_pass1(const ChainTP& C, const M3& Rwb, SV V0, uint32_t slot_valid, UA& U, RA& rv, uint32_t& active_mask) {
-    const float dt = u.dt;
-#pragma unroll 1
-    for (int g = (SUB == 1 ? 0 : sub); g <= CL; g += SUB) {
-      if (!ctx.any(((slot_valid >> (g * SPL)) & ((1u << SPL) - 1u)) != 0u)) continue;
-      float rad[SPL];
-      V3 cb[SPL], cw[SPL];
-      TerrainPatch tp[SPL];
-      M3 Rg;
-      V3 pg;
-      group_frame(C, g, Rg, pg);
-#pragma unroll
-      for (int s = 0; s < SPL; ++s) {
-        sphere_center_in(Rg, pg, Rwb, g, s, rad[s], cb[s], cw[s]);
-        tp[s] = terrain_fetch(u, S.terrain, cw[s].x, cw[s].y);
-      }
-      float phi[SPL];
-      V3 nw[SPL];
-      bool touching = false;
-#pragma unroll
-      for (int s = 0; s < SPL; ++s) {
-        patch_phi(tp[s], rad[s], cw[s], phi[s], nw[s]);
-        touching = touching || phi[s] > 0.f;
-      }
-      if (!ctx.any(touching)) continue;  // most link groups of most wavefronts touch nothing
-      const int wd = wdepth(g);
-      auto one_slot = [&](const int s, const float rad_s, const V3 cb_s, const float phi_s, const V3 nw_s) __attribute__((always_inline)) {
-        Contact c = contact_from_phi(C, Rwb, V0, qd, g, s, rad_s, cb_s, phi_s, nw_s);
-        if (c.act) {
-          active_mask |= 1u << (g * SPL + s);
-          if (STASH && g == stash_group()) {  // keep the contact for the sensor pass
-            float* st = ctx.lane_scratch() + (LS::CT + s * CONTACT_WORDS) * LSS;
-            st[0 * LSS] = c.x.x; st[1 * LSS] = c.x.y; st[2 * LSS] = c.x.z; st[3 * LSS] = c.n.x; st[4 * LSS] = c.n.y; st[5 * LSS] = c.n.z;
-            st[6 * LSS] = c.bias; st[7 * LSS] = c.dn; st[8 * LSS] = c.dt;
-          }
-          // J = [ [x]x^T | 1 | a_m x (x - p_m) ... ] (point velocity wrt [omega_b, v_b, joints]); add
-          // dt (d_t J^T J + (d_n - d_t) g g^T) with g = J^T n, exploiting the block structure of J
-          const V3 x = c.x, n = c.n;
-          const float kt = dt * c.dt, kn = dt * (c.dn - c.dt), fb = dt * c.bias;
-          const V3 ga = cross(x, n);
-          const float g6[6] = {ga.x, ga.y, ga.z, n.x, n.y, n.z};
-          const float xx = dot(x, x);
-          // base block: kt [x]x^T [x]x  /  kt [x]x^T  /  kt 1   plus the rank-1 normal term - one update per entry
-          float b6[SymIdx<6>::size];
-#pragma unroll
-          for (int i = 0; i < SymIdx<6>::size; ++i) b6[i] = 0.f;
-          using B6 = SymIdx<6>;
-          b6[B6::at(0, 0)] = kt * (xx - x.x * x.x); b6[B6::at(1, 1)] = kt * (xx - x.y * x.y); b6[B6::at(2, 2)] = kt * (xx - x.z * x.z);
-          b6[B6::at(0, 1)] = -kt * x.x * x.y; b6[B6::at(0, 2)] = -kt * x.x * x.z; b6[B6::at(1, 2)] = -kt * x.y * x.z;
-          b6[B6::at(0, 4)] = -kt * x.z; b6[B6::at(0, 5)] = kt * x.y;
-          b6[B6::at(1, 3)] = kt * x.z; b6[B6::at(1, 5)] = -kt * x.x;
-          b6[B6::at(2, 3)] = -kt * x.y; b6[B6::at(2, 4)] = kt * x.x;
-          b6[B6::at(3, 3)] = kt; b6[B6::at(4, 4)] = kt; b6[B6::at(5, 5)] = kt;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            rv[i] += fb * g6[i];
-            const float kg = kn * g6[i];
-#pragma unroll
-            for (int jj = i; jj < 6; ++jj) U[UI::at(i, jj)] += b6[B6::at(i, jj)] + kg * g6[jj];
-          }
-          // joint columns (only the joints between the base and the sphere's link move the point); columns
-          // of joints that do not move it are zero vectors, so the pair loop needs no second predicate
-          V3 cj[JX];
-          float gc[JX];
-          bool mv[JX];
-#pragma unroll
-          for (int m = 0; m < JX; ++m) {
-            const bool moves = m < NW ? (m < wd) : (m - NW < g);
-            mv[m] = moves;
-            cj[m] = {0.f, 0.f, 0.f};
-            gc[m] = 0.f;
-            if (moves) {
-              cj[m] = m < NW ? cross(C.axw(m < NW ? m : 0), x - C.pw(m < NW ? m : 0)) : cross(C.ax(m < NW ? 0 : m - NW), x - C.p(m < NW ? 0 : m - NW));
-              gc[m] = dot(cj[m], n);
-              const V3 w = cross(x, cj[m]);
-              const float kg = kn * gc[m];
-              U[UI::at(0, 6 + m)] += kt * w.x + kg * g6[0]; U[UI::at(1, 6 + m)] += kt * w.y + kg * g6[1]; U[UI::at(2, 6 + m)] += kt * w.z + kg * g6[2];
-              U[UI::at(3, 6 + m)] += kt * cj[m].x + kg * g6[3]; U[UI::at(4, 6 + m)] += kt * cj[m].y + kg * g6[4]; U[UI::at(5, 6 + m)] += kt * cj[m].z + kg * g6[5];
-              rv[6 + m] += fb * gc[m];
-#pragma unroll
-              for (int i = 0; i <= m; ++i)
-                if (NW == 0 || mv[i]) U[UI::at(6 + i, 6 + m)] += kt * dot(cj[i], cj[m]) + kg * gc[i];  // (adds of an exact 0 are LDS atomics on G1)
-            }
-          }
-        }
-      };
-      if constexpr (NW > 0) {
-        // G1-sized instances: each lane walks ITS touching slots (usually one of the SPL) - the trip count is the
-        // maximum over the wavefront of the touching-slot count and the (large) accumulation block exists once
-        uint32_t tm = 0;
-#pragma unroll
-        for (int s = 0; s < SPL; ++s) tm |= phi[s] > 0.f ? (1u << s) : 0u;
-#pragma unroll 1
-        for (; ctx.any(tm != 0u); tm &= tm - 1u) {
-          const int s = tm != 0u ? __builtin_ctz(tm) : 0;
-          float rad_s = rad[0], phi_s = tm != 0u ? phi[0] : -1.f;
-          V3 cb_s = cb[0], nw_s = nw[0];
-#pragma unroll
-          for (int i = 1; i < SPL; ++i)
-            if (s == i) { rad_s = rad[i]; phi_s = tm != 0u ? phi[i] : -1.f; cb_s = cb[i]; nw_s = nw[i]; }
-          one_slot(s, rad_s, cb_s, phi_s, nw_s);
-        }
-      } else {  // quadrupeds: plain unrolled loop over the SPL slots (measured faster there)
-#pragma unroll
-        for (int s = 0; s < SPL; ++s) one_slot(s, rad[s], cb[s], phi[s], nw[s]);
-      }
-    }
-  }
-
-  // U/rv += a rigid composite with spatial inertia I (base coords), momentum h and bias force f that rides
-  // on the trunk link reached after `depth` trunk joints: base block, trunk-joint columns, bias.
-  template <class UT, class RT>
-  RL_FN void add_composite(const SI& I, const SV& h, const SV& f, int depth, const SV (&Sw)[TP::NW > 0 ? TP::NW : 1], UT& U, RT& rv) const {
-    const float dt = u.dt;
-    // 6x6 block from the spatial inertia: [[I, hx],[hx^T, m 1]]
-    U[UI::at(0, 0)] += I.I.xx; U[UI::at(1, 1)] += I.I.yy; U[UI::at(2, 2)] += I.I.zz;
-    U[UI::at(0, 1)] += I.I.xy; U[UI::at(0, 2)] += I.I.xz; U[UI::at(1, 2)] += I.I.yz;
-    U[UI::at(3, 3)] += I.m; U[UI::at(4, 4)] += I.m; U[UI::at(5, 5)] += I.m;
-    U[UI::at(0, 4)] += -I.h.z; U[UI::at(0, 5)] += I.h.y;
-    U[UI::at(1, 3)] += I.h.z;  U[UI::at(1, 5)] += -I.h.x;
-    U[UI::at(2, 3)] += -I.h.y; U[UI::at(2, 4)] += I.h.x;
-    const SV r = h - f * dt;
-    rv[0] += r.a.x; rv[1] += r.a.y; rv[2] += r.a.z;
-    rv[3] += r.l.x; rv[4] += r.l.y; rv[5] += r.l.z;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      if (i < depth) {
-        const SV B = apply(I, Sw[i]);
-        U[UI::at(0, 6 + i)] += B.a.x; U[UI::at(1, 6 + i)] += B.a.y; U[UI::at(2, 6 + i)] += B.a.z;
-        U[UI::at(3, 6 + i)] += B.l.x; U[UI::at(4, 6 + i)] += B.l.y; U[UI::at(5, 6 + i)] += B.l.z;
-#pragma unroll
-        for (int i2 = 0; i2 <= i; ++i2) U[UI::at(6 + i2, 6 + i)] += dot(Sw[i2], B);
-        rv[6 + i] += dot(Sw[i], r);
-      }
-    }
-  }
-
   // ================================================================== quadruped instances: articulated-body form
   // (H + A) nu+ = rhs is tree structured: every limb is a serial chain hanging off the base.  Instead of assembling the limb's
   // (6 + CL)^2 block and taking its Schur complement onto the base (the form the trunk + limbs instance still uses, below), the
@@ -736,7 +580,7 @@ struct EnvLane {
   // Work split over the SUB sub-lanes of a limb: link group g = sub + SUB * it (it < NIT) - group 0 is the lane's share of the
   // base link's spheres, group j + 1 is limb link j.  The owner of a group evaluates its contacts AND builds its link's rigid
   // record, adds the two, and the 27 numbers travel to the other sub-lanes with DPP quad broadcasts when the recursion gets there.
-  static constexpr bool ABA = NW == 0;
+  static constexpr bool ABA = NW == 0;  // register-resident, software-pipelined form (substeps_aba); NW > 0: substep_aba_trunk
   static constexpr int NIT = (CL + SUB) / SUB;  // ceil((CL + 1) / SUB) link groups per sub-lane
   using B6 = SymIdx<6>;
   struct LinkRec {
@@ -1070,314 +914,178 @@ struct EnvLane {
     }
   }
 
-  // ------------------------------------------------------------------ one physics substep
-  RL_FN void substep(const float (&q_tgt)[JX], const float (&qd_tgt)[JX]) {
-    // keep the compiler from hoisting the (loop-invariant) LDS table reads of all four substeps to the
-    // top of the kernel, where ~200 of them stayed live and spilled to scratch
-    asm volatile("" ::: "memory");
-    RL_PHASE(2, "sub.actuators+kinematics");
-    float tau_e[JX], pd_diag[JX], pd_rhs[JX];
-    actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
+  // ================================================================== trunk + limbs instance: articulated-body form
+  // Same recursion as substeps_aba, for a base that carries NW serial trunk joints (G1: the waist) with limbs hanging off the base
+  // (legs) and off the last trunk link (arms), and 7-joint limbs.  Nothing of that size stays in registers: the kinematics, the
+  // link records and the per-joint elimination results live in limb-shared LDS words (the 4 sub-lanes of a limb hold identical
+  // values: same word, a broadcast), and the limbs meet in 27-word per-trunk-link accumulators of the ENV (ds_add_f32), which
+  // every lane then reads to eliminate the trunk joints and solve the 6 x 6 base system redundantly.
+  RL_FN float* rec_words(int g) const { return ctx.limb_scratch() + (LB_REC + g * LINK_REC) * LBS; }
+  RL_FN float* va_words(int j) const { return ctx.limb_scratch() + (LB_VA + j * 12) * LBS; }
+  RL_FN float* trunk_words(int d) const { return ctx.env_scratch() + d * LINK_REC; }
 
-    const M3 Rwb = quat_to_mat(quat);
-    SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
-    SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
-    ChainTP C = new_chain();
-    chain_kinematics<TP>(L, q, C);
-
-    // ---- contacts first (they only need the kinematics): every sub-lane accumulates the spheres of its
-    // link groups into the zero-initialised (U, rv), the leg's sub-lanes are summed, and the CRBA terms are
-    // added on top - so only one copy of the system is ever live.
-    uint32_t active_mask = 0;
-    const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
-    if constexpr (LDSU && Ctx::LIMB_ATOMICS) {
-      // G1-sized system on the GPU: ds_add_f32 straight into the limb-shared LDS words (no 152-register private
-      // copy, no quad sum of 152 values)
-      LdsVec<LBS> U{ctx.limb_scratch() + LB_U * LBS}, rv{ctx.limb_scratch() + LB_RV * LBS};
+  // P -= (P S)(P S)^T / D etc. for one joint with motion subspace s6 and joint-local terms (D0, u0); returns U / D and u / D
+  RL_FN void eliminate(LinkRec& P, const float (&s6)[6], float D, float uu, float (&Uh)[6], float& ui) const {
+    float U6[6];
 #pragma unroll
-      for (int i = 0; i < UI::size; ++i) U[i] = 0.f;
+    for (int r = 0; r < 6; ++r) {
+      float t = 0.f;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) rv[i] = 0.f;
-      LdsAcc<Ctx, LBS> Ua{U.p}, ra{rv.p};
-      contact_pass1(C, Rwb, V0, slot_valid, Ua, ra, active_mask);
-      solve_and_integrate(U, rv, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
-    } else {
-      float Uc[UI::size];
-      float rvc[NV];
+      for (int c = 0; c < 6; ++c) t += P.A[B6::at(r, c)] * s6[c];
+      U6[r] = t;
+      D += s6[r] * t;
+      uu += s6[r] * P.r[r];
+    }
+    const float inv = frcp(D);
+    ui = uu * inv;
 #pragma unroll
-      for (int i = 0; i < UI::size; ++i) Uc[i] = 0.f;
+    for (int r = 0; r < 6; ++r) Uh[r] = U6[r] * inv;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) rvc[i] = 0.f;
-      RL_PHASE(5, "sub.contact_pass1");
-      contact_pass1(C, Rwb, V0, slot_valid, Uc, rvc, active_mask);
-      RL_PHASE(6, "sub.leg_sum");
-      if (SUB > 1 && ctx.any(active_mask != 0u)) {
+    for (int r = 0; r < 6; ++r) {
+      P.r[r] -= U6[r] * ui;
 #pragma unroll
-        for (int i = 0; i < UI::size; ++i) Uc[i] = ctx.leg_sum(Uc[i]);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) rvc[i] = ctx.leg_sum(rvc[i]);
-      }
-      if constexpr (LDSU) {
-        LdsVec<LBS> U{ctx.limb_scratch() + LB_U * LBS}, rv{ctx.limb_scratch() + LB_RV * LBS};
-#pragma unroll
-        for (int i = 0; i < UI::size; ++i) U[i] = Uc[i];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) rv[i] = rvc[i];
-        solve_and_integrate(U, rv, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
-      } else {
-        solve_and_integrate(Uc, rvc, C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, active_mask);
-      }
+      for (int c = r; c < 6; ++c) P.A[B6::at(r, c)] -= U6[r] * Uh[c];
     }
   }
+  // joint-local terms of joint jx (limb joint j or trunk joint CL + i): armature, implicit PD, limit spring-damper, and the
+  // identity row of an inert padding joint
+  RL_FN void joint_terms(int jx, bool padding, const float (&tau_e)[JX], const float (&pd_diag)[JX], const float (&pd_rhs)[JX], float& D, float& uu) const {
+    const float dt = u.dt, arm = L.armature[jx];
+    const float below = L.lower[jx] - q[jx], above = q[jx] - L.upper[jx];
+    const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
+    const bool lim = (below > 0.f) || (above > 0.f);
+    D = arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f) + (padding ? 1.0f : 0.f);
+    uu = arm * qd[jx] + dt * tau_e[jx] + pd_rhs[jx] + dt * u.limit_k * viol;
+  }
 
-  // CRBA / RNEA terms on top of the contact terms, Schur complement, trunk solve, contact sensor, integration
-  template <class UT, class RT>
-  RL_FN void solve_and_integrate(UT& U, RT& rv, const ChainTP& C, const M3& Rwb, const SV V0, const SV a0, const float (&tau_e)[JX], const float (&pd_diag)[JX],
-                                 const float (&pd_rhs)[JX], const uint32_t active_mask) {
+  RL_FN void substep_aba_trunk(const float (&q_tgt)[JX], const float (&qd_tgt)[JX]) {
+    static_assert(NW > 0, "trunk + limbs instance");
+    asm volatile("" ::: "memory");
+    RL_PHASE(2, "sub.actuators+kinematics");
     const float dt = u.dt;
-    RL_PHASE(7, "sub.crba");
-    // ---- trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
-    constexpr int NWA = NW > 0 ? NW : 1;
-    SV Sw[NWA], Vw[NWA], aw[NWA];
+    float tau_e[JX], pd_diag[JX], pd_rhs[JX];
+    actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
+    const M3 Rwb = quat_to_mat(quat);
+    const SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
+    const SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
+    ChainTP C = new_chain();
+    chain_kinematics<TP>(L, q, C);
+    // trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
+    SV Sw[NW], Vw[NW], aw[NW];
     {
       SV Vp = V0, ap = a0;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
         Sw[i] = SV{C.axw(i), cross(C.pw(i), C.axw(i))};
-        SV vj = Sw[i] * qd[CL + i];
+        const SV vj = Sw[i] * qd[CL + i];
         Vw[i] = Vp + vj;
         aw[i] = ap + crm(Vw[i], vj);
         Vp = Vw[i];
         ap = aw[i];
       }
     }
-    if constexpr (LDSU) {
-      // ---- streaming CRBA + RNEA (G1-sized limbs): the forward pass keeps only the running link velocity /
-      // bias acceleration and parks each link's momentum and bias force in LDS (the observation staging rows
-      // are idle during the substeps); the backward pass rebuilds the link inertia, carries ONE running
-      // composite (inertia, force, momentum) and emits the joint's column.  The array form below keeps
-      // 4 x CL spatial quantities live - fine for 3-4 joints, ~200 VGPRs of spills for 7.
-      // W[j]: 22 limb-shared words per link: momentum h_j (6), bias force f_j (6), spatial inertia I_j (10)
-      constexpr int WL = 22;
-      LdsVec<LBS> W{ctx.aux_limb_scratch()};
-      auto link_inertia = [&](int j) {
-        const uint32_t li = (uint32_t)(LY.LF_INERTIA + j * INERTIA_NF);
-        const M3 Rj = C.R(j);
-        const V3 cb = C.p(j) + mul(Rj, V3{LF(li + 1), LF(li + 2), LF(li + 3)});
-        return make_si(LF(li), cb, rotate(Rj, S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
-      };
-      auto joint_axis = [&](int j) {
-        const V3 ax = C.ax(j);
-        return SV{ax, cross(C.p(j), ax)};
-      };
-      auto put_sv = [&](int o, const SV& v) { W[o] = v.a.x; W[o + 1] = v.a.y; W[o + 2] = v.a.z; W[o + 3] = v.l.x; W[o + 4] = v.l.y; W[o + 5] = v.l.z; };
-      auto get_sv = [&](int o) { return SV{{W[o], W[o + 1], W[o + 2]}, {W[o + 3], W[o + 4], W[o + 5]}}; };
-      auto heavy = [&](int j, const SV& Vj, const SV& aj) {  // link j: inertia, momentum, bias force -> W[j]
-        const SI Ij = link_inertia(j);
-        const SV h = apply(Ij, Vj);
-        const SV f = apply(Ij, aj) + crf(Vj, h);
-        const int o = j * WL;
-        put_sv(o, h);
-        put_sv(o + 6, f);
-        W[o + 12] = Ij.m; W[o + 13] = Ij.h.x; W[o + 14] = Ij.h.y; W[o + 15] = Ij.h.z;
-        W[o + 16] = Ij.I.xx; W[o + 17] = Ij.I.yy; W[o + 18] = Ij.I.zz; W[o + 19] = Ij.I.xy; W[o + 20] = Ij.I.xz; W[o + 21] = Ij.I.yz;
-      };
-      {
-        SV Vp = V0, ap = a0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-          if (L.attach == i + 1) { Vp = Vw[i]; ap = aw[i]; }
-        if constexpr (Ctx::LIMB_ATOMICS && SUB == 4) {
-          // the limb words are real shared LDS: all sub-lanes run the (cheap) velocity recursion and park V_j, a_j
-          // in W[j]; then sub-lane s does the heavy part of links s and s + 4 only and overwrites them with h, f, I
-#pragma unroll
-          for (int j = 0; j < CL; ++j) {
-            const SV vj = joint_axis(j) * qd[j];
-            const SV Vj = Vp + vj;
-            const SV aj = ap + crm(Vj, vj);
-            put_sv(j * WL, Vj);
-            put_sv(j * WL + 6, aj);
-            Vp = Vj;
-            ap = aj;
-          }
-#pragma unroll
-          for (int t = 0; t < (CL + 3) / 4; ++t) {
-            const int j = sub + 4 * t;  // per-lane link index: LDS / HBM addressing only, no register arrays
-            if (j < CL) heavy(j, get_sv(j * WL), get_sv(j * WL + 6));
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < CL; ++j) {
-            const SV vj = joint_axis(j) * qd[j];
-            const SV Vj = Vp + vj;
-            const SV aj = ap + crm(Vj, vj);
-            heavy(j, Vj, aj);
-            Vp = Vj;
-            ap = aj;
-          }
-        }
-      }
-      SI Ic{0.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
-      SV Fc{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, Hc = Fc;
-#pragma unroll
-      for (int j = CL - 1; j >= 0; --j) {
-        const int o = j * WL;
-        Ic = Ic + SI{W[o + 12], {W[o + 13], W[o + 14], W[o + 15]}, {W[o + 16], W[o + 17], W[o + 18], W[o + 19], W[o + 20], W[o + 21]}};
-        Hc = Hc + get_sv(o);
-        Fc = Fc + get_sv(o + 6);
-        const SV Sjj = joint_axis(j);
-        const SV B = apply(Ic, Sjj);
-        U[UI::at(0, NB + j)] += B.a.x; U[UI::at(1, NB + j)] += B.a.y; U[UI::at(2, NB + j)] += B.a.z;
-        U[UI::at(3, NB + j)] += B.l.x; U[UI::at(4, NB + j)] += B.l.y; U[UI::at(5, NB + j)] += B.l.z;
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-          if (i < L.attach) U[UI::at(6 + i, NB + j)] += dot(Sw[i], B);
-#pragma unroll
-        for (int i = 0; i <= j; ++i) U[UI::at(NB + i, NB + j)] += dot(i == j ? Sjj : joint_axis(i), B);
-        const float arm = L.armature[j];
-        const float below = L.lower[j] - q[j], above = q[j] - L.upper[j];
-        const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
-        const bool lim = (below > 0.f) || (above > 0.f);
-        U[UI::at(NB + j, NB + j)] += arm + (j >= L.nj ? 1.0f : 0.f) + pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
-        rv[NB + j] += dot(Sjj, Hc) + arm * qd[j] + dt * (tau_e[j] - dot(Sjj, Fc)) + pd_rhs[j] + dt * u.limit_k * viol;
-      }
-      add_composite(Ic, Hc, Fc, L.attach, Sw, U, rv);
-      if (k <= NW) {  // lane group k adds trunk link k (0 = the base link) + the persistent external wrench [UPSTREAM B8]
-        const int bi = LY.EF_BASE_INERTIA + k * INERTIA_NF;
-        M3 Rf;
-        V3 pf;
-        trunk_frame<TP>(C, k, Rf, pf);
-        SV Vl = V0, al = a0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-          if (k == i + 1) { Vl = Vw[i]; al = aw[i]; }
-        const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
-        const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
-        SV h0 = apply(I0, Vl);
-        SV f0 = apply(I0, al) + crf(Vl, h0);
-        if (k == T.wrench_depth) {
-          const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
-          f0.a -= mul(Rf, extT) + cross(xc, Fb);
-          f0.l -= Fb;
-        }
-        add_composite(I0, h0, f0, k, Sw, U, rv);
-      }
-      if (k == 0) {  // joint-local terms of the trunk joints (armature, actuators, limits): once
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-          const int jx = CL + i;
-          float arm = L.armature[jx];
-          float below = L.lower[jx] - q[jx], above = q[jx] - L.upper[jx];
-          float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
-          bool lim = (below > 0.f) || (above > 0.f);
-          U[UI::at(6 + i, 6 + i)] += arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f) + (i >= T.nw_used ? 1.0f : 0.f);  // padding trunk joint: identity row
-          rv[6 + i] += arm * qd[jx] + dt * tau_e[jx] + pd_rhs[jx] + dt * u.limit_k * viol;
-        }
-      }
-    } else {
-    // ---- CRBA + RNEA of the limb in base coordinates
-    SV Sj[CL];
-    SI Ic[CL];
-    SV Fs[CL], Hs[CL];
-    if constexpr (SUB == 4 && NW == 0 && CL <= 4) {
-      // 16-lane mapping: the four sub-lanes of a leg used to repeat the whole pass.  Now every sub-lane runs
-      // the (cheap) velocity recursion, builds the inertia / momentum / bias force of ONE link - link `sub` -
-      // and the three or four records are exchanged with DPP quad broadcasts (22 values per link).
-      SV Vl[CL], al[CL];
-      {
-        SV Vp = V0, ap = a0;
-#pragma unroll
-        for (int j = 0; j < CL; ++j) {
-          Sj[j] = SV{C.ax(j), cross(C.p(j), C.ax(j))};
-          const SV vj = Sj[j] * qd[j];
-          Vl[j] = Vp + vj;
-          al[j] = ap + crm(Vl[j], vj);
-          Vp = Vl[j];
-          ap = al[j];
-        }
-      }
-      const int m = sub < CL ? sub : CL - 1;  // my link (the spare sub-lane of a 3-joint leg repeats the last one)
-      // my link's frame / velocity / bias acceleration as a 0-1 weighted blend: a chain of selects on `m` is
-      // rewritten by the compiler into an indexed load from a scratch copy of the arrays (a trip to memory)
-      M3 Rm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-      V3 pm{0.f, 0.f, 0.f};
-      SV Vm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, am = Vm;
-#pragma unroll
-      for (int j = 0; j < CL; ++j) {
-        const float w = m == j ? 1.f : 0.f;
-        const M3 Rj = C.R(j);
-        Rm.r0 += w * Rj.r0; Rm.r1 += w * Rj.r1; Rm.r2 += w * Rj.r2;
-        pm += w * C.p(j);
-        Vm.a += w * Vl[j].a; Vm.l += w * Vl[j].l;
-        am.a += w * al[j].a; am.l += w * al[j].l;
-      }
-      const uint32_t li = (uint32_t)(LY.LF_INERTIA + m * INERTIA_NF);
-      const V3 cb = pm + mul(Rm, V3{LF(li + 1), LF(li + 2), LF(li + 3)});
-      const SI Im = make_si(LF(li), cb, rotate(Rm, S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
-      const SV hm = apply(Im, Vm);
-      const SV fm = apply(Im, am) + crf(Vm, hm);
-      auto bc = [&](auto tag, int j) {
-        constexpr int J = decltype(tag)::value;
-        auto b = [&](float v) { return ctx.template leg_bcast<J>(v); };
-        Ic[j] = SI{b(Im.m), {b(Im.h.x), b(Im.h.y), b(Im.h.z)}, {b(Im.I.xx), b(Im.I.yy), b(Im.I.zz), b(Im.I.xy), b(Im.I.xz), b(Im.I.yz)}};
-        Hs[j] = SV{{b(hm.a.x), b(hm.a.y), b(hm.a.z)}, {b(hm.l.x), b(hm.l.y), b(hm.l.z)}};
-        Fs[j] = SV{{b(fm.a.x), b(fm.a.y), b(fm.a.z)}, {b(fm.l.x), b(fm.l.y), b(fm.l.z)}};
-      };
-      bc(std::integral_constant<int, 0>{}, 0);
-      if constexpr (CL > 1) bc(std::integral_constant<int, 1>{}, 1);
-      if constexpr (CL > 2) bc(std::integral_constant<int, 2>{}, 2);
-      if constexpr (CL > 3) bc(std::integral_constant<int, 3>{}, 3);
-#pragma unroll
-      for (int j = CL - 2; j >= 0; --j) {  // suffix sums: composite inertia / force / momentum
-        Ic[j] = Ic[j] + Ic[j + 1];
-        Fs[j] = Fs[j] + Fs[j + 1];
-        Hs[j] = Hs[j] + Hs[j + 1];
-      }
-    } else {
+    // limb link velocities / bias accelerations -> limb-shared words (identical in the 4 sub-lanes); env accumulators cleared
+    {
       SV Vp = V0, ap = a0;
 #pragma unroll
       for (int i = 0; i < NW; ++i)
         if (L.attach == i + 1) { Vp = Vw[i]; ap = aw[i]; }
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
-        Sj[j] = SV{C.ax(j), cross(C.p(j), C.ax(j))};
-        SV vj = Sj[j] * qd[j];
-        SV Vj = Vp + vj;
-        SV aj = ap + crm(Vj, vj);
-        // per-env link inertia (mass, com, inertia about com; randomised at startup) straight from HBM/L1
-        const int li = LY.LF_INERTIA + j * INERTIA_NF;
-        V3 cb = C.p(j) + mul(C.R(j), V3{LF(li + 1), LF(li + 2), LF(li + 3)});
-        Ic[j] = make_si(LF(li), cb, rotate(C.R(j), S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
-        Hs[j] = apply(Ic[j], Vj);
-        Fs[j] = apply(Ic[j], aj) + crf(Vj, Hs[j]);
+        const V3 ax = C.ax(j);
+        const SV Sj{ax, cross(C.p(j), ax)};
+        const SV vj = Sj * qd[j];
+        const SV Vj = Vp + vj;
+        const SV aj = ap + crm(Vj, vj);
+        float* w = va_words(j);
+        w[0 * LBS] = Vj.a.x; w[1 * LBS] = Vj.a.y; w[2 * LBS] = Vj.a.z; w[3 * LBS] = Vj.l.x; w[4 * LBS] = Vj.l.y; w[5 * LBS] = Vj.l.z;
+        w[6 * LBS] = aj.a.x; w[7 * LBS] = aj.a.y; w[8 * LBS] = aj.a.z; w[9 * LBS] = aj.l.x; w[10 * LBS] = aj.l.y; w[11 * LBS] = aj.l.z;
         Vp = Vj;
         ap = aj;
       }
-#pragma unroll
-      for (int j = CL - 2; j >= 0; --j) {  // suffix sums: composite inertia / force / momentum
-        Ic[j] = Ic[j] + Ic[j + 1];
-        Fs[j] = Fs[j] + Fs[j + 1];
-        Hs[j] = Hs[j] + Hs[j + 1];
-      }
+      for (int i = li; i < (NW + 1) * LINK_REC; i += LPE) ctx.env_scratch()[i] = 0.f;
     }
-    if constexpr (NW == 0) {  // quadrupeds: the base link rides in lane group 0's composite
-      SI Itop = Ic[0];
-      SV ftop = Fs[0], htop = Hs[0];
-      if (k == 0) {  // the base link itself, its bias force and the persistent external wrench [UPSTREAM B8]
-        const int bi = LY.EF_BASE_INERTIA;
-        const SI I0 = make_si(EF(bi), V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)}, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)});
-        SV h0 = apply(I0, V0);
-        SV f0 = apply(I0, a0) + crf(V0, h0);
-        f0.a -= extT + cross(base_com, extF);
-        f0.l -= extF;
-        Itop = Itop + I0;
-        ftop = ftop + f0;
-        htop = htop + h0;
+    ctx.group_sync();
+    // ---- per link group this lane owns: contacts + rigid record -> the limb's record words (group 0 = the lane's share of a
+    // trunk link's spheres: straight into that trunk link's accumulator)
+    uint32_t active_mask = 0;
+    const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
+    static_for<0, NIT>([&](auto it) {
+      const int g = sub + SUB * it.value;
+      RL_PHASE(3, "sub.contact_fetch");
+      GroupFetch gf;
+      const bool fetched = group_fetch<it.value>(C, Rwb, slot_valid, gf);
+      RL_PHASE(4, "sub.link_records");
+      LinkRec rec;
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) rec.A[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rec.r[i] = 0.f;
+      const int l = g - 1;
+      const bool has = l >= 0 && l < CL;
+      {  // rigid part of limb link l (mass 0 when the lane has no link in this iteration, or the limb is shorter)
+        const int lc = has ? l : 0;
+        const M3 Rl = C.R(lc);
+        const float* w = va_words(lc);
+        const SV Vl{{w[0 * LBS], w[1 * LBS], w[2 * LBS]}, {w[3 * LBS], w[4 * LBS], w[5 * LBS]}};
+        const SV al{{w[6 * LBS], w[7 * LBS], w[8 * LBS]}, {w[9 * LBS], w[10 * LBS], w[11 * LBS]}};
+        const uint32_t fi = (uint32_t)(LY.LF_INERTIA + lc * INERTIA_NF);
+        const float mass = has ? LF(fi) : 0.f;
+        const V3 cb = C.p(lc) + mul(Rl, V3{LF(fi + 1), LF(fi + 2), LF(fi + 3)});
+        const SI Il = make_si(mass, cb, rotate(Rl, S3{LF(fi + 4), LF(fi + 5), LF(fi + 6), LF(fi + 7), LF(fi + 8), LF(fi + 9)}));
+        add_rigid(rec, Il, Vl, al, SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
       }
-      add_composite(Itop, htop, ftop, 0, Sw, U, rv);
-    } else {
-      add_composite(Ic[0], Hs[0], Fs[0], L.attach, Sw, U, rv);
-      if (k <= NW) {  // lane group k adds trunk link k (0 = the base link) + the persistent external wrench [UPSTREAM B8]
+      RL_PHASE(5, "sub.contact_pass1");
+      const uint32_t before = active_mask;
+      if (fetched) group_contacts<it.value>(C, Rwb, V0, gf, rec, active_mask);
+      if (has) {
+        float* w = rec_words(g);
+#pragma unroll
+        for (int i = 0; i < B6::size; ++i) w[i * LBS] = rec.A[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[(B6::size + i) * LBS] = rec.r[i];
+      } else if (g == 0 && active_mask != before) {  // contacts of the trunk-link share
+        float* w = trunk_words(L.grp0_depth);
+#pragma unroll
+        for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(w + i, rec.A[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + B6::size + i, rec.r[i]);
+      }
+    });
+    ctx.group_sync();
+    // ---- limb elimination, tip -> attachment (every sub-lane: same values; results parked for the outward pass)
+    RL_PHASE(9, "sub.aba");
+    LinkRec P;
+#pragma unroll
+    for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
+#pragma unroll
+    for (int j = CL - 1; j >= 0; --j) {
+      const float* w = rec_words(j + 1);
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) P.A[i] += w[i * LBS];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.r[i] += w[(B6::size + i) * LBS];
+      const V3 ax = C.ax(j);
+      const V3 lx = cross(C.p(j), ax);
+      const float s6[6] = {ax.x, ax.y, ax.z, lx.x, lx.y, lx.z};
+      float D, uu, Uh[6], ui;
+      joint_terms(j, j >= L.nj, tau_e, pd_diag, pd_rhs, D, uu);
+      eliminate(P, s6, D, uu, Uh, ui);
+      float* o = va_words(j);  // (the link velocities parked here are no longer needed)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) o[r * LBS] = Uh[r];
+      o[6 * LBS] = ui;
+    }
+    // the limb as seen from its attachment link, and the trunk links' own rigid records, into the env's accumulators
+    if (sub == 0) {
+      float* w = trunk_words(L.attach);
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(w + i, P.A[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + B6::size + i, P.r[i]);
+      if (k <= NW) {  // lane group k also owns trunk link k (0 = the base link); the persistent external wrench [UPSTREAM B8]
         const int bi = LY.EF_BASE_INERTIA + k * INERTIA_NF;
         M3 Rf;
         V3 pf;
@@ -1388,152 +1096,123 @@ struct EnvLane {
           if (k == i + 1) { Vl = Vw[i]; al = aw[i]; }
         const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
         const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
-        SV h0 = apply(I0, Vl);
-        SV f0 = apply(I0, al) + crf(Vl, h0);
+        SV fx{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         if (k == T.wrench_depth) {
           const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
-          f0.a -= mul(Rf, extT) + cross(xc, Fb);
-          f0.l -= Fb;
+          fx.a = -(mul(Rf, extT) + cross(xc, Fb));
+          fx.l = -Fb;
         }
-        add_composite(I0, h0, f0, k, Sw, U, rv);
+        LinkRec tr;
+#pragma unroll
+        for (int i = 0; i < B6::size; ++i) tr.A[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tr.r[i] = 0.f;
+        add_rigid(tr, I0, Vl, al, fx);
+        float* wt = trunk_words(k);
+#pragma unroll
+        for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(wt + i, tr.A[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(wt + B6::size + i, tr.r[i]);
       }
     }
-    if (NW > 0 && k == 0) {  // joint-local terms of the trunk joints (armature, actuators, limits): once
-#pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const int jx = CL + i;
-        float arm = L.armature[jx];
-        float below = L.lower[jx] - q[jx], above = q[jx] - L.upper[jx];
-        float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
-        bool lim = (below > 0.f) || (above > 0.f);
-        U[UI::at(6 + i, 6 + i)] += arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f) + (i >= T.nw_used ? 1.0f : 0.f);
-        rv[6 + i] += arm * qd[jx] + dt * tau_e[jx] + pd_rhs[jx] + dt * u.limit_k * viol;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < CL; ++j) {
-      SV B = apply(Ic[j], Sj[j]);
-      U[UI::at(0, NB + j)] += B.a.x; U[UI::at(1, NB + j)] += B.a.y; U[UI::at(2, NB + j)] += B.a.z;
-      U[UI::at(3, NB + j)] += B.l.x; U[UI::at(4, NB + j)] += B.l.y; U[UI::at(5, NB + j)] += B.l.z;
-#pragma unroll
-      for (int i = 0; i < NW; ++i)
-        if (i < L.attach) U[UI::at(6 + i, NB + j)] += dot(Sw[i], B);
-#pragma unroll
-      for (int i = 0; i <= j; ++i) U[UI::at(NB + i, NB + j)] += dot(Sj[i], B);
-      float arm = L.armature[j];
-      U[UI::at(NB + j, NB + j)] += arm + ((NW > 0 && j >= L.nj) ? 1.0f : 0.f);  // padding joints of a shorter chain: identity row
-      rv[NB + j] += dot(Sj[j], Hs[j]) + arm * qd[j] + dt * (tau_e[j] - dot(Sj[j], Fs[j])) + pd_rhs[j];
-      // joint limits: implicit spring-damper (hard limits in the reference, a1.urdf:369,411,439)
-      float below = L.lower[j] - q[j], above = q[j] - L.upper[j];
-      float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
-      bool lim = (below > 0.f) || (above > 0.f);
-      U[UI::at(NB + j, NB + j)] += pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
-      rv[NB + j] += dt * u.limit_k * viol;
-    }
-
-    }
-
-    // ---- Schur complement of the limb block, cross-limb reduction, NB x NB trunk solve, back substitution
-    RL_PHASE(8, "sub.schur");
-    float Lc[CL][CL];
-#pragma unroll
-    for (int j = 0; j < CL; ++j) {
-      float s = U[UI::at(NB + j, NB + j)];
-#pragma unroll
-      for (int m = 0; m < j; ++m) s -= Lc[j][m] * Lc[j][m];
-      float inv = frsqrt(s);
-      Lc[j][j] = inv;  // the diagonal holds 1 / L_jj
-#pragma unroll
-      for (int i = j + 1; i < CL; ++i) {
-        float t = U[UI::at(NB + j, NB + i)];
-#pragma unroll
-        for (int m = 0; m < j; ++m) t -= Lc[i][m] * Lc[j][m];
-        Lc[i][j] = t * inv;
-      }
-    }
-    float Y[NB][CL], z[CL];
-#pragma unroll
-    for (int r = 0; r < NB; ++r)
-#pragma unroll
-      for (int j = 0; j < CL; ++j) {
-        float t = U[UI::at(r, NB + j)];
-#pragma unroll
-        for (int m = 0; m < j; ++m) t -= Lc[j][m] * Y[r][m];
-        Y[r][j] = t * Lc[j][j];
-      }
-#pragma unroll
-    for (int j = 0; j < CL; ++j) {
-      float t = rv[NB + j];
-#pragma unroll
-      for (int m = 0; m < j; ++m) t -= Lc[j][m] * z[m];
-      z[j] = t * Lc[j][j];
-    }
+    ctx.group_sync();
+    // ---- trunk elimination (every lane), base solve, velocities outwards
     RL_PHASE(10, "sub.cross_leg_sum");
-    using BI = SymIdx<NB>;
-    float Cb[BI::size], db[NB];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      float t = rv[r];
+    for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
 #pragma unroll
-      for (int j = 0; j < CL; ++j) t -= Y[r][j] * z[j];
-      db[r] = ctx.gsum(t);
+    for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
+    float Uhw[NW][6], uiw[NW];
 #pragma unroll
-      for (int c = r; c < NB; ++c) {
-        float v = U[UI::at(r, c)];
+    for (int d = NW; d >= 1; --d) {
+      const float* w = trunk_words(d);
 #pragma unroll
-        for (int j = 0; j < CL; ++j) v -= Y[r][j] * Y[c][j];
-        Cb[BI::at(r, c)] = ctx.gsum(v);
-      }
+      for (int i = 0; i < LINK_REC; ++i) (i < B6::size ? P.A[i] : P.r[i - B6::size]) += w[i];
+      const float s6[6] = {Sw[d - 1].a.x, Sw[d - 1].a.y, Sw[d - 1].a.z, Sw[d - 1].l.x, Sw[d - 1].l.y, Sw[d - 1].l.z};
+      float D, uu;
+      joint_terms(CL + d - 1, d - 1 >= T.nw_used, tau_e, pd_diag, pd_rhs, D, uu);
+      eliminate(P, s6, D, uu, Uhw[d - 1], uiw[d - 1]);
+    }
+    {
+      const float* w = trunk_words(0);
+#pragma unroll
+      for (int i = 0; i < LINK_REC; ++i) (i < B6::size ? P.A[i] : P.r[i - B6::size]) += w[i];
     }
     RL_PHASE(11, "sub.trunk_solve");
-    float nu0[NB];
-    {  // NB x NB Cholesky solve
-      float G[NB][NB];
+    float nu0[NB], qdn[JX];
+    {
+      float n6[6];
+      solve6(P.A, P.r, n6);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        float s = Cb[BI::at(j, j)];
-#pragma unroll
-        for (int m = 0; m < j; ++m) s -= G[j][m] * G[j][m];
-        float inv = frsqrt(s);
-        G[j][j] = inv;  // 1 / G_jj
-#pragma unroll
-        for (int i = j + 1; i < NB; ++i) {
-          float t = Cb[BI::at(j, i)];
-#pragma unroll
-          for (int m = 0; m < j; ++m) t -= G[i][m] * G[j][m];
-          G[i][j] = t * inv;
-        }
-      }
-      float y6[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        float t = db[j];
-#pragma unroll
-        for (int m = 0; m < j; ++m) t -= G[j][m] * y6[m];
-        y6[j] = t * G[j][j];
-      }
-#pragma unroll
-      for (int j = NB - 1; j >= 0; --j) {
-        float t = y6[j];
-#pragma unroll
-        for (int i = j + 1; i < NB; ++i) t -= G[i][j] * nu0[i];
-        nu0[j] = t * G[j][j];
-      }
+      for (int i = 0; i < 6; ++i) nu0[i] = n6[i];
     }
     RL_PHASE(12, "sub.back_subst");
-    float qdn[JX];
+    {
+      float vp[6] = {nu0[0], nu0[1], nu0[2], nu0[3], nu0[4], nu0[5]};
+      float va[6] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5]};  // velocity of the link this limb hangs off
 #pragma unroll
-    for (int j = CL - 1; j >= 0; --j) {
-      float t = z[j];
+      for (int i = 0; i < NW; ++i) {
+        float t = uiw[i];
 #pragma unroll
-      for (int r = 0; r < NB; ++r) t -= Y[r][j] * nu0[r];
+        for (int r = 0; r < 6; ++r) t -= Uhw[i][r] * vp[r];
+        qdn[CL + i] = t;
+        nu0[6 + i] = t;
+        vp[0] += Sw[i].a.x * t; vp[1] += Sw[i].a.y * t; vp[2] += Sw[i].a.z * t;
+        vp[3] += Sw[i].l.x * t; vp[4] += Sw[i].l.y * t; vp[5] += Sw[i].l.z * t;
+        if (L.attach == i + 1) {
 #pragma unroll
-      for (int i = j + 1; i < CL; ++i) t -= Lc[i][j] * qdn[i];
-      qdn[j] = t * Lc[j][j];
+          for (int r = 0; r < 6; ++r) va[r] = vp[r];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CL; ++j) {
+        const float* o = va_words(j);
+        float t = o[6 * LBS];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t -= o[r * LBS] * va[r];
+        qdn[j] = t;
+        const V3 ax = C.ax(j);
+        const V3 lx = cross(C.p(j), ax);
+        va[0] += ax.x * t; va[1] += ax.y * t; va[2] += ax.z * t;
+        va[3] += lx.x * t; va[4] += lx.y * t; va[5] += lx.z * t;
+      }
+    }
+    sensor_and_integrate(C, Rwb, V0, nu0, qdn, active_mask);
+  }
+
+  // 6 x 6 SPD solve (Cholesky) of the base system
+  RL_FN void solve6(const float (&Cb)[B6::size], const float (&db)[6], float (&x)[6]) const {
+    float G[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float sacc = Cb[B6::at(j, j)];
+#pragma unroll
+      for (int m = 0; m < j; ++m) sacc -= G[j][m] * G[j][m];
+      const float inv = frsqrt(sacc);
+      G[j][j] = inv;  // 1 / G_jj
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        float t = Cb[B6::at(j, i)];
+#pragma unroll
+        for (int m = 0; m < j; ++m) t -= G[i][m] * G[j][m];
+        G[i][j] = t * inv;
+      }
+    }
+    float y6[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float t = db[j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) t -= G[j][m] * y6[m];
+      y6[j] = t * G[j][j];
     }
 #pragma unroll
-    for (int i = 0; i < NW; ++i) qdn[CL + i] = nu0[6 + i];
-    sensor_and_integrate(C, Rwb, V0, nu0, qdn, active_mask);
+    for (int j = 5; j >= 0; --j) {
+      float t = y6[j];
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) t -= G[i][j] * x[i];
+      x[j] = t * G[j][j];
+    }
   }
 
   // The tail of a substep (both formulations): contact-sensor forces with the new velocities, integration, sensor timers.

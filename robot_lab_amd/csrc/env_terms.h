@@ -773,7 +773,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     if constexpr (Base::ABA) {
       this->substeps_aba(q_tgt, qd_tgt, T.decimation);
     } else {
-      for (int s = 0; s < T.decimation; ++s) this->substep(q_tgt, qd_tgt);
+      for (int s = 0; s < T.decimation; ++s) this->substep_aba_trunk(q_tgt, qd_tgt);
     }
     RL_PHASE(15, "terminations");
     // 3 counters

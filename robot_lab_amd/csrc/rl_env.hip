@@ -45,6 +45,7 @@ struct WaveCtx {
   static constexpr int EPT = 64 / LPE;
   float* lscratch;
   float* lbscratch;
+  float* envs;  // this env's words shared by all its lanes (trunk + limbs instance: per-trunk-link accumulators)
   const void* T;  // TablesT<TP> staged in LDS
   float* stage[2];
   float* rstage;
@@ -53,8 +54,7 @@ struct WaveCtx {
   int lane;
   __device__ float* lane_scratch() const { return lscratch + lane; }
   __device__ float* limb_scratch() const { return lbscratch + lane / SUB; }
-  // second limb-shared area, valid only while the observation staging rows are idle (inside the substeps)
-  __device__ float* aux_limb_scratch() const { return stage[0] + lane / SUB; }
+  __device__ float* env_scratch() const { return envs; }
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
@@ -183,15 +183,21 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   }
   ctx.lscratch = smem + TAB_F;
   ctx.lbscratch = ctx.lscratch + LS::WORDS * 64;
-  float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE;
+  ctx.envs = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + (lane / Ctx::LPE) * LbLayout<TP>::ENV_WORDS;
+  float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + Ctx::EPT * LbLayout<TP>::ENV_WORDS;
   // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
   ctx.fdim = feat_count(Tl->D);
   ctx.rtdim = rew_tab_words(Tl->D, Tl->n_bodies);
   // reward stage | [ observation rows + feature vectors ] = [ reward tables ] (the tables die before the rows are written)
   int region = s0w + s1w + Ctx::EPT * ctx.fdim;
   if (region < Ctx::EPT * ctx.rtdim) s1w += Ctx::EPT * ctx.rtdim - region, region = Ctx::EPT * ctx.rtdim;
-  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;  // same rule as Backend::configure
-  float* base = alias ? ctx.lscratch + LS::CT * 64 : tail;
+  // Where they live (same rule as Backend::configure): quadrupeds - on the contact stash of the lane scratchpad, dead once the
+  // substeps are over; trunk + limbs instance - on the link-record / elimination words of the limb-shared area, dead likewise
+  // (its kinematics words stay: rewards and the scanner pose recompute the chain into them); else behind everything.
+  constexpr int LB_FREE = TP::NW > 0 ? (LbLayout<TP>::WORDS - LbLayout<TP>::REC) * Ctx::LB_STRIDE : 0;
+  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;
+  const bool alias_lb = TP::NW > 0 && Ctx::EPT * MAX_T + region <= LB_FREE;
+  float* base = alias ? ctx.lscratch + LS::CT * 64 : (alias_lb ? ctx.lbscratch + LbLayout<TP>::REC * Ctx::LB_STRIDE : tail);
   ctx.rstage = base;
   ctx.stage[0] = base + Ctx::EPT * MAX_T;
   ctx.stage[1] = ctx.stage[0] + s0w;
@@ -279,13 +285,15 @@ struct Backend {
     if (s0 + s1 < aux) s1 = aux - s0;
     const size_t ls_words = T.NW > 0 ? LsFor<TopoG1, 4>::type::WORDS : (sub > 1 ? LsFor<TopoQuad3, 4>::type::WORDS : LsFor<TopoQuad3, 1>::type::WORDS);
     const size_t lb_words = T.NW > 0 ? LbLayout<TopoG1>::WORDS : 0;
+    const size_t env_words = T.NW > 0 ? LbLayout<TopoG1>::ENV_WORDS : 0;
     const size_t stash = (T.NW == 0 && sub > 1) ? (size_t)LsFor<TopoQuad3, 4>::STASH * CONTACT_WORDS * 64 * 4 : 0;
     // reward stage + max(observation rows + feature vectors, reward tables): on the contact stash when they fit (env_kernel)
     size_t region = s0 + s1 + ept * feat_count(T.D) * 4;
     region = std::max(region, ept * (size_t)rew_tab_words(T.D, T.n_bodies) * 4);
     size_t rows = ept * MAX_T * 4 + region;
     if (stash > 0 && rows <= stash) rows = 0;
-    lds_bytes = tab + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + rows;
+    if (T.NW > 0 && rows <= (size_t)(LbLayout<TopoG1>::WORDS - LbLayout<TopoG1>::REC) * (64 / sub) * 4) rows = 0;  // on the limb-shared record words
+    lds_bytes = tab + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + env_words * ept * 4 + rows;
     if (lds_bytes > 160 * 1024) {
       err = "observation rows do not fit the 160 KiB LDS of a CU";
       return -1;

@@ -49,6 +49,8 @@ struct alignas(64) Team {
   alignas(64) float slot[LPE];
   float rstage[rl::MAX_T];
   float feat[rl::feat_count(rl::TopoMax::DMAX)];
+  float lb[rl::NLANE][rl::LbLayout<rl::TopoG1>::WORDS + 1];  // limb-shared words (really shared by the limb's sub-lane threads)
+  float envw[rl::LbLayout<rl::TopoG1>::ENV_WORDS + 1];        // env-shared words
   float rtab[rl::rew_tab_words(RL_MAX_DOF, RL_MAX_BODIES)];
   std::vector<float> stage[2];
   Team() { bar.n = LPE; }
@@ -119,18 +121,22 @@ class Pool {
 template <int SUB_>
 struct HostCtx {
   static constexpr int LS_STRIDE = 1;
-  static constexpr bool LIMB_ATOMICS = false;  // per-thread copies: the register accumulation + leg_sum path is emulated
-  static void limb_atomic_add(float* p, float v) { *p += v; }
+  static constexpr bool LIMB_ATOMICS = true;
+  static void limb_atomic_add(float* p, float v) {  // ds_add_f32 of the kernel: lane threads of several limbs add into env words
+    static std::atomic_flag lock = ATOMIC_FLAG_INIT;
+    while (lock.test_and_set(std::memory_order_acquire)) {
+    }
+    *p += v;
+    lock.clear(std::memory_order_release);
+  }
   static constexpr int LB_STRIDE = 1;  // "limb-shared" words are private per lane thread here (the sub-lanes hold identical values)
   static constexpr int SUB = SUB_;
   static constexpr int LPE = rl::NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
   float scratch[rl::LsLayout<rl::MAX_NBS, rl::MAX_SPL>::WORDS];
   float* lane_scratch() { return scratch; }
-  float lb[rl::LbLayout<rl::TopoG1>::WORDS + 1];
-  float* limb_scratch() { return lb; }
-  float aux[rl::MAX_CL * 22];
-  float* aux_limb_scratch() { return aux; }
+  float* limb_scratch() { return team->lb[k_]; }
+  float* env_scratch() { return team->envw; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
   Team<LPE>* team;
