@@ -287,14 +287,15 @@ struct LbLayout {
 // STASH > 0: room for the contacts of one link group (x, n, bias, d_n, d_t per sphere slot) so that the sensor
 // pass after the solve does not re-evaluate them (quadrupeds in the 16-lane mapping; 4 workgroups x 40 KB of LDS
 // still share a CU)
-constexpr int CONTACT_WORDS = 10;
+constexpr int CONTACT_WORDS = 9;  // x (3), n (3), bias, d_n, d_t
 template <int ROWS, int STASH = 0>
 struct LsLayout {  // ROWS sensor rows (timers 4, force history 3, last force 3, friction 3 words each) + the contact stash
   enum { TIM = 0, HIST = TIM + ROWS * 4, CF = HIST + ROWS * 3, FRIC = CF + ROWS * 3, CT = FRIC + ROWS * 3, WORDS = CT + STASH * CONTACT_WORDS };
 };
 template <class TP, int SUB>
 struct LsFor {  // lane scratchpad layout of an instance
-  static constexpr int STASH = SUB > 1 ? TP::SPL : 0;  // contacts of the most distal link group a sub-lane evaluates (feet, wheels, hands)
+  static constexpr int NIT = (TP::CL + SUB) / SUB;            // link groups a sub-lane evaluates: g = sub + SUB * it
+  static constexpr int STASH = SUB > 1 ? NIT * TP::SPL : 0;  // every contact of pass 1 is kept for the sensor pass (slot it * SPL + s)
   static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::MAXOWN;      // 16-lane mapping: rows for the owned slots only
   using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::MAXOWN), STASH>;
 };
@@ -530,13 +531,15 @@ struct EnvLane {
     terrain_eval(u, tp, hz, nw);
     phi = rad > 0.f ? rad - (cw.z - hz) * nw.z : -1.f;
   }
-  RL_FN Contact contact_from_phi(const ChainTP& C, const M3& Rwb, SV V0, const float (&qdv)[JX], int g, int s, float rad, V3 cb, float phi, V3 nw) const {
+  // `Vg`: spatial velocity (base coordinates, referred to the base origin) of the link the sphere rides on - the velocity of a
+  // point x of that link is Vg.l + Vg.a x x, whatever the number of joints between it and the base
+  RL_FN Contact contact_from_phi(const M3& Rwb, const SV& Vg, int g, int s, float rad, V3 cb, float phi, V3 nw) const {
     Contact c;
     c.act = false;
     if (phi > 0.f) {
       V3 nb = mulT(Rwb, nw);
       V3 x = cb - rad * nb;
-      V3 uu = point_velocity<TP, ChainTP>(C, wdepth(g), g, x, V0, qdv);
+      V3 uu = Vg.l + cross(Vg.a, x);
       float un = dot(nb, uu);
       V3 ut = uu - un * nb;
       float utn = norm(ut);
@@ -555,12 +558,24 @@ struct EnvLane {
     }
     return c;
   }
+  // spatial velocity of the link of group g from the generalised velocities (the one-lane-per-limb mapping's sensor pass)
+  RL_FN SV link_twist(const ChainTP& C, int g, SV V0, const float (&qdv)[JX]) const {
+    SV V = V0;
+    const int wd = wdepth(g);
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (i < wd) { V.a += qdv[CL + i] * C.axw(i); V.l += qdv[CL + i] * cross(C.pw(i), C.axw(i)); }
+#pragma unroll
+    for (int i = 0; i < CL; ++i)
+      if (i < g) { V.a += qdv[i] * C.ax(i); V.l += qdv[i] * cross(C.p(i), C.ax(i)); }
+    return V;
+  }
   RL_FN Contact contact_from_patch(const ChainTP& C, const M3& Rwb, SV V0, const float (&qdv)[JX], int g, int s, float rad, V3 cb, V3 cw,
                                    const TerrainPatch& tp) const {
     float phi;
     V3 nw;
     patch_phi(tp, rad, cw, phi, nw);
-    return contact_from_phi(C, Rwb, V0, qdv, g, s, rad, cb, phi, nw);
+    return contact_from_phi(Rwb, link_twist(C, g, V0, qdv), g, s, rad, cb, phi, nw);
   }
 
   // ================================================================== quadruped instances: articulated-body form
@@ -614,7 +629,7 @@ struct EnvLane {
 
   // stage B: penetration, contact activation, and the contact's 6 x 6 block / bias onto the group's link record
   template <int IT>
-  RL_FN void group_contacts(const ChainTP& C, const M3& Rwb, SV V0, const GroupFetch& gf, LinkRec& acc, uint32_t& active_mask) {
+  RL_FN void group_contacts(const M3& Rwb, const SV& Vg, const GroupFetch& gf, LinkRec& acc, uint32_t& active_mask) {
     const float dt = u.dt;
     const int g = sub + SUB * IT;
     const int gi = g <= CL ? g : CL;
@@ -631,11 +646,11 @@ struct EnvLane {
     // the maximum over the wavefront of the touching-slot count and the code exists once; measured 3.5 us SLOWER on A1 Rough,
     // 56.6 vs 53.0 us in one gpurun call: the select chain per trip and the ballot per trip cost more than the skipped copies)
     auto one_slot = [&](const int s, const float rad_s, const V3 cb_s, const float phi_s, const V3 nw_s) __attribute__((always_inline)) {
-      Contact c = contact_from_phi(C, Rwb, V0, qd, gi, s, rad_s, cb_s, phi_s, nw_s);
+      Contact c = contact_from_phi(Rwb, Vg, gi, s, rad_s, cb_s, phi_s, nw_s);
       if (c.act) {
         active_mask |= 1u << (gi * SPL + s);
-        if (STASH && gi == stash_group()) {  // keep the contact for the sensor pass
-          float* st = ctx.lane_scratch() + (LS::CT + s * CONTACT_WORDS) * LSS;
+        if (STASH) {  // keep the contact for the sensor pass
+          float* st = ctx.lane_scratch() + (LS::CT + (IT * SPL + s) * CONTACT_WORDS) * LSS;
           st[0 * LSS] = c.x.x; st[1 * LSS] = c.x.y; st[2 * LSS] = c.x.z; st[3 * LSS] = c.n.x; st[4 * LSS] = c.n.y; st[5 * LSS] = c.n.z;
           st[6 * LSS] = c.bias; st[7 * LSS] = c.dn; st[8 * LSS] = c.dt;
         }
@@ -701,7 +716,7 @@ struct EnvLane {
 
   // rigid record of the limb link this lane owns in iteration IT (link sub + SUB * IT - 1, if the limb has it)
   template <int IT>
-  RL_FN void link_rigid(const ChainTP& C, const SV (&Vl)[CL], const SV (&al)[CL], LinkRec& rec) const {
+  RL_FN SV link_rigid(const ChainTP& C, const SV V0, const SV (&Vl)[CL], const SV (&al)[CL], LinkRec& rec) const {
     const int l = sub + SUB * IT - 1;
     const bool has = l >= 0 && l < CL;
     // the link's frame / velocity / bias acceleration as a 0-1 weighted blend over the links an owner of this iteration can
@@ -724,6 +739,20 @@ struct EnvLane {
     const V3 cb = pm + mul(Rm, V3{LF(li + 1), LF(li + 2), LF(li + 3)});
     const SI Im = make_si(mass, cb, rotate(Rm, S3{LF(li + 4), LF(li + 5), LF(li + 6), LF(li + 7), LF(li + 8), LF(li + 9)}));
     add_rigid(rec, Im, Vm, am, SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
+    return has ? Vm : V0;  // twist of the link the lane's spheres of this iteration ride on (group 0: the base link)
+  }
+  // the same blend for a per-joint array of twists (the new link twists of the outward pass)
+  template <int IT>
+  RL_FN SV pick_twist(const SV V0, const SV (&Vl)[CL]) const {
+    const int l = sub + SUB * IT - 1;
+    SV Vm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < CL; ++j) {
+      if (j < SUB * IT - 1 || j > SUB * IT + SUB - 2) continue;
+      const float w = l == j ? 1.f : 0.f;
+      Vm.a += w * Vl[j].a; Vm.l += w * Vl[j].l;
+    }
+    return (l >= 0 && l < CL) ? Vm : V0;
   }
 
   RL_FN void fetch_all(const ChainTP& C, const M3& Rwb, uint32_t slot_valid, GroupFetch (&gf)[NIT], bool (&fetched)[NIT]) {
@@ -755,9 +784,10 @@ struct EnvLane {
       const SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
       float nu0[NB], qdn[JX];
       uint32_t active_mask = 0;
-      aba_solve(C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, gf, fetched, nu0, qdn, active_mask);
+      SV Vnew[NIT];
+      aba_solve(C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, gf, fetched, nu0, qdn, active_mask, Vnew);
       V3 fown[MAXOWN];
-      sensor_forces(C, Rwb, V0, nu0, qdn, active_mask, fown);
+      sensor_forces(C, Rwb, V0, nu0, qdn, active_mask, Vnew, fown);
       integrate(Rwb, V0, nu0, qdn);
       if (s + 1 < n) {
         RL_PHASE(2, "sub.actuators+kinematics");
@@ -772,7 +802,7 @@ struct EnvLane {
 
   RL_FN void aba_solve(const ChainTP& C, const M3& Rwb, const SV V0, const SV a0, const float (&tau_e)[JX], const float (&pd_diag)[JX],
                        const float (&pd_rhs)[JX], const GroupFetch (&gf)[NIT], const bool (&fetched)[NIT], float (&nu0)[NB], float (&qdn)[JX],
-                       uint32_t& active_mask) {
+                       uint32_t& active_mask, SV (&Vnew)[NIT]) {
     const float dt = u.dt;
     // ---- link velocities / bias accelerations (every sub-lane: cheap), rigid record of the owned link(s)
     RL_PHASE(4, "sub.link_records");
@@ -790,17 +820,18 @@ struct EnvLane {
       }
     }
     LinkRec rec[NIT];
+    SV Vold[NIT];
     static_for<0, NIT>([&](auto it) {
 #pragma unroll
       for (int i = 0; i < B6::size; ++i) rec[it.value].A[i] = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) rec[it.value].r[i] = 0.f;
-      link_rigid<it.value>(C, Vl, al, rec[it.value]);
+      Vold[it.value] = link_rigid<it.value>(C, V0, Vl, al, rec[it.value]);
     });
     // ---- contacts, stage B
     RL_PHASE(5, "sub.contact_pass1");
     static_for<0, NIT>([&](auto it) {
-      if (fetched[it.value]) group_contacts<it.value>(C, Rwb, V0, gf[it.value], rec[it.value], active_mask);
+      if (fetched[it.value]) group_contacts<it.value>(Rwb, Vold[it.value], gf[it.value], rec[it.value], active_mask);
     });
     // ---- articulated-body recursion, tip -> base (every sub-lane; the records come from their owners)
     RL_PHASE(9, "sub.aba");
@@ -902,6 +933,10 @@ struct EnvLane {
     RL_PHASE(12, "sub.back_subst");
     {
       float vp[6] = {nu0[0], nu0[1], nu0[2], nu0[3], nu0[4], nu0[5]};
+      // new link twists for the contact sensor: built from the velocity-limited joint velocities (the limit is applied to the
+      // solution, then the forces are evaluated - oracle/physics.py), while the recursion itself runs on the solution
+      SV vc{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
+      SV Vn[CL];
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
         float t = ui[j];
@@ -910,7 +945,12 @@ struct EnvLane {
         qdn[j] = t;
         vp[0] += Sj[j].a.x * t; vp[1] += Sj[j].a.y * t; vp[2] += Sj[j].a.z * t;
         vp[3] += Sj[j].l.x * t; vp[4] += Sj[j].l.y * t; vp[5] += Sj[j].l.z * t;
+        const float tc = clampf(t, -L.vel_limit[j], L.vel_limit[j]);
+        vc.a += tc * Sj[j].a; vc.l += tc * Sj[j].l;
+        Vn[j] = vc;
       }
+      const SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
+      static_for<0, NIT>([&](auto it) { Vnew[it.value] = pick_twist<it.value>(V0n, Vn); });
     }
   }
 
@@ -1037,7 +1077,18 @@ struct EnvLane {
       }
       RL_PHASE(5, "sub.contact_pass1");
       const uint32_t before = active_mask;
-      if (fetched) group_contacts<it.value>(C, Rwb, V0, gf, rec, active_mask);
+      if (fetched) {
+        SV Vg = V0;  // twist of the link the group's spheres ride on: limb link l, or the trunk link of the lane's share
+        if (has) {
+          const float* w = va_words(l);
+          Vg = SV{{w[0 * LBS], w[1 * LBS], w[2 * LBS]}, {w[3 * LBS], w[4 * LBS], w[5 * LBS]}};
+        } else {
+#pragma unroll
+          for (int i = 0; i < NW; ++i)
+            if (L.grp0_depth == i + 1) Vg = Vw[i];
+        }
+        group_contacts<it.value>(Rwb, Vg, gf, rec, active_mask);
+      }
       if (has) {
         float* w = rec_words(g);
 #pragma unroll
@@ -1147,9 +1198,13 @@ struct EnvLane {
       for (int i = 0; i < 6; ++i) nu0[i] = n6[i];
     }
     RL_PHASE(12, "sub.back_subst");
+    SV Vnew[NIT];
     {
       float vp[6] = {nu0[0], nu0[1], nu0[2], nu0[3], nu0[4], nu0[5]};
       float va[6] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5]};  // velocity of the link this limb hangs off
+      // the contact sensor sees the velocity-LIMITED joint velocities (limit applied to the solution, then the forces -
+      // oracle/physics.py): a second running twist built from the clamped values, kept per link for the sensor pass
+      SV vc{{vp[0], vp[1], vp[2]}, {vp[3], vp[4], vp[5]}}, vca = vc;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
         float t = uiw[i];
@@ -1159,11 +1214,15 @@ struct EnvLane {
         nu0[6 + i] = t;
         vp[0] += Sw[i].a.x * t; vp[1] += Sw[i].a.y * t; vp[2] += Sw[i].a.z * t;
         vp[3] += Sw[i].l.x * t; vp[4] += Sw[i].l.y * t; vp[5] += Sw[i].l.z * t;
+        const float tc = clampf(t, -L.vel_limit[CL + i], L.vel_limit[CL + i]);
+        vc.a += tc * Sw[i].a; vc.l += tc * Sw[i].l;
         if (L.attach == i + 1) {
 #pragma unroll
           for (int r = 0; r < 6; ++r) va[r] = vp[r];
+          vca = vc;
         }
       }
+      vc = vca;
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
         const float* o = va_words(j);
@@ -1175,9 +1234,22 @@ struct EnvLane {
         const V3 lx = cross(C.p(j), ax);
         va[0] += ax.x * t; va[1] += ax.y * t; va[2] += ax.z * t;
         va[3] += lx.x * t; va[4] += lx.y * t; va[5] += lx.z * t;
+        const float tc = clampf(t, -L.vel_limit[j], L.vel_limit[j]);
+        vc.a += tc * ax; vc.l += tc * lx;
+        float* nw = rec_words(j + 1);  // (the record of link j was consumed by the elimination)
+        nw[0 * LBS] = vc.a.x; nw[1 * LBS] = vc.a.y; nw[2 * LBS] = vc.a.z; nw[3 * LBS] = vc.l.x; nw[4 * LBS] = vc.l.y; nw[5 * LBS] = vc.l.z;
       }
+      ctx.group_sync();
+      static_for<0, NIT>([&](auto it) {
+        const int g = sub + SUB * it.value;
+        Vnew[it.value] = vca;  // group 0: the trunk link the limb hangs off (grp0_depth == attach)
+        if (g >= 1 && g <= CL) {
+          const float* w = rec_words(g);
+          Vnew[it.value] = SV{{w[0 * LBS], w[1 * LBS], w[2 * LBS]}, {w[3 * LBS], w[4 * LBS], w[5 * LBS]}};
+        }
+      });
     }
-    sensor_and_integrate(C, Rwb, V0, nu0, qdn, active_mask);
+    sensor_and_integrate(C, Rwb, V0, nu0, qdn, active_mask, Vnew);
   }
 
   // 6 x 6 SPD solve (Cholesky) of the base system
@@ -1216,23 +1288,25 @@ struct EnvLane {
   }
 
   // The tail of a substep (both formulations): contact-sensor forces with the new velocities, integration, sensor timers.
-  RL_FN void sensor_and_integrate(const ChainTP& C, const M3& Rwb, const SV V0, const float (&nu0)[NB], float (&qdn)[JX], const uint32_t active_mask) {
+  RL_FN void sensor_and_integrate(const ChainTP& C, const M3& Rwb, const SV V0, const float (&nu0)[NB], float (&qdn)[JX], const uint32_t active_mask,
+                                  const SV (&Vnew)[NIT]) {
     V3 fown[MAXOWN];
-    sensor_forces(C, Rwb, V0, nu0, qdn, active_mask, fown);
+    sensor_forces(C, Rwb, V0, nu0, qdn, active_mask, Vnew, fown);
     sensor_timers(fown);
     integrate(Rwb, V0, nu0, qdn);
   }
 
-  // net contact force per owned body slot with the NEW velocities (world frame): what was actually applied
-  RL_FN void sensor_forces(const ChainTP& C, const M3& Rwb, const SV V0, const float (&nu0)[NB], float (&qdn)[JX], const uint32_t active_mask, V3 (&fown)[MAXOWN]) {
+  // net contact force per owned body slot with the NEW velocities (world frame): what was actually applied.
+  // `Vnew[it]`: new twist of the link of the lane's group in iteration it (16-lane mapping; unused with one lane per limb)
+  RL_FN void sensor_forces(const ChainTP& C, const M3& Rwb, const SV V0, const float (&nu0)[NB], float (&qdn)[JX], const uint32_t active_mask,
+                           const SV (&Vnew)[NIT], V3 (&fown)[MAXOWN]) {
 #pragma unroll
     for (int j = 0; j < JX; ++j) qdn[j] = clampf(qdn[j], -L.vel_limit[j], L.vel_limit[j]);
     RL_PHASE(13, "sub.contact_pass2");
-    SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) fown[i] = {0.f, 0.f, 0.f};
-    auto apply = [&](const Contact& c, int g, int slot) __attribute__((always_inline)) {
-      V3 uu = point_velocity<TP, ChainTP>(C, wdepth(g), g, c.x, V0n, qdn);
+    auto apply = [&](const Contact& c, const SV& Vg, int slot) __attribute__((always_inline)) {
+      V3 uu = Vg.l + cross(Vg.a, c.x);
       float un = dot(c.n, uu);
       V3 Fb = (c.bias - (c.dn - c.dt) * un) * c.n - c.dt * uu;
       V3 Fw = mul(Rwb, Fb);
@@ -1240,61 +1314,41 @@ struct EnvLane {
       for (int i = 0; i < MAXOWN; ++i)
         if (own[i] == slot) fown[i] += Fw;
     };
-    if constexpr (ABA && STASH) {
-      // static structure: the SPL slots of every link group the lane evaluates, masked by the pass-1 activity bits - the
-      // stash words of the distal group are read in one batch (no per-contact loop with its LDS round trips)
+    if constexpr (STASH) {
+      // every contact of pass 1 sits in the lane's stash: SPL slots per link group, masked by the activity bits, read in one batch
       static_for<0, NIT>([&](auto it) {
         const int g = sub + SUB * it.value;
         const int gi = g <= CL ? g : CL;
         const uint32_t bits = g <= CL ? (active_mask >> (gi * SPL)) & ((1u << SPL) - 1u) : 0u;
         if (!ctx.any(bits != 0u)) return;
-        if (gi == stash_group()) {
-          Contact c[SPL];
-          int slot[SPL];
+        Contact c[SPL];
+        int slot[SPL];
 #pragma unroll
-          for (int s2 = 0; s2 < SPL; ++s2) {
-            const float* st = ctx.lane_scratch() + (LS::CT + s2 * CONTACT_WORDS) * LSS;
-            c[s2].act = (bits >> s2) & 1u;
-            c[s2].x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
-            c[s2].n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
-            c[s2].bias = st[6 * LSS]; c[s2].dn = st[7 * LSS]; c[s2].dt = st[8 * LSS];
-            slot[s2] = L.sph_slot[gi][s2];
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < SPL; ++s2)
-            if (c[s2].act) apply(c[s2], gi, slot[s2]);
-        } else {  // not stashed (the base-link share of a lane that also carries a distal group): evaluate again
-#pragma unroll 1
-          for (uint32_t m = bits; m != 0; m &= m - 1) {
-            const int s2 = __builtin_ctz(m);
-            float rad;
-            V3 cb, cw;
-            sphere_center(C, Rwb, gi, s2, rad, cb, cw);
-            Contact c = contact_from_patch(C, Rwb, V0, qd, gi, s2, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
-            if (c.act) apply(c, gi, L.sph_slot[gi][s2]);
-          }
+        for (int s2 = 0; s2 < SPL; ++s2) {
+          const float* st = ctx.lane_scratch() + (LS::CT + (it.value * SPL + s2) * CONTACT_WORDS) * LSS;
+          c[s2].act = (bits >> s2) & 1u;
+          c[s2].x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
+          c[s2].n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
+          c[s2].bias = st[6 * LSS]; c[s2].dn = st[7 * LSS]; c[s2].dt = st[8 * LSS];
+          slot[s2] = L.sph_slot[gi][s2];
         }
+#pragma unroll
+        for (int s2 = 0; s2 < SPL; ++s2)
+          if (c[s2].act) apply(c[s2], Vnew[it.value], slot[s2]);
       });
     } else {
-      // pass 2: only the spheres that were active in pass 1 are re-evaluated (same state -> same contact)
+      // one lane per limb (RL_ENV_SUB=1 / the CPU emulator's default): no stash - the spheres that were active in pass 1 are
+      // evaluated again (same state -> same contact), twists from the generalised velocities
+      const SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
 #pragma unroll 1
       for (uint32_t m = active_mask; m != 0; m &= m - 1) {
         const int ci = __builtin_ctz(m);
         const int g = ci / SPL, s2 = ci - g * SPL;
-        Contact c;
-        if (STASH && g == stash_group()) {
-          const float* st = ctx.lane_scratch() + (LS::CT + s2 * CONTACT_WORDS) * LSS;
-          c.act = true;
-          c.x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
-          c.n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
-          c.bias = st[6 * LSS]; c.dn = st[7 * LSS]; c.dt = st[8 * LSS];
-        } else {
-          float rad;
-          V3 cb, cw;
-          sphere_center(C, Rwb, g, s2, rad, cb, cw);
-          c = contact_from_patch(C, Rwb, V0, qd, g, s2, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
-        }
-        if (c.act) apply(c, g, L.sph_slot[g][s2]);
+        float rad;
+        V3 cb, cw;
+        sphere_center(C, Rwb, g, s2, rad, cb, cw);
+        const Contact c = contact_from_patch(C, Rwb, V0, qd, g, s2, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
+        if (c.act) apply(c, link_twist(C, g, V0n, qdn), L.sph_slot[g][s2]);
       }
     }
     RL_PHASE(14, "sub.sensor+integrate");
