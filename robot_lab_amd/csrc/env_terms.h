@@ -509,7 +509,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       const uint64_t rel_mask = T.rew_rel_mask;
       const bool any_rel = ctx.uniform_i((int)(rel_mask != 0ull)) != 0;
       ChainTP C = this->new_chain();
-      if (any_rel) chain_kinematics<TP>(L, q, C);
+      // (trunk + limbs instance: the chain words in LDS already hold the kinematics of the final joint positions, step() stage 3)
+      if (any_rel && NW == 0) chain_kinematics<TP>(L, q, C);
 #pragma unroll
       for (int i = 0; i < Base::MAXOWN; ++i) {
         const int s = this->own[i];
@@ -567,13 +568,18 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 
   // ---------------------------------------------------------------- observations [UPSTREAM B2 / B6]
   // pose of the height scanner: the root link on the quadrupeds, the torso on G1 (rides on trunk link scan_depth)
-  RL_FN void scanner_pose(float& cy, float& sy, V3& scan_p) {
+  // (`chain_fresh`: the chain words in LDS hold the kinematics of the current joint positions - no env of the wavefront was reset
+  // since step() refreshed them)
+  RL_FN void scanner_pose(float& cy, float& sy, V3& scan_p, bool chain_fresh) {
     if (NW == 0) {
       cy = yaw_c; sy = yaw_s; scan_p = pos;
       return;
     }
     ChainTP C = this->new_chain();
-    chain_kinematics<TP>(L, q, C);
+    if (!chain_fresh) {
+      chain_kinematics<TP>(L, q, C);
+      ctx.group_sync();
+    }
     M3 Rf;
     V3 pf;
     trunk_frame<TP>(C, T.scan_depth, Rf, pf);
@@ -687,7 +693,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
   }
 
-  RL_FN void observations() {
+  RL_FN void observations(bool chain_fresh) {
     derive();
     // the height-scan loads go out first and are consumed by the group(s) that carry the scan, after the feature vector and the
     // non-scan columns.  (Issuing them before the reward stage was tried: the 72 patch registers do not survive it - the compiler
@@ -695,7 +701,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     ScanPatches sp;
     float cy, sy;
     V3 scan_p;
-    scanner_pose(cy, sy, scan_p);
+    scanner_pose(cy, sy, scan_p, chain_fresh);
     scan_fetch(cy, sy, scan_p, sp);
     // the env's feature vector -> LDS (env_tables.h FEAT_*): lane 0 the base block, the first sub-lane of a limb its joints
     float* F = ctx.feat_stage();
@@ -779,6 +785,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // 3 counters
     ep_len += 1;
     derive();
+    if constexpr (NW > 0) {  // kinematics of the final joint positions, once, for the reward stage (feet) and the scanner pose
+      ChainTP Cf = this->new_chain();
+      chain_kinematics<TP>(L, q, Cf);
+      ctx.group_sync();
+    }
 
     // 4 terminations (velocity_env_cfg.py:648-664)
     bool t_timeout = T.term_time_out && ep_len >= (long long)T.max_episode_length;
@@ -873,7 +884,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // 9 observations
     RL_PHASE(20, "observations");
 #ifndef RL_ABL_NO_OBS
-    observations();
+    observations(!ctx.any(terminated || time_out));
 #endif
     RL_PHASE(23, "store");
     this->store();
@@ -888,7 +899,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #pragma unroll
     for (int j = 0; j < JX; ++j) prev_act[j] = act[j];
     if (S.reset_mask == nullptr || S.reset_mask[e]) reset_env(false);
-    observations();
+    observations(false);
     this->store();
     store_task();
   }

@@ -3,9 +3,22 @@
 import argparse
 
 
+import os
+
+
 class _App:
+    """`simulation_app`: the reference's scripts loop `while simulation_app.is_running()` (zero_agent.py:63, play.py:242) until the
+    viewer is closed.  Headless there is nobody to close it: RL_SHIM_MAX_STEPS=<n> ends the loop after n polls (tests, benchmarks);
+    unset, it runs until interrupted, as upstream does headless."""
+
+    def __init__(self):
+        self._left = int(os.environ["RL_SHIM_MAX_STEPS"]) if os.environ.get("RL_SHIM_MAX_STEPS") else None
+
     def is_running(self):
-        return True
+        if self._left is None:
+            return True
+        self._left -= 1
+        return self._left >= 0
 
     def close(self):
         pass

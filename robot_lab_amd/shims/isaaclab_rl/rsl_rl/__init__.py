@@ -140,6 +140,64 @@ class RslRlVecEnvWrapper:
             return obs
 
 
+class _PolicyExporter:
+    """[UPSTREAM isaaclab_rl.rsl_rl.exporter] what `play.py:209-233` exports: normaliser followed by the actor MLP (the
+    feed-forward policies of the reference's agent cfgs; recurrent policies are not used by any robot_lab task)."""
+
+    @staticmethod
+    def build(policy, normalizer=None):
+        import copy
+
+        import torch
+
+        actor = getattr(policy, "actor", None)
+        if actor is None:
+            actor = getattr(policy, "student", None)
+        if actor is None and isinstance(policy, torch.nn.Module):
+            actor = policy
+        if actor is None:
+            raise TypeError("export_policy_as_*: the policy has no `actor` / `student` module")
+
+        class Exported(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.normalizer = copy.deepcopy(normalizer) if normalizer is not None else torch.nn.Identity()
+                self.actor = copy.deepcopy(actor)
+
+            def forward(self, x):
+                return self.actor(self.normalizer(x))
+
+        return Exported().to("cpu").eval()
+
+
+def export_policy_as_jit(policy, normalizer=None, path: str = ".", filename: str = "policy.pt"):
+    """TorchScript export of the inference policy (`scripts/reinforcement_learning/rsl_rl/play.py:232`)."""
+    import os
+
+    import torch
+
+    os.makedirs(path, exist_ok=True)
+    module = _PolicyExporter.build(policy, normalizer)
+    torch.jit.script(module).save(os.path.join(path, filename))
+
+
+def export_policy_as_onnx(policy, normalizer=None, path: str = ".", filename: str = "policy.onnx", verbose: bool = False):
+    """ONNX export of the inference policy (`play.py:233`); needs the `onnx` package, as upstream does."""
+    import os
+
+    import torch
+
+    try:
+        import onnx  # noqa: F401
+    except ImportError as e:
+        raise ImportError("export_policy_as_onnx needs the `onnx` package (torch.onnx.export); export_policy_as_jit does not") from e
+    os.makedirs(path, exist_ok=True)
+    module = _PolicyExporter.build(policy, normalizer)
+    first = next(p for p in module.actor.parameters() if p.dim() == 2)
+    torch.onnx.export(module, torch.zeros(1, first.shape[1]), os.path.join(path, filename), export_params=True, opset_version=11,
+                      verbose=verbose, input_names=["obs"], output_names=["actions"], dynamic_axes={}, dynamo=False)
+
+
 def __getattr__(name):
     if name.startswith("__") or not name[:1].isupper():
         raise AttributeError(name)

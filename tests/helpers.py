@@ -156,14 +156,14 @@ def teacher_forced_check(ora, state, action, got, n_twins=3, gain=32.0, base=1e-
     w = np.abs(np.array([ora.desc.task.rewards[i].weight for i in range(ora.desc.task.n_rewards)], dtype=np.float64))
     err_t = np.abs(np.asarray(got["reward_terms"], dtype=np.float64) - want["reward_terms"])
     # (absolute floor base * 1e-2 = 1e-7 reward units: terms with tiny weights such as joint_acc_l2, w = 2.5e-7 on (rad/s^2)^2)
-    # (1e-3 relative: terms like joint_acc_l2 square a finite difference of the velocities, (qd+ - qd) / dt, i.e. amplify the
-    # velocity error 2 / dt = 400 times before squaring)
-    tol_t = base * (w[:, None] + 1e-2) + 1e-3 * np.abs(want["reward_terms"]) + gain * sens["reward_terms"]
+    # (5e-3 relative: terms like joint_acc_l2 square a finite difference of the velocities, (qd+ - qd) / dt, i.e. amplify the
+    # velocity error 2 / dt = 400 times before squaring; a wrong term, mask or weight is an O(1) relative error)
+    tol_t = base * (w[:, None] + 1e-2) + 5e-3 * np.abs(want["reward_terms"]) + gain * sens["reward_terms"]
     bt = np.argwhere((err_t > tol_t) & ok[None])
     if len(bt):
         bad["reward_terms"] = [(int(t), int(i), float(err_t[t, i]), float(tol_t[t, i])) for t, i in bt[:8]]
     err_r = np.abs(np.asarray(got["reward"], dtype=np.float64) - want["reward"])
-    tol_r = base * np.maximum(w.sum(), 1.0) * ora.step_dt + base * np.abs(want["reward"]) + gain * sens["reward"]
+    tol_r = base * np.maximum(w.sum(), 1.0) * ora.step_dt + 5e-3 * np.abs(want["reward_terms"]).sum(axis=0) + gain * sens["reward"]
     br = np.nonzero((err_r > tol_r) & ok)[0]
     if len(br):
         bad["reward"] = [(int(i), float(err_r[i]), float(tol_r[i])) for i in br[:8]]

@@ -30,7 +30,7 @@ def _load(robot):
     return g, desc, ora
 
 
-@pytest.mark.parametrize("robot", ["a1", "go2", "g1", "a1_handstand", "tita"])
+@pytest.mark.parametrize("robot", ["a1", "go2", "go2w", "g1", "a1_handstand", "tita"])
 def test_reward_terms_match_reference_functions(robot):
     g, desc, ora = _load(robot)
     hist = np.linalg.norm(ora.force_hist, axis=-1).max(axis=1)
@@ -46,7 +46,9 @@ def test_reward_terms_match_reference_functions(robot):
                  # config/others/unitree_a1_handstand/env/rewards.py:18-59
                  "a1_handstand": ("handstand_feet_height_exp", "handstand_feet_on_air", "handstand_feet_air_time", "handstand_orientation_l2"),
                  # rewards.py:616-644 (ray caster branch), 132-153, 439-461
-                 "tita": ("base_height_l2", "wheel_vel_penalty", "feet_distance_y_exp", "feet_slide", "contact_forces")}
+                 "tita": ("base_height_l2", "wheel_vel_penalty", "feet_distance_y_exp", "feet_slide", "contact_forces"),
+                 # wheeled/unitree_go2w/rough_env_cfg.py:149-171: its own term list, incl. the wheel-joint acceleration term
+                 "go2w": ("undesired_contacts", "contact_forces", "joint_mirror", "joint_acc_wheel_l2", "joint_pos_penalty")}
     for name in exercised.get(robot, ("undesired_contacts", "contact_forces", "feet_height_body", "joint_mirror")):
         assert np.abs(g["term_values"][names.index(name)]).max() > 0, name
 
@@ -71,3 +73,31 @@ def test_reset_root_state_uniform(robot):
     quat = sp.quat_mul(np.tile(arr(m.default_root_quat).astype(np.float64), (len(ps), 1)), sp.quat_from_euler_xyz(ps[:, 3], ps[:, 4], ps[:, 5]))
     np.testing.assert_allclose(np.concatenate([pos, quat], -1), g["reset_pose"], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(vs, g["reset_vel"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("robot", ["a1", "go2", "go2w", "g1", "tita"])
+def test_observation_rows_match_reference_cfg(robot):
+    """The two observation groups against rows built from the REFERENCE's ObservationsCfg (VEL/velocity_env_cfg.py:134-254 and the
+    robot's overrides) term by term in declaration order - its own `joint_pos_rel_without_wheel` (VEL/mdp/observations.py:17-27)
+    where the cfg names it (Go2W, Tita), clip, scale, concatenation [UPSTREAM B2].  Noise off (a random draw: the Philox tests)."""
+    g, desc, ora = _load(robot)
+    desc.task.policy_corrupt = 0
+    desc.task.critic_corrupt = 0
+    pol, cri = ora.compute_observations()
+    np.testing.assert_allclose(pol, g["obs_policy"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(cri, g["obs_critic"], rtol=1e-6, atol=1e-7)
+    # the compiled descriptor lists the same terms in the same order with the same widths
+    from robot_lab_amd.desc import OBS_KINDS
+
+    for grp, terms, n in (("policy", desc.task.policy, desc.task.n_policy), ("critic", desc.task.critic, desc.task.n_critic)):
+        widths = [int(w) for w in g[f"obs_{grp}_widths"]]
+        assert n == len(widths)
+        D, scan = desc.model.num_dof, desc.task.scan_nx * desc.task.scan_ny
+        mine = [scan if OBS_KINDS[terms[i].kind] == "height_scan" else (D if "joint" in OBS_KINDS[terms[i].kind] or OBS_KINDS[terms[i].kind] == "last_action" else 3) for i in range(n)]
+        assert mine == widths, (grp, [str(x) for x in g[f"obs_{grp}_terms"]])
+    if robot in ("go2w", "tita"):  # the wheel joints' columns of joint_pos are zero, the others are not
+        names = [str(x) for x in g["obs_policy_terms"]]
+        off = int(np.sum(g["obs_policy_widths"][: names.index("joint_pos")]))
+        wheels = [i for i in range(desc.model.num_dof) if (desc.task.wheel_joint_mask >> i) & 1]
+        assert wheels and np.all(pol[:, [off + i for i in wheels]] == 0)
+        assert np.abs(pol[:, off:off + desc.model.num_dof]).max() > 0

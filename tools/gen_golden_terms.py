@@ -114,6 +114,43 @@ def resolve(params, desc):
     return out
 
 
+def observation_rows(cfg, env, ora, desc):
+    """Rows of the two observation groups built the way ObservationManager.compute does [UPSTREAM B2] - terms in the
+    DECLARATION ORDER of the reference's ObservationsCfg (VEL/velocity_env_cfg.py:134-254 and the robot's overrides), each
+    through its own function (the reference's joint_pos_rel_without_wheel where the cfg names it; the shim's restatement of the
+    upstream functions otherwise), then clip, then scale, concatenated.  Noise is left out (it is a random draw: pinned
+    separately by the Philox tests); what the fixture pins is order, widths, clip, scale and the reference-owned function."""
+    from isaaclab.envs import mdp as up
+
+    R = mu.matrix_from_quat(T(ora.st["root_quat"])) if hasattr(mu, "matrix_from_quat") else None
+    # height scanner data for the upstream height_scan(): ray hits of the yaw-aligned grid under the scanner body
+    hs = ora.height_scan() + desc.task.scan_offset          # = sensor z - hit z
+    sensor_z = T(ora.st["root_pos"][:, 2:3]) if desc.task.scan_body == 0 else None
+    out = {}
+    for gname in ("policy", "critic"):
+        group = getattr(cfg.observations, gname)
+        rows, names, widths = [], [], []
+        for name, term in vars(group).items():
+            if term is None or not hasattr(term, "func"):
+                continue
+            params = resolve(term.params, desc)
+            if term.func is up.height_scan:
+                v = T(hs) - 0.5  # height_scan(env, sensor_cfg, offset=0.5) = sensor z - hit z - offset [UPSTREAM B6]
+            else:
+                v = term.func(env, **params).to(torch.float64)
+            if term.clip is not None:
+                v = v.clip(term.clip[0], term.clip[1])
+            if term.scale is not None:
+                v = v * term.scale
+            rows.append(v.numpy())
+            names.append(name)
+            widths.append(v.shape[1])
+        out[f"obs_{gname}"] = np.concatenate(rows, -1)
+        out[f"obs_{gname}_terms"] = np.array(names)
+        out[f"obs_{gname}_widths"] = np.array(widths)
+    return out
+
+
 def snapshot(ora):
     keys = ["root_pos", "root_quat", "root_lin_vel", "root_ang_vel", "q", "qd", "base_com", "root_com"]
     snap = {"st_" + k: ora.st[k] for k in keys}
@@ -125,8 +162,11 @@ def snapshot(ora):
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
-    todo = [a for a in sys.argv[1:]] or ["A1", "Go2", "G1", "A1_HandStand", "Tita"]
+    todo = [a for a in sys.argv[1:]] or ["A1", "Go2", "G1", "A1_HandStand", "Tita", "Go2W"]
     for robot, seed, task in (("A1", 3, None), ("Go2", 4, None), ("G1", 6, None),
+                              # wheeled: its own term list (wheeled/unitree_go2w/rough_env_cfg.py:149-171) and the reference-owned
+                              # observation function joint_pos_rel_without_wheel (VEL/mdp/observations.py:17-27)
+                              ("Go2W", 9, "RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0"),
                               # the hand-stand terms (config/others/unitree_a1_handstand/env/rewards.py) and, on rough terrain,
                               # base_height_l2 with its ray caster, wheel_vel_penalty, feet_distance_y_exp
                               ("A1_HandStand", 7, "RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0"),
@@ -190,8 +230,9 @@ def main():
         env.scene.terrain = None
         rp = cfg.events.randomize_reset_base.params
         ref_events.reset_root_state_uniform(env, torch.arange(N), rp["pose_range"], rp["velocity_range"])
+        obs = observation_rows(cfg, env, ora, desc)
         np.savez_compressed(
-            os.path.join(out_dir, f"terms_{robot.lower()}.npz"), seed=seed, N=N, task=task,
+            os.path.join(out_dir, f"terms_{robot.lower()}.npz"), seed=seed, N=N, task=task, **obs,
             term_names=np.array(list(expected.keys())), term_values=np.stack(list(expected.values())),
             cmd_in=cmd_in.numpy(), cmd_out=obj.vel_command_b.numpy(),
             reset_pose_samples=samples[0].numpy(), reset_vel_samples=samples[1].numpy(), reset_pose=written["pose"], reset_vel=written["vel"],
