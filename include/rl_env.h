@@ -222,6 +222,15 @@ typedef struct rl_task_desc {
   float reset_pose[6][2], reset_vel[6][2];
   float push_interval[2], push_vel[6][2];
   int32_t base_body;      /* body addressed by the mass-add / COM / external-wrench events (base_link_name; G1: torso_link) */
+  /* curriculum: command_levels_lin_vel / command_levels_ang_vel (VEL/mdp/curriculums.py:21-94; velocity_env_cfg.py:673-690).
+   * The command ranges of lin_vel_x / lin_vel_y (resp. ang_vel_z) start at range * mult[0] and, whenever the step counter is
+   * a multiple of the episode length, widen by 0.1 on either side (clamped to range * mult[1]) if the mean episode sum of
+   * reward term `*_term` over the envs reset in that step, divided by the episode length in seconds, exceeds 0.8 x its weight.
+   * Deviation from the reference: the widened range takes effect from the NEXT step (there it already applies to the commands
+   * resampled by that very reset): the decision needs a reduction over all envs of the step, i.e. the end of the launch. */
+  int32_t cur_cmd_lin, cur_cmd_ang;            /* term enabled */
+  int32_t cur_cmd_lin_term, cur_cmd_ang_term;  /* reward term index (reward_term_name) */
+  float cur_cmd_lin_mult[2], cur_cmd_ang_mult[2]; /* range_multiplier */
 } rl_task_desc;
 
 typedef struct rl_env_desc {
@@ -261,6 +270,9 @@ enum rl_buffer {
   RL_BUF_GAINS = 21,       /* float [N, 2, D] per-env actuator stiffness / damping (randomize_actuator_gains, velocity_env_cfg.py:337-347) */
   RL_BUF_OBS_POLICY_RING = 22, /* float [2, Npad, obs_policy_dim] both observation buffers; step()/reset() alternate between them */
   RL_BUF_OBS_CRITIC_RING = 23, /* float [2, Npad, obs_critic_dim] */
+  RL_BUF_CMD_LEVELS = 24,  /* float [16]: current command ranges of the command_levels_* curricula - lin_vel_x lo/hi, lin_vel_y lo/hi,
+                              ang_vel_z lo/hi (what the reference logs as Curriculum/command_levels_lin_vel = [1], _ang_vel = [5]),
+                              then the accumulators of the running decision (sum, count per term) */
   RL_BUF_COUNT
 };
 

@@ -144,6 +144,7 @@ struct TaskTab {  // everything that is not per limb
   int32_t max_episode_length;
   float cmd_range[4][2], cmd_resample[2], cmd_rel_standing, cmd_rel_heading, cmd_heading_stiffness, cmd_small_threshold;
   int32_t cmd_heading;
+  int32_t cur_lin, cur_ang, cur_lin_term, cur_ang_term;  // command_levels_* curricula (KState::cmd_levels holds the live ranges)
   int32_t n_policy, n_critic, policy_dim, critic_dim, policy_corrupt, critic_corrupt;
   ObsTab policy[MAX_OBS], critic[MAX_OBS];
   int32_t scan_nx, scan_ny;
@@ -251,6 +252,28 @@ RL_FN size_t lane_index(const Layout& ly, int e, int k, int f, int ept) {
 }
 RL_FN size_t env_index(const Layout& ly, int e, int f, int ept) { return ((size_t)(e / ept) * ly.NF_ENV + (size_t)f) * (size_t)ept + (size_t)(e % ept); }
 
+// layout of KState::cmd_levels / RL_BUF_CMD_LEVELS
+enum CmdLevels { CL_LIN_X = 0, CL_LIN_Y = 2, CL_ANG_Z = 4, CL_SUM_LIN = 8, CL_CNT_LIN = 9, CL_SUM_ANG = 10, CL_CNT_ANG = 11, CL_WORDS = 16 };
+struct CmdLevelParams {  // what the end-of-step decision needs (VEL/mdp/curriculums.py:21-94)
+  int32_t lin, ang;
+  float lin_weight, ang_weight, max_episode_length_s;
+  float final_x[2], final_y[2], final_z[2];
+};
+// the decision itself, run once after a step whose counter is a multiple of the episode length (one thread / the host)
+RL_FN void apply_cmd_levels(float* lv, const CmdLevelParams& P) {
+  if (P.lin && lv[CL_CNT_LIN] > 0.f && lv[CL_SUM_LIN] / lv[CL_CNT_LIN] / P.max_episode_length_s > 0.8f * P.lin_weight) {
+    lv[CL_LIN_X + 0] = fminf(fmaxf(lv[CL_LIN_X + 0] - 0.1f, P.final_x[0]), P.final_x[1]);
+    lv[CL_LIN_X + 1] = fminf(fmaxf(lv[CL_LIN_X + 1] + 0.1f, P.final_x[0]), P.final_x[1]);
+    lv[CL_LIN_Y + 0] = fminf(fmaxf(lv[CL_LIN_Y + 0] - 0.1f, P.final_y[0]), P.final_y[1]);
+    lv[CL_LIN_Y + 1] = fminf(fmaxf(lv[CL_LIN_Y + 1] + 0.1f, P.final_y[0]), P.final_y[1]);
+  }
+  if (P.ang && lv[CL_CNT_ANG] > 0.f && lv[CL_SUM_ANG] / lv[CL_CNT_ANG] / P.max_episode_length_s > 0.8f * P.ang_weight) {
+    lv[CL_ANG_Z + 0] = fminf(fmaxf(lv[CL_ANG_Z + 0] - 0.1f, P.final_z[0]), P.final_z[1]);
+    lv[CL_ANG_Z + 1] = fminf(fmaxf(lv[CL_ANG_Z + 1] + 0.1f, P.final_z[0]), P.final_z[1]);
+  }
+  lv[CL_SUM_LIN] = lv[CL_CNT_LIN] = lv[CL_SUM_ANG] = lv[CL_CNT_ANG] = 0.f;
+}
+
 struct KState {
   int32_t N;      // environments the caller sees
   int32_t Npad;   // simulated (multiple of ENVS_PER_WAVE)
@@ -281,6 +304,7 @@ struct KState {
   float* ro_rewards;               // [N] <- reward + gamma * V * time_out
   uint8_t* ro_dones;               // [N] <- terminated | time_out
   float ro_gamma;
+  float* cmd_levels;               // [16] live command ranges + decision accumulators of the command_levels_* curricula (CmdLevels)
   uint64_t seed;
   uint32_t step_counter;
   uint32_t table_bytes;  // bytes of the packed table image the env kernels stage into LDS (multiple of 16)

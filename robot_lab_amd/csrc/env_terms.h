@@ -94,9 +94,12 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 
   // UniformVelocityCommand._resample_command [UPSTREAM B7] + threshold (VEL/mdp/commands.py:43-47)
   RL_FN void resample_command(uint32_t stream, uint32_t idx) {
-    float vx = U(stream, idx + 0, T.cmd_range[0][0], T.cmd_range[0][1]);
-    float vy = U(stream, idx + 1, T.cmd_range[1][0], T.cmd_range[1][1]);
-    float wz = U(stream, idx + 2, T.cmd_range[2][0], T.cmd_range[2][1]);
+    // ranges: the table's, or the live ones of the command_levels_* curricula (VEL/mdp/curriculums.py:21-94)
+    const float* lv = S.cmd_levels;
+    const bool cl = T.cur_lin != 0, ca = T.cur_ang != 0;
+    float vx = U(stream, idx + 0, cl ? lv[CL_LIN_X] : T.cmd_range[0][0], cl ? lv[CL_LIN_X + 1] : T.cmd_range[0][1]);
+    float vy = U(stream, idx + 1, cl ? lv[CL_LIN_Y] : T.cmd_range[1][0], cl ? lv[CL_LIN_Y + 1] : T.cmd_range[1][1]);
+    float wz = U(stream, idx + 2, ca ? lv[CL_ANG_Z] : T.cmd_range[2][0], ca ? lv[CL_ANG_Z + 1] : T.cmd_range[2][1]);
     float hd = U(stream, idx + 3, T.cmd_range[3][0], T.cmd_range[3][1]);
     bool ih = U(stream, idx + 4, 0.f, 1.f) <= T.cmd_rel_heading;
     bool is = U(stream, idx + 5, 0.f, 1.f) <= T.cmd_rel_standing;
@@ -171,9 +174,14 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       vang = {vs[3], vs[4], vs[5]};
     }
     // manager resets: episode-sum log + zero, command metrics log + resample, interval timer
+    // command_levels_* curricula: a step whose counter is a multiple of the episode length collects the episode sums of the
+    // driving reward terms over the envs it resets (the decision is taken behind the launch, rl_env_host.h step())
+    const bool levels = log_episode && e < S.N && (T.cur_lin || T.cur_ang) && S.step_counter % (uint32_t)T.max_episode_length == 0u;
     for (int t = li; t < T.n_rewards; t += LPE) {
       float* p = S.ep_sums + (size_t)t * Np + e;
       if (log_episode && e < S.N) ctx.atomic_add(log_slot() + LOG_EP_SUM0 + t, *p);
+      if (levels && T.cur_lin && t == T.cur_lin_term) { ctx.atomic_add(S.cmd_levels + CL_SUM_LIN, *p); ctx.atomic_add(S.cmd_levels + CL_CNT_LIN, 1.f); }
+      if (levels && T.cur_ang && t == T.cur_ang_term) { ctx.atomic_add(S.cmd_levels + CL_SUM_ANG, *p); ctx.atomic_add(S.cmd_levels + CL_CNT_ANG, 1.f); }
       *p = 0.f;
     }
     if (li == 0 && log_episode && e < S.N) {
@@ -485,7 +493,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       acc[i] = t < n_rewards ? S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] : 0.f;
     }
     // ---- publish the joint statistics (first sub-lane of a limb: its joints; limb 0 also the trunk joints) ...
+#ifdef RL_ABL_NO_REW_PUBLISH
+    if (false) {
+#else
     if (sub == 0) {
+#endif
 #pragma unroll
       for (int j = 0; j < JX; ++j) {
         const int jid = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1;
@@ -543,7 +555,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     const float step_dt = ctx.uniform(T.step_dt);
     float* rstage = ctx.rew_stage();
     float mine = 0.f;
+#ifdef RL_ABL_NO_REW_TERMS
+    for (int t = li; t < 0; t += LPE) {
+#else
     for (int t = li; t < n_rewards; t += LPE) {
+#endif
       const RewTab& R = T.rew[t];
       const float val = term_value(R, E) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
       rstage[t] = val;
@@ -865,7 +881,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       }
       if (T.cmd_heading && is_heading) {  // the only consumer of the heading angle itself (everything else uses its cos / sin)
         const float heading_w = atan2f(yaw_s, yaw_c);
-        cmd.z = clampf(T.cmd_heading_stiffness * wrap_to_pi(heading_target - heading_w), T.cmd_range[2][0], T.cmd_range[2][1]);
+        cmd.z = clampf(T.cmd_heading_stiffness * wrap_to_pi(heading_target - heading_w), T.cur_ang ? S.cmd_levels[CL_ANG_Z] : T.cmd_range[2][0],
+                       T.cur_ang ? S.cmd_levels[CL_ANG_Z + 1] : T.cmd_range[2][1]);  // the LIVE range: the curriculum edits cfg.ranges in place
       }
       if (is_standing) cmd = {0.f, 0.f, 0.f};
       // the "pits" branch of commands.py:61-85 never fires: ROUGH_TERRAINS_CFG has no sub-terrain of that name (utils.py:27-28)

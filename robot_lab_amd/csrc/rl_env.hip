@@ -214,6 +214,9 @@ __global__ void export_kernel(KState S, const Tables* __restrict__ T, AosPtrs A)
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < S.Npad) export_env(S, *T, A, e);
 }
+__global__ void cmd_levels_kernel(float* lv, CmdLevelParams P) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) apply_cmd_levels(lv, P);
+}
 __global__ void commit_kernel(KState S, const Tables* __restrict__ T, AosPtrs A) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < S.Npad) commit_env(S, *T, A, e);
@@ -330,6 +333,10 @@ struct Backend {
   }
   int launch_export(const KState& S, const Tables* T, const AosPtrs& A, void* stream) {
     hipLaunchKernelGGL(export_kernel, dim3((S.Npad + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, T, A);
+    return check(hipGetLastError());
+  }
+  int launch_cmd_levels(float* lv, const CmdLevelParams& P, void* stream) {
+    hipLaunchKernelGGL(cmd_levels_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lv, P);
     return check(hipGetLastError());
   }
   int launch_commit(const KState& S, const Tables* T, const AosPtrs& A, void* stream) {

@@ -51,6 +51,7 @@ int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[
     case RL_BUF_OBS_CRITIC_RING: return set(I.obs_ring[1][0], 3, 2, Np, I.tables.critic_dim, 4);
     case RL_BUF_TASK_STATE: return set(I.task_state, 2, N, RL_TASK_STATE_NF, 1, 4);
     case RL_BUF_GAINS: return set(I.gains, 3, N, 2, D, 4);
+    case RL_BUF_CMD_LEVELS: return set(I.S.cmd_levels, 1, rl::CL_WORDS, 1, 1, 4);
     case RL_BUF_REWARD: return set(I.S.reward, 1, N, 1, 1, 4);
     case RL_BUF_TERMINATED: return set(I.S.terminated, 1, N, 1, 1, 1);
     case RL_BUF_TIME_OUT: return set(I.S.time_out, 1, N, 1, 1, 1);

@@ -262,6 +262,9 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   memcpy(T.cmd_resample, t.cmd_resample, sizeof(T.cmd_resample));
   T.cmd_rel_standing = t.cmd_rel_standing; T.cmd_rel_heading = t.cmd_rel_heading; T.cmd_heading_stiffness = t.cmd_heading_stiffness;
   T.cmd_small_threshold = t.cmd_small_threshold; T.cmd_heading = t.cmd_heading;
+  T.cur_lin = t.cur_cmd_lin; T.cur_ang = t.cur_cmd_ang; T.cur_lin_term = t.cur_cmd_lin_term; T.cur_ang_term = t.cur_cmd_ang_term;
+  if ((t.cur_cmd_lin && (t.cur_cmd_lin_term < 0 || t.cur_cmd_lin_term >= t.n_rewards)) || (t.cur_cmd_ang && (t.cur_cmd_ang_term < 0 || t.cur_cmd_ang_term >= t.n_rewards)))
+    return fail("command_levels curriculum names a reward term that does not exist");
   if (t.n_policy > MAX_OBS || t.n_critic > MAX_OBS || t.n_rewards > MAX_T) return fail("too many terms");
   T.n_policy = t.n_policy; T.n_critic = t.n_critic; T.policy_corrupt = t.policy_corrupt; T.critic_corrupt = t.critic_corrupt;
   for (int grp = 0; grp < 2; ++grp) {
@@ -383,6 +386,7 @@ struct EnvImpl {
   Tables* tables_dev = nullptr;   // unpacked (export / import kernels)
   void* packed_dev = nullptr;     // TablesT<Topo> image the env kernels stage into LDS
   KState S;
+  CmdLevelParams cmd_level_params{};
   int N = 0, Npad = 0, D = 0, B = 0, CL = 0, ept = ENVS_PER_WAVE;
   uint64_t seed = 0;
   uint32_t step_counter = 0;
@@ -447,6 +451,7 @@ struct EnvImpl {
     ctimers = alloc<float>(Np * B * 4); action_aos = alloc<float>(Np * D); env_origin_aos = alloc<float>(Np * 3);
     task_state = alloc<float>(Np * TASK_NF); gains = alloc<float>(Np * 2 * D);
     reset_mask = alloc<uint8_t>(Np);
+    S.cmd_levels = alloc<float>(CL_WORDS);
     tables_dev = alloc<Tables>(1);
     if (alloc_failed) return fail("device allocation failed: " + be.error());
     if (!desc.terrain.is_plane) {
@@ -470,6 +475,22 @@ struct EnvImpl {
       be.h2d(packed_dev, img.data(), img.size());
     }
     startup(terrain_origins, env_origins);
+    {  // command_levels_* curricula: ranges start at range x range_multiplier[0] (curriculums.py:30-41), end at x [1]
+      const rl_task_desc& t = desc.task;
+      float lv[CL_WORDS] = {};
+      const float ml = t.cur_cmd_lin ? t.cur_cmd_lin_mult[0] : 1.f, ma = t.cur_cmd_ang ? t.cur_cmd_ang_mult[0] : 1.f;
+      for (int i = 0; i < 2; ++i) {
+        lv[CL_LIN_X + i] = t.cmd_range[0][i] * ml; lv[CL_LIN_Y + i] = t.cmd_range[1][i] * ml; lv[CL_ANG_Z + i] = t.cmd_range[2][i] * ma;
+        cmd_level_params.final_x[i] = t.cmd_range[0][i] * t.cur_cmd_lin_mult[1];
+        cmd_level_params.final_y[i] = t.cmd_range[1][i] * t.cur_cmd_lin_mult[1];
+        cmd_level_params.final_z[i] = t.cmd_range[2][i] * t.cur_cmd_ang_mult[1];
+      }
+      cmd_level_params.lin = t.cur_cmd_lin; cmd_level_params.ang = t.cur_cmd_ang;
+      cmd_level_params.lin_weight = t.cur_cmd_lin ? t.rewards[t.cur_cmd_lin_term].weight : 0.f;
+      cmd_level_params.ang_weight = t.cur_cmd_ang ? t.rewards[t.cur_cmd_ang_term].weight : 0.f;
+      cmd_level_params.max_episode_length_s = t.episode_length_s;
+      be.h2d(S.cmd_levels, lv, sizeof(lv));
+    }
     return 0;
   }
 
@@ -630,7 +651,12 @@ struct EnvImpl {
     flip_obs(s);
     s.action_in = action_dev;
     s.ro_values = ro_values; s.ro_rewards = ro_rewards; s.ro_dones = ro_dones; s.ro_gamma = ro_gamma;
-    return be.launch(s, packed_dev, CL, /*reset=*/0, stream) ? fail("launch failed: " + be.error()) : 0;
+    if (be.launch(s, packed_dev, CL, /*reset=*/0, stream)) return fail("launch failed: " + be.error());
+    // command_levels_* curricula: the decision of a step whose counter is a multiple of the episode length needs the episode
+    // sums of every env reset in it - one more (single-thread) launch behind that step, once per episode length
+    if ((tables.cur_lin || tables.cur_ang) && step_counter % (uint32_t)tables.max_episode_length == 0u)
+      if (be.launch_cmd_levels(S.cmd_levels, cmd_level_params, stream)) return fail("launch failed: " + be.error());
+    return 0;
   }
 
   int export_state(void* stream) {

@@ -44,7 +44,7 @@ BUF = dict(
     OBS_POLICY=0, OBS_CRITIC=1, REWARD=2, TERMINATED=3, TIME_OUT=4, EPISODE_LENGTH=5, ROOT_STATE=6,
     JOINT_POS=7, JOINT_VEL=8, REWARD_TERMS=9, EPISODE_SUMS=10, COMMAND=11, CONTACT_FORCE=12,
     CONTACT_TIMERS=13, LOG=14, ACTION=15, JOINT_TORQUE=16, JOINT_ACC=17, ENV_ORIGIN=18, TERRAIN_LEVEL=19,
-    TASK_STATE=20, GAINS=21, OBS_POLICY_RING=22, OBS_CRITIC_RING=23,
+    TASK_STATE=20, GAINS=21, OBS_POLICY_RING=22, OBS_CRITIC_RING=23, CMD_LEVELS=24,
 )
 # fields of one RL_BUF_TASK_STATE row (include/rl_env.h rl_task_state_field)
 TASK_STATE = dict(CMD=slice(0, 3), HEADING_TARGET=3, CMD_TIME_LEFT=4, METRIC_XY=5, METRIC_YAW=6, PUSH_TIME_LEFT=7,
@@ -147,6 +147,8 @@ class TaskDesc(C.Structure):
         ("reset_pose", (f32 * 2) * 6), ("reset_vel", (f32 * 2) * 6),
         ("push_interval", f32 * 2), ("push_vel", (f32 * 2) * 6),
         ("base_body", i32),
+        ("cur_cmd_lin", i32), ("cur_cmd_ang", i32), ("cur_cmd_lin_term", i32), ("cur_cmd_ang_term", i32),
+        ("cur_cmd_lin_mult", f32 * 2), ("cur_cmd_ang_mult", f32 * 2),
     ]
 
 

@@ -102,6 +102,10 @@ class _LazyLog(dict):
             dict.__setitem__(self, "Episode_Termination/illegal_contact", s[3])
         if e.desc.terrain.curriculum and not e.desc.terrain.is_plane:
             dict.__setitem__(self, "Curriculum/terrain_levels", e.terrain_levels.float().mean())
+        if e.desc.task.cur_cmd_lin:  # what the term functions return (curriculums.py:62, 96): the live upper bounds
+            dict.__setitem__(self, "Curriculum/command_levels_lin_vel", e.command_levels[1])
+        if e.desc.task.cur_cmd_ang:
+            dict.__setitem__(self, "Curriculum/command_levels_ang_vel", e.command_levels[5])
 
     def __getitem__(self, k):
         self._fill()
@@ -357,6 +361,11 @@ class ManagerBasedRLEnv(_EnvBase):
     @property
     def terrain_levels(self) -> torch.Tensor:
         return self._bufs["TERRAIN_LEVEL"]
+
+    @property
+    def command_levels(self) -> torch.Tensor:
+        """float[16]: live command ranges of the command_levels_* curricula (lin_vel_x lo/hi, lin_vel_y lo/hi, ang_vel_z lo/hi, ...)."""
+        return self._bufs["CMD_LEVELS"]
 
     @property
     def reward_buf(self):

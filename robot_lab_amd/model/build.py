@@ -305,6 +305,12 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
         t.illegal_threshold = tm["illegal_contact"]["threshold"]
     ev = ts["events"]
     t.base_body = find_names(ts["base_body_name"], bn)[0]
+    for key, pre in (("lin_vel", "cur_cmd_lin"), ("ang_vel", "cur_cmd_ang")):  # command_levels_* curricula (curriculums.py:21-94)
+        c = (ts.get("command_levels") or {}).get(key)
+        if c:
+            setattr(t, pre, 1)
+            setattr(t, pre + "_term", d.reward_names.index(c["reward_term_name"]))
+            set_arr(getattr(t, pre + "_mult"), c["range_multiplier"])
     if ev.get("material"):
         e = ev["material"]
         t.ev_material = 1

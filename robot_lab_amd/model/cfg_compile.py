@@ -85,12 +85,19 @@ def compile_spec(cfg) -> tuple[dict, str]:
     spec["actions"] = actions
     spec["sim"] = dict(dt=cfg.sim.dt, decimation=cfg.decimation)
     # terrain
-    # curricula: terrain_levels_vel is built in; the command_levels_* terms (mdp/curriculums.py:21-94) rescale the
-    # global command ranges from a mean over the envs reset in one step - every cfg of the reference deletes them
-    # (e.g. unitree_a1/rough_env_cfg.py:158-159) and the lane program has no such grid-wide step: refuse, do not ignore
+    # curricula: terrain_levels_vel is built in; the command_levels_* terms (mdp/curriculums.py:21-94) become the live range
+    # table of the kernels (rl_task_desc.cur_cmd_*); every shipped cfg of the reference deletes them (e.g.
+    # unitree_a1/rough_env_cfg.py:158-159), the base cfg (velocity_env_cfg.py:673-690) carries them
+    cmd_levels = {}
     for name, t in _terms(getattr(cfg, "curriculum", None) or object()):
-        if _fname(t) != "terrain_levels_vel":
-            raise UnsupportedTerm(f"curriculum term {_fname(t)} ({name})")
+        fn = _fname(t)
+        if fn in ("command_levels_lin_vel", "command_levels_ang_vel"):
+            p = t.params or {}
+            cmd_levels[fn[len("command_levels_"):]] = dict(reward_term_name=p["reward_term_name"],
+                                                          range_multiplier=tuple(p.get("range_multiplier", (0.1, 1.0))))
+        elif fn != "terrain_levels_vel":
+            raise UnsupportedTerm(f"curriculum term {fn} ({name})")
+    spec["command_levels"] = cmd_levels
     ter = cfg.scene.terrain
     if ter.terrain_type == "plane":
         spec["terrain"] = dict(is_plane=1)
@@ -236,6 +243,10 @@ def compile_spec(cfg) -> tuple[dict, str]:
             raise UnsupportedTerm(f"event term {fn} ({name})")
     task["events"] = ev
     task["base_body_name"] = base_name or [getattr(cfg, "base_link_name", "base")]
+    task["command_levels"] = spec.pop("command_levels")
+    for k, c in task["command_levels"].items():
+        if c["reward_term_name"] not in [r["name"] for r in task["rewards"]]:
+            raise UnsupportedTerm(f"command_levels_{k}: reward term {c['reward_term_name']} is not active (weight 0 or removed)")
     spec["task"] = task
     is_regex = lambda n: any(c in n for c in "*()[]|?+^$")
     spec["joint_order"] = list(actions[0]["joint_names"]) if len(actions) == 1 and actions[0]["preserve_order"] else None

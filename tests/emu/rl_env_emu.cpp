@@ -6,6 +6,7 @@
 // oracle without a GPU.  The product path (robot_lab_amd.env) never loads this library: it requires
 // librl_env_hip.so and fails loudly without it.
 #include <pthread.h>
+#include <sched.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -92,6 +93,21 @@ class Pool {
 
  private:
   void worker(int id) {
+    if (const char* v = std::getenv("RL_EMU_PIN")) {  // RL_EMU_PIN=<stride>: lane thread i of the pool on allowed CPU (i * stride) mod n -
+      const int stride = std::max(1, std::atoi(v));   // the 4 lanes of a team on neighbouring CPUs (a barrier every few hundred instructions)
+      cpu_set_t allowed;
+      if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+        std::vector<int> cpus;
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+          if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+        if (!cpus.empty()) {
+          cpu_set_t one;
+          CPU_ZERO(&one);
+          CPU_SET(cpus[((size_t)id * stride) % cpus.size()], &one);
+          pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+        }
+      }
+    }
     for (;;) {
       const std::function<void(int)>* job;
       {
@@ -285,6 +301,10 @@ struct Backend {
   }
   int launch_export(const rl::KState& S, const rl::Tables* T, const rl::AosPtrs& A, void*) {
     for (int e = 0; e < S.Npad; ++e) rl::export_env(S, *T, A, e);
+    return 0;
+  }
+  int launch_cmd_levels(float* lv, const rl::CmdLevelParams& P, void*) {
+    rl::apply_cmd_levels(lv, P);
     return 0;
   }
   int launch_commit(const rl::KState& S, const rl::Tables* T, const rl::AosPtrs& A, void*) {

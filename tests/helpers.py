@@ -7,11 +7,13 @@ from oracle.env import OracleEnv
 from robot_lab_amd.scene import build_world, load_bundle
 
 
-def make_pair(task, N, seed, lib_path=None, device=0):
+def make_pair(task, N, seed, lib_path=None, device=0, mutate=None):
     """(oracle env, native env driven through the C-ABI) on the same descriptor, world and seed."""
     from robot_lab_amd.capi import NativeEnv
 
     desc, extra = load_bundle(task)
+    if mutate is not None:
+        mutate(desc)
     h, to, eo = build_world(desc, extra, N, 0)
     ora = OracleEnv(desc, h, to, N, seed, eo)
     nat = NativeEnv(desc, h, to, eo, N, seed, device, lib_path)

@@ -105,6 +105,35 @@ def test_bundles_recompile_from_reference_cfg():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs /root/reference")
+def test_command_level_curricula_compile_into_the_descriptor():
+    """The base cfg's command_levels_* terms (velocity_env_cfg.py:673-690), which every shipped robot cfg deletes, put back the way
+    the commented-out lines of the robot cfgs would (unitree_g1/rough_env_cfg.py:159-160)."""
+    from robot_lab_amd import shims
+
+    shims.install(shims.REFERENCE_SOURCE)
+    import robot_lab.tasks  # noqa: F401
+    from isaaclab_tasks.utils import parse_env_cfg
+    from robot_lab.tasks.manager_based.locomotion.velocity.velocity_env_cfg import CurriculumCfg
+
+    from robot_lab_amd.model.cfg_compile import UnsupportedTerm, compile_cfg
+
+    cfg = parse_env_cfg(A1R, device="cpu", num_envs=8)
+    assert cfg.curriculum.command_levels_lin_vel is None
+    base = CurriculumCfg()
+    cfg.curriculum.command_levels_lin_vel = base.command_levels_lin_vel
+    cfg.curriculum.command_levels_ang_vel = base.command_levels_ang_vel
+    cfg.curriculum.command_levels_ang_vel.params["range_multiplier"] = (0.2, 1.0)
+    desc, _ = compile_cfg(cfg)
+    t, names = desc.task, list(desc.reward_names)
+    assert t.cur_cmd_lin == 1 and t.cur_cmd_ang == 1
+    assert names[t.cur_cmd_lin_term] == "track_lin_vel_xy_exp" and names[t.cur_cmd_ang_term] == "track_ang_vel_z_exp"
+    assert tuple(t.cur_cmd_lin_mult) == pytest.approx((0.1, 1.0)) and tuple(t.cur_cmd_ang_mult) == pytest.approx((0.2, 1.0))
+    cfg.curriculum.command_levels_lin_vel.params["reward_term_name"] = "feet_gait"  # weight 0 in the A1 cfg: not an active term
+    with pytest.raises(UnsupportedTerm):
+        compile_cfg(cfg)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs /root/reference")
 def test_entry_point_resolves_to_the_hip_env():
     from robot_lab_amd import shims
 
