@@ -351,6 +351,22 @@ int32_t rl_env_obs_slot(const rl_env* env);
 int64_t rl_env_step_count(const rl_env* env);
 int rl_env_set_step_count(rl_env* env, int64_t count);
 
+/* ---- hipGraph capture of a loop around rl_env_step (the 24-step collection loop of train.py:224 -> OnPolicyRunner.learn) --------
+ * Everything a step launch takes from the host is either a pointer that repeats with period 2 (the observation buffers) or the
+ * step count, and the kernels read the step count as  *device word + launch literal.  So a stream capture that contains an EVEN
+ * number n of step launches replays correctly any number of times:
+ *     rl_env_graph_begin(env, stream);            before hipStreamBeginCapture: anchors the device word at the current count
+ *     hipStreamBeginCapture(stream, ...);  n x { ...; rl_env_step[_record](env, ..., stream); ... }
+ *     rl_env_graph_end(env, stream);              still inside the capture: appends the node that advances the device word by n,
+ *                                                 rolls the host-side mirrors back (capturing ran nothing); returns n or -1
+ *     hipStreamEndCapture(stream, &graph); hipGraphInstantiate(...);
+ *     per replay:  rl_env_graph_launching(env, stream);  hipGraphLaunch(exec, stream);
+ * rl_env_graph_launching accounts the n steps on the host side (rl_env_step_count, rl_env_log_slot, rl_env_obs_slot) and fails
+ * when the env is not where the capture found it (observation slot parity).  Direct rl_env_step calls may be mixed with replays. */
+int rl_env_graph_begin(rl_env* env, void* stream);
+int rl_env_graph_end(rl_env* env, void* stream);
+int rl_env_graph_launching(rl_env* env, void* stream);
+
 int32_t rl_env_num_envs(const rl_env* env);
 int32_t rl_env_num_actions(const rl_env* env);
 int32_t rl_env_obs_dim(const rl_env* env, int32_t group); /* 0 policy, 1 critic */

@@ -74,6 +74,18 @@ int rl_rollout_compute_returns(rl_rollout* r, const float* last_values, float ga
 /* RolloutStorage.clear(): back to step 0 (the random counter keeps running). */
 int rl_rollout_clear(rl_rollout* r);
 
+/* ---- hipGraph capture of a collection iteration (include/rl_env.h has the env's half and the protocol) ------------------
+ * The only launch argument of this library that changes from one iteration to the next is the random counter; the act kernel
+ * takes it as  *device word + launch literal.  A captured stretch [rl_rollout_clear; T x (rl_rollout_act; record); compute_returns]
+ * therefore replays with fresh noise every time:
+ *     rl_rollout_graph_begin(r, stream);        before hipStreamBeginCapture (anchors the device word)
+ *     ... the captured calls ...
+ *     rl_rollout_graph_end(r, stream);          inside the capture: appends the node advancing the word; host state rolled back
+ *     per replay:  rl_rollout_graph_launching(r, stream);  hipGraphLaunch(...)      (host state := state after the stretch) */
+int rl_rollout_graph_begin(rl_rollout* r, void* stream);
+int rl_rollout_graph_end(rl_rollout* r, void* stream);
+int rl_rollout_graph_launching(rl_rollout* r, void* stream);
+
 int rl_rollout_get_buffer(rl_rollout* r, int32_t which, void** dev_ptr, int64_t* count);
 int32_t rl_rollout_step(const rl_rollout* r); /* transitions recorded since the last clear */
 int rl_rollout_destroy(rl_rollout* r);

@@ -19,7 +19,7 @@ HIP_LIB = os.path.join(_HERE, "csrc", "librl_env_hip.so")
 EXPORTS = [
     "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_step_record", "rl_env_get_buffer", "rl_env_export_state", "rl_env_commit_state",
     "rl_env_import_state", "rl_env_read_log", "rl_env_log_slot", "rl_env_obs_slot", "rl_env_step_count", "rl_env_set_step_count", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length",
-    "rl_env_destroy", "rl_env_last_error", "rl_env_desc_size",
+    "rl_env_destroy", "rl_env_last_error", "rl_env_desc_size", "rl_env_graph_begin", "rl_env_graph_end", "rl_env_graph_launching",
 ]
 
 _libs: dict[str, C.CDLL] = {}
@@ -52,6 +52,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rl_env_step_count.restype = C.c_int64
     lib.rl_env_set_step_count.argtypes = [C.c_void_p, C.c_int64]
     lib.rl_env_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for n in ("rl_env_graph_begin", "rl_env_graph_end", "rl_env_graph_launching"):
+        getattr(lib, n).argtypes = [C.c_void_p, C.c_void_p]
     lib.rl_env_read_log.argtypes = [C.c_void_p, fp, C.c_void_p]
     lib.rl_env_log_slot.argtypes = [C.c_void_p]
     lib.rl_env_log_slot.restype = C.c_int32
@@ -145,6 +147,19 @@ class NativeEnv:
     @step_count.setter
     def step_count(self, n: int):
         self._check(self.lib.rl_env_set_step_count(self.handle, int(n)))
+
+    # hipGraph capture of a loop around step() (include/rl_env.h)
+    def graph_begin(self, stream: int = 0):
+        self._check(self.lib.rl_env_graph_begin(self.handle, C.c_void_p(stream)))
+
+    def graph_end(self, stream: int = 0) -> int:
+        n = self.lib.rl_env_graph_end(self.handle, C.c_void_p(stream))
+        if n < 0:
+            raise RlEnvError(self.error())
+        return n
+
+    def graph_launching(self, stream: int = 0):
+        self._check(self.lib.rl_env_graph_launching(self.handle, C.c_void_p(stream)))
 
     def import_state(self, root_ptr=0, qpos_ptr=0, qvel_ptr=0, stream: int = 0):
         self._check(self.lib.rl_env_import_state(self.handle, C.c_void_p(root_ptr), C.c_void_p(qpos_ptr), C.c_void_p(qvel_ptr), C.c_void_p(stream)))

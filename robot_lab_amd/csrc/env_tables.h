@@ -306,6 +306,7 @@ struct KState {
   float ro_gamma;
   float* cmd_levels;               // [16] live command ranges + decision accumulators of the command_levels_* curricula (CmdLevels)
   uint64_t seed;
+  const uint32_t* step_base;       // the step count of a launch = *step_base + step_counter (hipGraph replays advance the device word, rl_env_graph_*)
   uint32_t step_counter;
   uint32_t table_bytes;  // bytes of the packed table image the env kernels stage into LDS (multiple of 16)
 };

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
   float* smem = reinterpret_cast<float*>(smem4);
   Tables* Tl = reinterpret_cast<Tables*>(smem);
   const int lane = threadIdx.x;
+  S.step_counter += *S.step_base;  // scalar load: the launch carries the offset from the device-side anchor (rl_env_graph_*)
   {  // stage the used part of the table image into LDS (16-byte vectors): all loads in flight before the first LDS write
     const float4* src = reinterpret_cast<const float4*>(Tg);
     float4* dst = reinterpret_cast<float4*>(Tl);
@@ -214,8 +215,11 @@ __global__ void export_kernel(KState S, const Tables* __restrict__ T, AosPtrs A)
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < S.Npad) export_env(S, *T, A, e);
 }
-__global__ void cmd_levels_kernel(float* lv, CmdLevelParams P) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) apply_cmd_levels(lv, P);
+__global__ void cmd_levels_kernel(float* lv, CmdLevelParams P, const uint32_t* step_base, uint32_t step_offset, uint32_t period) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (*step_base + step_offset) % period == 0u) apply_cmd_levels(lv, P);
+}
+__global__ void u32_kernel(uint32_t* p, uint32_t v, int add) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p = add ? *p + v : v;
 }
 __global__ void commit_kernel(KState S, const Tables* __restrict__ T, AosPtrs A) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,8 +339,12 @@ struct Backend {
     hipLaunchKernelGGL(export_kernel, dim3((S.Npad + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, T, A);
     return check(hipGetLastError());
   }
-  int launch_cmd_levels(float* lv, const CmdLevelParams& P, void* stream) {
-    hipLaunchKernelGGL(cmd_levels_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lv, P);
+  int launch_cmd_levels(float* lv, const CmdLevelParams& P, const uint32_t* step_base, uint32_t step_offset, uint32_t period, void* stream) {
+    hipLaunchKernelGGL(cmd_levels_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lv, P, step_base, step_offset, period);
+    return check(hipGetLastError());
+  }
+  int launch_u32(uint32_t* p, uint32_t v, int add, void* stream) {  // *p = v / *p += v, stream-ordered (capturable)
+    hipLaunchKernelGGL(u32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v, add);
     return check(hipGetLastError());
   }
   int launch_commit(const KState& S, const Tables* T, const AosPtrs& A, void* stream) {

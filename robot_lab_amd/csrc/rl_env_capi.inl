@@ -112,9 +112,11 @@ int64_t rl_env_step_count(const rl_env* env) { return env ? (int64_t) reinterpre
 int rl_env_set_step_count(rl_env* env, int64_t count) {
   if (!env) return rl::fail("null env");
   if (count < 0 || count > 0xffffffffll) return rl::fail("step count out of range");
-  reinterpret_cast<Impl*>(env)->step_counter = (uint32_t)count;
-  return 0;
+  return reinterpret_cast<Impl*>(env)->set_step_count((uint32_t)count);
 }
+int rl_env_graph_begin(rl_env* env, void* stream) { return env ? reinterpret_cast<Impl*>(env)->graph_begin(stream) : rl::fail("null env"); }
+int rl_env_graph_end(rl_env* env, void* stream) { return env ? reinterpret_cast<Impl*>(env)->graph_end(stream) : rl::fail("null env"); }
+int rl_env_graph_launching(rl_env* env, void* stream) { return env ? reinterpret_cast<Impl*>(env)->graph_launching(stream) : rl::fail("null env"); }
 
 int32_t rl_env_num_envs(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->N; }
 int32_t rl_env_num_actions(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->D; }

@@ -390,6 +390,12 @@ struct EnvImpl {
   int N = 0, Npad = 0, D = 0, B = 0, CL = 0, ept = ENVS_PER_WAVE;
   uint64_t seed = 0;
   uint32_t step_counter = 0;
+  // the kernels take the step count as *step_base + launch literal (rl_env_graph_*): `anchor` mirrors the device word
+  uint32_t* step_base = nullptr;
+  uint32_t anchor = 0;
+  bool capturing = false;
+  uint32_t snap_step = 0, graph_n = 0;
+  int snap_slot = 0, graph_slot = -1;
   std::vector<int> body_lane, body_slot, link_lane, link_pos;
   std::vector<void*> allocs;
   // AoS inspection buffers
@@ -452,6 +458,8 @@ struct EnvImpl {
     task_state = alloc<float>(Np * TASK_NF); gains = alloc<float>(Np * 2 * D);
     reset_mask = alloc<uint8_t>(Np);
     S.cmd_levels = alloc<float>(CL_WORDS);
+    step_base = alloc<uint32_t>(4);
+    S.step_base = step_base;
     tables_dev = alloc<Tables>(1);
     if (alloc_failed) return fail("device allocation failed: " + be.error());
     if (!desc.terrain.is_plane) {
@@ -625,7 +633,7 @@ struct EnvImpl {
   int reset(const int32_t* env_ids, int32_t n, void* stream) {
     if (be.activate()) return fail("device activation failed: " + be.error());
     KState s = S;
-    s.step_counter = step_counter;
+    s.step_counter = step_counter - anchor;
     if (env_ids == nullptr) {
       s.reset_mask = nullptr;
     } else {
@@ -647,15 +655,56 @@ struct EnvImpl {
     if ((ro_values || ro_rewards || ro_dones) && !(ro_values && ro_rewards && ro_dones)) return fail("rollout sink needs values, rewards and dones");
     if (be.activate()) return fail("device activation failed: " + be.error());
     KState s = S;
-    s.step_counter = ++step_counter;
+    s.step_counter = ++step_counter - anchor;
     flip_obs(s);
     s.action_in = action_dev;
     s.ro_values = ro_values; s.ro_rewards = ro_rewards; s.ro_dones = ro_dones; s.ro_gamma = ro_gamma;
     if (be.launch(s, packed_dev, CL, /*reset=*/0, stream)) return fail("launch failed: " + be.error());
     // command_levels_* curricula: the decision of a step whose counter is a multiple of the episode length needs the episode
     // sums of every env reset in it - one more (single-thread) launch behind that step, once per episode length
-    if ((tables.cur_lin || tables.cur_ang) && step_counter % (uint32_t)tables.max_episode_length == 0u)
-      if (be.launch_cmd_levels(S.cmd_levels, cmd_level_params, stream)) return fail("launch failed: " + be.error());
+    // (the launch tests the step count itself: it sits in captured graphs, too)
+    if (tables.cur_lin || tables.cur_ang)
+      if (be.launch_cmd_levels(S.cmd_levels, cmd_level_params, S.step_base, step_counter - anchor, (uint32_t)tables.max_episode_length, stream))
+        return fail("launch failed: " + be.error());
+    return 0;
+  }
+
+  // include/rl_env.h "hipGraph capture of a loop around rl_env_step"
+  int set_step_count(uint32_t count) {
+    if (capturing) return fail("rl_env_set_step_count inside a capture");
+    step_counter = count;  // the launch literal is step_counter - anchor (mod 2^32): nothing to do on the device
+    return 0;
+  }
+  int graph_begin(void* stream) {
+    if (capturing) return fail("rl_env_graph_begin: a capture is already open");
+    if (be.activate()) return fail("device activation failed: " + be.error());
+    if (be.launch_u32(step_base, step_counter, /*add=*/0, stream)) return fail("launch failed: " + be.error());
+    anchor = step_counter;
+    snap_step = step_counter; snap_slot = obs_slot;
+    capturing = true;
+    return 0;
+  }
+  int graph_end(void* stream) {
+    if (!capturing) return fail("rl_env_graph_end without rl_env_graph_begin");
+    capturing = false;
+    const uint32_t n = step_counter - snap_step;
+    // capturing executed nothing: back to where the capture started
+    step_counter = snap_step;
+    if (obs_slot != snap_slot) flip_obs(S);
+    if (n == 0 || (n & 1u)) return fail("a captured loop needs an even, positive number of rl_env_step launches (observation buffers alternate), got " + std::to_string(n));
+    if (be.launch_u32(step_base, n, /*add=*/1, stream)) return fail("launch failed: " + be.error());
+    graph_n = n; graph_slot = snap_slot;
+    return (int)n;
+  }
+  int graph_launching(void* stream) {
+    if (capturing || graph_n == 0) return fail("rl_env_graph_launching: no captured loop");
+    if (obs_slot != graph_slot) return fail("the env is not where the capture found it: an odd number of steps / resets since (observation slot parity)");
+    if (be.activate()) return fail("device activation failed: " + be.error());
+    if (step_counter != anchor) {  // direct steps since the last replay: re-anchor (the graph's literals count from the anchor)
+      if (be.launch_u32(step_base, step_counter, 0, stream)) return fail("launch failed: " + be.error());
+      anchor = step_counter;
+    }
+    step_counter += graph_n; anchor += graph_n;  // what the replay's last node does to the device word
     return 0;
   }
 

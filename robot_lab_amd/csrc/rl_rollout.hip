@@ -39,12 +39,17 @@ int fail(const std::string& m) {
     if (e_ != hipSuccess) return fail(std::string(#x ": ") + hipGetErrorString(e_)); \
   } while (0)
 
+__global__ void u32_kernel(uint32_t* p, uint32_t v, int add) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p = add ? *p + v : v;
+}
+
 struct ActArgs {
   const float *obs, *critic_obs, *mean, *std, *values;
   float *actions_out, *s_obs, *s_critic, *s_actions, *s_mu, *s_sigma, *s_logp, *s_values;
   int N, obs_dim, critic_dim, act_dim;
   int copy_blocks_obs, copy_blocks_critic, sample_blocks;
   uint64_t seed;
+  const uint32_t* counter_base;  // Philox counter of the launch = *counter_base + counter (graph replays advance the device word)
   uint32_t counter;
 };
 
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
   if (live) {
     const float* mu = a.mean + (size_t)e * A;
     float z[4];
-    normal4(a.seed, (uint32_t)e, a.counter, (uint32_t)blk, z);
+    normal4(a.seed, (uint32_t)e, *a.counter_base + a.counter, (uint32_t)blk, z);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int j = 4 * blk + i;
@@ -233,6 +238,13 @@ struct rl_rollout {
   void* buf[RL_RO_NUM_BUFFERS] = {};
   int64_t count[RL_RO_NUM_BUFFERS] = {};
   double *partial_sum = nullptr, *partial_sq = nullptr;
+  // hipGraph capture (rl_rollout_graph_*): the act kernel takes the counter as *counter_base + literal; `anchor` mirrors the word
+  uint32_t* counter_base = nullptr;
+  uint32_t anchor = 0;
+  bool capturing = false;
+  uint32_t snap_counter = 0, graph_n = 0;
+  int snap_step = 0, end_step = 0;
+  bool snap_acted = false;
 };
 
 namespace {
@@ -276,6 +288,11 @@ int rl_rollout_create(int32_t num_envs, int32_t num_steps, int32_t obs_dim, int3
     rl_rollout_destroy(r);
     return fail("hipMalloc of the reduction scratch failed");
   }
+  if (hipMalloc(&r->counter_base, 4 * sizeof(uint32_t)) != hipSuccess || hipMemset(r->counter_base, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
+    rl_rollout_destroy(r);
+    return fail("hipMalloc of the counter word failed");
+  }
+  HIP_OK(hipDeviceSynchronize());  // the memsets ran on the null stream; callers launch on non-blocking streams
   *out = r;
   return 0;
 }
@@ -292,7 +309,7 @@ int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, con
   a.s_obs = slot<float>(r, RL_RO_OBS, t); a.s_critic = slot<float>(r, RL_RO_CRITIC_OBS, t); a.s_actions = slot<float>(r, RL_RO_ACTIONS, t);
   a.s_mu = slot<float>(r, RL_RO_MU, t); a.s_sigma = slot<float>(r, RL_RO_SIGMA, t); a.s_logp = slot<float>(r, RL_RO_LOG_PROB, t);
   a.s_values = slot<float>(r, RL_RO_VALUES, t);
-  a.N = r->N; a.obs_dim = r->obs_dim; a.critic_dim = r->critic_dim; a.act_dim = r->act_dim; a.seed = r->seed; a.counter = r->counter;
+  a.N = r->N; a.obs_dim = r->obs_dim; a.critic_dim = r->critic_dim; a.act_dim = r->act_dim; a.seed = r->seed; a.counter_base = r->counter_base; a.counter = r->counter - r->anchor;
   // 4 float4 per thread of the copy blocks
   a.copy_blocks_obs = std::max(1, blocks_for(((size_t)r->N * r->obs_dim) >> 4));
   a.copy_blocks_critic = std::max(1, blocks_for(((size_t)r->N * r->critic_dim) >> 4));
@@ -366,6 +383,50 @@ int rl_rollout_get_buffer(rl_rollout* r, int32_t which, void** dev_ptr, int64_t*
 
 int32_t rl_rollout_step(const rl_rollout* r) { return r ? r->step : -1; }
 
+// include/rl_rollout.h "hipGraph capture"
+int rl_rollout_graph_begin(rl_rollout* r, void* stream) {
+  if (!r) return fail("NULL handle");
+  if (r->capturing) return fail("rl_rollout_graph_begin: a capture is already open");
+  HIP_OK(hipSetDevice(r->device));
+  hipLaunchKernelGGL(u32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, r->counter_base, r->counter, 0);
+  HIP_OK(hipGetLastError());
+  r->anchor = r->counter;
+  r->snap_counter = r->counter; r->snap_step = r->step; r->snap_acted = r->acted;
+  r->capturing = true;
+  return 0;
+}
+
+int rl_rollout_graph_end(rl_rollout* r, void* stream) {
+  if (!r) return fail("NULL handle");
+  if (!r->capturing) return fail("rl_rollout_graph_end without rl_rollout_graph_begin");
+  r->capturing = false;
+  const uint32_t n = r->counter - r->snap_counter;
+  r->end_step = r->step;
+  const bool open_step = r->acted;
+  r->counter = r->snap_counter; r->step = r->snap_step; r->acted = r->snap_acted;  // capturing executed nothing
+  if (open_step) return fail("the captured loop ends between rl_rollout_act and the record of that step");
+  HIP_OK(hipSetDevice(r->device));
+  hipLaunchKernelGGL(u32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, r->counter_base, n, 1);
+  HIP_OK(hipGetLastError());
+  r->graph_n = n;
+  return (int)n;
+}
+
+int rl_rollout_graph_launching(rl_rollout* r, void* stream) {
+  if (!r) return fail("NULL handle");
+  if (r->capturing) return fail("rl_rollout_graph_launching inside a capture");
+  if (r->acted) return fail("rl_rollout_graph_launching between rl_rollout_act and the record of that step");
+  HIP_OK(hipSetDevice(r->device));
+  if (r->counter != r->anchor) {  // transitions drawn directly since the last replay: re-anchor
+    hipLaunchKernelGGL(u32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, r->counter_base, r->counter, 0);
+    HIP_OK(hipGetLastError());
+    r->anchor = r->counter;
+  }
+  r->counter += r->graph_n; r->anchor += r->graph_n;  // what the replay's last node does to the device word
+  r->step = r->end_step;
+  return 0;
+}
+
 int rl_symmetry_create(int32_t n_sym, int32_t dim, const int32_t* perm, const float* sign, int32_t device, rl_symmetry** out) {
   if (!perm || !sign || !out) return fail("NULL argument");
   if (n_sym < 1 || dim < 1) return fail("sizes must be positive");
@@ -410,6 +471,7 @@ int rl_rollout_destroy(rl_rollout* r) {
     if (p) (void)hipFree(p);
   if (r->partial_sum) (void)hipFree(r->partial_sum);
   if (r->partial_sq) (void)hipFree(r->partial_sq);
+  if (r->counter_base) (void)hipFree(r->counter_base);
   delete r;
   return 0;
 }

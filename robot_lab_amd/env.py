@@ -340,6 +340,27 @@ class ManagerBasedRLEnv(_EnvBase):
     def get_observations(self):
         return self._obs
 
+    # -- hipGraph capture of a loop around step() (include/rl_env.h; robot_lab_amd/collect.py drives it) -------------------
+    def graph_begin(self):
+        self._native.graph_begin(self._stream())
+        self._graph_snap = self.common_step_counter
+
+    def graph_end(self) -> int:
+        n = self._native.graph_end(self._stream())
+        self.common_step_counter = self._graph_snap  # capturing ran nothing
+        self._obs = self._obs_slots[self._native.obs_slot()]
+        return n
+
+    def graph_launching(self, n: int):
+        """Call right before replaying a captured loop of `n` steps: accounts them on the host side."""
+        self._native.graph_launching(self._stream())
+        self.common_step_counter += n
+        self._export_stamp = -1
+        self._obs = self._obs_slots[self._native.obs_slot()]
+        if self.log_episodes:
+            k = self._native.log_slot()
+            self.extras = {"log": _LazyLog(self, self._bufs["LOG"][k], self._bufs["LOG"][(k - 1) % RL_LOG_RING], self.common_step_counter)}
+
     def close(self):
         if getattr(self, "_native", None) is not None:
             torch.cuda.synchronize(self._dev_index)

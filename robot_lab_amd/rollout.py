@@ -18,7 +18,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROLLOUT_LIB = os.path.join(_HERE, "csrc", "librl_rollout_hip.so")
 ROLLOUT_EXPORTS = ["rl_rollout_create", "rl_rollout_act", "rl_rollout_record", "rl_rollout_record_slots", "rl_rollout_compute_returns", "rl_rollout_clear",
-                   "rl_rollout_get_buffer", "rl_rollout_step", "rl_rollout_destroy", "rl_rollout_last_error"]
+                   "rl_rollout_get_buffer", "rl_rollout_step", "rl_rollout_destroy", "rl_rollout_last_error",
+                   "rl_rollout_graph_begin", "rl_rollout_graph_end", "rl_rollout_graph_launching"]
 # name -> (rl_rollout_buffer id, dtype, has a trailing feature dim)
 BUFFERS = dict(observations=(0, np.float32, True), privileged_observations=(1, np.float32, True), actions=(2, np.float32, True),
                mu=(3, np.float32, True), sigma=(4, np.float32, True), actions_log_prob=(5, np.float32, False),
@@ -46,6 +47,8 @@ def load_rollout_library(path: str | None = None) -> C.CDLL:
     lib.rl_rollout_record_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.rl_rollout_compute_returns.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int32, vp]
     lib.rl_rollout_clear.argtypes = [vp]
+    for n in ("rl_rollout_graph_begin", "rl_rollout_graph_end", "rl_rollout_graph_launching"):
+        getattr(lib, n).argtypes = [vp, vp]
     lib.rl_rollout_get_buffer.argtypes = [vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.rl_rollout_step.argtypes = [vp]
     lib.rl_rollout_step.restype = C.c_int32
@@ -142,6 +145,21 @@ class RolloutStorage:
 
     def clear(self):
         if self.lib.rl_rollout_clear(self.handle) != 0:
+            raise RlRolloutError(self._err())
+
+    # -- hipGraph capture of a collection iteration (include/rl_rollout.h; robot_lab_amd/collect.py drives it)
+    def graph_begin(self):
+        if self.lib.rl_rollout_graph_begin(self.handle, self._stream()) != 0:
+            raise RlRolloutError(self._err())
+
+    def graph_end(self) -> int:
+        n = self.lib.rl_rollout_graph_end(self.handle, self._stream())
+        if n < 0:
+            raise RlRolloutError(self._err())
+        return n
+
+    def graph_launching(self):
+        if self.lib.rl_rollout_graph_launching(self.handle, self._stream()) != 0:
             raise RlRolloutError(self._err())
 
     def close(self):

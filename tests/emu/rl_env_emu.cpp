@@ -241,7 +241,9 @@ struct HostCtx {
 };
 
 template <class TP, int SUB>
-void run(const rl::KState& S, const void* Tv, int reset) {
+void run(const rl::KState& S_launch, const void* Tv, int reset) {
+  rl::KState S = S_launch;
+  S.step_counter += *S.step_base;  // as the kernel entry does
   const rl::TablesT<TP>* T = static_cast<const rl::TablesT<TP>*>(Tv);
   using Ctx = HostCtx<SUB>;
   int teams = 1;
@@ -303,8 +305,12 @@ struct Backend {
     for (int e = 0; e < S.Npad; ++e) rl::export_env(S, *T, A, e);
     return 0;
   }
-  int launch_cmd_levels(float* lv, const rl::CmdLevelParams& P, void*) {
-    rl::apply_cmd_levels(lv, P);
+  int launch_cmd_levels(float* lv, const rl::CmdLevelParams& P, const uint32_t* step_base, uint32_t step_offset, uint32_t period, void*) {
+    if ((*step_base + step_offset) % period == 0u) rl::apply_cmd_levels(lv, P);
+    return 0;
+  }
+  int launch_u32(uint32_t* p, uint32_t v, int add, void*) {
+    *p = add ? *p + v : v;
     return 0;
   }
   int launch_commit(const rl::KState& S, const rl::Tables* T, const rl::AosPtrs& A, void*) {

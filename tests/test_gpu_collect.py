@@ -1,0 +1,66 @@
+"""The 24-step collection iteration as one hipGraph launch (robot_lab_amd/collect.py) against the same iteration launched
+kernel by kernel: same env seed, same storage seed, same networks -> the storages must agree bit for bit after every iteration
+(fresh noise and fresh step counts on every replay come from the device words, include/rl_env.h `rl_env_graph_*`)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TASK = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
+
+
+def _setup(use_graph, N=256, T=24):
+    import torch
+
+    from robot_lab_amd.collect import Collector
+    from robot_lab_amd.env import ManagerBasedRLEnv
+    from robot_lab_amd.policy import MlpPolicy
+    from robot_lab_amd.rollout import RolloutStorage
+
+    env = ManagerBasedRLEnv(TASK, num_envs=N, seed=11, device="cuda:0")
+    obs, _ = env.reset()
+    od, cd, A = obs["policy"].shape[1], obs["critic"].shape[1], env.num_actions
+    rng = np.random.default_rng(0)
+
+    def net(dims):
+        ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+        return MlpPolicy(ws, [0.05 * rng.standard_normal(d).astype(np.float32) for d in dims[1:]], "elu", device="cuda:0")
+
+    actor, critic = net([od, 512, 256, 128, A]), net([cd, 512, 256, 128, 1])
+    storage = RolloutStorage(N, T, od, cd, A, seed=3, device="cuda:0")
+    std = torch.full((A,), 0.5, device="cuda:0")
+    return env, storage, Collector(env, actor, critic, storage, std, use_graph=use_graph)
+
+
+def test_graph_replay_matches_eager_iterations():
+    import torch
+
+    env_e, st_e, eager = _setup(False)
+    env_g, st_g, graph = _setup(True)
+    for it in range(4):  # iteration 0 of the graphed collector is eager + capture, 1.. are replays
+        oe, og = eager.collect(), graph.collect()
+        torch.cuda.synchronize()
+        assert env_e.common_step_counter == env_g.common_step_counter == 24 * (it + 1)
+        for name in ("observations", "privileged_observations", "actions", "mu", "actions_log_prob", "values", "rewards", "dones", "returns",
+                     "advantages"):
+            a, b = getattr(st_e, name), getattr(st_g, name)
+            assert torch.equal(a, b), f"iteration {it}: {name} differs (max |d| {float((a.float() - b.float()).abs().max()):.3e})"
+        assert torch.equal(oe["policy"], og["policy"]) and torch.equal(oe["critic"], og["critic"])
+        assert torch.equal(env_e.episode_length_buf, env_g.episode_length_buf)
+        if it >= 1:  # the replays draw fresh noise: not the actions of the previous iteration
+            assert not torch.equal(st_g.actions, prev)
+        prev = st_g.actions.clone()
+    # the episode log of the last step is readable after a replay and equal to the eager one
+    le, lg = dict(eager.env.extras["log"]), dict(graph.env.extras["log"])
+    assert le.keys() == lg.keys()
+    for k in le:
+        assert float(le[k]) == float(lg[k]), k
+    # direct steps and replays can be mixed: two direct steps on both sides, then another iteration
+    for c in (eager, graph):
+        for _ in range(2):
+            c.obs, *_ = c.env.step(torch.zeros(c.env.num_envs, c.env.num_actions, device="cuda:0"))
+    eager.collect(), graph.collect()
+    torch.cuda.synchronize()
+    assert torch.equal(st_e.actions, st_g.actions) and torch.equal(st_e.advantages, st_g.advantages)
+    for e in (env_e, env_g):
+        e.close()

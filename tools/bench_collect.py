@@ -40,18 +40,26 @@ std = torch.ones(A, device="cuda:0")  # init_noise_std = 1.0 (rsl_rl_ppo_cfg.py:
 storage = RolloutStorage(N, T, od, cd, A, seed=1, device="cuda:0")
 
 
-def iteration(obs):
-    storage.clear()
-    for _ in range(T):
-        mean, values = actor.forward_pair(obs["policy"], critic, obs["critic"]) if PAIR else (actor(obs["policy"]), critic(obs["critic"]))
-        actions = storage.act(obs["policy"], obs["critic"], mean, std, values)
-        if FUSED:  # the env kernel writes the transition's rewards / dones into the storage slot (rl_env_step_record)
-            obs, rew, term, tout, extras = env.step(actions, rollout=storage, gamma=GAMMA)
-        else:
-            obs, rew, term, tout, extras = env.step(actions)
-            storage.process_env_step(rew, term, tout, GAMMA)
-    storage.compute_returns(critic(obs["critic"]), GAMMA, LAM)
-    return obs
+GRAPH = os.environ.get("RL_GRAPH", "1") == "1"  # the whole iteration as one hipGraph launch (robot_lab_amd/collect.py)
+if GRAPH and FUSED and PAIR:
+    from robot_lab_amd.collect import Collector  # noqa: E402
+
+    col = Collector(env, actor, critic, storage, std, GAMMA, LAM, use_graph=True)
+    iteration = lambda obs: col.collect()  # noqa: E731
+else:
+
+    def iteration(obs):
+        storage.clear()
+        for _ in range(T):
+            mean, values = actor.forward_pair(obs["policy"], critic, obs["critic"]) if PAIR else (actor(obs["policy"]), critic(obs["critic"]))
+            actions = storage.act(obs["policy"], obs["critic"], mean, std, values)
+            if FUSED:  # the env kernel writes the transition's rewards / dones into the storage slot (rl_env_step_record)
+                obs, rew, term, tout, extras = env.step(actions, rollout=storage, gamma=GAMMA)
+            else:
+                obs, rew, term, tout, extras = env.step(actions)
+                storage.process_env_step(rew, term, tout, GAMMA)
+        storage.compute_returns(critic(obs["critic"]), GAMMA, LAM)
+        return obs
 
 
 with torch.inference_mode():
@@ -64,5 +72,5 @@ with torch.inference_mode():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 ok = bool(torch.isfinite(storage.advantages).all() and torch.isfinite(storage.returns).all())
-print(f"{task} N={N}: collection of {T} steps + GAE {1e3 * dt / ITERS:.3f} ms / iteration = {N * T * ITERS / dt / 1e6:.1f} M env-steps/s "
+print(f"{task} N={N} graph={int(GRAPH and FUSED and PAIR)}: collection of {T} steps + GAE {1e3 * dt / ITERS:.3f} ms / iteration = {N * T * ITERS / dt / 1e6:.1f} M env-steps/s "
       f"({1e6 * dt / ITERS / T:.1f} us / step; finite: {ok}; adv mean {float(storage.advantages.mean()):+.2e} std {float(storage.advantages.std()):.4f})")
