@@ -26,7 +26,7 @@ class Collector:
         if self.T % 2:
             use_graph = False  # the env's observation buffers alternate: a captured loop needs an even number of steps
         self.use_graph = use_graph
-        self._graph = None
+        self._graph, self._warm = None, False
         self.obs = env.get_observations()
 
     def _iteration(self, obs):
@@ -59,8 +59,11 @@ class Collector:
         if not self.use_graph:
             self.obs = self._iteration(self.obs)
             return self.obs
+        if not self._warm:  # eager once: every library has its per-device setup behind it
+            self._warm = True
+            self.obs = self._iteration(self.obs)
+            return self.obs
         if self._graph is None:
-            self.obs = self._iteration(self.obs)  # eager once: every library has its per-device setup behind it
             self._capture()
         self.env.graph_launching(self.T)
         self.storage.graph_launching()

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -59,7 +60,7 @@ __device__ inline int lds_index(int row, int k) { return ((((k >> 4) * 4 + (k & 
 // (at 16 rows per workgroup every CU pulls ~32 B / cycle of weights at full MFMA rate, ~20 TB/s of L2 reads chip-wide).
 template <int TPW, int RT, int WAVES>
 __device__ inline void layer(const MlpParams& P, int l, const float* __restrict__ xin, float* __restrict__ xout, float* __restrict__ y, int row0,
-                             int n_rows, int lane, int wave) {
+                             int n_rows, int lane, int wave) {  // wave: index of this wavefront's first tile (tiles wave, wave + WAVES, ...)
   const int KB = P.KB[l];
   const int NT = 8 * P.NT8[l];     // tiles per k block in the weight image (>= WAVES * TPW: only the tiles that carry
                                    // real or next-layer-padding columns are computed)
@@ -85,6 +86,10 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
   f32x4 b0[TPW], b1[TPW], b2[TPW];
   load_b(0, b0);
   load_b(1, b1);
+  // the epilogue's biases travel with the first weight blocks (loaded at the end they are one more exposed L2 round trip)
+  float bias_r[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) bias_r[t] = ((const float __attribute__((address_space(1)))*)(uintptr_t)P.b[l])[(wave + WAVES * t) * 16 + (lane & 15)];
   auto mma = [&](int kb, const f32x4 (&b)[TPW]) {
     f32x4 a[RT];
 #pragma unroll
@@ -117,7 +122,7 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int n = (wave + WAVES * t) * 16 + col;
-    const float bias = ((const float __attribute__((address_space(1)))*)(uintptr_t)P.b[l])[n];
+    const float bias = bias_r[t];
     const bool valid = n < P.N[l];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -189,12 +194,115 @@ struct MlpPair {
   const MlpParams *a, *b;  // device copies
   const float *xa, *xb;
   float *ya, *yb;
+  unsigned long long* clk;  // -DRL_MLP_CLOCK: [workgroup][16] s_memtime stamps of wavefront 0 (kernel analysis builds only)
 };
+#ifdef RL_MLP_CLOCK
+#define MLP_STAMP(i) do { if ((threadIdx.x & 63) == 0) q.clk[(size_t)blockIdx.x * 128 + ((threadIdx.x >> 6) & 7) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MLP_STAMP(i) do { } while (0)
+#endif
 template <int RT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void mlp_forward_pair_kernel(MlpPair q, int n_rows) {
   const bool second = blockIdx.x & 1;
   const MlpParams& P = *(second ? q.b : q.a);  // workgroup-uniform address: the fields arrive by scalar loads
   mlp_tile<RT, WAVES>(P, second ? q.xb : q.xa, second ? q.yb : q.ya, n_rows, blockIdx.x >> 1);
+}
+
+// ---- actor + critic, FUSED per row tile ------------------------------------------------------------------------------------
+// One workgroup (8 wavefronts) owns 16 rows and runs BOTH networks on them, layer by layer: in layer l the 16-column output
+// tiles of network A and of network B form one list that is dealt round-robin to the eight wavefronts, so every wavefront has
+// the same work in every layer whatever the two networks' widths are (the critic of the A1 task is 1.5x the actor: with one
+// network per workgroup the actor's CUs idle a third of the call), the 1-tile last layers land on two different SIMDs instead
+// of being padded to eight tiles, and each SIMD carries two wavefronts for the whole call.  4096 rows = 256 workgroups = one
+// per CU.  LDS: two activation buffers per network, 4 x 32 KB.  Both networks must have the same number of layers (one
+// barrier per layer).  16 wavefronts per workgroup (4 per SIMD, 1 - 2 tiles each) by default: the kernel enters a rollout loop
+// with cold caches (the env step ran in between) and four wavefronts per SIMD ride out the misses that two cannot
+// (RL_MLP_FUSED_WAVES=8 selects the 8-wavefront build: same speed with warm caches, 12 us slower cold).
+// Measured and dropped: an explicit L2 warm-up sweep of the weight image at kernel start (+5 us in the loop), a deeper
+// asm-pinned weight pipeline (the L2-hit latency of ~200 cycles is already covered; +3 us).
+template <int WAVES>
+__device__ __forceinline__ void stage_rows(const MlpParams& P, const float* __restrict__ x, float* __restrict__ dst, int row0, int n_rows, int lane, int wave) {
+  // 16 rows over WAVES wavefronts (rows wave, wave + WAVES, ...); every load of the wavefront is in flight before the first LDS
+  // write (the rows were just written by another kernel: each is an L2 miss, and a load -> wait -> write loop pays that per load)
+  constexpr int JMAX = KMAX / 64, H = MT / WAVES;
+  const int K0 = P.KB[0] * 16;
+  float v[H][JMAX];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const int r = wave + WAVES * h;
+    const bool live = row0 + r < n_rows;
+    const float* __restrict__ xr = x + (size_t)(row0 + r) * P.in_dim;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int c = lane + 64 * j;
+      v[h][j] = (64 * j < K0 && live && c < P.in_dim) ? xr[c] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int c = lane + 64 * j;
+      if (64 * j < K0 && c < K0) dst[lds_index(wave + WAVES * h, c)] = v[h][j];
+    }
+}
+
+// the tiles first, first + WAVES, ... < nt of layer l (none: returns)
+template <int WAVES>
+__device__ __forceinline__ void fused_segment(const MlpParams& P, int l, const float* xin, float* xout, float* y, int row0, int n_rows, int lane, int first) {
+  const int nt = (P.N[l] + 15) >> 4;
+  if (first >= nt) return;
+  const int cnt = (nt - first + WAVES - 1) / WAVES;
+  if constexpr (WAVES == 8) {
+    switch (cnt) {
+      case 1: layer<1, 1, WAVES>(P, l, xin, xout, y, row0, n_rows, lane, first); break;
+      case 2: layer<2, 1, WAVES>(P, l, xin, xout, y, row0, n_rows, lane, first); break;
+      case 3: layer<3, 1, WAVES>(P, l, xin, xout, y, row0, n_rows, lane, first); break;
+      default: layer<4, 1, WAVES>(P, l, xin, xout, y, row0, n_rows, lane, first); break;  // 512 columns = 32 tiles = 4 per wavefront
+    }
+  } else {
+    if (cnt == 1) layer<1, 1, WAVES>(P, l, xin, xout, y, row0, n_rows, lane, first);
+    else layer<2, 1, WAVES>(P, l, xin, xout, y, row0, n_rows, lane, first);  // 512 columns = 32 tiles = 2 per wavefront
+  }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mlp_fused_pair_kernel(MlpPair q, int n_rows) {
+  extern __shared__ float4 smem4[];
+  constexpr int TILE = MT * KMAX;
+  float* bufA = reinterpret_cast<float*>(smem4);
+  float* bufB = bufA + 2 * TILE;
+  const MlpParams& A = *q.a;
+  const MlpParams& B = *q.b;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * MT;
+  MLP_STAMP(0);
+  stage_rows<WAVES>(A, q.xa, bufA, row0, n_rows, lane, wave);
+  stage_rows<WAVES>(B, q.xb, bufB, row0, n_rows, lane, wave);
+  MLP_STAMP(1);
+  __syncthreads();
+  MLP_STAMP(2);
+  int cur = 0;
+  const bool a_first = ((wave >> 2) & 1) == 0;
+  for (int l = 0; l < A.n_layers; ++l) {
+    const int ntA = (A.N[l] + 15) >> 4;
+    const int firstB = (wave - ntA) & (WAVES - 1);  // B's tiles continue A's round-robin
+    // Wavefronts that share a SIMD (w, w + 4, ...) take their two segments in alternating order: the pipeline fill / bias + ELU +
+    // LDS-store drain of one (several thousand cycles per segment, whatever its length) falls into another one's MFMA stream.
+    // ONE call site (the network is picked by a wavefront-uniform pointer): the layer code is inlined once, not four times -
+    // the kernel must fit the instruction cache, which it enters cold in a rollout loop (the env step ran in between).
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const bool isA = (h == 0) == a_first;
+      const MlpParams& P = isA ? A : B;
+      float* buf = isA ? bufA : bufB;
+      fused_segment<WAVES>(P, l, buf + cur * TILE, buf + (cur ^ 1) * TILE, isA ? q.ya : q.yb, row0, n_rows, lane, isA ? wave : firstB);
+      MLP_STAMP(3 + 3 * l + h);
+    }
+    __syncthreads();
+    MLP_STAMP(5 + 3 * l);
+    cur ^= 1;
+  }
 }
 
 std::string& err() {
@@ -269,25 +377,63 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
 int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b, const float* xb_dev, float* yb_dev, int32_t n_rows, void* stream) {
   if (!a || !b || !xa_dev || !ya_dev || !xb_dev || !yb_dev) return fail("null argument");
   if (n_rows <= 0) return 0;
-  // 32-row, 8-wavefront workgroups once they fill the chip (2 networks x n_rows / 32 >= 256 CUs); RL_MLP_PAIR_RT overrides (1 | 2)
+  // fused (one workgroup = 16 rows of BOTH networks, balanced) once its n_rows / 16 workgroups fill the chip; below that one
+  // network per workgroup (twice the workgroups).  RL_MLP_PAIR_MODE=fused|split overrides; RL_MLP_PAIR_RT=1|2 picks the split tile.
   static const int forced = [] { const char* e = getenv("RL_MLP_PAIR_RT"); return e ? atoi(e) : 0; }();
+  static const int mode = [] { const char* e = getenv("RL_MLP_PAIR_MODE"); return !e ? 0 : (e[0] == 'f' ? 1 : 2); }();
+  const bool fused = a->P.n_layers == b->P.n_layers && (mode == 1 || (mode == 0 && n_rows >= 3072));
   const int RT = forced == 1 || forced == 2 ? forced : (n_rows >= 4096 ? 2 : 1);
-  const size_t lds = sizeof(float) * 2 * MT * KMAX * RT;
+  const size_t lds = fused ? sizeof(float) * 4 * MT * KMAX : sizeof(float) * 2 * MT * KMAX * RT;
   if (a->device != b->device) return fail("the two networks live on different devices");
   if (hipSetDevice(a->device) != hipSuccess) return fail("hipSetDevice failed");
   static bool attr_done[64] = {};  // the LDS opt-in belongs to the (kernel, device) pair
   if (!attr_done[a->device & 63]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 2 * MT * KMAX)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * MT * KMAX)) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * MT * KMAX)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_pair_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * MT * KMAX)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_pair_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 4 * MT * KMAX)) != hipSuccess)
       return fail("cannot reserve the LDS of the paired kernel");
     attr_done[a->device & 63] = true;
   }
-  MlpPair q{a->dP, b->dP, xa_dev, xb_dev, ya_dev, yb_dev};
+  MlpPair q{a->dP, b->dP, xa_dev, xb_dev, ya_dev, yb_dev, nullptr};
+#ifdef RL_MLP_CLOCK
+  static unsigned long long* clk = nullptr;
+  const int n_wg = (n_rows + MT - 1) / MT;
+  if (!clk) (void)hipMalloc(&clk, sizeof(unsigned long long) * 128 * 8192);
+  q.clk = clk;
+#endif
   const int tiles = (n_rows + RT * MT - 1) / (RT * MT);
-  if (RT == 2)
+  static const int fw = [] { const char* e = getenv("RL_MLP_FUSED_WAVES"); return e ? atoi(e) : 16; }();
+  if (fused && fw == 16)
+    hipLaunchKernelGGL(mlp_fused_pair_kernel<16>, dim3((n_rows + MT - 1) / MT), dim3(1024), lds, (hipStream_t)stream, q, n_rows);
+  else if (fused)
+    hipLaunchKernelGGL(mlp_fused_pair_kernel<8>, dim3((n_rows + MT - 1) / MT), dim3(512), lds, (hipStream_t)stream, q, n_rows);
+  else if (RT == 2)
     hipLaunchKernelGGL((mlp_forward_pair_kernel<2, 8>), dim3(2 * tiles), dim3(512), lds, (hipStream_t)stream, q, n_rows);
   else
     hipLaunchKernelGGL((mlp_forward_pair_kernel<1, 4>), dim3(2 * tiles), dim3(256), lds, (hipStream_t)stream, q, n_rows);
+#ifdef RL_MLP_CLOCK
+  static int calls = 0;
+  if (fused && ++calls == 100) {  // one report: per-phase cycles of every wavefront, averaged over the workgroups
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)n_wg * 128);
+    (void)hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+    const int ns = 3 + 3 * a->P.n_layers;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int g = 0; g < n_wg; ++g)
+      for (int w = 0; w < 8; ++w) { t0 = std::min(t0, h[(size_t)g * 128 + w * 16]); t1 = std::max(t1, h[(size_t)g * 128 + w * 16 + ns - 1]); }
+    printf("[mlp clock] %d workgroups, first stamp -> last stamp: %llu cycles\n", n_wg, t1 - t0);
+    for (int w = 0; w < 8; ++w) {
+      printf("[mlp clock] wave %d: start+%6.0f |", w, [&] { double s = 0; for (int g = 0; g < n_wg; ++g) s += (double)(h[(size_t)g * 128 + w * 16] - t0); return s / n_wg; }());
+      for (int i = 1; i < ns; ++i) {
+        double s = 0;
+        for (int g = 0; g < n_wg; ++g) s += (double)(h[(size_t)g * 128 + w * 16 + i] - h[(size_t)g * 128 + w * 16 + i - 1]);
+        printf(" %6.0f", s / n_wg);
+      }
+      printf("\n");
+    }
+  }
+#endif
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
 }

@@ -92,19 +92,23 @@ def test_hip_mlp_from_rsl_rl_state_dict_and_env_obs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [4096, 37])
-def test_hip_mlp_pair_is_bitwise_the_two_single_launches(N):
-    """rl_mlp_forward_pair (actor + critic in one launch) = the same row tiles through the same code: identical bits."""
+@pytest.mark.parametrize("N,da,dc", [(4096, [45, 512, 256, 128, 12], [235, 512, 256, 128, 1]), (37, [45, 512, 256, 128, 12], [235, 512, 256, 128, 1]),
+                                     (4099, [45, 512, 256, 128, 12], [235, 512, 256, 128, 1]),  # fused kernel, ragged last row tile
+                                     (3100, [96, 400, 200, 29], [310, 512, 136, 1]),            # widths that are no multiples of 128 / 16
+                                     (3072, [45, 64, 12], [235, 512, 1])])                        # two layers, very different networks
+def test_hip_mlp_pair_is_bitwise_the_two_single_launches(N, da, dc):
+    """rl_mlp_forward_pair (actor + critic in one launch; from 3072 rows on the fused kernel that runs both networks on a row
+    tile) = the same k-ordered MFMA chains as the single launches: identical bits."""
     import torch
 
     from robot_lab_amd.policy import MlpPolicy
 
-    wa, ba = _net([45, 512, 256, 128, 12], 5)
-    wc, bc = _net([235, 512, 256, 128, 1], 6)
+    wa, ba = _net(da, 5)
+    wc, bc = _net(dc, 6)
     actor, critic = MlpPolicy(wa, ba, "elu", device="cuda:0"), MlpPolicy(wc, bc, "elu", device="cuda:0")
     rng = np.random.default_rng(7)
-    xo = torch.from_numpy(rng.uniform(-2, 2, (N, 45)).astype(np.float32)).cuda()
-    xc = torch.from_numpy(rng.uniform(-2, 2, (N, 235)).astype(np.float32)).cuda()
+    xo = torch.from_numpy(rng.uniform(-2, 2, (N, da[0])).astype(np.float32)).cuda()
+    xc = torch.from_numpy(rng.uniform(-2, 2, (N, dc[0])).astype(np.float32)).cuda()
     ya, yc = actor(xo).clone(), critic(xc).clone()
     pa, pc = actor.forward_pair(xo, critic, xc)
     assert torch.equal(pa, ya) and torch.equal(pc, yc)
