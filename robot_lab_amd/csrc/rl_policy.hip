@@ -61,27 +61,50 @@ __device__ inline int lds_index(int row, int k) { return ((((k >> 4) * 4 + (k & 
 template <int TPW, int RT, int WAVES>
 __device__ inline void layer(const MlpParams& P, int l, const float* __restrict__ xin, float* __restrict__ xout, float* __restrict__ y, int row0,
                              int n_rows, int lane, int wave) {  // wave: index of this wavefront's first tile (tiles wave, wave + WAVES, ...)
-  const int KB = P.KB[l];
-  const int NT = 8 * P.NT8[l];     // tiles per k block in the weight image (>= WAVES * TPW: only the tiles that carry
-                                   // real or next-layer-padding columns are computed)
+  // Everything that is the same for the 64 lanes is moved into SGPRs by hand: the parameter block may be reached through a
+  // pointer the compiler cannot prove uniform, and then the k-block count, the tile stride and the weight pointer live in VGPRs
+  // and every weight load costs 64-bit VALU address arithmetic (two v_mul_lo_u32 + a v_mad_u64_u32 per k block).  That is not
+  // free here: the f32 MFMA runs at the vector rate and VALU instructions do NOT issue in its shadow (tools/micro/mfma_rate.hip:
+  // 2 VALU per MFMA cost 25 %).  With scalar bases a weight load is `global_load_dwordx4 v, v_lane16, s[base]`.
+  const int KB = __builtin_amdgcn_readfirstlane(P.KB[l]);
+  const int NT = 8 * __builtin_amdgcn_readfirstlane(P.NT8[l]);  // tiles per k block in the weight image (>= WAVES * TPW: only the
+                                                                // tiles that carry real or next-layer-padding columns are computed)
+  const int Nl = __builtin_amdgcn_readfirstlane(P.N[l]);
+  wave = __builtin_amdgcn_readfirstlane(wave);
+  auto uniform_ptr = [](const float* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  };
+  const uint64_t Wu = uniform_ptr(P.W[l]), bu = uniform_ptr(P.b[l]);
   constexpr int TILE = MT * KMAX;  // floats of one 16-row LDS tile
-  const bool last = l == P.n_layers - 1;
-  f32x4 acc[RT][TPW];
+  const bool last = l == __builtin_amdgcn_readfirstlane(P.n_layers) - 1;
+  // TWO accumulators per output tile (even / odd k-steps, summed in the epilogue): a dependent v_mfma_f32_16x16x4_f32 can start
+  // 40 cycles after its predecessor, an independent one after 32, so a wavefront that owns ONE tile (the 16-wavefront kernel's
+  // 256- and 128-wide layers) would issue a dependent chain.  Every kernel of this file uses the same split, so they all produce
+  // the same bits.  (Measured effect: none - the wavefronts of a SIMD cover each other's dependent gaps; kept because it costs
+  // one add per output and removes the question.)
+  f32x4 acc[RT][TPW][2];
 #pragma unroll
   for (int r = 0; r < RT; ++r)
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TPW; ++t) acc[r][t][0] = acc[r][t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;                                    // + kb * 64 (+ r * TILE / 4)
   // the weight pointer is loaded from the parameter block, so the compiler would fall back to FLAT loads (they count on
   // vmcnt AND lgkmcnt: every wait for an LDS operand then drains the whole weight pipeline) - say that it is global memory
   typedef const f32x4 __attribute__((address_space(1))) * GlobalV4;
-  const GlobalV4 wb = (GlobalV4)(uintptr_t)P.W[l] + (size_t)wave * 64 + lane;                       // + (kb * NT + WAVES t) * 64
+  const uint32_t lane16 = (uint32_t)lane * 16u;                                                     // the only per-lane part of a weight address
   // software pipeline, two k blocks deep: the operands of blocks kb + 1 and kb + 2 are in flight while block kb's
   // 4 x TPW x RT MFMAs issue (an L2 hit is ~600-800 cycles, a block's MFMAs are 128 x TPW x RT cycles)
   auto load_b = [&](int kb, f32x4 (&b)[TPW]) {
+#ifdef MLP_ABL_NOLOAD  // kernel analysis: the weight fragments of the first blocks are reused for the whole layer (wrong results)
+    if (kb > 2) return;
+#endif
     const int kc = kb < KB ? kb : KB - 1;  // clamped: the tail re-reads the last block instead of branching
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) b[t] = wb[((size_t)kc * NT + WAVES * t) * 64];
+    for (int t = 0; t < TPW; ++t) {
+      const uint64_t tile = Wu + ((uint64_t)(uint32_t)(kc * NT + wave + WAVES * t) << 10);  // scalar: 1 KB per (k block, tile)
+      b[t] = *(GlobalV4)(uintptr_t)(tile + lane16);
+    }
   };
   f32x4 b0[TPW], b1[TPW], b2[TPW];
   load_b(0, b0);
@@ -89,17 +112,26 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
   // the epilogue's biases travel with the first weight blocks (loaded at the end they are one more exposed L2 round trip)
   float bias_r[TPW];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) bias_r[t] = ((const float __attribute__((address_space(1)))*)(uintptr_t)P.b[l])[(wave + WAVES * t) * 16 + (lane & 15)];
+  for (int t = 0; t < TPW; ++t) bias_r[t] = *(const float __attribute__((address_space(1)))*)(uintptr_t)(bu + (uint64_t)(uint32_t)((wave + WAVES * t) * 64) + (uint32_t)((lane & 15) * 4));
   auto mma = [&](int kb, const f32x4 (&b)[TPW]) {
     f32x4 a[RT];
 #pragma unroll
+#ifdef MLP_ABL_NOLDS  // kernel analysis: one activation block for the whole layer (wrong results)
+    for (int r = 0; r < RT; ++r) a[r] = xa[r * (TILE / 4)];
+#else
     for (int r = 0; r < RT; ++r) a[r] = xa[kb * 64 + r * (TILE / 4)];
+#endif
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int r = 0; r < RT; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][s], b[t][s], acc[r][t], 0, 0, 0);
+        for (int r = 0; r < RT; ++r) {
+          acc[r][t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][s], b[t][s], acc[r][t][s & 1], 0, 0, 0);
+#ifdef MLP_PIN  // kernel analysis: pin the issue order (hipcc sorts the MFMAs into runs on one accumulator); measured +3 %, i.e. worse
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
   };
   int kb = 0;
   for (; kb + 3 <= KB; kb += 3) {  // rotate the three buffers by unrolling three blocks
@@ -116,19 +148,23 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
   }
   // epilogue: D[row = (lane >> 4) * 4 + reg][col = lane & 15] -> bias, activation -> next LDS tile / global
   const int col = lane & 15, rbase = (lane >> 4) * 4;
-  const int act = P.act;  // wave-uniform: the selects below become scalar branches around straight-line code
+  const int act = __builtin_amdgcn_readfirstlane(P.act);  // wave-uniform: the selects below become scalar branches around straight-line code
   // lds_index(rbase + r, (wave + WAVES t) * 16 + col) = lane-constant + 256 WAVES t + 4 r
   const int obase = wave * 256 + (col & 3) * 64 + rbase * 4 + ((col >> 2) & 3);
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int n = (wave + WAVES * t) * 16 + col;
     const float bias = bias_r[t];
-    const bool valid = n < P.N[l];
+    const bool valid = n < Nl;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = acc[rt][t][r] + bias;
+        const float v = (acc[rt][t][0][r] + acc[rt][t][1][r]) + bias;
+#ifdef MLP_ABL_NOEPI  // kernel analysis: no activation, one store per accumulator register group (wrong results)
+        if (r == 0 && v == 1.2345e-30f) xout[0] = v;
+        continue;
+#endif
         if (!last) {
           const float av = act == RL_ACT_ELU ? (v > 0.f ? v : __expf(v) - 1.0f) : act == RL_ACT_RELU ? fmaxf(v, 0.f) : tanhf(v);
           xout[rt * TILE + obase + 256 * WAVES * t + 4 * r] = valid ? av : 0.f;  // padded columns feed zeros into the next layer
@@ -158,23 +194,14 @@ __device__ __forceinline__ void mlp_tile(const MlpParams& P, const float* __rest
   float *cur = buf0, *nxt = buf1;
   for (int l = 0; l < P.n_layers; ++l) {
     const int tpw = ((P.N[l] + 15) / 16 + WAVES - 1) / WAVES;  // 16-column tiles per wavefront that carry output columns
-    if constexpr (WAVES == 4) {
-      switch (tpw) {
-        case 1: layer<1, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        case 2: layer<2, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        case 3: layer<3, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        case 4: layer<4, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        case 5: layer<5, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        case 6: layer<6, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        case 7: layer<7, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        default: layer<8, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-      }
-    } else {
-      switch (tpw) {
-        case 1: layer<1, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        case 2: layer<2, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        case 3: layer<3, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
-        default: layer<4, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, wave); break;
+    // at most 4 tiles (8 accumulators) per wavefront and pass: wider layers take two passes over the input tile (LDS re-read)
+    for (int done = 0; done < tpw; done += 4) {
+      const int first = wave + WAVES * done;
+      switch (tpw - done >= 4 ? 4 : tpw - done) {
+        case 1: layer<1, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, first); break;
+        case 2: layer<2, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, first); break;
+        case 3: layer<3, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, first); break;
+        default: layer<4, RT, WAVES>(P, l, cur, nxt, y, row0, n_rows, lane, first); break;
       }
     }
     __syncthreads();
@@ -197,7 +224,7 @@ struct MlpPair {
   unsigned long long* clk;  // -DRL_MLP_CLOCK: [workgroup][16] s_memtime stamps of wavefront 0 (kernel analysis builds only)
 };
 #ifdef RL_MLP_CLOCK
-#define MLP_STAMP(i) do { if ((threadIdx.x & 63) == 0) q.clk[(size_t)blockIdx.x * 128 + ((threadIdx.x >> 6) & 7) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define MLP_STAMP(i) do { if ((threadIdx.x & 63) == 0) q.clk[(size_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MLP_STAMP(i) do { } while (0)
 #endif
@@ -399,7 +426,7 @@ int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b
 #ifdef RL_MLP_CLOCK
   static unsigned long long* clk = nullptr;
   const int n_wg = (n_rows + MT - 1) / MT;
-  if (!clk) (void)hipMalloc(&clk, sizeof(unsigned long long) * 128 * 8192);
+  if (!clk) (void)hipMalloc(&clk, sizeof(unsigned long long) * 256 * 8192);
   q.clk = clk;
 #endif
   const int tiles = (n_rows + RT * MT - 1) / (RT * MT);
@@ -416,18 +443,22 @@ int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b
   static int calls = 0;
   if (fused && ++calls == 100) {  // one report: per-phase cycles of every wavefront, averaged over the workgroups
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h((size_t)n_wg * 128);
+    std::vector<unsigned long long> h((size_t)n_wg * 256);
     (void)hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
-    const int ns = 3 + 3 * a->P.n_layers;
-    unsigned long long t0 = ~0ull, t1 = 0;
-    for (int g = 0; g < n_wg; ++g)
-      for (int w = 0; w < 8; ++w) { t0 = std::min(t0, h[(size_t)g * 128 + w * 16]); t1 = std::max(t1, h[(size_t)g * 128 + w * 16 + ns - 1]); }
-    printf("[mlp clock] %d workgroups, first stamp -> last stamp: %llu cycles\n", n_wg, t1 - t0);
-    for (int w = 0; w < 8; ++w) {
-      printf("[mlp clock] wave %d: start+%6.0f |", w, [&] { double s = 0; for (int g = 0; g < n_wg; ++g) s += (double)(h[(size_t)g * 128 + w * 16] - t0); return s / n_wg; }());
+    const int ns = 3 + 3 * a->P.n_layers, nw = fw == 16 ? 16 : 8;
+    // per workgroup: span from the earliest first stamp to the latest last stamp of its wavefronts; then the phases per wavefront
+    double span = 0;
+    for (int g = 0; g < n_wg; ++g) {
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (int w = 0; w < nw; ++w) { t0 = std::min(t0, h[(size_t)g * 256 + w * 16]); t1 = std::max(t1, h[(size_t)g * 256 + w * 16 + ns - 1]); }
+      span += (double)(t1 - t0);
+    }
+    printf("[mlp clock] %d workgroups x %d wavefronts, mean first stamp -> last stamp per workgroup: %.0f ticks\n", n_wg, nw, span / n_wg);
+    for (int w = 0; w < nw; ++w) {
+      printf("[mlp clock] wave %2d:", w);
       for (int i = 1; i < ns; ++i) {
         double s = 0;
-        for (int g = 0; g < n_wg; ++g) s += (double)(h[(size_t)g * 128 + w * 16 + i] - h[(size_t)g * 128 + w * 16 + i - 1]);
+        for (int g = 0; g < n_wg; ++g) s += (double)(h[(size_t)g * 256 + w * 16 + i] - h[(size_t)g * 256 + w * 16 + i - 1]);
         printf(" %6.0f", s / n_wg);
       }
       printf("\n");
