@@ -8,13 +8,12 @@
 //   * by g++ for the CPU lane emulator (tests/emu): Ctx = 4 x SUB host threads + a barrier.  That build is
 //     test infrastructure for `-m "not gpu"` CI only and is never loaded by the product path.
 //
-// Physics (DESIGN.md "Simulator"): floating-base articulation = a trunk (base + NW serial joints, G1:
-// the waist) carrying 4 limb chains; composite-rigid-body inertia and RNEA bias in BASE coordinates;
-// linearly-implicit contact / joint-limit / PD terms; the (NB+CL) x (NB+CL) per-lane system (NB = 6 +
-// NW trunk DoF) is reduced by a Schur complement onto the trunk DoF, the four limbs' NB x NB
-// contributions are summed with wavefront shuffles, every lane solves the trunk system redundantly
-// and back-substitutes its own chain.  Same equations as oracle/physics.py, different formulation
-// (that one is generic-tree, dense, fp64, link coordinates).
+// Physics (DESIGN.md "Simulator"): floating-base articulation = a trunk (base + NW serial joints, G1: the waist) carrying 4
+// limb chains; link inertias, velocities and bias forces in BASE coordinates; linearly-implicit contact / joint-limit / PD terms.
+// The velocity-level system (H + A) nu+ = rhs is solved by an articulated-body recursion: every limb is eliminated joint by joint
+// from the tip (6 x 6 symmetric link records, a contact is a 6 x 6 block on its link), the limbs' articulated inertias meet at the
+// base (DPP sums / ds_add_f32), every lane solves the 6 x 6 base system redundantly and walks its own chain outwards.  Same
+// equations as oracle/physics.py, different formulation (that one is generic-tree, dense, fp64, link coordinates).
 #pragma once
 #include <type_traits>
 
@@ -964,6 +963,21 @@ struct EnvLane {
   RL_FN float* va_words(int j) const { return ctx.limb_scratch() + (LB_VA + j * 12) * LBS; }
   RL_FN float* trunk_words(int d) const { return ctx.env_scratch() + d * LINK_REC; }
 
+  // twist of trunk link `depth` (0 = the base: `base`; i + 1 = behind trunk joint i: arr[i]) for a per-lane depth.  A 0/1-weighted
+  // sum, not a select chain: hipcc turns the chain into an indexed load from a SCRATCH copy of the array (112 bytes of private
+  // memory per lane and 48 scratch instructions on the G1 instance).
+  RL_FN SV pick_trunk(const SV& base, const SV (&arr)[NW > 0 ? NW : 1], int depth) const {
+    float w0 = depth == 0 ? 1.f : 0.f;
+    SV r{w0 * base.a, w0 * base.l};
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const float w = depth == i + 1 ? 1.f : 0.f;
+      r.a += w * arr[i].a;
+      r.l += w * arr[i].l;
+    }
+    return r;
+  }
+
   // P -= (P S)(P S)^T / D etc. for one joint with motion subspace s6 and joint-local terms (D0, u0); returns U / D and u / D
   RL_FN void eliminate(LinkRec& P, const float (&s6)[6], float D, float uu, float (&Uh)[6], float& ui) const {
     float U6[6];
@@ -1083,9 +1097,7 @@ struct EnvLane {
           const float* w = va_words(l);
           Vg = SV{{w[0 * LBS], w[1 * LBS], w[2 * LBS]}, {w[3 * LBS], w[4 * LBS], w[5 * LBS]}};
         } else {
-#pragma unroll
-          for (int i = 0; i < NW; ++i)
-            if (L.grp0_depth == i + 1) Vg = Vw[i];
+          Vg = pick_trunk(V0, Vw, L.grp0_depth);
         }
         group_contacts<it.value>(Rwb, Vg, gf, rec, active_mask);
       }
@@ -1141,10 +1153,7 @@ struct EnvLane {
         M3 Rf;
         V3 pf;
         trunk_frame<TP>(C, k, Rf, pf);
-        SV Vl = V0, al = a0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-          if (k == i + 1) { Vl = Vw[i]; al = aw[i]; }
+        const SV Vl = pick_trunk(V0, Vw, k), al = pick_trunk(a0, aw, k);
         const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
         const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
         SV fx{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
