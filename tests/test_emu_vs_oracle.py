@@ -96,15 +96,16 @@ def test_resets_and_logs(emu_lib):
     nat.close()
 
 
-def test_sixteen_lane_mapping_matches_oracle(emu_lib, monkeypatch):
-    """The 16-lanes-per-env mapping (a DPP quad per leg; the default on the GPU) run by 16 host threads."""
+@pytest.mark.parametrize("task,N,steps", [(TASKS[1], 16, 2), (TASKS[3], 8, 2), (TASKS[5], 4, 3)])  # A1, Go2W (4-joint chains), G1 (trunk + limbs)
+def test_sixteen_lane_mapping_matches_oracle(task, N, steps, emu_lib, monkeypatch):
+    """The 16-lanes-per-env mapping (a DPP quad per limb; the default on the GPU: link groups dealt to the sub-lanes, contact
+    stash, the trunk instance's limb-shared records) run by 16 host threads per env."""
     monkeypatch.setenv("RL_EMU_SUB", "4")
-    task, N = TASKS[1], 16
     desc, ora, nat = make_pair(task, N, 21, emu_lib)
     o = ora.reset()
     nat.reset()
     rng = np.random.default_rng(5)
-    for s in range(2):
+    for s in range(steps):
         a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
         o = ora.step(a)
         nat.step(a.ctypes.data)
