@@ -22,6 +22,261 @@ enum ObsKind {
   OBS_JOINT_VEL_REL, OBS_LAST_ACTION, OBS_HEIGHT_SCAN, OBS_JOINT_POS_REL_NO_WHEEL
 };
 
+// ---- reward terms: tables, env scalars, and the evaluation of ONE term by ONE lane (used by the lane program and by the terms
+// kernel of the split path) ------------------------------------------------------------------------------------------------
+enum { JS_TAU2 = 0, JS_ACC2, JS_QD2, JS_LIMIT, JS_POWER, JS_DEV1, JS_DEV2, JS_DA2, JS_Q, JS_ABSQD, JS_ROWS };  // = env_tables.h REW_JS_ROWS
+enum { BT_HMAX = 0, BT_CA, BT_CC, BT_LA, BT_LC, BT_FX, BT_FY, BT_FZ, BT_PX, BT_PY, BT_PZ, BT_VX, BT_VY, BT_VZ, BT_NF };  // = REW_BT_NF
+static_assert(JS_ROWS == REW_JS_ROWS && BT_NF == REW_BT_NF, "reward tables: LDS sizing in env_tables.h");
+
+struct RewEnv {
+  float gate, cmd_norm, bv, fc_hi, moving;
+  bool terminated;
+  const float* JT;  // [JS_ROWS][D]
+  const float* BT;  // [n_bodies][BT_NF]
+  int D;
+  // the env's own scalars a term may read (the lane program's registers, or the record of the split path)
+  V3 cmd, lin_b, ang_b, lin_w, vang, grav_b, pos;
+  float yaw_c, yaw_s;
+  M3 Rwb;
+};
+
+// unweighted value of one term, evaluated by ONE lane
+template <class TabT>
+RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ terrain, const RewTab& R, const RewEnv& E) {
+  const float gate = E.gate, cmd_norm = E.cmd_norm, bv = E.bv, moving = E.moving;
+  const float* BT = E.BT;
+  const int32_t* ia = T.idx_pool_a + R.idx_off;
+  const int32_t* ib = T.idx_pool_b + R.idx_off;
+  auto first_c = [&](const float* r) { return r[BT_CC] > 0.f && r[BT_CC] < E.fc_hi; };   // ContactSensor.compute_first_contact(step_dt)
+  auto first_a = [&](const float* r) { return r[BT_CA] > 0.f && r[BT_CA] < E.fc_hi; };   // compute_first_air(step_dt)
+  // joint-sum kinds share one loop: R.row = row of the joint-statistics table (host: rl_env_host.h), -1 for every other kind
+  // (8 columns per trip, all LDS reads of a trip in flight together: a lone wavefront cannot hide a round trip per joint)
+  float js = 0.f;
+  if (R.row >= 0) {
+    const float* g = E.JT + R.row * E.D;
+    for (int j0 = 0; j0 < E.D; j0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v[w] = g[j0 + w];  // columns >= D: reads inside the tables, dropped by the mask (the host keeps joint masks below 1 << D)
+#pragma unroll
+      for (int w = 0; w < 8; ++w) js += ((R.joint_mask >> (j0 + w)) & 1u) ? v[w] : 0.f;
+    }
+  }
+  float f = 0.f;
+  switch (R.kind) {
+    case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
+      float ex = E.cmd.x - E.lin_b.x, ey = E.cmd.y - E.lin_b.y;
+      f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
+    } break;
+    case REW_TRACK_ANG_VEL_Z_EXP: {  // rewards.py:38-48
+      float ez = E.cmd.z - E.ang_b.z;
+      f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
+    } break;
+    case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // rewards.py:51-66: root COM velocity in the yaw-only frame
+      float ex = E.cmd.x - (E.yaw_c * E.lin_w.x + E.yaw_s * E.lin_w.y), ey = E.cmd.y - (-E.yaw_s * E.lin_w.x + E.yaw_c * E.lin_w.y);
+      f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
+    } break;
+    case REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // rewards.py:69-78
+      float ez = E.cmd.z - E.vang.z;
+      f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
+    } break;
+    case REW_LIN_VEL_Z_L2: f = E.lin_b.z * E.lin_b.z * gate; break;                         // rewards.py:647-653
+    case REW_ANG_VEL_XY_L2: f = (E.ang_b.x * E.ang_b.x + E.ang_b.y * E.ang_b.y) * gate; break;  // rewards.py:656-662
+    case REW_FLAT_ORIENTATION_L2: f = (E.grav_b.x * E.grav_b.x + E.grav_b.y * E.grav_b.y) * gate; break;  // rewards.py:678-687
+    case REW_UPWARD: f = (1.f - E.grav_b.z) * (1.f - E.grav_b.z); break;                     // rewards.py:608-613
+    case REW_IS_TERMINATED: f = E.terminated ? 1.f : 0.f; break;
+    // joint sums [UPSTREAM isaaclab.envs.mdp] + rewards.py:81-90: the statistic is in the table, the mask picked the joints
+    case REW_JOINT_TORQUES_L2: case REW_JOINT_ACC_L2: case REW_JOINT_VEL_L2: case REW_JOINT_POS_LIMITS: case REW_JOINT_POWER:
+    case REW_JOINT_DEVIATION_L1: case REW_ACTION_RATE_L2:
+      f = js;
+      break;
+    case REW_STAND_STILL: f = js * (cmd_norm < R.p[0] ? 1.f : 0.f) * gate; break;  // rewards.py:93-104
+    case REW_JOINT_POS_PENALTY: {  // rewards.py:107-129
+      float run = fsqrt(js);
+      f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
+    } break;
+    case REW_JOINT_MIRROR: {  // rewards.py:259-278
+      const float* qt = E.JT + JS_Q * E.D;
+      float part = 0.f;
+      for (int i0 = 0; i0 < R.n_idx; i0 += 4) {  // 4 pairs per trip: index reads, then the 8 position reads, in flight together
+        int a4[4], b4[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a4[w] = ia[i0 + w < R.n_idx ? i0 + w : i0]; b4[w] = ib[i0 + w < R.n_idx ? i0 + w : i0]; }
+        float qa[4], qb[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { qa[w] = qt[a4[w]]; qb[w] = qt[b4[w]]; }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float d = qa[w] - qb[w];
+          part += i0 + w < R.n_idx ? d * d : 0.f;
+        }
+      }
+      f = part * R.p[0] * gate;
+    } break;
+    case REW_WHEEL_VEL_PENALTY: {  // rewards.py:132-153: pairs (wheel body, wheel joint)
+      const float* aq = E.JT + JS_ABSQD * E.D;
+      const bool running = cmd_norm > R.p[1] || bv > R.p[0];
+      float part = 0.f;
+      for (int i = 0; i < R.n_idx; ++i) part += (running ? (first_a(BT + ia[i] * BT_NF) ? 1.f : 0.f) : 1.f) * aq[ib[i]];
+      f = part;
+    } break;
+    case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256: product of exponentials = exponential of the sum
+      float air[4], con[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* r = BT + ia[i] * BT_NF;
+        air[i] = r[BT_CA];
+        con[i] = r[BT_CC];
+      }
+      const float inv_std = frcp(R.p[0]), me2 = R.p[1] * R.p[1];
+      auto se = [&](float a, float b) { float d = a - b; return fminf(d * d, me2); };
+      float acc = se(air[0], air[1]) + se(con[0], con[1]) + se(air[2], air[3]) + se(con[2], con[3]);
+      acc += se(air[0], con[2]) + se(con[0], air[2]) + se(air[1], con[3]) + se(con[1], air[3]);
+      acc += se(air[0], con[3]) + se(con[0], air[3]) + se(air[2], con[1]) + se(con[2], air[1]);
+      f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? fexp(-acc * inv_std) : 0.f) * gate;
+    } break;
+    case REW_FEET_DISTANCE_Y_EXP:
+    case REW_FEET_DISTANCE_XY_EXP: {  // rewards.py:439-461, 464-505: feet (link frames) against a stance rectangle in the base frame
+      float part = 0.f;
+      for (int i = 0; i < R.n_idx; ++i) {
+        const float* r = BT + ia[i] * BT_NF;
+        const float ey = ((i & 1) ? -0.5f : 0.5f) * R.p[1] - r[BT_PY];
+        const float ex = R.kind == REW_FEET_DISTANCE_XY_EXP ? (i < 2 ? 0.5f : -0.5f) * R.p[2] - r[BT_PX] : 0.f;
+        part += ex * ex + ey * ey;
+      }
+      f = fexp(-part * frcp(R.p[0])) * gate;
+    } break;
+    case REW_HANDSTAND_ORIENTATION_L2: {  // config/others/unitree_a1_handstand/env/rewards.py:50-59
+      const float dx = E.grav_b.x - R.p[0], dy = E.grav_b.y - R.p[1], dz = E.grav_b.z - R.p[2];
+      f = dx * dx + dy * dy + dz * dz;
+    } break;
+    case REW_BASE_HEIGHT_L2: {  // rewards.py:616-644; the 3 x 3 base ray caster (velocity_env_cfg.py:78-85)
+      float tgt = R.p[0];
+      if (R.p[1] > 0.5f) {
+        float hsum = 0.f;
+        for (int r9 = 0; r9 < 9; ++r9) {
+          const int iy = r9 / 3, ix = r9 - 3 * iy;
+          const float lx = (float)(ix - 1) * 0.05f, ly = (float)(iy - 1) * 0.05f;
+          float hz;
+          V3 nn;
+          terrain_sample(u, terrain, E.pos.x + E.yaw_c * lx - E.yaw_s * ly, E.pos.y + E.yaw_s * lx + E.yaw_c * ly, hz, nn);
+          hsum += hz;
+        }
+        tgt += hsum * (1.0f / 9.0f);
+      }
+      f = (E.pos.z - tgt) * (E.pos.z - tgt) * gate;
+    } break;
+    default: {  // sums over the bodies of the term's body mask
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, mn = 1e30f;
+      // 4 bodies per trip, their table rows read together (a lone wavefront cannot hide an LDS round trip per body)
+      for (uint64_t m = R.body_mask; m != 0ull;) {
+        const float* rr[4];
+        bool on[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          on[w] = m != 0ull;
+          rr[w] = BT + (on[w] ? __builtin_ctzll(m) : 0) * BT_NF;
+          m &= m - 1ull;  // (0 stays 0)
+        }
+        float hm[4], ca[4], cc[4], la[4], lc[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { hm[w] = rr[w][BT_HMAX]; ca[w] = rr[w][BT_CA]; cc[w] = rr[w][BT_CC]; la[w] = rr[w][BT_LA]; lc[w] = rr[w][BT_LC]; }
+        switch (R.kind) {
+          case REW_UNDESIRED_CONTACTS:  // rewards.py:665-675
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] && hm[w] > R.p[0] ? 1.f : 0.f;
+            break;
+          case REW_CONTACT_FORCES:  // [UPSTREAM] contact_forces
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] ? fmaxf(hm[w] - R.p[0], 0.f) : 0.f;
+            break;
+          case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT:  // rewards.py:416-425, 399-413
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] && cc[w] > 0.f && cc[w] < E.fc_hi ? 1.f : 0.f;
+            break;
+          case REW_FEET_AIR_TIME: case REW_HANDSTAND_FEET_AIR_TIME:  // rewards.py:340-360
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] && cc[w] > 0.f && cc[w] < E.fc_hi ? la[w] - R.p[0] : 0.f;
+            break;
+          case REW_FEET_AIR_TIME_POSITIVE_BIPED:  // rewards.py:363-383
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const bool inc = cc[w] > 0.f;
+              a0 += on[w] && inc ? 1.f : 0.f;
+              mn = on[w] ? fminf(mn, inc ? cc[w] : ca[w]) : mn;
+            }
+            break;
+          case REW_HANDSTAND_FEET_ON_AIR:  // .../env/rewards.py:31-37: counts the feet that have NOT just lifted
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] && !(ca[w] > 0.f && ca[w] < E.fc_hi) ? 1.f : 0.f;
+            break;
+          case REW_FEET_AIR_TIME_VARIANCE:  // rewards.py:386-397 (torch.var is unbiased)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const float xa = fminf(la[w], 0.5f), xc = fminf(lc[w], 0.5f), o = on[w] ? 1.f : 0.f;
+              a0 += o; a1 += o * xa; a2 += o * xa * xa; a3 += o * xc; a4 += o * xc * xc;
+            }
+            break;
+          case REW_FEET_STUMBLE:  // rewards.py:428-436
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const float fx = rr[w][BT_FX], fy = rr[w][BT_FY], fz = rr[w][BT_FZ];
+              a0 += on[w] && fsqrt(fx * fx + fy * fy) > 4.f * fabsf(fz) ? 1.f : 0.f;
+            }
+            break;
+          default: {  // the kinds that look at a foot's position / velocity relative to the root
+            V3 relp[4], relv[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              relp[w] = {rr[w][BT_PX], rr[w][BT_PY], rr[w][BT_PZ]};
+              relv[w] = {rr[w][BT_VX], rr[w][BT_VY], rr[w][BT_VZ]};
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              float v = 0.f;
+              if (R.kind == REW_FEET_HEIGHT_BODY) {  // rewards.py:527-554
+                const float er = relp[w].z - R.p[0];
+                v = er * er * ftanh(R.p[1] * fsqrt(relv[w].x * relv[w].x + relv[w].y * relv[w].y));
+              } else if (R.kind == REW_FEET_SLIDE) {  // rewards.py:557-587
+                v = hm[w] > 1.0f ? fsqrt(relv[w].x * relv[w].x + relv[w].y * relv[w].y) : 0.f;
+              } else if (R.kind == REW_FEET_HEIGHT) {  // feet_height, world frame (rewards.py:507-524)
+                const V3 vw = E.lin_w + mul(E.Rwb, relv[w]);
+                const float er = E.pos.z + dot(E.Rwb.r2, relp[w]) - R.p[0];
+                v = er * er * ftanh(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
+              } else if (R.kind == REW_HANDSTAND_FEET_HEIGHT_EXP) {  // .../env/rewards.py:18-28
+                const float dz = E.pos.z + dot(E.Rwb.r2, relp[w]) - R.p[1];
+                v = dz * dz;
+              }
+              a0 += on[w] ? v : 0.f;
+            }
+          } break;
+        }
+      }
+      switch (R.kind) {
+        case REW_UNDESIRED_CONTACTS: f = a0 * gate; break;
+        case REW_CONTACT_FORCES: f = a0; break;
+        case REW_FEET_CONTACT_WITHOUT_CMD: f = a0 * (cmd_norm < 0.1f ? 1.f : 0.f) * gate; break;
+        case REW_FEET_CONTACT: f = (a0 != R.p[0] ? 1.f : 0.f) * moving * gate; break;
+        case REW_FEET_AIR_TIME: f = a0 * moving * gate; break;
+        case REW_HANDSTAND_FEET_AIR_TIME: f = a0; break;
+        case REW_FEET_STUMBLE: f = (a0 > 0.f ? 1.f : 0.f) * gate; break;
+        case REW_FEET_HEIGHT_BODY: case REW_FEET_HEIGHT: f = a0 * moving * gate; break;
+        case REW_FEET_SLIDE: f = a0 * gate; break;
+        case REW_FEET_AIR_TIME_POSITIVE_BIPED: f = (a0 == 1.f ? fminf(mn, R.p[0]) : 0.f) * moving * gate; break;
+        case REW_HANDSTAND_FEET_HEIGHT_EXP: f = fexp(-a0 * frcp(R.p[0])); break;
+        case REW_HANDSTAND_FEET_ON_AIR: f = a0 == 0.f ? 1.f : 0.f; break;
+        case REW_FEET_AIR_TIME_VARIANCE: {
+          const float inv_n = frcp(a0), inv_den = frcp(fmaxf(a0 - 1.f, 1.f));
+          f = ((a2 - a1 * a1 * inv_n) + (a4 - a3 * a3 * inv_n)) * inv_den * gate;
+        } break;
+        default: break;
+      }
+    } break;
+  }
+  return f;
+}
+
+
 template <class Ctx, class TP>
 struct EnvProgram : EnvLane<Ctx, TP> {
   using Base = EnvLane<Ctx, TP>;
@@ -232,253 +487,6 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // executes each reward KIND that occurs once, for all environments and all terms of that kind), instead of one after the other
   // with a descriptor pinned into SGPRs, a scalar dispatch and a cross-lane reduction per term (round 1: ~1100 cycles per term,
   // 20 k of a 125 k-cycle step).  Every term cites the reference function it restates; oracle/env.py has the same arithmetic in fp64.
-  enum { JS_TAU2 = 0, JS_ACC2, JS_QD2, JS_LIMIT, JS_POWER, JS_DEV1, JS_DEV2, JS_DA2, JS_Q, JS_ABSQD, JS_ROWS };  // = env_tables.h REW_JS_ROWS
-  enum { BT_HMAX = 0, BT_CA, BT_CC, BT_LA, BT_LC, BT_FX, BT_FY, BT_FZ, BT_PX, BT_PY, BT_PZ, BT_VX, BT_VY, BT_VZ, BT_NF };  // = REW_BT_NF
-  static_assert(JS_ROWS == REW_JS_ROWS && BT_NF == REW_BT_NF, "reward tables: LDS sizing in env_tables.h");
-
-  struct RewEnv {
-    float gate, cmd_norm, bv, fc_hi, moving;
-    bool terminated;
-    const float* JT;  // [JS_ROWS][D]
-    const float* BT;  // [n_bodies][BT_NF]
-    int D;
-  };
-
-  // unweighted value of one term, evaluated by ONE lane
-  RL_FN float term_value(const RewTab& R, const RewEnv& E) {
-    const float gate = E.gate, cmd_norm = E.cmd_norm, bv = E.bv, moving = E.moving;
-    const float* BT = E.BT;
-    const int32_t* ia = T.idx_pool_a + R.idx_off;
-    const int32_t* ib = T.idx_pool_b + R.idx_off;
-    auto first_c = [&](const float* r) { return r[BT_CC] > 0.f && r[BT_CC] < E.fc_hi; };   // ContactSensor.compute_first_contact(step_dt)
-    auto first_a = [&](const float* r) { return r[BT_CA] > 0.f && r[BT_CA] < E.fc_hi; };   // compute_first_air(step_dt)
-    // joint-sum kinds share one loop: R.row = row of the joint-statistics table (host: rl_env_host.h), -1 for every other kind
-    // (8 columns per trip, all LDS reads of a trip in flight together: a lone wavefront cannot hide a round trip per joint)
-    float js = 0.f;
-    if (R.row >= 0) {
-      const float* g = E.JT + R.row * E.D;
-      for (int j0 = 0; j0 < E.D; j0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) v[w] = g[j0 + w];  // columns >= D: reads inside the tables, dropped by the mask (the host keeps joint masks below 1 << D)
-#pragma unroll
-        for (int w = 0; w < 8; ++w) js += ((R.joint_mask >> (j0 + w)) & 1u) ? v[w] : 0.f;
-      }
-    }
-    float f = 0.f;
-    switch (R.kind) {
-      case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
-        float ex = cmd.x - lin_b.x, ey = cmd.y - lin_b.y;
-        f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
-      } break;
-      case REW_TRACK_ANG_VEL_Z_EXP: {  // rewards.py:38-48
-        float ez = cmd.z - ang_b.z;
-        f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
-      } break;
-      case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // rewards.py:51-66: root COM velocity in the yaw-only frame
-        float ex = cmd.x - (yaw_c * lin_w.x + yaw_s * lin_w.y), ey = cmd.y - (-yaw_s * lin_w.x + yaw_c * lin_w.y);
-        f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
-      } break;
-      case REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // rewards.py:69-78
-        float ez = cmd.z - vang.z;
-        f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
-      } break;
-      case REW_LIN_VEL_Z_L2: f = lin_b.z * lin_b.z * gate; break;                         // rewards.py:647-653
-      case REW_ANG_VEL_XY_L2: f = (ang_b.x * ang_b.x + ang_b.y * ang_b.y) * gate; break;  // rewards.py:656-662
-      case REW_FLAT_ORIENTATION_L2: f = (grav_b.x * grav_b.x + grav_b.y * grav_b.y) * gate; break;  // rewards.py:678-687
-      case REW_UPWARD: f = (1.f - grav_b.z) * (1.f - grav_b.z); break;                     // rewards.py:608-613
-      case REW_IS_TERMINATED: f = E.terminated ? 1.f : 0.f; break;
-      // joint sums [UPSTREAM isaaclab.envs.mdp] + rewards.py:81-90: the statistic is in the table, the mask picked the joints
-      case REW_JOINT_TORQUES_L2: case REW_JOINT_ACC_L2: case REW_JOINT_VEL_L2: case REW_JOINT_POS_LIMITS: case REW_JOINT_POWER:
-      case REW_JOINT_DEVIATION_L1: case REW_ACTION_RATE_L2:
-        f = js;
-        break;
-      case REW_STAND_STILL: f = js * (cmd_norm < R.p[0] ? 1.f : 0.f) * gate; break;  // rewards.py:93-104
-      case REW_JOINT_POS_PENALTY: {  // rewards.py:107-129
-        float run = fsqrt(js);
-        f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
-      } break;
-      case REW_JOINT_MIRROR: {  // rewards.py:259-278
-        const float* qt = E.JT + JS_Q * E.D;
-        float part = 0.f;
-        for (int i0 = 0; i0 < R.n_idx; i0 += 4) {  // 4 pairs per trip: index reads, then the 8 position reads, in flight together
-          int a4[4], b4[4];
-#pragma unroll
-          for (int w = 0; w < 4; ++w) { a4[w] = ia[i0 + w < R.n_idx ? i0 + w : i0]; b4[w] = ib[i0 + w < R.n_idx ? i0 + w : i0]; }
-          float qa[4], qb[4];
-#pragma unroll
-          for (int w = 0; w < 4; ++w) { qa[w] = qt[a4[w]]; qb[w] = qt[b4[w]]; }
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const float d = qa[w] - qb[w];
-            part += i0 + w < R.n_idx ? d * d : 0.f;
-          }
-        }
-        f = part * R.p[0] * gate;
-      } break;
-      case REW_WHEEL_VEL_PENALTY: {  // rewards.py:132-153: pairs (wheel body, wheel joint)
-        const float* aq = E.JT + JS_ABSQD * E.D;
-        const bool running = cmd_norm > R.p[1] || bv > R.p[0];
-        float part = 0.f;
-        for (int i = 0; i < R.n_idx; ++i) part += (running ? (first_a(BT + ia[i] * BT_NF) ? 1.f : 0.f) : 1.f) * aq[ib[i]];
-        f = part;
-      } break;
-      case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256: product of exponentials = exponential of the sum
-        float air[4], con[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float* r = BT + ia[i] * BT_NF;
-          air[i] = r[BT_CA];
-          con[i] = r[BT_CC];
-        }
-        const float inv_std = frcp(R.p[0]), me2 = R.p[1] * R.p[1];
-        auto se = [&](float a, float b) { float d = a - b; return fminf(d * d, me2); };
-        float acc = se(air[0], air[1]) + se(con[0], con[1]) + se(air[2], air[3]) + se(con[2], con[3]);
-        acc += se(air[0], con[2]) + se(con[0], air[2]) + se(air[1], con[3]) + se(con[1], air[3]);
-        acc += se(air[0], con[3]) + se(con[0], air[3]) + se(air[2], con[1]) + se(con[2], air[1]);
-        f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? fexp(-acc * inv_std) : 0.f) * gate;
-      } break;
-      case REW_FEET_DISTANCE_Y_EXP:
-      case REW_FEET_DISTANCE_XY_EXP: {  // rewards.py:439-461, 464-505: feet (link frames) against a stance rectangle in the base frame
-        float part = 0.f;
-        for (int i = 0; i < R.n_idx; ++i) {
-          const float* r = BT + ia[i] * BT_NF;
-          const float ey = ((i & 1) ? -0.5f : 0.5f) * R.p[1] - r[BT_PY];
-          const float ex = R.kind == REW_FEET_DISTANCE_XY_EXP ? (i < 2 ? 0.5f : -0.5f) * R.p[2] - r[BT_PX] : 0.f;
-          part += ex * ex + ey * ey;
-        }
-        f = fexp(-part * frcp(R.p[0])) * gate;
-      } break;
-      case REW_HANDSTAND_ORIENTATION_L2: {  // config/others/unitree_a1_handstand/env/rewards.py:50-59
-        const float dx = grav_b.x - R.p[0], dy = grav_b.y - R.p[1], dz = grav_b.z - R.p[2];
-        f = dx * dx + dy * dy + dz * dz;
-      } break;
-      case REW_BASE_HEIGHT_L2: {  // rewards.py:616-644; the 3 x 3 base ray caster (velocity_env_cfg.py:78-85)
-        float tgt = R.p[0];
-        if (R.p[1] > 0.5f) {
-          float hsum = 0.f;
-          for (int r9 = 0; r9 < 9; ++r9) {
-            const int iy = r9 / 3, ix = r9 - 3 * iy;
-            const float lx = (float)(ix - 1) * 0.05f, ly = (float)(iy - 1) * 0.05f;
-            float hz;
-            V3 nn;
-            terrain_sample(this->u, S.terrain, pos.x + yaw_c * lx - yaw_s * ly, pos.y + yaw_s * lx + yaw_c * ly, hz, nn);
-            hsum += hz;
-          }
-          tgt += hsum * (1.0f / 9.0f);
-        }
-        f = (pos.z - tgt) * (pos.z - tgt) * gate;
-      } break;
-      default: {  // sums over the bodies of the term's body mask
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, mn = 1e30f;
-        // 4 bodies per trip, their table rows read together (a lone wavefront cannot hide an LDS round trip per body)
-        for (uint64_t m = R.body_mask; m != 0ull;) {
-          const float* rr[4];
-          bool on[4];
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            on[w] = m != 0ull;
-            rr[w] = BT + (on[w] ? __builtin_ctzll(m) : 0) * BT_NF;
-            m &= m - 1ull;  // (0 stays 0)
-          }
-          float hm[4], ca[4], cc[4], la[4], lc[4];
-#pragma unroll
-          for (int w = 0; w < 4; ++w) { hm[w] = rr[w][BT_HMAX]; ca[w] = rr[w][BT_CA]; cc[w] = rr[w][BT_CC]; la[w] = rr[w][BT_LA]; lc[w] = rr[w][BT_LC]; }
-          switch (R.kind) {
-            case REW_UNDESIRED_CONTACTS:  // rewards.py:665-675
-#pragma unroll
-              for (int w = 0; w < 4; ++w) a0 += on[w] && hm[w] > R.p[0] ? 1.f : 0.f;
-              break;
-            case REW_CONTACT_FORCES:  // [UPSTREAM] contact_forces
-#pragma unroll
-              for (int w = 0; w < 4; ++w) a0 += on[w] ? fmaxf(hm[w] - R.p[0], 0.f) : 0.f;
-              break;
-            case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT:  // rewards.py:416-425, 399-413
-#pragma unroll
-              for (int w = 0; w < 4; ++w) a0 += on[w] && cc[w] > 0.f && cc[w] < E.fc_hi ? 1.f : 0.f;
-              break;
-            case REW_FEET_AIR_TIME: case REW_HANDSTAND_FEET_AIR_TIME:  // rewards.py:340-360
-#pragma unroll
-              for (int w = 0; w < 4; ++w) a0 += on[w] && cc[w] > 0.f && cc[w] < E.fc_hi ? la[w] - R.p[0] : 0.f;
-              break;
-            case REW_FEET_AIR_TIME_POSITIVE_BIPED:  // rewards.py:363-383
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                const bool inc = cc[w] > 0.f;
-                a0 += on[w] && inc ? 1.f : 0.f;
-                mn = on[w] ? fminf(mn, inc ? cc[w] : ca[w]) : mn;
-              }
-              break;
-            case REW_HANDSTAND_FEET_ON_AIR:  // .../env/rewards.py:31-37: counts the feet that have NOT just lifted
-#pragma unroll
-              for (int w = 0; w < 4; ++w) a0 += on[w] && !(ca[w] > 0.f && ca[w] < E.fc_hi) ? 1.f : 0.f;
-              break;
-            case REW_FEET_AIR_TIME_VARIANCE:  // rewards.py:386-397 (torch.var is unbiased)
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                const float xa = fminf(la[w], 0.5f), xc = fminf(lc[w], 0.5f), o = on[w] ? 1.f : 0.f;
-                a0 += o; a1 += o * xa; a2 += o * xa * xa; a3 += o * xc; a4 += o * xc * xc;
-              }
-              break;
-            case REW_FEET_STUMBLE:  // rewards.py:428-436
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                const float fx = rr[w][BT_FX], fy = rr[w][BT_FY], fz = rr[w][BT_FZ];
-                a0 += on[w] && fsqrt(fx * fx + fy * fy) > 4.f * fabsf(fz) ? 1.f : 0.f;
-              }
-              break;
-            default: {  // the kinds that look at a foot's position / velocity relative to the root
-              V3 relp[4], relv[4];
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                relp[w] = {rr[w][BT_PX], rr[w][BT_PY], rr[w][BT_PZ]};
-                relv[w] = {rr[w][BT_VX], rr[w][BT_VY], rr[w][BT_VZ]};
-              }
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                float v = 0.f;
-                if (R.kind == REW_FEET_HEIGHT_BODY) {  // rewards.py:527-554
-                  const float er = relp[w].z - R.p[0];
-                  v = er * er * ftanh(R.p[1] * fsqrt(relv[w].x * relv[w].x + relv[w].y * relv[w].y));
-                } else if (R.kind == REW_FEET_SLIDE) {  // rewards.py:557-587
-                  v = hm[w] > 1.0f ? fsqrt(relv[w].x * relv[w].x + relv[w].y * relv[w].y) : 0.f;
-                } else if (R.kind == REW_FEET_HEIGHT) {  // feet_height, world frame (rewards.py:507-524)
-                  const V3 vw = lin_w + mul(Rwb, relv[w]);
-                  const float er = pos.z + dot(Rwb.r2, relp[w]) - R.p[0];
-                  v = er * er * ftanh(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
-                } else if (R.kind == REW_HANDSTAND_FEET_HEIGHT_EXP) {  // .../env/rewards.py:18-28
-                  const float dz = pos.z + dot(Rwb.r2, relp[w]) - R.p[1];
-                  v = dz * dz;
-                }
-                a0 += on[w] ? v : 0.f;
-              }
-            } break;
-          }
-        }
-        switch (R.kind) {
-          case REW_UNDESIRED_CONTACTS: f = a0 * gate; break;
-          case REW_CONTACT_FORCES: f = a0; break;
-          case REW_FEET_CONTACT_WITHOUT_CMD: f = a0 * (cmd_norm < 0.1f ? 1.f : 0.f) * gate; break;
-          case REW_FEET_CONTACT: f = (a0 != R.p[0] ? 1.f : 0.f) * moving * gate; break;
-          case REW_FEET_AIR_TIME: f = a0 * moving * gate; break;
-          case REW_HANDSTAND_FEET_AIR_TIME: f = a0; break;
-          case REW_FEET_STUMBLE: f = (a0 > 0.f ? 1.f : 0.f) * gate; break;
-          case REW_FEET_HEIGHT_BODY: case REW_FEET_HEIGHT: f = a0 * moving * gate; break;
-          case REW_FEET_SLIDE: f = a0 * gate; break;
-          case REW_FEET_AIR_TIME_POSITIVE_BIPED: f = (a0 == 1.f ? fminf(mn, R.p[0]) : 0.f) * moving * gate; break;
-          case REW_HANDSTAND_FEET_HEIGHT_EXP: f = fexp(-a0 * frcp(R.p[0])); break;
-          case REW_HANDSTAND_FEET_ON_AIR: f = a0 == 0.f ? 1.f : 0.f; break;
-          case REW_FEET_AIR_TIME_VARIANCE: {
-            const float inv_n = frcp(a0), inv_den = frcp(fmaxf(a0 - 1.f, 1.f));
-            f = ((a2 - a1 * a1 * inv_n) + (a4 - a3 * a3 * inv_n)) * inv_den * gate;
-          } break;
-          default: break;
-        }
-      } break;
-    }
-    return f;
-  }
-
   RL_FN float compute_rewards(bool terminated) {
     const int D = ctx.uniform_i(T.D), n_rewards = ctx.uniform_i(T.n_rewards);
     float* JT = ctx.rew_tab();
@@ -552,6 +560,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     E.moving = E.cmd_norm > 0.1f ? 1.f : 0.f;
     E.terminated = terminated;
     E.JT = JT; E.BT = BT; E.D = D;
+    E.cmd = cmd; E.lin_b = lin_b; E.ang_b = ang_b; E.lin_w = lin_w; E.vang = vang; E.grav_b = grav_b; E.pos = pos;
+    E.yaw_c = yaw_c; E.yaw_s = yaw_s; E.Rwb = Rwb;
     const float step_dt = ctx.uniform(T.step_dt);
     float* rstage = ctx.rew_stage();
     float mine = 0.f;
@@ -561,7 +571,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     for (int t = li; t < n_rewards; t += LPE) {
 #endif
       const RewTab& R = T.rew[t];
-      const float val = term_value(R, E) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
+      const float val = term_value(T, this->u, S.terrain, R, E) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
       rstage[t] = val;
       mine += val;
     }
