@@ -908,14 +908,20 @@ struct EnvProgram : EnvLane<Ctx, TP> {
                    U(STREAM_PUSH, 5, T.push_vel[5][0], T.push_vel[5][1])};
       }
     }
+    // The state is final here: write it back BEFORE the observation stage, so that the stores drain behind that stage's
+    // arithmetic instead of behind the end of the kernel (a wavefront has 63 memory operations in flight at most; the trunk +
+    // limbs instance issues ~100 stores, i.e. it used to sit out a full HBM write round trip with nothing else to do: 11 us of
+    // G1's 150)
+    RL_PHASE(23, "store");
+#ifndef RL_ABL_NO_STORE  // analysis builds: what the write-back of the state costs (wrong results)
+    this->store();
+    store_task();
+#endif
     // 9 observations
     RL_PHASE(20, "observations");
 #ifndef RL_ABL_NO_OBS
     observations(!ctx.any(terminated || time_out));
 #endif
-    RL_PHASE(23, "store");
-    this->store();
-    store_task();
     RL_PHASE(24, "end");
   }
 

@@ -113,14 +113,24 @@ __device__ inline void layer(const MlpParams& P, int l, const float* __restrict_
   float bias_r[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) bias_r[t] = *(const float __attribute__((address_space(1)))*)(uintptr_t)(bu + (uint64_t)(uint32_t)((wave + WAVES * t) * 64) + (uint32_t)((lane & 15) * 4));
+  // the A fragment (LDS) of block kb + 1 is read while block kb's MFMAs issue: a wavefront that has the SIMD to itself (the
+  // wavefronts of a SIMD do not finish a layer together) would otherwise sit out an LDS round trip per k block
+  f32x4 an[RT];
+  auto load_a = [&](int kb, f32x4 (&a)[RT]) {
+    const int kc = kb < KB ? kb : KB - 1;
+#pragma unroll
+#ifdef MLP_ABL_NOLDS  // kernel analysis: one activation block for the whole layer (wrong results)
+    for (int r = 0; r < RT; ++r) a[r] = xa[r * (TILE / 4) + 0 * kc];
+#else
+    for (int r = 0; r < RT; ++r) a[r] = xa[kc * 64 + r * (TILE / 4)];
+#endif
+  };
+  load_a(0, an);
   auto mma = [&](int kb, const f32x4 (&b)[TPW]) {
     f32x4 a[RT];
 #pragma unroll
-#ifdef MLP_ABL_NOLDS  // kernel analysis: one activation block for the whole layer (wrong results)
-    for (int r = 0; r < RT; ++r) a[r] = xa[r * (TILE / 4)];
-#else
-    for (int r = 0; r < RT; ++r) a[r] = xa[kb * 64 + r * (TILE / 4)];
-#endif
+    for (int r = 0; r < RT; ++r) a[r] = an[r];
+    load_a(kb + 1, an);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
