@@ -22,6 +22,9 @@ There is no CPU path: without `librl_env_hip.so` or without a GPU the constructo
 """
 from __future__ import annotations
 
+import collections
+import weakref
+
 import math
 
 import numpy as np
@@ -83,7 +86,9 @@ class _LazyLog(dict):
             return
         e = self._env
         # the kernel logs step k into ring slot k % RL_LOG_RING and clears the slot of step k + 1 (include/rl_env.h):
-        # this step's numbers are on the device, untouched, until RL_LOG_RING - 2 further steps have been launched
+        # this step's numbers are on the device, untouched, until RL_LOG_RING - 2 further steps have been launched.  The env
+        # materialises a log that is still referenced just before that happens (ManagerBasedRLEnv._retire_logs), so this only
+        # fires for a log that was detached from its env
         if e.common_step_counter - self._step > RL_LOG_RING - 2:
             raise RuntimeError(f'extras["log"] of step {self._step} was read {e.common_step_counter - self._step} steps later: '
                                f"the device keeps the last {RL_LOG_RING - 2} steps")
@@ -262,6 +267,7 @@ class ManagerBasedRLEnv(_EnvBase):
         self.physics_dt = float(desc.sim.dt)
         self.step_dt = float(desc.sim.dt) * int(desc.sim.decimation)
         self.common_step_counter = 0
+        self._live_logs = collections.deque()
         self._bufs = _Buffers(self)
         for name in ("OBS_POLICY_RING", "OBS_CRITIC_RING", "REWARD", "TERMINATED", "TIME_OUT", "EPISODE_LENGTH", "ROOT_STATE", "JOINT_POS",
                      "JOINT_VEL", "REWARD_TERMS", "EPISODE_SUMS", "COMMAND", "CONTACT_TIMERS", "LOG", "ACTION", "ENV_ORIGIN", "TERRAIN_LEVEL",
@@ -332,10 +338,24 @@ class ManagerBasedRLEnv(_EnvBase):
         self._obs = self._obs_slots[self._native.obs_slot()]
         if self.log_episodes:  # no snapshot, no memset: views of this step's ring slot and its predecessor, read only if somebody asks
             k = self._native.log_slot()
-            self.extras = {"log": _LazyLog(self, self._bufs["LOG"][k], self._bufs["LOG"][(k - 1) % RL_LOG_RING], self.common_step_counter)}
+            log = _LazyLog(self, self._bufs["LOG"][k], self._bufs["LOG"][(k - 1) % RL_LOG_RING], self.common_step_counter)
+            self.extras = {"log": log}
+            self._retire_logs(log)
         else:
             self.extras = {}
         return self._obs, self._bufs["REWARD"], self._terminated, self._time_outs, self.extras
+
+    def _retire_logs(self, new_log=None):
+        """A log dict somebody still holds is materialised (device-side copies, no host sync) a few steps before its ring slot is
+        reused, so `extras["log"]` stays readable however late it is read; logs nobody kept cost nothing."""
+        q = self._live_logs
+        if new_log is not None:
+            q.append((self.common_step_counter, weakref.ref(new_log)))
+        while q and self.common_step_counter - q[0][0] >= RL_LOG_RING - 4:
+            _, ref = q.popleft()
+            log = ref()
+            if log is not None:
+                log._fill()
 
     def get_observations(self):
         return self._obs
@@ -357,6 +377,11 @@ class ManagerBasedRLEnv(_EnvBase):
         self.common_step_counter += n
         self._export_stamp = -1
         self._obs = self._obs_slots[self._native.obs_slot()]
+        for _, ref in self._live_logs:  # the replay advances the ring by n slots: what is still held is materialised now
+            log = ref()
+            if log is not None:
+                log._fill()
+        self._live_logs.clear()
         if self.log_episodes:
             k = self._native.log_slot()
             self.extras = {"log": _LazyLog(self, self._bufs["LOG"][k], self._bufs["LOG"][(k - 1) % RL_LOG_RING], self.common_step_counter)}
