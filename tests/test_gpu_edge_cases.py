@@ -161,7 +161,10 @@ def test_episode_log_stays_readable_past_the_ring():
             assert want[1][0] >= 16 and float(kept[1]["Episode_Termination/time_out"]) == 16.0
     # never read inside the window: the env materialised it before the ring wrapped.  Step 2 reset nobody, so its log is the log of
     # the most recent step that did (step 1), as in the reference
-    assert float(kept[2]["Episode_Termination/time_out"]) == 16.0
-    np.testing.assert_allclose(float(kept[2]["Episode_Reward/action_rate_l2"]), float(kept[1]["Episode_Reward/action_rate_l2"]), rtol=0, atol=0)
+    if want[2][0] == 0:
+        assert float(kept[2]["Episode_Termination/time_out"]) == 16.0
+        assert float(kept[2]["Episode_Reward/action_rate_l2"]) == float(kept[1]["Episode_Reward/action_rate_l2"])
+    else:  # somebody fell over in step 2: its own log
+        np.testing.assert_allclose(float(kept[2]["Episode_Reward/action_rate_l2"]), want[2][1]["Episode_Reward/action_rate_l2"], rtol=2e-3, atol=1e-6)
     assert float(kept[1]["Episode_Termination/time_out"]) == 16.0  # materialised at step 30: stays
     env.close()
