@@ -83,6 +83,9 @@ __device__ inline void normal4(uint64_t seed, uint32_t env, uint32_t counter, ui
 
 __global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
   int b = blockIdx.x;
+#ifdef RL_ACT_NOCOPY  // analysis: what the two observation copies cost
+  if (b < a.copy_blocks_obs + a.copy_blocks_critic) return;
+#endif
   if (b < a.copy_blocks_obs) {
     stream_copy(a.obs, a.s_obs, (size_t)a.N * a.obs_dim, b, a.copy_blocks_obs);
     return;

@@ -34,7 +34,7 @@ class RlRolloutError(RuntimeError):
 
 def load_rollout_library(path: str | None = None) -> C.CDLL:
     global _lib
-    path = path or ROLLOUT_LIB
+    path = path or os.environ.get("RL_ROLLOUT_LIB") or ROLLOUT_LIB  # RL_ROLLOUT_LIB: alternative build (kernel analysis)
     if _lib is not None and path == ROLLOUT_LIB:
         return _lib
     if not os.path.isfile(path):
