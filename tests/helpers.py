@@ -142,7 +142,8 @@ def teacher_forced_check(ora, state, action, got, n_twins=3, gain=32.0, base=1e-
         sens["reward"] = np.maximum(sens["reward"], np.abs(ora.reward - want["reward"]))
         sens["reward_terms"] = np.maximum(sens["reward_terms"], np.abs(ora.reward_terms - want["reward_terms"]))
     ok = ~mask
-    report = dict(n=N, masked=int(mask.sum()), masked_frac=float(mask.mean()), margins_min={k: float(np.min(v)) for k, v in margins.items()})
+    report = dict(n=N, masked=int(mask.sum()), masked_frac=float(mask.mean()), margins_min={k: float(np.min(v)) for k, v in margins.items()},
+                  masked_by_margin={k: int((np.asarray(v) < SWITCH_EPS[k]).sum()) for k, v in margins.items()})  # envs each margin flags (they overlap)
     bad = {}
     for f in fields:
         err = rel_err(got[f], want[f], 1.0)
