@@ -112,6 +112,8 @@ class Physics:
         # result (conditioning of H + A: light distal links next to a heavy trunk, stiff contacts) - never by the checker itself.
         self.solve_dtype = None
 
+    cell_probe = 2e-6  # [m] a touching sphere this close to a heightfield cell edge counts as sitting on it (margins["cell"])
+
     def _margin(self, key, val):
         m = self.margins
         m[key] = np.minimum(m[key], val) if key in m else np.asarray(val, dtype=np.float64).copy()
@@ -268,7 +270,8 @@ class Physics:
             if not self.desc.terrain.is_plane:
                 near = phi > -1e-4  # touching, or about to
                 jump = np.zeros_like(phi)
-                for dx, dy in ((2e-5, 0.0), (-2e-5, 0.0), (0.0, 2e-5), (0.0, -2e-5)):
+                pr = self.cell_probe
+                for dx, dy in ((pr, 0.0), (-pr, 0.0), (0.0, pr), (0.0, -pr)):
                     _, n2 = self.terrain.sample(cw[..., 0] + dx, cw[..., 1] + dy)
                     jump = np.maximum(jump, np.abs(n2 - nrm).max(axis=-1))
                 self._margin("cell", np.where(near & (jump > 1e-3), 0.0, np.inf).min(axis=1))

@@ -72,6 +72,7 @@ struct Uni {
   float dt, inv_dt, gravity, contact_k, contact_c, inv_phi_ref, contact_ct, contact_vdep, contact_vstick, limit_k, limit_c, force_threshold;
   float inv_hscale, x0, y0;
   int is_plane, nx, ny;
+  double x0d, y0d, inv_hd;  // the grid transform of the heightfield in fp64 (terrain_fetch)
 };
 template <class Ctx>
 RL_FN Uni make_uni(const Ctx& ctx, const TaskTab& T) {
@@ -82,6 +83,14 @@ RL_FN Uni make_uni(const Ctx& ctx, const TaskTab& T) {
   u.limit_k = ctx.uniform(T.limit_k); u.limit_c = ctx.uniform(T.limit_c); u.force_threshold = ctx.uniform(T.force_threshold);
   u.inv_hscale = ctx.uniform(T.is_plane ? 1.0f : 1.0f / T.hscale); u.x0 = ctx.uniform(T.x0); u.y0 = ctx.uniform(T.y0);
   u.is_plane = ctx.uniform_i(T.is_plane); u.nx = ctx.uniform_i(T.nx); u.ny = ctx.uniform_i(T.ny);
+  auto uni_d = [&](double v) {  // a wave-uniform double: both halves pinned
+    union { double d; int i[2]; } w;
+    w.d = v;
+    w.i[0] = ctx.uniform_i(w.i[0]); w.i[1] = ctx.uniform_i(w.i[1]);
+    return w.d;
+  };
+  u.x0d = uni_d((double)T.x0); u.y0d = uni_d((double)T.y0);
+  u.inv_hd = uni_d(T.is_plane ? 1.0 : 1.0 / (double)T.hscale);
   return u;
 }
 
@@ -102,18 +111,23 @@ RL_FN F2 ld2(const float* p) {  // 4-byte aligned 8-byte load
 struct TerrainPatch {
   float h00, h01, h10, h11, fx, fy;
 };
-RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, float x, float y) {
+// The query point is (bx + dx, by + dy): a base that is a WORLD coordinate (root position: tens of metres on the 80 m x 40 m
+// terrain, fp32 ulp 4e-6 m) plus a small offset (sphere centre / scan ray relative to the root).  Summed and turned into grid
+// coordinates in fp64 (a handful of half-rate instructions per query), so that the cell index and the in-cell fractions carry
+// no world-coordinate round-off: in fp32 the sum alone moved a sphere by up to 4e-6 m = 0.08 N of contact force at k = 2e4 N/m,
+// which is what sized the switch margins of the teacher-forced parity tests (tests/helpers.py SWITCH_EPS).
+RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, float bx, float by, float dx, float dy) {
   TerrainPatch p;
   if (u.is_plane) {
     p.h00 = p.h01 = p.h10 = p.h11 = 0.f;
     p.fx = p.fy = 0.f;
     return p;
   }
-  float gx = (x - u.x0) * u.inv_hscale, gy = (y - u.y0) * u.inv_hscale;
-  int ix = (int)fminf(fmaxf(floorf(gx), 0.f), (float)(u.nx - 2));
-  int iy = (int)fminf(fmaxf(floorf(gy), 0.f), (float)(u.ny - 2));
-  p.fx = clampf(gx - (float)ix, 0.f, 1.f);
-  p.fy = clampf(gy - (float)iy, 0.f, 1.f);
+  const double gx = (((double)bx - u.x0d) + (double)dx) * u.inv_hd, gy = (((double)by - u.y0d) + (double)dy) * u.inv_hd;
+  const double cx = fmin(fmax(floor(gx), 0.0), (double)(u.nx - 2)), cy = fmin(fmax(floor(gy), 0.0), (double)(u.ny - 2));
+  const int ix = (int)cx, iy = (int)cy;
+  p.fx = clampf((float)(gx - cx), 0.f, 1.f);
+  p.fy = clampf((float)(gy - cy), 0.f, 1.f);
   // (iy, iy+1) are adjacent in memory: two 8-byte loads per query instead of four 4-byte ones
   const float* b = hf + (uint32_t)ix * (uint32_t)u.ny + (uint32_t)iy;
   F2 r0 = ld2(b), r1 = ld2(b + u.ny);
@@ -132,8 +146,8 @@ RL_FN float terrain_height(const TerrainPatch& p) {  // the height alone (ray ca
   const float hx0 = p.h00 + p.fx * (p.h10 - p.h00), hx1 = p.h01 + p.fx * (p.h11 - p.h01);
   return hx0 + p.fy * (hx1 - hx0);
 }
-RL_FN void terrain_sample(const Uni& u, const float* __restrict__ hf, float x, float y, float& h, V3& n) {
-  terrain_eval(u, terrain_fetch(u, hf, x, y), h, n);
+RL_FN void terrain_sample(const Uni& u, const float* __restrict__ hf, float bx, float by, float dx, float dy, float& h, V3& n) {
+  terrain_eval(u, terrain_fetch(u, hf, bx, by, dx, dy), h, n);
 }
 
 RL_FN M3 ld_m3(const float* p) { return M3{{p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}}; }
@@ -502,7 +516,8 @@ struct EnvLane {
   };
   // joints that move link group g: the first wdepth(g) trunk joints and the first g limb joints
   RL_FN int wdepth(int g) const { return NW == 0 ? 0 : (g == 0 ? L.grp0_depth : L.attach); }
-  // sphere centre in base coordinates (cb) and world (cw); empty slots (radius <= 0) sit at the group's link origin
+  // sphere centre in base coordinates (cb) and world (cw: x, y as OFFSETS from the root position - the terrain lookup adds the
+  // root in fp64 -, z the world height); empty slots (radius <= 0) sit at the group's link origin
   // frame (base coordinates) of link group g: the trunk link of group 0, else limb link g - 1.  Selected once
   // per group (12 selects per candidate) instead of one matrix-vector product per candidate per sphere.
   RL_FN void group_frame(const ChainTP& C, int g, M3& Rg, V3& pg) const {
@@ -516,7 +531,8 @@ struct EnvLane {
   RL_FN void sphere_center_in(const M3& Rg, V3 pg, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
     rad = L.sph_r[g][s];
     cb = pg + mul(Rg, ld3(L.sph_c[g][s]));
-    cw = pos + mul(Rwb, cb);
+    const V3 ow = mul(Rwb, cb);
+    cw = {ow.x, ow.y, pos.z + ow.z};
   }
   RL_FN void sphere_center(const ChainTP& C, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
     M3 Rg;
@@ -621,7 +637,7 @@ struct EnvLane {
     for (int s = 0; s < SPL; ++s) {
       sphere_center_in(Rg, pg, Rwb, gi, s, gf.rad[s], gf.cb[s], gf.cw[s]);
       if (!mine) gf.rad[s] = -1.f;
-      gf.tp[s] = terrain_fetch(u, S.terrain, gf.cw[s].x, gf.cw[s].y);
+      gf.tp[s] = terrain_fetch(u, S.terrain, pos.x, pos.y, gf.cw[s].x, gf.cw[s].y);
     }
     return true;
   }
@@ -1356,7 +1372,7 @@ struct EnvLane {
         float rad;
         V3 cb, cw;
         sphere_center(C, Rwb, g, s2, rad, cb, cw);
-        const Contact c = contact_from_patch(C, Rwb, V0, qd, g, s2, rad, cb, cw, terrain_fetch(u, S.terrain, cw.x, cw.y));
+        const Contact c = contact_from_patch(C, Rwb, V0, qd, g, s2, rad, cb, cw, terrain_fetch(u, S.terrain, pos.x, pos.y, cw.x, cw.y));
         if (c.act) apply(c, link_twist(C, g, V0n, qdn), L.sph_slot[g][s2]);
       }
     }

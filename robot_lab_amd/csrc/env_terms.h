@@ -159,7 +159,7 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
           const float lx = (float)(ix - 1) * 0.05f, ly = (float)(iy - 1) * 0.05f;
           float hz;
           V3 nn;
-          terrain_sample(u, terrain, E.pos.x + E.yaw_c * lx - E.yaw_s * ly, E.pos.y + E.yaw_s * lx + E.yaw_c * ly, hz, nn);
+          terrain_sample(u, terrain, E.pos.x, E.pos.y, E.yaw_c * lx - E.yaw_s * ly, E.yaw_s * lx + E.yaw_c * ly, hz, nn);
           hsum += hz;
         }
         tgt += hsum * (1.0f / 9.0f);
@@ -593,12 +593,13 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   }
 
   // ---------------------------------------------------------------- observations [UPSTREAM B2 / B6]
-  // pose of the height scanner: the root link on the quadrupeds, the torso on G1 (rides on trunk link scan_depth)
+  // pose of the height scanner: the root link on the quadrupeds, the torso on G1 (rides on trunk link scan_depth).  `scan_p`: x, y
+  // as offsets from the root position (the terrain lookup adds the root in fp64, env_step.h terrain_fetch), z the world height
   // (`chain_fresh`: the chain words in LDS hold the kinematics of the current joint positions - no env of the wavefront was reset
   // since step() refreshed them)
   RL_FN void scanner_pose(float& cy, float& sy, V3& scan_p, bool chain_fresh) {
     if (NW == 0) {
-      cy = yaw_c; sy = yaw_s; scan_p = pos;
+      cy = yaw_c; sy = yaw_s; scan_p = {0.f, 0.f, pos.z};
       return;
     }
     ChainTP C = this->new_chain();
@@ -612,7 +613,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     const M3 Rs = mul(Rwb, Rf);
     const float hn = frsqrt(fmaxf(Rs.r0.x * Rs.r0.x + Rs.r1.x * Rs.r1.x, 1e-30f));
     cy = Rs.r0.x * hn; sy = Rs.r1.x * hn;
-    scan_p = pos + mul(Rwb, pf + mul(Rf, V3{T.scan_pos[0], T.scan_pos[1], T.scan_pos[2]}));
+    const V3 so = mul(Rwb, pf + mul(Rf, V3{T.scan_pos[0], T.scan_pos[1], T.scan_pos[2]}));
+    scan_p = {so.x, so.y, pos.z + so.z};
   }
 
   // One observation group -> its LDS-staged row.  No dispatch on terms: the host expanded the term list into per-column
@@ -638,7 +640,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       r = r < scan_n ? r : scan_n - 1;
       int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
       float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
-      sp.tp[i] = terrain_fetch(this->u, S.terrain, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
+      sp.tp[i] = terrain_fetch(this->u, S.terrain, pos.x, pos.y, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
     }
   }
   RL_FN void scan_fetch(float cy, float sy, V3 scan_p, ScanPatches& sp) const {

@@ -77,9 +77,11 @@ def emu_load_state(nat, s):
 # where fp32 and fp64 may legitimately land on different sides: contact on/off (penetration, lagged normal force),
 # static/dynamic friction, joint-limit damper, implicit-actuator saturation, contact-sensor force threshold, and a touching
 # sphere on a heightfield cell edge across which the terrain normal jumps ("cell": 0 = yes).
-# Sized by what fp32 can resolve: root positions are world coordinates up to +-60 m (ulp 4e-6 m, x the terrain slope), velocities
-# a few m/s (ulp 5e-7), and a position error of 4e-6 m is 0.08 N of contact force at k = 2e4 N/m.
-SWITCH_EPS = dict(phi=1e-5, fn0=0.1, stick=5e-5, limit=1e-5, saturation=1e-3, force=0.1, cell=0.5)
+# Sized by what the fp32 side can resolve.  The terrain lookups add the root position (a world coordinate of tens of metres) and
+# the sphere / ray offsets in fp64 (csrc/env_step.h terrain_fetch), so a penetration depth carries the round-off of metre-sized
+# numbers only (~3e-7 m, i.e. ~0.006 N of contact force at k = 2e4 N/m); joint angles are ~1 rad (ulp 1.2e-7), velocities a few
+# m/s (ulp 5e-7).  (Round 1 summed in fp32: the margins were 1e-5 m / 0.1 N then and flagged 3-4 % of the envs.)
+SWITCH_EPS = dict(phi=1e-6, fn0=0.01, stick=1e-5, limit=2e-6, saturation=1e-3, force=0.01, cell=0.5)
 
 
 def switch_mask(margins, eps=SWITCH_EPS):
@@ -203,6 +205,7 @@ class OracleWithTwin:
         self.twin.phys.solve_dtype = np.float32
         self.gain, self.rng = gain, np.random.default_rng(seed)
         self.done_differs = np.zeros(self.ora.N, dtype=bool)  # envs whose twin took a different reset decision at some step
+        self.ora.phys.margins = {}  # smallest distance to every switch of the model over the whole run (Physics._margin keeps minima)
 
     def _perturb(self):
         st = self.ora.read_state()
@@ -223,12 +226,17 @@ class OracleWithTwin:
         return o
 
     def close(self, name, got, pick, rtol, atol):
-        """`pick(env)` extracts the compared array from an OracleEnv; envs whose twin reset differently are skipped."""
+        """`pick(env)` extracts the compared array from an OracleEnv; envs whose twin reset differently, or that came within
+        SWITCH_EPS of a switch of the model at some substep, are skipped (`self.masked` counts them)."""
         want, tw = np.asarray(pick(self.ora), dtype=np.float64), np.asarray(pick(self.twin), dtype=np.float64)
         got = np.asarray(got, dtype=np.float64)
         assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
         env_axis = [i for i, n in enumerate(want.shape) if n == self.ora.N][0]
-        keep = np.moveaxis(np.broadcast_to(np.expand_dims(~self.done_differs, tuple(i for i in range(want.ndim) if i != env_axis)), want.shape), 0, 0)
+        ok_env = ~self.done_differs
+        if self.ora.phys.margins:  # envs that sat ON a switch at some substep of the run (same rule as the teacher-forced check)
+            ok_env = ok_env & ~switch_mask(self.ora.phys.margins)
+        self.masked = int((~ok_env).sum())
+        keep = np.moveaxis(np.broadcast_to(np.expand_dims(ok_env, tuple(i for i in range(want.ndim) if i != env_axis)), want.shape), 0, 0)
         bad = (np.abs(got - want) > atol + rtol * np.abs(want) + self.gain * np.abs(tw - want)) & keep
         assert not bad.any(), (f"{name}: {int(bad.sum())} of {bad.size} entries outside atol {atol} + rtol {rtol} + {self.gain} x twin drift; "
                                f"worst |err| {np.abs(got - want)[bad].max():.3e} where the twin drifted {np.abs(tw - want)[bad].max():.3e}")
