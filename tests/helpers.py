@@ -107,7 +107,8 @@ def teacher_forced_check(ora, state, action, got, n_twins=3, gain=32.0, base=1e-
 
     Tolerance, per env and per field:   err <= base + gain * s   (1e-5 + 32 s),   err = max |got - want| / max(|want|, 1)
     where s is the oracle's OWN response (same metric) to fp32-sized disturbances, maximum over `n_twins` twins: each twin
-    starts from the shared root / joint state perturbed by a random relative 1e-6 (16 fp32 ulp) AND solves its linear systems
+    starts from the shared root / joint state perturbed by a random relative 1e-6 (16 fp32 ulp; the root's world x, y by an
+    absolute 1e-6 m) AND solves its linear systems
     in single precision (Physics.solve_dtype: the conditioning of H + A, which an input perturbation alone does not probe).  Why not a flat 1e-5: the step map of a robot in stiff
     contact amplifies an input perturbation of 1e-6 by 30x (median) to 2000x (joint velocities; measured),
     so fp32 round-off inside 4 substeps necessarily shows up at 1e-5 .. 1e-3 there, while airborne envs agree to < 1e-5.
@@ -133,6 +134,9 @@ def teacher_forced_check(ora, state, action, got, n_twins=3, gain=32.0, base=1e-
         tw = dict(state)
         for k in ("root_state", "joint_pos", "joint_vel"):
             tw[k] = np.asarray(state[k], dtype=np.float64) * (1.0 + 1e-6 * rng.uniform(-1, 1, np.shape(state[k])))
+        # (the root's world x, y - tens of metres - by an ABSOLUTE 1e-6 m: the kernels' terrain lookups are free of world-coordinate
+        # round-off, so a relative perturbation there would be 4e-5 m and hand the contacts a tolerance they do not need)
+        tw["root_state"][:, 0:2] = np.asarray(state["root_state"], dtype=np.float64)[:, 0:2] + 1e-6 * rng.uniform(-1, 1, (len(tw["root_state"]), 2))
         ora.load_state(tw)
         ora.phys.solve_dtype = np.float32
         ot = ora.step(action)
@@ -209,8 +213,10 @@ class OracleWithTwin:
 
     def _perturb(self):
         st = self.ora.read_state()
+        xy = st["root_state"][:, 0:2].copy()
         for k in ("root_state", "joint_pos", "joint_vel"):
             st[k] = st[k] * (1.0 + 1e-6 * self.rng.uniform(-1, 1, st[k].shape))
+        st["root_state"][:, 0:2] = xy + 1e-6 * self.rng.uniform(-1, 1, xy.shape)  # world x, y: absolute (see teacher_forced_check)
         self.twin.load_state(st)
 
     def reset(self):
