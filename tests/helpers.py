@@ -81,7 +81,7 @@ def emu_load_state(nat, s):
 # the sphere / ray offsets in fp64 (csrc/env_step.h terrain_fetch), so a penetration depth carries the round-off of metre-sized
 # numbers only (~3e-7 m, i.e. ~0.006 N of contact force at k = 2e4 N/m); joint angles are ~1 rad (ulp 1.2e-7), velocities a few
 # m/s (ulp 5e-7).  (Round 1 summed in fp32: the margins were 1e-5 m / 0.1 N then and flagged 3-4 % of the envs.)
-SWITCH_EPS = dict(phi=1e-6, fn0=0.01, stick=1e-5, limit=2e-6, saturation=1e-3, force=0.01, cell=0.5)
+SWITCH_EPS = dict(phi=1e-6, fn0=0.01, stick=1e-5, limit=1e-6, saturation=1e-3, force=0.01, cell=0.5)
 
 
 def switch_mask(margins, eps=SWITCH_EPS):

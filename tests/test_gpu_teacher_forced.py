@@ -5,7 +5,7 @@ The HIP env runs K random-action steps (so the batch holds every phase of contac
 state is exported (rl_env_export_state), the oracle adopts it, and BOTH take one step from that shared state.  100 % of the
 envs outside the explicitly computed switch mask must agree within the per-env bound of helpers.teacher_forced_check
 (1e-5 + 32 x the oracle's own response to fp32-sized disturbances); dones, episode lengths, terrain levels and contact
-timers exactly; the mask itself must stay below 1 % of the batch.  A second HIP env takes the same step from the state
+timers exactly; the mask itself must stay below 0.5 % of the batch.  A second HIP env takes the same step from the state
 committed back through rl_env_commit_state and must reproduce the first one bit for bit (the exchange carries everything)."""
 import json
 import os
@@ -67,7 +67,7 @@ def test_one_step_from_shared_state_full_size(task, N):
     desc, extra = load_bundle(task)
     h, to, eo = build_world(desc, extra, N, 0)
     ora = OracleEnv(desc, h, to, N, seed, eo)
-    rep = teacher_forced_check(ora, state, a.cpu().numpy(), _outputs(env, *out1[:4]), n_twins=2, max_mask=0.01)
+    rep = teacher_forced_check(ora, state, a.cpu().numpy(), _outputs(env, *out1[:4]), n_twins=2, max_mask=0.005)
     assert rep["done_count"] > 0
     rep["task"], rep["warmup_steps"] = task, K
     print("\n[teacher-forced]", json.dumps(rep))
