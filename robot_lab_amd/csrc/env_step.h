@@ -307,7 +307,8 @@ struct LsLayout {  // ROWS sensor rows (timers 4, force history 3, last force 3,
 };
 template <class TP, int SUB>
 struct LsFor {  // lane scratchpad layout of an instance
-  static constexpr int NIT = (TP::CL + SUB) / SUB;            // link groups a sub-lane evaluates: g = sub + SUB * it
+  // link groups a sub-lane evaluates: g = sub + SUB * it over the groups 0 .. CL (merged instances: 1 .. CL, g = 1 + sub + SUB * it)
+  static constexpr int NIT = (TP::CL + SUB - TP::M0) / SUB;
   static constexpr int STASH = SUB > 1 ? NIT * TP::SPL : 0;  // every contact of pass 1 is kept for the sensor pass (slot it * SPL + s)
   static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::MAXOWN;      // 16-lane mapping: rows for the owned slots only
   using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::MAXOWN), STASH>;
@@ -391,10 +392,21 @@ struct EnvLane {
 #endif
   RL_FN float& LF(int f) const { return lt[(uint32_t)f * ROW]; }
   RL_FN float& EF(int f) const { return et[(uint32_t)f * (uint32_t)EPT]; }
-  // link group g (0 = base share, 1.. = chain links) is evaluated by sub-lane g % SUB of the leg
-  RL_FN bool owns_group(int g) const { return SUB == 1 || (g % SUB) == sub; }
-  // the link group whose contacts are stashed for the sensor pass: the most distal one this lane evaluates (Go2W: the wheel)
-  RL_FN int stash_group() const { return SUB == 1 ? CL : sub + SUB * ((CL - sub) / SUB); }
+  // link group g (0 = base share, 1.. = chain links) is evaluated by sub-lane g % SUB of the leg; merged instances (Topo::M0) have
+  // no group 0 - their base-share spheres sit in flagged slots of group 1 -, group g is sub-lane (g - 1) % SUB's and the trunk
+  // body's slot (group 0) belongs to sub-lane 0
+  static constexpr bool M0 = TP::M0 != 0;
+  static constexpr int G0 = M0 ? 1 : 0;  // first link group of the sub-lane mapping
+  RL_FN int grp_of(int it) const { return G0 + sub + SUB * it; }
+  RL_FN bool owns_group(int g) const { return SUB == 1 || (g < G0 ? sub == 0 : ((g - G0) % SUB) == sub); }
+  // does the sphere in slot (g, s) ride on the base link instead of limb link g - 1 (merged instances)
+  RL_FN bool on_base(int g, int s) const { return M0 && ((L.sph_base_mask >> (g * SPL + s)) & 1u) != 0u; }
+  // componentwise select (a ?: on the struct becomes a select of two ADDRESSES and a private-memory copy of both operands)
+  RL_FN static SV pick_sv(bool c, const SV& a, const SV& b) {
+    return SV{{c ? a.a.x : b.a.x, c ? a.a.y : b.a.y, c ? a.a.z : b.a.z}, {c ? a.l.x : b.l.x, c ? a.l.y : b.l.y, c ? a.l.z : b.l.z}};
+  }
+  // activity bits of the lane's base-share spheres
+  RL_FN uint32_t base_bits() const { return M0 ? L.sph_base_mask : ((1u << SPL) - 1u); }
   RL_FN bool owns_slot(int s) const { return owns_group(L.slot_grp[s]); }
 
   // ------------------------------------------------------------------ load / store
@@ -530,7 +542,9 @@ struct EnvLane {
   }
   RL_FN void sphere_center_in(const M3& Rg, V3 pg, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
     rad = L.sph_r[g][s];
-    cb = pg + mul(Rg, ld3(L.sph_c[g][s]));
+    const V3 c = ld3(L.sph_c[g][s]);
+    cb = pg + mul(Rg, c);
+    if (M0 && on_base(g, s)) cb = c;  // a base-share sphere hosted by this group's slots: base frame
     const V3 ow = mul(Rwb, cb);
     cw = {ow.x, ow.y, pos.z + ow.z};
   }
@@ -574,8 +588,9 @@ struct EnvLane {
     return c;
   }
   // spatial velocity of the link of group g from the generalised velocities (the one-lane-per-limb mapping's sensor pass)
-  RL_FN SV link_twist(const ChainTP& C, int g, SV V0, const float (&qdv)[JX]) const {
+  RL_FN SV link_twist(const ChainTP& C, int g, int s, SV V0, const float (&qdv)[JX]) const {
     SV V = V0;
+    if (M0 && on_base(g, s)) return V;
     const int wd = wdepth(g);
 #pragma unroll
     for (int i = 0; i < NW; ++i)
@@ -590,7 +605,7 @@ struct EnvLane {
     float phi;
     V3 nw;
     patch_phi(tp, rad, cw, phi, nw);
-    return contact_from_phi(Rwb, link_twist(C, g, V0, qdv), g, s, rad, cb, phi, nw);
+    return contact_from_phi(Rwb, link_twist(C, g, s, V0, qdv), g, s, rad, cb, phi, nw);
   }
 
   // ================================================================== quadruped instances: articulated-body form
@@ -611,7 +626,7 @@ struct EnvLane {
   // base link's spheres, group j + 1 is limb link j.  The owner of a group evaluates its contacts AND builds its link's rigid
   // record, adds the two, and the 27 numbers travel to the other sub-lanes with DPP quad broadcasts when the recursion gets there.
   static constexpr bool ABA = NW == 0;  // register-resident, software-pipelined form (substeps_aba); NW > 0: substep_aba_trunk
-  static constexpr int NIT = (CL + SUB) / SUB;  // ceil((CL + 1) / SUB) link groups per sub-lane
+  static constexpr int NIT = LsFor<TP, SUB>::NIT;  // ceil((CL + 1) / SUB) link groups per sub-lane (merged: ceil(CL / SUB))
   using B6 = SymIdx<6>;
   struct LinkRec {
     float A[B6::size];  // 6 x 6 symmetric, [omega; v] order
@@ -626,7 +641,7 @@ struct EnvLane {
   // stage A of a link group: sphere centres, terrain loads issued (consumed by group_contacts after unrelated work)
   template <int IT>
   RL_FN bool group_fetch(const ChainTP& C, const M3& Rwb, uint32_t slot_valid, GroupFetch& gf) {
-    const int g = sub + SUB * IT;
+    const int g = grp_of(IT);
     const bool mine = g <= CL;
     const int gi = mine ? g : CL;  // lanes without a group in this iteration index the last one and evaluate nothing
     if (!ctx.any(mine && ((slot_valid >> (gi * SPL)) & ((1u << SPL) - 1u)) != 0u)) return false;
@@ -643,10 +658,16 @@ struct EnvLane {
   }
 
   // stage B: penetration, contact activation, and the contact's 6 x 6 block / bias onto the group's link record
+  // `V0`, `acc0`: twist and record of the BASE link, for the base-share spheres a merged instance hosts in this group's slots
   template <int IT>
   RL_FN void group_contacts(const M3& Rwb, const SV& Vg, const GroupFetch& gf, LinkRec& acc, uint32_t& active_mask) {
+    static_assert(!M0, "merged instances pass the base link's twist and record");
+    group_contacts<IT>(Rwb, Vg, Vg, gf, acc, acc, active_mask);
+  }
+  template <int IT>
+  RL_FN void group_contacts(const M3& Rwb, const SV& Vg, const SV& V0, const GroupFetch& gf, LinkRec& acc, LinkRec& acc0, uint32_t& active_mask) {
     const float dt = u.dt;
-    const int g = sub + SUB * IT;
+    const int g = grp_of(IT);
     const int gi = g <= CL ? g : CL;
     float phi[SPL];
     V3 nw[SPL];
@@ -661,7 +682,10 @@ struct EnvLane {
     // the maximum over the wavefront of the touching-slot count and the code exists once; measured 3.5 us SLOWER on A1 Rough,
     // 56.6 vs 53.0 us in one gpurun call: the select chain per trip and the ballot per trip cost more than the skipped copies)
     auto one_slot = [&](const int s, const float rad_s, const V3 cb_s, const float phi_s, const V3 nw_s) __attribute__((always_inline)) {
-      Contact c = contact_from_phi(Rwb, Vg, gi, s, rad_s, cb_s, phi_s, nw_s);
+      const bool onb = M0 && on_base(gi, s);
+      SV Vs = Vg;
+      if (M0) Vs = pick_sv(onb, V0, Vg);
+      Contact c = contact_from_phi(Rwb, Vs, gi, s, rad_s, cb_s, phi_s, nw_s);
       if (c.act) {
         active_mask |= 1u << (gi * SPL + s);
         if (STASH) {  // keep the contact for the sensor pass
@@ -684,13 +708,17 @@ struct EnvLane {
         b6[B6::at(1, 3)] = kt * x.z; b6[B6::at(1, 5)] = -kt * x.x;
         b6[B6::at(2, 3)] = -kt * x.y; b6[B6::at(2, 4)] = kt * x.x;
         b6[B6::at(3, 3)] = kt; b6[B6::at(4, 4)] = kt; b6[B6::at(5, 5)] = kt;
+        auto add_to = [&](LinkRec& d) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          acc.r[i] += fb * g6[i];
-          const float kg = kn * g6[i];
+          for (int i = 0; i < 6; ++i) {
+            d.r[i] += fb * g6[i];
+            const float kg = kn * g6[i];
 #pragma unroll
-          for (int jj = i; jj < 6; ++jj) acc.A[B6::at(i, jj)] += b6[B6::at(i, jj)] + kg * g6[jj];
-        }
+            for (int jj = i; jj < 6; ++jj) d.A[B6::at(i, jj)] += b6[B6::at(i, jj)] + kg * g6[jj];
+          }
+        };
+        if (M0 && onb) add_to(acc0);
+        else add_to(acc);
       }
     };
 #ifndef RL_CONTACT_LOOP
@@ -732,7 +760,7 @@ struct EnvLane {
   // rigid record of the limb link this lane owns in iteration IT (link sub + SUB * IT - 1, if the limb has it)
   template <int IT>
   RL_FN SV link_rigid(const ChainTP& C, const SV V0, const SV (&Vl)[CL], const SV (&al)[CL], LinkRec& rec) const {
-    const int l = sub + SUB * IT - 1;
+    const int l = grp_of(IT) - 1;
     const bool has = l >= 0 && l < CL;
     // the link's frame / velocity / bias acceleration as a 0-1 weighted blend over the links an owner of this iteration can
     // have (a chain of selects on a per-lane index turns into an indexed load from a scratch copy of the arrays)
@@ -741,7 +769,7 @@ struct EnvLane {
     SV Vm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, am = Vm;
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
-      if (j < SUB * IT - 1 || j > SUB * IT + SUB - 2) continue;
+      if (j < G0 + SUB * IT - 1 || j > G0 + SUB * IT + SUB - 2) continue;
       const float w = l == j ? 1.f : 0.f;
       const M3 Rj = C.R(j);
       Rm.r0 += w * Rj.r0; Rm.r1 += w * Rj.r1; Rm.r2 += w * Rj.r2;
@@ -759,11 +787,11 @@ struct EnvLane {
   // the same blend for a per-joint array of twists (the new link twists of the outward pass)
   template <int IT>
   RL_FN SV pick_twist(const SV V0, const SV (&Vl)[CL]) const {
-    const int l = sub + SUB * IT - 1;
+    const int l = grp_of(IT) - 1;
     SV Vm{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
     for (int j = 0; j < CL; ++j) {
-      if (j < SUB * IT - 1 || j > SUB * IT + SUB - 2) continue;
+      if (j < G0 + SUB * IT - 1 || j > G0 + SUB * IT + SUB - 2) continue;
       const float w = l == j ? 1.f : 0.f;
       Vm.a += w * Vl[j].a; Vm.l += w * Vl[j].l;
     }
@@ -835,6 +863,13 @@ struct EnvLane {
       }
     }
     LinkRec rec[NIT];
+    LinkRec rec0;  // merged instances: contacts of the base-share spheres (sub-lane 0 has them); else unused
+    if (M0) {
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) rec0.A[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rec0.r[i] = 0.f;
+    }
     SV Vold[NIT];
     static_for<0, NIT>([&](auto it) {
 #pragma unroll
@@ -846,7 +881,7 @@ struct EnvLane {
     // ---- contacts, stage B
     RL_PHASE(5, "sub.contact_pass1");
     static_for<0, NIT>([&](auto it) {
-      if (fetched[it.value]) group_contacts<it.value>(Rwb, Vold[it.value], gf[it.value], rec[it.value], active_mask);
+      if (fetched[it.value]) group_contacts<it.value>(Rwb, Vold[it.value], V0, gf[it.value], rec[it.value], M0 ? rec0 : rec[it.value], active_mask);
     });
     // ---- articulated-body recursion, tip -> base (every sub-lane; the records come from their owners)
     RL_PHASE(9, "sub.aba");
@@ -857,7 +892,7 @@ struct EnvLane {
     for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
     float Uh[CL][6], ui[CL];
     static_for_down<CL - 1>([&](auto jc) {
-      constexpr int j = jc.value, g = j + 1, so = g % SUB, io = g / SUB;
+      constexpr int j = jc.value, gq = j + 1 - G0, so = gq % SUB, io = gq / SUB;  // owner sub-lane / iteration of link group j + 1
 #pragma unroll
       for (int i = 0; i < B6::size; ++i) P.A[i] += ctx.template leg_bcast<so>(rec[io].A[i]);
 #pragma unroll
@@ -892,11 +927,12 @@ struct EnvLane {
       }
     });
     // the lane's share of the base link's contacts (group 0, owned by sub-lane 0 in iteration 0), when anybody has one
-    if (ctx.any(sub == 0 && (active_mask & ((1u << SPL) - 1u)) != 0u)) {
+    if (ctx.any(sub == 0 && (active_mask & base_bits()) != 0u)) {
+      const LinkRec& rb = M0 ? rec0 : rec[0];
 #pragma unroll
-      for (int i = 0; i < B6::size; ++i) P.A[i] += ctx.template leg_bcast<0>(rec[0].A[i]);
+      for (int i = 0; i < B6::size; ++i) P.A[i] += ctx.template leg_bcast<0>(rb.A[i]);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<0>(rec[0].r[i]);
+      for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<0>(rb.r[i]);
     }
     if (k == 0) {  // the base link itself and the persistent external wrench [UPSTREAM B8]: rides with limb 0
       const int bi = LY.EF_BASE_INERTIA;
@@ -1339,10 +1375,11 @@ struct EnvLane {
       for (int i = 0; i < MAXOWN; ++i)
         if (own[i] == slot) fown[i] += Fw;
     };
+    const SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
     if constexpr (STASH) {
       // every contact of pass 1 sits in the lane's stash: SPL slots per link group, masked by the activity bits, read in one batch
       static_for<0, NIT>([&](auto it) {
-        const int g = sub + SUB * it.value;
+        const int g = grp_of(it.value);
         const int gi = g <= CL ? g : CL;
         const uint32_t bits = g <= CL ? (active_mask >> (gi * SPL)) & ((1u << SPL) - 1u) : 0u;
         if (!ctx.any(bits != 0u)) return;
@@ -1359,12 +1396,15 @@ struct EnvLane {
         }
 #pragma unroll
         for (int s2 = 0; s2 < SPL; ++s2)
-          if (c[s2].act) apply(c[s2], Vnew[it.value], slot[s2]);
+          if (c[s2].act) {
+            SV Vs = Vnew[it.value];
+            if (M0) Vs = pick_sv(on_base(gi, s2), V0n, Vs);
+            apply(c[s2], Vs, slot[s2]);
+          }
       });
     } else {
       // one lane per limb (RL_ENV_SUB=1 / the CPU emulator's default): no stash - the spheres that were active in pass 1 are
       // evaluated again (same state -> same contact), twists from the generalised velocities
-      const SV V0n{{nu0[0], nu0[1], nu0[2]}, {nu0[3], nu0[4], nu0[5]}};
 #pragma unroll 1
       for (uint32_t m = active_mask; m != 0; m &= m - 1) {
         const int ci = __builtin_ctz(m);
@@ -1373,13 +1413,13 @@ struct EnvLane {
         V3 cb, cw;
         sphere_center(C, Rwb, g, s2, rad, cb, cw);
         const Contact c = contact_from_patch(C, Rwb, V0, qd, g, s2, rad, cb, cw, terrain_fetch(u, S.terrain, pos.x, pos.y, cw.x, cw.y));
-        if (c.act) apply(c, link_twist(C, g, V0n, qdn), L.sph_slot[g][s2]);
+        if (c.act) apply(c, link_twist(C, g, s2, V0n, qdn), L.sph_slot[g][s2]);
       }
     }
     RL_PHASE(14, "sub.sensor+integrate");
     // trunk-link bodies can be fed by several lanes (A1: the trunk box corners are spread over 4 lanes); slot 0,
     // when a lane has it, is the first entry of its list.  Nothing to sum when no lane of the wavefront touches with group 0.
-    if (ctx.any((active_mask & ((1u << SPL) - 1u)) != 0u)) {
+    if (ctx.any((active_mask & base_bits()) != 0u)) {
       for (int bi = 0; bi < T.n_base_bodies; ++bi) {
         const bool mine = L.base_body_local == bi && own[0] == 0;
         V3 f{ctx.esum(mine ? fown[0].x : 0.f), ctx.esum(mine ? fown[0].y : 0.f), ctx.esum(mine ? fown[0].z : 0.f)};

@@ -25,15 +25,20 @@ constexpr int MAX_NBS = 9;  // body slots per lane: 0 = a trunk-link body (or em
 
 // Compile-time shape of a lane program instance: limb chain length, trunk joints, sphere slots per link
 // group, body slots per lane.  Loops are bounded by these (the tables / HBM layout by the MAX_* above).
-template <int CL_, int NW_, int SPL_, int NBS_>
+// M0 = 1 ("merged"): the lane's share of the base link's spheres has no link group of its own - its spheres sit in free sphere
+// slots of the limb link groups, flagged in LaneTabT::sph_base_mask (frame, twist and record of the BASE link for those slots).
+// A 4-joint limb then has 4 link groups for its 4 sub-lanes instead of 5: one contact pass per substep instead of two.
+template <int CL_, int NW_, int SPL_, int NBS_, int M0_ = 0>
 struct Topo {
-  static constexpr int CL = CL_, NW = NW_, SPL = SPL_, NBS = NBS_, JX = CL_ + NW_, NB = 6 + NW_;
+  static constexpr int CL = CL_, NW = NW_, SPL = SPL_, NBS = NBS_, JX = CL_ + NW_, NB = 6 + NW_, M0 = M0_;
+  static_assert(M0_ == 0 || NW_ == 0, "merged base share: quadruped instances only");
   static constexpr bool ROT = NW_ > 0;  // joint frames may be rotated w.r.t. the parent link (URDF joint rpy)
   static constexpr int DMAX = NLANE_ * CL_ + NW_;  // joints a model of this shape can have
   static constexpr int OBS_NC = 12 + 3 * DMAX;     // non-scan columns of an observation group (ObsGroupTabT)
 };
 using TopoQuad3 = Topo<3, 0, 3, 6>;  // A1, Go2
-using TopoQuad4 = Topo<4, 0, 3, 6>;  // Go2W
+using TopoQuad4 = Topo<4, 0, 3, 6>;  // wheeled quadrupeds whose base spheres do not fit the free limb slots
+using TopoQuad4M = Topo<4, 0, 3, 6, 1>;  // Go2W and the other wheeled quadrupeds
 using TopoG1 = Topo<7, 3, 4, 9>;     // G1 29-DoF
 constexpr int MAX_T = 40;   // reward terms
 constexpr int MAX_OBS = 12;
@@ -74,6 +79,7 @@ struct LaneTabT {
   float slot_pos[TP::NBS][3];          // body frame origin in its link frame
   int32_t base_body_local;             // which sphere-carrying trunk body (0..n_base_bodies-1) slot 0 / group 0 belongs to, -1 none
   int32_t owns_base_body;              // 1 if this lane keeps the timers of that trunk body
+  uint32_t sph_base_mask;              // bit g*SPL+s: the sphere in slot (g, s) rides on the BASE link (merged instances; else 0)
   static constexpr int MAXOWN = TP::NBS > 6 ? 4 : 2;
   int32_t own_slot[4][MAXOWN];         // 16-lanes-per-env mapping: the body slots sub-lane s updates (ascending, -1 padded)
 };
@@ -126,6 +132,7 @@ struct TaskTab {  // everything that is not per limb
   int32_t CL, NW, SPL, NBS, D, n_bodies, n_base_bodies;
   int32_t nw_used;      // trunk joints the model really has (<= NW; the rest are inert padding)
   uint32_t slot_valid;  // bit g*SPL+s: some lane has a collision sphere in slot (g, s)
+  int32_t merged;       // 1: tables built for a Topo<..., M0 = 1> instance (base-share spheres in limb slots, LaneTabT::sph_base_mask)
   int32_t wrench_depth; // trunk link (0 = base, i = after i trunk joints) carrying the body the wrench / COM events address
   int32_t scan_depth;   // trunk link carrying the height-scanner body
   float scan_pos[3];    // scanner body origin in that link's frame
@@ -203,7 +210,7 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
       b.slot_body[q] = a.slot_body[q]; b.slot_grp[q] = a.slot_grp[q];
       for (int c = 0; c < 3; ++c) b.slot_pos[q][c] = a.slot_pos[q][c];
     }
-    b.base_body_local = a.base_body_local; b.owns_base_body = a.owns_base_body;
+    b.base_body_local = a.base_body_local; b.owns_base_body = a.owns_base_body; b.sph_base_mask = a.sph_base_mask;
     for (int q = 0; q < 4; ++q)
       for (int i = 0; i < LaneTabT<TP>::MAXOWN; ++i) b.own_slot[q][i] = a.own_slot[q][i];
   }

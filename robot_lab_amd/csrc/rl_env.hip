@@ -283,33 +283,48 @@ struct Backend {
     return check(hipGetLastError());
   }
   size_t lds_bytes = 0;
-  int configure(const Tables& T) {  // dynamic LDS: tables + observation staging tiles + lane scratchpad + reward stage
-    const size_t ept = 16 / sub;
-    const size_t tab = staged_bytes(T);
-    size_t s0 = (ept * T.policy_dim + 3) / 4 * 16;
-    size_t s1 = (ept * T.critic_dim + 3) / 4 * 16;
-    const size_t aux = T.NW > 0 ? (size_t)LbLayout<TopoG1>::AUX_WORDS * (64 / sub) * 4 : 0;
-    if (s0 + s1 < aux) s1 = aux - s0;
-    const size_t ls_words = T.NW > 0 ? LsFor<TopoG1, 4>::type::WORDS : (sub > 1 ? LsFor<TopoQuad3, 4>::type::WORDS : LsFor<TopoQuad3, 1>::type::WORDS);
-    const size_t lb_words = T.NW > 0 ? LbLayout<TopoG1>::WORDS : 0;
-    const size_t env_words = T.NW > 0 ? LbLayout<TopoG1>::ENV_WORDS : 0;
-    const size_t stash = (T.NW == 0 && sub > 1) ? (size_t)LsFor<TopoQuad3, 4>::STASH * CONTACT_WORDS * 64 * 4 : 0;
-    // reward stage + max(observation rows + feature vectors, reward tables): on the contact stash when they fit (env_kernel)
-    size_t region = s0 + s1 + ept * feat_count(T.D) * 4;
-    region = std::max(region, ept * (size_t)rew_tab_words(T.D, T.n_bodies) * 4);
-    size_t rows = ept * MAX_T * 4 + region;
-    if (stash > 0 && rows <= stash) rows = 0;
-    if (T.NW > 0 && rows <= (size_t)(LbLayout<TopoG1>::WORDS - LbLayout<TopoG1>::REC) * (64 / sub) * 4) rows = 0;  // on the limb-shared record words
-    lds_bytes = tab + ls_words * 64 * 4 + lb_words * (64 / sub) * 4 + env_words * ept * 4 + rows;
+  // dynamic LDS of an instance: the SAME layout arithmetic as env_kernel (tables | lane scratchpad | limb-shared words | per-env
+  // words | staging rows + reward stage unless they alias the contact stash / the record words)
+  template <class TP, int SUB>
+  static size_t lds_need(const Tables& T) {
+    using Ctx = WaveCtx<SUB>;
+    using LS = typename LsFor<TP, SUB>::type;
+    const int s0w = (Ctx::EPT * T.policy_dim + 3) & ~3;
+    int s1w = (Ctx::EPT * T.critic_dim + 3) & ~3;
+    const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
+    if (s0w + s1w < need) s1w = need - s0w;
+    int region = s0w + s1w + Ctx::EPT * feat_count(T.D);
+    region = std::max(region, Ctx::EPT * rew_tab_words(T.D, T.n_bodies));
+    constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
+    constexpr int LB_FREE = TP::NW > 0 ? (LbLayout<TP>::WORDS - LbLayout<TP>::REC) * Ctx::LB_STRIDE : 0;
+    const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;
+    const bool alias_lb = TP::NW > 0 && Ctx::EPT * MAX_T + region <= LB_FREE;
+    size_t words = (size_t)LS::WORDS * 64 + (size_t)LbLayout<TP>::WORDS * Ctx::LB_STRIDE + (size_t)Ctx::EPT * LbLayout<TP>::ENV_WORDS;
+    if (!alias && !alias_lb) words += (size_t)Ctx::EPT * MAX_T + region;
+    return staged_bytes(T) + words * 4;
+  }
+  int configure(const Tables& T) {
+    const int key = (T.CL + (T.merged ? 100 : 0)) * 10 + sub;
+    switch (key) {
+      case 31: lds_bytes = lds_need<TopoQuad3, 1>(T); break;
+      case 34: lds_bytes = lds_need<TopoQuad3, 4>(T); break;
+      case 41: lds_bytes = lds_need<TopoQuad4, 1>(T); break;
+      case 44: lds_bytes = lds_need<TopoQuad4, 4>(T); break;
+      case 1041: lds_bytes = lds_need<TopoQuad4M, 1>(T); break;
+      case 1044: lds_bytes = lds_need<TopoQuad4M, 4>(T); break;
+      case 71: lds_bytes = lds_need<TopoG1, 1>(T); break;
+      case 74: lds_bytes = lds_need<TopoG1, 4>(T); break;
+      default: err = "no lane-program instance for chain length " + std::to_string(T.CL); return -1;
+    }
     if (lds_bytes > 160 * 1024) {
       err = "observation rows do not fit the 160 KiB LDS of a CU";
       return -1;
     }
     return 0;
   }
-  int launch(const KState& S, const void* T, int CL, int reset, void* stream) {
+  int launch(const KState& S, const void* T, int CL, int reset, void* stream) {  // CL: chain length, + 100 for a merged instance
     hipStream_t st = (hipStream_t)stream;
-    // RL_ENV_ONLY=<CL * 10 + SUB> (e.g. 34): build that one instance only - kernel experiments compile in 15 s instead of 80
+    // RL_ENV_ONLY=<CL * 10 + SUB> (e.g. 34; 1044: merged): build that one instance only - kernel experiments compile in 15 s instead of 80
 #ifndef RL_ENV_ONLY
 #define RL_ENV_ONLY 0
 #endif
@@ -325,6 +340,12 @@ struct Backend {
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 44
       case 44: return launch_cl<TopoQuad4, 4>(S, T, reset, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 1041
+      case 1041: return launch_cl<TopoQuad4M, 1>(S, T, reset, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 1044
+      case 1044: return launch_cl<TopoQuad4M, 4>(S, T, reset, lds_bytes, st);
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 71
       case 71: return launch_cl<TopoG1, 1>(S, T, reset, lds_bytes, st);

@@ -62,13 +62,14 @@ inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& N
 }
 
 inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_lane, std::vector<int>& body_slot, std::vector<int>& link_lane_out,
-                        std::vector<int>& link_pos_out) {
+                        std::vector<int>& link_pos_out, bool merge = false) {
   memset(&T, 0, sizeof(T));
   const rl_model_desc& m = d.model;
   int CL, NW, SPL, NBS;
   if (topo_shape(m, CL, NW, SPL, NBS)) return -1;
   const int NGRP = CL + 1;
-  T.CL = CL; T.NW = NW; T.SPL = SPL; T.NBS = NBS; T.nw_used = m.num_trunk;
+  if (merge && !(NW == 0 && CL == 4)) return fail("merged base share: 4-joint quadruped limbs only");
+  T.CL = CL; T.NW = NW; T.SPL = SPL; T.NBS = NBS; T.nw_used = m.num_trunk; T.merged = merge ? 1 : 0;
   T.D = m.num_dof;
   T.n_bodies = m.num_bodies;
   body_lane.assign(m.num_bodies, -1);
@@ -176,45 +177,60 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   // riding on the same trunk link that own no trunk body: first every such body reserves the lanes it needs
   // (MagicLab Dog-W: 6-sphere base + 4-sphere head), then the lanes still free go to the first of them in body
   // order (A1 trunk: 8 corner spheres -> 2 per lane); the spheres are dealt round-robin over a body's lanes.
+  // Limb spheres first: a merged instance (Topo<..., M0 = 1>) hosts the lane's share of the trunk link's spheres in the sphere
+  // slots its hip link group leaves free (the group sub-lane 0 evaluates, which also owns body slot 0), so a lane's room for
+  // trunk spheres is known only then.  When the trunk spheres do not fit, the caller builds the tables again unmerged.
   int fill[NLANE][MAX_NGRP];
   memset(fill, 0, sizeof(fill));
+  auto put_sphere = [&](int k, int grp, int g, int slot) {
+    LaneTab& L = T.lane[k];
+    const int s = fill[k][grp]++;
+    for (int c = 0; c < 3; ++c) L.sph_c[grp][s][c] = m.sphere_center[g][c];
+    L.sph_r[grp][s] = m.sphere_radius[g];
+    L.sph_slot[grp][s] = slot;
+    return s;
+  };
+  for (int g = 0; g < m.num_spheres; ++g) {
+    const int b = m.sphere_body[g], link = m.body_link[b];
+    if (link_k[link] == -1) continue;
+    const int k = link_k[link], grp = link_j[link] + 1;
+    if (fill[k][grp] >= SPL) return fail("too many collision spheres on one link group (body " + std::to_string(b) + ")");
+    put_sphere(k, grp, g, body_slot[b]);
+  }
+  const int base_grp = merge ? 1 : 0;
+  int base_cap[NLANE], base_fill[NLANE] = {0, 0, 0, 0};
+  for (int k = 0; k < NLANE; ++k) base_cap[k] = SPL - fill[k][base_grp];
   std::vector<uint32_t> lanes_of(m.num_bodies, 0u);
   for (int pass = 0; pass < 2; ++pass)
     for (int b = 0; b < m.num_bodies; ++b) {
       const int link = m.body_link[b];
-      if (link_k[link] != -1 || nsph[b] <= SPL) continue;
+      if (link_k[link] != -1 || nsph[b] == 0 || body_lane[b] < 0 || body_slot[b] != 0) continue;
+      if (pass == 0 && nsph[b] <= base_cap[body_lane[b]]) continue;
+      if (pass == 1 && lanes_of[b] == 0u) continue;
       if (pass == 0) lanes_of[b] = 1u << body_lane[b];
-      int have = 0;
-      for (int kk = 0; kk < NLANE; ++kk) have += (lanes_of[b] >> kk) & 1u;
-      const int want = pass == 0 ? (nsph[b] + SPL - 1) / SPL : NLANE;
-      for (int kk = 0; kk < NLANE && have < want; ++kk)
+      int room = 0;
+      for (int kk = 0; kk < NLANE; ++kk) room += ((lanes_of[b] >> kk) & 1u) ? base_cap[kk] : 0;
+      for (int kk = 0; kk < NLANE && (pass == 1 || room < nsph[b]); ++kk)
         if (T.lane[kk].base_body_local == -1 && T.lane[kk].grp0_depth == link_j[link]) {
           T.lane[kk].base_body_local = T.lane[body_lane[b]].base_body_local;
           lanes_of[b] |= 1u << kk;
-          ++have;
+          room += base_cap[kk];
         }
     }
   int rr = 0;
   for (int g = 0; g < m.num_spheres; ++g) {
-    int b = m.sphere_body[g], link = m.body_link[b];
-    int k, grp, slot;
-    if (link_k[link] == -1) {
-      grp = 0; slot = 0;
-      k = body_lane[b];
-      if (nsph[b] > SPL)
-        for (int tries = 0; tries < NLANE; ++tries, ++rr) {
-          int kk = rr % NLANE;
-          if (((lanes_of[b] >> kk) & 1u) && fill[kk][0] < SPL) { k = kk; ++rr; break; }
-        }
-    } else {
-      k = link_k[link]; grp = link_j[link] + 1; slot = body_slot[b];
-    }
-    LaneTab& L = T.lane[k];
-    if (fill[k][grp] >= SPL) return fail("too many collision spheres on one link group (body " + std::to_string(b) + ")");
-    int s = fill[k][grp]++;
-    for (int c = 0; c < 3; ++c) L.sph_c[grp][s][c] = m.sphere_center[g][c];
-    L.sph_r[grp][s] = m.sphere_radius[g];
-    L.sph_slot[grp][s] = slot;
+    const int b = m.sphere_body[g], link = m.body_link[b];
+    if (link_k[link] != -1) continue;
+    int k = body_lane[b];
+    if (lanes_of[b] != 0u)
+      for (int tries = 0; tries < NLANE; ++tries, ++rr) {
+        int kk = rr % NLANE;
+        if (((lanes_of[b] >> kk) & 1u) && base_fill[kk] < base_cap[kk]) { k = kk; ++rr; break; }
+      }
+    if (base_fill[k] >= base_cap[k]) return fail("too many collision spheres on one link group (body " + std::to_string(b) + ")");
+    ++base_fill[k];
+    const int s = put_sphere(k, base_grp, g, 0);
+    if (merge) T.lane[k].sph_base_mask |= 1u << (base_grp * SPL + s);
   }
   // 16-lanes-per-env mapping: body slots each sub-lane updates (the slots of the link groups it evaluates)
   for (int k = 0; k < NLANE; ++k) {
@@ -225,7 +241,9 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       for (int i = 0; i < LaneTab::MAXOWN; ++i) L.own_slot[q][i] = -1;
       for (int sl = 0; sl < NBS; ++sl) {
         const bool used = L.slot_body[sl] >= 0 || (sl == 0 && L.base_body_local >= 0);
-        if (!used || (L.slot_grp[sl] % 4) != q) continue;
+        // the sub-lane that evaluates the slot's link group: g % 4, merged instances (g - 1) % 4 with the trunk slot on sub-lane 0
+        const int gq = merge ? (L.slot_grp[sl] == 0 ? 0 : (L.slot_grp[sl] - 1) % 4) : L.slot_grp[sl] % 4;
+        if (!used || gq != q) continue;
         if (n >= maxown) return fail("too many body slots on one sub-lane");
         L.own_slot[q][n++] = sl;
       }
@@ -387,7 +405,7 @@ struct EnvImpl {
   void* packed_dev = nullptr;     // TablesT<Topo> image the env kernels stage into LDS
   KState S;
   CmdLevelParams cmd_level_params{};
-  int N = 0, Npad = 0, D = 0, B = 0, CL = 0, ept = ENVS_PER_WAVE;
+  int N = 0, Npad = 0, D = 0, B = 0, CL = 0, inst = 0, ept = ENVS_PER_WAVE;  // inst: lane-program instance key (CL, + 100 merged)
   uint64_t seed = 0;
   uint32_t step_counter = 0;
   // the kernels take the step count as *step_base + launch literal (rl_env_graph_*): `anchor` mirrors the device word
@@ -431,8 +449,20 @@ struct EnvImpl {
     D = d->model.num_dof;
     B = d->model.num_bodies;
     if (N <= 0) return fail("num_envs must be positive");
-    if (build_tables(*d, tables, body_lane, body_slot, link_lane, link_pos)) return -1;
+    {
+      // wheeled quadrupeds (4-joint limbs): the merged instance when the trunk's spheres fit the free hip-group slots (Go2W, B2W,
+      // ZSL1W), else (M20, Dog-W) the instance with a link group for the trunk share.  RL_ENV_MERGE=0: never merged, 2: whenever it fits.
+      const char* mv = std::getenv("RL_ENV_MERGE");
+      const bool want = d->model.num_trunk == 0 && d->model.chain_len == 4 && !(mv && atoi(mv) == 0);
+      bool merged = want && build_tables(*d, tables, body_lane, body_slot, link_lane, link_pos, true) == 0;
+      // it pays when the last link group (the wheels) has spheres - the group that costs the unmerged instance a second contact
+      // pass; without (B2W) the unmerged instance skips that pass anyway and is 1 % faster (profiles/r02_merged_wheeled.txt)
+      if (merged && ((tables.slot_valid >> (tables.CL * tables.SPL)) & ((1u << tables.SPL) - 1u)) == 0u && !(mv && atoi(mv) == 2)) merged = false;
+      if (!merged && build_tables(*d, tables, body_lane, body_slot, link_lane, link_pos, false)) return -1;
+    }
     CL = tables.CL;
+    inst = tables.CL + (tables.merged ? 100 : 0);
+    if (std::getenv("RL_ENV_DEBUG")) fprintf(stderr, "rl_env: lane program CL %d NW %d merged %d, %d envs per wavefront\n", tables.CL, tables.NW, tables.merged, ept);
     if (be.init(device)) return fail("device init failed: " + be.error());
     if (be.configure(tables)) return fail("kernel configuration failed: " + be.error());
     const size_t Np = Npad, ntile = Npad / ept;
@@ -646,7 +676,7 @@ struct EnvImpl {
       s.reset_mask = reset_mask;
     }
     flip_obs(s);
-    return be.launch(s, packed_dev, CL, /*reset=*/1, stream) ? fail("launch failed: " + be.error()) : 0;
+    return be.launch(s, packed_dev, inst, /*reset=*/1, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 
   int step(const float* action_dev, void* stream, const float* ro_values = nullptr, float* ro_rewards = nullptr, uint8_t* ro_dones = nullptr,
@@ -659,7 +689,7 @@ struct EnvImpl {
     flip_obs(s);
     s.action_in = action_dev;
     s.ro_values = ro_values; s.ro_rewards = ro_rewards; s.ro_dones = ro_dones; s.ro_gamma = ro_gamma;
-    if (be.launch(s, packed_dev, CL, /*reset=*/0, stream)) return fail("launch failed: " + be.error());
+    if (be.launch(s, packed_dev, inst, /*reset=*/0, stream)) return fail("launch failed: " + be.error());
     // command_levels_* curricula: the decision of a step whose counter is a multiple of the episode length needs the episode
     // sums of every env reset in it - one more (single-thread) launch behind that step, once per episode length
     // (the launch tests the step count itself: it sits in captured graphs, too)

@@ -296,6 +296,8 @@ struct Backend {
       case 41: run<rl::TopoQuad4, 1>(S, T, reset); return 0;
       case 34: run<rl::TopoQuad3, 4>(S, T, reset); return 0;
       case 44: run<rl::TopoQuad4, 4>(S, T, reset); return 0;
+      case 1041: run<rl::TopoQuad4M, 1>(S, T, reset); return 0;
+      case 1044: run<rl::TopoQuad4M, 4>(S, T, reset); return 0;
       case 71: run<rl::TopoG1, 1>(S, T, reset); return 0;
       case 74: run<rl::TopoG1, 4>(S, T, reset); return 0;
       default: err = "unsupported chain length"; return -1;
