@@ -352,6 +352,7 @@ struct EnvLane {
   V3 base_com;  // COM of the root body (root COM velocity)
   V3 wr_com;    // COM of the wrench body in its trunk link frame
   V3 extF, extT;
+  float fric0[3];  // merged instances: material of the trunk body in slot 0 (its spheres may sit with any sub-lane; the rows below are the owner's)
   // per-step scratch
   float tau_app[JX], qacc[JX];
   // contact-sensor state + friction in the lane-private LDS scratchpad
@@ -440,6 +441,10 @@ struct EnvLane {
     for (int j = 0; j < JX; ++j) {
       tau_app[j] = 0.f;
       qacc[j] = 0.f;
+    }
+    if (M0) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) fric0[t] = LF(LY.LF_FRICTION + t);
     }
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) {  // sensor state + material of the body slots this lane owns (the others are never read unmasked)
@@ -574,6 +579,10 @@ struct EnvLane {
       float utn = norm(ut);
       int slot = L.sph_slot[g][s];
       float mus = fric[slot][0], mud = fric[slot][1], rest = fric[slot][2];
+      if (M0) {
+        const bool ob = on_base(g, s);
+        mus = ob ? fric0[0] : mus; mud = ob ? fric0[1] : mud; rest = ob ? fric0[2] : rest;
+      }
       float cnrm = u.contact_c * fminf(1.0f, phi * u.inv_phi_ref) * (1.0f - rest);
       float dn = cnrm + u.contact_k * u.dt;
       float bias = fminf(u.contact_k * phi, u.contact_vdep * dn);
@@ -927,12 +936,18 @@ struct EnvLane {
       }
     });
     // the lane's share of the base link's contacts (group 0, owned by sub-lane 0 in iteration 0), when anybody has one
-    if (ctx.any(sub == 0 && (active_mask & base_bits()) != 0u)) {
-      const LinkRec& rb = M0 ? rec0 : rec[0];
+    if (M0) {  // flagged slots of any sub-lane
+      if (ctx.any((active_mask & base_bits()) != 0u)) {
 #pragma unroll
-      for (int i = 0; i < B6::size; ++i) P.A[i] += ctx.template leg_bcast<0>(rb.A[i]);
+        for (int i = 0; i < B6::size; ++i) P.A[i] += ctx.leg_sum(rec0.A[i]);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<0>(rb.r[i]);
+        for (int i = 0; i < 6; ++i) P.r[i] += ctx.leg_sum(rec0.r[i]);
+      }
+    } else if (ctx.any(sub == 0 && (active_mask & base_bits()) != 0u)) {
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) P.A[i] += ctx.template leg_bcast<0>(rec[0].A[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<0>(rec[0].r[i]);
     }
     if (k == 0) {  // the base link itself and the persistent external wrench [UPSTREAM B8]: rides with limb 0
       const int bi = LY.EF_BASE_INERTIA;
@@ -1366,11 +1381,16 @@ struct EnvLane {
     RL_PHASE(13, "sub.contact_pass2");
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) fown[i] = {0.f, 0.f, 0.f};
-    auto apply = [&](const Contact& c, const SV& Vg, int slot) __attribute__((always_inline)) {
+    V3 fb0{0.f, 0.f, 0.f};  // merged instances: force on the trunk body from the flagged slots of this lane (whoever owns slot 0)
+    auto apply = [&](const Contact& c, const SV& Vg, int slot, bool onb) __attribute__((always_inline)) {
       V3 uu = Vg.l + cross(Vg.a, c.x);
       float un = dot(c.n, uu);
       V3 Fb = (c.bias - (c.dn - c.dt) * un) * c.n - c.dt * uu;
       V3 Fw = mul(Rwb, Fb);
+      if (M0 && onb) {
+        fb0 += Fw;
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < MAXOWN; ++i)
         if (own[i] == slot) fown[i] += Fw;
@@ -1398,8 +1418,9 @@ struct EnvLane {
         for (int s2 = 0; s2 < SPL; ++s2)
           if (c[s2].act) {
             SV Vs = Vnew[it.value];
-            if (M0) Vs = pick_sv(on_base(gi, s2), V0n, Vs);
-            apply(c[s2], Vs, slot[s2]);
+            const bool onb = on_base(gi, s2);
+            if (M0) Vs = pick_sv(onb, V0n, Vs);
+            apply(c[s2], Vs, slot[s2], onb);
           }
       });
     } else {
@@ -1413,7 +1434,7 @@ struct EnvLane {
         V3 cb, cw;
         sphere_center(C, Rwb, g, s2, rad, cb, cw);
         const Contact c = contact_from_patch(C, Rwb, V0, qd, g, s2, rad, cb, cw, terrain_fetch(u, S.terrain, pos.x, pos.y, cw.x, cw.y));
-        if (c.act) apply(c, link_twist(C, g, s2, V0n, qdn), L.sph_slot[g][s2]);
+        if (c.act) apply(c, link_twist(C, g, s2, V0n, qdn), L.sph_slot[g][s2], on_base(g, s2));
       }
     }
     RL_PHASE(14, "sub.sensor+integrate");
@@ -1421,8 +1442,10 @@ struct EnvLane {
     // when a lane has it, is the first entry of its list.  Nothing to sum when no lane of the wavefront touches with group 0.
     if (ctx.any((active_mask & base_bits()) != 0u)) {
       for (int bi = 0; bi < T.n_base_bodies; ++bi) {
-        const bool mine = L.base_body_local == bi && own[0] == 0;
-        V3 f{ctx.esum(mine ? fown[0].x : 0.f), ctx.esum(mine ? fown[0].y : 0.f), ctx.esum(mine ? fown[0].z : 0.f)};
+        const bool member = L.base_body_local == bi, mine = member && own[0] == 0;
+        const V3 part = M0 ? fb0 : fown[0];
+        const bool has = M0 ? member : mine;
+        V3 f{ctx.esum(has ? part.x : 0.f), ctx.esum(has ? part.y : 0.f), ctx.esum(has ? part.z : 0.f)};
         if (mine) fown[0] = f;
       }
     }

@@ -178,8 +178,8 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   // (MagicLab Dog-W: 6-sphere base + 4-sphere head), then the lanes still free go to the first of them in body
   // order (A1 trunk: 8 corner spheres -> 2 per lane); the spheres are dealt round-robin over a body's lanes.
   // Limb spheres first: a merged instance (Topo<..., M0 = 1>) hosts the lane's share of the trunk link's spheres in the sphere
-  // slots its hip link group leaves free (the group sub-lane 0 evaluates, which also owns body slot 0), so a lane's room for
-  // trunk spheres is known only then.  When the trunk spheres do not fit, the caller builds the tables again unmerged.
+  // slots its limb link groups leave free, so a lane's room for trunk spheres is known only then.  When the trunk spheres do not
+  // fit, the caller builds the tables again unmerged.
   int fill[NLANE][MAX_NGRP];
   memset(fill, 0, sizeof(fill));
   auto put_sphere = [&](int k, int grp, int g, int slot) {
@@ -197,9 +197,11 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     if (fill[k][grp] >= SPL) return fail("too many collision spheres on one link group (body " + std::to_string(b) + ")");
     put_sphere(k, grp, g, body_slot[b]);
   }
-  const int base_grp = merge ? 1 : 0;
   int base_cap[NLANE], base_fill[NLANE] = {0, 0, 0, 0};
-  for (int k = 0; k < NLANE; ++k) base_cap[k] = SPL - fill[k][base_grp];
+  for (int k = 0; k < NLANE; ++k) {
+    base_cap[k] = 0;
+    for (int g = merge ? 1 : 0; g <= (merge ? CL : 0); ++g) base_cap[k] += SPL - fill[k][g];
+  }
   std::vector<uint32_t> lanes_of(m.num_bodies, 0u);
   for (int pass = 0; pass < 2; ++pass)
     for (int b = 0; b < m.num_bodies; ++b) {
@@ -229,8 +231,15 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       }
     if (base_fill[k] >= base_cap[k]) return fail("too many collision spheres on one link group (body " + std::to_string(b) + ")");
     ++base_fill[k];
-    const int s = put_sphere(k, base_grp, g, 0);
-    if (merge) T.lane[k].sph_base_mask |= 1u << (base_grp * SPL + s);
+    int grp = 0;
+    if (merge) {  // a free slot of a limb link group: one that has spheres of its own first (its contact code runs anyway)
+      for (int gg = 1; gg <= CL && grp == 0; ++gg)
+        if (fill[k][gg] > 0 && fill[k][gg] < SPL) grp = gg;
+      for (int gg = 1; gg <= CL && grp == 0; ++gg)
+        if (fill[k][gg] < SPL) grp = gg;
+    }
+    const int s = put_sphere(k, grp, g, 0);
+    if (merge) T.lane[k].sph_base_mask |= 1u << (grp * SPL + s);
   }
   // 16-lanes-per-env mapping: body slots each sub-lane updates (the slots of the link groups it evaluates)
   for (int k = 0; k < NLANE; ++k) {
@@ -450,8 +459,8 @@ struct EnvImpl {
     B = d->model.num_bodies;
     if (N <= 0) return fail("num_envs must be positive");
     {
-      // wheeled quadrupeds (4-joint limbs): the merged instance when the trunk's spheres fit the free hip-group slots (Go2W, B2W,
-      // ZSL1W), else (M20, Dog-W) the instance with a link group for the trunk share.  RL_ENV_MERGE=0: never merged, 2: whenever it fits.
+      // wheeled quadrupeds (4-joint limbs): the merged instance when the trunk's spheres fit the free sphere slots of the limbs
+      // (Go2W, ZSL1W, M20, Dog-W), else the instance with a link group for the trunk share.  RL_ENV_MERGE=0: never merged, 2: whenever it fits.
       const char* mv = std::getenv("RL_ENV_MERGE");
       const bool want = d->model.num_trunk == 0 && d->model.chain_len == 4 && !(mv && atoi(mv) == 0);
       bool merged = want && build_tables(*d, tables, body_lane, body_slot, link_lane, link_pos, true) == 0;

@@ -128,11 +128,59 @@ def _read_stl_vertices(path: str) -> np.ndarray:
     return np.asarray(verts, dtype=np.float64)
 
 
+def _read_dae_vertices(path: str) -> np.ndarray:
+    """Vertices [n, 3] of a COLLADA file (Unitree B2W: calves and wheels, `b2w_description.urdf` FL_calf / FL_foot collision):
+    the position arrays of every geometry, carried through the <matrix> transforms of the scene nodes that instance them
+    (Blender exports millimetres with a 0.001 scale matrix) and the asset's unit."""
+    ns = {"c": "http://www.collada.org/2005/11/COLLADASchema"}
+    root = ET.parse(path).getroot()
+    geoms = {}
+    for g in root.iterfind(".//c:library_geometries/c:geometry", ns):
+        mesh = g.find("c:mesh", ns)
+        vin = mesh.find("c:vertices/c:input[@semantic='POSITION']", ns) if mesh is not None else None
+        if vin is None:
+            continue
+        src = mesh.find(f"c:source[@id='{vin.get('source')[1:]}']/c:float_array", ns)
+        if src is not None and src.text:
+            geoms[g.get("id")] = np.array(src.text.split(), dtype=np.float64).reshape(-1, 3)
+    unit = root.find("c:asset/c:unit", ns)
+    meter = float(unit.get("meter", "1")) if unit is not None else 1.0
+    out = []
+
+    def visit(node, M):
+        for m in node.findall("c:matrix", ns):
+            M = M @ np.array(m.text.split(), dtype=np.float64).reshape(4, 4)
+        for ig in node.findall("c:instance_geometry", ns):
+            v = geoms.get(ig.get("url")[1:])
+            if v is not None:
+                out.append((v @ M[:3, :3].T + M[:3, 3]) * meter)
+        for ch in node.findall("c:node", ns):
+            visit(ch, M)
+
+    for scene in root.iterfind(".//c:library_visual_scenes/c:visual_scene", ns):
+        for node in scene.findall("c:node", ns):
+            visit(node, np.eye(4))
+    if not out:  # no scene graph: the bare arrays
+        out = [v * meter for v in geoms.values()]
+    return np.concatenate(out) if out else np.zeros((0, 3))
+
+
+def _read_obj_vertices(path: str) -> np.ndarray:
+    """Vertices [n, 3] of a Wavefront OBJ file (RobotEra Xbot: four links)."""
+    with open(path, "r", errors="ignore") as f:
+        return np.asarray([[float(x) for x in line.split()[1:4]] for line in f if line.startswith("v ")], dtype=np.float64).reshape(-1, 3)
+
+
+def _read_mesh_vertices(path: str) -> np.ndarray:
+    ext = os.path.splitext(path)[1].lower()
+    return _read_dae_vertices(path) if ext == ".dae" else _read_obj_vertices(path) if ext == ".obj" else _read_stl_vertices(path)
+
+
 def _mesh_to_spheres(verts: np.ndarray, scale: np.ndarray):
     """Capsule-like sphere row fitted to a vertex cloud: principal axis a (largest variance), half
     length h, radius r = 90th percentile of the distance from the axis (clamped to [1 cm, h]).
     h <= 1.5 r -> one sphere of radius max(r, h) at the centre; else 3 spheres at 0, +-(h - r) a."""
-    if verts.ndim != 2 or len(verts) < 4:  # not an STL file (.dae / .obj collision meshes are not parsed): no spheres
+    if verts.ndim != 2 or len(verts) < 4:  # unreadable file: no spheres
         return []
     v = np.unique(np.round(verts * scale[None], 5), axis=0)
     if len(v) < 4:
@@ -160,7 +208,7 @@ def _geom_to_spheres(geom: ET.Element, T_pos: np.ndarray, T_rot: np.ndarray, mes
                 radius = half the smaller cross-section side; otherwise 8 corner spheres inset by
                 r = min(0.02, min_half_extent) (a rounded box).
     cylinder -> length <= 2.5 r: one sphere of the cylinder radius at the centre; else 3 along the axis.
-    mesh     -> :func:`_mesh_to_spheres` of the STL vertex cloud (file looked up in ``mesh_dir``).
+    mesh     -> :func:`_mesh_to_spheres` of the vertex cloud of the STL / COLLADA / OBJ file (looked up in ``mesh_dir``).
     """
     out = []
     sph = geom.find("sphere")
@@ -170,7 +218,7 @@ def _geom_to_spheres(geom: ET.Element, T_pos: np.ndarray, T_rot: np.ndarray, mes
     if mesh is not None and mesh_dir is not None:
         fn = os.path.join(mesh_dir, os.path.basename(mesh.get("filename")))
         if os.path.isfile(fn):
-            out = _mesh_to_spheres(_read_stl_vertices(fn), _vec(mesh.get("scale"), 3, 1.0))
+            out = _mesh_to_spheres(_read_mesh_vertices(fn), _vec(mesh.get("scale"), 3, 1.0))
     elif sph is not None:
         out.append((np.zeros(3), float(sph.get("radius"))))
     elif box is not None:

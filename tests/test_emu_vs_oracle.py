@@ -96,11 +96,11 @@ def test_resets_and_logs(emu_lib):
     nat.close()
 
 
-# A1, Go2W (4-joint chains: the merged instance - the trunk's spheres ride in free hip-group slots), G1 (trunk + limbs); then the
-# choices the host does not make by default: Go2W on the unmerged 4-joint instance (what M20 / Dog-W run on), B2W merged (its 8
-# trunk spheres spread over the hip groups of all four limbs)
+# A1, Go2W (4-joint chains: the merged instance - the trunk's spheres ride in free sphere slots of the limb groups), G1 (trunk +
+# limbs); then Go2W on the unmerged 4-joint instance (RL_ENV_MERGE=0: what a robot whose trunk spheres do not fit runs on) and M20
+# (merged, with the trunk's six spheres in the WHEEL groups: flagged slots on sub-lanes that do not own the trunk body's slot)
 @pytest.mark.parametrize("task,N,steps,merge", [(TASKS[1], 16, 2, None), (TASKS[3], 8, 2, None), (TASKS[5], 4, 3, None),
-                                                (TASKS[3], 8, 2, "0"), ("RobotLab-Isaac-Velocity-Flat-Unitree-B2W-v0", 8, 2, "2")])
+                                                (TASKS[3], 8, 2, "0"), ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", 8, 2, None)])
 def test_sixteen_lane_mapping_matches_oracle(task, N, steps, merge, emu_lib, monkeypatch):
     """The 16-lanes-per-env mapping (a DPP quad per limb; the default on the GPU: link groups dealt to the sub-lanes, contact
     stash, the trunk instance's limb-shared records) run by 16 host threads per env."""

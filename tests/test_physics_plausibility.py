@@ -74,6 +74,26 @@ def test_quadruped_stands_for_two_seconds(task, lo, hi):
     assert (ora.contact_force[:, feet, 2].sum(axis=1) > 0.5 * mass * 9.81).all()
 
 
+def test_b2w_stands_on_its_wheels():
+    """B2W's calves and wheels carry COLLADA collision meshes (`b2w_description.urdf` *_calf / *_foot): the compile reads their
+    vertex clouds (model/urdf.py `_read_dae_vertices`) - a B2W without them sits on its thighs.  The wheel becomes one sphere of
+    the wheel radius (0.113 m) on the wheel axis."""
+    desc, ora = _upright("RobotLab-Isaac-Velocity-Flat-Unitree-B2W-v0", N=2)
+    feet = _feet(desc)
+    m = desc.model
+    radii = [m.sphere_radius[i] for i in range(m.num_spheres) if m.sphere_body[i] in feet]
+    assert len(radii) == 4 and all(0.10 < r < 0.125 for r in radii)
+    a = np.zeros((ora.N, m.num_dof))
+    for s in range(100):
+        ora.step(a)
+    assert not (ora.terminated | ora.time_outs).any()
+    z = ora.st["root_pos"][:, 2] - ora.env_origins[:, 2]
+    assert z.min() > 0.38 and z.max() < 0.65, z
+    weight = ora.body_mass.sum(axis=1) * 9.81
+    np.testing.assert_allclose(ora.contact_force[:, :, 2].sum(axis=1), weight, rtol=0.03)
+    assert (ora.contact_force[:, feet, 2].sum(axis=1) > 0.7 * weight).all()
+
+
 def test_g1_stands_for_a_second():
     desc, ora = _upright("RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0", N=2)
     a = np.zeros((ora.N, desc.model.num_dof))

@@ -46,6 +46,43 @@ def test_one_step_from_shared_state(task, N, K, emu_lib):
     nat.close()
 
 
+@pytest.mark.parametrize("task,merge", [("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", None), ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", "0"),
+                                        ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", None), ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", None)])
+def test_one_step_with_the_trunk_on_the_ground(task, merge, emu_lib, monkeypatch):
+    """Robots lying on their backs in the 16-lanes-per-env mapping: the TRUNK's collision spheres carry the robot - the contacts
+    random-action warm-ups rarely reach.  On the merged 4-joint instance those spheres sit in flagged slots
+    of limb link groups (Go2W: hip groups, with the sub-lane that owns the trunk body's slot; M20: wheel groups, with another
+    sub-lane - separate base record, twist, friction row and force sum); RL_ENV_MERGE=0 and A1 take the group-0 path."""
+    monkeypatch.setenv("RL_EMU_SUB", "4")
+    if merge is not None:
+        monkeypatch.setenv("RL_ENV_MERGE", merge)
+    N = 8
+    desc, ora, nat = make_pair(task, N, 5, emu_lib)
+    nat.reset()
+    rng = np.random.default_rng(3)
+    for _ in range(2):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        nat.step(a.ctypes.data)
+    state = emu_read_state(nat)
+    rs = state["root_state"].copy()
+    ground = ora.phys.terrain.sample(rs[:, 0].astype(np.float64), rs[:, 1].astype(np.float64))[0]
+    rs[:6, 2] = (ground + np.linspace(0.015, 0.04, N))[:6]  # ON ITS BACK (legs in the air, or they would carry it), the trunk's spheres
+    rs[:6, 3:7] = [0.0, 1.0, 0.0, 0.0]                       # (r = 0.047 m on Go2W) pressed 1 - 3 cm into the ground
+    rs[:6, 7:13] *= 0.1
+    state["root_state"] = rs
+    emu_load_state(nat, state)
+    state = emu_read_state(nat)
+    a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+    nat.step(a.ctypes.data)
+    # the trunk body (body 0) carries load in most of the lowered envs - or the env was terminated for it (illegal_contact on the
+    # base, where the cfg has that term) and reset, which clears the sensor
+    trunk = np.linalg.norm(host_view(nat, "CONTACT_FORCE")[:, 0], axis=1) > 1.0
+    done = host_view(nat, "TERMINATED").astype(bool)
+    assert (trunk | done)[:6].sum() >= 4 and not (trunk | done)[6:].any(), (trunk, done)
+    teacher_forced_check(ora, state, a, _outputs(nat, N), max_mask=0.5)
+    nat.close()
+
+
 def test_state_round_trip_is_exact(emu_lib):
     """export -> commit into a second env -> both step bit-identically (every carried field is in the exchange)."""
     task, N = CASES[0][0], 16
