@@ -55,7 +55,14 @@ inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& N
                 std::to_string(m.chain_len) + ", trunk " + std::to_string(m.num_trunk) + ")");
   bool equal = true;
   for (int k = 1; k < NLANE; ++k) equal = equal && m.chain_nj[k] == m.chain_nj[0];
-  if (m.num_trunk == 0 && m.chain_len <= 4 && equal && m.chain_len >= 3) { CL = m.chain_len; NW = 0; SPL = 3; NBS = 6; }
+  // joint frames rotated against the parent link (URDF joint rpy; DDT Tita): only the trunk + limbs instance carries the rotations
+  bool rotated = false;
+  for (int l = 1; l < m.num_links; ++l) {
+    const float* q = m.link_quat[l];
+    const float n = fabsf(q[0]) + fabsf(q[1]) + fabsf(q[2]) + fabsf(q[3]);
+    rotated = rotated || (n > 0.f && (fabsf(q[1]) > 1e-6f || fabsf(q[2]) > 1e-6f || fabsf(q[3]) > 1e-6f));  // all-zero: descriptor without rotations
+  }
+  if (m.num_trunk == 0 && m.chain_len <= 4 && equal && m.chain_len >= 3 && !rotated) { CL = m.chain_len; NW = 0; SPL = 3; NBS = 6; }
   else { CL = 7; NW = 3; SPL = 4; NBS = 9; }
   // a shorter trunk (ATOM01: one waist joint) or none runs on the NW = 3 instance with inert padding trunk joints
   return 0;
