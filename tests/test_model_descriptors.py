@@ -143,3 +143,34 @@ def test_entry_point_resolves_to_the_hip_env():
     from robot_lab_amd.env import ManagerBasedRLEnv
 
     assert isaaclab.envs.ManagerBasedRLEnv is ManagerBasedRLEnv
+
+
+def test_mesh_vertex_readers(tmp_path):
+    """COLLADA / OBJ collision meshes (B2W calves and wheels, four Xbot links): vertex clouds as the sphere fit consumes them.  A
+    COLLADA geometry is carried through the matrices of the scene nodes that instance it (Blender: millimetres + a 0.001 scale
+    and a rotation in the node) and the asset unit; the wheel-like cloud below becomes ONE sphere of the wheel radius."""
+    from robot_lab_amd.model.urdf import _mesh_to_spheres, _read_mesh_vertices
+
+    ang = np.linspace(0, 2 * np.pi, 48, endpoint=False)
+    rim = np.concatenate([np.stack([100 * np.cos(ang), 100 * np.sin(ang), np.full_like(ang, z)], 1) for z in (-20.0, 20.0)])  # mm, axis z
+    dae = tmp_path / "wheel.dae"
+    dae.write_text(f"""<?xml version="1.0"?>
+<COLLADA xmlns="http://www.collada.org/2005/11/COLLADASchema" version="1.4.1">
+ <asset><unit name="meter" meter="1"/><up_axis>Z_UP</up_axis></asset>
+ <library_geometries><geometry id="g"><mesh>
+  <source id="g-pos"><float_array id="g-pos-array" count="{rim.size}">{' '.join(f'{v:.6f}' for v in rim.ravel())}</float_array></source>
+  <source id="g-nrm"><float_array id="g-nrm-array" count="3">0 0 1</float_array></source>
+  <vertices id="g-vtx"><input semantic="POSITION" source="#g-pos"/></vertices>
+ </mesh></geometry></library_geometries>
+ <library_visual_scenes><visual_scene id="s"><node id="n"><matrix sid="transform">0.001 0 0 0  0 0 -0.001 0.05  0 0.001 0 0  0 0 0 1</matrix>
+  <instance_geometry url="#g"/></node></visual_scene></library_visual_scenes>
+</COLLADA>""")
+    v = _read_mesh_vertices(str(dae))
+    assert v.shape == (96, 3)
+    np.testing.assert_allclose(v.min(0), [-0.1, 0.03, -0.1], atol=2e-3)   # rotated about x (wheel axis now y), shifted 0.05 in y, metres
+    np.testing.assert_allclose(v.max(0), [0.1, 0.07, 0.1], atol=2e-3)
+    sph = _mesh_to_spheres(v, np.ones(3))
+    assert len(sph) == 1 and abs(sph[0][1] - 0.1) < 5e-3 and np.allclose(sph[0][0], [0, 0.05, 0], atol=2e-3)
+    obj = tmp_path / "box.obj"
+    obj.write_text("# box\n" + "".join(f"v {x} {y} {z}\n" for x in (0, 1) for y in (0, 2) for z in (0, 3)) + "vn 0 0 1\nf 1 2 3\n")
+    assert _read_mesh_vertices(str(obj)).shape == (8, 3) and _read_mesh_vertices(str(obj)).max() == 3.0
