@@ -383,7 +383,7 @@ struct EnvLane {
     __builtin_amdgcn_s_waitcnt(0);
     const long long t = (long long)__builtin_readcyclecounter();
     if (ctx.lane == 0) {
-      float* row = S.rew_terms + (size_t)RL_PHASE_ROW0 * (size_t)S.Npad + (size_t)blockIdx.x * RL_PHASE_SLOTS;
+      float* row = S.rew_terms + (size_t)RL_PHASE_ROW0 * (size_t)S.Npad + (size_t)ctx.tile() * RL_PHASE_SLOTS;
       row[ph_cur] += (float)(t - ph_t0);
     }
     ph_cur = id;

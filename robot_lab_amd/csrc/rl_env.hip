@@ -63,8 +63,9 @@ struct WaveCtx {
   __device__ int env_in_tile() const { return lane / LPE; }
   __device__ int k() const { return SUB == 1 ? (lane & 3) : ((lane >> 2) & 3); }
   __device__ int sub() const { return SUB == 1 ? 0 : (lane & 3); }
-  __device__ int tile() const { return blockIdx.x; }
-  __device__ int env() const { return blockIdx.x * EPT + env_in_tile(); }
+  int wtile;  // this wavefront's tile (= blockIdx.x with one wavefront per workgroup)
+  __device__ int tile() const { return wtile; }
+  __device__ int env() const { return wtile * EPT + env_in_tile(); }
   // sum over the 4 legs (inputs replicated over a leg's sub-lanes when SUB == 4: the mirrors then pair
   // lanes of different legs, and a + b == b + a bitwise, so all 16 lanes end with identical bits)
   __device__ float gsum(float v) const {
@@ -125,10 +126,10 @@ struct WaveCtx {
     const int n4 = (EPT * d) >> 2;  // the tile's rows are contiguous in `out`; 16-byte aligned when EPT * d % 4 == 0
     if (((EPT * d) & 3) == 0) {
       const float4* src = reinterpret_cast<const float4*>(stage[g]);
-      float4* dst = reinterpret_cast<float4*>(out + (size_t)blockIdx.x * EPT * d);
+      float4* dst = reinterpret_cast<float4*>(out + (size_t)wtile * EPT * d);
       for (int i = lane; i < n4; i += 64) dst[i] = src[i];
     } else {
-      float* dst = out + (size_t)blockIdx.x * EPT * d;
+      float* dst = out + (size_t)wtile * EPT * d;
       for (int i = lane; i < EPT * d; i += 64) dst[i] = stage[g][i];
     }
     wave_sync();
@@ -137,33 +138,41 @@ struct WaveCtx {
 
 extern __shared__ float4 smem4[];
 
-template <class TP, int RESET, int SUB>
-__global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restrict__ Tgv) {
+// WGW wavefronts per workgroup share ONE staged table image in LDS; apart from that staging (and its one s_barrier) the wavefronts
+// of a workgroup have nothing to do with each other: each has its own scratch region behind the tables (`wave_words` LDS words) and
+// orders its LDS traffic with wave_sync().  4 when the launch has at least 4 wavefronts for every CU (a CU then holds ONE workgroup
+// = one wavefront per SIMD, as with single-wavefront workgroups, but stages the tables once instead of four times and the dispatcher
+// places a quarter of the workgroups): A1 Rough 4096 52.1 -> 50.2 us.  Smaller launches keep single-wavefront workgroups, which
+// spread over more CUs (1024 envs: 49.5 us on 256 CUs, 55.9 us packed four to a CU - profiles/r02_wg_waves.txt).
+template <class TP, int RESET, int SUB, int WGW>
+__global__ __launch_bounds__(64 * WGW) void env_kernel(KState S, const void* __restrict__ Tgv, uint32_t wave_words) {
   using Ctx = WaveCtx<SUB>;
   using Tables = TablesT<TP>;
   const Tables* __restrict__ Tg = static_cast<const Tables*>(Tgv);
   float* smem = reinterpret_cast<float*>(smem4);
   Tables* Tl = reinterpret_cast<Tables*>(smem);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   S.step_counter += *S.step_base;  // scalar load: the launch carries the offset from the device-side anchor (rl_env_graph_*)
   {  // stage the used part of the table image into LDS (16-byte vectors): all loads in flight before the first LDS write
     const float4* src = reinterpret_cast<const float4*>(Tg);
     float4* dst = reinterpret_cast<float4*>(Tl);
-    constexpr int NIT = ((int)(sizeof(Tables) / 16) + 63) / 64;
+    constexpr int TPB = 64 * WGW;
+    constexpr int NIT = ((int)(sizeof(Tables) / 16) + TPB - 1) / TPB;
     const int n4 = (int)(S.table_bytes >> 4);
     float4 tmp[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = lane + 64 * it;
+      const int i = (int)threadIdx.x + TPB * it;
       tmp[it] = src[i < n4 ? i : n4 - 1];  // unconditional (clamped) loads keep tmp[] in registers
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = lane + 64 * it;
+      const int i = (int)threadIdx.x + TPB * it;
       if (i < n4) dst[i] = tmp[it];
     }
   }
-  Ctx::wave_sync();
+  if (WGW > 1) __syncthreads();
+  else Ctx::wave_sync();
   // LDS after the tables (only the staged bytes take room: the unused tail of the reward table is never touched):
   //   lane scratchpad | limb-shared words | observation staging rows | reward stage
   // On the instances with a contact stash (quadrupeds, 16 lanes per env) the staging rows and the reward stage live ON the
@@ -182,7 +191,9 @@ __global__ __launch_bounds__(64) void env_kernel(KState S, const void* __restric
     const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
     if (s0w + s1w < need) s1w = need - s0w;
   }
-  ctx.lscratch = smem + TAB_F;
+  ctx.lscratch = smem + TAB_F + (WGW > 1 ? wv * wave_words : 0u);  // wave_words: LDS words of one wavefront behind the shared tables
+  ctx.wtile = (int)blockIdx.x * WGW + wv;
+  if (WGW > 1 && ctx.wtile >= S.Npad / Ctx::EPT) return;
   ctx.lbscratch = ctx.lscratch + LS::WORDS * 64;
   ctx.envs = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + (lane / Ctx::LPE) * LbLayout<TP>::ENV_WORDS;
   float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + Ctx::EPT * LbLayout<TP>::ENV_WORDS;
@@ -236,10 +247,13 @@ struct Backend {
     }
     return 0;
   }
-  int device = 0;
+  int device = 0, n_cu = 256;
   int init(int dev) {
     device = dev;
-    return check(hipSetDevice(dev));
+    if (check(hipSetDevice(dev))) return -1;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    if (const char* v = std::getenv("RL_ENV_WG")) wg_waves = atoi(v) == 1 ? 1 : 4;
+    return 0;
   }
   // every entry point runs on the env's device, whatever the calling thread's current device is
   int activate() { return check(hipSetDevice(device)); }
@@ -260,9 +274,12 @@ struct Backend {
     if (const char* v = std::getenv("RL_ENV_SUB")) sub = atoi(v) == 1 ? 1 : 4;
     return 16 / sub;
   }
-  template <class TP, int SUB>
-  int launch_cl(const KState& S, const void* T, int reset, size_t lds, hipStream_t st) {
-    dim3 grid(S.Npad / (16 / SUB)), block(64);
+  template <class TP, int SUB, int WGW>
+  int launch_w(const KState& S, const void* T, int reset, size_t lds1, hipStream_t st) {  // lds1: LDS bytes with one wavefront per workgroup
+    const int tiles = S.Npad / (16 / SUB);
+    dim3 grid((tiles + WGW - 1) / WGW), block(64 * WGW);
+    const uint32_t wave_words = (uint32_t)((lds1 - S.table_bytes) >> 2);
+    const size_t lds = S.table_bytes + (size_t)WGW * (lds1 - S.table_bytes);
     if (lds > 64 * 1024) {
       // opt in to the large LDS carve-out (160 KB per CU on gfx950).  The attribute belongs to the (kernel, device) pair and
       // must cover the LARGEST request: remember per device what was configured and raise it when an env needs more.
@@ -271,16 +288,26 @@ struct Backend {
       std::lock_guard<std::mutex> lock(mu);
       size_t& have = configured[device & 63];
       if (lds > have) {
-        if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 1, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
-        if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 0, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
+        if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 1, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
+        if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 0, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
         have = lds;
       }
     }
     if (reset)
-      hipLaunchKernelGGL((env_kernel<TP, 1, SUB>), grid, block, lds, st, S, T);
+      hipLaunchKernelGGL((env_kernel<TP, 1, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
     else
-      hipLaunchKernelGGL((env_kernel<TP, 0, SUB>), grid, block, lds, st, S, T);
+      hipLaunchKernelGGL((env_kernel<TP, 0, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
     return check(hipGetLastError());
+  }
+  int wg_waves = 4;  // RL_ENV_WG=1: single-wavefront workgroups always
+  template <class TP, int SUB>
+  int launch_cl(const KState& S, const void* T, int reset, size_t lds1, hipStream_t st) {
+    if constexpr (TP::NW == 0 && SUB == 4) {  // (the trunk + limbs instance gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup)
+      const int tiles = S.Npad / (16 / SUB);
+      const size_t lds4 = S.table_bytes + 4 * (lds1 - S.table_bytes);
+      if (wg_waves == 4 && tiles >= 4 * n_cu && lds4 <= 160 * 1024) return launch_w<TP, SUB, 4>(S, T, reset, lds1, st);
+    }
+    return launch_w<TP, SUB, 1>(S, T, reset, lds1, st);
   }
   size_t lds_bytes = 0;
   // dynamic LDS of an instance: the SAME layout arithmetic as env_kernel (tables | lane scratchpad | limb-shared words | per-env
