@@ -144,8 +144,15 @@ extern __shared__ float4 smem4[];
 // = one wavefront per SIMD, as with single-wavefront workgroups, but stages the tables once instead of four times and the dispatcher
 // places a quarter of the workgroups): A1 Rough 4096 52.1 -> 50.2 us.  Smaller launches keep single-wavefront workgroups, which
 // spread over more CUs (1024 envs: 49.5 us on 256 CUs, 55.9 us packed four to a CU - profiles/r02_wg_waves.txt).
+// __launch_bounds__(256) also for the single-wavefront variant: declared as a 64-thread workgroup, the build without the SLP vectorizer
+// (-fno-slp-vectorize, __graft_entry__.py) computes wrong rewards on the 3-joint instance (GPU parity suites: 16 failures; 128 or
+// 256 declared threads: all green, same speed - gpurun_out r02dbg).  Not understood: every LDS exchange of the
+// lane program is wave-local and fenced (wave_sync), and the same source passes declared either way with the vectorizer on.
+#ifndef RL_LB
+#define RL_LB(w) 256
+#endif
 template <class TP, int RESET, int SUB, int WGW>
-__global__ __launch_bounds__(64 * WGW) void env_kernel(KState S, const void* __restrict__ Tgv, uint32_t wave_words) {
+__global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* __restrict__ Tgv, uint32_t wave_words) {
   using Ctx = WaveCtx<SUB>;
   using Tables = TablesT<TP>;
   const Tables* __restrict__ Tg = static_cast<const Tables*>(Tgv);
@@ -252,7 +259,7 @@ struct Backend {
     device = dev;
     if (check(hipSetDevice(dev))) return -1;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    if (const char* v = std::getenv("RL_ENV_WG")) wg_waves = atoi(v) == 1 ? 1 : 4;
+    if (const char* v = std::getenv("RL_ENV_WG")) { wg_waves = atoi(v) == 1 ? 1 : 4; wg_force = atoi(v) < 0; }  // -4: four-wavefront workgroups whatever the launch size (tests)
     return 0;
   }
   // every entry point runs on the env's device, whatever the calling thread's current device is
@@ -300,12 +307,13 @@ struct Backend {
     return check(hipGetLastError());
   }
   int wg_waves = 4;  // RL_ENV_WG=1: single-wavefront workgroups always
+  bool wg_force = false;
   template <class TP, int SUB>
   int launch_cl(const KState& S, const void* T, int reset, size_t lds1, hipStream_t st) {
     if constexpr (TP::NW == 0 && SUB == 4) {  // (the trunk + limbs instance gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup)
       const int tiles = S.Npad / (16 / SUB);
       const size_t lds4 = S.table_bytes + 4 * (lds1 - S.table_bytes);
-      if (wg_waves == 4 && tiles >= 4 * n_cu && lds4 <= 160 * 1024) return launch_w<TP, SUB, 4>(S, T, reset, lds1, st);
+      if (wg_waves == 4 && (tiles >= 4 * n_cu || wg_force) && lds4 <= 160 * 1024) return launch_w<TP, SUB, 4>(S, T, reset, lds1, st);
     }
     return launch_w<TP, SUB, 1>(S, T, reset, lds1, st);
   }

@@ -87,7 +87,9 @@ def test_short_horizon_parity(task):
     got = env.read_state()
     got.update(reward=rew.cpu().numpy(), reward_terms=env.reward_terms().cpu().numpy(), done=(term | tout).cpu().numpy(),
                obs_policy=obs["policy"].cpu().numpy(), obs_critic=obs["critic"].cpu().numpy())
-    teacher_forced_check(ora, state, a, got, max_mask=0.35)  # small batch: a few envs on a switch are already > 1.5 %
+    # (small batch: a few envs on a switch are already > 1.5 %; six twins: the envelope is the MAXIMUM response over the twins, and three
+    # draws leave it 1.4x short for one env in a few hundred)
+    teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=0.35)
     env.close()
 
 

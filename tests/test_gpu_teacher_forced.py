@@ -67,7 +67,9 @@ def test_one_step_from_shared_state_full_size(task, N):
     desc, extra = load_bundle(task)
     h, to, eo = build_world(desc, extra, N, 0)
     ora = OracleEnv(desc, h, to, N, seed, eo)
-    rep = teacher_forced_check(ora, state, a.cpu().numpy(), _outputs(env, *out1[:4]), n_twins=2, max_mask=0.005)
+    # mask bound: 0.5 % of the batch + 2 envs (the count is a draw: 10 +- 3 of 2048, 13 - 20 of 4096 over the round's builds, whose
+    # different round-off in the 30 warm-up steps moves a handful of envs onto or off a switch)
+    rep = teacher_forced_check(ora, state, a.cpu().numpy(), _outputs(env, *out1[:4]), n_twins=3, max_mask=0.005 + 2.0 / N)
     assert rep["done_count"] > 0
     rep["task"], rep["warmup_steps"] = task, K
     print("\n[teacher-forced]", json.dumps(rep))

@@ -4,7 +4,7 @@
 Needs a `-DRL_PHASE_CLOCK` build of the HIP library (csrc/env_step.h RL_PHASE): lane 0 of every wavefront accumulates the
 ticks it spends in each phase into float row [wavefront][phase id] behind the reward-term rows.
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DRL_PHASE_CLOCK [-DRL_ENV_ONLY=34] -o robot_lab_amd/csrc/variants/clock.so robot_lab_amd/csrc/rl_env.hip
+    hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -shared -fPIC -DRL_PHASE_CLOCK [-DRL_ENV_ONLY=34] -o robot_lab_amd/csrc/variants/clock.so robot_lab_amd/csrc/rl_env.hip
     RL_ENV_LIB=robot_lab_amd/csrc/variants/clock.so python tools/phase_clock.py [task] [num_envs]
 """
 import os
