@@ -144,10 +144,13 @@ extern __shared__ float4 smem4[];
 // = one wavefront per SIMD, as with single-wavefront workgroups, but stages the tables once instead of four times and the dispatcher
 // places a quarter of the workgroups): A1 Rough 4096 52.1 -> 50.2 us.  Smaller launches keep single-wavefront workgroups, which
 // spread over more CUs (1024 envs: 49.5 us on 256 CUs, 55.9 us packed four to a CU - profiles/r02_wg_waves.txt).
-// __launch_bounds__(256) also for the single-wavefront variant: declared as a 64-thread workgroup, the build without the SLP vectorizer
-// (-fno-slp-vectorize, __graft_entry__.py) computes wrong rewards on the 3-joint instance (GPU parity suites: 16 failures; 128 or
-// 256 declared threads: all green, same speed - gpurun_out r02dbg).  Not understood: every LDS exchange of the
-// lane program is wave-local and fenced (wave_sync), and the same source passes declared either way with the vectorizer on.
+// __launch_bounds__(256) also for the single-wavefront variant.  Declared as a 64-thread workgroup, the build without the SLP
+// vectorizer (-fno-slp-vectorize, __graft_entry__.py) is MISCOMPILED on the 3-joint instance: the register allocator parks the env's
+// push timer in an AGPR, lends its VGPR to a block that runs under a narrowed EXEC mask (the lanes that publish a body row of the
+// reward tables), and reloads it behind a further `s_and_b64 exec, exec, vcc` early-out - under the narrower mask, so the lanes that
+// left early keep the temporary and the push event fires in every env (profiles/r02_launch_bounds64_miscompile.txt: ISA excerpt and
+// state dump; 16 GPU parity failures).  Declared as 128 or 256 threads the same source keeps the timer in the AGPR until it is used.
+// The guard against this class of defect is the GPU parity tier (full-size teacher-forced steps, both workgroup shapes).
 #ifndef RL_LB
 #define RL_LB(w) 256
 #endif
