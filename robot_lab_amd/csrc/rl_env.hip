@@ -1,13 +1,12 @@
 // rl_env.hip - gfx950 (MI355X, CDNA4) build of the env-step lane program + the C-ABI of include/rl_env.h.
 //
-// Launch geometry: one 64-lane wavefront per workgroup = 4 environments x 16 lanes (a DPP row per env, a DPP
-// quad per limb); Npad/4 workgroups (4096 envs -> 1024 workgroups -> one wavefront on every SIMD of the 256
-// CUs, dealt round-robin over the 8 XCDs by the dispatcher; RL_ENV_SUB=1 selects the older 16 envs x 4 lanes
-// mapping).  The path has no dense contraction -> no MFMA; it is latency bound at this size,
-// so a wavefront gets a SIMD's whole register file and every cross-lane reduction is a DPP move (quad_perm
-// inside a limb, row mirrors across limbs - no LDS round trip).  The packed model / term tables are staged
-// once per workgroup into LDS; observation rows are staged in LDS and written back as one linear,
-// 16-byte-vectorised burst per wavefront.  DESIGN.md section 3 has the LDS budget (4 workgroups x <= 40 KB per CU).
+// Launch geometry: a 64-lane wavefront = 4 environments x 16 lanes (a DPP row per env, a DPP quad per limb); Npad/4 wavefronts
+// (4096 envs -> 1024 wavefronts -> one on every SIMD of the 256 CUs; RL_ENV_SUB=1 selects the older 16 envs x 4 lanes mapping),
+// launched four to a workgroup when the launch fills the chip (one staged table image per CU), else one to a workgroup (env_kernel
+// below).  The wavefronts of a workgroup share only the staged tables.  The path has no dense contraction -> no MFMA; it is latency
+// bound at this size, so a wavefront gets a SIMD's whole register file and every cross-lane reduction is a DPP
+// move (quad_perm inside a limb, row mirrors across limbs - no LDS round trip).  Observation rows are staged in LDS and written
+// back as one linear, 16-byte-vectorised burst per wavefront.  DESIGN.md section 3 has the LDS budget.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -107,7 +106,8 @@ struct WaveCtx {
   __device__ float* rew_stage() const { return rstage + env_in_tile() * MAX_T; }
   __device__ float* feat_stage() const { return fstage + env_in_tile() * fdim; }
   __device__ float* rew_tab() const { return stage[0] + env_in_tile() * rtdim; }
-  // Ordering point for LDS traffic between the lanes of the workgroup.  The workgroup IS one wavefront, and a wavefront's LDS
+  // Ordering point for LDS traffic between the lanes of the WAVEFRONT (its LDS region is its own, whatever the workgroup width - only
+  // the table image is shared, and that is read-only after the staging barrier).  A wavefront's LDS
   // instructions execute in issue order, so a later ds_read of any lane sees an earlier ds_write of any lane without a hardware
   // barrier: all that is needed is that the COMPILER keeps the accesses on their side of this point.  __syncthreads() would add
   // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier - draining every global load in flight (the terrain and height-scan gathers that
