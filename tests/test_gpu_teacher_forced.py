@@ -53,6 +53,17 @@ def test_one_step_from_shared_state_full_size(task, N):
         env.step(torch.rand(N, env.num_actions, device="cuda", generator=g) * 2 - 1)
     state = env.read_state()
     assert state["step_count"] == K
+    # the interval events are due in some envs on the compared step: the push (10 - 15 s apart, velocity_env_cfg.py:366-371) and the
+    # command resampling (every 10 s, :106-117) - their timers are part of the exchanged state (include/rl_env.h rl_task_state_field)
+    # (quadruped configs; the trunk + limbs instance has the same edit in its CPU-tier twin, tests/test_teacher_forced.py)
+    events = "G1" not in task
+    if events:
+        ts = state["task_state"].copy()
+        ts[2::7, 7] = 0.015   # RL_TS_PUSH_TIME_LEFT
+        ts[4::9, 4] = 0.015   # RL_TS_CMD_TIME_LEFT
+        state["task_state"] = ts
+        env.load_state(state)
+        state = env.read_state()
     a = torch.rand(N, env.num_actions, device="cuda", generator=g) * 2 - 1
     out1 = env.step(a)
     # --- the C-ABI state exchange carries everything: a second env continues bit-identically from the committed state
@@ -71,6 +82,8 @@ def test_one_step_from_shared_state_full_size(task, N):
     # different round-off in the 30 warm-up steps moves a handful of envs onto or off a switch)
     rep = teacher_forced_check(ora, state, a.cpu().numpy(), _outputs(env, *out1[:4]), n_twins=3, max_mask=0.005 + 2.0 / N)
     assert rep["done_count"] > 0
+    after = env.read_state()["task_state"]
+    assert not events or ((after[2::7, 7] > 5.0).all() and (after[4::9, 4] > 5.0).all())  # both events fired where they were due
     rep["task"], rep["warmup_steps"] = task, K
     print("\n[teacher-forced]", json.dumps(rep))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

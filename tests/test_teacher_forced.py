@@ -8,6 +8,8 @@ import pytest
 
 from helpers import emu_load_state, emu_read_state, host_view, make_pair, teacher_forced_check
 
+RL_TS_CMD_TIME_LEFT, RL_TS_PUSH_TIME_LEFT = 4, 7  # include/rl_env.h rl_task_state_field
+
 CASES = [
     ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 48, 8),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", 32, 6),
@@ -38,10 +40,21 @@ def test_one_step_from_shared_state(task, N, K, emu_lib):
         nat.step(a.ctypes.data)
     state = emu_read_state(nat)
     assert state["step_count"] == K
+    # the interval events of the compared step: the push (every 10 - 15 s, velocity_env_cfg.py:366-371) and the command resampling
+    # (every 10 s, :106-117) are due in a few envs - their timers are part of the exchanged state
+    ts = state["task_state"].copy()
+    ts[2::7, RL_TS_PUSH_TIME_LEFT] = 0.015
+    ts[4::9, RL_TS_CMD_TIME_LEFT] = 0.015
+    state["task_state"] = ts
+    emu_load_state(nat, state)
+    state = emu_read_state(nat)
     a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
     nat.step(a.ctypes.data)
+    got = _outputs(nat, N)
+    assert (got["task_state"][2::7, RL_TS_PUSH_TIME_LEFT] > 5.0).all()  # fired: redrawn U(10, 15) (the velocity kick is in the comparison below)
+    assert (got["task_state"][4::9, RL_TS_CMD_TIME_LEFT] > 5.0).all()   # resampled: 10 s
     # small batches: one env on a switch is already 2 - 12 % of the batch, so the mask-size bound is checked at full size only
-    rep = teacher_forced_check(ora, state, a, _outputs(nat, N), max_mask=0.25)
+    rep = teacher_forced_check(ora, state, a, got, max_mask=0.25)
     assert rep["done_count"] > 0  # the compared step itself resets somebody
     nat.close()
 
