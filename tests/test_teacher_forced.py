@@ -46,6 +46,18 @@ def test_one_step_from_shared_state(task, N, K, emu_lib):
     ts[2::7, RL_TS_PUSH_TIME_LEFT] = 0.015
     ts[4::9, RL_TS_CMD_TIME_LEFT] = 0.015
     state["task_state"] = ts
+    # ... and two envs are moved: one 4.5 m away from its origin on the step its episode times out (terrain_levels_vel: one level up,
+    # velocity_env_cfg.py:671), one across the border of the terrain (terrain_out_of_bounds, :656-664: a time-out-type termination)
+    td, tk = desc.terrain, desc.task
+    rs = state["root_state"].copy()
+    up, oob = 1, 6
+    rs[up, 0] += 4.5
+    rs[oob, 0] = 0.5 * (td.num_rows * td.tile_size + 2 * td.border) - tk.oob_buffer + 0.5
+    for i in (up, oob):
+        rs[i, 2] = ora.phys.terrain.sample(rs[i, 0:1].astype(np.float64), rs[i, 1:2].astype(np.float64))[0][0] + 0.45
+        rs[i, 3:7] = [1.0, 0.0, 0.0, 0.0]
+    state["root_state"] = rs
+    level_before = state["terrain_level"].copy()
     emu_load_state(nat, state)
     state = emu_read_state(nat)
     a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
@@ -53,6 +65,12 @@ def test_one_step_from_shared_state(task, N, K, emu_lib):
     got = _outputs(nat, N)
     assert (got["task_state"][2::7, RL_TS_PUSH_TIME_LEFT] > 5.0).all()  # fired: redrawn U(10, 15) (the velocity kick is in the comparison below)
     assert (got["task_state"][4::9, RL_TS_CMD_TIME_LEFT] > 5.0).all()   # resampled: 10 s
+    if not td.is_plane:
+        assert got["done"][oob] and got["done"][up]
+        if tk.term_out_of_bounds:
+            assert host_view(nat, "TIME_OUT")[oob] and not host_view(nat, "TERMINATED")[oob]
+        if td.curriculum and level_before[up] < td.num_rows - 1:
+            assert got["terrain_level"][up] == level_before[up] + 1
     # small batches: one env on a switch is already 2 - 12 % of the batch, so the mask-size bound is checked at full size only
     rep = teacher_forced_check(ora, state, a, got, max_mask=0.25)
     assert rep["done_count"] > 0  # the compared step itself resets somebody
