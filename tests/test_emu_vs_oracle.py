@@ -122,3 +122,37 @@ def test_sixteen_lane_mapping_matches_oracle(task, N, steps, merge, emu_lib, mon
     assert_close("timers", host_view(nat, "CONTACT_TIMERS"), ora.timers, 1e-5, 1e-6)
     assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
     nat.close()
+
+
+def _switch_kinds(desc):
+    """The reward kinds no shipped cfg gives a weight: `feet_height` (world frame, rewards.py:507-524) in place of A1's
+    `feet_height_body`, `feet_contact` (rewards.py:399-413, expects 2 feet down) in place of `feet_contact_without_cmd`, and
+    `joint_vel_l2` in place of `joint_acc_l2` - same body / joint masks, the kind and its parameters swapped."""
+    from robot_lab_amd.desc import REW as REW_KINDS
+
+    t, names = desc.task, list(desc.reward_names)
+    r = t.rewards[names.index("feet_height_body")]
+    r.kind, r.p[0], r.p[1] = REW_KINDS["feet_height"], 0.05, 2.0
+    r = t.rewards[names.index("feet_contact_without_cmd")]
+    r.kind, r.p[0], r.weight = REW_KINDS["feet_contact"], 2.0, -0.1
+    r = t.rewards[names.index("joint_acc_l2")]
+    r.kind, r.weight = REW_KINDS["joint_vel_l2"], -1e-3
+    return desc
+
+
+def test_reward_kinds_without_a_cfg(emu_lib):
+    desc, ora, nat = make_pair(TASKS[1], 16, 8, emu_lib, mutate=_switch_kinds)
+    ora.reset()
+    nat.reset()
+    rng = np.random.default_rng(2)
+    names = list(desc.reward_names)
+    seen = np.zeros(3)
+    for s in range(6):
+        a = rng.uniform(-1, 1, (16, desc.model.num_dof)).astype(np.float32)
+        ora.step(a)
+        nat.step(a.ctypes.data)
+        got, want = host_view(nat, "REWARD_TERMS")[:, :16], ora.reward_terms
+        assert_close(f"terms[{s}]", got, want, 2e-3, 2e-5)
+        seen += [np.abs(want[names.index(n)]).max() for n in ("feet_height_body", "feet_contact_without_cmd", "joint_acc_l2")]
+    assert (seen > 0).all(), seen  # the three swapped terms really produced something
+    nat.close()

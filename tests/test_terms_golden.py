@@ -101,3 +101,36 @@ def test_observation_rows_match_reference_cfg(robot):
         wheels = [i for i in range(desc.model.num_dof) if (desc.task.wheel_joint_mask >> i) & 1]
         assert wheels and np.all(pol[:, [off + i for i in wheels]] == 0)
         assert np.abs(pol[:, off:off + desc.model.num_dof]).max() > 0
+
+
+def test_reward_functions_without_a_cfg_match_reference():
+    """`feet_contact` (rewards.py:399-413) and `feet_height` (rewards.py:507-524): no shipped robot cfg gives them a weight, so the
+    per-robot fixtures never see them.  tests/golden/terms_extra.npz = the reference's functions on the recorded Go2 state
+    (tools/gen_golden_extra_terms.py); here the same two kinds take the place of Go2's `feet_contact_without_cmd` /
+    `feet_height_body` terms (same feet) in the descriptor and the oracle must reproduce them."""
+    from robot_lab_amd.desc import REW
+
+    x = np.load(os.path.join(GOLD, "terms_extra.npz"))
+    g = np.load(os.path.join(GOLD, str(x["source"])))
+    desc, extra = load_bundle(str(g["task"]))
+    t, names = desc.task, list(desc.reward_names)
+    swap = {"feet_contact": ("feet_contact_without_cmd", (float(x["expect_contact_num"]),)),
+            "feet_height": ("feet_height_body", (float(x["target_height"]), float(x["tanh_mult"])))}
+    for kind, (host, params) in swap.items():
+        r = t.rewards[names.index(host)]
+        r.kind = REW[kind]
+        for i, p in enumerate(params):
+            r.p[i] = p
+    N = int(g["N"])
+    h, to, eo = build_world(desc, extra, N, 0)
+    ora = OracleEnv(desc, h, to, N, int(g["seed"]), eo)
+    for k in ("root_pos", "root_quat", "root_lin_vel", "root_ang_vel", "q", "qd", "base_com", "root_com"):
+        ora.st[k] = g["st_" + k].copy()
+    for k in ("applied_torque", "joint_acc", "force_hist", "contact_force", "timers", "action", "prev_action", "vel_command_b", "terminated"):
+        setattr(ora, k, g[k].copy())
+    ora.compute_rewards(ora.derived(), np.linalg.norm(ora.force_hist, axis=-1).max(axis=1))
+    for j, kind in enumerate(str(n) for n in x["names"]):
+        i = names.index(swap[kind][0])
+        got = ora.reward_terms[i] / (float(t.rewards[i].weight) * ora.step_dt)
+        np.testing.assert_allclose(got, x["values"][j], rtol=2e-6, atol=1e-7, err_msg=kind)
+        assert np.abs(x["values"][j]).max() > 0
