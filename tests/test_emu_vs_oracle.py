@@ -156,3 +156,35 @@ def test_reward_kinds_without_a_cfg(emu_lib):
         seen += [np.abs(want[names.index(n)]).max() for n in ("feet_height_body", "feet_contact_without_cmd", "joint_acc_l2")]
     assert (seen > 0).all(), seen  # the three swapped terms really produced something
     nat.close()
+
+
+@pytest.mark.parametrize("task", [TASKS[1], TASKS[3]])
+def test_partial_reset_by_env_ids(task, emu_lib):
+    """rl_env_reset(env, ids, n): only the named envs are reset (all their draws as in the oracle), the others keep their state bit
+    for bit; an id out of range is an error.  (The GPU twin: tests/test_gpu_edge_cases.py.)"""
+    N = 16
+    desc, ora, nat = make_pair(task, N, 9, emu_lib)
+    ora.reset()
+    nat.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(2):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        ora.step(a)
+        nat.step(a.ctypes.data)
+    nat.export_state()
+    before = {k: host_view(nat, k).copy() for k in ("ROOT_STATE", "JOINT_POS", "JOINT_VEL", "OBS_CRITIC", "EPISODE_LENGTH")}
+    ids = [3, 4, 12, 15]
+    keep = np.setdiff1d(np.arange(N), ids)
+    nat.reset(ids)
+    o = ora.reset(env_ids=ids)
+    nat.export_state()
+    for k, v in before.items():
+        if k != "OBS_CRITIC":  # (observations are recomputed for everybody: fresh noise on the policy row, same critic row)
+            assert np.array_equal(host_view(nat, k)[keep], v[keep]), k
+    assert (host_view(nat, "EPISODE_LENGTH")[ids] == 0).all()
+    assert_close("root", host_view(nat, "ROOT_STATE")[ids], oracle_root_state(ora)[ids], 1e-4, 1e-5)
+    assert_close("q", host_view(nat, "JOINT_POS")[ids], ora.st["q"][ids], 1e-5, 1e-6)
+    assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
+    with pytest.raises(Exception):
+        nat.reset([N])
+    nat.close()
