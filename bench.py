@@ -100,9 +100,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     coll = "cpu" if share else dev  # where the collectives' tensors live
-    if world > 1:
+    # RL_BENCH_FORCE_DIST=1 (self-test on a 1-GPU box): run the RCCL leg - init_process_group("nccl", device_id), the float64
+    # all_gather, the MAX and SUM all-reduces on device tensors - with a world of ONE rank.  Never set by the driver.
+    use_dist = world > 1 or os.environ.get("RL_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_PORT" not in os.environ:  # (only without a launcher: the forced single-rank self-test)
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             dist.init_process_group(backend="gloo")
         else:
@@ -119,7 +130,7 @@ def main():
     env.reset()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -134,7 +145,7 @@ def main():
     elapsed_rank = time.perf_counter() - t0
     elapsed = elapsed_rank
     per_rank = [N * args.steps / elapsed_rank]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed_rank], device=coll, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
@@ -168,7 +179,7 @@ def main():
     log = env._bufs["LOG"]
     log_vec = torch.where(log[k][0] > 0, log[k], log[(k - 1) % log.shape[0]]).clone().to(coll)  # most recent step that reset an env
     log_vec[7] = float(N)  # spare slot: envs behind this vector, so the reduced vector carries the global env count
-    if world > 1:
+    if use_dist:
         dist.all_reduce(log_vec, op=dist.ReduceOp.SUM)
 
     traffic = sq = prof_src = None
@@ -193,7 +204,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.task}, {N} envs/GPU, random actions U(-1,1), seed 42+rank", "envs_per_gpu": N,
                    "parallelism": f"env-shard x{world}"},
-        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "collective_backend": ("gloo (RL_BENCH_SHARE_GPU self-test)" if share else "nccl (RCCL)") if world > 1 else None,
+        "rccl_ranks": dist.get_world_size() if use_dist else 1, "collective_backend": ("gloo (RL_BENCH_SHARE_GPU self-test)" if share else "nccl (RCCL)") if use_dist else None,
         "per_rank_env_steps_per_s": per_rank, "envs_behind_reduced_log": float(log_vec[7]),
         "window": {"envs_reset_in_window": envs_reset, "mean_bodies_in_contact_at_end": bodies_in_contact,
                    "note": "rank 0; episodes last 1000 steps, so a short window right after reset() is a cold one"},
@@ -209,7 +220,7 @@ def main():
     env.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

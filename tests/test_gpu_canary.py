@@ -1,0 +1,71 @@
+"""`-m gpu`: canary for the `__launch_bounds__(64)` miscompile (profiles/r02_launch_bounds64_miscompile.txt, csrc/rl_env.hip).
+
+The symptom of that defect: hipcc parked the env's push timer in an AGPR, lent its VGPR to a block that ran under a narrowed EXEC
+mask and reloaded it under the narrower mask, so `push_left < 1e-6` was evaluated on a stale register and the interval push
+(velocity_env_cfg.py:366-371) fired in EVERY env on EVERY step.  The full parity tier catches that, but only as "velocities
+differ"; this test names the symptom and is cheap enough to run for every lane-program instance x workgroup shape x lane mapping
+that the product library ships:
+
+    after one step from reset, the push timer and the command timer of every env that was not reset by that step have
+    decreased by exactly step_dt (one fp32 subtraction - bit exact), and nobody's timer was redrawn.
+
+`__graft_entry__.smoke()` runs the same assertion on A1 (both workgroup shapes) and G1."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RL_TS_CMD_TIME_LEFT, RL_TS_PUSH_TIME_LEFT = 4, 7  # include/rl_env.h rl_task_state_field
+
+# (task, RL_ENV_MERGE): one robot per lane-program instance
+INSTANCES = [
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", None),        # Topo<3,0,3,6>
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", None),       # Topo<3,0,3,6>, 21 reward terms (two trips of the term loop)
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", None),      # Topo<4,0,3,6,1> merged
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", "0"),       # Topo<4,0,3,6>
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", None),        # Topo<7,3,4,9>
+]
+# RL_ENV_WG: "" = the shape the launch size selects (single-wavefront workgroups at this size), "-4" = four wavefronts per workgroup
+# (what >= 4096 quadruped envs launch), RL_ENV_SUB=1 = the one-lane-per-limb mapping
+SHAPES = [("", "4"), ("-4", "4"), ("", "1")]
+
+
+def timers_tick_exactly(env, torch, steps=3):
+    """The assertion itself (shared with __graft_entry__.smoke): returns the number of (env, step) pairs checked."""
+    N = env.num_envs
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    dt = np.float32(env.step_dt)
+    checked = 0
+    for _ in range(steps):
+        before = env.read_state()["task_state"]
+        assert (before[:, RL_TS_PUSH_TIME_LEFT] > 2 * dt).all() and (before[:, RL_TS_CMD_TIME_LEFT] > 2 * dt).all()  # nothing is due
+        _, _, term, tout, _ = env.step(torch.rand(N, env.num_actions, device="cuda", generator=g) * 2 - 1)
+        alive = ~(term | tout).cpu().numpy()
+        after = env.read_state()["task_state"]
+        for f, name in ((RL_TS_PUSH_TIME_LEFT, "push"), (RL_TS_CMD_TIME_LEFT, "command")):
+            want = (before[:, f].astype(np.float32) - dt).astype(np.float32)
+            wrong = np.nonzero((after[:, f] != want) & alive)[0]
+            assert len(wrong) == 0, (f"{name} timer of {len(wrong)} / {int(alive.sum())} live envs did not tick by exactly step_dt "
+                                     f"(first: env {wrong[0]}: {before[wrong[0], f]} -> {after[wrong[0], f]}): the interval event fired or "
+                                     f"the timer register was clobbered - the launch-bounds miscompile symptom")
+        checked += int(alive.sum())
+    return checked
+
+
+@pytest.mark.parametrize("wg,sub", SHAPES)
+@pytest.mark.parametrize("task,merge", INSTANCES)
+def test_interval_timers_tick_by_exactly_step_dt(task, merge, wg, sub, monkeypatch):
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    if wg:
+        monkeypatch.setenv("RL_ENV_WG", wg)
+    if sub != "4":
+        monkeypatch.setenv("RL_ENV_SUB", sub)
+    if merge is not None:
+        monkeypatch.setenv("RL_ENV_MERGE", merge)
+    env = ManagerBasedRLEnv(task, num_envs=256, seed=3, device="cuda:0")
+    assert timers_tick_exactly(env, torch) > 256
+    env.close()

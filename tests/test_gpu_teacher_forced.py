@@ -19,11 +19,19 @@ from robot_lab_amd.scene import build_world, load_bundle
 
 pytestmark = pytest.mark.gpu
 
+# (task, envs, RL_ENV_MERGE): the four BASELINE configs, then one robot per lane-program instance that is NOT a BASELINE id, at the
+# size production launches it: B2W forced onto the unmerged 4-joint instance Topo<4,0,3,6,0> (what a wheeled
+# robot whose trunk spheres do not fit the free limb slots runs on), M20 on the merged one with its trunk spheres in the WHEEL
+# groups (another sub-lane than the trunk body's owner; Go2W has them in the hip groups), Xbot on the trunk + limbs instance with
+# inert padding (2 trunk joints of 3, legs hanging off the trunk).  4096 quadruped envs run the four-wavefront workgroup shape.
 CONFIGS = [
-    ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 4096),
-    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", 4096),
-    ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 2048),
-    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 4096),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 4096, None),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", 4096, None),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 2048, None),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 4096, None),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-B2W-v0", 4096, "0"),
+    ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", 4096, None),
+    ("RobotLab-Isaac-Velocity-Rough-RobotEra-Xbot-v0", 2048, None),
 ]
 
 
@@ -34,12 +42,14 @@ def _outputs(env, obs, rew, term, tout):
     return got
 
 
-@pytest.mark.parametrize("task,N", CONFIGS)
-def test_one_step_from_shared_state_full_size(task, N):
+@pytest.mark.parametrize("task,N,merge", CONFIGS)
+def test_one_step_from_shared_state_full_size(task, N, merge, monkeypatch):
     import torch
 
     from robot_lab_amd.env import ManagerBasedRLEnv
 
+    if merge is not None:
+        monkeypatch.setenv("RL_ENV_MERGE", merge)
     K, seed = 30, 42
     env = ManagerBasedRLEnv(task, num_envs=N, seed=seed, device="cuda:0")
     env2 = ManagerBasedRLEnv(task, num_envs=N, seed=seed, device="cuda:0")
@@ -55,8 +65,8 @@ def test_one_step_from_shared_state_full_size(task, N):
     assert state["step_count"] == K
     # the interval events are due in some envs on the compared step: the push (10 - 15 s apart, velocity_env_cfg.py:366-371) and the
     # command resampling (every 10 s, :106-117) - their timers are part of the exchanged state (include/rl_env.h rl_task_state_field)
-    # (quadruped configs; the trunk + limbs instance has the same edit in its CPU-tier twin, tests/test_teacher_forced.py)
-    events = "G1" not in task
+    # (every config, the trunk + limbs instance included)
+    events = True
     if events:
         ts = state["task_state"].copy()
         ts[2::7, 7] = 0.015   # RL_TS_PUSH_TIME_LEFT
@@ -88,7 +98,7 @@ def test_one_step_from_shared_state_full_size(task, N):
     print("\n[teacher-forced]", json.dumps(rep))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "teacher_forced_" + task.split("Unitree-")[1].replace("-v0", "") + ".json"), "w") as f:
+        with open(os.path.join(out_dir, "teacher_forced_" + task.split("-")[-2] + ".json"), "w") as f:
             json.dump(rep, f, indent=1)
     env.close()
     env2.close()
