@@ -185,9 +185,11 @@ def main():
     traffic = sq = prof_src = None
     try:  # measured separately with rocprofv3 PMC passes (cannot be collected inside this process)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            tr = json.load(f).get(args.task)
+            tj = json.load(f)
+        tr, cal = tj.get(args.task), tj.get("calibration", {})
         if tr and N == tr.get("num_envs", 4096):
-            traffic = tr["fetch_bytes"] + tr["write_bytes"]
+            # raw counters x the factors calibrated on this kernel's own access pattern (tools/micro/stream_rows.hip: FETCH_SIZE reads 1/2)
+            traffic = tr["fetch_bytes"] * cal.get("fetch_factor", 1.0) + tr["write_bytes"] * cal.get("write_factor", 1.0)
             sq = tr.get("sq")  # where a wavefront's cycles go (SQ counters, same offline pass): the kernel is issue / latency bound
             prof_src = tr.get("source", "profiles/traffic.json")
     except (OSError, ValueError, KeyError):
@@ -218,10 +220,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.task, N, args.cpu_seconds, args.cpu_oracle_envs, args.cpu_oracle_steps)
     env.close()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which a pipe buffers until exit
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 def build_host_port() -> str:

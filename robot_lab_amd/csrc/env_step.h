@@ -112,27 +112,52 @@ struct TerrainPatch {
   float h00, h01, h10, h11, fx, fy;
 };
 // The query point is (bx + dx, by + dy): a base that is a WORLD coordinate (root position: tens of metres on the 80 m x 40 m
-// terrain, fp32 ulp 4e-6 m) plus a small offset (sphere centre / scan ray relative to the root).  Summed and turned into grid
-// coordinates in fp64 (a handful of half-rate instructions per query), so that the cell index and the in-cell fractions carry
-// no world-coordinate round-off: in fp32 the sum alone moved a sphere by up to 4e-6 m = 0.08 N of contact force at k = 2e4 N/m,
-// which is what sized the switch margins of the teacher-forced parity tests (tests/helpers.py SWITCH_EPS).
-RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, float bx, float by, float dx, float dy) {
+// terrain, fp32 ulp 4e-6 m) plus a small offset (sphere centre / scan ray relative to the root).  The BASE is turned into grid
+// coordinates in fp64, once per environment and (sub)step: integer cell + fraction (terrain_base); a query then adds its offset to
+// the fraction in fp32 - numbers of at most a few dozen cells, so the cell index and the in-cell fractions carry no
+// world-coordinate round-off (error <= 2e-6 cells = 1e-7 m; summed in fp32 at world scale the sum alone moved a sphere by up to
+// 4e-6 m = 0.08 N of contact force at k = 2e4 N/m, which is what sized the switch margins of the teacher-forced parity tests,
+// tests/helpers.py SWITCH_EPS).  Round 2 did the whole transform in fp64 per QUERY: ~25 fp64 / conversion instructions each, 24
+// queries per lane and step on A1 (profiles/r03_a1_*).
+struct TerrainBase {
+  int cx, cy;    // cell of the base point (unclamped)
+  float fx, fy;  // its position inside that cell, [0, 1)
+};
+RL_FN TerrainBase terrain_base(const Uni& u, float bx, float by) {
+  TerrainBase b;
+  if (u.is_plane) {
+    b.cx = b.cy = 0;
+    b.fx = b.fy = 0.f;
+    return b;
+  }
+  const double gx = ((double)bx - u.x0d) * u.inv_hd, gy = ((double)by - u.y0d) * u.inv_hd;
+  const double cx = floor(gx), cy = floor(gy);
+  b.cx = (int)cx; b.cy = (int)cy;
+  b.fx = (float)(gx - cx); b.fy = (float)(gy - cy);
+  return b;
+}
+RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, const TerrainBase& tb, float dx, float dy) {
   TerrainPatch p;
   if (u.is_plane) {
     p.h00 = p.h01 = p.h10 = p.h11 = 0.f;
     p.fx = p.fy = 0.f;
     return p;
   }
-  const double gx = (((double)bx - u.x0d) + (double)dx) * u.inv_hd, gy = (((double)by - u.y0d) + (double)dy) * u.inv_hd;
-  const double cx = fmin(fmax(floor(gx), 0.0), (double)(u.nx - 2)), cy = fmin(fmax(floor(gy), 0.0), (double)(u.ny - 2));
-  const int ix = (int)cx, iy = (int)cy;
-  p.fx = clampf((float)(gx - cx), 0.f, 1.f);
-  p.fy = clampf((float)(gy - cy), 0.f, 1.f);
+  const float gx = tb.fx + dx * u.inv_hscale, gy = tb.fy + dy * u.inv_hscale;
+  const float flx = floorf(gx), fly = floorf(gy);
+  const int ux = tb.cx + (int)flx, uy = tb.cy + (int)fly;  // unclamped cell
+  // outside the grid: the border cell, the point pushed onto its edge (= clamp(floor(g), 0, n - 2), clamp(g - cell, 0, 1))
+  const int ix = ux < 0 ? 0 : (ux > u.nx - 2 ? u.nx - 2 : ux), iy = uy < 0 ? 0 : (uy > u.ny - 2 ? u.ny - 2 : uy);
+  p.fx = ux < 0 ? 0.f : (ux > u.nx - 2 ? 1.f : gx - flx);
+  p.fy = uy < 0 ? 0.f : (uy > u.ny - 2 ? 1.f : gy - fly);
   // (iy, iy+1) are adjacent in memory: two 8-byte loads per query instead of four 4-byte ones
   const float* b = hf + (uint32_t)ix * (uint32_t)u.ny + (uint32_t)iy;
   F2 r0 = ld2(b), r1 = ld2(b + u.ny);
   p.h00 = r0.x; p.h01 = r0.y; p.h10 = r1.x; p.h11 = r1.y;
   return p;
+}
+RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, float bx, float by, float dx, float dy) {
+  return terrain_fetch(u, hf, terrain_base(u, bx, by), dx, dy);
 }
 RL_FN void terrain_eval(const Uni& u, const TerrainPatch& p, float& h, V3& n) {
   float hx0 = p.h00 + p.fx * (p.h10 - p.h00), hx1 = p.h01 + p.fx * (p.h11 - p.h01);
@@ -649,7 +674,7 @@ struct EnvLane {
 
   // stage A of a link group: sphere centres, terrain loads issued (consumed by group_contacts after unrelated work)
   template <int IT>
-  RL_FN bool group_fetch(const ChainTP& C, const M3& Rwb, uint32_t slot_valid, GroupFetch& gf) {
+  RL_FN bool group_fetch(const ChainTP& C, const M3& Rwb, const TerrainBase& tb, uint32_t slot_valid, GroupFetch& gf) {
     const int g = grp_of(IT);
     const bool mine = g <= CL;
     const int gi = mine ? g : CL;  // lanes without a group in this iteration index the last one and evaluate nothing
@@ -661,7 +686,7 @@ struct EnvLane {
     for (int s = 0; s < SPL; ++s) {
       sphere_center_in(Rg, pg, Rwb, gi, s, gf.rad[s], gf.cb[s], gf.cw[s]);
       if (!mine) gf.rad[s] = -1.f;
-      gf.tp[s] = terrain_fetch(u, S.terrain, pos.x, pos.y, gf.cw[s].x, gf.cw[s].y);
+      gf.tp[s] = terrain_fetch(u, S.terrain, tb, gf.cw[s].x, gf.cw[s].y);
     }
     return true;
   }
@@ -812,7 +837,8 @@ struct EnvLane {
 #ifdef RL_ABL_NO_CONTACTS  // analysis builds (tools/ablate.sh)
     slot_valid = 0u;
 #endif
-    static_for<0, NIT>([&](auto it) { fetched[it.value] = group_fetch<it.value>(C, Rwb, slot_valid, gf[it.value]); });
+    const TerrainBase tb = terrain_base(u, pos.x, pos.y);  // the root in grid coordinates, once for all the lane's spheres
+    static_for<0, NIT>([&](auto it) { fetched[it.value] = group_fetch<it.value>(C, Rwb, tb, slot_valid, gf[it.value]); });
   }
 
   // The decimation loop of the quadruped instances, software-pipelined over the terrain loads: the kinematics of substep s + 1
@@ -1131,11 +1157,12 @@ struct EnvLane {
     // trunk link's spheres: straight into that trunk link's accumulator)
     uint32_t active_mask = 0;
     const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
+    const TerrainBase tb = terrain_base(u, pos.x, pos.y);
     static_for<0, NIT>([&](auto it) {
       const int g = sub + SUB * it.value;
       RL_PHASE(3, "sub.contact_fetch");
       GroupFetch gf;
-      const bool fetched = group_fetch<it.value>(C, Rwb, slot_valid, gf);
+      const bool fetched = group_fetch<it.value>(C, Rwb, tb, slot_valid, gf);
       RL_PHASE(4, "sub.link_records");
       LinkRec rec;
 #pragma unroll

@@ -631,6 +631,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     bool single_trip;
   };
   RL_FN void scan_fetch_trip(int r0, int scan_n, float cy, float sy, V3 scan_p, ScanPatches& sp) const {
+    const TerrainBase tb = terrain_base(this->u, pos.x, pos.y);  // the root in grid coordinates, once for all the lane's rays
     const int snx = ctx.uniform_i(T.scan_nx);
     const float inv_snx = ctx.uniform(1.0f / (float)T.scan_nx);
     const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1);
@@ -640,7 +641,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       r = r < scan_n ? r : scan_n - 1;
       int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
       float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
-      sp.tp[i] = terrain_fetch(this->u, S.terrain, pos.x, pos.y, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
+      sp.tp[i] = terrain_fetch(this->u, S.terrain, tb, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
     }
   }
   RL_FN void scan_fetch(float cy, float sy, V3 scan_p, ScanPatches& sp) const {

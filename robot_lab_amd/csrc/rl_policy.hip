@@ -38,6 +38,10 @@ struct MlpParams {
   int NT8[RL_MLP_MAX_LAYERS];  // groups of 8 output tiles (output width padded to 128 columns: 4 wavefronts x 2 or 8 x 1 tiles per group)
   const float* W[RL_MLP_MAX_LAYERS];  // fragment-major weight image [KB][8 * NT8 tiles][64 lanes][4 k-steps]
   const float* b[RL_MLP_MAX_LAYERS];  // [128 * NT8]
+  // split-precision path (layer_s): 32-deep k blocks of the layer's input (width padded to 32), 16-column output tiles the layer
+  // computes (non-last layers: padded to the next layer's 32-deep blocks) and the weight image as three bf16 planes
+  int KB32[RL_MLP_MAX_LAYERS], NTS[RL_MLP_MAX_LAYERS];
+  const uint16_t* Ws[RL_MLP_MAX_LAYERS];  // [KB32][NTS tiles][3 splits][64 lanes][8 k-steps] bf16
 };
 
 __device__ inline float activate(float v, int act) {
@@ -342,6 +346,211 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fused_pair_kernel(MlpPair q, i
   }
 }
 
+
+// ---- split-precision path: fp32 results from the bf16 matrix cores ---------------------------------------------------------------
+// An fp32 number is the EXACT sum of three bf16 numbers when each split truncates (hi = top 16 bits of x, mid = top 16 bits of
+// x - hi, lo = x - hi - mid: every step peels at least 8 of the 24 significand bits).  With both operands split that way,
+//     a b = (ah + am + al)(bh + bm + bl) = ah bh + [ah bm + am bh + am bm + ah bl + al bh] + O(2^-24 |a b|)
+// and every bf16 x bf16 product is exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16.  Six MFMAs of the bf16 rate
+// (16x the f32 MFMA rate per flop) replace 8 k-steps of v_mfma_f32_16x16x4_f32: 16 / 6 = 2.7x the contraction rate of the exact
+// f32 path, and the result is NOT lower precision - the three dropped products are below fp32 round-off of the term, and the sum
+// sees one fp32 rounding per 32-deep block instead of one per k (measured on the A1 networks against the fp64 oracle: max |err|
+// 8e-7 vs 2e-6 for an fp32 fmaf chain; tests/test_policy.py keeps rtol = atol = 2e-5).  The small products accumulate in their
+// own registers so that they are not rounded away against the running main sum.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Split3 {
+  uint16_t h, m, l;
+};
+__host__ __device__ inline Split3 split3(float v) {
+  union { float f; uint32_t u; } a, b, c, t;
+  a.f = v;
+  t.u = a.u & 0xffff0000u;
+  b.f = v - t.f;  // exact
+  t.u = b.u & 0xffff0000u;
+  c.f = b.f - t.f;  // exact, <= 8 significant bits left
+  Split3 r{(uint16_t)(a.u >> 16), (uint16_t)(b.u >> 16), (uint16_t)(c.u >> 16)};
+  if ((a.u & 0x7f800000u) == 0x7f800000u) r.m = r.l = 0;  // inf / nan: keep it in the leading part only (inf - inf would poison the rest)
+  return r;
+}
+
+// LDS activation tile of the split path, in bf16 units: element (row, k) of plane s sits where the A operand of
+// v_mfma_f32_16x16x32_bf16 wants it - lane (row = lane & 15, kg = lane >> 4) reads its eight k-steps k = 32 kb + 8 kg + j of a
+// 32-deep block as ONE aligned ds_read_b128 at 16-byte slot (kb * 3 + s) * 64 + lane (conflict-free).
+__device__ inline int lds_index_s(int row, int k, int s) { return (((((k >> 5) * 3 + s) * 4 + ((k >> 3) & 3)) * 16 + row) << 3) + (k & 7); }
+
+template <int TPW, int WAVES>
+__device__ inline void layer_s(const MlpParams& P, int l, const uint16_t* __restrict__ xin, uint16_t* __restrict__ xout, float* __restrict__ y, int row0,
+                               int n_rows, int lane, int wave) {  // wave: index of this wavefront's first tile (tiles wave, wave + WAVES, ...)
+  const int KB = __builtin_amdgcn_readfirstlane(P.KB32[l]);
+  const int NT = __builtin_amdgcn_readfirstlane(P.NTS[l]);
+  const int Nl = __builtin_amdgcn_readfirstlane(P.N[l]);
+  wave = __builtin_amdgcn_readfirstlane(wave);
+  auto uniform_ptr = [](const void* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  };
+  const uint64_t Wu = uniform_ptr(P.Ws[l]), bu = uniform_ptr(P.b[l]);
+  const bool last = l == __builtin_amdgcn_readfirstlane(P.n_layers) - 1;
+  // three accumulators per output tile: the leading product, and the five small ones on two chains
+  f32x4 acc[TPW][3];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t][0] = acc[t][1] = acc[t][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef const f32x4 __attribute__((address_space(1))) * GlobalV4;
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  struct BFrag {
+    f32x4 p[3];  // hi, mid, lo plane of the tile's 32 x 16 weight block: 8 bf16 per lane and plane
+  };
+  auto load_b = [&](int kb, BFrag (&b)[TPW]) {
+    const int kc = kb < KB ? kb : KB - 1;  // clamped: the tail re-reads the last block instead of branching
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const uint64_t tile = Wu + (uint64_t)(uint32_t)(kc * NT + wave + WAVES * t) * 3072u;  // scalar: 3 KB per (k block, tile)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) b[t].p[s] = *(GlobalV4)(uintptr_t)(tile + (uint32_t)(s * 1024) + lane16);
+    }
+  };
+  BFrag b0[TPW], b1[TPW];
+  load_b(0, b0);
+  float bias_r[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) bias_r[t] = *(const float __attribute__((address_space(1)))*)(uintptr_t)(bu + (uint64_t)(uint32_t)((wave + WAVES * t) * 64) + (uint32_t)((lane & 15) * 4));
+  const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;  // plane s of block kb: + (kb * 3 + s) * 64
+  f32x4 an[3];
+  auto load_a = [&](int kb, f32x4 (&a)[3]) {
+    const int kc = kb < KB ? kb : KB - 1;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a[s] = xa[(kc * 3 + s) * 64];
+  };
+  load_a(0, an);
+  auto mma = [&](int kb, const BFrag (&b)[TPW]) {
+    bf16x8 a[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a[s] = __builtin_bit_cast(bf16x8, an[s]);
+    load_a(kb + 1, an);
+#define RL_MMA(ai, bi, ci) acc[t][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai], __builtin_bit_cast(bf16x8, b[t].p[bi]), acc[t][ci], 0, 0, 0)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) RL_MMA(0, 0, 0);  // hi hi
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) RL_MMA(0, 1, 1);  // hi mid
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) RL_MMA(1, 0, 2);  // mid hi
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) RL_MMA(1, 1, 1);  // mid mid
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) RL_MMA(0, 2, 2);  // hi lo
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) RL_MMA(2, 0, 1);  // lo hi
+#undef RL_MMA
+  };
+  int kb = 0;
+  for (; kb + 2 <= KB; kb += 2) {  // two weight buffers, rotated by unrolling two blocks
+    load_b(kb + 1, b1);
+    mma(kb, b0);
+    load_b(kb + 2, b0);
+    mma(kb + 1, b1);
+  }
+  if (kb < KB) mma(kb, b0);
+  // epilogue: D[row = (lane >> 4) * 4 + reg][col = lane & 15] -> bias, activation -> the next layer's three planes / global
+  const int col = lane & 15, rbase = (lane >> 4) * 4;
+  const int act = __builtin_amdgcn_readfirstlane(P.act);
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int n = (wave + WAVES * t) * 16 + col;
+    const float bias = bias_r[t];
+    const bool valid = n < Nl;
+    const int o = lds_index_s(rbase, n, 0);  // + 8 r per row, + 512 s per plane
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = ((acc[t][1][r] + acc[t][2][r]) + acc[t][0][r]) + bias;
+      if (!last) {
+        const float av = act == RL_ACT_ELU ? (v > 0.f ? v : __expf(v) - 1.0f) : act == RL_ACT_RELU ? fmaxf(v, 0.f) : tanhf(v);
+        const Split3 sp = split3(valid ? av : 0.f);  // padded columns feed zeros into the next layer
+        xout[o + 8 * r] = sp.h;
+        xout[o + 8 * r + 512] = sp.m;
+        xout[o + 8 * r + 1024] = sp.l;
+      } else if (valid && row0 + rbase + r < n_rows) {
+        y[(size_t)(row0 + rbase + r) * P.out_dim + n] = v;
+      }
+    }
+  }
+}
+
+template <int WAVES>
+__device__ __forceinline__ void stage_rows_s(const MlpParams& P, const float* __restrict__ x, uint16_t* __restrict__ dst, int row0, int n_rows, int lane, int wave) {
+  // 16 rows over WAVES wavefronts; every load of the wavefront is in flight before the first LDS write (see stage_rows)
+  constexpr int JMAX = KMAX / 64, H = MT / WAVES;
+  const int K0 = P.KB32[0] * 32;
+  float v[H][JMAX];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const int r = wave + WAVES * h;
+    const bool live = row0 + r < n_rows;
+    const float* __restrict__ xr = x + (size_t)(row0 + r) * P.in_dim;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int c = lane + 64 * j;
+      v[h][j] = (64 * j < K0 && live && c < P.in_dim) ? xr[c] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int c = lane + 64 * j;
+      if (64 * j < K0 && c < K0) {
+        const Split3 sp = split3(v[h][j]);
+        const int o = lds_index_s(wave + WAVES * h, c, 0);
+        dst[o] = sp.h;
+        dst[o + 512] = sp.m;
+        dst[o + 1024] = sp.l;
+      }
+    }
+}
+
+template <int WAVES>
+__device__ __forceinline__ void split_segment(const MlpParams& P, int l, const uint16_t* xin, uint16_t* xout, float* y, int row0, int n_rows, int lane, int first) {
+  const int nt = P.NTS[l];
+  if (first >= nt) return;
+  const int cnt = (nt - first + WAVES - 1) / WAVES;
+  if (cnt == 1) layer_s<1, WAVES>(P, l, xin, xout, y, row0, n_rows, lane, first);
+  else layer_s<2, WAVES>(P, l, xin, xout, y, row0, n_rows, lane, first);  // 512 columns = 32 tiles = 2 per wavefront
+}
+
+// One workgroup (16 wavefronts) owns 16 rows and runs network A and - when q.b is given - network B on them, layer by layer, as
+// mlp_fused_pair_kernel does (tiles of the two networks dealt round-robin, SIMD-mates alternate the order of their two segments).
+// LDS: per network two activation buffers of three bf16 planes; layer l reads buffer l & 1 (widths: host, rl_mlp_split_lds).
+struct SplitLds {
+  int a1, b0, b1;  // offsets (in bf16 units) of A's second buffer and of B's two buffers; A's first buffer starts at 0
+};
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mlp_split_kernel(MlpPair q, int n_rows, SplitLds o) {
+  extern __shared__ float4 smem4[];
+  uint16_t* base = reinterpret_cast<uint16_t*>(smem4);
+  const MlpParams& A = *q.a;
+  const bool two = q.b != nullptr;
+  const MlpParams& B = two ? *q.b : *q.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * MT;
+  stage_rows_s<WAVES>(A, q.xa, base, row0, n_rows, lane, wave);
+  if (two) stage_rows_s<WAVES>(B, q.xb, base + o.b0, row0, n_rows, lane, wave);
+  __syncthreads();
+  const bool a_first = ((wave >> 2) & 1) == 0;
+  for (int l = 0; l < A.n_layers; ++l) {
+    const int ntA = A.NTS[l];
+    const int firstB = (wave - ntA) & (WAVES - 1);  // B's tiles continue A's round-robin
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const bool isA = (h == 0) == a_first;
+      if (!isA && !two) continue;
+      const MlpParams& P = isA ? A : B;
+      const int even = isA ? 0 : o.b0, odd = isA ? o.a1 : o.b1;  // (offsets, not an array of pointers indexed by l: that would live in scratch)
+      split_segment<WAVES>(P, l, base + ((l & 1) ? odd : even), base + ((l & 1) ? even : odd), isA ? q.ya : q.yb, row0, n_rows, lane, isA ? wave : firstB);
+    }
+    __syncthreads();
+  }
+}
+
 std::string& err() {
   static thread_local std::string e;
   return e;
@@ -357,8 +566,35 @@ struct rl_mlp {
   MlpParams P;
   MlpParams* dP = nullptr;  // device copy (rl_mlp_forward_pair)
   int device = 0;
+  int cols[2] = {0, 0};  // split path: widest (32-padded) layer input held by the even / the odd activation buffer
   std::vector<void*> allocs;
 };
+
+namespace {
+// RL_MLP_PRECISION=f32 selects the exact-f32 MFMA kernels (v_mfma_f32_16x16x4_f32); default: the split-bf16 path (layer_s), which
+// is at least as accurate (see its header) and 2.7x the contraction rate.  Networks whose activation planes do not fit the 160 KB
+// of LDS fall back to the f32 kernels by themselves.
+bool split_wanted() {  // (read at every call: the tests switch it inside one process)
+  const char* e = getenv("RL_MLP_PRECISION");
+  return !(e && (e[0] == 'f' || e[0] == 'F'));
+}
+constexpr size_t LDS_MAX = 160 * 1024;
+size_t split_lds_bytes(const rl_mlp* m) { return (size_t)(m->cols[0] + m->cols[1]) * MT * 3 * sizeof(uint16_t); }
+int launch_split(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* xb, float* yb, int n_rows, void* stream) {
+  const size_t la = split_lds_bytes(a), lb = b ? split_lds_bytes(b) : 0;
+  static size_t configured[64] = {};  // the LDS opt-in belongs to the (kernel, device) pair
+  if (la + lb > configured[a->device & 63]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_split_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(la + lb)) != hipSuccess)
+      return fail("cannot reserve the LDS of the split-precision kernel");
+    configured[a->device & 63] = la + lb;
+  }
+  MlpPair q{a->dP, b ? b->dP : nullptr, xa, xb, ya, yb, nullptr};
+  SplitLds o{a->cols[0] * MT * 3, (int)(la / 2), (int)(la / 2) + (b ? b->cols[0] * MT * 3 : 0)};
+  hipLaunchKernelGGL(mlp_split_kernel<16>, dim3((n_rows + MT - 1) / MT), dim3(1024), la + lb, (hipStream_t)stream, q, n_rows, o);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
+}
+}  // namespace
 
 extern "C" {
 
@@ -398,6 +634,31 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
     (void)hipMemcpy(dW, Wf.data(), Wf.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
     m->P.W[l] = (const float*)dW; m->P.b[l] = (const float*)db;
+    // split-precision image: 32-deep k blocks; a non-last layer also computes the zero columns that pad its output to the next
+    // layer's 32-deep blocks (never more tiles than the 128-column padding of the bias vector holds)
+    const int KB32 = (K + 31) / 32, NTS = l + 1 < n_layers ? 2 * ((N + 31) / 32) : (N + 15) / 16;
+    m->P.KB32[l] = KB32; m->P.NTS[l] = NTS;
+    m->cols[l & 1] = std::max(m->cols[l & 1], KB32 * 32);
+    std::vector<uint16_t> Wsp((size_t)KB32 * NTS * 3 * 64 * 8, 0);
+    for (int kb = 0; kb < KB32; ++kb)
+      for (int t = 0; t < NTS; ++t)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int j = 0; j < 8; ++j) {
+            const int k = kb * 32 + 8 * (ln >> 4) + j, n = t * 16 + (ln & 15);
+            if (k < K && n < N) {
+              const Split3 sp = split3(weights[l][(size_t)n * K + k]);
+              const size_t o = ((((size_t)kb * NTS + t) * 3) * 64 + ln) * 8 + j;
+              Wsp[o] = sp.h; Wsp[o + 512] = sp.m; Wsp[o + 1024] = sp.l;
+            }
+          }
+    void* dWs = nullptr;
+    if (hipMalloc(&dWs, Wsp.size() * 2) != hipSuccess) {
+      rl_mlp_destroy(m);
+      return fail("device allocation failed");
+    }
+    m->allocs.push_back(dWs);
+    (void)hipMemcpy(dWs, Wsp.data(), Wsp.size() * 2, hipMemcpyHostToDevice);
+    m->P.Ws[l] = (const uint16_t*)dWs;
   }
   void* dP = nullptr;
   if (hipMalloc(&dP, sizeof(MlpParams)) != hipSuccess) {
@@ -423,6 +684,8 @@ int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b
   const size_t lds = fused ? sizeof(float) * 4 * MT * KMAX : sizeof(float) * 2 * MT * KMAX * RT;
   if (a->device != b->device) return fail("the two networks live on different devices");
   if (hipSetDevice(a->device) != hipSuccess) return fail("hipSetDevice failed");
+  if (split_wanted() && a->P.n_layers == b->P.n_layers && split_lds_bytes(a) + split_lds_bytes(b) <= LDS_MAX)
+    return launch_split(a, xa_dev, ya_dev, b, xb_dev, yb_dev, n_rows, stream);
   static bool attr_done[64] = {};  // the LDS opt-in belongs to the (kernel, device) pair
   if (!attr_done[a->device & 63]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_pair_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 2 * MT * KMAX)) != hipSuccess ||
@@ -484,6 +747,7 @@ int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, 
   if (n_rows <= 0) return 0;
   constexpr size_t lds = sizeof(float) * 2 * MT * KMAX;
   if (hipSetDevice(m->device) != hipSuccess) return fail("hipSetDevice failed");
+  if (split_wanted() && split_lds_bytes(m) <= LDS_MAX) return launch_split(m, x_dev, y_dev, nullptr, nullptr, nullptr, n_rows, stream);
   static bool attr_done[64] = {};
   if (!attr_done[m->device & 63]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

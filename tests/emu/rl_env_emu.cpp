@@ -44,9 +44,95 @@ struct LaneBarrier {
   }
 };
 
+// ---- lane FIBERS: the LPE lanes of an environment as coroutines of ONE host thread (RL_EMU_FIBERS=1) --------------------------------
+// The lane program is SPMD with collectives (gsum, leg_bcast, any ...); with a host thread per lane every collective is two
+// inter-core barriers, which is what bench.py's "lane-emulator" CPU figure measures.  A CPU program would run an environment on
+// one core: here the lanes are fibers that hand the core to the next lane at every barrier (round robin: when the last lane
+// arrives, the first one is past it), so an environment costs no inter-core traffic at all and the box runs one environment per
+// core (bench.py `cpu_baseline`, kind "port").  A switch saves / restores the six callee-saved registers and the stack pointer.
+#if defined(__x86_64__)
+extern "C" void rl_fiber_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl rl_fiber_switch
+.type rl_fiber_switch,@function
+rl_fiber_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size rl_fiber_switch,.-rl_fiber_switch
+)");
+#define RL_HAVE_FIBERS 1
+#else
+#define RL_HAVE_FIBERS 0
+#endif
+
+struct FiberSet {
+  static constexpr size_t STACK = 512 * 1024;
+  int n = 0, cur = -1;
+  void* sp[17] = {};     // saved stack pointers of the lanes; [n] = the host thread's own context
+  std::vector<std::unique_ptr<char[]>> stacks;
+  std::function<void(int)> body;
+  static thread_local FiberSet* active;
+  static void entry() {  // first activation of a lane: run its body, then hand on to the next lane (the last one: back to the host)
+    FiberSet* fs = active;
+    const int me = fs->cur;
+    fs->body(me);
+    fs->cur = me + 1;
+#if RL_HAVE_FIBERS
+    void* dead;
+    rl_fiber_switch(&dead, fs->sp[me + 1]);
+#endif
+    __builtin_trap();
+  }
+  void run(int lanes, const std::function<void(int)>& f) {
+#if RL_HAVE_FIBERS
+    n = lanes;
+    body = f;
+    stacks.resize(n);
+    for (int i = 0; i < n; ++i) {
+      if (!stacks[i]) stacks[i].reset(new char[STACK]);
+      uintptr_t top = ((uintptr_t)stacks[i].get() + STACK) & ~(uintptr_t)63;
+      void** s = (void**)(top - 64);  // 16-byte aligned slot for the return address: rsp = 16 k + 8 at `entry`, as after a call
+      s[0] = (void*)&FiberSet::entry;
+      for (int r = 1; r <= 6; ++r) s[-r] = nullptr;
+      sp[i] = (void*)(s - 6);
+    }
+    active = this;
+    cur = 0;
+    rl_fiber_switch(&sp[n], sp[0]);
+#else
+    (void)lanes; (void)f;
+#endif
+  }
+  void yield(int me) {  // called by lane `me` at a barrier: the next lane runs
+#if RL_HAVE_FIBERS
+    const int nx = me + 1 == n ? 0 : me + 1;
+    cur = nx;
+    rl_fiber_switch(&sp[me], sp[nx]);
+#else
+    (void)me;
+#endif
+  }
+};
+thread_local FiberSet* FiberSet::active = nullptr;
+
 template <int LPE>
 struct alignas(64) Team {
   LaneBarrier bar;
+  FiberSet* fibers = nullptr;  // set: the lanes are fibers of one thread
   alignas(64) float slot[LPE];
   float rstage[rl::MAX_T];
   float feat[rl::feat_count(rl::TopoMax::DMAX)];
@@ -55,7 +141,10 @@ struct alignas(64) Team {
   float rtab[rl::rew_tab_words(RL_MAX_DOF, RL_MAX_BODIES)];
   std::vector<float> stage[2];
   Team() { bar.n = LPE; }
-  void barrier(int&) { bar.wait(); }
+  void barrier(int lane) {
+    if (fibers) fibers->yield(lane);
+    else bar.wait();
+  }
 };
 
 // Persistent worker pool: RL_EMU_TEAMS teams (default 1) of LPE lane threads; team t simulates the environments
@@ -169,56 +258,56 @@ struct HostCtx {
   // sum over the 4 legs of the values held at the same sub-lane index (replicated inputs -> leg sum)
   float gsum(float v) {
     team->slot[li()] = v;
-    team->barrier(sense_);
+    team->barrier(li());
     const float* p = team->slot;
     float a = p[0 * SUB + sub_] + p[1 * SUB + sub_], b = p[2 * SUB + sub_] + p[3 * SUB + sub_];
     float s = k_ < 2 ? a + b : b + a;
-    team->barrier(sense_);
+    team->barrier(li());
     return s;
   }
   // sum over the SUB sub-lanes of this leg (butterfly order of the DPP quad: (x0+x1)+(x2+x3))
   float leg_sum(float v) {
     if (SUB == 1) return v;
     team->slot[li()] = v;
-    team->barrier(sense_);
+    team->barrier(li());
     const float* p = team->slot + k_ * SUB;
     float s = (p[0] + p[1]) + (p[2 % SUB] + p[3 % SUB]);
-    team->barrier(sense_);
+    team->barrier(li());
     return s;
   }
   float esum(float v) { return gsum(leg_sum(v)); }
   // min over all lanes of the env
   float emin(float v) {
     team->slot[li()] = v;
-    team->barrier(sense_);
+    team->barrier(li());
     float r = team->slot[0];
     for (int i = 1; i < LPE; ++i) r = r < team->slot[i] ? r : team->slot[i];
-    team->barrier(sense_);
+    team->barrier(li());
     return r;
   }
   // wave-level vote on the GPU; here an env-level OR (it may guard collectives, so it must be uniform)
   bool any(bool c) {
     team->slot[li()] = c ? 1.f : 0.f;
-    team->barrier(sense_);
+    team->barrier(li());
     bool r = false;
     for (int i = 0; i < LPE; ++i) r = r || team->slot[i] != 0.f;
-    team->barrier(sense_);
+    team->barrier(li());
     return r;
   }
   template <int J>
   float leg_bcast(float v) {
     if (SUB == 1) return v;  // a lane is the whole leg
     team->slot[li()] = v;
-    team->barrier(sense_);
+    team->barrier(li());
     float r = team->slot[k_ * SUB + (J < SUB ? J : 0)];
-    team->barrier(sense_);
+    team->barrier(li());
     return r;
   }
   float gshfl(float v, int leg) {
     team->slot[li()] = v;
-    team->barrier(sense_);
+    team->barrier(li());
     float r = team->slot[leg * SUB + sub_];
-    team->barrier(sense_);
+    team->barrier(li());
     return r;
   }
   void atomic_add(float* p, float v) {
@@ -232,11 +321,11 @@ struct HostCtx {
   float* rew_stage() { return team->rstage; }
   float* feat_stage() { return team->feat; }
   float* rew_tab() { return team->rtab; }
-  void group_sync() { team->barrier(sense_); }
+  void group_sync() { team->barrier(li()); }
   void flush_obs(float* out, int dim, int g) {
-    team->barrier(sense_);
+    team->barrier(li());
     for (int i = li(); i < dim; i += LPE) out[(size_t)e_ * dim + i] = team->stage[g][i];
-    team->barrier(sense_);
+    team->barrier(li());
   }
 };
 
@@ -254,6 +343,28 @@ void run(const rl::KState& S_launch, const void* Tv, int reset) {
     t.reset(new Team<Ctx::LPE>());
     t->stage[0].assign(std::max(1, T->policy_dim), 0.f);
     t->stage[1].assign(std::max(1, T->critic_dim), 0.f);
+  }
+  const auto lane_loop = [&](int tm, int l) {
+    Ctx ctx;
+    ctx.team = team[tm].get(); ctx.T = T; ctx.k_ = l / SUB; ctx.sub_ = l % SUB; ctx.e_ = 0;
+    for (int e = tm; e < S.Npad; e += teams) {
+      ctx.e_ = e;
+      rl::EnvProgram<Ctx, TP> prog(ctx, S);
+      if (reset)
+        prog.reset_entry();
+      else
+        prog.step();
+    }
+  };
+  if (RL_HAVE_FIBERS && std::getenv("RL_EMU_FIBERS") && std::atoi(std::getenv("RL_EMU_FIBERS")) != 0) {
+    // one host thread per team, the team's lanes as fibers of that thread: an environment never leaves its core
+    const std::function<void(int)> fjob = [&](int tm) {
+      static thread_local FiberSet fs;
+      team[tm]->fibers = &fs;
+      fs.run(Ctx::LPE, [&](int l) { lane_loop(tm, l); });
+    };
+    Pool::get().run(teams, fjob);
+    return;
   }
   const std::function<void(int)> job = [&](int id) {
     const int tm = id / Ctx::LPE, l = id % Ctx::LPE;

@@ -42,7 +42,13 @@ def test_policy_library_exports():
         assert hasattr(lib, name), name
 
 
+# both contraction paths of csrc/rl_policy.hip: "" = the default (split-bf16: three exact bf16 planes per operand, six bf16 MFMAs per
+# 32-deep block, fp32 accumulate), "f32" = RL_MLP_PRECISION=f32, the exact-f32 MFMA kernels.  Same tolerance for both.
+PRECISIONS = ["", "f32"]
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("dims,act,N", [
     ([45, 512, 256, 128, 12], "elu", 4096),     # A1 actor
     ([235, 512, 256, 128, 1], "elu", 4096),     # A1 critic
@@ -51,17 +57,44 @@ def test_policy_library_exports():
     ([7, 33, 5], "tanh", 19),                   # odd widths: every padding path
     ([48, 64], "relu", 1),                      # single layer, single row
 ])
-def test_hip_mlp_matches_oracle(dims, act, N):
+def test_hip_mlp_matches_oracle(dims, act, N, prec, monkeypatch):
     import torch
 
     from robot_lab_amd.policy import MlpPolicy
+
+    if prec:
+        monkeypatch.setenv("RL_MLP_PRECISION", prec)
 
     ws, bs = _net(dims, 3)
     pol = MlpPolicy(ws, bs, act, device="cuda:0")
     x = np.random.default_rng(4).uniform(-2, 2, (N, dims[0])).astype(np.float32)
     got = pol(torch.from_numpy(x).cuda()).cpu().numpy()
     want = mlp_forward(x, ws, bs, act)
-    # exact-fp32 MFMA = a k-ordered fmaf chain: round-off of a K <= 512 dot product
+    # exact-fp32 MFMA = a k-ordered fmaf chain: round-off of a K <= 512 dot product; the split path sees fewer roundings
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+    err = np.abs(got - want) / (1.0 + np.abs(want))
+    print(f"\n[mlp {prec or 'split-bf16'}] {dims} x {N}: max |err| / (1 + |y|) = {err.max():.2e}")
+    pol.close()
+
+
+@pytest.mark.gpu
+def test_split_path_survives_large_and_tiny_values():
+    """The bf16 planes keep fp32's exponent range: activations of 1e4 and inputs of 1e-20 go through the split path like through
+    the f32 kernels (an fp16 split would overflow / flush them)."""
+    import torch
+
+    from robot_lab_amd.policy import MlpPolicy
+
+    dims = [40, 64, 8]
+    ws, bs = _net(dims, 11)
+    ws[0] *= 300.0
+    pol = MlpPolicy(ws, bs, "relu", device="cuda:0")
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-30, 30, (64, 40)).astype(np.float32)
+    x[::2] *= 1e-20
+    got = pol(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = mlp_forward(x, ws, bs, "relu")
+    assert np.abs(want).max() > 1e3
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
     pol.close()
 
@@ -92,16 +125,20 @@ def test_hip_mlp_from_rsl_rl_state_dict_and_env_obs():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("N,da,dc", [(4096, [45, 512, 256, 128, 12], [235, 512, 256, 128, 1]), (37, [45, 512, 256, 128, 12], [235, 512, 256, 128, 1]),
                                      (4099, [45, 512, 256, 128, 12], [235, 512, 256, 128, 1]),  # fused kernel, ragged last row tile
                                      (3100, [96, 400, 200, 29], [310, 512, 136, 1]),            # widths that are no multiples of 128 / 16
                                      (3072, [45, 64, 12], [235, 512, 1])])                        # two layers, very different networks
-def test_hip_mlp_pair_is_bitwise_the_two_single_launches(N, da, dc):
+def test_hip_mlp_pair_is_bitwise_the_two_single_launches(N, da, dc, prec, monkeypatch):
     """rl_mlp_forward_pair (actor + critic in one launch; from 3072 rows on the fused kernel that runs both networks on a row
     tile) = the same k-ordered MFMA chains as the single launches: identical bits."""
     import torch
 
     from robot_lab_amd.policy import MlpPolicy
+
+    if prec:
+        monkeypatch.setenv("RL_MLP_PRECISION", prec)
 
     wa, ba = _net(da, 5)
     wc, bc = _net(dc, 6)
