@@ -120,20 +120,23 @@ struct TerrainPatch {
 // tests/helpers.py SWITCH_EPS).  Round 2 did the whole transform in fp64 per QUERY: ~25 fp64 / conversion instructions each, 24
 // queries per lane and step on A1 (profiles/r03_a1_*).
 struct TerrainBase {
-  int cx, cy;    // cell of the base point (unclamped)
-  float fx, fy;  // its position inside that cell, [0, 1)
+  int cx, cy;            // cell of the base point (unclamped)
+  float fx, fy;          // its position inside that cell, [0, 1)
+  float lox, hix, loy, hiy;  // the grid's first / last cell relative to (cx, cy): a query's cell offset is clamped to them
 };
 RL_FN TerrainBase terrain_base(const Uni& u, float bx, float by) {
   TerrainBase b;
   if (u.is_plane) {
     b.cx = b.cy = 0;
-    b.fx = b.fy = 0.f;
+    b.fx = b.fy = b.lox = b.hix = b.loy = b.hiy = 0.f;
     return b;
   }
   const double gx = ((double)bx - u.x0d) * u.inv_hd, gy = ((double)by - u.y0d) * u.inv_hd;
   const double cx = floor(gx), cy = floor(gy);
   b.cx = (int)cx; b.cy = (int)cy;
   b.fx = (float)(gx - cx); b.fy = (float)(gy - cy);
+  b.lox = (float)(-b.cx); b.hix = (float)(u.nx - 2 - b.cx);
+  b.loy = (float)(-b.cy); b.hiy = (float)(u.ny - 2 - b.cy);
   return b;
 }
 RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, const TerrainBase& tb, float dx, float dy) {
@@ -143,13 +146,13 @@ RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, con
     p.fx = p.fy = 0.f;
     return p;
   }
+  // grid coordinates relative to the base cell; cell = clamp(floor(g), first, last), fraction = clamp(g - cell, 0, 1): outside the
+  // grid the border cell with the point pushed onto its edge (the same rule as oracle/physics.py TerrainSampler)
   const float gx = tb.fx + dx * u.inv_hscale, gy = tb.fy + dy * u.inv_hscale;
-  const float flx = floorf(gx), fly = floorf(gy);
-  const int ux = tb.cx + (int)flx, uy = tb.cy + (int)fly;  // unclamped cell
-  // outside the grid: the border cell, the point pushed onto its edge (= clamp(floor(g), 0, n - 2), clamp(g - cell, 0, 1))
-  const int ix = ux < 0 ? 0 : (ux > u.nx - 2 ? u.nx - 2 : ux), iy = uy < 0 ? 0 : (uy > u.ny - 2 ? u.ny - 2 : uy);
-  p.fx = ux < 0 ? 0.f : (ux > u.nx - 2 ? 1.f : gx - flx);
-  p.fy = uy < 0 ? 0.f : (uy > u.ny - 2 ? 1.f : gy - fly);
+  const float ox = clampf(floorf(gx), tb.lox, tb.hix), oy = clampf(floorf(gy), tb.loy, tb.hiy);
+  p.fx = clampf(gx - ox, 0.f, 1.f);
+  p.fy = clampf(gy - oy, 0.f, 1.f);
+  const int ix = tb.cx + (int)ox, iy = tb.cy + (int)oy;
   // (iy, iy+1) are adjacent in memory: two 8-byte loads per query instead of four 4-byte ones
   const float* b = hf + (uint32_t)ix * (uint32_t)u.ny + (uint32_t)iy;
   F2 r0 = ld2(b), r1 = ld2(b + u.ny);

@@ -158,6 +158,11 @@ struct TaskTab {  // everything that is not per limb
   float scan_res, scan_offset;
   uint32_t wheel_joint_mask;
   int32_t n_rewards;
+  // evaluation schedule of the reward terms (env_terms.h compute_rewards): slot s is evaluated as term rew_slot[s]; slots below
+  // n_main by the full term_value(), slots from n_main on - they hold "scalar" kinds only, terms of the env's own scalars - by the
+  // short scalar_term_value().  With 16 lanes per env, 17 - 32 terms cost one full trip + one scalar mini-trip instead of two full trips.
+  int32_t n_main;
+  int32_t rew_slot[MAX_T];
   uint64_t rew_rel_mask;  // bodies whose position / velocity relative to the root some reward term reads
   int32_t idx_pool_a[IDX_POOL], idx_pool_b[IDX_POOL];
   int32_t term_time_out, term_oob, term_illegal;

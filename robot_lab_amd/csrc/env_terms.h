@@ -40,6 +40,47 @@ struct RewEnv {
   M3 Rwb;
 };
 
+// "scalar" kinds: functions of the env's own scalars (velocities, gravity vector, command) and the term's parameters - no tables
+RL_FN constexpr bool is_scalar_reward_kind(int kind) {
+  return kind == REW_TRACK_LIN_VEL_XY_EXP || kind == REW_TRACK_ANG_VEL_Z_EXP || kind == REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP ||
+         kind == REW_TRACK_ANG_VEL_Z_WORLD_EXP || kind == REW_LIN_VEL_Z_L2 || kind == REW_ANG_VEL_XY_L2 || kind == REW_FLAT_ORIENTATION_L2 ||
+         kind == REW_UPWARD || kind == REW_IS_TERMINATED || kind == REW_HANDSTAND_ORIENTATION_L2;
+}
+// unweighted value of a scalar-kind term (the same arithmetic as the corresponding cases of term_value, which it serves too)
+RL_FN float scalar_term_value(const RewTab& R, const RewEnv& E) {
+  const float gate = E.gate;
+  float f = 0.f;
+  switch (R.kind) {
+    case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
+      float ex = E.cmd.x - E.lin_b.x, ey = E.cmd.y - E.lin_b.y;
+      f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
+    } break;
+    case REW_TRACK_ANG_VEL_Z_EXP: {  // rewards.py:38-48
+      float ez = E.cmd.z - E.ang_b.z;
+      f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
+    } break;
+    case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // rewards.py:51-66: root COM velocity in the yaw-only frame
+      float ex = E.cmd.x - (E.yaw_c * E.lin_w.x + E.yaw_s * E.lin_w.y), ey = E.cmd.y - (-E.yaw_s * E.lin_w.x + E.yaw_c * E.lin_w.y);
+      f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
+    } break;
+    case REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // rewards.py:69-78
+      float ez = E.cmd.z - E.vang.z;
+      f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
+    } break;
+    case REW_LIN_VEL_Z_L2: f = E.lin_b.z * E.lin_b.z * gate; break;                         // rewards.py:647-653
+    case REW_ANG_VEL_XY_L2: f = (E.ang_b.x * E.ang_b.x + E.ang_b.y * E.ang_b.y) * gate; break;  // rewards.py:656-662
+    case REW_FLAT_ORIENTATION_L2: f = (E.grav_b.x * E.grav_b.x + E.grav_b.y * E.grav_b.y) * gate; break;  // rewards.py:678-687
+    case REW_UPWARD: f = (1.f - E.grav_b.z) * (1.f - E.grav_b.z); break;                     // rewards.py:608-613
+    case REW_IS_TERMINATED: f = E.terminated ? 1.f : 0.f; break;
+    case REW_HANDSTAND_ORIENTATION_L2: {  // config/others/unitree_a1_handstand/env/rewards.py:50-59
+      const float dx = E.grav_b.x - R.p[0], dy = E.grav_b.y - R.p[1], dz = E.grav_b.z - R.p[2];
+      f = dx * dx + dy * dy + dz * dz;
+    } break;
+    default: break;
+  }
+  return f;
+}
+
 // unweighted value of one term, evaluated by ONE lane
 template <class TabT>
 RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ terrain, const RewTab& R, const RewEnv& E) {
@@ -64,27 +105,11 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
   }
   float f = 0.f;
   switch (R.kind) {
-    case REW_TRACK_LIN_VEL_XY_EXP: {  // VEL/mdp/rewards.py:22-35
-      float ex = E.cmd.x - E.lin_b.x, ey = E.cmd.y - E.lin_b.y;
-      f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
-    } break;
-    case REW_TRACK_ANG_VEL_Z_EXP: {  // rewards.py:38-48
-      float ez = E.cmd.z - E.ang_b.z;
-      f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
-    } break;
-    case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {  // rewards.py:51-66: root COM velocity in the yaw-only frame
-      float ex = E.cmd.x - (E.yaw_c * E.lin_w.x + E.yaw_s * E.lin_w.y), ey = E.cmd.y - (-E.yaw_s * E.lin_w.x + E.yaw_c * E.lin_w.y);
-      f = fexp(-(ex * ex + ey * ey) * frcp(R.p[0])) * gate;
-    } break;
-    case REW_TRACK_ANG_VEL_Z_WORLD_EXP: {  // rewards.py:69-78
-      float ez = E.cmd.z - E.vang.z;
-      f = fexp(-(ez * ez) * frcp(R.p[0])) * gate;
-    } break;
-    case REW_LIN_VEL_Z_L2: f = E.lin_b.z * E.lin_b.z * gate; break;                         // rewards.py:647-653
-    case REW_ANG_VEL_XY_L2: f = (E.ang_b.x * E.ang_b.x + E.ang_b.y * E.ang_b.y) * gate; break;  // rewards.py:656-662
-    case REW_FLAT_ORIENTATION_L2: f = (E.grav_b.x * E.grav_b.x + E.grav_b.y * E.grav_b.y) * gate; break;  // rewards.py:678-687
-    case REW_UPWARD: f = (1.f - E.grav_b.z) * (1.f - E.grav_b.z); break;                     // rewards.py:608-613
-    case REW_IS_TERMINATED: f = E.terminated ? 1.f : 0.f; break;
+    case REW_TRACK_LIN_VEL_XY_EXP: case REW_TRACK_ANG_VEL_Z_EXP: case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: case REW_TRACK_ANG_VEL_Z_WORLD_EXP:
+    case REW_LIN_VEL_Z_L2: case REW_ANG_VEL_XY_L2: case REW_FLAT_ORIENTATION_L2: case REW_UPWARD: case REW_IS_TERMINATED:
+    case REW_HANDSTAND_ORIENTATION_L2:
+      f = scalar_term_value(R, E);
+      break;
     // joint sums [UPSTREAM isaaclab.envs.mdp] + rewards.py:81-90: the statistic is in the table, the mask picked the joints
     case REW_JOINT_TORQUES_L2: case REW_JOINT_ACC_L2: case REW_JOINT_VEL_L2: case REW_JOINT_POS_LIMITS: case REW_JOINT_POWER:
     case REW_JOINT_DEVIATION_L1: case REW_ACTION_RATE_L2:
@@ -145,10 +170,6 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
         part += ex * ex + ey * ey;
       }
       f = fexp(-part * frcp(R.p[0])) * gate;
-    } break;
-    case REW_HANDSTAND_ORIENTATION_L2: {  // config/others/unitree_a1_handstand/env/rewards.py:50-59
-      const float dx = E.grav_b.x - R.p[0], dy = E.grav_b.y - R.p[1], dz = E.grav_b.z - R.p[2];
-      f = dx * dx + dy * dy + dz * dz;
     } break;
     case REW_BASE_HEIGHT_L2: {  // rewards.py:616-644; the 3 x 3 base ray caster (velocity_env_cfg.py:78-85)
       float tgt = R.p[0];
@@ -565,13 +586,23 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     const float step_dt = ctx.uniform(T.step_dt);
     float* rstage = ctx.rew_stage();
     float mine = 0.f;
+    // slots [0, n_main): any kind; slots [n_main, n_rewards): scalar kinds (the host's schedule, TaskTab::rew_slot)
 #ifdef RL_ABL_NO_REW_TERMS
-    for (int t = li; t < 0; t += LPE) {
+    const int n_main = 0, n_all = 0;
 #else
-    for (int t = li; t < n_rewards; t += LPE) {
+    const int n_main = ctx.uniform_i(T.n_main), n_all = n_rewards;
 #endif
+    for (int sl = li; sl < n_main; sl += LPE) {
+      const int t = T.rew_slot[sl];
       const RewTab& R = T.rew[t];
       const float val = term_value(T, this->u, S.terrain, R, E) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
+      rstage[t] = val;
+      mine += val;
+    }
+    for (int sl = n_main + li; sl < n_all; sl += LPE) {
+      const int t = T.rew_slot[sl];
+      const RewTab& R = T.rew[t];
+      const float val = scalar_term_value(R, E) * R.weight * step_dt;
       rstage[t] = val;
       mine += val;
     }

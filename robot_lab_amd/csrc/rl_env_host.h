@@ -371,12 +371,23 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       default: R.row = -1; break;
     }
     R.joint_mask &= m.num_dof >= 32 ? 0xffffffffu : ((1u << m.num_dof) - 1u);  // the lane that sums a row reads 8 columns per trip
+    for (int q = 0; q < nidx; ++q)  // index lists address the tables directly: validate them here, not in the kernel (and before any shift by them)
+      if (r.idx_a[q] < 0 || r.idx_a[q] >= RL_MAX_BODIES || r.idx_a[q] >= 64 || r.idx_b[q] < 0 || r.idx_b[q] >= RL_MAX_BODIES) return fail("reward term index list out of range");
     if (r.kind == RL_REW_FEET_HEIGHT_BODY || r.kind == RL_REW_FEET_SLIDE || r.kind == RL_REW_FEET_HEIGHT || r.kind == RL_REW_HANDSTAND_FEET_HEIGHT_EXP)
       T.rew_rel_mask |= r.body_mask;
     if (r.kind == RL_REW_FEET_DISTANCE_Y_EXP || r.kind == RL_REW_FEET_DISTANCE_XY_EXP)
       for (int q = 0; q < r.n_idx; ++q) T.rew_rel_mask |= 1ull << r.idx_a[q];
-    for (int q = 0; q < nidx; ++q)  // index lists address the tables directly: validate them here, not in the kernel
-      if (r.idx_a[q] < 0 || r.idx_a[q] >= RL_MAX_BODIES || r.idx_b[q] < 0 || r.idx_b[q] >= RL_MAX_BODIES) return fail("reward term index list out of range");
+  }
+  {  // evaluation schedule (TaskTab::rew_slot): scalar kinds last; whatever does not fit the first 16 slots and is scalar goes to the mini-trip
+    int ns = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int i = 0; i < t.n_rewards; ++i)
+        if (is_scalar_reward_kind(T.rew[i].kind) == (pass == 1)) T.rew_slot[ns++] = i;
+    for (int i = ns; i < MAX_T; ++i) T.rew_slot[i] = 0;
+    int n_scalar = 0;
+    for (int i = 0; i < t.n_rewards; ++i) n_scalar += is_scalar_reward_kind(T.rew[i].kind) ? 1 : 0;
+    const int LPE16 = 16;
+    T.n_main = t.n_rewards <= LPE16 ? t.n_rewards : std::max(LPE16, t.n_rewards - n_scalar);
   }
   T.term_time_out = t.term_time_out; T.term_oob = t.term_out_of_bounds; T.term_illegal = t.term_illegal_contact;
   T.oob_buffer = t.oob_buffer; T.illegal_threshold = t.illegal_threshold; T.illegal_body_mask = t.illegal_body_mask;

@@ -147,7 +147,14 @@ RL_FN SI make_si(float m, V3 c, S3 Ic) {
   return {m, m * c, I};
 }
 
-RL_FN float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// lo <= hi at every call site: on the GPU one v_med3_f32 instead of v_max_f32 + v_min_f32 (same value for non-NaN inputs)
+RL_FN float clampf(float v, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(v, lo, hi);
+#else
+  return fminf(fmaxf(v, lo), hi);
+#endif
+}
 RL_FN float wrap_to_pi(float a) {  // (a + pi) mod 2 pi - pi without fmodf
   const float PI = 3.14159265358979323846f;
   return a - 2.0f * PI * floorf((a + PI) * (0.5f / PI));

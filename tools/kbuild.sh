@@ -7,7 +7,8 @@ mkdir -p $OUT && cd $OUT
 python - <<PY
 import re
 s=open('$OUT/rl_env-hip-amdgcn-amd-amdhsa-gfx950.s').read()
-for m in re.finditer(r'^(_ZN12_GLOBAL__N_110env_kernel[^:\n]*Li0ELi\dEEEvNS1_6KStateEPKv):', s, flags=re.M):
+# the step kernels (RESET = 0): template <Topo, RESET, SUB, WGW>; the last one written to step.s is the four-wavefront-workgroup variant when it exists
+for m in sorted(re.finditer(r'^(_ZN12_GLOBAL__N_110env_kernel[^:\n]*Li0ELi\dELi(\d)EEEvNS1_6KStateEPKvj):', s, flags=re.M), key=lambda m: int(m.group(2))):
     i=m.start(); j=s.index('s_endpgm', i)
     open('$OUT/step.s','w').write(s[i:j+10])
     tail=s[j:j+4000]
