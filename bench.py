@@ -19,8 +19,9 @@ re-executes itself under `torch.distributed.run` with N ranks; with it, a mismat
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch
 (3.4 KB per env-step x 4096 envs) / mean kernel duration measured with HIP events
 on the launch stream; `cpu_baseline` = the same lane program compiled for the host (tests/emu: the source
-hipcc compiles, g++ -O3 -march=native) run by a thread pool over the box's host cores on a bounded sample
-(rank 0, N=1 only), with the fp64 numpy oracle's figure next to it.
+hipcc compiles, g++ -O3 -march=native) as a CPU program - one environment per core, its four lanes as fibers of one
+thread - over all host cores on a bounded sample (rank 0, N=1 only), with the round-2 lane-emulator figure and the fp64
+numpy oracle's next to it.
 """
 from __future__ import annotations
 
@@ -249,10 +250,14 @@ def build_host_port() -> str:
 
 
 def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
-    """Two CPU figures on this box's host cores, same task and env count as the GPU line:
-    (i) `value`: the lane program compiled for the host (kind "port": tests/emu, 4 lane threads per environment in lock
-        step, one team of 4 per 4 host cores, every core busy) - the "tuned CPU" number SURVEY.md 8(d) asks for;
-    (ii) `oracle`: the fp64 numpy oracle (oracle/env.py, single process) on a smaller sample."""
+    """CPU figures on this box's host cores, same task and env count as the GPU line:
+    (i) `value` (kind "port"): the env-step lane program compiled for the host as a CPU PROGRAM - one environment per core, the four
+        lanes of an environment (one per limb) as fibers of ONE thread that hand the core over at every collective
+        (tests/emu/rl_env_emu.cpp FiberSet: no inter-core barrier anywhere), one pinned thread per core, environments dealt round
+        robin - SURVEY.md 8(d)'s "scalar restatement with one env per iteration over all cores";
+    (ii) `lane_emulator`: the same library with a host THREAD per lane and spin barriers between them (what round 2 reported: a
+        test harness, barrier bound, not a tuned CPU path);
+    (iii) `oracle`: the fp64 numpy oracle (oracle/env.py, single process) on a smaller sample."""
     import numpy as np
 
     from oracle.env import OracleEnv
@@ -268,8 +273,8 @@ def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
     D = desc.model.num_dof
     lib = build_host_port()
 
-    def run(teams, steps):
-        """env-steps/s of `teams` teams of 4 pinned lane threads (a fresh pool per setting: a child process)"""
+    def run(teams, steps, fibers):
+        """env-steps/s of `teams` teams (fibers: one pinned thread each; else 4 pinned lane threads each), a fresh pool per setting"""
         code = ("import sys, time, numpy as np\nsys.path.insert(0, %r)\n"
                 "from robot_lab_amd.capi import NativeEnv\nfrom robot_lab_amd.scene import build_world, load_bundle\n"
                 "desc, extra = load_bundle(%r)\nh, to, eo = build_world(desc, extra, %d, 0)\n"
@@ -277,21 +282,24 @@ def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
                 "a = np.random.default_rng(0).uniform(-1, 1, (8, %d, %d)).astype(np.float32)\nnat.step(a[0].ctypes.data)\n"
                 "t0 = time.perf_counter()\nfor s in range(%d): nat.step(a[s %% 8].ctypes.data)\nprint(time.perf_counter() - t0)\n"
                 % (ROOT, task, n_envs, n_envs, lib, n_envs, D, steps))
-        env = dict(os.environ, RL_EMU_TEAMS=str(teams), RL_EMU_PIN="1")
+        env = dict(os.environ, RL_EMU_TEAMS=str(teams), RL_EMU_PIN="1", RL_EMU_FIBERS="1" if fibers else "0")
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         if p.returncode != 0:
             return 0.0, 0.0
         dt = float(p.stdout.strip().splitlines()[-1])
         return n_envs * steps / dt, dt
 
-    # how many teams make the box fastest is not obvious (SMT siblings, memory channels): probe, then measure the best setting
-    probes = {}
-    for teams in sorted({max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}, reverse=True):
-        probes[teams] = run(teams, 2)[0]
+    # (i) one env per core: all cores, or half of them where two hardware threads share a core's FP units - probe, keep the better
+    probes = {t: run(t, 2, True)[0] for t in sorted({cores, max(1, cores // 2)}, reverse=True)}
     teams = max(probes, key=probes.get)
-    steps = int(max(3, min(200, budget_s * probes[teams] / n_envs))) if probes[teams] > 0 else 3
-    port, dt = run(teams, steps)
-    # fp64 numpy oracle, as in round 1 (one process; numpy's own threading aside)
+    steps = int(max(3, min(4000, budget_s * probes[teams] / n_envs))) if probes[teams] > 0 else 3
+    port, dt = run(teams, steps, True)
+    # (ii) the round-2 figure, for continuity: a thread per lane, spin barriers (bounded: a third of the budget)
+    lt = max(1, cores // 4)
+    lprobe = run(lt, 2, False)[0]
+    lsteps = int(max(3, min(100, budget_s / 3 * lprobe / n_envs))) if lprobe > 0 else 3
+    lane_emu, ldt = run(lt, lsteps, False)
+    # (iii) fp64 numpy oracle (one process; numpy's own threading aside)
     h, to, eo = build_world(desc, extra, oracle_envs, 0)
     ora = OracleEnv(desc, h, to, oracle_envs, 42, eo)
     ora.reset()
@@ -301,11 +309,15 @@ def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
     for s in range(oracle_steps):
         ora.step(oa[s + 1])
     odt = time.perf_counter() - t0
-    return {"value": port, "unit": "env-steps/s", "cores": teams * 4, "kind": "port", "per_core": port / (teams * 4),
+    return {"value": port, "unit": "env-steps/s", "cores": teams, "kind": "port", "per_core": port / teams,
             "sample": f"{n_envs} envs x {steps} steps of the same task ({dt:.1f} s): the env-step lane program compiled for the host "
-                      f"(g++ -O3 -march=native), {teams} teams x 4 pinned lane threads (best of the probed team counts "
-                      f"{ {k: round(v) for k, v in probes.items()} } env-steps/s)",
+                      f"(g++ -O3 -march=native), one environment per core - {teams} pinned threads, each running the 4 lanes of its "
+                      f"environment as fibers (no inter-core barriers); probed thread counts "
+                      f"{ {k: round(v) for k, v in probes.items()} } env-steps/s",
             "host_cores_available": cores,
+            "lane_emulator": {"value": lane_emu, "unit": "env-steps/s", "cores": lt * 4, "kind": "lane-emulator", "per_core": lane_emu / (lt * 4),
+                              "sample": f"{n_envs} envs x {lsteps} steps ({ldt:.1f} s): a host thread per lane, {lt} teams x 4 pinned threads, "
+                                        f"spin barriers at every collective (the round-2 baseline: barrier bound)"},
             "oracle": {"value": oracle_envs * oracle_steps / odt, "unit": "env-steps/s", "cores": 1, "kind": "oracle",
                        "sample": f"{oracle_envs} envs x {oracle_steps} steps, fp64 numpy oracle (oracle/env.py), single process"}}
 
