@@ -81,7 +81,23 @@ RL_FN float scalar_term_value(const RewTab& R, const RewEnv& E) {
   return f;
 }
 
-// unweighted value of one term, evaluated by ONE lane
+// The term's descriptor, read from the LDS table image into REGISTERS before the evaluation diverges by kind.  Left to itself the
+// compiler sinks every field's ds_read into the case that uses it: each of the ~16 kinds a wavefront walks through then starts
+// with its own LDS round trip + s_waitcnt lgkmcnt(0) (64 - 128 cycles that a lone wavefront per SIMD cannot hide; the ISA of
+// round 2 had 148 waits in this stage).  The empty asm pins the loaded value where it is.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RL_PIN_REG(x) asm volatile("" : "+v"(x))
+#else
+#define RL_PIN_REG(x) ((void)0)
+#endif
+RL_FN RewTab load_rew_desc(const RewTab& src) {
+  RewTab R = src;
+  RL_PIN_REG(R.kind); RL_PIN_REG(R.weight); RL_PIN_REG(R.p[0]); RL_PIN_REG(R.p[1]); RL_PIN_REG(R.p[2]); RL_PIN_REG(R.p[3]);
+  RL_PIN_REG(R.joint_mask); RL_PIN_REG(R.n_idx); RL_PIN_REG(R.body_mask); RL_PIN_REG(R.idx_off); RL_PIN_REG(R.row);
+  return R;
+}
+
+// unweighted value of one term, evaluated by ONE lane (`R`: a register copy of the descriptor, load_rew_desc)
 template <class TabT>
 RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ terrain, const RewTab& R, const RewEnv& E) {
   const float gate = E.gate, cmd_norm = E.cmd_norm, bv = E.bv, moving = E.moving;
@@ -594,14 +610,14 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #endif
     for (int sl = li; sl < n_main; sl += LPE) {
       const int t = T.rew_slot[sl];
-      const RewTab& R = T.rew[t];
+      const RewTab R = load_rew_desc(T.rew[t]);
       const float val = term_value(T, this->u, S.terrain, R, E) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
       rstage[t] = val;
       mine += val;
     }
     for (int sl = n_main + li; sl < n_all; sl += LPE) {
       const int t = T.rew_slot[sl];
-      const RewTab& R = T.rew[t];
+      const RewTab R = load_rew_desc(T.rew[t]);
       const float val = scalar_term_value(R, E) * R.weight * step_dt;
       rstage[t] = val;
       mine += val;

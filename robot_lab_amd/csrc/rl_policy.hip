@@ -379,9 +379,12 @@ __host__ __device__ inline Split3 split3(float v) {
 // 32-deep block as ONE aligned ds_read_b128 at 16-byte slot (kb * 3 + s) * 64 + lane (conflict-free).
 __device__ inline int lds_index_s(int row, int k, int s) { return (((((k >> 5) * 3 + s) * 4 + ((k >> 3) & 3)) * 16 + row) << 3) + (k & 7); }
 
-template <int TPW, int WAVES>
+// RT 16-row tiles per workgroup (row tile r of an activation buffer starts `tstride` bf16 units behind row tile r - 1): every weight
+// fragment is used for RT row tiles, i.e. 1 / RT of the L2 -> CU weight stream per flop.  DEPTH weight buffers (k blocks in flight).
+template <int TPW, int WAVES, int RT = 1, int DEPTH = 2>
 __device__ inline void layer_s(const MlpParams& P, int l, const uint16_t* __restrict__ xin, uint16_t* __restrict__ xout, float* __restrict__ y, int row0,
-                               int n_rows, int lane, int wave) {  // wave: index of this wavefront's first tile (tiles wave, wave + WAVES, ...)
+                               int n_rows, int lane, int wave, int tstride_in = 0, int tstride_out = 0) {  // wave: this wavefront's first tile (tiles wave, wave + WAVES, ...)
+  static_assert(DEPTH == 2 || DEPTH == 3, "two or three weight buffers");
   const int KB = __builtin_amdgcn_readfirstlane(P.KB32[l]);
   const int NT = __builtin_amdgcn_readfirstlane(P.NTS[l]);
   const int Nl = __builtin_amdgcn_readfirstlane(P.N[l]);
@@ -393,9 +396,11 @@ __device__ inline void layer_s(const MlpParams& P, int l, const uint16_t* __rest
   const uint64_t Wu = uniform_ptr(P.Ws[l]), bu = uniform_ptr(P.b[l]);
   const bool last = l == __builtin_amdgcn_readfirstlane(P.n_layers) - 1;
   // three accumulators per output tile: the leading product, and the five small ones on two chains
-  f32x4 acc[TPW][3];
+  f32x4 acc[RT][TPW][3];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) acc[t][0] = acc[t][1] = acc[t][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[r][t][0] = acc[r][t][1] = acc[r][t][2] = f32x4{0.f, 0.f, 0.f, 0.f};
   typedef const f32x4 __attribute__((address_space(1))) * GlobalV4;
   const uint32_t lane16 = (uint32_t)lane * 16u;
   struct BFrag {
@@ -405,52 +410,74 @@ __device__ inline void layer_s(const MlpParams& P, int l, const uint16_t* __rest
     const int kc = kb < KB ? kb : KB - 1;  // clamped: the tail re-reads the last block instead of branching
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const uint64_t tile = Wu + (uint64_t)(uint32_t)(kc * NT + wave + WAVES * t) * 3072u;  // scalar: 3 KB per (k block, tile)
+      // a wavefront's slot t may lie behind the layer's last tile (odd tile counts): it re-reads the last tile and its result is dropped
+      const int tile_i = wave + WAVES * t < NT ? wave + WAVES * t : NT - 1;
+      const uint64_t tile = Wu + (uint64_t)(uint32_t)(kc * NT + tile_i) * 3072u;  // scalar: 3 KB per (k block, tile)
 #pragma unroll
       for (int s = 0; s < 3; ++s) b[t].p[s] = *(GlobalV4)(uintptr_t)(tile + (uint32_t)(s * 1024) + lane16);
     }
   };
-  BFrag b0[TPW], b1[TPW];
-  load_b(0, b0);
+  BFrag bq[DEPTH][TPW];
+  load_b(0, bq[0]);
+  if (DEPTH == 3) load_b(1, bq[1]);
   float bias_r[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) bias_r[t] = *(const float __attribute__((address_space(1)))*)(uintptr_t)(bu + (uint64_t)(uint32_t)((wave + WAVES * t) * 64) + (uint32_t)((lane & 15) * 4));
-  const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;  // plane s of block kb: + (kb * 3 + s) * 64
-  f32x4 an[3];
-  auto load_a = [&](int kb, f32x4 (&a)[3]) {
+  const f32x4* xa = reinterpret_cast<const f32x4*>(xin) + lane;  // plane s of block kb of row tile r: + (kb * 3 + s) * 64 + r * tstride_in / 8
+  const int ts4 = tstride_in >> 3;
+  f32x4 an[RT][3];
+  auto load_a = [&](int kb, f32x4 (&a)[RT][3]) {
     const int kc = kb < KB ? kb : KB - 1;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) a[s] = xa[(kc * 3 + s) * 64];
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a[r][s] = xa[(kc * 3 + s) * 64 + r * ts4];
   };
   load_a(0, an);
   auto mma = [&](int kb, const BFrag (&b)[TPW]) {
-    bf16x8 a[3];
+    bf16x8 a[RT][3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) a[s] = __builtin_bit_cast(bf16x8, an[s]);
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a[r][s] = __builtin_bit_cast(bf16x8, an[r][s]);
     load_a(kb + 1, an);
-#define RL_MMA(ai, bi, ci) acc[t][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai], __builtin_bit_cast(bf16x8, b[t].p[bi]), acc[t][ci], 0, 0, 0)
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) RL_MMA(0, 0, 0);  // hi hi
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) RL_MMA(0, 1, 1);  // hi mid
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) RL_MMA(1, 0, 2);  // mid hi
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) RL_MMA(1, 1, 1);  // mid mid
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) RL_MMA(0, 2, 2);  // hi lo
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) RL_MMA(2, 0, 1);  // lo hi
+#define RL_MMA(ai, bi, ci) acc[r][t][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[r][ai], __builtin_bit_cast(bf16x8, b[t].p[bi]), acc[r][t][ci], 0, 0, 0)
+#define RL_MMA_ALL(ai, bi, ci)                                  \
+  _Pragma("unroll") for (int t = 0; t < TPW; ++t)               \
+      _Pragma("unroll") for (int r = 0; r < RT; ++r) RL_MMA(ai, bi, ci);
+    RL_MMA_ALL(0, 0, 0)  // hi hi
+    RL_MMA_ALL(0, 1, 1)  // hi mid
+    RL_MMA_ALL(1, 0, 2)  // mid hi
+    RL_MMA_ALL(1, 1, 1)  // mid mid
+    RL_MMA_ALL(0, 2, 2)  // hi lo
+    RL_MMA_ALL(2, 0, 1)  // lo hi
+#undef RL_MMA_ALL
 #undef RL_MMA
   };
   int kb = 0;
-  for (; kb + 2 <= KB; kb += 2) {  // two weight buffers, rotated by unrolling two blocks
-    load_b(kb + 1, b1);
-    mma(kb, b0);
-    load_b(kb + 2, b0);
-    mma(kb + 1, b1);
+  if (DEPTH == 2) {
+    for (; kb + 2 <= KB; kb += 2) {  // two weight buffers, rotated by unrolling two blocks
+      load_b(kb + 1, bq[1]);
+      mma(kb, bq[0]);
+      load_b(kb + 2, bq[0]);
+      mma(kb + 1, bq[1]);
+    }
+    if (kb < KB) mma(kb, bq[0]);
+  } else {
+    constexpr int D2 = DEPTH - 1;  // (= 2: written so that the DEPTH == 2 instantiation indexes inside its array)
+    for (; kb + 3 <= KB; kb += 3) {  // three weight buffers: blocks kb + 1 and kb + 2 in flight while block kb's MFMAs issue
+      load_b(kb + 2, bq[D2]);
+      mma(kb, bq[0]);
+      load_b(kb + 3, bq[0]);
+      mma(kb + 1, bq[1]);
+      load_b(kb + 4, bq[1]);
+      mma(kb + 2, bq[D2]);
+    }
+    if (kb < KB) {
+      mma(kb, bq[0]);
+      if (kb + 1 < KB) mma(kb + 1, bq[1]);
+    }
   }
-  if (kb < KB) mma(kb, b0);
   // epilogue: D[row = (lane >> 4) * 4 + reg][col = lane & 15] -> bias, activation -> the next layer's three planes / global
   const int col = lane & 15, rbase = (lane >> 4) * 4;
   const int act = __builtin_amdgcn_readfirstlane(P.act);
@@ -458,21 +485,26 @@ __device__ inline void layer_s(const MlpParams& P, int l, const uint16_t* __rest
   for (int t = 0; t < TPW; ++t) {
     const int n = (wave + WAVES * t) * 16 + col;
     const float bias = bias_r[t];
-    const bool valid = n < Nl;
+    const bool valid = n < Nl, in_layer = wave + WAVES * t < NT;
     const int o = lds_index_s(rbase, n, 0);  // + 8 r per row, + 512 s per plane
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = ((acc[t][1][r] + acc[t][2][r]) + acc[t][0][r]) + bias;
-      if (!last) {
-        const float av = act == RL_ACT_ELU ? (v > 0.f ? v : __expf(v) - 1.0f) : act == RL_ACT_RELU ? fmaxf(v, 0.f) : tanhf(v);
-        const Split3 sp = split3(valid ? av : 0.f);  // padded columns feed zeros into the next layer
-        xout[o + 8 * r] = sp.h;
-        xout[o + 8 * r + 512] = sp.m;
-        xout[o + 8 * r + 1024] = sp.l;
-      } else if (valid && row0 + rbase + r < n_rows) {
-        y[(size_t)(row0 + rbase + r) * P.out_dim + n] = v;
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ((acc[rt][t][1][r] + acc[rt][t][2][r]) + acc[rt][t][0][r]) + bias;
+        if (!last) {
+          const float av = act == RL_ACT_ELU ? (v > 0.f ? v : __expf(v) - 1.0f) : act == RL_ACT_RELU ? fmaxf(v, 0.f) : tanhf(v);
+          const Split3 sp = split3(valid ? av : 0.f);  // padded columns feed zeros into the next layer
+          if (in_layer) {
+            uint16_t* xo = xout + rt * tstride_out + o + 8 * r;
+            xo[0] = sp.h;
+            xo[512] = sp.m;
+            xo[1024] = sp.l;
+          }
+        } else if (valid && in_layer && row0 + rt * MT + rbase + r < n_rows) {
+          y[(size_t)(row0 + rt * MT + rbase + r) * P.out_dim + n] = v;
+        }
       }
-    }
   }
 }
 
@@ -551,6 +583,79 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_split_kernel(MlpPair q, int n_
   }
 }
 
+// ---- 32 rows of ONE network per workgroup (the rollout size) --------------------------------------------------------------------
+// mlp_split_kernel runs both networks on 16 rows: every CU streams all of both networks' weights (2.8 MB of bf16 planes for the A1
+// pair, 726 MB out of the L2s per call) and pays a pipeline fill / drain / barrier for each of its eight (network, layer) segments -
+// measured, that overhead and the weight stream, not the MFMAs, are what the call costs (44.7 us against 10 us of MFMA issue,
+// profiles/r03b_policy.txt).  Here a workgroup owns 32 rows of one network (even workgroups network A, odd ones network B on the
+// same rows): each weight fragment feeds two row tiles (half the L2 -> CU bytes per flop), a workgroup has four segments instead of
+// eight, each twice as long.  8 wavefronts (2 per SIMD, 256 registers each), two output tiles per wavefront and pass, three
+// weight buffers.  LDS: (widest even-layer input + widest odd-layer input) x 32 rows x three bf16 planes - 147 KB for the A1 critic.
+// The actor's workgroups finish early (0.47x the critic's flops); the call is as long as a critic workgroup.
+template <int WAVES>
+__device__ __forceinline__ void stage_rows_s2(const MlpParams& P, const float* __restrict__ x, uint16_t* __restrict__ dst, int tstride, int row0, int n_rows, int lane, int wave) {
+  // 32 rows over WAVES wavefronts (rows wave, wave + WAVES, ...), all loads of the wavefront in flight before the first LDS write
+  constexpr int JMAX = KMAX / 64, H = 2 * MT / WAVES;
+  const int K0 = P.KB32[0] * 32;
+  float v[H][JMAX];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const int r = wave + WAVES * h;
+    const bool live = row0 + r < n_rows;
+    const float* __restrict__ xr = x + (size_t)(row0 + r) * P.in_dim;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int c = lane + 64 * j;
+      v[h][j] = (64 * j < K0 && live && c < P.in_dim) ? xr[c] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int c = lane + 64 * j, r = wave + WAVES * h;
+      if (64 * j < K0 && c < K0) {
+        const Split3 sp = split3(v[h][j]);
+        uint16_t* d = dst + (r >> 4) * tstride + lds_index_s(r & 15, c, 0);
+        d[0] = sp.h;
+        d[512] = sp.m;
+        d[1024] = sp.l;
+      }
+    }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mlp_split2_kernel(MlpPair q, int n_rows, int cols_a0, int cols_a1, int cols_b0, int cols_b1) {
+  extern __shared__ float4 smem4[];
+  uint16_t* base = reinterpret_cast<uint16_t*>(smem4);
+  const bool two = q.b != nullptr;
+  const bool second = two && (blockIdx.x & 1);
+  const MlpParams& P = *(second ? q.b : q.a);  // workgroup-uniform: scalar loads
+  const float* x = second ? q.xb : q.xa;
+  float* y = second ? q.yb : q.ya;
+  const int c0 = second ? cols_b0 : cols_a0, c1 = second ? cols_b1 : cols_a1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = (two ? (int)(blockIdx.x >> 1) : (int)blockIdx.x) * (2 * MT);
+  // buffer of the even layers' inputs: 2 row tiles of c0 columns; behind it the odd layers': 2 row tiles of c1 columns
+  const int ts0 = c0 * MT * 3, ts1 = c1 * MT * 3;
+  uint16_t* buf0 = base;
+  uint16_t* buf1 = base + 2 * ts0;
+  stage_rows_s2<WAVES>(P, x, buf0, ts0, row0, n_rows, lane, wave);
+  __syncthreads();
+  for (int l = 0; l < P.n_layers; ++l) {
+    const int nt = P.NTS[l];
+    const uint16_t* xin = (l & 1) ? buf1 : buf0;
+    uint16_t* xout = (l & 1) ? buf0 : buf1;
+    const int tsi = (l & 1) ? ts1 : ts0, tso = (l & 1) ? ts0 : ts1;
+    // two tiles per wavefront and pass: tiles first, first + WAVES with first = wave + 2 WAVES pass
+    for (int first = wave; first < nt; first += 2 * WAVES) {
+      if (first + WAVES < nt) layer_s<2, WAVES, 2, 3>(P, l, xin, xout, y, row0, n_rows, lane, first, tsi, tso);
+      else layer_s<1, WAVES, 2, 3>(P, l, xin, xout, y, row0, n_rows, lane, first, tsi, tso);
+    }
+    __syncthreads();
+  }
+}
+
 std::string& err() {
   static thread_local std::string e;
   return e;
@@ -580,7 +685,31 @@ bool split_wanted() {  // (read at every call: the tests switch it inside one pr
 }
 constexpr size_t LDS_MAX = 160 * 1024;
 size_t split_lds_bytes(const rl_mlp* m) { return (size_t)(m->cols[0] + m->cols[1]) * MT * 3 * sizeof(uint16_t); }
+// 32 rows x one network per workgroup (mlp_split2_kernel) once that fills the chip's CUs; RL_MLP_SPLIT_RT=1|2 forces either kernel
+int launch_split2(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* xb, float* yb, int n_rows, void* stream) {
+  const size_t la = 2 * split_lds_bytes(a), lb = b ? 2 * split_lds_bytes(b) : 0, lds = std::max(la, lb);
+  static size_t configured[64] = {};
+  if (lds > configured[a->device & 63]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_split2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail("cannot reserve the LDS of the 32-row split-precision kernel");
+    configured[a->device & 63] = lds;
+  }
+  MlpPair q{a->dP, b ? b->dP : nullptr, xa, xb, ya, yb, nullptr};
+  const int tiles = (n_rows + 2 * MT - 1) / (2 * MT);
+  hipLaunchKernelGGL(mlp_split2_kernel<8>, dim3(b ? 2 * tiles : tiles), dim3(512), lds, (hipStream_t)stream, q, n_rows, a->cols[0], a->cols[1],
+                     b ? b->cols[0] : 0, b ? b->cols[1] : 0);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
+}
 int launch_split(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* xb, float* yb, int n_rows, void* stream) {
+  {
+    const char* e = getenv("RL_MLP_SPLIT_RT");
+    const int forced = e ? atoi(e) : 0;
+    const size_t need2 = 2 * std::max(split_lds_bytes(a), b ? split_lds_bytes(b) : (size_t)0);
+    // from 4096 rows on (128 row tiles x 2 networks = one workgroup per CU; a single network: 8192 rows)
+    const bool big = (size_t)n_rows * (b ? 2 : 1) >= 8192;
+    if (need2 <= LDS_MAX && (forced == 2 || (forced != 1 && big))) return launch_split2(a, xa, ya, b, xb, yb, n_rows, stream);
+  }
   const size_t la = split_lds_bytes(a), lb = b ? split_lds_bytes(b) : 0;
   static size_t configured[64] = {};  // the LDS opt-in belongs to the (kernel, device) pair
   if (la + lb > configured[a->device & 63]) {

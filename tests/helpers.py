@@ -260,3 +260,86 @@ class OracleWithTwin:
         bad = (np.abs(got - want) > atol + rtol * np.abs(want) + self.gain * np.abs(tw - want)) & keep
         assert not bad.any(), (f"{name}: {int(bad.sum())} of {bad.size} entries outside atol {atol} + rtol {rtol} + {self.gain} x twin drift; "
                                f"worst |err| {np.abs(got - want)[bad].max():.3e} where the twin drifted {np.abs(tw - want)[bad].max():.3e}")
+
+
+# ------------------------------------------------------------------------------------------------
+# distributional parity: episode statistics over a long free run (SURVEY.md section 7 "Chaotic divergence")
+# ------------------------------------------------------------------------------------------------
+class EpisodeStats:
+    """Per-ENV time averages over a free run, from what step() returns and from read_state() dicts: the statistics a PPO run
+    is sensitive to.  A free-running fp32 trajectory decorrelates from the fp64 oracle's within tens of steps, so trajectories
+    cannot be compared - but their statistics must agree: a small systematic bias (a wrong sign in a rarely active term, a
+    contact that is slightly too soft, a timer that drifts) hides inside the per-step envelopes and shows up here."""
+
+    def __init__(self, n_envs, n_terms, n_levels):
+        self.N, self.T, self.n_levels, self.steps = n_envs, n_terms, n_levels, 0
+        self.term_sum = np.zeros((n_terms, n_envs))
+        self.reward_sum, self.terminated, self.time_out = np.zeros(n_envs), np.zeros(n_envs), np.zeros(n_envs)
+        self.contacts, self.height, self.speed, self.tilt = np.zeros(n_envs), np.zeros(n_envs), np.zeros(n_envs), np.zeros(n_envs)
+        self.level = np.zeros(n_envs)
+
+    def add(self, reward, reward_terms, terminated, time_out, state):
+        """`state`: read_state() after the step (root_state, contact_timers, env_origin, terrain_level)."""
+        self.steps += 1
+        self.term_sum += np.asarray(reward_terms, dtype=np.float64)[: self.T, : self.N]
+        self.reward_sum += np.asarray(reward, dtype=np.float64)
+        self.terminated += np.asarray(terminated, dtype=np.float64)
+        self.time_out += np.asarray(time_out, dtype=np.float64)
+        rs = np.asarray(state["root_state"], dtype=np.float64)
+        self.contacts += (np.asarray(state["contact_timers"])[:, :, 1] > 0).sum(axis=1)       # bodies in contact (current contact time > 0)
+        self.height += rs[:, 2] - np.asarray(state["env_origin"], dtype=np.float64)[:, 2]  # root height above the tile's origin
+        self.speed += np.linalg.norm(rs[:, 7:10], axis=1)
+        w, x, y, z = rs[:, 3], rs[:, 4], rs[:, 5], rs[:, 6]
+        self.tilt += 1.0 - (1.0 - 2.0 * (x * x + y * y))                                       # 1 - cos(angle between body z and world z)
+        self.level = np.asarray(state["terrain_level"], dtype=np.float64)                    # the last one: where the curriculum left the env
+
+    def per_env(self):
+        """dict name -> [N] per-env time averages (terrain level: the final one)."""
+        s = float(self.steps)
+        out = {f"term_{t}": self.term_sum[t] / s for t in range(self.T)}
+        out.update(reward=self.reward_sum / s, terminated=self.terminated / s, time_out=self.time_out / s, contacts=self.contacts / s,
+                   height=self.height / s, speed=self.speed / s, tilt=self.tilt / s, level=self.level)
+        return out
+
+
+def staggered_episode_lengths(n_envs, max_episode_length):
+    """Episode counters spread over [0, max_episode_length) (what rsl_rl's `init_at_random_ep_len` does, train.py:224): within a
+    300-step run ~30 % of the envs time out, so resets - curriculum moves, event draws, command resampling - are in the statistics."""
+    return (np.arange(n_envs, dtype=np.int64) * 37 + 11) % int(max_episode_length)
+
+
+def run_episode_stats(step_fn, read_state_fn, n_envs, n_terms, n_levels, action_dim, steps, action_seed):
+    """Drives `step_fn(action [N, A] float32) -> (reward, reward_terms, terminated, time_out)` for `steps` steps with the action
+    stream numpy default_rng(action_seed).uniform(-1, 1) - the stream both sides and the committed fixture share."""
+    rng = np.random.default_rng(action_seed)
+    st = EpisodeStats(n_envs, n_terms, n_levels)
+    for _ in range(steps):
+        a = rng.uniform(-1, 1, (n_envs, action_dim)).astype(np.float32)
+        st.add(*step_fn(a), read_state_fn())
+    return st.per_env()
+
+
+def compare_episode_stats(got, ora, twin, k_sigma=4.0, boot=400, seed=0, weights=None):
+    """`got`, `ora`, `twin`: per_env() dicts of the tested side, the fp64 oracle and its fp32-disturbed twin over the SAME envs, seeds
+    and action stream.  For every statistic: |mean(got) - mean(ora)| must lie inside k_sigma standard deviations of the
+    oracle-vs-twin difference of means, estimated by a paired bootstrap over the envs (plus that difference itself: the twin is one
+    legitimate realisation, the tested side another) and an absolute floor for statistics that are constant across the batch.
+    Returns the report; raises AssertionError naming the statistics outside their interval."""
+    rng = np.random.default_rng(seed)
+    N = len(ora["reward"])
+    idx = rng.integers(0, N, (boot, N))
+    report, bad = {}, []
+    for name in ora:
+        a, b, g = np.asarray(ora[name]), np.asarray(twin[name]), np.asarray(got[name])
+        d = b - a
+        sigma = d[idx].mean(axis=1).std()
+        # the tested side's own sampling noise against the oracle (paired), in case the twin happens to track the oracle closely
+        sigma = max(sigma, (g - a)[idx].mean(axis=1).std())
+        floor = 1e-6 + 1e-4 * max(abs(a.mean()), abs(b.mean()))
+        tol = abs(d.mean()) + k_sigma * sigma + floor
+        diff = g.mean() - a.mean()
+        report[name] = dict(oracle=float(a.mean()), twin=float(b.mean()), got=float(g.mean()), diff=float(diff), tol=float(tol), sigma=float(sigma))
+        if abs(diff) > tol:
+            bad.append((name, float(diff), float(tol)))
+    assert not bad, f"episode statistics outside the oracle-vs-twin interval: {bad}\n{report}"
+    return report

@@ -30,6 +30,7 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Flat-Unitree-B2W-v0",
     "RobotLab-Isaac-Velocity-Rough-MagicLab-Dog-W-v0",
     "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-v0",
+    "RobotLab-Isaac-Velocity-Rough-Agibot-D1-v0",  # registers since the shims carry a `cusrl` stand-in (agibot_d1/agents/__init__.py:4)
 ]
 
 

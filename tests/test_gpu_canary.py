@@ -66,8 +66,10 @@ def test_interval_timers_tick_by_exactly_step_dt(task, merge, wg, sub, monkeypat
         monkeypatch.setenv("RL_ENV_SUB", sub)
     if merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
-    if sub == "1" and "G1" in task:  # 16 envs per wavefront x the 310-column critic row of G1 Rough exceed the LDS of a CU: the Flat id
-        task = task.replace("Rough", "Flat")
+    if sub == "1" and "G1" in task:
+        # the trunk + limbs instance keeps its kinematics / link records in limb-shared LDS words: with one lane per limb (64 limbs per
+        # wavefront) that is 115 KB + 30 KB of sensor rows - it exists on the CPU lane emulator only, rl_env_create refuses it on the GPU
+        pytest.skip("the one-lane-per-limb mapping of the trunk + limbs instance does not fit the LDS of a CU (CPU emulator only)")
     env = ManagerBasedRLEnv(task, num_envs=256, seed=3, device="cuda:0")
     assert timers_tick_exactly(env, torch) > 256
     env.close()

@@ -41,6 +41,7 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Rough-Unitree-B2W-v0",
     "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-W-v0",
     "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-v0",
+    "RobotLab-Isaac-Velocity-Rough-Agibot-D1-v0",
 ]
 
 

@@ -152,3 +152,32 @@ def test_hip_mlp_pair_is_bitwise_the_two_single_launches(N, da, dc, prec, monkey
     np.testing.assert_allclose(pc.cpu().numpy(), mlp_forward(xc.cpu().numpy(), wc, bc, "elu"), rtol=2e-5, atol=2e-5)
     actor.close()
     critic.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rt", ["1", "2"])
+@pytest.mark.parametrize("N,da,dc", [(37, [45, 512, 256, 128, 12], [235, 512, 256, 128, 1]), (4099, [45, 512, 256, 128, 12], [235, 512, 256, 128, 1]),
+                                     (1000, [96, 400, 200, 29], [310, 512, 136, 1])])
+def test_split_kernels_agree_bitwise(N, da, dc, rt, monkeypatch):
+    """The two kernels of the split-bf16 path - 16 rows x both networks per workgroup (RL_MLP_SPLIT_RT=1) and 32 rows x one network
+    per workgroup (RL_MLP_SPLIT_RT=2, what a 4096-row rollout step launches) - run the same per-tile MFMA chains: forced onto every
+    shape (ragged row counts, odd widths), each gives the bits of the default single launches and stays inside the oracle tolerance."""
+    import torch
+
+    from robot_lab_amd.policy import MlpPolicy
+
+    wa, ba = _net(da, 15)
+    wc, bc = _net(dc, 16)
+    actor, critic = MlpPolicy(wa, ba, "elu", device="cuda:0"), MlpPolicy(wc, bc, "elu", device="cuda:0")
+    rng = np.random.default_rng(17)
+    xo = torch.from_numpy(rng.uniform(-2, 2, (N, da[0])).astype(np.float32)).cuda()
+    xc = torch.from_numpy(rng.uniform(-2, 2, (N, dc[0])).astype(np.float32)).cuda()
+    ya, yc = actor(xo).clone(), critic(xc).clone()  # default dispatch
+    monkeypatch.setenv("RL_MLP_SPLIT_RT", rt)
+    pa, pc = actor.forward_pair(xo, critic, xc)
+    sa = actor(xo).clone()
+    assert torch.equal(pa, ya) and torch.equal(pc, yc) and torch.equal(sa, ya)
+    np.testing.assert_allclose(pa.cpu().numpy(), mlp_forward(xo.cpu().numpy(), wa, ba, "elu"), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(pc.cpu().numpy(), mlp_forward(xc.cpu().numpy(), wc, bc, "elu"), rtol=2e-5, atol=2e-5)
+    actor.close()
+    critic.close()

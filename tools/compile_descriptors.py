@@ -25,7 +25,7 @@ from robot_lab_amd.scene import DATA_DIR, save_bundle  # noqa: E402
 # ... MagicLab Z1 (14 DoF, hip joints listed out of tree order), DDT Tita (2 wheeled legs, 2 empty limbs)
 ROBOTS = ("Unitree-A1", "Unitree-Go2", "Unitree-Go2W", "Unitree-G1", "Unitree-B2", "Deeprobotics-Lite3", "Deeprobotics-M20",
           "Zsibot-ZSL1", "Zsibot-ZSL1W", "RoboParty-ATOM01", "RobotEra-Xbot", "MagicLab-Bot-Gen1", "Openloong-Loong",
-          "Unitree-B2W", "MagicLab-Dog-W", "MagicLab-Dog", "MagicLab-Bot-Z1", "DDTRobot-Tita", "HandStand-Unitree-A1")
+          "Unitree-B2W", "MagicLab-Dog-W", "MagicLab-Dog", "MagicLab-Bot-Z1", "DDTRobot-Tita", "HandStand-Unitree-A1", "Agibot-D1")
 # not compiled: Unitree-H1 (asset lives in isaaclab_assets, not in the reference), Booster-T1 (5 limbs: head + arms + legs),
 # FFTAI GR1T1/T2 (more links than the descriptor holds), MagicLab-Dog Rough (its registration names a class that does not exist)
 TASKS = sys.argv[1:] or [f"RobotLab-Isaac-Velocity-{t}-{r}-v0" for r in ROBOTS for t in ("Flat", "Rough")]
