@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Throughput of the env-step kernel vs environments per GPU (A1 Rough): where the chip fills.
-    python tools/sweep_envs.py [task]"""
+    python tools/sweep_envs.py [task] [N1,N2,...]      (RL_ENV_SUB=1 selects the one-lane-per-limb mapping for the whole sweep)"""
 import os
 import sys
 
@@ -11,7 +11,8 @@ from robot_lab_amd.env import ManagerBasedRLEnv  # noqa: E402
 
 task = sys.argv[1] if len(sys.argv) > 1 else "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
 print(f"{task}\n{'envs':>8} {'us/step':>10} {'M env-steps/s':>14}")
-for N in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+SIZES = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536)
+for N in SIZES:
     env = ManagerBasedRLEnv(task, num_envs=N, seed=42, device="cuda:0")
     env.reset()
     A = env.num_actions
