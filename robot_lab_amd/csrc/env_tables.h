@@ -286,6 +286,10 @@ RL_FN void apply_cmd_levels(float* lv, const CmdLevelParams& P) {
   lv[CL_SUM_LIN] = lv[CL_CNT_LIN] = lv[CL_SUM_ANG] = lv[CL_CNT_ANG] = 0.f;
 }
 
+// what a launch of the env kernels runs (KState::mode): a whole step, the reset entry, or one half of a step that is split around
+// the decision of the command_levels_* curricula (env_terms.h step_head / step_tail)
+enum KMode { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_STEP_HEAD = 2, KMODE_STEP_TAIL = 3 };
+
 struct KState {
   int32_t N;      // environments the caller sees
   int32_t Npad;   // simulated (multiple of ENVS_PER_WAVE)
@@ -321,6 +325,7 @@ struct KState {
   const uint32_t* step_base;       // the step count of a launch = *step_base + step_counter (hipGraph replays advance the device word, rl_env_graph_*)
   uint32_t step_counter;
   uint32_t table_bytes;  // bytes of the packed table image the env kernels stage into LDS (multiple of 16)
+  int32_t mode;          // KMode
 };
 
 }  // namespace rl

@@ -81,11 +81,12 @@ RL_FN float scalar_term_value(const RewTab& R, const RewEnv& E) {
   return f;
 }
 
-// The term's descriptor, read from the LDS table image into REGISTERS before the evaluation diverges by kind.  Left to itself the
-// compiler sinks every field's ds_read into the case that uses it: each of the ~16 kinds a wavefront walks through then starts
-// with its own LDS round trip + s_waitcnt lgkmcnt(0) (64 - 128 cycles that a lone wavefront per SIMD cannot hide; the ISA of
-// round 2 had 148 waits in this stage).  The empty asm pins the loaded value where it is.
-#if defined(__HIP_DEVICE_COMPILE__)
+// The term's descriptor.  -DRL_PIN_DESC reads it from the LDS table image into REGISTERS before the evaluation diverges by kind (left
+// to itself the compiler sinks every field's ds_read into the case that uses it: each of the ~16 kinds a wavefront walks through
+// then starts with its own LDS round trip + s_waitcnt).  NOT the default: measured 42.85 vs 42.93 us on A1 Rough 4096 (noise), and
+// the eleven pinned registers at the kernel's pressure peak were enough to bring the reload-under-a-narrowed-EXEC miscompile
+// back on the four-wavefront 3-joint variant (profiles/r03d_pin_desc_miscompile.txt: commands / heading flags of ~1 % of the envs).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RL_PIN_DESC)
 #define RL_PIN_REG(x) asm volatile("" : "+v"(x))
 #else
 #define RL_PIN_REG(x) ((void)0)
@@ -466,14 +467,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       vang = {vs[3], vs[4], vs[5]};
     }
     // manager resets: episode-sum log + zero, command metrics log + resample, interval timer
-    // command_levels_* curricula: a step whose counter is a multiple of the episode length collects the episode sums of the
-    // driving reward terms over the envs it resets (the decision is taken behind the launch, rl_env_host.h step())
-    const bool levels = log_episode && e < S.N && (T.cur_lin || T.cur_ang) && S.step_counter % (uint32_t)T.max_episode_length == 0u;
+    // (command_levels_* curricula: the live ranges read by resample_command were decided between the two launches of this step,
+    // from the sums collect_cmd_levels gathered in the first one - step_head)
     for (int t = li; t < T.n_rewards; t += LPE) {
       float* p = S.ep_sums + (size_t)t * Np + e;
       if (log_episode && e < S.N) ctx.atomic_add(log_slot() + LOG_EP_SUM0 + t, *p);
-      if (levels && T.cur_lin && t == T.cur_lin_term) { ctx.atomic_add(S.cmd_levels + CL_SUM_LIN, *p); ctx.atomic_add(S.cmd_levels + CL_CNT_LIN, 1.f); }
-      if (levels && T.cur_ang && t == T.cur_ang_term) { ctx.atomic_add(S.cmd_levels + CL_SUM_ANG, *p); ctx.atomic_add(S.cmd_levels + CL_CNT_ANG, 1.f); }
       *p = 0.f;
     }
     if (li == 0 && log_episode && e < S.N) {
@@ -814,8 +812,62 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // slot is what the reference rebuilds as extras["log"] on every call - no snapshot + memset between steps on the host
   RL_FN float* log_slot() const { return S.log + (S.step_counter & (uint32_t)(LOG_RING - 1)) * LOG_SIZE; }
 
+  // command_levels_lin_vel / _ang_vel (VEL/mdp/curriculums.py:21-94) decide on the mean episode sum of a driving reward term over
+  // the envs that the deciding step (count % max_episode_length == 0) resets - a reduction over the whole launch that the reference
+  // takes FIRST inside _reset_idx, so the commands those very resets draw, and the heading clip of that step, already see the
+  // widened range.  Envs with these curricula therefore step in TWO launches (rl_env_host.h step()): step_head() - everything up
+  // to the rewards, this collection, state written back -, the one-thread decision (apply_cmd_levels), then step_tail() from the
+  // re-loaded state: resets, commands, push, observations.  Tasks without the curricula (every shipped cfg deletes the terms,
+  // unitree_a1/rough_env_cfg.py:158-159) run step(): one launch.
+  RL_FN void collect_cmd_levels(bool done) {
+    if (!(T.cur_lin || T.cur_ang) || !done || e >= S.N || S.step_counter % (uint32_t)T.max_episode_length != 0u) return;
+    for (int t = li; t < T.n_rewards; t += LPE) {
+      const float v = S.ep_sums[(size_t)t * Np + e];
+      if (T.cur_lin && t == T.cur_lin_term) { ctx.atomic_add(S.cmd_levels + CL_SUM_LIN, v); ctx.atomic_add(S.cmd_levels + CL_CNT_LIN, 1.f); }
+      if (T.cur_ang && t == T.cur_ang_term) { ctx.atomic_add(S.cmd_levels + CL_SUM_ANG, v); ctx.atomic_add(S.cmd_levels + CL_CNT_ANG, 1.f); }
+    }
+  }
+  // inspection views as a reader sees them after step(): zeroed by the reset of a done env (`live` = 0)
+  RL_FN void write_dbg_views(float live) {
+    if (S.dbg_torque == nullptr) return;
+    if (sub == 0)
+#pragma unroll
+      for (int j = 0; j < JX; ++j) {
+        if (NW > 0 && !L.joint_own[j]) continue;
+        S.dbg_torque[(size_t)e * T.D + L.joint_id[j]] = live * tau_app[j];
+        S.dbg_acc[(size_t)e * T.D + L.joint_id[j]] = live * qacc[j];
+      }
+#pragma unroll
+    for (int s = 0; s < NBS; ++s) {
+      int b = L.slot_body[s];
+      if (b >= 0 && (s != 0 || L.owns_base_body) && this->owns_slot(s)) {
+        float* o = S.dbg_cforce + ((size_t)e * T.n_bodies + b) * 3;
+        o[0] = live * cf[s][0]; o[1] = live * cf[s][1]; o[2] = live * cf[s][2];
+      }
+    }
+  }
+  RL_FN bool out_of_bounds() const {  // terrain_out_of_bounds (velocity_env_cfg.py:655-659)
+    if (!T.term_oob || T.is_plane) return false;
+    const float mw = (float)T.num_rows * T.tile_size + 2.f * T.border, mh = (float)T.num_cols * T.tile_size + 2.f * T.border;
+    return fabsf(pos.x) > 0.5f * mw - T.oob_buffer || fabsf(pos.y) > 0.5f * mh - T.oob_buffer;
+  }
+
   // ---------------------------------------------------------------- step()
-  RL_FN void step() {
+  RL_FN void step() { step_front<false>(); }
+  RL_FN void step_head() { step_front<true>(); }
+  // second launch of a split step: the state step_head() wrote back, its termination flags, then stages 6 - 9
+  RL_FN void step_tail() {
+    this->load();
+    load_task();
+    derive();
+    const bool terminated = S.terminated[e] != 0, time_out = S.time_out[e] != 0;
+    const bool t_oob = out_of_bounds();
+    const bool t_timeout = T.term_time_out && ep_len >= (long long)T.max_episode_length;  // (step_head counted this step already)
+    step_back<true>(terminated, time_out, t_timeout, t_oob, terminated);
+  }
+
+  template <bool HEAD>
+  RL_FN void step_front() {
     {  // episode-log ring upkeep by the lanes of env 0 (nobody else touches these two slots during this launch)
       // (a) the previous step's slot is final now: if that step reset nobody, it inherits its predecessor, so that every
       //     slot reads as "the log of the most recent step that reset an env" - what a caller of the reference sees, which
@@ -869,11 +921,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 
     // 4 terminations (velocity_env_cfg.py:648-664)
     bool t_timeout = T.term_time_out && ep_len >= (long long)T.max_episode_length;
-    bool t_oob = false;
-    if (T.term_oob && !T.is_plane) {
-      float mw = (float)T.num_rows * T.tile_size + 2.f * T.border, mh = (float)T.num_cols * T.tile_size + 2.f * T.border;
-      t_oob = fabsf(pos.x) > 0.5f * mw - T.oob_buffer || fabsf(pos.y) > 0.5f * mh - T.oob_buffer;
-    }
+    const bool t_oob = out_of_bounds();
     bool t_illegal = false;
     if (T.term_illegal) {
       float c = 0.f;
@@ -900,6 +948,18 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         S.ro_dones[e] = (terminated || time_out) ? 1 : 0;
       }
     }
+    if constexpr (HEAD) {  // first launch of a split step: the decision's inputs, the views, the state; step_tail() goes on from here
+      collect_cmd_levels(terminated || time_out);
+      write_dbg_views((terminated || time_out) ? 0.f : 1.f);
+      this->store();
+      store_task();
+    } else {
+      step_back<false>(terminated, time_out, t_timeout, t_oob, t_illegal);
+    }
+  }
+
+  template <bool TAIL>
+  RL_FN void step_back(const bool terminated, const bool time_out, const bool t_timeout, const bool t_oob, const bool t_illegal) {
     // 6 reset done envs
     if (terminated || time_out) {
       if (li == 0 && e < S.N) {
@@ -910,24 +970,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       reset_env(true);
       derive();
     }
-    if (S.dbg_torque != nullptr) {  // inspection views as a reader sees them after step(): zeroed by the reset of a done env
-      const float live = (terminated || time_out) ? 0.f : 1.f;
-      if (sub == 0)
-#pragma unroll
-        for (int j = 0; j < JX; ++j) {
-          if (NW > 0 && !L.joint_own[j]) continue;
-          S.dbg_torque[(size_t)e * T.D + L.joint_id[j]] = live * tau_app[j];
-          S.dbg_acc[(size_t)e * T.D + L.joint_id[j]] = live * qacc[j];
-        }
-#pragma unroll
-      for (int s = 0; s < NBS; ++s) {
-        int b = L.slot_body[s];
-        if (b >= 0 && (s != 0 || L.owns_base_body) && this->owns_slot(s)) {
-          float* o = S.dbg_cforce + ((size_t)e * T.n_bodies + b) * 3;
-          o[0] = cf[s][0]; o[1] = cf[s][1]; o[2] = cf[s][2];
-        }
-      }
-    }
+    if constexpr (!TAIL) write_dbg_views((terminated || time_out) ? 0.f : 1.f);  // (a split step wrote them in its first launch)
     // 7 CommandManager.compute [UPSTREAM B7]
     {
       const float inv_max_step = T.step_dt * frcp(T.cmd_resample[1]);
@@ -970,13 +1013,17 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // 9 observations
     RL_PHASE(20, "observations");
 #ifndef RL_ABL_NO_OBS
-    observations(!ctx.any(terminated || time_out));
+    observations(!TAIL && !ctx.any(terminated || time_out));  // (a tail launch starts without the chain words of the trunk + limbs instance)
 #endif
     RL_PHASE(24, "end");
   }
 
   // ---------------------------------------------------------------- reset() entry: reset masked envs, recompute obs
   RL_FN void reset_entry() {
+    if (S.mode == KMODE_STEP_TAIL) {  // (rides in the reset kernels: neither is on the hot path, and the step kernels stay as they are)
+      step_tail();
+      return;
+    }
     this->load();
     load_task();
 #pragma unroll

@@ -226,8 +226,10 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   ctx.fstage = ctx.stage[1] + s1w;
   ctx.lane = lane;
   EnvProgram<Ctx, TP> prog(ctx, S);
-  if (RESET)
-    prog.reset_entry();
+  if (RESET == 1)
+    prog.reset_entry();  // (KMODE_RESET, and KMODE_STEP_TAIL: the second launch of a step split around the command-range decision)
+  else if (RESET == 2)
+    prog.step_head();    // KMODE_STEP_HEAD: the first launch of such a step
   else
     prog.step();
 }
@@ -285,7 +287,7 @@ struct Backend {
     return 16 / sub;
   }
   template <class TP, int SUB, int WGW>
-  int launch_w(const KState& S, const void* T, int reset, size_t lds1, hipStream_t st) {  // lds1: LDS bytes with one wavefront per workgroup
+  int launch_w(const KState& S, const void* T, size_t lds1, hipStream_t st) {  // lds1: LDS bytes with one wavefront per workgroup; S.mode picks the kernel
     const int tiles = S.Npad / (16 / SUB);
     dim3 grid((tiles + WGW - 1) / WGW), block(64 * WGW);
     const uint32_t wave_words = (uint32_t)((lds1 - S.table_bytes) >> 2);
@@ -300,25 +302,31 @@ struct Backend {
       if (lds > have) {
         if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 1, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
         if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 0, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
+        if constexpr (WGW == 1)
+          if (check(hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 2, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))) return -1;
         have = lds;
       }
     }
-    if (reset)
+    if (S.mode == KMODE_RESET || S.mode == KMODE_STEP_TAIL)
       hipLaunchKernelGGL((env_kernel<TP, 1, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
-    else
+    else if (S.mode == KMODE_STEP_HEAD) {
+      if constexpr (WGW == 1) hipLaunchKernelGGL((env_kernel<TP, 2, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
+    } else
       hipLaunchKernelGGL((env_kernel<TP, 0, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
     return check(hipGetLastError());
   }
   int wg_waves = 4;  // RL_ENV_WG=1: single-wavefront workgroups always
   bool wg_force = false;
   template <class TP, int SUB>
-  int launch_cl(const KState& S, const void* T, int reset, size_t lds1, hipStream_t st) {
+  int launch_cl(const KState& S, const void* T, size_t lds1, hipStream_t st) {
     if constexpr (TP::NW == 0 && SUB == 4) {  // (the trunk + limbs instance gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup)
       const int tiles = S.Npad / (16 / SUB);
       const size_t lds4 = S.table_bytes + 4 * (lds1 - S.table_bytes);
-      if (wg_waves == 4 && (tiles >= 4 * n_cu || wg_force) && lds4 <= 160 * 1024) return launch_w<TP, SUB, 4>(S, T, reset, lds1, st);
+      // (the two launches of a split step - command-range curricula, no shipped cfg - use the single-wavefront workgroups: half the kernels to build)
+      if (wg_waves == 4 && (tiles >= 4 * n_cu || wg_force) && lds4 <= 160 * 1024 && S.mode != KMODE_STEP_HEAD && S.mode != KMODE_STEP_TAIL)
+        return launch_w<TP, SUB, 4>(S, T, lds1, st);
     }
-    return launch_w<TP, SUB, 1>(S, T, reset, lds1, st);
+    return launch_w<TP, SUB, 1>(S, T, lds1, st);
   }
   size_t lds_bytes = 0;
   // dynamic LDS of an instance: the SAME layout arithmetic as env_kernel (tables | lane scratchpad | limb-shared words | per-env
@@ -350,7 +358,9 @@ struct Backend {
       case 44: lds_bytes = lds_need<TopoQuad4, 4>(T); break;
       case 1041: lds_bytes = lds_need<TopoQuad4M, 1>(T); break;
       case 1044: lds_bytes = lds_need<TopoQuad4M, 4>(T); break;
-      case 71: lds_bytes = lds_need<TopoG1, 1>(T); break;
+      case 71:  // 64 limbs per wavefront: 115 KB of limb-shared words + 30 KB of sensor rows.  The CPU lane emulator runs it (tests/emu); no kernel is built for it
+        err = "the one-lane-per-limb mapping (RL_ENV_SUB=1) of the trunk + limbs instance needs more LDS than a CU has";
+        return -1;
       case 74: lds_bytes = lds_need<TopoG1, 4>(T); break;
       default: err = "no lane-program instance for chain length " + std::to_string(T.CL); return -1;
     }
@@ -360,7 +370,7 @@ struct Backend {
     }
     return 0;
   }
-  int launch(const KState& S, const void* T, int CL, int reset, void* stream) {  // CL: chain length, + 100 for a merged instance
+  int launch(const KState& S, const void* T, int CL, void* stream) {  // CL: chain length, + 100 for a merged instance; S.mode: what to run
     hipStream_t st = (hipStream_t)stream;
     // RL_ENV_ONLY=<CL * 10 + SUB> (e.g. 34; 1044: merged): build that one instance only - kernel experiments compile in 15 s instead of 80
 #ifndef RL_ENV_ONLY
@@ -368,28 +378,25 @@ struct Backend {
 #endif
     switch (CL * 10 + sub) {
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 31
-      case 31: return launch_cl<TopoQuad3, 1>(S, T, reset, lds_bytes, st);
+      case 31: return launch_cl<TopoQuad3, 1>(S, T, lds_bytes, st);
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 41
-      case 41: return launch_cl<TopoQuad4, 1>(S, T, reset, lds_bytes, st);
+      case 41: return launch_cl<TopoQuad4, 1>(S, T, lds_bytes, st);
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 34
-      case 34: return launch_cl<TopoQuad3, 4>(S, T, reset, lds_bytes, st);
+      case 34: return launch_cl<TopoQuad3, 4>(S, T, lds_bytes, st);
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 44
-      case 44: return launch_cl<TopoQuad4, 4>(S, T, reset, lds_bytes, st);
+      case 44: return launch_cl<TopoQuad4, 4>(S, T, lds_bytes, st);
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 1041
-      case 1041: return launch_cl<TopoQuad4M, 1>(S, T, reset, lds_bytes, st);
+      case 1041: return launch_cl<TopoQuad4M, 1>(S, T, lds_bytes, st);
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 1044
-      case 1044: return launch_cl<TopoQuad4M, 4>(S, T, reset, lds_bytes, st);
-#endif
-#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 71
-      case 71: return launch_cl<TopoG1, 1>(S, T, reset, lds_bytes, st);
+      case 1044: return launch_cl<TopoQuad4M, 4>(S, T, lds_bytes, st);
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 74
-      case 74: return launch_cl<TopoG1, 4>(S, T, reset, lds_bytes, st);
+      case 74: return launch_cl<TopoG1, 4>(S, T, lds_bytes, st);
 #endif
       default: err = "this build does not carry the lane-program instance for chain length " + std::to_string(CL) + " / " + std::to_string(sub) + " lanes per limb"; return -1;
     }

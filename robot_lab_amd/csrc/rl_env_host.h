@@ -703,7 +703,8 @@ struct EnvImpl {
       s.reset_mask = reset_mask;
     }
     flip_obs(s);
-    return be.launch(s, packed_dev, inst, /*reset=*/1, stream) ? fail("launch failed: " + be.error()) : 0;
+    s.mode = KMODE_RESET;
+    return be.launch(s, packed_dev, inst, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 
   int step(const float* action_dev, void* stream, const float* ro_values = nullptr, float* ro_rewards = nullptr, uint8_t* ro_dones = nullptr,
@@ -716,14 +717,22 @@ struct EnvImpl {
     flip_obs(s);
     s.action_in = action_dev;
     s.ro_values = ro_values; s.ro_rewards = ro_rewards; s.ro_dones = ro_dones; s.ro_gamma = ro_gamma;
-    if (be.launch(s, packed_dev, inst, /*reset=*/0, stream)) return fail("launch failed: " + be.error());
-    // command_levels_* curricula: the decision of a step whose counter is a multiple of the episode length needs the episode
-    // sums of every env reset in it - one more (single-thread) launch behind that step, once per episode length
-    // (the launch tests the step count itself: it sits in captured graphs, too)
-    if (tables.cur_lin || tables.cur_ang)
-      if (be.launch_cmd_levels(S.cmd_levels, cmd_level_params, S.step_base, step_counter - anchor, (uint32_t)tables.max_episode_length, stream))
-        return fail("launch failed: " + be.error());
-    return 0;
+    if (!(tables.cur_lin || tables.cur_ang)) {
+      s.mode = KMODE_STEP;
+      return be.launch(s, packed_dev, inst, stream) ? fail("launch failed: " + be.error()) : 0;
+    }
+    // command_levels_* curricula (VEL/mdp/curriculums.py:21-94): the decision of a step whose counter is a multiple of the episode
+    // length is a reduction over every env that step resets, and the reference takes it FIRST inside _reset_idx - the commands those
+    // resets draw and that step's heading clip already see the widened range.  So such an env steps in three launches: the step up
+    // to the rewards (collects the decision's inputs, writes the state back), the one-thread decision (it tests the step count
+    // itself: it sits in captured graphs, too), and the rest of the step - resets, commands, push, observations - from the
+    // re-loaded state (env_terms.h step_head / step_tail).  Every shipped cfg deletes these terms: one launch, above.
+    s.mode = KMODE_STEP_HEAD;
+    if (be.launch(s, packed_dev, inst, stream)) return fail("launch failed: " + be.error());
+    if (be.launch_cmd_levels(S.cmd_levels, cmd_level_params, S.step_base, step_counter - anchor, (uint32_t)tables.max_episode_length, stream))
+      return fail("launch failed: " + be.error());
+    s.mode = KMODE_STEP_TAIL;
+    return be.launch(s, packed_dev, inst, stream) ? fail("launch failed: " + be.error()) : 0;
   }
 
   // include/rl_env.h "hipGraph capture of a loop around rl_env_step"

@@ -86,12 +86,12 @@ class _LazyLog(dict):
             return
         e = self._env
         # the kernel logs step k into ring slot k % RL_LOG_RING and clears the slot of step k + 1 (include/rl_env.h):
-        # this step's numbers are on the device, untouched, until RL_LOG_RING - 2 further steps have been launched.  The env
-        # materialises a log that is still referenced just before that happens (ManagerBasedRLEnv._retire_logs), so this only
-        # fires for a log that was detached from its env
-        if e.common_step_counter - self._step > RL_LOG_RING - 2:
+        # this step's slot is untouched until RL_LOG_RING - 2 further steps have been launched, its PREDECESSOR's slot (read when
+        # this step reset nobody) one step less: step k + RL_LOG_RING - 2 clears slot k - 1.  The env materialises a log that is
+        # still referenced before that happens (ManagerBasedRLEnv._retire_logs), so this only fires for a log detached from its env
+        if e.common_step_counter - self._step > RL_LOG_RING - 3:
             raise RuntimeError(f'extras["log"] of step {self._step} was read {e.common_step_counter - self._step} steps later: '
-                               f"the device keeps the last {RL_LOG_RING - 2} steps")
+                               f"the device keeps the last {RL_LOG_RING - 3} steps")
         self._done = True
         # this step's slot if it reset an env, else its predecessor (which the kernel has already resolved the same way)
         s = torch.where(self._slot[0] > 0, self._slot, self._prev)
@@ -361,7 +361,15 @@ class ManagerBasedRLEnv(_EnvBase):
         return self._obs
 
     # -- hipGraph capture of a loop around step() (include/rl_env.h; robot_lab_amd/collect.py drives it) -------------------
+    def _fill_live_logs(self):
+        for _, ref in self._live_logs:
+            log = ref()
+            if log is not None:
+                log._fill()
+        self._live_logs.clear()
+
     def graph_begin(self):
+        self._fill_live_logs()  # before the capture: a _fill() inside it would be RECORDED into the graph instead of executed
         self._native.graph_begin(self._stream())
         self._graph_snap = self.common_step_counter
 
@@ -373,18 +381,16 @@ class ManagerBasedRLEnv(_EnvBase):
 
     def graph_launching(self, n: int):
         """Call right before replaying a captured loop of `n` steps: accounts them on the host side."""
+        self._fill_live_logs()  # the replay advances the ring by n slots: what is still held is materialised now (ahead of it on the stream)
         self._native.graph_launching(self._stream())
         self.common_step_counter += n
         self._export_stamp = -1
         self._obs = self._obs_slots[self._native.obs_slot()]
-        for _, ref in self._live_logs:  # the replay advances the ring by n slots: what is still held is materialised now
-            log = ref()
-            if log is not None:
-                log._fill()
-        self._live_logs.clear()
-        if self.log_episodes:
+        if self.log_episodes:  # the log of the replay's last step: tracked like a step()'s, so that later replays materialise it in time
             k = self._native.log_slot()
-            self.extras = {"log": _LazyLog(self, self._bufs["LOG"][k], self._bufs["LOG"][(k - 1) % RL_LOG_RING], self.common_step_counter)}
+            log = _LazyLog(self, self._bufs["LOG"][k], self._bufs["LOG"][(k - 1) % RL_LOG_RING], self.common_step_counter)
+            self.extras = {"log": log}
+            self._live_logs.append((self.common_step_counter, weakref.ref(log)))
 
     def close(self):
         if getattr(self, "_native", None) is not None:

@@ -130,8 +130,11 @@ def _read_stl_vertices(path: str) -> np.ndarray:
 
 def _read_dae_vertices(path: str) -> np.ndarray:
     """Vertices [n, 3] of a COLLADA file (Unitree B2W: calves and wheels, `b2w_description.urdf` FL_calf / FL_foot collision):
-    the position arrays of every geometry, carried through the <matrix> transforms of the scene nodes that instance them
-    (Blender exports millimetres with a 0.001 scale matrix) and the asset's unit."""
+    the position arrays of every geometry, carried through the transforms of the scene nodes that instance them - <matrix>
+    (Blender exports millimetres with a 0.001 scale matrix), <translate>, <rotate> (axis + degrees) and <scale>, composed in
+    document order as the COLLADA 1.4 specification prescribes -, the asset's unit, and its up axis (Y_UP / X_UP files are
+    turned into the Z_UP convention URDF meshes are interpreted in).  Anything else that is malformed raises ValueError: the
+    caller treats that as "unreadable file: no spheres" (_read_mesh_vertices)."""
     ns = {"c": "http://www.collada.org/2005/11/COLLADASchema"}
     root = ET.parse(path).getroot()
     geoms = {}
@@ -145,11 +148,42 @@ def _read_dae_vertices(path: str) -> np.ndarray:
             geoms[g.get("id")] = np.array(src.text.split(), dtype=np.float64).reshape(-1, 3)
     unit = root.find("c:asset/c:unit", ns)
     meter = float(unit.get("meter", "1")) if unit is not None else 1.0
+    up = root.find("c:asset/c:up_axis", ns)
+    up_axis = (up.text or "Y_UP").strip().upper() if up is not None else "Y_UP"  # the specification's default
+    # right-handed change of basis into Z_UP (COLLADA 1.4.1 "up_axis": Y_UP = x right, y up, z in;  X_UP = x up, y left (-), z in)
+    UP = {"Z_UP": np.eye(3), "Y_UP": np.array([[1.0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]]), "X_UP": np.array([[0, -1.0, 0], [0, 0, -1.0], [1.0, 0, 0]])}
+    if up_axis not in UP:
+        raise ValueError(f"{path}: unknown up_axis {up_axis!r}")
     out = []
+    tag = lambda el: el.tag.rsplit("}", 1)[-1]  # noqa: E731
+
+    def local(el):
+        v = np.array((el.text or "").split(), dtype=np.float64)
+        M = np.eye(4)
+        kind = tag(el)
+        if kind == "matrix" and v.size == 16:
+            M = v.reshape(4, 4)
+        elif kind == "translate" and v.size == 3:
+            M[:3, 3] = v
+        elif kind == "scale" and v.size == 3:
+            M[:3, :3] = np.diag(v)
+        elif kind == "rotate" and v.size == 4:
+            a, th = v[:3] / max(np.linalg.norm(v[:3]), 1e-30), np.deg2rad(v[3])
+            K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            M[:3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+        elif kind in ("lookat", "skew"):
+            raise ValueError(f"{path}: <{kind}> node transforms are not supported")
+        elif kind in ("matrix", "translate", "scale", "rotate"):
+            raise ValueError(f"{path}: malformed <{kind}>")
+        else:
+            return None
+        return M
 
     def visit(node, M):
-        for m in node.findall("c:matrix", ns):
-            M = M @ np.array(m.text.split(), dtype=np.float64).reshape(4, 4)
+        for el in node:  # transforms apply in document order, ahead of the geometry and the child nodes they precede or follow alike
+            L = local(el)
+            if L is not None:
+                M = M @ L
         for ig in node.findall("c:instance_geometry", ns):
             v = geoms.get(ig.get("url")[1:])
             if v is not None:
@@ -162,7 +196,8 @@ def _read_dae_vertices(path: str) -> np.ndarray:
             visit(node, np.eye(4))
     if not out:  # no scene graph: the bare arrays
         out = [v * meter for v in geoms.values()]
-    return np.concatenate(out) if out else np.zeros((0, 3))
+    verts = np.concatenate(out) if out else np.zeros((0, 3))
+    return verts @ UP[up_axis].T
 
 
 def _read_obj_vertices(path: str) -> np.ndarray:
@@ -173,7 +208,13 @@ def _read_obj_vertices(path: str) -> np.ndarray:
 
 def _read_mesh_vertices(path: str) -> np.ndarray:
     ext = os.path.splitext(path)[1].lower()
-    return _read_dae_vertices(path) if ext == ".dae" else _read_obj_vertices(path) if ext == ".obj" else _read_stl_vertices(path)
+    try:
+        return _read_dae_vertices(path) if ext == ".dae" else _read_obj_vertices(path) if ext == ".obj" else _read_stl_vertices(path)
+    except (ET.ParseError, ValueError, IndexError, KeyError, AttributeError, OSError) as exc:  # -> "unreadable file: no spheres" (_mesh_to_spheres)
+        import warnings
+
+        warnings.warn(f"collision mesh {path} could not be read ({type(exc).__name__}: {exc}); the link gets no spheres from it")
+        return np.zeros((0, 3))
 
 
 def _mesh_to_spheres(verts: np.ndarray, scale: np.ndarray):

@@ -330,7 +330,7 @@ struct HostCtx {
 };
 
 template <class TP, int SUB>
-void run(const rl::KState& S_launch, const void* Tv, int reset) {
+void run(const rl::KState& S_launch, const void* Tv) {
   rl::KState S = S_launch;
   S.step_counter += *S.step_base;  // as the kernel entry does
   const rl::TablesT<TP>* T = static_cast<const rl::TablesT<TP>*>(Tv);
@@ -350,8 +350,10 @@ void run(const rl::KState& S_launch, const void* Tv, int reset) {
     for (int e = tm; e < S.Npad; e += teams) {
       ctx.e_ = e;
       rl::EnvProgram<Ctx, TP> prog(ctx, S);
-      if (reset)
+      if (S.mode == rl::KMODE_RESET || S.mode == rl::KMODE_STEP_TAIL)
         prog.reset_entry();
+      else if (S.mode == rl::KMODE_STEP_HEAD)
+        prog.step_head();
       else
         prog.step();
     }
@@ -373,8 +375,10 @@ void run(const rl::KState& S_launch, const void* Tv, int reset) {
     for (int e = tm; e < S.Npad; e += teams) {
       ctx.e_ = e;
       rl::EnvProgram<Ctx, TP> prog(ctx, S);
-      if (reset)
+      if (S.mode == rl::KMODE_RESET || S.mode == rl::KMODE_STEP_TAIL)
         prog.reset_entry();
+      else if (S.mode == rl::KMODE_STEP_HEAD)
+        prog.step_head();
       else
         prog.step();
     }
@@ -401,16 +405,16 @@ struct Backend {
   void zero(void* p, size_t n) { std::memset(p, 0, n); }
   void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
   void h2d_stream(void* d, const void* s, size_t n, void*) { std::memcpy(d, s, n); }
-  int launch(const rl::KState& S, const void* T, int CL, int reset, void*) {
+  int launch(const rl::KState& S, const void* T, int CL, void*) {
     switch (CL * 10 + sub) {
-      case 31: run<rl::TopoQuad3, 1>(S, T, reset); return 0;
-      case 41: run<rl::TopoQuad4, 1>(S, T, reset); return 0;
-      case 34: run<rl::TopoQuad3, 4>(S, T, reset); return 0;
-      case 44: run<rl::TopoQuad4, 4>(S, T, reset); return 0;
-      case 1041: run<rl::TopoQuad4M, 1>(S, T, reset); return 0;
-      case 1044: run<rl::TopoQuad4M, 4>(S, T, reset); return 0;
-      case 71: run<rl::TopoG1, 1>(S, T, reset); return 0;
-      case 74: run<rl::TopoG1, 4>(S, T, reset); return 0;
+      case 31: run<rl::TopoQuad3, 1>(S, T); return 0;
+      case 41: run<rl::TopoQuad4, 1>(S, T); return 0;
+      case 34: run<rl::TopoQuad3, 4>(S, T); return 0;
+      case 44: run<rl::TopoQuad4, 4>(S, T); return 0;
+      case 1041: run<rl::TopoQuad4M, 1>(S, T); return 0;
+      case 1044: run<rl::TopoQuad4M, 4>(S, T); return 0;
+      case 71: run<rl::TopoG1, 1>(S, T); return 0;
+      case 74: run<rl::TopoG1, 4>(S, T); return 0;
       default: err = "unsupported chain length"; return -1;
     }
   }

@@ -109,18 +109,20 @@ def test_emu_matches_oracle_with_curricula(emu_lib):
         widened += int(not np.allclose(lv[:6], lv0[:6]))
         lv0 = lv.copy()
     # every env times out at step 20, 40, 60 -> three decisions: 0.1 -> 0.2 -> 0.3 -> 0.35 (clamped)
-    assert widened == 3
+    assert widened == 3 and ora.cmd_levels_immediate  # the reference order: the deciding step's own resets draw from the widened range
     np.testing.assert_allclose(lv[:6], [-0.35, 0.35, -0.35, 0.35, -0.5, 0.5], atol=1e-6)
     # commands are drawn inside the live range, not the table's
     assert np.abs(host_view(emu, "COMMAND")[:24, 0]).max() <= lv[1] + 1e-6
 
 
 def test_deferred_decision_is_bounded_against_the_reference_order():
-    """the reference runs curriculum_manager.compute() FIRST inside _reset_idx, so the envs reset in the deciding
-    step already draw their commands from the widened range (oracle: cmd_levels_immediate = True - the reference-exact mode, the rule
-    itself is pinned by test_golden_is_what_the_reference_does); the kernels decide behind the launch (False), so those envs - and the
-    deciding step's heading clip - still use the old range.  Worst case by construction: every env times out on the deciding
-    step.  What the deviation is, measured between the two modes of the oracle on the same seeds and actions:
+    """ADVICE r2 (medium), history: the reference runs curriculum_manager.compute() FIRST inside _reset_idx, so the envs reset in the
+    deciding step already draw their commands from the widened range (oracle: cmd_levels_immediate = True, the default - the rule
+    itself is pinned by test_golden_is_what_the_reference_does).  The round-2 kernels decided behind the launch (False): those envs -
+    and the deciding step's heading clip - still used the old range.  Round 3 splits such a step around the decision (csrc/
+    rl_env_host.h step(): head launch, decision, tail launch), and test_emu_matches_oracle_with_curricula now holds the lane
+    program to the reference order on every step.  This test keeps the measure of what the deferred order cost, between the two
+    modes of the oracle on the same seeds and actions (worst case by construction: every env times out on the deciding step):
       * the live range tables agree from the end of the deciding step on (the decision itself is the same);
       * commands differ only in envs reset on a deciding step: per component by at most the widening step 0.1 (same uniform sample,
         range ends moved by -0.1 / +0.1) - unless the small-command rule (VEL/mdp/commands.py:43-47: |v_xy| <= threshold -> 0) zeroes

@@ -57,7 +57,9 @@ def test_fixture_is_eventful_and_self_consistent(key):
     ora = {k.split("/", 1)[1]: fx[k] for k in fx.files if k.startswith("oracle/")}
     twin = {k.split("/", 1)[1]: fx[k] for k in fx.files if k.startswith("twin/")}
     assert set(ora) == set(twin) and all(np.isfinite(v).all() for v in ora.values())
-    assert ora["time_out"].mean() > 5e-4 and ora["contacts"].mean() > 0.5 and len(ora["reward"]) == int(fx["n_envs"])
+    # eventful: episodes end inside the run (A1: the staggered time-outs; G1 under random actions falls - most of its resets are terminations)
+    assert ora["time_out"].mean() > 1e-4 and (ora["time_out"] + ora["terminated"]).mean() > 5e-4
+    assert ora["contacts"].mean() > 0.5 and len(ora["reward"]) == int(fx["n_envs"])
     compare_episode_stats(twin, ora, twin)
     # reward = sum of its terms, also on average
     total = sum(ora[k] for k in ora if k.startswith("term_"))

@@ -73,3 +73,62 @@ def test_interval_timers_tick_by_exactly_step_dt(task, merge, wg, sub, monkeypat
     env = ManagerBasedRLEnv(task, num_envs=256, seed=3, device="cuda:0")
     assert timers_tick_exactly(env, torch) > 256
     env.close()
+
+
+def _eventful_state(env, seed):
+    """Edit the carried state so that the next steps contain every rare branch: a seventh of the episodes at their last step (time-out
+    resets with all their draws), push / command timers about to expire in a ninth / an eleventh of the envs."""
+    st = env.read_state()
+    N, L = env.num_envs, env.max_episode_length
+    rng = np.random.default_rng(seed)
+    ep = rng.integers(0, L - 40, N)
+    ep[::7] = L - 1 - (np.arange(len(ep[::7])) % 5)
+    ts = st["task_state"].copy()
+    dt = np.float32(env.step_dt)
+    ts[::9, RL_TS_PUSH_TIME_LEFT] = dt * (1 + np.arange(len(ts[::9])) % 4).astype(np.float32)
+    ts[::11, RL_TS_CMD_TIME_LEFT] = dt * (1 + np.arange(len(ts[::11])) % 4).astype(np.float32)
+    env.load_state({"task_state": ts, "episode_length": ep})
+
+
+@pytest.mark.parametrize("task,merge", INSTANCES)
+def test_kernel_shapes_agree_bit_for_bit(task, merge, monkeypatch):
+    """The SAME lane program is compiled into several kernels (workgroup of one / of four wavefronts; step / reset entry): different
+    register allocations of identical arithmetic.  Run from the same state with the same actions they must produce the same BITS - a
+    value clobbered by a live-range split under a narrowed EXEC mask (the defect class of profiles/r02_launch_bounds64_miscompile.txt,
+    seen again as corrupted commands in profiles/r03d_pin_desc_miscompile.txt) shows up as a difference in whichever state word,
+    observation, reward term or flag it touches, without an oracle and at a size that takes seconds.  12 eventful steps: time-out
+    resets, interval pushes and command resampling are due in some envs on every one of them."""
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    if merge is not None:
+        monkeypatch.setenv("RL_ENV_MERGE", merge)
+    N = 512
+    runs = []
+    for wg in ("1", "-4"):
+        monkeypatch.setenv("RL_ENV_WG", wg)
+        env = ManagerBasedRLEnv(task, num_envs=N, seed=5, device="cuda:0")
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for _ in range(3):
+            env.step(torch.rand(N, env.num_actions, device="cuda", generator=g) * 2 - 1)
+        _eventful_state(env, 0)
+        trace = []
+        for _ in range(12):
+            obs, rew, term, tout, _ = env.step(torch.rand(N, env.num_actions, device="cuda", generator=g) * 2 - 1)
+            trace.append(dict(policy=obs["policy"].cpu().numpy().copy(), critic=obs["critic"].cpu().numpy().copy(), reward=rew.cpu().numpy().copy(),
+                              terms=env.reward_terms().cpu().numpy().copy(), done=(term | tout).cpu().numpy().copy(), **env.read_state()))
+        runs.append(trace)
+        env.close()
+    if "G1" in task:  # the trunk + limbs instance ships single-wavefront workgroups only (csrc/rl_env.hip launch_cl): both runs are the same kernel
+        assert all(np.array_equal(a[k], b[k]) for a, b in zip(*runs) for k in a)
+        return
+    assert sum(int(t["done"].sum()) for t in runs[0]) > N // 8  # the window is eventful
+    for s, (a, b) in enumerate(zip(*runs)):
+        for k in a:
+            same = np.array_equal(a[k], b[k], equal_nan=True) if np.asarray(a[k]).dtype.kind == "f" else np.array_equal(a[k], b[k])
+            if not same:
+                bad = np.argwhere(np.asarray(a[k]) != np.asarray(b[k]))
+                raise AssertionError(f"step {s}: '{k}' differs between one- and four-wavefront workgroups in {len(bad)} entries, first at {bad[0].tolist()}: "
+                                     f"{np.asarray(a[k])[tuple(bad[0])]} vs {np.asarray(b[k])[tuple(bad[0])]} - same arithmetic, different register allocation: a miscompile")

@@ -171,6 +171,23 @@ def test_mesh_vertex_readers(tmp_path):
     np.testing.assert_allclose(v.max(0), [0.1, 0.07, 0.1], atol=2e-3)
     sph = _mesh_to_spheres(v, np.ones(3))
     assert len(sph) == 1 and abs(sph[0][1] - 0.1) < 5e-3 and np.allclose(sph[0][0], [0, 0.05, 0], atol=2e-3)
+    # the same wheel through <scale> / <rotate> / <translate> node elements (document order) in a Y_UP file: the reader composes them
+    # and turns the result into the Z_UP convention (other exporters than Blender's matrix form)
+    dae2 = tmp_path / "wheel_yup.dae"
+    dae2.write_text(dae.read_text().replace("<up_axis>Z_UP</up_axis>", "<up_axis>Y_UP</up_axis>").replace(
+        '<matrix sid="transform">0.001 0 0 0  0 0 -0.001 0.05  0 0.001 0 0  0 0 0 1</matrix>',
+        "<translate>0 0.05 0</translate><rotate>1 0 0 90</rotate><scale>0.001 0.001 0.001</scale>"))
+    v2 = _read_mesh_vertices(str(dae2))
+    # node transform = T R S = the matrix above (wheel axis y, centre y = 0.05 in the file's frame); Y_UP -> Z_UP maps (x, y, z) to (x, -z, y)
+    np.testing.assert_allclose(v2, np.stack([v[:, 0], -v[:, 2], v[:, 1]], 1), atol=1e-12)
+    bad = tmp_path / "bad.dae"
+    bad.write_text(dae.read_text().replace('<matrix sid="transform">', '<lookat>0 0 0 1 1 1 0 0 1</lookat><matrix sid="transform">'))
+    with pytest.warns(UserWarning, match="could not be read"):
+        assert _read_mesh_vertices(str(bad)).shape == (0, 3) and _mesh_to_spheres(_read_mesh_vertices(str(bad)), np.ones(3)) == []
+    trunc = tmp_path / "trunc.dae"
+    trunc.write_text(dae.read_text()[:400])
+    with pytest.warns(UserWarning, match="could not be read"):
+        assert _read_mesh_vertices(str(trunc)).shape == (0, 3)
     obj = tmp_path / "box.obj"
     obj.write_text("# box\n" + "".join(f"v {x} {y} {z}\n" for x in (0, 1) for y in (0, 2) for z in (0, 3)) + "vn 0 0 1\nf 1 2 3\n")
     assert _read_mesh_vertices(str(obj)).shape == (8, 3) and _read_mesh_vertices(str(obj)).max() == 3.0
