@@ -96,8 +96,14 @@ struct RewTab {  // 48 bytes; index lists (joint_mirror pairs, gait feet) live i
   int32_t row;      // joint-sum kinds: row of the env's joint-statistics table the term sums over its joint mask; else -1
 };
 // per-env reward tables in LDS (env_terms.h compute_rewards): REW_JS_ROWS statistics per task joint, REW_BT_NF words per body
-constexpr int REW_JS_ROWS = 10, REW_BT_NF = 14;
-RL_FN constexpr int rew_tab_words(int D, int n_bodies) { return REW_JS_ROWS * D + REW_BT_NF * n_bodies; }
+// (a body's row is REW_BT_NS words of contact-sensor state, + REW_BT_NX more - net force, position and velocity relative to the
+// root - only for the bodies of TaskTab::rew_ext_mask: the feet, typically.  17 bodies x 14 words x 16 envs per wavefront were
+// 15 KB of LDS in the one-lane-per-limb mapping - one wavefront per CU less than fits now.)
+constexpr int REW_JS_ROWS = 10, REW_BT_NS = 5, REW_BT_NX = 9, REW_BT_NF = REW_BT_NS + REW_BT_NX;
+RL_FN int popcount64(uint64_t m) { return __builtin_popcountll(m); }
+RL_FN int rew_tab_words(int D, int n_bodies, uint64_t ext_mask) { return REW_JS_ROWS * D + REW_BT_NS * n_bodies + REW_BT_NX * popcount64(ext_mask); }
+// word offset of body b's row in the body table
+RL_FN int rew_bt_row(uint64_t ext_mask, int b) { return REW_BT_NS * b + REW_BT_NX * popcount64(ext_mask & ((1ull << b) - 1ull)); }
 constexpr int IDX_POOL = 48;
 
 struct ObsTab {
@@ -164,6 +170,7 @@ struct TaskTab {  // everything that is not per limb
   int32_t n_main;
   int32_t rew_slot[MAX_T];
   uint64_t rew_rel_mask;  // bodies whose position / velocity relative to the root some reward term reads
+  uint64_t rew_ext_mask;  // bodies with a long row in the reward body table: rew_rel_mask + the bodies whose net force a term reads
   int32_t idx_pool_a[IDX_POOL], idx_pool_b[IDX_POOL];
   int32_t term_time_out, term_oob, term_illegal;
   float oob_buffer, illegal_threshold;
@@ -263,6 +270,11 @@ RL_FN size_t lane_index(const Layout& ly, int e, int k, int f, int ept) {
   return ((size_t)(e / ept) * ly.NF_LANE + (size_t)f) * (size_t)(NLANE * ept) + (size_t)(e % ept) * NLANE + k;
 }
 RL_FN size_t env_index(const Layout& ly, int e, int f, int ept) { return ((size_t)(e / ept) * ly.NF_ENV + (size_t)f) * (size_t)ept + (size_t)(e % ept); }
+
+// observation group g of a one-lane-per-limb launch is written straight to HBM (no LDS staging row) when it carries no noise
+// (env_terms.h write_group<DIRECT>; the LDS sizing in rl_env.hip follows the same predicate)
+template <class TabT>
+RL_FN bool direct_group(const TabT& T, int g) { return T.obs[g].corrupt == 0; }
 
 // layout of KState::cmd_levels / RL_BUF_CMD_LEVELS
 enum CmdLevels { CL_LIN_X = 0, CL_LIN_Y = 2, CL_ANG_Z = 4, CL_SUM_LIN = 8, CL_CNT_LIN = 9, CL_SUM_ANG = 10, CL_CNT_ANG = 11, CL_WORDS = 16 };

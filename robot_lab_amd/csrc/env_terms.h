@@ -26,13 +26,15 @@ enum ObsKind {
 // kernel of the split path) ------------------------------------------------------------------------------------------------
 enum { JS_TAU2 = 0, JS_ACC2, JS_QD2, JS_LIMIT, JS_POWER, JS_DEV1, JS_DEV2, JS_DA2, JS_Q, JS_ABSQD, JS_ROWS };  // = env_tables.h REW_JS_ROWS
 enum { BT_HMAX = 0, BT_CA, BT_CC, BT_LA, BT_LC, BT_FX, BT_FY, BT_FZ, BT_PX, BT_PY, BT_PZ, BT_VX, BT_VY, BT_VZ, BT_NF };  // = REW_BT_NF
-static_assert(JS_ROWS == REW_JS_ROWS && BT_NF == REW_BT_NF, "reward tables: LDS sizing in env_tables.h");
+static_assert(JS_ROWS == REW_JS_ROWS && BT_NF == REW_BT_NF && BT_FX == REW_BT_NS, "reward tables: LDS sizing in env_tables.h");
 
 struct RewEnv {
   float gate, cmd_norm, bv, fc_hi, moving;
   bool terminated;
   const float* JT;  // [JS_ROWS][D]
-  const float* BT;  // [n_bodies][BT_NF]
+  const float* BT;  // body rows: BT_FX.. only for the bodies of ext_mask (row(b), env_tables.h rew_bt_row)
+  uint64_t ext_mask;
+  RL_FN const float* row(int b) const { return BT + rew_bt_row(ext_mask, b); }
   int D;
   // the env's own scalars a term may read (the lane program's registers, or the record of the split path)
   V3 cmd, lin_b, ang_b, lin_w, vang, grav_b, pos;
@@ -159,14 +161,14 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
       const float* aq = E.JT + JS_ABSQD * E.D;
       const bool running = cmd_norm > R.p[1] || bv > R.p[0];
       float part = 0.f;
-      for (int i = 0; i < R.n_idx; ++i) part += (running ? (first_a(BT + ia[i] * BT_NF) ? 1.f : 0.f) : 1.f) * aq[ib[i]];
+      for (int i = 0; i < R.n_idx; ++i) part += (running ? (first_a(E.row(ia[i])) ? 1.f : 0.f) : 1.f) * aq[ib[i]];
       f = part;
     } break;
     case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256: product of exponentials = exponential of the sum
       float air[4], con[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float* r = BT + ia[i] * BT_NF;
+        const float* r = E.row(ia[i]);
         air[i] = r[BT_CA];
         con[i] = r[BT_CC];
       }
@@ -181,7 +183,7 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
     case REW_FEET_DISTANCE_XY_EXP: {  // rewards.py:439-461, 464-505: feet (link frames) against a stance rectangle in the base frame
       float part = 0.f;
       for (int i = 0; i < R.n_idx; ++i) {
-        const float* r = BT + ia[i] * BT_NF;
+        const float* r = E.row(ia[i]);
         const float ey = ((i & 1) ? -0.5f : 0.5f) * R.p[1] - r[BT_PY];
         const float ex = R.kind == REW_FEET_DISTANCE_XY_EXP ? (i < 2 ? 0.5f : -0.5f) * R.p[2] - r[BT_PX] : 0.f;
         part += ex * ex + ey * ey;
@@ -213,7 +215,7 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           on[w] = m != 0ull;
-          rr[w] = BT + (on[w] ? __builtin_ctzll(m) : 0) * BT_NF;
+          rr[w] = E.row(on[w] ? __builtin_ctzll(m) : 0);
           m &= m - 1ull;  // (0 stays 0)
         }
         float hm[4], ca[4], cc[4], la[4], lc[4];
@@ -381,6 +383,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     yaw_s = Rwb.r1.x * hn;
   }
 
+  RL_FN uint64_t uniform_u64(uint64_t v) const {  // a wave-uniform 64-bit value: both halves pinned (SGPR pair on the GPU)
+    return ((uint64_t)(uint32_t)ctx.uniform_i((int)(uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)ctx.uniform_i((int)(uint32_t)v);
+  }
   RL_FN float U(uint32_t stream, uint32_t idx, float lo, float hi) const {
     return uniform_range(S.seed, (uint32_t)e, S.step_counter, stream, idx, lo, hi);
   }
@@ -562,6 +567,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // the bodies some term looks at that way - T.rew_rel_mask)
     {
       const uint64_t rel_mask = T.rew_rel_mask;
+      const uint64_t ext_mask = uniform_u64(T.rew_ext_mask);
       const bool any_rel = ctx.uniform_i((int)(rel_mask != 0ull)) != 0;
       ChainTP C = this->new_chain();
       // (trunk + limbs instance: the chain words in LDS already hold the kinematics of the final joint positions, step() stage 3)
@@ -572,10 +578,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         if (s < 0) continue;
         const int b = L.slot_body[s];
         if (b < 0 || (s == 0 && !L.owns_base_body)) continue;
-        float* r = BT + b * BT_NF;
+        float* r = BT + rew_bt_row(ext_mask, b);
         r[BT_HMAX] = fmaxf(hist_n[s][0], fmaxf(hist_n[s][1], hist_n[s][2]));
         r[BT_CA] = tim[s][0]; r[BT_CC] = tim[s][1]; r[BT_LA] = tim[s][2]; r[BT_LC] = tim[s][3];
-        r[BT_FX] = cf[s][0]; r[BT_FY] = cf[s][1]; r[BT_FZ] = cf[s][2];
+        if ((ext_mask >> b) & 1ull) { r[BT_FX] = cf[s][0]; r[BT_FY] = cf[s][1]; r[BT_FZ] = cf[s][2]; }
         if (any_rel && ((rel_mask >> b) & 1ull)) {
           V3 relp, relv;
           body_rel(C, s, relp, relv);
@@ -595,6 +601,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     E.moving = E.cmd_norm > 0.1f ? 1.f : 0.f;
     E.terminated = terminated;
     E.JT = JT; E.BT = BT; E.D = D;
+    E.ext_mask = uniform_u64(T.rew_ext_mask);
     E.cmd = cmd; E.lin_b = lin_b; E.ang_b = ang_b; E.lin_w = lin_w; E.vang = vang; E.grav_b = grav_b; E.pos = pos;
     E.yaw_c = yaw_c; E.yaw_s = yaw_s; E.Rwb = Rwb;
     const float step_dt = ctx.uniform(T.step_dt);
@@ -699,7 +706,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     if (sp.single_trip) scan_fetch_trip(li, scan_n, cy, sy, scan_p, sp);
   }
 
-  template <class GT>
+  // DIRECT: the row goes straight to its place in HBM (`stage` = the env's row of the output buffer) instead of an LDS staging row
+  // that flush_obs() bursts out - for groups without noise in the one-lane-per-limb mapping, whose 16 envs x 235 critic columns
+  // would otherwise cost 15 KB of LDS per wavefront, i.e. the fourth wavefront of a CU (direct_group below).  The 4 lanes of an env
+  // write 16 consecutive bytes per instruction; the L2 merges the partial lines.
+  template <bool DIRECT, class GT>
   RL_FN void write_group(const GT& G, const float* F, float* stage, uint32_t noise_base, float cy, float sy, V3 scan_p, const ScanPatches& sp) {
     constexpr int NITC = (TP::OBS_NC + LPE - 1) / LPE;
 #ifdef RL_ABL_NO_SCAN
@@ -708,7 +719,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     const int n_cols = ctx.uniform_i(G.n_cols), scan_off = ctx.uniform_i(G.scan_off), scan_n = ctx.uniform_i(G.scan_n);
 #endif
     const int dim = ctx.uniform_i(G.dim);
-    const bool corrupt = ctx.uniform_i(G.corrupt) != 0;
+    const bool corrupt = !DIRECT && ctx.uniform_i(G.corrupt) != 0;
     {  // non-scan columns: ordinal n = li, li + LPE, ...; all descriptor reads, then all feature reads, then the arithmetic
       ObsColTab d[NITC];
       float f[NITC];
@@ -800,12 +811,15 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       }
     }
     ctx.group_sync();
-    write_group(T.obs[0], F, ctx.obs_stage(0), 0u, cy, sy, scan_p, sp);
+    const bool d0 = direct_group(T, 0), d1 = direct_group(T, 1);
+    if (SUB == 1 && d0) write_group<true>(T.obs[0], F, S.obs_policy + (size_t)e * (size_t)T.policy_dim, 0u, cy, sy, scan_p, sp);
+    else write_group<false>(T.obs[0], F, ctx.obs_stage(0), 0u, cy, sy, scan_p, sp);
     RL_PHASE(21, "obs.policy_done");
-    write_group(T.obs[1], F, ctx.obs_stage(1), 1024u, cy, sy, scan_p, sp);
+    if (SUB == 1 && d1) write_group<true>(T.obs[1], F, S.obs_critic + (size_t)e * (size_t)T.critic_dim, 1024u, cy, sy, scan_p, sp);
+    else write_group<false>(T.obs[1], F, ctx.obs_stage(1), 1024u, cy, sy, scan_p, sp);
     RL_PHASE(22, "obs.flush");
-    ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
-    ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
+    if (!(SUB == 1 && d0)) ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
+    if (!(SUB == 1 && d1)) ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
   }
 
   // episode log of THIS step: slot step_counter % LOG_RING.  Every step starts from a slot the previous step zeroed, so a

@@ -9,6 +9,8 @@
 // back as one linear, 16-byte-vectorised burst per wavefront.  DESIGN.md section 3 has the LDS budget.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 
@@ -195,8 +197,9 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   ctx.T = Tl;
   ctx.dim[0] = Tl->policy_dim;
   ctx.dim[1] = Tl->critic_dim;
-  const int s0w = (Ctx::EPT * ctx.dim[0] + 3) & ~3;
-  int s1w = (Ctx::EPT * ctx.dim[1] + 3) & ~3;
+  // (one lane per limb: a group without noise has no staging row - env_terms.h write_group<DIRECT>)
+  const int s0w = (SUB == 1 && direct_group(*Tl, 0)) ? 0 : (Ctx::EPT * ctx.dim[0] + 3) & ~3;
+  int s1w = (SUB == 1 && direct_group(*Tl, 1)) ? 0 : (Ctx::EPT * ctx.dim[1] + 3) & ~3;
   {  // the staging rows double as limb-shared scratch inside the substeps (streaming CRBA): at least that big
     const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
     if (s0w + s1w < need) s1w = need - s0w;
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + Ctx::EPT * LbLayout<TP>::ENV_WORDS;
   // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
   ctx.fdim = feat_count(Tl->D);
-  ctx.rtdim = rew_tab_words(Tl->D, Tl->n_bodies);
+  ctx.rtdim = rew_tab_words(Tl->D, Tl->n_bodies, Tl->rew_ext_mask);
   // reward stage | [ observation rows + feature vectors ] = [ reward tables ] (the tables die before the rows are written)
   int region = s0w + s1w + Ctx::EPT * ctx.fdim;
   if (region < Ctx::EPT * ctx.rtdim) s1w += Ctx::EPT * ctx.rtdim - region, region = Ctx::EPT * ctx.rtdim;
@@ -281,9 +284,39 @@ struct Backend {
     check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)stream));
     check(hipStreamSynchronize((hipStream_t)stream));  // the host staging vector dies on return
   }
-  int sub = 4;  // lanes per leg; RL_ENV_SUB=1 selects the one-lane-per-leg mapping
-  int envs_per_wave() {
-    if (const char* v = std::getenv("RL_ENV_SUB")) sub = atoi(v) == 1 ? 1 : 4;
+  // Lanes per limb.  4 (a DPP quad per limb, 16 lanes per env) is the latency mapping: 4096 envs put one wavefront on every SIMD and
+  // each lane's instruction stream is short - but the limb recursion is replicated over the sub-lanes, so a wavefront-instruction
+  // serves 4 envs.  1 (a lane per limb, 16 envs per wavefront) is the throughput mapping: ~1.5x the instructions per wavefront for
+  // 4x the envs, and it fills the chip only from ~12 k envs on.  Measured on A1 Rough (profiles/r03d_sweep_sub1_vs_sub4.txt): one
+  // round of one-lane-per-limb wavefronts takes 2.1x a round of the 16-lane mapping (88.6 vs 43.5 us at one wavefront per CU / SIMD);
+  // beyond the chip the 16-lane mapping scales with the wavefront count (no slack: a wavefront owns its SIMD), the other one in
+  // rounds of `slots` wavefronts (LDS decides how many fit a CU).  RL_ENV_SUB=1|4 forces either; the trunk + limbs instance has 4 only.
+  int sub = 4;
+  int envs_per_wave(const Tables& T, int Npad) {
+    sub = 4;
+    if (const char* v = std::getenv("RL_ENV_SUB")) {
+      sub = atoi(v) == 1 ? 1 : 4;
+    } else if (T.NW == 0) {
+      size_t lds1 = 0;
+      switch (T.CL + (T.merged ? 100 : 0)) {
+        case 3: lds1 = lds_need<TopoQuad3, 1>(T); break;
+        case 4: lds1 = lds_need<TopoQuad4, 1>(T); break;
+        case 104: lds1 = lds_need<TopoQuad4M, 1>(T); break;
+        default: break;
+      }
+      if (lds1 > 0 && lds1 <= 160 * 1024) {
+        // wavefronts a CU holds: single-wavefront workgroups each stage their own table image, a four-wavefront workgroup shares one
+        const size_t tb = staged_bytes(T);
+        const size_t per_cu = (tb + 4 * (lds1 - tb) <= 160 * 1024) ? 4 : std::min<size_t>(4, (160 * 1024) / lds1);
+        const double slots = (double)n_cu * (double)per_cu;
+        const double t1 = 2.1 * std::ceil((Npad / 16) / slots);                // in rounds of the 16-lane mapping
+        const double t4 = std::max(1.0, (Npad / 4) / (4.0 * (double)n_cu));
+        if (t1 < 0.95 * t4) sub = 1;
+        if (std::getenv("RL_ENV_DEBUG"))
+          fprintf(stderr, "rl_env: one lane per limb needs %zu B of LDS per wavefront (%u B of them tables): %.0f wavefront slots; %d envs -> %.2f vs %.2f rounds -> %d lane(s) per limb\n",
+                  lds1, (unsigned)staged_bytes(T), slots, Npad, t1, t4, sub);
+      }
+    }
     return 16 / sub;
   }
   template <class TP, int SUB, int WGW>
@@ -319,7 +352,7 @@ struct Backend {
   bool wg_force = false;
   template <class TP, int SUB>
   int launch_cl(const KState& S, const void* T, size_t lds1, hipStream_t st) {
-    if constexpr (TP::NW == 0 && SUB == 4) {  // (the trunk + limbs instance gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup)
+    if constexpr (TP::NW == 0) {  // (the trunk + limbs instance gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup)
       const int tiles = S.Npad / (16 / SUB);
       const size_t lds4 = S.table_bytes + 4 * (lds1 - S.table_bytes);
       // (the two launches of a split step - command-range curricula, no shipped cfg - use the single-wavefront workgroups: half the kernels to build)
@@ -335,12 +368,12 @@ struct Backend {
   static size_t lds_need(const Tables& T) {
     using Ctx = WaveCtx<SUB>;
     using LS = typename LsFor<TP, SUB>::type;
-    const int s0w = (Ctx::EPT * T.policy_dim + 3) & ~3;
-    int s1w = (Ctx::EPT * T.critic_dim + 3) & ~3;
+    const int s0w = (SUB == 1 && direct_group(T, 0)) ? 0 : (Ctx::EPT * T.policy_dim + 3) & ~3;
+    int s1w = (SUB == 1 && direct_group(T, 1)) ? 0 : (Ctx::EPT * T.critic_dim + 3) & ~3;
     const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
     if (s0w + s1w < need) s1w = need - s0w;
     int region = s0w + s1w + Ctx::EPT * feat_count(T.D);
-    region = std::max(region, Ctx::EPT * rew_tab_words(T.D, T.n_bodies));
+    region = std::max(region, Ctx::EPT * rew_tab_words(T.D, T.n_bodies, T.rew_ext_mask));
     constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
     constexpr int LB_FREE = TP::NW > 0 ? (LbLayout<TP>::WORDS - LbLayout<TP>::REC) * Ctx::LB_STRIDE : 0;
     const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;

@@ -377,7 +377,9 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       T.rew_rel_mask |= r.body_mask;
     if (r.kind == RL_REW_FEET_DISTANCE_Y_EXP || r.kind == RL_REW_FEET_DISTANCE_XY_EXP)
       for (int q = 0; q < r.n_idx; ++q) T.rew_rel_mask |= 1ull << r.idx_a[q];
+    if (r.kind == RL_REW_FEET_STUMBLE) T.rew_ext_mask |= r.body_mask;  // reads the net force
   }
+  T.rew_ext_mask |= T.rew_rel_mask;
   {  // evaluation schedule (TaskTab::rew_slot): scalar kinds last; whatever does not fit the first 16 slots and is scalar goes to the mini-trip
     int ns = 0;
     for (int pass = 0; pass < 2; ++pass)
@@ -471,7 +473,6 @@ struct EnvImpl {
     desc = *d;
     seed = seed_;
     N = num_envs;
-    ept = be.envs_per_wave();
     Npad = (N + ENVS_PER_WAVE - 1) / ENVS_PER_WAVE * ENVS_PER_WAVE;  // multiple of 16 suits both lane mappings
     D = d->model.num_dof;
     B = d->model.num_bodies;
@@ -489,8 +490,9 @@ struct EnvImpl {
     }
     CL = tables.CL;
     inst = tables.CL + (tables.merged ? 100 : 0);
-    if (std::getenv("RL_ENV_DEBUG")) fprintf(stderr, "rl_env: lane program CL %d NW %d merged %d, %d envs per wavefront\n", tables.CL, tables.NW, tables.merged, ept);
     if (be.init(device)) return fail("device init failed: " + be.error());
+    ept = be.envs_per_wave(tables, Npad);  // the lane mapping (16 or 4 lanes per env) decides the layout of the state tiles
+    if (std::getenv("RL_ENV_DEBUG")) fprintf(stderr, "rl_env: lane program CL %d NW %d merged %d, %d envs per wavefront\n", tables.CL, tables.NW, tables.merged, ept);
     if (be.configure(tables)) return fail("kernel configuration failed: " + be.error());
     const size_t Np = Npad, ntile = Npad / ept;
     const Layout ly(tables.CL, tables.NW, tables.NBS);

@@ -138,7 +138,7 @@ struct alignas(64) Team {
   float feat[rl::feat_count(rl::TopoMax::DMAX)];
   float lb[rl::NLANE][rl::LbLayout<rl::TopoG1>::WORDS + 1];  // limb-shared words (really shared by the limb's sub-lane threads)
   float envw[rl::LbLayout<rl::TopoG1>::ENV_WORDS + 1];        // env-shared words
-  float rtab[rl::rew_tab_words(RL_MAX_DOF, RL_MAX_BODIES)];
+  float rtab[rl::REW_JS_ROWS * RL_MAX_DOF + rl::REW_BT_NF * RL_MAX_BODIES];
   std::vector<float> stage[2];
   Team() { bar.n = LPE; }
   void barrier(int lane) {
@@ -395,7 +395,7 @@ struct Backend {
     if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : 1;
     return 0;
   }
-  int envs_per_wave() {
+  int envs_per_wave(const rl::Tables&, int) {
     if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : 1;
     return 16 / sub;
   }

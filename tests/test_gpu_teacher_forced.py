@@ -32,6 +32,10 @@ CONFIGS = [
     ("RobotLab-Isaac-Velocity-Rough-Unitree-B2W-v0", 4096, "0"),
     ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", 4096, None),
     ("RobotLab-Isaac-Velocity-Rough-RobotEra-Xbot-v0", 2048, None),
+    # the one-lane-per-limb mapping (what >= ~12 k quadruped envs per GPU launch, csrc/rl_env.hip envs_per_wave) in its production
+    # shape - four wavefronts per workgroup, the critic row written straight to HBM: "sub1" forces it at this size
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 4096, "sub1"),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 4096, "sub1"),
 ]
 
 
@@ -48,7 +52,10 @@ def test_one_step_from_shared_state_full_size(task, N, merge, monkeypatch):
 
     from robot_lab_amd.env import ManagerBasedRLEnv
 
-    if merge is not None:
+    if merge == "sub1":
+        monkeypatch.setenv("RL_ENV_SUB", "1")
+        monkeypatch.setenv("RL_ENV_WG", "-4")
+    elif merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
     K, seed = 30, 42
     env = ManagerBasedRLEnv(task, num_envs=N, seed=seed, device="cuda:0")
