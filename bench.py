@@ -48,6 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--task", type=str, default="RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--large-batch-envs", type=int, default=65536, help="0: skip the large-batch leg (rank 0 of a 1-GPU run, after the timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work the baseline leg may spend on the lane-program port")
     ap.add_argument("--cpu-oracle-envs", type=int, default=256)
     ap.add_argument("--cpu-oracle-steps", type=int, default=10)
@@ -218,9 +219,11 @@ def main():
                      # rocprofv3 PMC passes of an earlier run of the same command, read from the file named here
                      "offline": {"fields": ["traffic", "wavefront_cycle_breakdown"], "source": prof_src} if traffic is not None else None},
     }
+    env.close()
+    if rank == 0 and world == 1 and args.large_batch_envs > N:
+        out["large_batch"] = large_batch(args.task, args.large_batch_envs, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.task, N, args.cpu_seconds, args.cpu_oracle_envs, args.cpu_oracle_steps)
-    env.close()
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
@@ -230,6 +233,32 @@ def main():
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
+
+
+def large_batch(task: str, n_envs: int, dev: str) -> dict:
+    """Not the headline (BASELINE.json quotes 4096 envs/GPU): the same env.step() loop at a launch size that fills the chip several
+    times over, where rl_env_create picks the one-lane-per-limb mapping (16 envs per wavefront, csrc/rl_env.hip envs_per_wave).
+    Reported beside `value`, never instead of it."""
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    env = ManagerBasedRLEnv(task, num_envs=n_envs, seed=42, device=dev)
+    A = env.num_actions
+    gen = torch.Generator(device=dev).manual_seed(99)
+    ring = [torch.rand(n_envs, A, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+    env.reset()
+    for i in range(30):
+        env.step(ring[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 200
+    for i in range(K):
+        env.step(ring[i % 4])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ept = int(env._native.envs_per_wavefront()) if hasattr(env._native, "envs_per_wavefront") else None
+    env.close()
+    return {"envs_per_gpu": n_envs, "value": n_envs * K / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / K, "steps": K,
+            "envs_per_wavefront": ept, "note": "same task and loop as `value`, larger launch; the lane mapping is chosen from the launch size"}
 
 
 def build_host_port() -> str:

@@ -371,6 +371,11 @@ int32_t rl_env_num_envs(const rl_env* env);
 int32_t rl_env_num_actions(const rl_env* env);
 int32_t rl_env_obs_dim(const rl_env* env, int32_t group); /* 0 policy, 1 critic */
 int32_t rl_env_max_episode_length(const rl_env* env);
+/* Environments a 64-lane wavefront simulates: 4 (sixteen lanes per env - the latency mapping, what <= ~8 k quadruped envs per GPU and
+ * every trunk + limbs robot get) or 16 (one lane per limb - the throughput mapping of large launches).  Chosen by rl_env_create from
+ * the launch size (csrc/rl_env.hip envs_per_wave; RL_ENV_SUB=4|1 forces either); results do not depend on it beyond fp32 round-off.
+ * No counterpart in the reference (PhysX picks its own launch geometry): informational. */
+int32_t rl_env_envs_per_wavefront(const rl_env* env);
 
 int rl_env_destroy(rl_env* env);
 const char* rl_env_last_error(void);

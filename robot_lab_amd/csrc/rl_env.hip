@@ -146,13 +146,13 @@ extern __shared__ float4 smem4[];
 // = one wavefront per SIMD, as with single-wavefront workgroups, but stages the tables once instead of four times and the dispatcher
 // places a quarter of the workgroups): A1 Rough 4096 52.1 -> 50.2 us.  Smaller launches keep single-wavefront workgroups, which
 // spread over more CUs (1024 envs: 49.5 us on 256 CUs, 55.9 us packed four to a CU - profiles/r02_wg_waves.txt).
-// __launch_bounds__(256) also for the single-wavefront variant.  Declared as a 64-thread workgroup, the build without the SLP
-// vectorizer (-fno-slp-vectorize, __graft_entry__.py) is MISCOMPILED on the 3-joint instance: the register allocator parks the env's
-// push timer in an AGPR, lends its VGPR to a block that runs under a narrowed EXEC mask (the lanes that publish a body row of the
-// reward tables), and reloads it behind a further `s_and_b64 exec, exec, vcc` early-out - under the narrower mask, so the lanes that
-// left early keep the temporary and the push event fires in every env (profiles/r02_launch_bounds64_miscompile.txt: ISA excerpt and
-// state dump; 16 GPU parity failures).  Declared as 128 or 256 threads the same source keeps the timer in the AGPR until it is used.
-// The guard against this class of defect is the GPU parity tier (full-size teacher-forced steps, both workgroup shapes).
+// __launch_bounds__(256) also for the single-wavefront variant: a leftover of round 2, when declaring 64 threads "caused" a miscompile
+// (the push event fired in every env).  The cause is known since round 3 and has nothing to do with the declaration (DESIGN.md
+// section 3, profiles/r03d_pin_desc_miscompile.txt): LLVM drops the EXEC restore of an inner divergent region that ends where the
+// enclosing one ends, the register allocator then places a live-range-split reload (v_accvgpr_read vX, aY) into the empty flow block,
+// and it executes under the inner region's - or an empty - EXEC mask while the outer region's lanes hold a temporary in vX.  Which
+// value is hit is a matter of register pressure.  This library is therefore built with -mllvm -amdgpu-remove-redundant-endcf=false,
+// and __graft_entry__.build() refuses a build in whose assembly tools/isa_exec_hazard.py finds a vector write under a stale EXEC.
 #ifndef RL_LB
 #define RL_LB(w) 256
 #endif

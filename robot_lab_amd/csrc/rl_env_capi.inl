@@ -125,6 +125,7 @@ int32_t rl_env_obs_dim(const rl_env* env, int32_t group) {
   return group == 0 ? I->tables.policy_dim : I->tables.critic_dim;
 }
 int32_t rl_env_max_episode_length(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->tables.max_episode_length; }
+int32_t rl_env_envs_per_wavefront(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->ept; }
 
 int rl_env_destroy(rl_env* env) {
   if (!env) return 0;
