@@ -239,6 +239,8 @@ def large_batch(task: str, n_envs: int, dev: str) -> dict:
     """Not the headline (BASELINE.json quotes 4096 envs/GPU): the same env.step() loop at a launch size that fills the chip several
     times over, where rl_env_create picks the one-lane-per-limb mapping (16 envs per wavefront, csrc/rl_env.hip envs_per_wave).
     Reported beside `value`, never instead of it."""
+    import torch
+
     from robot_lab_amd.env import ManagerBasedRLEnv
 
     env = ManagerBasedRLEnv(task, num_envs=n_envs, seed=42, device=dev)

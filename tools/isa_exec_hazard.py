@@ -13,8 +13,12 @@ otherwise.  Lanes of the OUTER region that clobbered vX as a temporary never get
 wavefront reads vX.  Nothing in the source can rule this out (which value is split depends on register pressure), which is why the
 symptom moved between the push timer (round 2) and the commands / heading flags (round 3) with unrelated edits.
 
-The check: for every `s_cbranch_execz L`, walk from L to the first instruction that writes EXEC; any vector-register write on the way
-executes under the stale mask -> hazard.  `__graft_entry__.build()` runs it on the device assembly of the env library (built with
+The check: for every region skip - an `s_cbranch_execz L` that directly follows the instruction(s) narrowing EXEC for the region
+(`s_and_b64 exec, exec, vcc`, `s_and_saveexec_b64`, `s_or_saveexec_b64` + `s_xor_b64 exec`, `s_mov_b64 exec`) -, walk from L to the
+first instruction that writes EXEC; any vector-register write on the way executes under the stale mask -> hazard.  (An
+`s_cbranch_execz` that does NOT follow an EXEC write is something else: with EXEC = 0 nothing a block does has an effect, and the
+compiler routes such a wavefront through any convenient real code block - e.g. the cases of a switch it could not prove uniform.
+Those targets are full of vector writes and harmless.)  `__graft_entry__.build()` runs it on the device assembly of the env library (built with
 `-mllvm -amdgpu-remove-redundant-endcf=false`, which removes the empty-flow-block shape altogether) and refuses a build with a hit.
 
     python tools/isa_exec_hazard.py <file.s> [...]        exit code 1 when a hazard is found"""
@@ -57,6 +61,10 @@ def hazards(items):
     for i, (no, _, ins) in enumerate(items):
         if not ins or not ins.startswith("s_cbranch_execz"):
             continue
+        # a region skip: EXEC was narrowed by one of the (up to three) instructions in front of the branch
+        prev = [x for _, _, x in items[max(0, i - 6):i] if x and not x.startswith(("s_waitcnt", "s_nop"))][-3:]
+        if not any(EXEC_WRITE.match(x) for x in prev):
+            continue
         target = ins.split()[-1]
         j = labels.get(target)
         if j is None:
@@ -72,13 +80,22 @@ def hazards(items):
     return out
 
 
+def count_skips(items):
+    n = 0
+    for i, (_, _, ins) in enumerate(items):
+        if ins and ins.startswith("s_cbranch_execz"):
+            prev = [x for _, _, x in items[max(0, i - 6):i] if x and not x.startswith(("s_waitcnt", "s_nop"))][-3:]
+            n += any(EXEC_WRITE.match(x) for x in prev)
+    return n
+
+
 def main(paths):
     bad = 0
     for p in paths:
         funcs = parse(p)
         n_br = 0
         for name, items in funcs.items():
-            n_br += sum(1 for _, _, ins in items if ins and ins.startswith("s_cbranch_execz"))
+            n_br += count_skips(items)
             for no, target, no2, ins2 in hazards(items):
                 bad += 1
                 print(f"{p}:{no2}: HAZARD in {name[:90]}: '{ins2}' runs under the stale EXEC of the skip path 's_cbranch_execz {target}' (line {no})")
