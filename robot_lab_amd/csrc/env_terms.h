@@ -24,13 +24,19 @@ enum ObsKind {
 
 // ---- reward terms: tables, env scalars, and the evaluation of ONE term by ONE lane (used by the lane program and by the terms
 // kernel of the split path) ------------------------------------------------------------------------------------------------
-// joint statistic a joint-sum term sums over its joint mask (RewTab::row, set by the host: rl_env_host.h build_tables)
-enum { JS_TAU2 = 0, JS_ACC2, JS_QD2, JS_LIMIT, JS_POWER, JS_DEV1, JS_DEV2, JS_DA2, JS_ROWS };
+enum { JS_TAU2 = 0, JS_ACC2, JS_QD2, JS_LIMIT, JS_POWER, JS_DEV1, JS_DEV2, JS_DA2, JS_Q, JS_ABSQD, JS_ROWS };  // = env_tables.h REW_JS_ROWS
+enum { BT_HMAX = 0, BT_CA, BT_CC, BT_LA, BT_LC, BT_FX, BT_FY, BT_FZ, BT_PX, BT_PY, BT_PZ, BT_VX, BT_VY, BT_VZ, BT_NF };  // = REW_BT_NF
+static_assert(JS_ROWS == REW_JS_ROWS && BT_NF == REW_BT_NF && BT_FX == REW_BT_NS, "reward tables: LDS sizing in env_tables.h");
 
 struct RewEnv {
   float gate, cmd_norm, bv, fc_hi, moving;
   bool terminated;
-  // the env's own scalars a term may read (identical in all lanes of the env)
+  const float* JT;  // [JS_ROWS][D]
+  const float* BT;  // body rows: BT_FX.. only for the bodies of ext_mask (row(b), env_tables.h rew_bt_row)
+  uint64_t ext_mask;
+  RL_FN const float* row(int b) const { return BT + rew_bt_row(ext_mask, b); }
+  int D;
+  // the env's own scalars a term may read (the lane program's registers, or the record of the split path)
   V3 cmd, lin_b, ang_b, lin_w, vang, grav_b, pos;
   float yaw_c, yaw_s;
   M3 Rwb;
@@ -77,13 +83,247 @@ RL_FN float scalar_term_value(const RewTab& R, const RewEnv& E) {
   return f;
 }
 
+// The term's descriptor.  -DRL_PIN_DESC reads it from the LDS table image into REGISTERS before the evaluation diverges by kind (left
+// to itself the compiler sinks every field's ds_read into the case that uses it: each of the ~16 kinds a wavefront walks through
+// then starts with its own LDS round trip + s_waitcnt).  NOT the default: measured 42.85 vs 42.93 us on A1 Rough 4096 (noise), and
+// the eleven pinned registers at the kernel's pressure peak were enough to bring the reload-under-a-narrowed-EXEC miscompile
+// back on the four-wavefront 3-joint variant (profiles/r03d_pin_desc_miscompile.txt: commands / heading flags of ~1 % of the envs).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RL_PIN_DESC)
+#define RL_PIN_REG(x) asm volatile("" : "+v"(x))
+#else
+#define RL_PIN_REG(x) ((void)0)
+#endif
+RL_FN RewTab load_rew_desc(const RewTab& src) {
+  RewTab R = src;
+  RL_PIN_REG(R.kind); RL_PIN_REG(R.weight); RL_PIN_REG(R.p[0]); RL_PIN_REG(R.p[1]); RL_PIN_REG(R.p[2]); RL_PIN_REG(R.p[3]);
+  RL_PIN_REG(R.joint_mask); RL_PIN_REG(R.n_idx); RL_PIN_REG(R.body_mask); RL_PIN_REG(R.idx_off); RL_PIN_REG(R.row);
+  return R;
+}
+
+// unweighted value of one term, evaluated by ONE lane (`R`: a register copy of the descriptor, load_rew_desc)
+template <class TabT>
+RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ terrain, const RewTab& R, const RewEnv& E) {
+  const float gate = E.gate, cmd_norm = E.cmd_norm, bv = E.bv, moving = E.moving;
+  const float* BT = E.BT;
+  const int32_t* ia = T.idx_pool_a + R.idx_off;
+  const int32_t* ib = T.idx_pool_b + R.idx_off;
+  auto first_c = [&](const float* r) { return r[BT_CC] > 0.f && r[BT_CC] < E.fc_hi; };   // ContactSensor.compute_first_contact(step_dt)
+  auto first_a = [&](const float* r) { return r[BT_CA] > 0.f && r[BT_CA] < E.fc_hi; };   // compute_first_air(step_dt)
+  // joint-sum kinds share one loop: R.row = row of the joint-statistics table (host: rl_env_host.h), -1 for every other kind
+  // (8 columns per trip, all LDS reads of a trip in flight together: a lone wavefront cannot hide a round trip per joint)
+  float js = 0.f;
+  if (R.row >= 0) {
+    const float* g = E.JT + R.row * E.D;
+    for (int j0 = 0; j0 < E.D; j0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v[w] = g[j0 + w];  // columns >= D: reads inside the tables, dropped by the mask (the host keeps joint masks below 1 << D)
+#pragma unroll
+      for (int w = 0; w < 8; ++w) js += ((R.joint_mask >> (j0 + w)) & 1u) ? v[w] : 0.f;
+    }
+  }
+  float f = 0.f;
+  switch (R.kind) {
+    case REW_TRACK_LIN_VEL_XY_EXP: case REW_TRACK_ANG_VEL_Z_EXP: case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: case REW_TRACK_ANG_VEL_Z_WORLD_EXP:
+    case REW_LIN_VEL_Z_L2: case REW_ANG_VEL_XY_L2: case REW_FLAT_ORIENTATION_L2: case REW_UPWARD: case REW_IS_TERMINATED:
+    case REW_HANDSTAND_ORIENTATION_L2:
+      f = scalar_term_value(R, E);
+      break;
+    // joint sums [UPSTREAM isaaclab.envs.mdp] + rewards.py:81-90: the statistic is in the table, the mask picked the joints
+    case REW_JOINT_TORQUES_L2: case REW_JOINT_ACC_L2: case REW_JOINT_VEL_L2: case REW_JOINT_POS_LIMITS: case REW_JOINT_POWER:
+    case REW_JOINT_DEVIATION_L1: case REW_ACTION_RATE_L2:
+      f = js;
+      break;
+    case REW_STAND_STILL: f = js * (cmd_norm < R.p[0] ? 1.f : 0.f) * gate; break;  // rewards.py:93-104
+    case REW_JOINT_POS_PENALTY: {  // rewards.py:107-129
+      float run = fsqrt(js);
+      f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
+    } break;
+    case REW_JOINT_MIRROR: {  // rewards.py:259-278
+      const float* qt = E.JT + JS_Q * E.D;
+      float part = 0.f;
+      for (int i0 = 0; i0 < R.n_idx; i0 += 4) {  // 4 pairs per trip: index reads, then the 8 position reads, in flight together
+        int a4[4], b4[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a4[w] = ia[i0 + w < R.n_idx ? i0 + w : i0]; b4[w] = ib[i0 + w < R.n_idx ? i0 + w : i0]; }
+        float qa[4], qb[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { qa[w] = qt[a4[w]]; qb[w] = qt[b4[w]]; }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float d = qa[w] - qb[w];
+          part += i0 + w < R.n_idx ? d * d : 0.f;
+        }
+      }
+      f = part * R.p[0] * gate;
+    } break;
+    case REW_WHEEL_VEL_PENALTY: {  // rewards.py:132-153: pairs (wheel body, wheel joint)
+      const float* aq = E.JT + JS_ABSQD * E.D;
+      const bool running = cmd_norm > R.p[1] || bv > R.p[0];
+      float part = 0.f;
+      for (int i = 0; i < R.n_idx; ++i) part += (running ? (first_a(E.row(ia[i])) ? 1.f : 0.f) : 1.f) * aq[ib[i]];
+      f = part;
+    } break;
+    case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256: product of exponentials = exponential of the sum
+      float air[4], con[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* r = E.row(ia[i]);
+        air[i] = r[BT_CA];
+        con[i] = r[BT_CC];
+      }
+      const float inv_std = frcp(R.p[0]), me2 = R.p[1] * R.p[1];
+      auto se = [&](float a, float b) { float d = a - b; return fminf(d * d, me2); };
+      float acc = se(air[0], air[1]) + se(con[0], con[1]) + se(air[2], air[3]) + se(con[2], con[3]);
+      acc += se(air[0], con[2]) + se(con[0], air[2]) + se(air[1], con[3]) + se(con[1], air[3]);
+      acc += se(air[0], con[3]) + se(con[0], air[3]) + se(air[2], con[1]) + se(con[2], air[1]);
+      f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? fexp(-acc * inv_std) : 0.f) * gate;
+    } break;
+    case REW_FEET_DISTANCE_Y_EXP:
+    case REW_FEET_DISTANCE_XY_EXP: {  // rewards.py:439-461, 464-505: feet (link frames) against a stance rectangle in the base frame
+      float part = 0.f;
+      for (int i = 0; i < R.n_idx; ++i) {
+        const float* r = E.row(ia[i]);
+        const float ey = ((i & 1) ? -0.5f : 0.5f) * R.p[1] - r[BT_PY];
+        const float ex = R.kind == REW_FEET_DISTANCE_XY_EXP ? (i < 2 ? 0.5f : -0.5f) * R.p[2] - r[BT_PX] : 0.f;
+        part += ex * ex + ey * ey;
+      }
+      f = fexp(-part * frcp(R.p[0])) * gate;
+    } break;
+    case REW_BASE_HEIGHT_L2: {  // rewards.py:616-644; the 3 x 3 base ray caster (velocity_env_cfg.py:78-85)
+      float tgt = R.p[0];
+      if (R.p[1] > 0.5f) {
+        float hsum = 0.f;
+        for (int r9 = 0; r9 < 9; ++r9) {
+          const int iy = r9 / 3, ix = r9 - 3 * iy;
+          const float lx = (float)(ix - 1) * 0.05f, ly = (float)(iy - 1) * 0.05f;
+          float hz;
+          V3 nn;
+          terrain_sample(u, terrain, E.pos.x, E.pos.y, E.yaw_c * lx - E.yaw_s * ly, E.yaw_s * lx + E.yaw_c * ly, hz, nn);
+          hsum += hz;
+        }
+        tgt += hsum * (1.0f / 9.0f);
+      }
+      f = (E.pos.z - tgt) * (E.pos.z - tgt) * gate;
+    } break;
+    default: {  // sums over the bodies of the term's body mask
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, mn = 1e30f;
+      // 4 bodies per trip, their table rows read together (a lone wavefront cannot hide an LDS round trip per body)
+      for (uint64_t m = R.body_mask; m != 0ull;) {
+        const float* rr[4];
+        bool on[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          on[w] = m != 0ull;
+          rr[w] = E.row(on[w] ? __builtin_ctzll(m) : 0);
+          m &= m - 1ull;  // (0 stays 0)
+        }
+        float hm[4], ca[4], cc[4], la[4], lc[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { hm[w] = rr[w][BT_HMAX]; ca[w] = rr[w][BT_CA]; cc[w] = rr[w][BT_CC]; la[w] = rr[w][BT_LA]; lc[w] = rr[w][BT_LC]; }
+        switch (R.kind) {
+          case REW_UNDESIRED_CONTACTS:  // rewards.py:665-675
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] && hm[w] > R.p[0] ? 1.f : 0.f;
+            break;
+          case REW_CONTACT_FORCES:  // [UPSTREAM] contact_forces
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] ? fmaxf(hm[w] - R.p[0], 0.f) : 0.f;
+            break;
+          case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT:  // rewards.py:416-425, 399-413
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] && cc[w] > 0.f && cc[w] < E.fc_hi ? 1.f : 0.f;
+            break;
+          case REW_FEET_AIR_TIME: case REW_HANDSTAND_FEET_AIR_TIME:  // rewards.py:340-360
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] && cc[w] > 0.f && cc[w] < E.fc_hi ? la[w] - R.p[0] : 0.f;
+            break;
+          case REW_FEET_AIR_TIME_POSITIVE_BIPED:  // rewards.py:363-383
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const bool inc = cc[w] > 0.f;
+              a0 += on[w] && inc ? 1.f : 0.f;
+              mn = on[w] ? fminf(mn, inc ? cc[w] : ca[w]) : mn;
+            }
+            break;
+          case REW_HANDSTAND_FEET_ON_AIR:  // .../env/rewards.py:31-37: counts the feet that have NOT just lifted
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a0 += on[w] && !(ca[w] > 0.f && ca[w] < E.fc_hi) ? 1.f : 0.f;
+            break;
+          case REW_FEET_AIR_TIME_VARIANCE:  // rewards.py:386-397 (torch.var is unbiased)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const float xa = fminf(la[w], 0.5f), xc = fminf(lc[w], 0.5f), o = on[w] ? 1.f : 0.f;
+              a0 += o; a1 += o * xa; a2 += o * xa * xa; a3 += o * xc; a4 += o * xc * xc;
+            }
+            break;
+          case REW_FEET_STUMBLE:  // rewards.py:428-436
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const float fx = rr[w][BT_FX], fy = rr[w][BT_FY], fz = rr[w][BT_FZ];
+              a0 += on[w] && fsqrt(fx * fx + fy * fy) > 4.f * fabsf(fz) ? 1.f : 0.f;
+            }
+            break;
+          default: {  // the kinds that look at a foot's position / velocity relative to the root
+            V3 relp[4], relv[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              relp[w] = {rr[w][BT_PX], rr[w][BT_PY], rr[w][BT_PZ]};
+              relv[w] = {rr[w][BT_VX], rr[w][BT_VY], rr[w][BT_VZ]};
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              float v = 0.f;
+              if (R.kind == REW_FEET_HEIGHT_BODY) {  // rewards.py:527-554
+                const float er = relp[w].z - R.p[0];
+                v = er * er * ftanh(R.p[1] * fsqrt(relv[w].x * relv[w].x + relv[w].y * relv[w].y));
+              } else if (R.kind == REW_FEET_SLIDE) {  // rewards.py:557-587
+                v = hm[w] > 1.0f ? fsqrt(relv[w].x * relv[w].x + relv[w].y * relv[w].y) : 0.f;
+              } else if (R.kind == REW_FEET_HEIGHT) {  // feet_height, world frame (rewards.py:507-524)
+                const V3 vw = E.lin_w + mul(E.Rwb, relv[w]);
+                const float er = E.pos.z + dot(E.Rwb.r2, relp[w]) - R.p[0];
+                v = er * er * ftanh(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
+              } else if (R.kind == REW_HANDSTAND_FEET_HEIGHT_EXP) {  // .../env/rewards.py:18-28
+                const float dz = E.pos.z + dot(E.Rwb.r2, relp[w]) - R.p[1];
+                v = dz * dz;
+              }
+              a0 += on[w] ? v : 0.f;
+            }
+          } break;
+        }
+      }
+      switch (R.kind) {
+        case REW_UNDESIRED_CONTACTS: f = a0 * gate; break;
+        case REW_CONTACT_FORCES: f = a0; break;
+        case REW_FEET_CONTACT_WITHOUT_CMD: f = a0 * (cmd_norm < 0.1f ? 1.f : 0.f) * gate; break;
+        case REW_FEET_CONTACT: f = (a0 != R.p[0] ? 1.f : 0.f) * moving * gate; break;
+        case REW_FEET_AIR_TIME: f = a0 * moving * gate; break;
+        case REW_HANDSTAND_FEET_AIR_TIME: f = a0; break;
+        case REW_FEET_STUMBLE: f = (a0 > 0.f ? 1.f : 0.f) * gate; break;
+        case REW_FEET_HEIGHT_BODY: case REW_FEET_HEIGHT: f = a0 * moving * gate; break;
+        case REW_FEET_SLIDE: f = a0 * gate; break;
+        case REW_FEET_AIR_TIME_POSITIVE_BIPED: f = (a0 == 1.f ? fminf(mn, R.p[0]) : 0.f) * moving * gate; break;
+        case REW_HANDSTAND_FEET_HEIGHT_EXP: f = fexp(-a0 * frcp(R.p[0])); break;
+        case REW_HANDSTAND_FEET_ON_AIR: f = a0 == 0.f ? 1.f : 0.f; break;
+        case REW_FEET_AIR_TIME_VARIANCE: {
+          const float inv_n = frcp(a0), inv_den = frcp(fmaxf(a0 - 1.f, 1.f));
+          f = ((a2 - a1 * a1 * inv_n) + (a4 - a3 * a3 * inv_n)) * inv_den * gate;
+        } break;
+        default: break;
+      }
+    } break;
+  }
+  return f;
+}
+
+
 template <class Ctx, class TP>
 struct EnvProgram : EnvLane<Ctx, TP> {
   using Base = EnvLane<Ctx, TP>;
   using ChainTP = typename Base::ChainTP;
   static constexpr Layout LY = Base::LY;
   static constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NBS = TP::NBS;
-  using Base::ctx; using Base::S; using Base::T; using Base::TG; using Base::L; using Base::e; using Base::k; using Base::sub; using Base::li; using Base::Np;
+  using Base::ctx; using Base::S; using Base::T; using Base::L; using Base::e; using Base::k; using Base::sub; using Base::li; using Base::Np;
   static constexpr int SUB = Base::SUB;
   static constexpr int LPE = Base::LPE;
   using Base::pos; using Base::quat; using Base::vlin; using Base::vang; using Base::q; using Base::qd; using Base::kp; using Base::kd;
@@ -279,312 +519,18 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     relv = point_velocity<TP, ChainTP>(C, this->wdepth(g), g, x, SV{ang_b, cross(base_com, ang_b)}, qd);  // relative to the root COM velocity
   }
 
-  // Reward evaluation: ALL LANES OF AN ENV WORK ON ONE TERM AT A TIME, terms in a uniform loop (round 3).
-  // The term's descriptor is wave-uniform (every env of a wavefront runs the same task): it is read from the table image in HBM with
-  // scalar loads and the dispatch on its kind is a scalar branch - no lane ever walks a kind it does not evaluate.  Inside a term the
-  // env's lanes split the DATA: the sub-lanes of a limb take the limb's joints in turn (joint j -> sub-lane j % SUB), every lane the
-  // body slots it owns (their contact-sensor state already sits in its scratchpad rows), and one DPP row sum (esum: 4 moves + adds)
-  // gives every lane of the env the term's value.  No tables are published, nothing is gathered.
-  // History: round 1 had this shape with descriptors fetched through LDS + readfirstlane and a latency chain per term (~1100 cycles
-  // per term); round 2 evaluated LANE PER TERM from two per-env LDS tables that the owners of joints / bodies published first -
-  // side by side, but a wavefront then walks every KIND that occurs with a handful of lanes active: 6.4 us of A1's 43 for ~1 us
-  // of arithmetic (profiles/r03b_ab_a1.txt).  Every term cites the reference function it restates; oracle/env.py has the same
-  // arithmetic in fp64.
-  static constexpr int NMY = (JX + SUB - 1) / SUB;  // joints a lane accounts for in joint sums
-  static constexpr int NREL = 2;                    // bodies per lane whose position / velocity relative to the root a term may read
-  struct RewLane {
-    int jid[NMY];                                          // task joint index (bit of a joint mask); -1: none
-    float q[NMY], qd[NMY], tau[NMY], acc[NMY], da[NMY], dq[NMY], lim[NMY];
-    int bidx[Base::MAXOWN];                                // global body index of own slot i; -1: none
-    float hm[Base::MAXOWN];                                // max of the force-norm history of that body
-    int rel_b[NREL];                                       // bodies of T.rew_rel_mask this lane owns (-1: none) ...
-    float rel_hm[NREL];
-    V3 relp[NREL], relv[NREL];                             // ... their position / velocity relative to the root (body_rel)
-  };
-  // what the lane contributes, gathered once per step
-  RL_FN void rew_lane_setup(RewLane& W) {
-#pragma unroll
-    for (int m = 0; m < NMY; ++m) {
-      // local joint sub + SUB * m of the lane's limb: a select over the candidates (SUB == 1: index m itself)
-      int jid = -1;
-      float vq = 0.f, vqd = 0.f, vtau = 0.f, vacc = 0.f, vda = 0.f;
-#pragma unroll
-      for (int c = 0; c < SUB; ++c) {
-        const int j = SUB * m + c;
-        if (j >= JX) continue;
-        const bool me = SUB == 1 || sub == c;
-        vq = me ? q[j] : vq; vqd = me ? qd[j] : vqd; vtau = me ? tau_app[j] : vtau; vacc = me ? qacc[j] : vacc;
-        vda = me ? act[j] - prev_act[j] : vda;
-      }
-      const int jl = SUB * m + (SUB == 1 ? 0 : sub);  // the table rows are read with the lane's own index
-      const bool has = jl < JX;
-      const int jc = has ? jl : 0;
-      if (has && (NW == 0 || L.joint_own[jc])) jid = L.joint_id[jc];
-      W.jid[m] = jid;
-      W.q[m] = vq; W.qd[m] = vqd; W.tau[m] = vtau; W.acc[m] = vacc; W.da[m] = vda;
-      W.dq[m] = vq - L.q0[jc];
-      W.lim[m] = fmaxf(L.soft_lo[jc] - vq, 0.f) + fmaxf(vq - L.soft_hi[jc], 0.f);
-    }
-    const uint64_t rel_mask = uniform_u64(T.rew_rel_mask);
-    const bool any_rel = rel_mask != 0ull;
-    ChainTP C = this->new_chain();
-    // (trunk + limbs instance: the chain words in LDS already hold the kinematics of the final joint positions, step() stage 3)
-    if (any_rel && NW == 0) chain_kinematics<TP>(L, q, C);
-#pragma unroll
-    for (int r = 0; r < NREL; ++r) { W.rel_b[r] = -1; W.rel_hm[r] = 0.f; W.relp[r] = {0.f, 0.f, 0.f}; W.relv[r] = {0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int i = 0; i < Base::MAXOWN; ++i) {
-      const int s = this->own[i];
-      int b = s < 0 ? -1 : L.slot_body[s < 0 ? 0 : s];
-      if (s == 0 && !L.owns_base_body) b = -1;
-      W.bidx[i] = b;
-      W.hm[i] = b >= 0 ? hist_max(s) : 0.f;
-      const bool rel = any_rel && b >= 0 && ((rel_mask >> (b < 0 ? 0 : b)) & 1ull);
-      if (ctx.any(rel)) {  // (the feet sit at the same own-slot index in every limb: one trip for all of them)
-        V3 rp{0.f, 0.f, 0.f}, rv{0.f, 0.f, 0.f};
-        if (rel) body_rel(C, s, rp, rv);
-        const bool first = rel && W.rel_b[0] < 0, second = rel && !first;  // (the host admits at most NREL such bodies per limb)
-        // (componentwise selects: a ?: on a struct becomes a select of two ADDRESSES and puts the whole working set into scratch)
-        auto sel3 = [](bool c, const V3& a, const V3& o) { return V3{c ? a.x : o.x, c ? a.y : o.y, c ? a.z : o.z}; };
-        W.rel_b[0] = first ? b : W.rel_b[0]; W.rel_hm[0] = first ? W.hm[i] : W.rel_hm[0];
-        W.relp[0] = sel3(first, rp, W.relp[0]); W.relv[0] = sel3(first, rv, W.relv[0]);
-        W.rel_b[1] = second ? b : W.rel_b[1]; W.rel_hm[1] = second ? W.hm[i] : W.rel_hm[1];
-        W.relp[1] = sel3(second, rp, W.relp[1]); W.relv[1] = sel3(second, rv, W.relv[1]);
-      }
-    }
-  }
-  // the joint statistic of a joint-sum kind (JS_*; `row` is wave-uniform: a scalar branch)
-  RL_FN static float joint_stat(int row, const RewLane& W, int m) {
-    switch (row) {
-      case JS_TAU2: return W.tau[m] * W.tau[m];
-      case JS_ACC2: return W.acc[m] * W.acc[m];
-      case JS_QD2: return W.qd[m] * W.qd[m];
-      case JS_LIMIT: return W.lim[m];
-      case JS_POWER: return fabsf(W.qd[m] * W.tau[m]);
-      case JS_DEV1: return fabsf(W.dq[m]);
-      case JS_DEV2: return W.dq[m] * W.dq[m];
-      default: return W.da[m] * W.da[m];  // JS_DA2
-    }
-  }
-  RL_FN static bool bit64(uint64_t m, int b) { return b >= 0 && ((m >> (b < 0 ? 0 : b)) & 1ull) != 0ull; }
-  // value of task joint `jt` (held by exactly one lane of the env) x `v`, summed over the lane's joints: feeds an esum
-  RL_FN static float pick_joint(const RewLane& W, int jt, const float (&v)[NMY]) {
-    float r = 0.f;
-#pragma unroll
-    for (int m = 0; m < NMY; ++m) r += W.jid[m] == jt ? v[m] : 0.f;
-    return r;
-  }
-
-  // unweighted value of ONE term (`R`: wave-uniform descriptor), the same in every lane of the env on return
-  RL_FN float coop_term(const RewTab& R, const RewEnv& E, const RewLane& W) {
-    const float gate = E.gate, cmd_norm = E.cmd_norm, bv = E.bv, moving = E.moving;
-    const int32_t* ia = TG.idx_pool_a + R.idx_off;  // index lists: scalar loads from the table image in HBM
-    const int32_t* ib = TG.idx_pool_b + R.idx_off;
-    auto first_c = [&](float cc) { return cc > 0.f && cc < E.fc_hi; };  // ContactSensor.compute_first_contact(step_dt)
-    auto first_a = [&](float ca) { return ca > 0.f && ca < E.fc_hi; };  // compute_first_air(step_dt)
-    // own body slot i as seen by this term: in its body mask?
-    auto in_mask = [&](int i) { return bit64(R.body_mask, W.bidx[i]); };
-    float f = 0.f;
-    switch (R.kind) {
-      case REW_TRACK_LIN_VEL_XY_EXP: case REW_TRACK_ANG_VEL_Z_EXP: case REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: case REW_TRACK_ANG_VEL_Z_WORLD_EXP:
-      case REW_LIN_VEL_Z_L2: case REW_ANG_VEL_XY_L2: case REW_FLAT_ORIENTATION_L2: case REW_UPWARD: case REW_IS_TERMINATED:
-      case REW_HANDSTAND_ORIENTATION_L2:
-        f = scalar_term_value(R, E);  // functions of the env's own scalars: every lane computes the same
-        break;
-      // joint sums [UPSTREAM isaaclab.envs.mdp] + rewards.py:81-90: the statistic of the lane's joints under the term's mask, one row sum
-      case REW_JOINT_TORQUES_L2: case REW_JOINT_ACC_L2: case REW_JOINT_VEL_L2: case REW_JOINT_POS_LIMITS: case REW_JOINT_POWER:
-      case REW_JOINT_DEVIATION_L1: case REW_ACTION_RATE_L2: case REW_STAND_STILL: case REW_JOINT_POS_PENALTY: {
-        float part = 0.f;
-#pragma unroll
-        for (int m = 0; m < NMY; ++m) {
-          const bool in = W.jid[m] >= 0 && ((R.joint_mask >> (W.jid[m] < 0 ? 0 : W.jid[m])) & 1u);
-          part += in ? joint_stat(R.row, W, m) : 0.f;
-        }
-        const float js = ctx.esum(part);
-        if (R.kind == REW_STAND_STILL) f = js * (cmd_norm < R.p[0] ? 1.f : 0.f) * gate;  // rewards.py:93-104
-        else if (R.kind == REW_JOINT_POS_PENALTY) {                                       // rewards.py:107-129
-          const float run = fsqrt(js);
-          f = ((cmd_norm > R.p[2] || bv > R.p[1]) ? run : R.p[0] * run) * gate;
-        } else f = js;
-      } break;
-      case REW_JOINT_MIRROR: {  // rewards.py:259-278: q_a - q_b per pair = ONE signed row sum (a single lane holds each)
-        float part = 0.f;
-        for (int i = 0; i < R.n_idx; ++i) {
-          const int a = ia[i], b = ib[i];
-          float v = 0.f;
-#pragma unroll
-          for (int m = 0; m < NMY; ++m) v += W.jid[m] == a ? W.q[m] : (W.jid[m] == b ? -W.q[m] : 0.f);
-          const float d = ctx.esum(v);
-          part += d * d;
-        }
-        f = part * R.p[0] * gate;
-      } break;
-      case REW_WHEEL_VEL_PENALTY: {  // rewards.py:132-153: pairs (wheel body, wheel joint)
-        const bool running = cmd_norm > R.p[1] || bv > R.p[0];
-        float part = 0.f;
-        for (int i = 0; i < R.n_idx; ++i) {
-          float fa = 0.f, aq = 0.f;
-#pragma unroll
-          for (int o = 0; o < Base::MAXOWN; ++o)
-            if (W.bidx[o] == ia[i]) fa += first_a(tim[this->own[o]][0]) ? 1.f : 0.f;
-#pragma unroll
-          for (int m = 0; m < NMY; ++m) aq += W.jid[m] == ib[i] ? fabsf(W.qd[m]) : 0.f;
-          fa = ctx.esum(fa); aq = ctx.esum(aq);
-          part += (running ? fa : 1.f) * aq;
-        }
-        f = part;
-      } break;
-      case REW_FEET_GAIT: {  // GaitReward, rewards.py:156-256: product of exponentials = exponential of the sum
-        float air[4], con[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float va = 0.f, vc = 0.f;
-#pragma unroll
-          for (int o = 0; o < Base::MAXOWN; ++o)
-            if (W.bidx[o] == ia[i]) { va += tim[this->own[o]][0]; vc += tim[this->own[o]][1]; }
-          air[i] = ctx.esum(va);
-          con[i] = ctx.esum(vc);
-        }
-        const float inv_std = frcp(R.p[0]), me2 = R.p[1] * R.p[1];
-        auto se = [&](float a, float b) { float d = a - b; return fminf(d * d, me2); };
-        float acc = se(air[0], air[1]) + se(con[0], con[1]) + se(air[2], air[3]) + se(con[2], con[3]);
-        acc += se(air[0], con[2]) + se(con[0], air[2]) + se(air[1], con[3]) + se(con[1], air[3]);
-        acc += se(air[0], con[3]) + se(con[0], air[3]) + se(air[2], con[1]) + se(con[2], air[1]);
-        f = ((cmd_norm > R.p[3] || bv > R.p[2]) ? fexp(-acc * inv_std) : 0.f) * gate;
-      } break;
-      case REW_FEET_DISTANCE_Y_EXP:
-      case REW_FEET_DISTANCE_XY_EXP: {  // rewards.py:439-461, 464-505: feet (link frames) against a stance rectangle in the base frame
-        float part = 0.f;
-        for (int i = 0; i < R.n_idx; ++i) {
-#pragma unroll
-          for (int r = 0; r < NREL; ++r) {
-            const float ey = ((i & 1) ? -0.5f : 0.5f) * R.p[1] - W.relp[r].y;
-            const float ex = R.kind == REW_FEET_DISTANCE_XY_EXP ? (i < 2 ? 0.5f : -0.5f) * R.p[2] - W.relp[r].x : 0.f;
-            part += W.rel_b[r] == ia[i] ? ex * ex + ey * ey : 0.f;
-          }
-        }
-        f = fexp(-ctx.esum(part) * frcp(R.p[0])) * gate;
-      } break;
-      case REW_BASE_HEIGHT_L2: {  // rewards.py:616-644; the 3 x 3 base ray caster (velocity_env_cfg.py:78-85): rays spread over the lanes
-        float tgt = R.p[0];
-        if (R.p[1] > 0.5f) {
-          float hsum = 0.f;
-          for (int r9 = li; r9 < 9; r9 += LPE) {
-            const int iy = r9 / 3, ix = r9 - 3 * iy;
-            const float lx = (float)(ix - 1) * 0.05f, ly = (float)(iy - 1) * 0.05f;
-            float hz;
-            V3 nn;
-            terrain_sample(this->u, S.terrain, E.pos.x, E.pos.y, E.yaw_c * lx - E.yaw_s * ly, E.yaw_s * lx + E.yaw_c * ly, hz, nn);
-            hsum += hz;
-          }
-          tgt += ctx.esum(hsum) * (1.0f / 9.0f);
-        }
-        f = (E.pos.z - tgt) * (E.pos.z - tgt) * gate;
-      } break;
-      case REW_FEET_HEIGHT_BODY: case REW_FEET_SLIDE: case REW_FEET_HEIGHT: case REW_HANDSTAND_FEET_HEIGHT_EXP: {
-        // the kinds that look at a foot's position / velocity relative to the root (the lane's cached bodies of T.rew_rel_mask)
-        float a0 = 0.f;
-#pragma unroll
-        for (int r = 0; r < NREL; ++r) {
-          const V3 rp = W.relp[r], rv = W.relv[r];
-          float v = 0.f;
-          if (R.kind == REW_FEET_HEIGHT_BODY) {  // rewards.py:527-554
-            const float er = rp.z - R.p[0];
-            v = er * er * ftanh(R.p[1] * fsqrt(rv.x * rv.x + rv.y * rv.y));
-          } else if (R.kind == REW_FEET_SLIDE) {  // rewards.py:557-587
-            v = W.rel_hm[r] > 1.0f ? fsqrt(rv.x * rv.x + rv.y * rv.y) : 0.f;
-          } else if (R.kind == REW_FEET_HEIGHT) {  // feet_height, world frame (rewards.py:507-524)
-            const V3 vw = E.lin_w + mul(E.Rwb, rv);
-            const float er = E.pos.z + dot(E.Rwb.r2, rp) - R.p[0];
-            v = er * er * ftanh(R.p[1] * fsqrt(vw.x * vw.x + vw.y * vw.y));
-          } else {  // REW_HANDSTAND_FEET_HEIGHT_EXP, .../env/rewards.py:18-28
-            const float dz = E.pos.z + dot(E.Rwb.r2, rp) - R.p[1];
-            v = dz * dz;
-          }
-          a0 += bit64(R.body_mask, W.rel_b[r]) ? v : 0.f;
-        }
-        a0 = ctx.esum(a0);
-        if (R.kind == REW_FEET_SLIDE) f = a0 * gate;
-        else if (R.kind == REW_HANDSTAND_FEET_HEIGHT_EXP) f = fexp(-a0 * frcp(R.p[0]));
-        else f = a0 * moving * gate;
-      } break;
-      case REW_FEET_AIR_TIME_VARIANCE: {  // rewards.py:386-397 (torch.var is unbiased)
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-#pragma unroll
-        for (int o = 0; o < Base::MAXOWN; ++o) {
-          const int s = this->own[o] < 0 ? 0 : this->own[o];
-          const float xa = fminf(tim[s][2], 0.5f), xc = fminf(tim[s][3], 0.5f), w = in_mask(o) ? 1.f : 0.f;
-          a0 += w; a1 += w * xa; a2 += w * xa * xa; a3 += w * xc; a4 += w * xc * xc;
-        }
-        a0 = ctx.esum(a0); a1 = ctx.esum(a1); a2 = ctx.esum(a2); a3 = ctx.esum(a3); a4 = ctx.esum(a4);
-        const float inv_n = frcp(a0), inv_den = frcp(fmaxf(a0 - 1.f, 1.f));
-        f = ((a2 - a1 * a1 * inv_n) + (a4 - a3 * a3 * inv_n)) * inv_den * gate;
-      } break;
-      case REW_FEET_AIR_TIME_POSITIVE_BIPED: {  // rewards.py:363-383
-        float cnt = 0.f, mn = 1e30f;
-#pragma unroll
-        for (int o = 0; o < Base::MAXOWN; ++o) {
-          const int s = this->own[o] < 0 ? 0 : this->own[o];
-          const float ca = tim[s][0], cc = tim[s][1];
-          const bool on = in_mask(o), inc = cc > 0.f;
-          cnt += on && inc ? 1.f : 0.f;
-          mn = on ? fminf(mn, inc ? cc : ca) : mn;
-        }
-        cnt = ctx.esum(cnt);
-        mn = ctx.emin(mn);
-        f = (cnt == 1.f ? fminf(mn, R.p[0]) : 0.f) * moving * gate;
-      } break;
-      default: {  // one sum over the bodies of the term's body mask: the lane's own slots, then the row
-        float a0 = 0.f;
-#pragma unroll
-        for (int o = 0; o < Base::MAXOWN; ++o) {
-          const int s = this->own[o] < 0 ? 0 : this->own[o];
-          const bool on = in_mask(o);
-          float v = 0.f;
-          switch (R.kind) {
-            case REW_UNDESIRED_CONTACTS: v = W.hm[o] > R.p[0] ? 1.f : 0.f; break;          // rewards.py:665-675
-            case REW_CONTACT_FORCES: v = fmaxf(W.hm[o] - R.p[0], 0.f); break;               // [UPSTREAM] contact_forces
-            case REW_FEET_CONTACT_WITHOUT_CMD: case REW_FEET_CONTACT: v = first_c(tim[s][1]) ? 1.f : 0.f; break;  // rewards.py:416-425, 399-413
-            case REW_FEET_AIR_TIME: case REW_HANDSTAND_FEET_AIR_TIME: v = first_c(tim[s][1]) ? tim[s][2] - R.p[0] : 0.f; break;  // rewards.py:340-360
-            case REW_HANDSTAND_FEET_ON_AIR: v = !first_a(tim[s][0]) ? 1.f : 0.f; break;      // .../env/rewards.py:31-37: the feet that have NOT just lifted
-            case REW_FEET_STUMBLE: {                                                           // rewards.py:428-436
-              const float fx = cf[s][0], fy = cf[s][1], fz = cf[s][2];
-              v = fsqrt(fx * fx + fy * fy) > 4.f * fabsf(fz) ? 1.f : 0.f;
-            } break;
-            default: break;
-          }
-          a0 += on ? v : 0.f;
-        }
-        a0 = ctx.esum(a0);
-        switch (R.kind) {
-          case REW_UNDESIRED_CONTACTS: f = a0 * gate; break;
-          case REW_CONTACT_FORCES: f = a0; break;
-          case REW_FEET_CONTACT_WITHOUT_CMD: f = a0 * (cmd_norm < 0.1f ? 1.f : 0.f) * gate; break;
-          case REW_FEET_CONTACT: f = (a0 != R.p[0] ? 1.f : 0.f) * moving * gate; break;
-          case REW_FEET_AIR_TIME: f = a0 * moving * gate; break;
-          case REW_HANDSTAND_FEET_AIR_TIME: f = a0; break;
-          case REW_FEET_STUMBLE: f = (a0 > 0.f ? 1.f : 0.f) * gate; break;
-          case REW_HANDSTAND_FEET_ON_AIR: f = a0 == 0.f ? 1.f : 0.f; break;
-          default: break;
-        }
-      } break;
-    }
-    return f;
-  }
-
-  // a term's descriptor as wave-uniform scalars (scalar loads from the table image in HBM; the readfirstlane pins are no-ops then)
-  RL_FN RewTab uniform_desc(const RewTab& src) const {
-    RewTab R;
-    R.kind = ctx.uniform_i(src.kind); R.weight = ctx.uniform(src.weight);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) R.p[i] = ctx.uniform(src.p[i]);
-    R.joint_mask = (uint32_t)ctx.uniform_i((int)src.joint_mask); R.n_idx = ctx.uniform_i(src.n_idx);
-    R.body_mask = uniform_u64(src.body_mask); R.idx_off = ctx.uniform_i(src.idx_off); R.row = ctx.uniform_i(src.row);
-    return R;
-  }
-
+  // Reward evaluation: LANE PER TERM.  The lanes that own joints / body slots first publish two small per-env tables in LDS -
+  // joint statistics (one row per statistic, one column per task joint) and a body table (contact sensor state, net force,
+  // foot position / velocity relative to the root) - and then lane l of the env evaluates terms l, l + LPE, ... completely:
+  // it reads its term's descriptor from the LDS table image, sums over the joints of its joint mask / the bodies of its body
+  // mask from the tables and applies the term's own arithmetic.  The terms of an env are thus evaluated side by side (the wavefront
+  // executes each reward KIND that occurs once, for all environments and all terms of that kind), instead of one after the other
+  // with a descriptor pinned into SGPRs, a scalar dispatch and a cross-lane reduction per term (round 1: ~1100 cycles per term,
+  // 20 k of a 125 k-cycle step).  Every term cites the reference function it restates; oracle/env.py has the same arithmetic in fp64.
   RL_FN float compute_rewards(bool terminated) {
-    const int n_rewards = ctx.uniform_i(T.n_rewards);
+    const int D = ctx.uniform_i(T.D), n_rewards = ctx.uniform_i(T.n_rewards);
+    float* JT = ctx.rew_tab();
+    float* BT = JT + JS_ROWS * D;
     // episode sums of the terms this lane writes back (t = li, li + LPE, ...): loaded now, consumed after the
     // terms - the HBM round trip overlaps the term arithmetic
     constexpr int NACC = (MAX_T + LPE - 1) / LPE;
@@ -594,10 +540,58 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       const int t = li + LPE * i;
       acc[i] = t < n_rewards ? S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] : 0.f;
     }
-    RewLane W;
-#ifndef RL_ABL_NO_REW_PUBLISH
-    rew_lane_setup(W);
+    // ---- publish the joint statistics (first sub-lane of a limb: its joints; limb 0 also the trunk joints) ...
+#ifdef RL_ABL_NO_REW_PUBLISH
+    if (false) {
+#else
+    if (sub == 0) {
 #endif
+#pragma unroll
+      for (int j = 0; j < JX; ++j) {
+        const int jid = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1;
+        if (jid < 0) continue;
+        const float dq = q[j] - L.q0[j], da = act[j] - prev_act[j];
+        JT[JS_TAU2 * D + jid] = tau_app[j] * tau_app[j];
+        JT[JS_ACC2 * D + jid] = qacc[j] * qacc[j];
+        JT[JS_QD2 * D + jid] = qd[j] * qd[j];
+        JT[JS_LIMIT * D + jid] = fmaxf(L.soft_lo[j] - q[j], 0.f) + fmaxf(q[j] - L.soft_hi[j], 0.f);
+        JT[JS_POWER * D + jid] = fabsf(qd[j] * tau_app[j]);
+        JT[JS_DEV1 * D + jid] = fabsf(dq);
+        JT[JS_DEV2 * D + jid] = dq * dq;
+        JT[JS_DA2 * D + jid] = da * da;
+        JT[JS_Q * D + jid] = q[j];
+        JT[JS_ABSQD * D + jid] = fabsf(qd[j]);
+      }
+    }
+    // ---- ... and the body table (the lane that owns a body slot: sensor state; position / velocity relative to the root for
+    // the bodies some term looks at that way - T.rew_rel_mask)
+    {
+      const uint64_t rel_mask = T.rew_rel_mask;
+      const uint64_t ext_mask = uniform_u64(T.rew_ext_mask);
+      const bool any_rel = ctx.uniform_i((int)(rel_mask != 0ull)) != 0;
+      ChainTP C = this->new_chain();
+      // (trunk + limbs instance: the chain words in LDS already hold the kinematics of the final joint positions, step() stage 3)
+      if (any_rel && NW == 0) chain_kinematics<TP>(L, q, C);
+#pragma unroll
+      for (int i = 0; i < Base::MAXOWN; ++i) {
+        const int s = this->own[i];
+        if (s < 0) continue;
+        const int b = L.slot_body[s];
+        if (b < 0 || (s == 0 && !L.owns_base_body)) continue;
+        float* r = BT + rew_bt_row(ext_mask, b);
+        r[BT_HMAX] = fmaxf(hist_n[s][0], fmaxf(hist_n[s][1], hist_n[s][2]));
+        r[BT_CA] = tim[s][0]; r[BT_CC] = tim[s][1]; r[BT_LA] = tim[s][2]; r[BT_LC] = tim[s][3];
+        if ((ext_mask >> b) & 1ull) { r[BT_FX] = cf[s][0]; r[BT_FY] = cf[s][1]; r[BT_FZ] = cf[s][2]; }
+        if (any_rel && ((rel_mask >> b) & 1ull)) {
+          V3 relp, relv;
+          body_rel(C, s, relp, relv);
+          r[BT_PX] = relp.x; r[BT_PY] = relp.y; r[BT_PZ] = relp.z;
+          r[BT_VX] = relv.x; r[BT_VY] = relv.y; r[BT_VZ] = relv.z;
+        }
+      }
+    }
+    ctx.group_sync();
+    // ---- lane per term
     RL_PHASE(17, "rewards.terms");
     RewEnv E;
     E.gate = clampf(-grav_b.z, 0.f, 0.7f) * (1.0f / 0.7f);
@@ -606,37 +600,47 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     E.fc_hi = T.step_dt + 1e-8f;
     E.moving = E.cmd_norm > 0.1f ? 1.f : 0.f;
     E.terminated = terminated;
+    E.JT = JT; E.BT = BT; E.D = D;
+    E.ext_mask = uniform_u64(T.rew_ext_mask);
     E.cmd = cmd; E.lin_b = lin_b; E.ang_b = ang_b; E.lin_w = lin_w; E.vang = vang; E.grav_b = grav_b; E.pos = pos;
     E.yaw_c = yaw_c; E.yaw_s = yaw_s; E.Rwb = Rwb;
     const float step_dt = ctx.uniform(T.step_dt);
     float* rstage = ctx.rew_stage();
-    float total = 0.f;
+    float mine = 0.f;
+    // slots [0, n_main): any kind; slots [n_main, n_rewards): scalar kinds (the host's schedule, TaskTab::rew_slot)
 #ifdef RL_ABL_NO_REW_TERMS
-    const int n_eval = 0;
+    const int n_main = 0, n_all = 0;
 #else
-    const int n_eval = n_rewards;
+    const int n_main = ctx.uniform_i(T.n_main), n_all = n_rewards;
 #endif
-#pragma unroll 1
-    for (int t = 0; t < n_eval; ++t) {
-      const RewTab R = uniform_desc(TG.rew[t]);
-      const float val = coop_term(R, E, W) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
-      if (li == 0) rstage[t] = val;
-      total += val;  // (the same in every lane of the env)
+    for (int sl = li; sl < n_main; sl += LPE) {
+      const int t = T.rew_slot[sl];
+      const RewTab R = load_rew_desc(T.rew[t]);
+      const float val = term_value(T, this->u, S.terrain, R, E) * R.weight * step_dt;  // RewardManager [UPSTREAM B2]
+      rstage[t] = val;
+      mine += val;
     }
-    ctx.group_sync();
+    for (int sl = n_main + li; sl < n_all; sl += LPE) {
+      const int t = T.rew_slot[sl];
+      const RewTab R = load_rew_desc(T.rew[t]);
+      const float val = scalar_term_value(R, E) * R.weight * step_dt;
+      rstage[t] = val;
+      mine += val;
+    }
+    const float total = ctx.esum(mine);
     // per-term outputs + episode sums: staged through LDS so that each lane's read-modify-writes of
     // `ep_sums` (terms t = li, li + LPE, ...) are issued as one batch instead of one HBM round trip per term
     RL_PHASE(18, "rewards.writeback");
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       const int t = li + LPE * i;
-      if (t < n_eval) {
+      if (t < n_rewards) {
         const float v = rstage[t];
         S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = v;
         S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = acc[i] + v;
       }
     }
-    ctx.group_sync();  // the reward stage shares LDS with the observation rows written next
+    ctx.group_sync();  // the tables share LDS with the observation rows written next
     return total;
   }
 

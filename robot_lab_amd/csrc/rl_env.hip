@@ -48,9 +48,6 @@ struct WaveCtx {
   float* lbscratch;
   float* envs;  // this env's words shared by all its lanes (trunk + limbs instance: per-trunk-link accumulators)
   const void* T;  // TablesT<TP> staged in LDS
-  const void* Tg; // ... and where it was staged from (HBM): scalar loads of wave-uniform entries
-  template <class TT>
-  __device__ const TT& gtables() const { return *static_cast<const TT*>(Tg); }
   float* stage[2];
   float* rstage;
   float* fstage;  // feature vectors of the tile's envs (observations)
@@ -198,7 +195,6 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
   Ctx ctx;
   ctx.T = Tl;
-  ctx.Tg = Tgv;
   ctx.dim[0] = Tl->policy_dim;
   ctx.dim[1] = Tl->critic_dim;
   // (one lane per limb: a group without noise has no staging row - env_terms.h write_group<DIRECT>)
@@ -216,7 +212,7 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + Ctx::EPT * LbLayout<TP>::ENV_WORDS;
   // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
   ctx.fdim = feat_count(Tl->D);
-  ctx.rtdim = 0;  // (round 2's per-env reward tables: gone - env_terms.h compute_rewards)
+  ctx.rtdim = rew_tab_words(Tl->D, Tl->n_bodies, Tl->rew_ext_mask);
   // reward stage | [ observation rows + feature vectors ] = [ reward tables ] (the tables die before the rows are written)
   int region = s0w + s1w + Ctx::EPT * ctx.fdim;
   if (region < Ctx::EPT * ctx.rtdim) s1w += Ctx::EPT * ctx.rtdim - region, region = Ctx::EPT * ctx.rtdim;
@@ -377,7 +373,7 @@ struct Backend {
     const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
     if (s0w + s1w < need) s1w = need - s0w;
     int region = s0w + s1w + Ctx::EPT * feat_count(T.D);
-    
+    region = std::max(region, Ctx::EPT * rew_tab_words(T.D, T.n_bodies, T.rew_ext_mask));
     constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
     constexpr int LB_FREE = TP::NW > 0 ? (LbLayout<TP>::WORDS - LbLayout<TP>::REC) * Ctx::LB_STRIDE : 0;
     const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;

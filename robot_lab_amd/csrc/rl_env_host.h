@@ -380,12 +380,6 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     if (r.kind == RL_REW_FEET_STUMBLE) T.rew_ext_mask |= r.body_mask;  // reads the net force
   }
   T.rew_ext_mask |= T.rew_rel_mask;
-  {  // the lane program caches position / velocity relative to the root of at most 2 bodies per limb (env_terms.h RewLane::NREL)
-    int per_limb[NLANE] = {0, 0, 0, 0};
-    for (int b = 0; b < m.num_bodies; ++b)
-      if (((T.rew_rel_mask >> b) & 1ull) && body_lane[b] >= 0 && body_lane[b] < NLANE && ++per_limb[body_lane[b]] > 2)
-        return fail("reward terms read the kinematics of more than two bodies of one limb (feet_height / feet_slide / feet_distance body lists)");
-  }
   {  // evaluation schedule (TaskTab::rew_slot): scalar kinds last; whatever does not fit the first 16 slots and is scalar goes to the mini-trip
     int ns = 0;
     for (int pass = 0; pass < 2; ++pass)

@@ -249,8 +249,6 @@ struct HostCtx {
   int k_, sub_, e_, sense_ = 0;
   template <class TT>
   const TT& tables() const { return *static_cast<const TT*>(T); }
-  template <class TT>
-  const TT& gtables() const { return *static_cast<const TT*>(T); }
   int k() const { return k_; }
   int sub() const { return sub_; }
   int env() const { return e_; }
