@@ -365,8 +365,7 @@ struct EnvLane {
 
   Ctx& ctx;
   const KState& S;
-  const TablesT<TP>& T;   // the table image staged in LDS
-  const TablesT<TP>& TG;  // the same image in HBM: wave-uniform entries are read from here with scalar loads (reward descriptors)
+  const TablesT<TP>& T;
   const LaneTabT<TP>& L;
   const Uni u;
   int e, k, sub, li, Np;  // env, leg, sub-lane of the leg, lane index inside the env (k * SUB + sub)
@@ -392,7 +391,7 @@ struct EnvLane {
   LsMat<LSS, 3, NOWN> fric;    // [slot][mu_s, mu_d, restitution]
 
   RL_FN EnvLane(Ctx& c, const KState& s)
-      : ctx(c), S(s), T(c.template tables<TablesT<TP>>()), TG(c.template gtables<TablesT<TP>>()), L(c.template tables<TablesT<TP>>().lane[c.k()]), u(make_uni(c, c.template tables<TablesT<TP>>())), tim{c.lane_scratch() + LS::TIM * LSS, {}}, hist_n{c.lane_scratch() + LS::HIST * LSS, {}},
+      : ctx(c), S(s), T(c.template tables<TablesT<TP>>()), L(c.template tables<TablesT<TP>>().lane[c.k()]), u(make_uni(c, c.template tables<TablesT<TP>>())), tim{c.lane_scratch() + LS::TIM * LSS, {}}, hist_n{c.lane_scratch() + LS::HIST * LSS, {}},
         cf{c.lane_scratch() + LS::CF * LSS, {}}, fric{c.lane_scratch() + LS::FRIC * LSS, {}} {
     e = ctx.env();
     k = ctx.k();
