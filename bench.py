@@ -222,6 +222,9 @@ def main():
     env.close()
     if rank == 0 and world == 1 and args.large_batch_envs > N:
         out["large_batch"] = large_batch(args.task, args.large_batch_envs, dev)
+        lb = out["large_batch"]  # the same algorithmic bytes per env-step, priced with the loop time of that leg (no separate kernel timing)
+        lb["achieved_GBps"] = (algo_bytes / N) * lb["envs_per_gpu"] / (lb["ms_per_step"] * 1e-3) / 1e9
+        lb["roofline_frac"] = lb["achieved_GBps"] / HBM_PEAK_GBS
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.task, N, args.cpu_seconds, args.cpu_oracle_envs, args.cpu_oracle_steps)
     if use_dist:
