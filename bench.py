@@ -48,7 +48,8 @@ def parse_args(argv=None):
     ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--task", type=str, default="RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--large-batch-envs", type=int, default=65536, help="0: skip the large-batch leg (rank 0 of a 1-GPU run, after the timed region)")
+    ap.add_argument("--large-batch-envs", type=int, default=65536, help="0: skip the large-batch legs (rank 0 of a 1-GPU run, after the timed region)")
+    ap.add_argument("--mid-batch-envs", type=int, default=8192, help="second such leg (two sub-lanes per limb at this size); skipped with --large-batch-envs 0")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work the baseline leg may spend on the lane-program port")
     ap.add_argument("--cpu-oracle-envs", type=int, default=256)
     ap.add_argument("--cpu-oracle-steps", type=int, default=10)
@@ -222,9 +223,12 @@ def main():
     env.close()
     if rank == 0 and world == 1 and args.large_batch_envs > N:
         out["large_batch"] = large_batch(args.task, args.large_batch_envs, dev)
-        lb = out["large_batch"]  # the same algorithmic bytes per env-step, priced with the loop time of that leg (no separate kernel timing)
-        lb["achieved_GBps"] = (algo_bytes / N) * lb["envs_per_gpu"] / (lb["ms_per_step"] * 1e-3) / 1e9
-        lb["roofline_frac"] = lb["achieved_GBps"] / HBM_PEAK_GBS
+        if args.mid_batch_envs > N and args.mid_batch_envs != args.large_batch_envs:
+            out["mid_batch"] = large_batch(args.task, args.mid_batch_envs, dev)
+        for lb in (out["large_batch"], out.get("mid_batch")):  # the same algorithmic bytes per env-step, priced with the loop time of that leg
+            if lb is not None:
+                lb["achieved_GBps"] = (algo_bytes / N) * lb["envs_per_gpu"] / (lb["ms_per_step"] * 1e-3) / 1e9
+                lb["roofline_frac"] = lb["achieved_GBps"] / HBM_PEAK_GBS
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.task, N, args.cpu_seconds, args.cpu_oracle_envs, args.cpu_oracle_steps)
     if use_dist:

@@ -338,8 +338,8 @@ struct LsFor {  // lane scratchpad layout of an instance
   // link groups a sub-lane evaluates: g = sub + SUB * it over the groups 0 .. CL (merged instances: 1 .. CL, g = 1 + sub + SUB * it)
   static constexpr int NIT = (TP::CL + SUB - TP::M0) / SUB;
   static constexpr int STASH = SUB > 1 ? NIT * TP::SPL : 0;  // every contact of pass 1 is kept for the sensor pass (slot it * SPL + s)
-  static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::MAXOWN;      // 16-lane mapping: rows for the owned slots only
-  using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::MAXOWN), STASH>;
+  static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::template maxown<SUB>();  // 16- / 8-lane mappings: rows for the owned slots only
+  using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::template maxown<SUB>()), STASH>;
 };
 
 template <class Ctx, class TP>
@@ -369,7 +369,7 @@ struct EnvLane {
   const LaneTabT<TP>& L;
   const Uni u;
   int e, k, sub, li, Np;  // env, leg, sub-lane of the leg, lane index inside the env (k * SUB + sub)
-  static constexpr int MAXOWN = SUB == 1 ? NBS : LaneTabT<TP>::MAXOWN;
+  static constexpr int MAXOWN = SUB == 1 ? NBS : LaneTabT<TP>::template maxown<SUB>();
   int own[MAXOWN];        // body slots this lane updates every substep (all of them when a lane is a whole leg)
   float* lt;  // this leg's column of the wave tile:   field f -> lt[f * ROW]
   float* et;  // this env's column of the env tile:    field f -> et[f * EPT]
@@ -399,7 +399,7 @@ struct EnvLane {
     li = k * SUB + sub;
     Np = S.Npad;
 #pragma unroll
-    for (int i = 0; i < MAXOWN; ++i) own[i] = SUB == 1 ? i : L.own_slot[SUB == 1 ? 0 : sub][SUB == 1 ? 0 : i];
+    for (int i = 0; i < MAXOWN; ++i) own[i] = SUB == 1 ? i : (SUB == 2 ? L.own_slot2[sub & 1][i < LaneTabT<TP>::MAXOWN2 ? i : 0] : L.own_slot[sub & 3][i < LaneTabT<TP>::MAXOWN ? i : 0]);
     tim.set_own(own); hist_n.set_own(own); cf.set_own(own); fric.set_own(own);
     lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
     et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();

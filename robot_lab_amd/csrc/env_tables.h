@@ -82,6 +82,10 @@ struct LaneTabT {
   uint32_t sph_base_mask;              // bit g*SPL+s: the sphere in slot (g, s) rides on the BASE link (merged instances; else 0)
   static constexpr int MAXOWN = TP::NBS > 6 ? 4 : 2;
   int32_t own_slot[4][MAXOWN];         // 16-lanes-per-env mapping: the body slots sub-lane s updates (ascending, -1 padded)
+  static constexpr int MAXOWN2 = 4;
+  int32_t own_slot2[2][MAXOWN2];       // 8-lanes-per-env mapping (two sub-lanes per limb; quadrupeds): likewise
+  template <int SUB>
+  static constexpr int maxown() { return SUB == 2 ? MAXOWN2 : MAXOWN; }
 };
 using LaneTab = LaneTabT<TopoMax>;
 
@@ -225,6 +229,8 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
     b.base_body_local = a.base_body_local; b.owns_base_body = a.owns_base_body; b.sph_base_mask = a.sph_base_mask;
     for (int q = 0; q < 4; ++q)
       for (int i = 0; i < LaneTabT<TP>::MAXOWN; ++i) b.own_slot[q][i] = a.own_slot[q][i];
+    for (int q = 0; q < 2; ++q)
+      for (int i = 0; i < LaneTabT<TP>::MAXOWN2; ++i) b.own_slot2[q][i] = a.own_slot2[q][i];
   }
 }
 

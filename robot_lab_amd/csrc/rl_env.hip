@@ -62,17 +62,22 @@ struct WaveCtx {
   template <class TT>
   __device__ const TT& tables() const { return *static_cast<const TT*>(T); }
   __device__ int env_in_tile() const { return lane / LPE; }
-  __device__ int k() const { return SUB == 1 ? (lane & 3) : ((lane >> 2) & 3); }
-  __device__ int sub() const { return SUB == 1 ? 0 : (lane & 3); }
+  __device__ int k() const { return (lane / SUB) & 3; }
+  __device__ int sub() const { return lane & (SUB - 1); }
   int wtile;  // this wavefront's tile (= blockIdx.x with one wavefront per workgroup)
   __device__ int tile() const { return wtile; }
   __device__ int env() const { return wtile * EPT + env_in_tile(); }
   // sum over the 4 legs (inputs replicated over a leg's sub-lanes when SUB == 4: the mirrors then pair
   // lanes of different legs, and a + b == b + a bitwise, so all 16 lanes end with identical bits)
+  // (SUB == 2: a limb is a lane pair, an env a half row of 8 lanes - the quad xor-2 pairs limbs 0 / 1 and 2 / 3, the half mirror
+  // i <-> 7 - i then pairs those sums across the quads)
   __device__ float gsum(float v) const {
     if (SUB == 1) {
       v += dpp<DPP_QUAD_XOR1>(v);
       v += dpp<DPP_QUAD_XOR2>(v);
+    } else if (SUB == 2) {
+      v += dpp<DPP_QUAD_XOR2>(v);
+      v += dpp<DPP_ROW_HALF_MIRROR>(v);
     } else {
       v += dpp<DPP_ROW_HALF_MIRROR>(v);
       v += dpp<DPP_ROW_MIRROR>(v);
@@ -82,7 +87,7 @@ struct WaveCtx {
   __device__ float leg_sum(float v) const {
     if (SUB == 1) return v;
     v += dpp<DPP_QUAD_XOR1>(v);
-    v += dpp<DPP_QUAD_XOR2>(v);
+    if (SUB == 4) v += dpp<DPP_QUAD_XOR2>(v);
     return v;
   }
   __device__ float esum(float v) const { return gsum(leg_sum(v)); }
@@ -90,19 +95,18 @@ struct WaveCtx {
   __device__ float emin(float v) const {
     v = fminf(v, dpp<DPP_QUAD_XOR1>(v));
     v = fminf(v, dpp<DPP_QUAD_XOR2>(v));
-    if (SUB > 1) {
-      v = fminf(v, dpp<DPP_ROW_HALF_MIRROR>(v));
-      v = fminf(v, dpp<DPP_ROW_MIRROR>(v));
-    }
+    if (SUB > 1) v = fminf(v, dpp<DPP_ROW_HALF_MIRROR>(v));
+    if (SUB > 2) v = fminf(v, dpp<DPP_ROW_MIRROR>(v));
     return v;
   }
   // value held by sub-lane J of this lane's leg (DPP quad_perm broadcast; SUB == 4)
   template <int J>
   __device__ float leg_bcast(float v) const {
     if constexpr (SUB == 1) return v;  // a lane is the whole leg
+    else if constexpr (SUB == 2) return dpp<J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);  // lane pairs: [J, J, 2 + J, 2 + J]
     else return dpp<J | (J << 2) | (J << 4) | (J << 6)>(v);
   }
-  __device__ float gshfl(float v, int leg) const { return __shfl(v, SUB == 1 ? ((lane & ~3) | leg) : ((lane & ~15) | (leg << 2) | (lane & 3))); }
+  __device__ float gshfl(float v, int leg) const { return __shfl(v, (lane & ~(LPE - 1)) | (leg * SUB) | (lane & (SUB - 1))); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
   __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }
   __device__ float* rew_stage() const { return rstage + env_in_tile() * MAX_T; }
@@ -284,38 +288,46 @@ struct Backend {
     check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)stream));
     check(hipStreamSynchronize((hipStream_t)stream));  // the host staging vector dies on return
   }
-  // Lanes per limb.  4 (a DPP quad per limb, 16 lanes per env) is the latency mapping: 4096 envs put one wavefront on every SIMD and
-  // each lane's instruction stream is short - but the limb recursion is replicated over the sub-lanes, so a wavefront-instruction
-  // serves 4 envs.  1 (a lane per limb, 16 envs per wavefront) is the throughput mapping: ~1.5x the instructions per wavefront for
-  // 4x the envs, and it fills the chip only from ~12 k envs on.  Measured on A1 Rough (profiles/r03d_sweep_sub1_vs_sub4.txt): one
-  // round of one-lane-per-limb wavefronts takes 2.1x a round of the 16-lane mapping (88.6 vs 43.5 us at one wavefront per CU / SIMD);
-  // beyond the chip the 16-lane mapping scales with the wavefront count (no slack: a wavefront owns its SIMD), the other one in
-  // rounds of `slots` wavefronts (LDS decides how many fit a CU).  RL_ENV_SUB=1|4 forces either; the trunk + limbs instance has 4 only.
+  // Lanes per limb - three mappings of one source, picked from the launch size:
+  //   4 (a DPP quad per limb, 16 lanes per env, 4 envs per wavefront): the latency mapping - 4096 envs put one wavefront on every SIMD
+  //     and each lane's instruction stream is as short as it gets; but the limb recursion is replicated over the sub-lanes;
+  //   2 (a lane pair per limb, 8 envs per wavefront): 1.15x the instructions per wavefront for twice the envs;
+  //   1 (a lane per limb, 16 envs per wavefront): the throughput mapping, ~2x the instructions for 4x the envs.
+  // A wavefront owns its SIMD (300 - 500 registers), so every mapping runs in ROUNDS of `slots` wavefronts (4 per CU when the LDS
+  // allows it - four wavefronts of a workgroup share one staged table image), and a round costs 1 : 1.45 : 2.48 (43.5 / 62.5 / 107
+  // us on A1 Rough with the chip full; Go2W 49.5 / 69.5 / 132: profiles/r03j_sweep_three_mappings.txt).  The choice is the mapping
+  // with the cheapest ceil(wavefronts / slots) x cost; on a near-tie the one with more lanes per env (shorter step latency).
+  // A1 Rough: <= 4096 envs 16 lanes (43 us), 4097 - 8192 envs 8 lanes (8192: 62.5 us = 131 M env-steps/s against 95 M), ~8.5 k - 16 k
+  // envs one lane per limb (16384: 107 us = 153 M), and so on by the same rule.  RL_ENV_SUB=4|2|1 forces a mapping; the trunk + limbs
+  // instance has 4 only.
   int sub = 4;
   int envs_per_wave(const Tables& T, int Npad) {
     sub = 4;
     if (const char* v = std::getenv("RL_ENV_SUB")) {
-      sub = atoi(v) == 1 ? 1 : 4;
+      sub = atoi(v) == 1 ? 1 : (atoi(v) == 2 && T.NW == 0 ? 2 : 4);
     } else if (T.NW == 0) {
-      size_t lds1 = 0;
+      const size_t tb = staged_bytes(T);
+      size_t need[3] = {0, 0, 0};  // LDS of a single-wavefront workgroup, mappings 4 / 2 / 1
       switch (T.CL + (T.merged ? 100 : 0)) {
-        case 3: lds1 = lds_need<TopoQuad3, 1>(T); break;
-        case 4: lds1 = lds_need<TopoQuad4, 1>(T); break;
-        case 104: lds1 = lds_need<TopoQuad4M, 1>(T); break;
+        case 3: need[0] = lds_need<TopoQuad3, 4>(T); need[1] = lds_need<TopoQuad3, 2>(T); need[2] = lds_need<TopoQuad3, 1>(T); break;
+        case 4: need[0] = lds_need<TopoQuad4, 4>(T); need[1] = lds_need<TopoQuad4, 2>(T); need[2] = lds_need<TopoQuad4, 1>(T); break;
+        case 104: need[0] = lds_need<TopoQuad4M, 4>(T); need[1] = lds_need<TopoQuad4M, 2>(T); need[2] = lds_need<TopoQuad4M, 1>(T); break;
         default: break;
       }
-      if (lds1 > 0 && lds1 <= 160 * 1024) {
+      const int subs[3] = {4, 2, 1};
+      const double cost[3] = {1.0, 1.45, 2.48};
+      double best = 0.0, t[3] = {0.0, 0.0, 0.0};
+      for (int i = 0; i < 3; ++i) {
+        if (need[i] == 0 || need[i] > 160 * 1024) continue;
         // wavefronts a CU holds: single-wavefront workgroups each stage their own table image, a four-wavefront workgroup shares one
-        const size_t tb = staged_bytes(T);
-        const size_t per_cu = (tb + 4 * (lds1 - tb) <= 160 * 1024) ? 4 : std::min<size_t>(4, (160 * 1024) / lds1);
-        const double slots = (double)n_cu * (double)per_cu;
-        const double t1 = 2.1 * std::ceil((Npad / 16) / slots);                // in rounds of the 16-lane mapping
-        const double t4 = std::max(1.0, (Npad / 4) / (4.0 * (double)n_cu));
-        if (t1 < 0.95 * t4) sub = 1;
-        if (std::getenv("RL_ENV_DEBUG"))
-          fprintf(stderr, "rl_env: one lane per limb needs %zu B of LDS per wavefront (%u B of them tables): %.0f wavefront slots; %d envs -> %.2f vs %.2f rounds -> %d lane(s) per limb\n",
-                  lds1, (unsigned)staged_bytes(T), slots, Npad, t1, t4, sub);
+        const size_t per_cu = (tb + 4 * (need[i] - tb) <= 160 * 1024) ? 4 : std::min<size_t>(4, (160 * 1024) / need[i]);
+        const double slots = (double)n_cu * (double)per_cu, waves = (double)(Npad / (16 / subs[i]));
+        t[i] = cost[i] * std::ceil(waves / slots);
+        if (best == 0.0 || t[i] < 0.97 * best) { best = t[i]; sub = subs[i]; }
       }
+      if (std::getenv("RL_ENV_DEBUG"))
+        fprintf(stderr, "rl_env: %d envs: rounds x cost of 4 / 2 / 1 lanes per limb = %.2f / %.2f / %.2f (LDS per wavefront %zu / %zu / %zu B, tables %zu B) -> %d lane(s) per limb\n",
+                Npad, t[0], t[1], t[2], need[0], need[1], need[2], tb, sub);
     }
     return 16 / sub;
   }
@@ -386,10 +398,13 @@ struct Backend {
     const int key = (T.CL + (T.merged ? 100 : 0)) * 10 + sub;
     switch (key) {
       case 31: lds_bytes = lds_need<TopoQuad3, 1>(T); break;
+      case 32: lds_bytes = lds_need<TopoQuad3, 2>(T); break;
       case 34: lds_bytes = lds_need<TopoQuad3, 4>(T); break;
       case 41: lds_bytes = lds_need<TopoQuad4, 1>(T); break;
+      case 42: lds_bytes = lds_need<TopoQuad4, 2>(T); break;
       case 44: lds_bytes = lds_need<TopoQuad4, 4>(T); break;
       case 1041: lds_bytes = lds_need<TopoQuad4M, 1>(T); break;
+      case 1042: lds_bytes = lds_need<TopoQuad4M, 2>(T); break;
       case 1044: lds_bytes = lds_need<TopoQuad4M, 4>(T); break;
       case 71:  // 64 limbs per wavefront: 115 KB of limb-shared words + 30 KB of sensor rows.  The CPU lane emulator runs it (tests/emu); no kernel is built for it
         err = "the one-lane-per-limb mapping (RL_ENV_SUB=1) of the trunk + limbs instance needs more LDS than a CU has";
@@ -418,6 +433,15 @@ struct Backend {
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 34
       case 34: return launch_cl<TopoQuad3, 4>(S, T, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 32
+      case 32: return launch_cl<TopoQuad3, 2>(S, T, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 42
+      case 42: return launch_cl<TopoQuad4, 2>(S, T, lds_bytes, st);
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 1042
+      case 1042: return launch_cl<TopoQuad4M, 2>(S, T, lds_bytes, st);
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 44
       case 44: return launch_cl<TopoQuad4, 4>(S, T, lds_bytes, st);

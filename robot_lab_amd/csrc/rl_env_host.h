@@ -264,6 +264,18 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
         L.own_slot[q][n++] = sl;
       }
     }
+    // ... and with two sub-lanes per limb (quadrupeds; the trunk + limbs instance has the 16-lane mapping only)
+    for (int q = 0; q < 2; ++q) {
+      int n = 0;
+      for (int i = 0; i < LaneTab::MAXOWN2; ++i) L.own_slot2[q][i] = -1;
+      for (int sl = 0; sl < NBS && NW == 0; ++sl) {
+        const bool used = L.slot_body[sl] >= 0 || (sl == 0 && L.base_body_local >= 0);
+        const int gq = merge ? (L.slot_grp[sl] == 0 ? 0 : (L.slot_grp[sl] - 1) % 2) : L.slot_grp[sl] % 2;
+        if (!used || gq != q) continue;
+        if (n >= LaneTab::MAXOWN2) return fail("too many body slots on one sub-lane (two sub-lanes per limb)");
+        L.own_slot2[q][n++] = sl;
+      }
+    }
   }
   // bodies the events / the scanner address
   {

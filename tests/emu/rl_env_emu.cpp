@@ -271,7 +271,7 @@ struct HostCtx {
     team->slot[li()] = v;
     team->barrier(li());
     const float* p = team->slot + k_ * SUB;
-    float s = (p[0] + p[1]) + (p[2 % SUB] + p[3 % SUB]);
+    float s = SUB == 2 ? p[0] + p[1] : (p[0] + p[1]) + (p[2 % SUB] + p[3 % SUB]);
     team->barrier(li());
     return s;
   }
@@ -392,11 +392,11 @@ struct Backend {
   int sub = 1;  // RL_EMU_SUB=4 selects the 16-lanes-per-env mapping (16 host threads per env: slow)
   int activate() { return 0; }
   int init(int) {
-    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : 1;
+    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : (std::atoi(v) == 2 ? 2 : 1);
     return 0;
   }
   int envs_per_wave(const rl::Tables&, int) {
-    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : 1;
+    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : (std::atoi(v) == 2 ? 2 : 1);
     return 16 / sub;
   }
   int configure(const rl::Tables&) { return 0; }
@@ -410,6 +410,9 @@ struct Backend {
       case 31: run<rl::TopoQuad3, 1>(S, T); return 0;
       case 41: run<rl::TopoQuad4, 1>(S, T); return 0;
       case 34: run<rl::TopoQuad3, 4>(S, T); return 0;
+      case 32: run<rl::TopoQuad3, 2>(S, T); return 0;
+      case 42: run<rl::TopoQuad4, 2>(S, T); return 0;
+      case 1042: run<rl::TopoQuad4M, 2>(S, T); return 0;
       case 44: run<rl::TopoQuad4, 4>(S, T); return 0;
       case 1041: run<rl::TopoQuad4M, 1>(S, T); return 0;
       case 1044: run<rl::TopoQuad4M, 4>(S, T); return 0;

@@ -102,10 +102,14 @@ def test_resets_and_logs(emu_lib):
 # (merged, with the trunk's six spheres in the WHEEL groups: flagged slots on sub-lanes that do not own the trunk body's slot)
 @pytest.mark.parametrize("task,N,steps,merge", [(TASKS[1], 16, 2, None), (TASKS[3], 8, 2, None), (TASKS[5], 4, 3, None),
                                                 (TASKS[3], 8, 2, "0"), ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", 8, 2, None)])
-def test_sixteen_lane_mapping_matches_oracle(task, N, steps, merge, emu_lib, monkeypatch):
+@pytest.mark.parametrize("sub", ["4", "2"])
+def test_sixteen_lane_mapping_matches_oracle(task, N, steps, merge, sub, emu_lib, monkeypatch):
     """The 16-lanes-per-env mapping (a DPP quad per limb; the default on the GPU: link groups dealt to the sub-lanes, contact
-    stash, the trunk instance's limb-shared records) run by 16 host threads per env."""
-    monkeypatch.setenv("RL_EMU_SUB", "4")
+    stash, the trunk instance's limb-shared records) run by 16 host threads per env; and the 8-lane mapping (two sub-lanes per limb:
+    what 5 - 11 k quadruped envs per GPU launch - each sub-lane takes two link groups)."""
+    if sub == "2" and "G1" in task:
+        pytest.skip("the trunk + limbs instance has the 16-lane mapping only")
+    monkeypatch.setenv("RL_EMU_SUB", sub)
     if merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
     desc, ora, nat = make_pair(task, N, 21, emu_lib)

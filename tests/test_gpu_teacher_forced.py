@@ -36,6 +36,9 @@ CONFIGS = [
     # shape - four wavefronts per workgroup, the critic row written straight to HBM: "sub1" forces it at this size
     ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 4096, "sub1"),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 4096, "sub1"),
+    # two sub-lanes per limb (8 envs per wavefront: what 5 - 11 k quadruped envs per GPU launch), likewise forced at this size
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 4096, "sub2"),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 4096, "sub2"),
 ]
 
 
@@ -52,8 +55,8 @@ def test_one_step_from_shared_state_full_size(task, N, merge, monkeypatch):
 
     from robot_lab_amd.env import ManagerBasedRLEnv
 
-    if merge == "sub1":
-        monkeypatch.setenv("RL_ENV_SUB", "1")
+    if merge in ("sub1", "sub2"):
+        monkeypatch.setenv("RL_ENV_SUB", merge[-1])
         monkeypatch.setenv("RL_ENV_WG", "-4")
     elif merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
