@@ -86,7 +86,9 @@ def test_short_horizon_parity(task, wg, merge, monkeypatch):
         two.close(f"reward[{s}]", rew.cpu().numpy(), lambda e: e.reward, 1e-3, 2e-5)
         ok = ~two.done_differs
         assert np.array_equal((term | tout).cpu().numpy()[ok], (ora.terminated | ora.time_outs)[ok])
-    assert two.done_differs.mean() <= 0.15
+    # (measured on the round-3 build: 0 of N on every id and shape - five steps after a reset the robots are still falling and nothing
+    # sits on a switch; one env is allowed to flip with a future build's round-off, the 15 % of round 2 would have hidden a broken lane)
+    assert two.done_differs.sum() <= 1
     d = env.scene["robot"].data
     two.close("root", d.root_state_w.cpu().numpy(), oracle_root_state, 2e-3, 2e-4)
     two.close("q", d.joint_pos.cpu().numpy(), lambda e: e.st["q"], 2e-3, 2e-4)
@@ -101,9 +103,10 @@ def test_short_horizon_parity(task, wg, merge, monkeypatch):
     got = env.read_state()
     got.update(reward=rew.cpu().numpy(), reward_terms=env.reward_terms().cpu().numpy(), done=(term | tout).cpu().numpy(),
                obs_policy=obs["policy"].cpu().numpy(), obs_critic=obs["critic"].cpu().numpy())
-    # (small batch: a few envs on a switch are already > 1.5 %; six twins: the envelope is the MAXIMUM response over the twins, and three
-    # draws leave it 1.4x short for one env in a few hundred)
-    teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=0.35)
+    # (six twins: the envelope is the MAXIMUM response over the twins, and three draws leave it 1.4x short for one env in a few hundred;
+    # the switch mask: 0 of N on every id and shape of the round-3 build - at most three envs, where round 2 tolerated a third of the batch)
+    rep = teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=3.0 / N)
+    print(f"\n[parity-small] {task} wg={wg!r} merge={merge}: done_differs {two.done_differs.mean():.3f}, teacher-forced mask {rep['masked']}/{N}")
     env.close()
 
 

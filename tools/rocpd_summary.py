@@ -28,7 +28,8 @@ def main(path):
     total = sum(sum(v) for v in stats.values())
     print(f"# {path}")
     print(f"# {len(rows)} dispatches, {total / 1e6:.3f} ms total kernel time")
-    print(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}  grid wg lds scratch sgpr vgpr agpr")
+    print(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}  grid wg lds scratch sgpr vgpr* agpr*")
+    print("# (* rocprofv3's arch_vgpr_count / accum_vgpr_count columns: NOT the allocation - the env-step kernel allocates 256 VGPR + 54-58 AGPR per llvm-readelf --notes / the .s metadata, tools/kbuild.sh)")
     for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1])):
         g, w, lds, scr = meta[k]
         r = regs.get(k, (0, 0, 0, 0, 0))
