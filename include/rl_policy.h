@@ -34,6 +34,12 @@ typedef struct rl_mlp rl_mlp;
 int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, const float* const* weights,
                   const float* const* biases, int32_t device, rl_mlp** out);
 
+/* New parameters for an existing network, in place (same HOST layout as rl_mlp_create): what a training loop calls after every
+ * optimiser step so that the next rollout runs the updated actor / critic (train.py:224 -> rsl_rl OnPolicyRunner.learn: `alg.update()`
+ * is followed by `alg.act()` on the same modules).  The device images keep their addresses, so a captured graph that launches this
+ * network stays valid.  Waits for the launches already queued on `stream`, then copies synchronously. */
+int rl_mlp_set_weights(rl_mlp* m, const float* const* weights, const float* const* biases, void* stream);
+
 /* y[n_rows][dims[n_layers]] = MLP(x[n_rows][dims[0]]); x, y: device pointers, row-major; stream-ordered. */
 int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream);
 

@@ -672,6 +672,7 @@ struct rl_mlp {
   MlpParams* dP = nullptr;  // device copy (rl_mlp_forward_pair)
   int device = 0;
   int cols[2] = {0, 0};  // split path: widest (32-padded) layer input held by the even / the odd activation buffer
+  int dims[RL_MLP_MAX_LAYERS + 1] = {};  // true layer widths (rl_mlp_set_weights re-reads nn.Linear images of these shapes)
   std::vector<void*> allocs;
 };
 
@@ -723,9 +724,51 @@ int launch_split(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* 
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
 }
+// host re-layout of one layer's parameters (nn.Linear [out][in]) into the two device images the kernels read, and the copy
+int upload_layer(rl_mlp* m, int l, const float* weights, const float* biases) {
+  if (!weights || !biases) return fail("null layer pointer");
+  const int K = m->dims[l], N = m->dims[l + 1];
+  const int KB = m->P.KB[l], NT = 8 * m->P.NT8[l], KB32 = m->P.KB32[l], NTS = m->P.NTS[l];
+  std::vector<float> Wf((size_t)KB * NT * 64 * 4, 0.f), bp((size_t)NT * 16, 0.f);
+  for (int n = 0; n < N; ++n) bp[n] = biases[n];
+  for (int kb = 0; kb < KB; ++kb)
+    for (int t = 0; t < NT; ++t)
+      for (int ln = 0; ln < 64; ++ln)
+        for (int sI = 0; sI < 4; ++sI) {
+          const int k = kb * 16 + 4 * sI + (ln >> 4), n = t * 16 + (ln & 15);  // B[k][n] = W[n][k] (nn.Linear: [out][in])
+          if (k < K && n < N) Wf[(((size_t)kb * NT + t) * 64 + ln) * 4 + sI] = weights[(size_t)n * K + k];
+        }
+  std::vector<uint16_t> Wsp((size_t)KB32 * NTS * 3 * 64 * 8, 0);
+  for (int kb = 0; kb < KB32; ++kb)
+    for (int t = 0; t < NTS; ++t)
+      for (int ln = 0; ln < 64; ++ln)
+        for (int j = 0; j < 8; ++j) {
+          const int k = kb * 32 + 8 * (ln >> 4) + j, n = t * 16 + (ln & 15);
+          if (k < K && n < N) {
+            const Split3 sp = split3(weights[(size_t)n * K + k]);
+            const size_t o = ((((size_t)kb * NTS + t) * 3) * 64 + ln) * 8 + j;
+            Wsp[o] = sp.h; Wsp[o + 512] = sp.m; Wsp[o + 1024] = sp.l;
+          }
+        }
+  if (hipMemcpy(const_cast<float*>(m->P.W[l]), Wf.data(), Wf.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(const_cast<float*>(m->P.b[l]), bp.data(), bp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(const_cast<uint16_t*>(m->P.Ws[l]), Wsp.data(), Wsp.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+    return fail("weight upload failed");
+  return 0;
+}
 }  // namespace
 
 extern "C" {
+
+int rl_mlp_set_weights(rl_mlp* m, const float* const* weights, const float* const* biases, void* stream) {
+  if (!m || !weights || !biases) return fail("null argument");
+  if (hipSetDevice(m->device) != hipSuccess) return fail("hipSetDevice failed");
+  // launches in flight on the caller's stream read the old images: let them finish (the copies below are synchronous)
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail("stream synchronisation failed");
+  for (int l = 0; l < m->P.n_layers; ++l)
+    if (upload_layer(m, l, weights[l], biases[l])) return -1;
+  return 0;
+}
 
 int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, const float* const* weights, const float* const* biases,
                   int32_t device, rl_mlp** out) {
@@ -741,53 +784,28 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
   m->P.n_layers = n_layers; m->P.act = activation; m->P.in_dim = dims[0]; m->P.out_dim = dims[n_layers];
   for (int l = 0; l < n_layers; ++l) {
     const int K = dims[l], N = dims[l + 1];
+    m->dims[l] = K; m->dims[l + 1] = N;
     // layer l contracts over the 16-padded width of its input; its output is padded to 128 columns (groups of 8 tiles).
     // For l > 0 the input's padding columns were written as zeros by layer l-1 (128-padded >= 16-padded).
     const int KB = (K + 15) / 16, NT8 = (N + 127) / 128, NT = 8 * NT8;
     m->P.KB[l] = KB; m->P.N[l] = N; m->P.NT8[l] = NT8;
-    std::vector<float> Wf((size_t)KB * NT * 64 * 4, 0.f), bp((size_t)NT * 16, 0.f);
-    for (int n = 0; n < N; ++n) bp[n] = biases[l][n];
-    for (int kb = 0; kb < KB; ++kb)
-      for (int t = 0; t < NT; ++t)
-        for (int ln = 0; ln < 64; ++ln)
-          for (int sI = 0; sI < 4; ++sI) {
-            const int k = kb * 16 + 4 * sI + (ln >> 4), n = t * 16 + (ln & 15);  // B[k][n] = W[n][k] (nn.Linear: [out][in])
-            if (k < K && n < N) Wf[(((size_t)kb * NT + t) * 64 + ln) * 4 + sI] = weights[l][(size_t)n * K + k];
-          }
-    void *dW = nullptr, *db = nullptr;
-    if (hipMalloc(&dW, Wf.size() * 4) != hipSuccess || hipMalloc(&db, bp.size() * 4) != hipSuccess) {
-      rl_mlp_destroy(m);
-      return fail("device allocation failed");
-    }
-    m->allocs.push_back(dW); m->allocs.push_back(db);
-    (void)hipMemcpy(dW, Wf.data(), Wf.size() * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
-    m->P.W[l] = (const float*)dW; m->P.b[l] = (const float*)db;
     // split-precision image: 32-deep k blocks; a non-last layer also computes the zero columns that pad its output to the next
     // layer's 32-deep blocks (never more tiles than the 128-column padding of the bias vector holds)
     const int KB32 = (K + 31) / 32, NTS = l + 1 < n_layers ? 2 * ((N + 31) / 32) : (N + 15) / 16;
     m->P.KB32[l] = KB32; m->P.NTS[l] = NTS;
     m->cols[l & 1] = std::max(m->cols[l & 1], KB32 * 32);
-    std::vector<uint16_t> Wsp((size_t)KB32 * NTS * 3 * 64 * 8, 0);
-    for (int kb = 0; kb < KB32; ++kb)
-      for (int t = 0; t < NTS; ++t)
-        for (int ln = 0; ln < 64; ++ln)
-          for (int j = 0; j < 8; ++j) {
-            const int k = kb * 32 + 8 * (ln >> 4) + j, n = t * 16 + (ln & 15);
-            if (k < K && n < N) {
-              const Split3 sp = split3(weights[l][(size_t)n * K + k]);
-              const size_t o = ((((size_t)kb * NTS + t) * 3) * 64 + ln) * 8 + j;
-              Wsp[o] = sp.h; Wsp[o + 512] = sp.m; Wsp[o + 1024] = sp.l;
-            }
-          }
-    void* dWs = nullptr;
-    if (hipMalloc(&dWs, Wsp.size() * 2) != hipSuccess) {
+    void *dW = nullptr, *db = nullptr, *dWs = nullptr;
+    if (hipMalloc(&dW, (size_t)KB * NT * 64 * 4 * 4) != hipSuccess || hipMalloc(&db, (size_t)NT * 16 * 4) != hipSuccess ||
+        hipMalloc(&dWs, (size_t)KB32 * NTS * 3 * 64 * 8 * 2) != hipSuccess) {
       rl_mlp_destroy(m);
       return fail("device allocation failed");
     }
-    m->allocs.push_back(dWs);
-    (void)hipMemcpy(dWs, Wsp.data(), Wsp.size() * 2, hipMemcpyHostToDevice);
-    m->P.Ws[l] = (const uint16_t*)dWs;
+    m->allocs.push_back(dW); m->allocs.push_back(db); m->allocs.push_back(dWs);
+    m->P.W[l] = (const float*)dW; m->P.b[l] = (const float*)db; m->P.Ws[l] = (const uint16_t*)dWs;
+    if (upload_layer(m, l, weights[l], biases[l])) {
+      rl_mlp_destroy(m);
+      return -1;
+    }
   }
   void* dP = nullptr;
   if (hipMalloc(&dP, sizeof(MlpParams)) != hipSuccess) {

@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 POLICY_LIB = os.path.join(_HERE, "csrc", "librl_policy_hip.so")
-POLICY_EXPORTS = ["rl_mlp_create", "rl_mlp_forward", "rl_mlp_forward_pair", "rl_mlp_in_dim", "rl_mlp_out_dim", "rl_mlp_destroy", "rl_mlp_last_error"]
+POLICY_EXPORTS = ["rl_mlp_create", "rl_mlp_set_weights", "rl_mlp_forward", "rl_mlp_forward_pair", "rl_mlp_in_dim", "rl_mlp_out_dim", "rl_mlp_destroy", "rl_mlp_last_error"]
 ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2}
 _lib = None
 
@@ -35,6 +35,7 @@ def load_policy_library(path: str | None = None) -> C.CDLL:
     lib = C.CDLL(path)
     fpp = C.POINTER(C.POINTER(C.c_float))
     lib.rl_mlp_create.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, fpp, fpp, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.rl_mlp_set_weights.argtypes = [C.c_void_p, fpp, fpp, C.c_void_p]
     lib.rl_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rl_mlp_forward_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rl_mlp_in_dim.argtypes = [C.c_void_p]
@@ -70,6 +71,7 @@ class MlpPolicy:
         if rc != 0:
             raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
         self.in_dim, self.out_dim = dims[0], dims[-1]
+        self._shapes = [w.shape for w in ws]
         self._out = None
 
     @classmethod
@@ -78,6 +80,26 @@ class MlpPolicy:
         idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith(prefix + ".") and k.endswith(".weight")})
         to_np = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)  # noqa: E731
         return cls([to_np(sd[f"{prefix}.{i}.weight"]) for i in idx], [to_np(sd[f"{prefix}.{i}.bias"]) for i in idx], activation, **kw)
+
+    def set_weights(self, weights, biases):
+        """New parameters in place (`rl_mlp_set_weights`): after an optimiser step of a training loop.  Same shapes as at creation;
+        the device images keep their addresses (captured graphs that launch this network stay valid)."""
+        to_np = lambda t: np.ascontiguousarray((t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)).astype(np.float32, copy=False))  # noqa: E731
+        ws, bs = [to_np(w) for w in weights], [to_np(b) for b in biases]
+        if [w.shape for w in ws] != self._shapes or [b.shape for b in bs] != [(s[0],) for s in self._shapes]:
+            raise ValueError("set_weights: layer shapes differ from the network's")
+        fp = C.POINTER(C.c_float)
+        n = len(ws)
+        wp = (fp * n)(*[w.ctypes.data_as(fp) for w in ws])
+        bp = (fp * n)(*[b.ctypes.data_as(fp) for b in bs])
+        stream = self._torch.cuda.current_stream(self.device).cuda_stream
+        if self.lib.rl_mlp_set_weights(self.handle, wp, bp, C.c_void_p(stream)) != 0:
+            raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
+
+    def load_linear_layers(self, module):
+        """`set_weights` from the nn.Linear layers of a torch module (an `nn.Sequential` of Linear / activation pairs, rsl_rl's actor / critic)."""
+        lin = [m for m in module.modules() if isinstance(m, self._torch.nn.Linear)]
+        self.set_weights([m.weight for m in lin], [m.bias for m in lin])
 
     def _prepare(self, obs):
         torch = self._torch
