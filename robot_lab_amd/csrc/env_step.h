@@ -152,7 +152,10 @@ RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, con
   const float ox = clampf(floorf(gx), tb.lox, tb.hix), oy = clampf(floorf(gy), tb.loy, tb.hiy);
   p.fx = clampf(gx - ox, 0.f, 1.f);
   p.fy = clampf(gy - oy, 0.f, 1.f);
-  const int ix = tb.cx + (int)ox, iy = tb.cy + (int)oy;
+  // the integer clamp is the memory-safety net: a non-finite or astronomically large root position (a diverged env) makes the float
+  // arithmetic above meaningless - (int)NaN is 0, (float)(-cx) rounds - and an unclamped cell index then reads far outside the
+  // heightfield (a GPU memory fault took the whole launch down on a model with a zero velocity limit, profiles/r03p_all_tasks.txt)
+  const int ix = imin(imax(tb.cx + (int)ox, 0), u.nx - 2), iy = imin(imax(tb.cy + (int)oy, 0), u.ny - 2);
   // (iy, iy+1) are adjacent in memory: two 8-byte loads per query instead of four 4-byte ones
   const float* b = hf + (uint32_t)ix * (uint32_t)u.ny + (uint32_t)iy;
   F2 r0 = ld2(b), r1 = ld2(b + u.ny);

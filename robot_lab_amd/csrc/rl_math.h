@@ -90,6 +90,8 @@ RL_FN void fsincos(float x, float& s, float& c) {
 #else
 RL_FN void fsincos(float x, float& s, float& c) { s = sinf(x); c = cosf(x); }
 #endif
+RL_FN int imin(int a, int b) { return a < b ? a : b; }
+RL_FN int imax(int a, int b) { return a > b ? a : b; }
 RL_FN M3 rodrigues(V3 a, float ang) {
   float s, c;
   fsincos(ang, s, c);

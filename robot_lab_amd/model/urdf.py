@@ -369,6 +369,13 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
                 hi = float(lim.get("upper", "1e9")) if (lim is not None and jtype == "revolute") else 1e9
                 vl = float(lim.get("velocity", "1e9")) if lim is not None else 1e9
                 ef = float(lim.get("effort", "1e9")) if lim is not None else 1e9
+                # CAD exporters write velocity="0" effort="0" for "not specified" (agibot/d1/urdf/edu.urdf:99-103): a literal zero would
+                # freeze the joint - which no importer does; like the missing attribute it means no limit from the URDF (the actuator
+                # cfg sets effort / velocity limits of its own, assets/agibot.py)
+                if vl <= 0.0:
+                    vl = 1e9
+                if ef <= 0.0:
+                    ef = 1e9
                 ax = _vec(j.find("axis").get("xyz")) if j.find("axis") is not None else np.array([1.0, 0, 0])
                 model.links.append(Link(cname, lidx, j.get("name"), jtype, pos + rot @ jpos, rot @ jrot, ax / np.linalg.norm(ax), lo, hi, vl, ef))
                 queue.append((cname, len(model.links) - 1, np.zeros(3), np.eye(3), None))

@@ -191,3 +191,20 @@ def test_mesh_vertex_readers(tmp_path):
     obj = tmp_path / "box.obj"
     obj.write_text("# box\n" + "".join(f"v {x} {y} {z}\n" for x in (0, 1) for y in (0, 2) for z in (0, 3)) + "vn 0 0 1\nf 1 2 3\n")
     assert _read_mesh_vertices(str(obj)).shape == (8, 3) and _read_mesh_vertices(str(obj)).max() == 3.0
+
+
+def test_no_bundle_freezes_a_joint():
+    """A URDF velocity limit of 0 (CAD exporters write it for "not specified": agibot/d1/urdf/edu.urdf:99-103) must not reach the
+    descriptor: the solver would compute joint velocities and the integrator would clamp them to zero - energy from nowhere (Agibot D1
+    diverged within ~100 steps until round 3).  Likewise no massless robot and no empty limit interval."""
+    import glob
+
+    from robot_lab_amd.scene import DATA_DIR, load_bundle
+
+    for path in sorted(glob.glob(os.path.join(DATA_DIR, "*.json"))):
+        m = load_bundle(os.path.basename(path)[:-5])[0].model
+        D = m.num_dof
+        vl = np.array([m.joint_vel_limit[i] for i in range(D)])
+        assert (vl > 0.1).all(), (path, vl)
+        assert all(m.joint_upper[i] > m.joint_lower[i] for i in range(D)), path
+        assert sum(m.body_mass[i] for i in range(m.num_bodies)) > 1.0, path
