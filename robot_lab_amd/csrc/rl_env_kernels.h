@@ -1,0 +1,303 @@
+// rl_env_kernels.h - the gfx950 wavefront context, the env kernel and its launch helpers: what every translation unit of the env
+// library shares.  The library is built from three of them so that hipcc compiles the kernels of the three lane mappings side by side
+// (rl_env.hip: 16 lanes per env + the C-ABI; rl_env_sub2.hip / rl_env_sub1.hip: 8 and 4 lanes per env - 33 kernels of ~10 s each);
+// -DRL_ENV_SINGLE_TU puts everything into rl_env.hip (tools/build_variant.sh, tools/kbuild.sh).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+
+#define RL_FN __host__ __device__ __forceinline__
+#include "env_aos.h"
+#include "env_terms.h"
+
+namespace {
+
+using namespace rl;
+
+template <int CTRL>
+__device__ inline float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15 - i of a 16-lane row
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7 - i of each half row
+
+// Wavefront context.  SUB_ = 1: a lane per leg, 4 lanes per env (a DPP quad), 16 envs per wavefront.
+// SUB_ = 4: a DPP quad per leg, 16 lanes per env (a DPP row), 4 envs per wavefront -> 4096 envs fill
+// 1024 wavefronts = one per SIMD of the chip, and each lane's instruction stream is ~half as long.
+template <int SUB_>
+struct WaveCtx {
+  static constexpr int LS_STRIDE = 64;
+  static constexpr int SUB = SUB_;
+  static constexpr int LB_STRIDE = 64 / SUB_;  // limb-shared words: one per limb of the wavefront
+  static constexpr bool LIMB_ATOMICS = true;   // limb-shared words are real shared LDS: sub-lanes can ds_add into them
+  __device__ static void limb_atomic_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  static constexpr int LPE = NLANE * SUB_;
+  static constexpr int EPT = 64 / LPE;
+  float* lscratch;
+  float* lbscratch;
+  float* envs;  // this env's words shared by all its lanes (trunk + limbs instance: per-trunk-link accumulators)
+  const void* T;  // TablesT<TP> staged in LDS
+  float* stage[2];
+  float* rstage;
+  float* fstage;  // feature vectors of the tile's envs (observations)
+  int dim[2], fdim, rtdim;  // rtdim: words of an env's reward tables (they share LDS with the observation rows + features)
+  int lane;
+  __device__ float* lane_scratch() const { return lscratch + lane; }
+  __device__ float* limb_scratch() const { return lbscratch + lane / SUB; }
+  __device__ float* env_scratch() const { return envs; }
+  __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+  __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+  __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+  template <class TT>
+  __device__ const TT& tables() const { return *static_cast<const TT*>(T); }
+  __device__ int env_in_tile() const { return lane / LPE; }
+  __device__ int k() const { return (lane / SUB) & 3; }
+  __device__ int sub() const { return lane & (SUB - 1); }
+  int wtile;  // this wavefront's tile (= blockIdx.x with one wavefront per workgroup)
+  __device__ int tile() const { return wtile; }
+  __device__ int env() const { return wtile * EPT + env_in_tile(); }
+  // sum over the 4 legs (inputs replicated over a leg's sub-lanes when SUB == 4: the mirrors then pair
+  // lanes of different legs, and a + b == b + a bitwise, so all 16 lanes end with identical bits)
+  // (SUB == 2: a limb is a lane pair, an env a half row of 8 lanes - the quad xor-2 pairs limbs 0 / 1 and 2 / 3, the half mirror
+  // i <-> 7 - i then pairs those sums across the quads)
+  __device__ float gsum(float v) const {
+    if (SUB == 1) {
+      v += dpp<DPP_QUAD_XOR1>(v);
+      v += dpp<DPP_QUAD_XOR2>(v);
+    } else if (SUB == 2) {
+      v += dpp<DPP_QUAD_XOR2>(v);
+      v += dpp<DPP_ROW_HALF_MIRROR>(v);
+    } else {
+      v += dpp<DPP_ROW_HALF_MIRROR>(v);
+      v += dpp<DPP_ROW_MIRROR>(v);
+    }
+    return v;
+  }
+  __device__ float leg_sum(float v) const {
+    if (SUB == 1) return v;
+    v += dpp<DPP_QUAD_XOR1>(v);
+    if (SUB == 4) v += dpp<DPP_QUAD_XOR2>(v);
+    return v;
+  }
+  __device__ float esum(float v) const { return gsum(leg_sum(v)); }
+  // min over the lanes of the env
+  __device__ float emin(float v) const {
+    v = fminf(v, dpp<DPP_QUAD_XOR1>(v));
+    v = fminf(v, dpp<DPP_QUAD_XOR2>(v));
+    if (SUB > 1) v = fminf(v, dpp<DPP_ROW_HALF_MIRROR>(v));
+    if (SUB > 2) v = fminf(v, dpp<DPP_ROW_MIRROR>(v));
+    return v;
+  }
+  // value held by sub-lane J of this lane's leg (DPP quad_perm broadcast; SUB == 4)
+  template <int J>
+  __device__ float leg_bcast(float v) const {
+    if constexpr (SUB == 1) return v;  // a lane is the whole leg
+    else if constexpr (SUB == 2) return dpp<J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);  // lane pairs: [J, J, 2 + J, 2 + J]
+    else return dpp<J | (J << 2) | (J << 4) | (J << 6)>(v);
+  }
+  __device__ float gshfl(float v, int leg) const { return __shfl(v, (lane & ~(LPE - 1)) | (leg * SUB) | (lane & (SUB - 1))); }
+  __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
+  __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }
+  __device__ float* rew_stage() const { return rstage + env_in_tile() * MAX_T; }
+  __device__ float* feat_stage() const { return fstage + env_in_tile() * fdim; }
+  __device__ float* rew_tab() const { return stage[0] + env_in_tile() * rtdim; }
+  // Ordering point for LDS traffic between the lanes of the WAVEFRONT (its LDS region is its own, whatever the workgroup width - only
+  // the table image is shared, and that is read-only after the staging barrier).  A wavefront's LDS
+  // instructions execute in issue order, so a later ds_read of any lane sees an earlier ds_write of any lane without a hardware
+  // barrier: all that is needed is that the COMPILER keeps the accesses on their side of this point.  __syncthreads() would add
+  // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier - draining every global load in flight (the terrain and height-scan gathers that
+  // are deliberately issued early) ~20 times per step.
+  __device__ static void wave_sync() {
+#ifdef RL_SYNCTHREADS  // the old form, for A/B runs
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+  }
+  __device__ void group_sync() const { wave_sync(); }
+  __device__ void flush_obs(float* out, int d, int g) const {
+    wave_sync();  // orders the LDS writes above before the reads below
+    const int n4 = (EPT * d) >> 2;  // the tile's rows are contiguous in `out`; 16-byte aligned when EPT * d % 4 == 0
+    if (((EPT * d) & 3) == 0) {
+      const float4* src = reinterpret_cast<const float4*>(stage[g]);
+      float4* dst = reinterpret_cast<float4*>(out + (size_t)wtile * EPT * d);
+      for (int i = lane; i < n4; i += 64) dst[i] = src[i];
+    } else {
+      float* dst = out + (size_t)wtile * EPT * d;
+      for (int i = lane; i < EPT * d; i += 64) dst[i] = stage[g][i];
+    }
+    wave_sync();
+  }
+};
+
+extern __shared__ float4 smem4[];
+
+// WGW wavefronts per workgroup share ONE staged table image in LDS; apart from that staging (and its one s_barrier) the wavefronts
+// of a workgroup have nothing to do with each other: each has its own scratch region behind the tables (`wave_words` LDS words) and
+// orders its LDS traffic with wave_sync().  4 when the launch has at least 4 wavefronts for every CU (a CU then holds ONE workgroup
+// = one wavefront per SIMD, as with single-wavefront workgroups, but stages the tables once instead of four times and the dispatcher
+// places a quarter of the workgroups): A1 Rough 4096 52.1 -> 50.2 us.  Smaller launches keep single-wavefront workgroups, which
+// spread over more CUs (1024 envs: 49.5 us on 256 CUs, 55.9 us packed four to a CU - profiles/r02_wg_waves.txt).
+// __launch_bounds__(256) also for the single-wavefront variant: a leftover of round 2, when declaring 64 threads "caused" a miscompile
+// (the push event fired in every env).  The cause is known since round 3 and has nothing to do with the declaration (DESIGN.md
+// section 3, profiles/r03d_pin_desc_miscompile.txt): LLVM drops the EXEC restore of an inner divergent region that ends where the
+// enclosing one ends, the register allocator then places a live-range-split reload (v_accvgpr_read vX, aY) into the empty flow block,
+// and it executes under the inner region's - or an empty - EXEC mask while the outer region's lanes hold a temporary in vX.  Which
+// value is hit is a matter of register pressure.  This library is therefore built with -mllvm -amdgpu-remove-redundant-endcf=false,
+// and __graft_entry__.build() refuses a build in whose assembly tools/isa_exec_hazard.py finds a vector write under a stale EXEC.
+#ifndef RL_LB
+#define RL_LB(w) 256
+#endif
+template <class TP, int RESET, int SUB, int WGW>
+__global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* __restrict__ Tgv, uint32_t wave_words) {
+  using Ctx = WaveCtx<SUB>;
+  using Tables = TablesT<TP>;
+  const Tables* __restrict__ Tg = static_cast<const Tables*>(Tgv);
+  float* smem = reinterpret_cast<float*>(smem4);
+  Tables* Tl = reinterpret_cast<Tables*>(smem);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  S.step_counter += *S.step_base;  // scalar load: the launch carries the offset from the device-side anchor (rl_env_graph_*)
+  {  // stage the used part of the table image into LDS (16-byte vectors): all loads in flight before the first LDS write
+    const float4* src = reinterpret_cast<const float4*>(Tg);
+    float4* dst = reinterpret_cast<float4*>(Tl);
+    constexpr int TPB = 64 * WGW;
+    constexpr int NIT = ((int)(sizeof(Tables) / 16) + TPB - 1) / TPB;
+    const int n4 = (int)(S.table_bytes >> 4);
+    float4 tmp[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = (int)threadIdx.x + TPB * it;
+      tmp[it] = src[i < n4 ? i : n4 - 1];  // unconditional (clamped) loads keep tmp[] in registers
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = (int)threadIdx.x + TPB * it;
+      if (i < n4) dst[i] = tmp[it];
+    }
+  }
+  if (WGW > 1) __syncthreads();
+  else Ctx::wave_sync();
+  // LDS after the tables (only the staged bytes take room: the unused tail of the reward table is never touched):
+  //   lane scratchpad | limb-shared words | observation staging rows | reward stage
+  // On the instances with a contact stash (quadrupeds, 16 lanes per env) the staging rows and the reward stage live ON the
+  // stash words of the scratchpad when they fit: the stash is dead once the substeps are over and nothing before them
+  // touches the rows.  26 KB -> 20 KB per workgroup = 8 instead of 6 workgroups per CU.
+  const int TAB_F = (int)(S.table_bytes >> 2);
+  using LS = typename LsFor<TP, SUB>::type;
+  constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
+  Ctx ctx;
+  ctx.T = Tl;
+  ctx.dim[0] = Tl->policy_dim;
+  ctx.dim[1] = Tl->critic_dim;
+  // (one lane per limb: a group without noise has no staging row - env_terms.h write_group<DIRECT>)
+  const int s0w = (SUB == 1 && direct_group(*Tl, 0)) ? 0 : (Ctx::EPT * ctx.dim[0] + 3) & ~3;
+  int s1w = (SUB == 1 && direct_group(*Tl, 1)) ? 0 : (Ctx::EPT * ctx.dim[1] + 3) & ~3;
+  {  // the staging rows double as limb-shared scratch inside the substeps (streaming CRBA): at least that big
+    const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
+    if (s0w + s1w < need) s1w = need - s0w;
+  }
+  ctx.lscratch = smem + TAB_F + (WGW > 1 ? wv * wave_words : 0u);  // wave_words: LDS words of one wavefront behind the shared tables
+  ctx.wtile = (int)blockIdx.x * WGW + wv;
+  if (WGW > 1 && ctx.wtile >= S.Npad / Ctx::EPT) return;
+  ctx.lbscratch = ctx.lscratch + LS::WORDS * 64;
+  ctx.envs = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + (lane / Ctx::LPE) * LbLayout<TP>::ENV_WORDS;
+  float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + Ctx::EPT * LbLayout<TP>::ENV_WORDS;
+  // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
+  ctx.fdim = feat_count(Tl->D);
+  ctx.rtdim = rew_tab_words(Tl->D, Tl->n_bodies, Tl->rew_ext_mask);
+  // reward stage | [ observation rows + feature vectors ] = [ reward tables ] (the tables die before the rows are written)
+  int region = s0w + s1w + Ctx::EPT * ctx.fdim;
+  if (region < Ctx::EPT * ctx.rtdim) s1w += Ctx::EPT * ctx.rtdim - region, region = Ctx::EPT * ctx.rtdim;
+  // Where they live (same rule as Backend::configure): quadrupeds - on the contact stash of the lane scratchpad, dead once the
+  // substeps are over; trunk + limbs instance - on the link-record / elimination words of the limb-shared area, dead likewise
+  // (its kinematics words stay: rewards and the scanner pose recompute the chain into them); else behind everything.
+  constexpr int LB_FREE = TP::NW > 0 ? (LbLayout<TP>::WORDS - LbLayout<TP>::REC) * Ctx::LB_STRIDE : 0;
+  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;
+  const bool alias_lb = TP::NW > 0 && Ctx::EPT * MAX_T + region <= LB_FREE;
+  float* base = alias ? ctx.lscratch + LS::CT * 64 : (alias_lb ? ctx.lbscratch + LbLayout<TP>::REC * Ctx::LB_STRIDE : tail);
+  ctx.rstage = base;
+  ctx.stage[0] = base + Ctx::EPT * MAX_T;
+  ctx.stage[1] = ctx.stage[0] + s0w;
+  ctx.fstage = ctx.stage[1] + s1w;
+  ctx.lane = lane;
+  EnvProgram<Ctx, TP> prog(ctx, S);
+  if (RESET == 1)
+    prog.reset_entry();  // (KMODE_RESET, and KMODE_STEP_TAIL: the second launch of a step split around the command-range decision)
+  else if (RESET == 2)
+    prog.step_head();    // KMODE_STEP_HEAD: the first launch of such a step
+  else
+    prog.step();
+}
+
+
+// what the launch helpers need from the env's backend
+struct LaunchCfg {
+  int device = 0, n_cu = 256;
+  int wg_waves = 4;       // RL_ENV_WG=1: single-wavefront workgroups always
+  bool wg_force = false;  // RL_ENV_WG=-4: four wavefronts per workgroup whatever the launch size (tests)
+};
+
+// lds1: LDS bytes with one wavefront per workgroup; S.mode picks the kernel.  Returns a hipError_t (hipSuccess = launched).
+// Kernels per (instance, mapping): step with one / four wavefronts per workgroup; the reset entry (+ the tail of a split step) with
+// one; the head of a split step - command-range curricula, which no shipped cfg has - with one and for the 16-lane mapping only
+// (rl_env_create keeps such tasks on it).
+template <class TP, int SUB, int WGW>
+hipError_t launch_w(const LaunchCfg& cfg, const KState& S, const void* T, size_t lds1, hipStream_t st) {
+  const int tiles = S.Npad / (16 / SUB);
+  dim3 grid((tiles + WGW - 1) / WGW), block(64 * WGW);
+  const uint32_t wave_words = (uint32_t)((lds1 - S.table_bytes) >> 2);
+  const size_t lds = S.table_bytes + (size_t)WGW * (lds1 - S.table_bytes);
+  constexpr bool HEAD = SUB == 4 && WGW == 1, RESET = WGW == 1;
+  if (lds > 64 * 1024) {
+    // opt in to the large LDS carve-out (160 KB per CU on gfx950).  The attribute belongs to the (kernel, device) pair and
+    // must cover the LARGEST request: remember per device what was configured and raise it when an env needs more.
+    static size_t configured[64] = {};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = configured[cfg.device & 63];
+    if (lds > have) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 0, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      if constexpr (RESET) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 1, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      if constexpr (HEAD) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 2, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      have = lds;
+    }
+  }
+  if (S.mode == KMODE_RESET || S.mode == KMODE_STEP_TAIL) {
+    if constexpr (RESET) hipLaunchKernelGGL((env_kernel<TP, 1, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
+    else return hipErrorInvalidValue;
+  } else if (S.mode == KMODE_STEP_HEAD) {
+    if constexpr (HEAD) hipLaunchKernelGGL((env_kernel<TP, 2, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
+    else return hipErrorInvalidValue;
+  } else {
+    hipLaunchKernelGGL((env_kernel<TP, 0, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
+  }
+  return hipGetLastError();
+}
+template <class TP, int SUB>
+hipError_t launch_cl(const LaunchCfg& cfg, const KState& S, const void* T, size_t lds1, hipStream_t st) {
+  if constexpr (TP::NW == 0) {  // (the trunk + limbs instance gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup)
+    const int tiles = S.Npad / (16 / SUB);
+    const size_t lds4 = S.table_bytes + 4 * (lds1 - S.table_bytes);
+    // (only the step kernel exists in the four-wavefront shape: resets and the halves of a split step are off the hot path)
+    if (cfg.wg_waves == 4 && (tiles >= 4 * cfg.n_cu || cfg.wg_force) && lds4 <= 160 * 1024 && S.mode == KMODE_STEP)
+      return launch_w<TP, SUB, 4>(cfg, S, T, lds1, st);
+  }
+  return launch_w<TP, SUB, 1>(cfg, S, T, lds1, st);
+}
+
+}  // namespace
