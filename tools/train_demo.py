@@ -60,11 +60,16 @@ def main():
             if k in ex:
                 row[k] = float(ex[k])
         row["action_std"] = float(tr.policy.std.detach().mean())
+        if it % a.print_every == 0 or it == a.iterations - 1:  # posture of the batch (an export of the state: only when a line is printed)
+            d = env.scene["robot"].data
+            qw = d.root_quat_w
+            row["root_height"] = float((d.root_pos_w[:, 2] - env.scene.env_origins[:, 2]).mean())
+            row["upright"] = float((1.0 - 2.0 * (qw[:, 1] ** 2 + qw[:, 2] ** 2)).mean())  # z component of the body's up axis: 1 = upright, 0 = on a side
         log.append(row)
         if it % a.print_every == 0 or it == a.iterations - 1:
             print(f"it {it:4d}  reward/step {row['mean_step_reward']:+.4f}  {track} {row.get('Episode_Reward/' + track, float('nan')):.3f}  "
                   f"err_xy {row.get('Metrics/base_velocity/error_vel_xy', float('nan')):.3f}  done/step {row['done_rate']:.4f}  std {row['action_std']:.3f}  "
-                  f"lr {row['learning_rate']:.1e}  kl {row['kl']:.4f}  v_loss {row['value_loss']:.4f}", flush=True)
+                  f"lr {row['learning_rate']:.1e}  kl {row['kl']:.4f}  v_loss {row['value_loss']:.4f}  height {row.get('root_height', float('nan')):.3f}  upright {row.get('upright', float('nan')):+.3f}", flush=True)
     wall = time.perf_counter() - t_start
     n_steps = a.iterations * st.num_transitions_per_env * a.num_envs
     summary = dict(task=a.task, num_envs=a.num_envs, iterations=a.iterations, wall_s=wall, env_steps=n_steps, env_steps_per_s=n_steps / wall,
