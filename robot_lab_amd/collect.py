@@ -19,10 +19,11 @@ import torch
 
 class Collector:
     def __init__(self, env, actor, critic, storage, action_std: torch.Tensor, gamma: float = 0.99, lam: float = 0.95,
-                 normalize_advantage: bool = True, use_graph: bool = True):
+                 normalize_advantage: bool = True, use_graph: bool = True, clip_actions: float | None = None):
         self.env, self.actor, self.critic, self.storage = env, actor, critic, storage
         self.std, self.gamma, self.lam, self.normalize = action_std, gamma, lam, normalize_advantage
         self.T = storage.num_transitions_per_env
+        self.clip_actions = clip_actions  # RslRlVecEnvWrapper.step clamps what the env sees; the storage keeps the sampled action
         if self.T % 2:
             use_graph = False  # the env's observation buffers alternate: a captured loop needs an even number of steps
         self.use_graph = use_graph
@@ -35,6 +36,8 @@ class Collector:
         for _ in range(self.T):
             mean, values = self.actor.forward_pair(obs["policy"], self.critic, obs["critic"])
             actions = st.act(obs["policy"], obs["critic"], mean, self.std, values)
+            if self.clip_actions is not None:
+                actions = actions.clamp(-self.clip_actions, self.clip_actions)
             obs, _, _, _, _ = env.step(actions, rollout=st, gamma=self.gamma)
         st.compute_returns(self.critic(obs["critic"]), self.gamma, self.lam, self.normalize)
         return obs

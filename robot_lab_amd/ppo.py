@@ -123,7 +123,8 @@ class PPO:
 class Trainer:
     """collect (HIP, one graph launch) -> update (torch) -> push parameters, repeated: `OnPolicyRunner.learn` in miniature."""
 
-    def __init__(self, env, num_steps_per_env=24, gamma=0.99, lam=0.95, seed=1, use_graph=True, **ppo_kw):
+    def __init__(self, env, num_steps_per_env=24, gamma=0.99, lam=0.95, seed=1, use_graph=True, actor_hidden=(512, 256, 128),
+                 critic_hidden=(512, 256, 128), init_noise_std=1.0, clip_actions=None, **ppo_kw):
         from .collect import Collector
         from .policy import MlpPolicy
         from .rollout import RolloutStorage
@@ -132,7 +133,7 @@ class Trainer:
         od, cd, A = obs["policy"].shape[1], obs["critic"].shape[1], env.num_actions
         torch.manual_seed(seed)
         self.env, self.device = env, obs["policy"].device
-        self.policy = ActorCritic(od, cd, A).to(self.device)
+        self.policy = ActorCritic(od, cd, A, tuple(actor_hidden), tuple(critic_hidden), init_noise_std).to(self.device)
         self.alg = PPO(self.policy, **ppo_kw)
         lin = lambda m: [x for x in m if isinstance(x, nn.Linear)]  # noqa: E731
         host = lambda t: t.detach().cpu().numpy()  # noqa: E731
@@ -140,7 +141,7 @@ class Trainer:
         self.critic = MlpPolicy([host(x.weight) for x in lin(self.policy.critic)], [host(x.bias) for x in lin(self.policy.critic)], "elu", device=str(self.device))
         self.storage = RolloutStorage(env.num_envs, num_steps_per_env, od, cd, A, seed=seed, device=str(self.device))
         self.std = self.policy.std.detach().clone()  # the tensor the sampling kernel reads: refreshed in place after every update
-        self.collector = Collector(env, self.actor, self.critic, self.storage, self.std, gamma=gamma, lam=lam, use_graph=use_graph)
+        self.collector = Collector(env, self.actor, self.critic, self.storage, self.std, gamma=gamma, lam=lam, use_graph=use_graph, clip_actions=clip_actions)
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.iteration = 0
 

@@ -1,0 +1,89 @@
+"""`OnPolicyRunner` as the reference's scripts use it (train.py:205-224, play.py:190-246):
+
+    runner = OnPolicyRunner(env, agent_cfg.to_dict(), log_dir=log_dir, device=agent_cfg.device)
+    runner.add_git_repo_to_log(__file__); runner.load(path); runner.learn(num_learning_iterations=..., init_at_random_ep_len=True)
+    policy = runner.get_inference_policy(device=...); runner.alg.policy  (exporters, `.reset(dones)`)
+
+`env` is the `RslRlVecEnvWrapper` of the shims around `robot_lab_amd.env.ManagerBasedRLEnv`.  Collection runs on the HIP kernels as
+one hipGraph launch per iteration (robot_lab_amd/collect.py), the update is robot_lab_amd/ppo.py, checkpoints use rsl_rl's layout
+(`model_<it>.pt`: model_state_dict / optimizer_state_dict / iter / infos)."""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg: dict, log_dir: str | None = None, device: str = "cpu"):
+        from robot_lab_amd.ppo import Trainer
+
+        self.env, self.cfg, self.log_dir, self.device = env, train_cfg, log_dir, device
+        pol, alg = dict(train_cfg.get("policy", {})), dict(train_cfg.get("algorithm", {}))
+        if pol.get("class_name", "ActorCritic") != "ActorCritic" or alg.get("class_name", "PPO") != "PPO":
+            raise NotImplementedError(f"stand-in runner: ActorCritic + PPO only, got {pol.get('class_name')} / {alg.get('class_name')}")
+        if pol.get("activation", "elu") != "elu" or pol.get("actor_obs_normalization") or pol.get("critic_obs_normalization"):
+            raise NotImplementedError("stand-in runner: ELU networks without observation normalisation (what every robot_lab agent cfg uses)")
+        if alg.get("symmetry_cfg") or alg.get("rnd_cfg"):
+            raise NotImplementedError("stand-in runner: symmetry augmentation / RND are not wired into the update")
+        keys = ("value_loss_coef", "use_clipped_value_loss", "clip_param", "entropy_coef", "num_learning_epochs", "num_mini_batches",
+                "learning_rate", "schedule", "desired_kl", "max_grad_norm")
+        self.trainer = Trainer(env.unwrapped, num_steps_per_env=int(train_cfg.get("num_steps_per_env", 24)), gamma=float(alg.get("gamma", 0.99)),
+                               lam=float(alg.get("lam", 0.95)), seed=int(train_cfg.get("seed", 42)), actor_hidden=pol.get("actor_hidden_dims", (512, 256, 128)),
+                               critic_hidden=pol.get("critic_hidden_dims", (512, 256, 128)), init_noise_std=float(pol.get("init_noise_std", 1.0)),
+                               clip_actions=getattr(env, "clip_actions", None), **{k: alg[k] for k in keys if k in alg})
+        self.alg = self.trainer.alg
+        self.alg.policy.reset = lambda dones=None: None  # feed-forward policy: nothing to reset (play.py:246)
+        self.save_interval = int(train_cfg.get("save_interval", 50))
+        self.current_learning_iteration = 0
+        self.git_status_repos = []
+
+    def add_git_repo_to_log(self, path):
+        self.git_status_repos.append(path)
+
+    def learn(self, num_learning_iterations: int, init_at_random_ep_len: bool = False):
+        env = self.env.unwrapped
+        if init_at_random_ep_len:
+            env.episode_length_buf = torch.randint(0, int(env.max_episode_length), (env.num_envs,))
+        if self.log_dir:
+            os.makedirs(self.log_dir, exist_ok=True)
+        start = self.current_learning_iteration
+        t0 = time.time()
+        for it in range(start, start + num_learning_iterations):
+            out = self.trainer.iterate()
+            self.current_learning_iteration = it + 1
+            steps = self.trainer.storage.num_transitions_per_env * env.num_envs
+            print(f"[rsl_rl stand-in] iteration {it + 1}/{start + num_learning_iterations}  mean reward/step {out['mean_reward']:+.4f}  value loss {out['value_loss']:.4f}  "
+                  f"surrogate {out['surrogate_loss']:+.4f}  std {out['action_std']:.3f}  lr {out['learning_rate']:.1e}  "
+                  f"{steps * (it + 1 - start) / max(time.time() - t0, 1e-9):.0f} steps/s", flush=True)
+            if self.log_dir and (it + 1) % self.save_interval == 0:
+                self.save(os.path.join(self.log_dir, f"model_{it + 1}.pt"))
+        if self.log_dir:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def save(self, path: str, infos=None):
+        torch.save({"model_state_dict": self.alg.policy.state_dict(), "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path: str, load_optimizer: bool = True, map_location=None):
+        d = torch.load(path, map_location=map_location or self.trainer.device, weights_only=False)
+        self.alg.policy.load_state_dict(d["model_state_dict"])
+        if load_optimizer and d.get("optimizer_state_dict"):
+            self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+        self.current_learning_iteration = int(d.get("iter", 0))
+        self.trainer.push_parameters()
+        return d.get("infos")
+
+    def get_inference_policy(self, device=None):
+        actor = self.trainer.actor  # the fused HIP inference kernel (csrc/rl_policy.hip), fed by push_parameters()
+
+        def policy(obs):
+            return actor(obs if torch.is_tensor(obs) else obs["policy"])
+
+        return policy
+
+
+class DistillationRunner:
+    def __init__(self, *a, **k):
+        raise NotImplementedError("stand-in for rsl_rl: DistillationRunner is not provided (no robot_lab velocity task uses it)")
