@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Long random/zero-action rollout on the GPU: finiteness, episode statistics, curriculum sanity."""
+"""Long random/zero-action rollout on the GPU: finiteness, episode statistics, curriculum sanity.
+    python tools/soak.py [task] [steps] [random|zero] [num_envs]"""
 import os
 import sys
 
@@ -11,7 +12,7 @@ from robot_lab_amd.env import ManagerBasedRLEnv
 task = sys.argv[1] if len(sys.argv) > 1 else "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 mode = sys.argv[3] if len(sys.argv) > 3 else "random"
-N = 4096
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 env = ManagerBasedRLEnv(task, num_envs=N, seed=1, device="cuda:0")
 env.reset()
 env.episode_length_buf = torch.randint(0, env.max_episode_length, (N,))
