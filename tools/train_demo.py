@@ -31,8 +31,22 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out"))
     ap.add_argument("--print-every", type=int, default=10)
+    ap.add_argument("--also-terminate-on", default="", help="DIAGNOSTIC, not the reference's cfg: regex of body names added to the illegal-contact termination")
     a = ap.parse_args()
-    env = ManagerBasedRLEnv(a.task, num_envs=a.num_envs, seed=a.seed, device="cuda:0")
+    if a.also_terminate_on:
+        import re
+
+        from robot_lab_amd.scene import load_bundle
+
+        desc, extra = load_bundle(a.task)
+        hit = [i for i, n in enumerate(desc.body_names) if re.fullmatch(a.also_terminate_on, n)]
+        for i in hit:
+            desc.task.illegal_body_mask |= 1 << i
+        desc.task.term_illegal_contact = 1
+        print(f"DIAGNOSTIC run: illegal-contact termination extended to {[desc.body_names[i] for i in hit]}")
+        env = ManagerBasedRLEnv(desc=desc, extra=extra, num_envs=a.num_envs, seed=a.seed, device="cuda:0")
+    else:
+        env = ManagerBasedRLEnv(a.task, num_envs=a.num_envs, seed=a.seed, device="cuda:0")
     tr = Trainer(env, seed=a.seed)
     # init_at_random_ep_len=True (train.py:224): the first time-outs are spread over an episode length
     env.episode_length_buf = torch.randint(0, env.max_episode_length, (a.num_envs,), generator=torch.Generator().manual_seed(a.seed))
