@@ -101,7 +101,9 @@ def test_resets_and_logs(emu_lib):
 # limbs); then Go2W on the unmerged 4-joint instance (RL_ENV_MERGE=0: what a robot whose trunk spheres do not fit runs on) and M20
 # (merged, with the trunk's six spheres in the WHEEL groups: flagged slots on sub-lanes that do not own the trunk body's slot)
 @pytest.mark.parametrize("task,N,steps,merge", [(TASKS[1], 16, 2, None), (TASKS[3], 8, 2, None), (TASKS[5], 4, 3, None),
-                                                (TASKS[3], 8, 2, "0"), ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", 8, 2, None)])
+                                                (TASKS[3], 8, 2, "0"), ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", 8, 2, None),
+                                                # Go2 (21 terms incl. the gait kind) and the HandStand task's own kinds
+                                                (TASKS[2], 8, 2, None), ("RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0", 8, 2, None)])
 @pytest.mark.parametrize("sub", ["4", "2"])
 def test_sixteen_lane_mapping_matches_oracle(task, N, steps, merge, sub, emu_lib, monkeypatch):
     """The 16-lanes-per-env mapping (a DPP quad per limb; the default on the GPU: link groups dealt to the sub-lanes, contact
