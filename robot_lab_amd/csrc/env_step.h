@@ -272,6 +272,54 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
   }
 }
 
+// The same kinematics on the trunk + limbs instance with several sub-lanes per limb.  The local joint transforms
+// T_j = rot0_j * Rodrigues(axis_j, q_j) (sin / cos and a 3 x 3 product per joint) come out the same in every sub-lane of a limb, so
+// they are DEALT: joint jx is computed by sub-lane jx % SUB only, and when the chain product reaches joint jx every sub-lane takes
+// T_jx from its owner with nine quad broadcasts.  What stays per lane and joint is R_j = R_parent * T_j, the joint origin and the
+// world axis (axis_w = R_j * axis: Rodrigues(axis, .) leaves its own axis where it is, so this equals rot-frame * axis).  About
+// 60 instead of 110 instructions per joint of the 10-joint chain, five times per step.
+template <class TP, int SUB, class Ctx, class CT>
+RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C) {
+  static_assert(TP::ROT && SUB > 1, "trunk + limbs instance, several sub-lanes per limb");
+  constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NS = (JX + SUB - 1) / SUB;
+  M3 Tl[NS];
+  static_for<0, NS>([&](auto ic) __attribute__((always_inline)) {  // this sub-lane's joint of round i: SUB * i + sub (a partial last round is clamped, unused)
+    constexpr int i = decltype(ic)::value;
+    float qi = opaque(q[SUB * i]);  // (opaque: a select over plain loads of q becomes one load through a selected address - rl_math.h)
+    static_for<1, SUB>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s2 = decltype(sc)::value, jq = SUB * i + s2 < JX ? SUB * i + s2 : JX - 1;
+      const float cand = opaque(q[jq]);
+      qi = sub == s2 ? cand : qi;
+    });
+    const int jx = imin(SUB * i + sub, JX - 1);
+    Tl[i] = mul(ld_m3(L.rot0[jx]), rodrigues(ld3(L.axis[jx]), qi));
+  });
+  M3 Rp = identity3(), Ra = identity3();
+  V3 pp{0.f, 0.f, 0.f}, pa{0.f, 0.f, 0.f};
+  // (the bodies must be inlined at all three call sites: a lambda left as a function takes its captures - the lane object - by address)
+  static_for<0, NW>([&](auto ic) __attribute__((always_inline)) {  // trunk joints (same in every lane)
+    constexpr int i = decltype(ic)::value, jx = CL + i;
+    const M3 Tj = ctx.template leg_bcast_m3<jx % SUB>(Tl[jx / SUB]);
+    const V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
+    const M3 Rj = mul(Rp, Tj);
+    C.setw(i, Rj, pj, mul(Rj, ld3(L.axis[jx])));
+    Rp = Rj;
+    pp = pj;
+    if (L.attach == i + 1) { Ra = Rj; pa = pj; }
+  });
+  Rp = Ra;
+  pp = pa;
+  static_for<0, CL>([&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const M3 Tj = ctx.template leg_bcast_m3<j % SUB>(Tl[j / SUB]);
+    const V3 pj = pp + mul(Rp, ld3(L.origin[j]));
+    const M3 Rj = mul(Rp, Tj);
+    C.set(j, Rj, pj, mul(Rj, ld3(L.axis[j])));
+    Rp = Rj;
+    pp = pj;
+  });
+}
+
 // velocity (base coords) of the point x rigidly attached to a link that is moved by the first `wd` trunk
 // joints and the first `lg` limb joints
 template <class TP, class CT>
@@ -364,6 +412,15 @@ struct EnvLane {
   static constexpr int LBS = Ctx::LB_STRIDE;
   using ChainTP = ChainT<TP, LDSU, LBS>;
   enum { LB_CHAIN = LbLayout<TP>::CHAIN, LB_REC = LbLayout<TP>::REC, LB_VA = LbLayout<TP>::VA, LB_WORDS = LbLayout<TP>::WORDS };
+  RL_FN void kinematics(ChainTP& C) {
+#ifndef RL_KIN_REPLICATED  // (A/B switch: every sub-lane computes every joint transform)
+    if constexpr (NW > 0 && SUB > 1) {
+      chain_kinematics_dealt<TP, SUB>(ctx, sub, L, q, C);
+      return;
+    }
+#endif
+    chain_kinematics<TP>(L, q, C);
+  }
   RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_scratch() + LB_CHAIN * LBS : nullptr); }
 
   Ctx& ctx;
@@ -1122,7 +1179,7 @@ struct EnvLane {
     const SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
     const SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
     ChainTP C = new_chain();
-    chain_kinematics<TP>(L, q, C);
+    kinematics(C);
     // trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
     SV Sw[NW], Vw[NW], aw[NW];
     {

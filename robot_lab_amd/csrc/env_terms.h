@@ -656,7 +656,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     ChainTP C = this->new_chain();
     if (!chain_fresh) {
-      chain_kinematics<TP>(L, q, C);
+      this->kinematics(C);
       ctx.group_sync();
     }
     M3 Rf;
@@ -929,7 +929,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     derive();
     if constexpr (NW > 0) {  // kinematics of the final joint positions, once, for the reward stage (feet) and the scanner pose
       ChainTP Cf = this->new_chain();
-      chain_kinematics<TP>(L, q, Cf);
+      this->kinematics(Cf);
       ctx.group_sync();
     }
 

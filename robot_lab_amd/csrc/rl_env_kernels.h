@@ -23,6 +23,11 @@ template <int CTRL>
 __device__ inline float dpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
+// a pure lane move (every lane has a valid source): bound_ctrl, so that no `old` value has to be materialised in front of the v_mov_dpp
+template <int CTRL>
+__device__ inline float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15 - i of a 16-lane row
@@ -99,8 +104,15 @@ struct WaveCtx {
   template <int J>
   __device__ float leg_bcast(float v) const {
     if constexpr (SUB == 1) return v;  // a lane is the whole leg
-    else if constexpr (SUB == 2) return dpp<J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);  // lane pairs: [J, J, 2 + J, 2 + J]
-    else return dpp<J | (J << 2) | (J << 4) | (J << 6)>(v);
+    else if constexpr (SUB == 2) return dpp_move<J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);  // lane pairs: [J, J, 2 + J, 2 + J]
+    else return dpp_move<J | (J << 2) | (J << 4) | (J << 6)>(v);
+  }
+  // a 3 x 3 matrix held by sub-lane J of this lane's leg (nine quad broadcasts)
+  template <int J>
+  __device__ __forceinline__ M3 leg_bcast_m3(const M3& m) const {
+    return M3{{leg_bcast<J>(m.r0.x), leg_bcast<J>(m.r0.y), leg_bcast<J>(m.r0.z)},
+              {leg_bcast<J>(m.r1.x), leg_bcast<J>(m.r1.y), leg_bcast<J>(m.r1.z)},
+              {leg_bcast<J>(m.r2.x), leg_bcast<J>(m.r2.y), leg_bcast<J>(m.r2.z)}};
   }
   __device__ float gshfl(float v, int leg) const { return __shfl(v, (lane & ~(LPE - 1)) | (leg * SUB) | (lane & (SUB - 1))); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }

@@ -28,6 +28,18 @@ RL_FN float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634
 #else
 RL_FN float fexp(float x) { return expf(x); }
 #endif
+// A value the optimizer does not see through.  Needed where lanes SELECT among elements of an array that lives in the lane object
+// (`sub == 1 ? q[1] : sub == 2 ? q[2] : ...`): InstCombine folds a select over loads of one object into ONE load through a selected
+// address, the object can then no longer be split into registers and the whole kernel runs out of scratch (env_step.h
+// chain_kinematics_dealt; seen as ScratchSize 1232 and ds_read -> flat_load all over the step kernel).
+#if defined(__HIP_DEVICE_COMPILE__)
+RL_FN float opaque(float x) {
+  asm("" : "+v"(x));
+  return x;
+}
+#else
+RL_FN float opaque(float x) { return x; }
+#endif
 RL_FN float ftanh(float x) {  // x >= 0 in every use (speed norms); 1 - 2 / (e^{2x} + 1)
   return 1.0f - 2.0f * frcp(fexp(2.0f * fminf(x, 20.0f)) + 1.0f);
 }

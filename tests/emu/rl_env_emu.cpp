@@ -134,6 +134,7 @@ struct alignas(64) Team {
   LaneBarrier bar;
   FiberSet* fibers = nullptr;  // set: the lanes are fibers of one thread
   alignas(64) float slot[LPE];
+  float slot9[LPE][9];
   float rstage[rl::MAX_T];
   float feat[rl::feat_count(rl::TopoMax::DMAX)];
   float lb[rl::NLANE][rl::LbLayout<rl::TopoG1>::WORDS + 1];  // limb-shared words (really shared by the limb's sub-lane threads)
@@ -302,6 +303,17 @@ struct HostCtx {
     float r = team->slot[k_ * SUB + (J < SUB ? J : 0)];
     team->barrier(li());
     return r;
+  }
+  template <int J>
+  rl::M3 leg_bcast_m3(const rl::M3& m) {  // one barrier pair for the nine words
+    if (SUB == 1) return m;
+    float* w = team->slot9[li()];
+    w[0] = m.r0.x; w[1] = m.r0.y; w[2] = m.r0.z; w[3] = m.r1.x; w[4] = m.r1.y; w[5] = m.r1.z; w[6] = m.r2.x; w[7] = m.r2.y; w[8] = m.r2.z;
+    team->barrier(li());
+    const float* r = team->slot9[k_ * SUB + (J < SUB ? J : 0)];
+    const rl::M3 out{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, {r[6], r[7], r[8]}};
+    team->barrier(li());
+    return out;
   }
   float gshfl(float v, int leg) {
     team->slot[li()] = v;
