@@ -32,6 +32,8 @@ extern "C" {
 #define RL_MAX_DOF 31
 #define RL_MAX_BODIES 48
 #define RL_MAX_SPHERES 96
+#define RL_MAX_CAPSULES 16   /* self-collision proxies: at most one capsule per selected link */
+#define RL_MAX_SELF_PAIRS 80 /* capsule pairs tested per substep (5 per lane of the 16-lane env) */
 #define RL_MAX_REWARD_TERMS 40
 #define RL_MAX_OBS_TERMS 12
 #define RL_TERM_NPARAM 8
@@ -158,6 +160,18 @@ typedef struct rl_model_desc {
   int32_t action_is_vel[RL_MAX_DOF];
   float action_scale[RL_MAX_DOF], action_offset[RL_MAX_DOF];
   float action_clip_lo[RL_MAX_DOF], action_clip_hi[RL_MAX_DOF];
+  /* self-collision (ArticulationRootPropertiesCfg.enabled_self_collisions: unitree.py:482 G1, roboparty.py:33 ATOM01; off
+     everywhere else).  The reference hands the links' collision meshes to PhysX, which collides every pair of links except
+     parent / child; here each of up to RL_MAX_CAPSULES links carries ONE capsule (segment p0 - p1 in the link frame + radius,
+     fitted to the link's collision geometry) and the listed capsule pairs repel each other with an explicit penalty force
+     (rl_sim_desc.self_k) once per substep.  0 capsules / 0 pairs = no self-collision (trunk + limbs instance only). */
+  int32_t self_collision;                /* the cfg's flag, as read */
+  int32_t num_capsules;
+  int32_t capsule_link[RL_MAX_CAPSULES];
+  float capsule_p0[RL_MAX_CAPSULES][3], capsule_p1[RL_MAX_CAPSULES][3];
+  float capsule_radius[RL_MAX_CAPSULES];
+  int32_t num_self_pairs;
+  int32_t self_pair[RL_MAX_SELF_PAIRS][2]; /* capsule indices a < b */
 } rl_model_desc;
 
 /* ---- simulator constants (ours; the reference delegates these to PhysX) ------------------ */
@@ -173,6 +187,7 @@ typedef struct rl_sim_desc {
   float contact_vstick;   /* |v_t| below which static friction applies */
   float limit_k, limit_c; /* joint-limit spring / damper */
   float force_threshold;  /* contact sensor threshold, 1.0 N [UPSTREAM ContactSensorCfg] */
+  float self_k;           /* self-collision penalty stiffness N/m (explicit: keep self_k dt^2 well below the lightest link's mass) */
 } rl_sim_desc;
 
 /* ---- terrain ------------------------------------------------------------------------------ */

@@ -67,6 +67,28 @@ class TerrainSampler:
         return z, n
 
 
+def segment_closest(a0, a1, b0, b1):
+    """Closest points of the segments a0-a1 and b0-b1, batched over the leading axis (Ericson, Real-Time Collision Detection 5.1.9;
+    the same branch order as csrc/env_step.h `segment_closest`, so that both sides pick the same points in the degenerate cases)."""
+    d1, d2, r = a1 - a0, b1 - b0, a0 - b0
+    a = np.einsum("ni,ni->n", d1, d1)
+    e = np.einsum("ni,ni->n", d2, d2)
+    f = np.einsum("ni,ni->n", d2, r)
+    c = np.einsum("ni,ni->n", d1, r)
+    b = np.einsum("ni,ni->n", d1, d2)
+    eps = 1e-12
+    den = a * e - b * b
+    s = np.where(den > eps, np.clip((b * f - c * e) / np.maximum(den, eps), 0.0, 1.0), 0.0)
+    s = np.where(a > eps, s, 0.0)
+    t = np.where(e > eps, (b * s + f) / np.maximum(e, eps), 0.0)
+    # t outside [0, 1]: clamp it and recompute s for the clamped t
+    s_lo = np.where(a > eps, np.clip(-c / np.maximum(a, eps), 0.0, 1.0), 0.0)
+    s_hi = np.where(a > eps, np.clip((b - c) / np.maximum(a, eps), 0.0, 1.0), 0.0)
+    s = np.where(e > eps, np.where(t < 0.0, s_lo, np.where(t > 1.0, s_hi, s)), s_lo)  # (b degenerate: the point of a nearest to b0)
+    t = np.clip(t, 0.0, 1.0)
+    return a0 + s[:, None] * d1, b0 + t[:, None] * d2
+
+
 class Physics:
     def __init__(self, desc, terrain_heights, num_envs):
         self.desc = desc
@@ -308,6 +330,37 @@ class Physics:
             A += dt * w[:, None, None] * (np.swapaxes(J, 1, 2) @ Dm @ J)
             r += dt * (w * bias)[:, None] * np.einsum("nij,ni->nj", J, n)
             contacts.append((bdy, J, n, bias, Dm, w))
+        # self-collision (include/rl_env.h rl_model_desc.self_pair; the reference: enabled_self_collisions, assets/unitree.py:482):
+        # capsule pairs repel with an EXPLICIT penalty force k * penetration along the line between the segments' closest points,
+        # evaluated at the positions of the start of the substep (no damping, no friction, not part of the contact sensor)
+        m = self.desc.model
+        if int(m.num_self_pairs) > 0:
+            ks = float(sim.self_k)
+            cw0, cw1, crad, clink = [], [], [], []
+            for c in range(int(m.num_capsules)):
+                l = int(m.capsule_link[c])
+                cw0.append(ow[:, l] + np.einsum("nij,j->ni", Rw[:, l], np.array(m.capsule_p0[c][:], dtype=np.float64)))
+                cw1.append(ow[:, l] + np.einsum("nij,j->ni", Rw[:, l], np.array(m.capsule_p1[c][:], dtype=np.float64)))
+                crad.append(float(m.capsule_radius[c]))
+                clink.append(l)
+            for pi in range(int(m.num_self_pairs)):
+                ca, cb = int(m.self_pair[pi][0]), int(m.self_pair[pi][1])
+                xa, xb = segment_closest(cw0[ca], cw1[ca], cw0[cb], cw1[cb])
+                dvec = xa - xb
+                dist = np.linalg.norm(dvec, axis=-1)
+                pen = crad[ca] + crad[cb] - dist
+                hit = pen > 0.0  # (no switch margin: the force is continuous at the onset of the contact)
+                if not np.any(hit):
+                    continue
+                nrm_ab = dvec / np.maximum(dist, 1e-9)[:, None]
+                F = (ks * np.where(hit, pen, 0.0))[:, None] * nrm_ab  # on a; -F on b
+                for l, x, sgn in ((clink[ca], xa, 1.0), (clink[cb], xb, -1.0)):
+                    ploc = np.einsum("nji,nj->ni", Rw[:, l], x - ow[:, l])
+                    P = np.zeros((N, 3, 6))
+                    P[:, :, :3] = -sp.skew(ploc)
+                    P[:, :, 3:] = np.eye(3)
+                    J = Rw[:, l] @ P @ K[:, l]
+                    r += dt * sgn * np.einsum("nij,ni->nj", J, F)
         rhs = np.einsum("nij,nj->ni", H, nu) + dt * (np.concatenate([np.zeros((N, 6)), tau], -1) - b) + r
         if self.solve_dtype is None:
             nu_new = np.linalg.solve(H + A, rhs[..., None])[..., 0]

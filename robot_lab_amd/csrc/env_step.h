@@ -231,6 +231,25 @@ struct ChainT<TP, true, STRIDE> {
   RL_FN void setw(int i, const M3& R, V3 p, V3 ax) { putj((CL + i) * 15, R, p, ax); }
 };
 
+// Closest points of the segments a0-a1 and b0-b1 (Ericson, Real-Time Collision Detection 5.1.9), branch-free: the same case order
+// as oracle/physics.py `segment_closest`, so that both sides pick the same points where a segment degenerates to a point
+// or the two are parallel.
+RL_FN void segment_closest(V3 a0, V3 a1, V3 b0, V3 b1, V3& xa, V3& xb) {
+  const V3 d1 = a1 - a0, d2 = b1 - b0, r = a0 - b0;
+  const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+  const float eps = 1e-12f;
+  const float den = a * e - b * b;
+  const float ia = a > eps ? frcp(a) : 0.f, ie = e > eps ? frcp(e) : 0.f;
+  float s = den > eps ? clampf((b * f - c * e) * frcp(den), 0.f, 1.f) : 0.f;
+  s = a > eps ? s : 0.f;
+  float t = (b * s + f) * ie;
+  const float s_lo = clampf(-c * ia, 0.f, 1.f), s_hi = clampf((b - c) * ia, 0.f, 1.f);
+  s = e > eps ? (t < 0.f ? s_lo : (t > 1.f ? s_hi : s)) : s_lo;
+  t = clampf(t, 0.f, 1.f);
+  xa = a0 + s * d1;
+  xb = b0 + t * d2;
+}
+
 // frame of the trunk link reached after `depth` trunk joints (0 = the base itself)
 template <class TP, class CT>
 RL_FN void trunk_frame(const CT& C, int depth, M3& Rf, V3& pf) {
@@ -367,13 +386,14 @@ struct LsMat {
 // Trunk + limbs instance (articulated-body form, substeps_aba_trunk): per limb the kinematics (15 words per joint), one 27-word
 // record per link group (rigid inertia + contact damping of a link, as seen in base coordinates) and 12 words per limb joint
 // that first hold the link velocity / bias acceleration and later the elimination's U / D and u / D; per ENV one 27-word
-// accumulator per trunk link (base, waist links, torso) that the limbs and the trunk links' owners ds_add into.
+// accumulator per trunk link (base, waist links, torso) that the limbs and the trunk links' owners ds_add into, and 8 words per
+// self-collision capsule (centre, half axis, radius, bounding radius in base coordinates: EnvLane::self_place).
 constexpr int LINK_REC = 27;  // 21 (6 x 6 symmetric) + 6
 template <class TP>
 struct LbLayout {
   enum { CHAIN = 0, REC = TP::JX * 15, VA = REC + (TP::CL + 1) * LINK_REC, WORDS = TP::NW > 0 ? VA + TP::CL * 12 : 0,
          AUX_WORDS = 0,
-         ENV_WORDS = TP::NW > 0 ? (TP::NW + 1) * LINK_REC : 0 };
+         ENV_WORDS = TP::NW > 0 ? (TP::NW + 1) * LINK_REC + SELF_CAPS * SELF_CAP_WORDS : 0 };  // trunk accumulators | placed self-collision capsules
 };
 
 // STASH > 0: room for the contacts of one link group (x, n, bias, d_n, d_t per sphere slot) so that the sensor
@@ -1119,6 +1139,84 @@ struct EnvLane {
   RL_FN float* va_words(int j) const { return ctx.limb_scratch() + (LB_VA + j * 12) * LBS; }
   RL_FN float* trunk_words(int d) const { return ctx.env_scratch() + d * LINK_REC; }
 
+  // ------------------------------------------------------------------ self-collision (trunk + limbs instance)
+  // enabled_self_collisions of the reference's ArticulationCfg (assets/unitree.py:482 G1, assets/roboparty.py:33 ATOM01): up to 16
+  // links carry a capsule, the listed pairs repel with an explicit penalty force k * penetration along the line between the
+  // segments' closest points, once per substep, at the positions of the start of the substep (oracle/physics.py does the same).
+  // Dealt to the env's 16 virtual lanes (env_tables.h SelfLaneTab): each places at most one capsule - centre and half axis in base
+  // coordinates into 8 env-shared words, ahead of the group_sync the link records need anyway - and, once the records are
+  // complete, tests at most five pairs; a hit ds_adds dt * [x cross F; F] into the bias of the two links' records.
+  static constexpr int SELF_V = 4 / SUB;  // virtual lanes this lane plays: v = 4 k + sub + SUB * i
+  SelfLaneTab self_tab[NW > 0 ? SELF_V : 1];
+  RL_FN bool self_on() const { return NW > 0 && S.self_k > 0.f; }
+  RL_FN float* cap_words(int c) const { return ctx.env_scratch() + (NW + 1) * LINK_REC + c * SELF_CAP_WORDS; }
+  RL_FN void self_load() {  // once per launch: this lane's share of the dealing, from the table image in HBM into registers
+    if constexpr (NW > 0) {
+      if (!self_on()) return;
+      const auto& Tg = ctx.template tables_global<TablesT<TP>>();
+#pragma unroll
+      for (int i = 0; i < SELF_V; ++i) self_tab[i] = Tg.self_lane[4 * k + sub + SUB * i];
+    }
+  }
+  RL_FN void self_place(const ChainTP& C) {
+    if constexpr (NW > 0) {
+#pragma unroll
+      for (int i = 0; i < SELF_V; ++i) {
+        const SelfLaneTab& t = self_tab[i];
+        if (t.cap < 0) continue;
+        M3 Rf = identity3();
+        V3 pf{0.f, 0.f, 0.f};
+        if (t.frame >= 0) { Rf = C.m3(t.frame * 15); pf = C.v3(t.frame * 15 + 9); }
+        const V3 p0 = pf + mul(Rf, ld3(t.p0)), p1 = pf + mul(Rf, ld3(t.p1));
+        const V3 c = 0.5f * (p0 + p1), h = 0.5f * (p1 - p0);
+        float* w = cap_words(t.cap);  // centre, half axis, radius, radius of the bounding sphere
+        w[0] = c.x; w[1] = c.y; w[2] = c.z; w[3] = h.x; w[4] = h.y; w[5] = h.z; w[6] = t.r; w[7] = t.r + fsqrt(dot(h, h));
+      }
+    }
+  }
+  RL_FN void self_add(int kk, int gg, V3 x, V3 F) {  // dt * [x cross F; F] onto the bias of a link record (limb kk's group gg; kk = 7: trunk depth gg)
+    const V3 m = u.dt * cross(x, F), f = u.dt * F;
+    const float v6[6] = {m.x, m.y, m.z, f.x, f.y, f.z};
+    float* w = kk == 7 ? trunk_words(gg) + B6::size : ctx.limb_scratch_of(kk) + (LB_REC + gg * LINK_REC + B6::size) * LBS;
+    const int stride = kk == 7 ? 1 : LBS;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + i * stride, v6[i]);
+  }
+  RL_FN void self_apply() {
+    if constexpr (NW > 0) {
+#pragma unroll
+      for (int i = 0; i < SELF_V; ++i)
+#pragma unroll
+        for (int p = 0; p < SELF_PPL; ++p) {
+          const int wd = self_tab[i].pair[p];
+          const bool valid = wd >= 0;
+          const int a = valid ? (wd & 15) : 0, b = valid ? ((wd >> 4) & 15) : 0;
+          const float* wa = cap_words(a);
+          const float* wb = cap_words(b);
+          // bounding spheres first: the host deals the pairs closest-in-the-default-pose first, so the later trips hold pairs that
+          // are far apart in every env of the wavefront and end here
+          const V3 ca{wa[0], wa[1], wa[2]}, cb{wb[0], wb[1], wb[2]};
+          const V3 dc = ca - cb;
+          const float rb = wa[7] + wb[7];
+          const bool near = valid && dot(dc, dc) < rb * rb;
+          if (!ctx.any(near)) continue;
+          const V3 ha{wa[3], wa[4], wa[5]}, hb{wb[3], wb[4], wb[5]};
+          V3 xa, xb;
+          segment_closest(ca - ha, ca + ha, cb - hb, cb + hb, xa, xb);
+          const V3 dv = xa - xb;
+          const float d2 = dot(dv, dv), rr = wa[6] + wb[6];
+          const bool hit = near && d2 < rr * rr;
+          if (!ctx.any(hit)) continue;  // the usual case: nothing of this trip touches anywhere in the wavefront
+          if (hit) {
+            const float dist = fsqrt(d2);
+            const V3 F = (S.self_k * (rr - dist) * frcp(fmaxf(dist, 1e-9f))) * dv;  // on a; -F on b
+            self_add((wd >> 8) & 7, (wd >> 11) & 15, xa, F);
+            self_add((wd >> 15) & 7, (wd >> 18) & 15, xb, V3{-F.x, -F.y, -F.z});
+          }
+        }
+    }
+  }
+
   // twist of trunk link `depth` (0 = the base: `base`; i + 1 = behind trunk joint i: arr[i]) for a per-lane depth.  A 0/1-weighted
   // sum, not a select chain: hipcc turns the chain into an indexed load from a SCRATCH copy of the array (112 bytes of private
   // memory per lane and 48 scratch instructions on the G1 instance).
@@ -1180,6 +1278,7 @@ struct EnvLane {
     const SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
     ChainTP C = new_chain();
     kinematics(C);
+    if (self_on()) self_place(C);  // (a lane reads frames of its own limb's words only: written by itself, identically in every sub-lane)
     // trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
     SV Sw[NW], Vw[NW], aw[NW];
     {
@@ -1273,6 +1372,10 @@ struct EnvLane {
       }
     });
     ctx.group_sync();
+    if (self_on()) {  // the records are complete: pair forces onto their bias words, then the elimination may read them
+      self_apply();
+      ctx.group_sync();
+    }
     // ---- limb elimination, tip -> attachment (every sub-lane: same values; results parked for the outward pass)
     RL_PHASE(9, "sub.aba");
     LinkRec P;

@@ -185,12 +185,37 @@ struct TaskTab {  // everything that is not per limb
   float default_root_pos[3], default_root_quat[4];
 };
 
+// Self-collision (trunk + limbs instance; include/rl_env.h rl_model_desc.self_pair).  The work of an env is dealt to 16 "virtual
+// lanes" v = 4 k + s (limb k, sub-lane s; with fewer sub-lanes per limb a lane plays several): virtual lane v places at most one
+// capsule - one of a link of ITS limb, or of a trunk link - and tests up to SELF_PPL capsule pairs.  These constants are read from
+// the table image in HBM once per launch and kept in registers (the trunk + limbs instance has no LDS left for them: DESIGN.md 2).
+constexpr int SELF_PPL = 5;   // pairs per virtual lane (RL_MAX_SELF_PAIRS / 16)
+constexpr int SELF_CAPS = 16; // capsule slots of an env (RL_MAX_CAPSULES)
+constexpr int SELF_CAP_WORDS = 8;  // env-shared LDS words of a placed capsule: centre, half axis (base coordinates), radius, bounding radius
+struct SelfLaneTab {  // 64 bytes
+  int32_t cap;          // capsule slot this virtual lane places, -1: none
+  int32_t frame;        // chain slot of the capsule's link frame: limb joint j -> j, trunk joint i -> CL + i, -1: the base
+  float p0[3], p1[3], r;  // link frame
+  // pair word: a | b << 4 | ka << 8 | ga << 11 | kb << 15 | gb << 18, -1: none.  a, b: capsule slots; k: limb whose record takes the
+  // force (7: a trunk link), g: link group of that limb (limb link j -> j + 1) or the trunk depth
+  int32_t pair[SELF_PPL];
+  int32_t pad_[2];
+};
+template <bool ON>
+struct SelfTail {
+  SelfLaneTab self_lane[SELF_CAPS];
+};
+template <>
+struct SelfTail<false> {};
+
 template <class TP>
-struct TablesT : TaskTab {
+struct TablesBody : TaskTab {
   LaneTabT<TP> lane[NLANE];
   ObsGroupTabT<TP::OBS_NC> obs[2];  // policy, critic
-  RewTab rew[MAX_T];  // last: only the first n_rewards entries are staged into LDS (KState::table_bytes)
+  RewTab rew[MAX_T];  // last of what is STAGED: only the first n_rewards entries go to LDS (KState::table_bytes)
 };
+template <class TP>
+struct TablesT : TablesBody<TP>, SelfTail<(TP::NW > 0)> {};  // (the tail sits behind rew[] in the image: never staged)
 using Tables = TablesT<TopoMax>;  // host side / export-import kernels; env kernels read the packed TablesT<TP>
 
 // host: unpacked -> the instance's compact layout (trunk joints already sit at [CL, CL + NW) of the joint arrays)
@@ -198,6 +223,8 @@ template <class TP>
 inline void pack_tables(const Tables& s, TablesT<TP>& d) {
   static_cast<TaskTab&>(d) = static_cast<const TaskTab&>(s);
   for (int t = 0; t < MAX_T; ++t) d.rew[t] = s.rew[t];
+  if constexpr (TP::NW > 0)
+    for (int v = 0; v < SELF_CAPS; ++v) d.self_lane[v] = s.self_lane[v];
   for (int g = 0; g < 2; ++g) {
     d.obs[g].n_cols = s.obs[g].n_cols; d.obs[g].scan_off = s.obs[g].scan_off; d.obs[g].scan_n = s.obs[g].scan_n;
     d.obs[g].dim = s.obs[g].dim; d.obs[g].corrupt = s.obs[g].corrupt; d.obs[g].scan = s.obs[g].scan;
@@ -344,6 +371,7 @@ struct KState {
   uint32_t step_counter;
   uint32_t table_bytes;  // bytes of the packed table image the env kernels stage into LDS (multiple of 16)
   int32_t mode;          // KMode
+  float self_k;          // self-collision penalty stiffness; 0: no self-collision pass (rl_sim_desc.self_k when the model lists capsule pairs)
 };
 
 }  // namespace rl

@@ -921,6 +921,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     if constexpr (Base::ABA) {
       this->substeps_aba(q_tgt, qd_tgt, T.decimation);
     } else {
+      this->self_load();
       for (int s = 0; s < T.decimation; ++s) this->substep_aba_trunk(q_tgt, qd_tgt);
     }
     RL_PHASE(15, "terminations");

@@ -159,6 +159,7 @@ struct Backend {
       case 74: lds_bytes = lds_need<TopoG1, 4>(T); break;
       default: err = "no lane-program instance for chain length " + std::to_string(T.CL); return -1;
     }
+    if (std::getenv("RL_ENV_DEBUG")) fprintf(stderr, "rl_env: %zu B of LDS per single-wavefront workgroup (%zu fit a CU)\n", lds_bytes, (size_t)(160 * 1024) / lds_bytes);
     if (lds_bytes > 160 * 1024) {
       err = "observation rows do not fit the 160 KiB LDS of a CU";
       return -1;

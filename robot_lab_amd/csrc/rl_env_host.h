@@ -134,6 +134,47 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   }
   for (int l = 0; l < m.num_links; ++l)
     if (link_k[l] == -2) return fail("link " + std::to_string(l) + " belongs to neither the trunk nor a limb chain");
+  // self-collision: capsules and capsule pairs dealt to the env's 16 virtual lanes (env_tables.h SelfLaneTab)
+  for (int v = 0; v < SELF_CAPS; ++v) {
+    SelfLaneTab& sl = T.self_lane[v];
+    memset(&sl, 0, sizeof(sl));
+    sl.cap = sl.frame = -1;
+    for (int i = 0; i < SELF_PPL; ++i) sl.pair[i] = -1;
+  }
+  if (m.num_self_pairs > 0) {
+    if (NW == 0) return fail("self-collision pairs need the trunk + limbs instance");
+    if (m.num_capsules < 2 || m.num_capsules > SELF_CAPS || m.num_capsules > RL_MAX_CAPSULES || m.num_self_pairs > SELF_CAPS * SELF_PPL || m.num_self_pairs > RL_MAX_SELF_PAIRS)
+      return fail("self-collision: capsule / pair count out of range");
+    int cap_k[SELF_CAPS], cap_g[SELF_CAPS];
+    for (int pass = 0; pass < 2; ++pass)  // capsules of limb links first (they must sit with a lane of their limb), trunk links wherever room is left
+      for (int c = 0; c < m.num_capsules; ++c) {
+        const int l = m.capsule_link[c];
+        if (l < 0 || l >= m.num_links) return fail("self-collision: capsule link out of range");
+        const bool limb = link_k[l] >= 0;
+        if (limb != (pass == 0)) continue;
+        int v = -1;
+        if (limb) {
+          for (int q = 0; q < 4 && v < 0; ++q)
+            if (T.self_lane[4 * link_k[l] + q].cap < 0) v = 4 * link_k[l] + q;
+        } else {
+          for (int q = SELF_CAPS - 1; q >= 0 && v < 0; --q)
+            if (T.self_lane[q].cap < 0) v = q;
+        }
+        if (v < 0) return fail("self-collision: more than four capsules on one limb");
+        SelfLaneTab& sl = T.self_lane[v];
+        sl.cap = c;
+        sl.frame = limb ? link_j[l] : (link_j[l] == 0 ? -1 : CL + link_j[l] - 1);
+        for (int q = 0; q < 3; ++q) { sl.p0[q] = m.capsule_p0[c][q]; sl.p1[q] = m.capsule_p1[c][q]; }
+        sl.r = m.capsule_radius[c];
+        cap_k[c] = limb ? link_k[l] : 7;
+        cap_g[c] = limb ? link_j[l] + 1 : link_j[l];
+      }
+    for (int p = 0; p < m.num_self_pairs; ++p) {
+      const int a = m.self_pair[p][0], b = m.self_pair[p][1];
+      if (a < 0 || b < 0 || a >= m.num_capsules || b >= m.num_capsules || a == b) return fail("self-collision: pair index out of range");
+      T.self_lane[p % SELF_CAPS].pair[p / SELF_CAPS] = a | b << 4 | cap_k[a] << 8 | cap_g[a] << 11 | cap_k[b] << 15 | cap_g[b] << 18;
+    }
+  }
   // bodies -> lane slots.  Trunk-link bodies with collision spheres: slot 0 of a lane whose group 0 rides
   // on that trunk link; limb bodies: slots 1.. of their lane; sphere-less trunk bodies: any free slot.
   std::vector<int> nsph(m.num_bodies, 0);
@@ -421,7 +462,7 @@ inline size_t packed_size(const TaskTab& T) {
 }
 template <class TP>
 inline size_t staged_bytes_t(const TaskTab& T) {  // `rew` is the last member: everything up to its first n_rewards entries
-  return (sizeof(TablesT<TP>) - (size_t)(MAX_T - T.n_rewards) * sizeof(RewTab) + 15) / 16 * 16;
+  return (sizeof(TablesBody<TP>) - (size_t)(MAX_T - T.n_rewards) * sizeof(RewTab) + 15) / 16 * 16;
 }
 inline size_t staged_bytes(const TaskTab& T) {
   return T.NW > 0 ? staged_bytes_t<TopoG1>(T) : (T.CL == 4 ? staged_bytes_t<TopoQuad4>(T) : staged_bytes_t<TopoQuad3>(T));
@@ -510,6 +551,9 @@ struct EnvImpl {
     const Layout ly(tables.CL, tables.NW, tables.NBS);
     memset(&S, 0, sizeof(S));
     S.N = N; S.Npad = Npad; S.seed = seed; S.ept = ept; S.table_bytes = (uint32_t)staged_bytes(tables);
+    S.self_k = d->model.num_self_pairs > 0 ? d->sim.self_k : 0.f;  // (build_tables has checked that the instance can run the pass)
+    if (const char* sv = std::getenv("RL_ENV_SELF"))  // RL_ENV_SELF=0: the pass off although the model lists pairs (timing A/Bs, diagnostics)
+      if (atoi(sv) == 0) S.self_k = 0.f;
     S.lane_state = alloc<float>(ntile * (size_t)ly.NF_LANE * NLANE * ept);
     S.env_state = alloc<float>(ntile * (size_t)ly.NF_ENV * ept);
     S.flags = alloc<int32_t>(Np); S.level = alloc<int32_t>(Np); S.ttype = alloc<int32_t>(Np);

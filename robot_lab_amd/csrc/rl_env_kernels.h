@@ -56,12 +56,16 @@ struct WaveCtx {
   int lane;
   __device__ float* lane_scratch() const { return lscratch + lane; }
   __device__ float* limb_scratch() const { return lbscratch + lane / SUB; }
+  __device__ float* limb_scratch_of(int k2) const { return lbscratch + (lane / LPE) * 4 + k2; }  // limb k2 of this lane's env
   __device__ float* env_scratch() const { return envs; }
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
   __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
   template <class TT>
   __device__ const TT& tables() const { return *static_cast<const TT*>(T); }
+  const void* Tg;  // the whole table image in HBM (the LDS copy `T` ends with the used reward descriptors)
+  template <class TT>
+  __device__ const TT& tables_global() const { return *static_cast<const TT*>(Tg); }
   __device__ int env_in_tile() const { return lane / LPE; }
   __device__ int k() const { return (lane / SUB) & 3; }
   __device__ int sub() const { return lane & (SUB - 1); }
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
   Ctx ctx;
   ctx.T = Tl;
+  ctx.Tg = Tgv;
   ctx.dim[0] = Tl->policy_dim;
   ctx.dim[1] = Tl->critic_dim;
   // (one lane per limb: a group without noise has no staging row - env_terms.h write_group<DIRECT>)

@@ -16,6 +16,8 @@ RL_MAX_LINKS = 32
 RL_MAX_DOF = 31
 RL_MAX_BODIES = 48
 RL_MAX_SPHERES = 96
+RL_MAX_CAPSULES = 16
+RL_MAX_SELF_PAIRS = 80
 RL_MAX_REWARD_TERMS = 40
 RL_MAX_OBS_TERMS = 12
 RL_TERM_NPARAM = 8
@@ -100,6 +102,9 @@ class ModelDesc(C.Structure):
         ("action_is_vel", i32 * RL_MAX_DOF),
         ("action_scale", f32 * RL_MAX_DOF), ("action_offset", f32 * RL_MAX_DOF),
         ("action_clip_lo", f32 * RL_MAX_DOF), ("action_clip_hi", f32 * RL_MAX_DOF),
+        ("self_collision", i32), ("num_capsules", i32), ("capsule_link", i32 * RL_MAX_CAPSULES),
+        ("capsule_p0", (f32 * 3) * RL_MAX_CAPSULES), ("capsule_p1", (f32 * 3) * RL_MAX_CAPSULES), ("capsule_radius", f32 * RL_MAX_CAPSULES),
+        ("num_self_pairs", i32), ("self_pair", (i32 * 2) * RL_MAX_SELF_PAIRS),
     ]
 
 
@@ -107,7 +112,7 @@ class SimDesc(C.Structure):
     _fields_ = [
         ("dt", f32), ("decimation", i32), ("gravity", f32), ("contact_k", f32), ("contact_c", f32),
         ("contact_phi_ref", f32), ("contact_ct", f32), ("contact_vdep", f32), ("contact_vstick", f32),
-        ("limit_k", f32), ("limit_c", f32), ("force_threshold", f32),
+        ("limit_k", f32), ("limit_c", f32), ("force_threshold", f32), ("self_k", f32),
     ]
 
 

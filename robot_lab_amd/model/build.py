@@ -12,7 +12,7 @@ import re
 
 import numpy as np
 
-from ..desc import EnvDesc, OBS, REW, RL_MAX_BODIES, RL_MAX_DOF, RL_MAX_LINKS, RL_MAX_SPHERES, mask_of, set_arr
+from ..desc import EnvDesc, OBS, REW, RL_MAX_BODIES, RL_MAX_CAPSULES, RL_MAX_DOF, RL_MAX_LINKS, RL_MAX_SELF_PAIRS, RL_MAX_SPHERES, mask_of, set_arr
 from .urdf import RobotModel, cap_spheres
 
 
@@ -67,7 +67,7 @@ def _mat_to_quat(R):
 DEFAULT_SIM = dict(
     dt=0.005, decimation=4, gravity=9.81,
     contact_k=2.0e4, contact_c=400.0, contact_phi_ref=0.005, contact_ct=4000.0, contact_vdep=1.0,
-    contact_vstick=0.01, limit_k=2000.0, limit_c=20.0, force_threshold=1.0,
+    contact_vstick=0.01, limit_k=2000.0, limit_c=20.0, force_threshold=1.0, self_k=5.0e3,
 )
 
 
@@ -159,6 +159,20 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
         m.sphere_body[g] = s.body
         set_arr(m.sphere_center[g], s.center)
         m.sphere_radius[g] = s.radius
+    # self-collision proxies (model/selfcol.py): only where the cfg enables it, and only on the trunk + limbs instance
+    m.self_collision = 1 if rob.get("self_collisions") else 0
+    m.num_capsules = m.num_self_pairs = 0
+    if m.self_collision and ok and not quad:
+        from .selfcol import fit
+
+        caps, pairs = fit(model, dq, list(trunk), [ch for _, ch in limbs], RL_MAX_CAPSULES, RL_MAX_SELF_PAIRS)
+        m.num_capsules, m.num_self_pairs = len(caps), len(pairs)
+        for c, (link, p0, p1, r) in enumerate(caps):
+            m.capsule_link[c], m.capsule_radius[c] = link, r
+            set_arr(m.capsule_p0[c], p0)
+            set_arr(m.capsule_p1[c], p1)
+        for i, (a, b) in enumerate(pairs):
+            m.self_pair[i][0], m.self_pair[i][1] = a, b
     set_arr(m.default_root_pos, rob["init_pos"])
     set_arr(m.default_root_quat, rob.get("init_rot", (1.0, 0.0, 0.0, 0.0)))
     # actuators

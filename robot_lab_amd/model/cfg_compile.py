@@ -71,6 +71,8 @@ def compile_spec(cfg) -> tuple[dict, str]:
     # (assets/booster.py:29-31) they are passive hinges whose action-vector entries have no effect
     gains = getattr(getattr(robot.spawn, "joint_drive", None), "gains", None)
     spec["robot"]["unactuated_passive"] = bool(gains is not None and gains.stiffness == 0 and gains.damping == 0)
+    # ArticulationRootPropertiesCfg.enabled_self_collisions (assets/unitree.py:482 G1, assets/roboparty.py:33 ATOM01: True)
+    spec["robot"]["self_collisions"] = bool(getattr(getattr(robot.spawn, "articulation_props", None), "enabled_self_collisions", False))
     # actions
     actions = []
     for name, a in vars(cfg.actions).items():

@@ -101,6 +101,7 @@ class RobotModel:
     links: list[Link] = field(default_factory=list)
     bodies: list[Body] = field(default_factory=list)
     spheres: list[Sphere] = field(default_factory=list)
+    geom_spheres: list[Sphere] = field(default_factory=list)  # the spheres of the collision geometry before pruning / thinning / capping (capsule fits: model/selfcol.py)
 
     @property
     def joint_names(self):
@@ -409,6 +410,7 @@ def load_urdf(path: str, name: str | None = None, joint_order: list[str] | None 
         model.bodies.append(Body(rb["name"], rb["link"], rb["pos"], rb["rot"], m, com, I))
         for c, r, ex in rb["spheres"]:
             model.spheres.append(Sphere(bi, c, r, ex))
+    model.geom_spheres = list(model.spheres)
     _prune_contained_spheres(model)
     _thin_spheres(model)
     return model

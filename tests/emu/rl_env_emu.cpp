@@ -242,6 +242,7 @@ struct HostCtx {
   float scratch[rl::LsLayout<rl::MAX_NBS, rl::MAX_SPL>::WORDS];
   float* lane_scratch() { return scratch; }
   float* limb_scratch() { return team->lb[k_]; }
+  float* limb_scratch_of(int k2) { return team->lb[k2]; }
   float* env_scratch() { return team->envw; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
@@ -250,6 +251,8 @@ struct HostCtx {
   int k_, sub_, e_, sense_ = 0;
   template <class TT>
   const TT& tables() const { return *static_cast<const TT*>(T); }
+  template <class TT>
+  const TT& tables_global() const { return *static_cast<const TT*>(T); }  // (here the lanes read the whole image in place)
   int k() const { return k_; }
   int sub() const { return sub_; }
   int env() const { return e_; }
