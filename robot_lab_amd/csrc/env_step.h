@@ -1184,28 +1184,36 @@ struct EnvLane {
   }
   RL_FN void self_apply() {
     if constexpr (NW > 0) {
+      // bounding spheres of all this lane's pairs first (one batch of LDS reads, no vote in between): the host deals the pairs
+      // closest-in-the-default-pose first, so the later trips hold pairs that are far apart in every env of the wavefront
+      bool near[SELF_V * SELF_PPL];
 #pragma unroll
       for (int i = 0; i < SELF_V; ++i)
 #pragma unroll
         for (int p = 0; p < SELF_PPL; ++p) {
+          near[i * SELF_PPL + p] = false;
+          if (p >= S.self_trips) continue;  // (uniform: the model has fewer pairs than slots)
           const int wd = self_tab[i].pair[p];
-          const bool valid = wd >= 0;
-          const int a = valid ? (wd & 15) : 0, b = valid ? ((wd >> 4) & 15) : 0;
-          const float* wa = cap_words(a);
-          const float* wb = cap_words(b);
-          // bounding spheres first: the host deals the pairs closest-in-the-default-pose first, so the later trips hold pairs that
-          // are far apart in every env of the wavefront and end here
-          const V3 ca{wa[0], wa[1], wa[2]}, cb{wb[0], wb[1], wb[2]};
-          const V3 dc = ca - cb;
+          const float* wa = cap_words(wd >= 0 ? (wd & 15) : 0);
+          const float* wb = cap_words(wd >= 0 ? ((wd >> 4) & 15) : 0);
+          const V3 dc = V3{wa[0], wa[1], wa[2]} - V3{wb[0], wb[1], wb[2]};
           const float rb = wa[7] + wb[7];
-          const bool near = valid && dot(dc, dc) < rb * rb;
-          if (!ctx.any(near)) continue;
-          const V3 ha{wa[3], wa[4], wa[5]}, hb{wb[3], wb[4], wb[5]};
+          near[i * SELF_PPL + p] = wd >= 0 && dot(dc, dc) < rb * rb;
+        }
+#pragma unroll
+      for (int i = 0; i < SELF_V; ++i)
+#pragma unroll
+        for (int p = 0; p < SELF_PPL; ++p) {
+          if (p >= S.self_trips || !ctx.any(near[i * SELF_PPL + p])) continue;
+          const int wd = self_tab[i].pair[p];
+          const float* wa = cap_words(wd >= 0 ? (wd & 15) : 0);
+          const float* wb = cap_words(wd >= 0 ? ((wd >> 4) & 15) : 0);
+          const V3 ca{wa[0], wa[1], wa[2]}, cb{wb[0], wb[1], wb[2]}, ha{wa[3], wa[4], wa[5]}, hb{wb[3], wb[4], wb[5]};
           V3 xa, xb;
           segment_closest(ca - ha, ca + ha, cb - hb, cb + hb, xa, xb);
           const V3 dv = xa - xb;
           const float d2 = dot(dv, dv), rr = wa[6] + wb[6];
-          const bool hit = near && d2 < rr * rr;
+          const bool hit = near[i * SELF_PPL + p] && d2 < rr * rr;
           if (!ctx.any(hit)) continue;  // the usual case: nothing of this trip touches anywhere in the wavefront
           if (hit) {
             const float dist = fsqrt(d2);

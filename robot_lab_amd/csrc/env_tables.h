@@ -372,6 +372,7 @@ struct KState {
   uint32_t table_bytes;  // bytes of the packed table image the env kernels stage into LDS (multiple of 16)
   int32_t mode;          // KMode
   float self_k;          // self-collision penalty stiffness; 0: no self-collision pass (rl_sim_desc.self_k when the model lists capsule pairs)
+  int32_t self_trips;    // pair slots per virtual lane that are in use: ceil(pairs / 16) <= SELF_PPL
 };
 
 }  // namespace rl

@@ -552,6 +552,7 @@ struct EnvImpl {
     memset(&S, 0, sizeof(S));
     S.N = N; S.Npad = Npad; S.seed = seed; S.ept = ept; S.table_bytes = (uint32_t)staged_bytes(tables);
     S.self_k = d->model.num_self_pairs > 0 ? d->sim.self_k : 0.f;  // (build_tables has checked that the instance can run the pass)
+    S.self_trips = (d->model.num_self_pairs + SELF_CAPS - 1) / SELF_CAPS;
     if (const char* sv = std::getenv("RL_ENV_SELF"))  // RL_ENV_SELF=0: the pass off although the model lists pairs (timing A/Bs, diagnostics)
       if (atoi(sv) == 0) S.self_k = 0.f;
     S.lane_state = alloc<float>(ntile * (size_t)ly.NF_LANE * NLANE * ept);

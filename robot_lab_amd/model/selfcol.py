@@ -9,10 +9,11 @@ instance, so the model here is deliberately small:
   (model/urdf.py `_geom_to_spheres`, before the thinning the ground contact's budget asks for) - axis = principal direction of the sphere centres,
   r = the largest (distance of a centre from the axis + that sphere's radius);
 * at most RL_MAX_CAPSULES links get one: the base, every trunk link that has geometry, per limb its outermost link and its two
-  largest others, then whatever is left of the budget by capsule size;
+  largest others;
 * the pairs that are tested are all pairs of capsules on different links that are not parent / child, MINUS the pairs that
   already overlap (or come within `margin`) in the default joint pose - fat proxies of neighbouring links (pelvis / thigh,
-  torso / shoulder) intersect where the meshes do not, and a pair that starts in contact would push forever;
+  torso / shoulder) intersect where the meshes do not, and a pair that starts in contact would push forever - and minus the pairs
+  that are more than `max_gap` (0.35 m) apart in that pose (a foot and the opposite shoulder, a knee and an elbow);
 * a tested pair repels with an explicit penalty force `self_k * penetration` along the line between the closest points of the
   two segments, once per substep (csrc/env_step.h `self_collision_pass`, oracle/physics.py).
 
@@ -91,7 +92,8 @@ def segment_distance(a0, a1, b0, b1):
     return float(np.linalg.norm(pa - pb)), pa, pb
 
 
-def fit(model: RobotModel, default_q, trunk_links, limbs, max_capsules: int, max_pairs: int, margin: float = 0.01, min_radius: float = 0.015):
+def fit(model: RobotModel, default_q, trunk_links, limbs, max_capsules: int, max_pairs: int, margin: float = 0.01, min_radius: float = 0.015,
+        max_gap: float = 0.35):
     """-> (capsules [(link, p0, p1, r)], pairs [(a, b)] with a < b indexing capsules).  `limbs`: the limb chains' link lists, root first."""
     by_link: dict[int, list] = {}
     for s in (model.geom_spheres or model.spheres):  # the geometry as read, not the thinned set the ground contact budgets
@@ -102,16 +104,14 @@ def fit(model: RobotModel, default_q, trunk_links, limbs, max_capsules: int, max
         caps[link] = (p0, p1, max(r, min_radius))
     size = lambda l: np.linalg.norm(caps[l][1] - caps[l][0]) + 2.0 * caps[l][2]  # noqa: E731
     # which links: the base and the trunk links that have geometry; per limb its outermost link with geometry (hand, foot) and its
-    # two largest others (G1: thigh + shin, upper arm + forearm); what is left of the budget by size
+    # two largest others (G1: thigh + shin, upper arm + forearm)
     chosen = [l for l in [0] + list(trunk_links) if l in caps]
     for chain in limbs:
         have = [l for l in chain if l in caps]
         if have:
             chosen.append(have[-1])
             chosen += sorted(have[:-1], key=size, reverse=True)[:2]
-    chosen = chosen[:max_capsules]
-    chosen += sorted((l for l in caps if l not in chosen), key=size, reverse=True)[:max_capsules - len(chosen)]
-    chosen = sorted(chosen)
+    chosen = sorted(chosen[:max_capsules])
     capsules = [(l, *caps[l]) for l in chosen]
     R, p = forward_kinematics(model, np.asarray(default_q, dtype=np.float64))
     world = [(R[l] @ p0 + p[l], R[l] @ p1 + p[l], r) for l, p0, p1, r in capsules]
@@ -124,6 +124,8 @@ def fit(model: RobotModel, default_q, trunk_links, limbs, max_capsules: int, max
             d, _, _ = segment_distance(world[i][0], world[i][1], world[j][0], world[j][1])
             gap = d - world[i][2] - world[j][2]
             if gap < margin:  # in contact in the default pose: proxies of neighbouring links, not a collision to resolve
+                continue
+            if gap > max_gap:  # far apart when the robot stands: a foot and the opposite shoulder do not meet
                 continue
             pairs.append((gap, i, j))
     # closest in the default pose first: those are the pairs that can meet - they survive a truncation, and the lane program, which
