@@ -2,8 +2,8 @@
 G1, assets/roboparty.py:33 ATOM01 - every other asset of the reference has it off).
 
 The reference hands the links' collision meshes to PhysX, which collides every pair of links of the articulation except
-parent / child.  The lane program has no mesh-mesh test and 640 bytes of LDS to spare per wavefront on the trunk + limbs
-instance, so the model here is deliberately small:
+parent / child.  The lane program has no mesh-mesh test and had 2.4 KB of LDS to spare per workgroup on the trunk + limbs
+instance (a second workgroup must still fit the CU), so the model here is deliberately small:
 
 * a link is ONE capsule (segment p0 - p1 in the link frame, radius r) fitted to the spheres its collision geometry was turned into
   (model/urdf.py `_geom_to_spheres`, before the thinning the ground contact's budget asks for) - axis = principal direction of the sphere centres,
