@@ -28,8 +28,8 @@
 extern "C" {
 #endif
 
-#define RL_MAX_LINKS 32
-#define RL_MAX_DOF 31
+#define RL_MAX_LINKS 33
+#define RL_MAX_DOF 32
 #define RL_MAX_BODIES 48
 #define RL_MAX_SPHERES 96
 #define RL_MAX_CAPSULES 16   /* self-collision proxies: at most one capsule per selected link */
@@ -132,7 +132,7 @@ typedef struct rl_model_desc {
   int32_t chain_nj[4];                  /* joints of chain k (G1: legs 6, arms 7) */
   int32_t chain_attach[4];
   int32_t num_trunk;
-  int32_t trunk_link[4];
+  int32_t trunk_link[8];                /* <= 6 in use (GR1: waist 3 + head 3, the arms leaving the spine at depth 3) */
   int32_t link_parent[RL_MAX_LINKS];
   float link_origin[RL_MAX_LINKS][3];   /* joint origin in parent link frame */
   float link_quat[RL_MAX_LINKS][4];     /* joint frame orientation in the parent link frame, (w,x,y,z) (URDF joint rpy) */

@@ -1416,16 +1416,21 @@ struct EnvLane {
       for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(w + i, P.A[i]);
 #pragma unroll
       for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + B6::size + i, P.r[i]);
-      if (k <= NW) {  // lane group k also owns trunk link k (0 = the base link); the persistent external wrench [UPSTREAM B8]
-        const int bi = LY.EF_BASE_INERTIA + k * INERTIA_NF;
+      // lane group k also owns the trunk links k, k + 4 (0 = the base link; a spine of more than three joints has more trunk links
+      // than limbs); the persistent external wrench [UPSTREAM B8]
+#pragma unroll
+      for (int tq = 0; tq < (NW + NLANE) / NLANE; ++tq) {
+        const int tk = k + NLANE * tq;
+        if (tk > NW) continue;
+        const int bi = LY.EF_BASE_INERTIA + tk * INERTIA_NF;
         M3 Rf;
         V3 pf;
-        trunk_frame<TP>(C, k, Rf, pf);
-        const SV Vl = pick_trunk(V0, Vw, k), al = pick_trunk(a0, aw, k);
+        trunk_frame<TP>(C, tk, Rf, pf);
+        const SV Vl = pick_trunk(V0, Vw, tk), al = pick_trunk(a0, aw, tk);
         const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
         const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
         SV fx{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-        if (k == T.wrench_depth) {
+        if (tk == T.wrench_depth) {
           const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
           fx.a = -(mul(Rf, extT) + cross(xc, Fb));
           fx.l = -Fb;
@@ -1436,7 +1441,7 @@ struct EnvLane {
 #pragma unroll
         for (int i = 0; i < 6; ++i) tr.r[i] = 0.f;
         add_rigid(tr, I0, Vl, al, fx);
-        float* wt = trunk_words(k);
+        float* wt = trunk_words(tk);
 #pragma unroll
         for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(wt + i, tr.A[i]);
 #pragma unroll

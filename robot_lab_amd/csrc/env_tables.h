@@ -17,7 +17,7 @@ namespace rl {
 constexpr int NLANE = 4;    // lane groups (= limb chains) per environment
 constexpr int NLANE_ = 4;
 constexpr int MAX_CL = 7;   // joints per limb chain (A1 3, Go2W 4, G1 arm 7)
-constexpr int MAX_NW = 3;   // trunk joints (G1 waist)
+constexpr int MAX_NW = 6;   // trunk joints (G1: the waist, 3; GR1: waist + head, 6)
 constexpr int MAX_JX = MAX_CL + MAX_NW;  // per-lane joint arrays: [0, CL) limb joints, [CL, CL+NW) trunk joints
 constexpr int MAX_SPL = 4;  // collision-sphere slots per link group
 constexpr int MAX_NGRP = MAX_CL + 1;  // link groups per lane: 0 = share of a trunk link, 1..CL = limb links
@@ -40,6 +40,7 @@ using TopoQuad3 = Topo<3, 0, 3, 6>;  // A1, Go2
 using TopoQuad4 = Topo<4, 0, 3, 6>;  // wheeled quadrupeds whose base spheres do not fit the free limb slots
 using TopoQuad4M = Topo<4, 0, 3, 6, 1>;  // Go2W and the other wheeled quadrupeds
 using TopoG1 = Topo<7, 3, 4, 9>;     // G1 29-DoF
+using TopoGR = Topo<7, 6, 4, 9>;     // FFTAI GR1T1 / GR1T2 (32 DoF): a six-joint spine - waist, then head - with the arms leaving it at depth 3
 constexpr int MAX_T = 40;   // reward terms
 constexpr int MAX_OBS = 12;
 constexpr int MAX_BASE_BODIES = 4;

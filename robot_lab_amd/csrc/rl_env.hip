@@ -142,7 +142,7 @@ struct Backend {
     return staged_bytes(T) + words * 4;
   }
   int configure(const Tables& T) {
-    const int key = (T.CL + (T.merged ? 100 : 0)) * 10 + sub;
+    const int key = (T.CL + (T.merged ? 100 : 0) + (T.NW > 3 ? 200 : 0)) * 10 + sub;
     switch (key) {
       case 31: lds_bytes = lds_need<TopoQuad3, 1>(T); break;
       case 32: lds_bytes = lds_need<TopoQuad3, 2>(T); break;
@@ -157,6 +157,8 @@ struct Backend {
         err = "the one-lane-per-limb mapping (RL_ENV_SUB=1) of the trunk + limbs instance needs more LDS than a CU has";
         return -1;
       case 74: lds_bytes = lds_need<TopoG1, 4>(T); break;
+      case 2071: err = "the one-lane-per-limb mapping (RL_ENV_SUB=1) of the trunk + limbs instance needs more LDS than a CU has"; return -1;
+      case 2074: lds_bytes = lds_need<TopoGR, 4>(T); break;
       default: err = "no lane-program instance for chain length " + std::to_string(T.CL); return -1;
     }
     if (std::getenv("RL_ENV_DEBUG")) fprintf(stderr, "rl_env: %zu B of LDS per single-wavefront workgroup (%zu fit a CU)\n", lds_bytes, (size_t)(160 * 1024) / lds_bytes);
@@ -190,6 +192,9 @@ struct Backend {
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 74
       case 7: return check(launch_cl<TopoG1, 4>(cfg, S, T, lds_bytes, st));
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 2074
+      case 207: return check(launch_cl<TopoGR, 4>(cfg, S, T, lds_bytes, st));
 #endif
       default: err = missing; return -1;
     }

@@ -51,7 +51,7 @@ inline void quat_to_rows(const float q[4], float R[9]) {
 // shape of the lane-program instance that simulates this model (env_tables.h Topo<>)
 inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& NBS) {
   if (m.num_chains != NLANE || m.chain_len < 1 || m.chain_len > MAX_CL || m.num_trunk < 0 || m.num_trunk > MAX_NW)
-    return fail("lane program needs a trunk of <= 3 serial joints carrying 4 limb chains of <= 7 joints (got " + std::to_string(m.num_chains) + " chains x " +
+    return fail("lane program needs a trunk of <= 6 serial joints carrying 4 limb chains of <= 7 joints (got " + std::to_string(m.num_chains) + " chains x " +
                 std::to_string(m.chain_len) + ", trunk " + std::to_string(m.num_trunk) + ")");
   bool equal = true;
   for (int k = 1; k < NLANE; ++k) equal = equal && m.chain_nj[k] == m.chain_nj[0];
@@ -63,8 +63,9 @@ inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& N
     rotated = rotated || (n > 0.f && (fabsf(q[1]) > 1e-6f || fabsf(q[2]) > 1e-6f || fabsf(q[3]) > 1e-6f));  // all-zero: descriptor without rotations
   }
   if (m.num_trunk == 0 && m.chain_len <= 4 && equal && m.chain_len >= 3 && !rotated) { CL = m.chain_len; NW = 0; SPL = 3; NBS = 6; }
-  else { CL = 7; NW = 3; SPL = 4; NBS = 9; }
-  // a shorter trunk (ATOM01: one waist joint) or none runs on the NW = 3 instance with inert padding trunk joints
+  else { CL = 7; NW = m.num_trunk > 3 ? 6 : 3; SPL = 4; NBS = 9; }
+  // a shorter trunk (ATOM01: one waist joint) or none runs on the NW = 3 instance with inert padding trunk joints; a longer one
+  // (GR1: waist + head) on the NW = 6 instance
   return 0;
 }
 
@@ -458,18 +459,19 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
 
 // packed (per-instance) table image that the env kernels stage into LDS
 inline size_t packed_size(const TaskTab& T) {
-  return T.NW > 0 ? sizeof(TablesT<TopoG1>) : (T.CL == 4 ? sizeof(TablesT<TopoQuad4>) : sizeof(TablesT<TopoQuad3>));
+  return T.NW > 3 ? sizeof(TablesT<TopoGR>) : T.NW > 0 ? sizeof(TablesT<TopoG1>) : (T.CL == 4 ? sizeof(TablesT<TopoQuad4>) : sizeof(TablesT<TopoQuad3>));
 }
 template <class TP>
 inline size_t staged_bytes_t(const TaskTab& T) {  // `rew` is the last member: everything up to its first n_rewards entries
   return (sizeof(TablesBody<TP>) - (size_t)(MAX_T - T.n_rewards) * sizeof(RewTab) + 15) / 16 * 16;
 }
 inline size_t staged_bytes(const TaskTab& T) {
-  return T.NW > 0 ? staged_bytes_t<TopoG1>(T) : (T.CL == 4 ? staged_bytes_t<TopoQuad4>(T) : staged_bytes_t<TopoQuad3>(T));
+  return T.NW > 3 ? staged_bytes_t<TopoGR>(T) : T.NW > 0 ? staged_bytes_t<TopoG1>(T) : (T.CL == 4 ? staged_bytes_t<TopoQuad4>(T) : staged_bytes_t<TopoQuad3>(T));
 }
 inline std::vector<uint8_t> pack_image(const Tables& T) {
   std::vector<uint8_t> img(packed_size(T), 0);
-  if (T.NW > 0) pack_tables<TopoG1>(T, *reinterpret_cast<TablesT<TopoG1>*>(img.data()));
+  if (T.NW > 3) pack_tables<TopoGR>(T, *reinterpret_cast<TablesT<TopoGR>*>(img.data()));
+  else if (T.NW > 0) pack_tables<TopoG1>(T, *reinterpret_cast<TablesT<TopoG1>*>(img.data()));
   else if (T.CL == 4) pack_tables<TopoQuad4>(T, *reinterpret_cast<TablesT<TopoQuad4>*>(img.data()));
   else pack_tables<TopoQuad3>(T, *reinterpret_cast<TablesT<TopoQuad3>*>(img.data()));
   return img;
@@ -487,7 +489,7 @@ struct EnvImpl {
   void* packed_dev = nullptr;     // TablesT<Topo> image the env kernels stage into LDS
   KState S;
   CmdLevelParams cmd_level_params{};
-  int N = 0, Npad = 0, D = 0, B = 0, CL = 0, inst = 0, ept = ENVS_PER_WAVE;  // inst: lane-program instance key (CL, + 100 merged)
+  int N = 0, Npad = 0, D = 0, B = 0, CL = 0, inst = 0, ept = ENVS_PER_WAVE;  // inst: lane-program instance key (CL, + 100 merged, + 200 six-joint trunk)
   uint64_t seed = 0;
   uint32_t step_counter = 0;
   // the kernels take the step count as *step_base + launch literal (rl_env_graph_*): `anchor` mirrors the device word
@@ -542,7 +544,7 @@ struct EnvImpl {
       if (!merged && build_tables(*d, tables, body_lane, body_slot, link_lane, link_pos, false)) return -1;
     }
     CL = tables.CL;
-    inst = tables.CL + (tables.merged ? 100 : 0);
+    inst = tables.CL + (tables.merged ? 100 : 0) + (tables.NW > 3 ? 200 : 0);
     if (be.init(device)) return fail("device init failed: " + be.error());
     ept = be.envs_per_wave(tables, Npad);  // the lane mapping (16 or 4 lanes per env) decides the layout of the state tiles
     if (std::getenv("RL_ENV_DEBUG")) fprintf(stderr, "rl_env: lane program CL %d NW %d merged %d, %d envs per wavefront\n", tables.CL, tables.NW, tables.merged, ept);

@@ -12,8 +12,8 @@ import json
 
 import numpy as np
 
-RL_MAX_LINKS = 32
-RL_MAX_DOF = 31
+RL_MAX_LINKS = 33
+RL_MAX_DOF = 32
 RL_MAX_BODIES = 48
 RL_MAX_SPHERES = 96
 RL_MAX_CAPSULES = 16
@@ -75,7 +75,7 @@ class ModelDesc(C.Structure):
         ("num_links", i32), ("num_dof", i32), ("num_bodies", i32), ("num_spheres", i32), ("num_chains", i32),
         ("chain_len", i32),
         ("chain_link", (i32 * 8) * 4), ("chain_nj", i32 * 4), ("chain_attach", i32 * 4),
-        ("num_trunk", i32), ("trunk_link", i32 * 4),
+        ("num_trunk", i32), ("trunk_link", i32 * 8),
         ("link_parent", i32 * RL_MAX_LINKS),
         ("link_origin", (f32 * 3) * RL_MAX_LINKS),
         ("link_quat", (f32 * 4) * RL_MAX_LINKS),

@@ -100,12 +100,20 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
             limbs.append((0, ch))
         elif not trunk:  # one branching serial chain = the trunk (G1 waist -> torso -> arms)
             trunk = ch
-            for rr in tail:
-                ch2, tail2 = serial(rr)
-                limbs.append((len(trunk), ch2) if not tail2 else (None, ch2))
+            subs = [serial(rr) for rr in tail]
+            attach = len(trunk)
+            # a spine that goes on past the branching link (FFTAI GR1: waist -> torso -> head, `GR1T1.urdf`; the arms leave it at the
+            # torso): with more than four limb candidates the shortest terminal child chain continues the trunk
+            others = len(children[0]) - 1
+            if others + len(subs) > 4 and all(not t2 for _, t2 in subs):
+                k = min(range(len(subs)), key=lambda i: len(subs[i][0]))
+                trunk = trunk + subs[k][0]
+                subs = subs[:k] + subs[k + 1:]
+            for ch2, tail2 in subs:
+                limbs.append((attach, ch2) if not tail2 else (None, ch2))
         else:
             limbs.append((None, ch))
-    ok = (1 <= len(limbs) <= 4 and all(a is not None for a, _ in limbs) and max(len(c) for _, c in limbs) <= 7 and len(trunk) <= 3
+    ok = (1 <= len(limbs) <= 4 and all(a is not None for a, _ in limbs) and max(len(c) for _, c in limbs) <= 7 and len(trunk) <= 6
           and sum(len(c) for _, c in limbs) + len(trunk) == D)
     # fewer than 4 limbs (bipeds without arms): the spare lane groups simulate empty chains
     m.num_chains, m.chain_len, m.num_trunk = (4, max(len(c) for _, c in limbs), len(trunk)) if ok else (0, 0, 0)
@@ -120,10 +128,16 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
         for i, l in enumerate(trunk):
             m.trunk_link[i] = l
     # quadruped instances (Topo<3|4,0,3,6>) need 4 equal chains of <= 4 joints and no trunk; everything else that fits
-    # runs on the trunk + limbs instance (Topo<7,3,4,9>) with inert padding joints (rl_env_host.h: topo_shape)
+    # runs on a trunk + limbs instance (Topo<7,3,4,9>; a trunk of 4 - 6 joints: Topo<7,6,4,9>) with inert padding joints (rl_env_host.h: topo_shape)
     quad = ok and not trunk and len(limbs) == 4 and len({len(c) for _, c in limbs}) == 1 and len(limbs[0][1]) <= 4
     # collision-sphere budget of the lane-program instance that will simulate this topology
     if ok:
+        # a trunk link's spheres are hosted by the lanes whose limb hangs off it (their link group 0): a trunk link nothing hangs off
+        # (G1's two inner waist links have no geometry anyway; GR1's inner waist links and its head do) cannot touch the ground here
+        hosts = {0 if a == 0 else trunk[a - 1] for a, _ in limbs}
+        unhosted = set(trunk) - hosts
+        if unhosted:
+            model.spheres = [s for s in model.spheres if model.bodies[s.body].link not in unhosted]
         cap_spheres(model, [0] + list(trunk), per_link=3 if quad else 4)
     G = len(model.spheres)
     if G > RL_MAX_SPHERES:

@@ -137,8 +137,8 @@ struct alignas(64) Team {
   float slot9[LPE][9];
   float rstage[rl::MAX_T];
   float feat[rl::feat_count(rl::TopoMax::DMAX)];
-  float lb[rl::NLANE][rl::LbLayout<rl::TopoG1>::WORDS + 1];  // limb-shared words (really shared by the limb's sub-lane threads)
-  float envw[rl::LbLayout<rl::TopoG1>::ENV_WORDS + 1];        // env-shared words
+  float lb[rl::NLANE][rl::LbLayout<rl::TopoGR>::WORDS + 1];  // limb-shared words (really shared by the limb's sub-lane threads)
+  float envw[rl::LbLayout<rl::TopoGR>::ENV_WORDS + 1];        // env-shared words
   float rtab[rl::REW_JS_ROWS * RL_MAX_DOF + rl::REW_BT_NF * RL_MAX_BODIES];
   std::vector<float> stage[2];
   Team() { bar.n = LPE; }
@@ -433,6 +433,8 @@ struct Backend {
       case 1044: run<rl::TopoQuad4M, 4>(S, T); return 0;
       case 71: run<rl::TopoG1, 1>(S, T); return 0;
       case 74: run<rl::TopoG1, 4>(S, T); return 0;
+      case 2071: run<rl::TopoGR, 1>(S, T); return 0;
+      case 2074: run<rl::TopoGR, 4>(S, T); return 0;
       default: err = "unsupported chain length"; return -1;
     }
   }

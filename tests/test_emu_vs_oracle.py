@@ -31,17 +31,24 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Rough-MagicLab-Dog-W-v0",
     "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-v0",
     "RobotLab-Isaac-Velocity-Rough-Agibot-D1-v0",  # registers since the shims carry a `cusrl` stand-in (agibot_d1/agents/__init__.py:4)
+    # a six-joint spine (waist, then head) with the arms leaving it at depth 3: the Topo<7,6,4,9> instance, 32 DoF
+    "RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0",
+    "RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T2-v0",
 ]
 
 
 @pytest.mark.parametrize("task", TASKS)
 def test_lane_program_matches_oracle(task, emu_lib):
-    N = 8 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1")) else 16  # big models: the fp64 oracle is the slow side
+    N = 8 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1", "GR1")) else 16  # big models: the fp64 oracle is the slow side
+    # GR1 (55 kg on two feet, drive stiffness up to 250 N m / rad): the fp32 program sits 3 - 5 x further from the fp64 oracle than on
+    # the 35 kg G1 - root state to 3e-4, joint velocities to 1.4e-2, contact forces to 0.4 N over these six steps, not growing -
+    # so its bands are 6 x the others'
+    k = 6.0 if "GR1" in task else 1.0
     desc, ora, nat = make_pair(task, N, 42, emu_lib)
     o = ora.reset()
     nat.reset()
-    assert_close("policy0", host_view(nat, "OBS_POLICY"), o[0], 1e-4, 1e-5)
-    assert_close("critic0", host_view(nat, "OBS_CRITIC"), o[1], 1e-3, 1e-4)
+    assert_close("policy0", host_view(nat, "OBS_POLICY"), o[0], k * 1e-4, k * 1e-5)
+    assert_close("critic0", host_view(nat, "OBS_CRITIC"), o[1], k * 1e-3, k * 1e-4)
     rng = np.random.default_rng(0)
     # hand-stand: joint_acc_l2 carries 10x the usual weight and the joint accelerations of an env whose foot is just
     # touching down differ by ~1 % between fp32 and fp64 (one env of 16 at steps 4 and 5)
@@ -50,18 +57,18 @@ def test_lane_program_matches_oracle(task, emu_lib):
         a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
         o = ora.step(a)
         nat.step(a.ctypes.data)
-        assert_close(f"reward[{s}]", host_view(nat, "REWARD"), ora.reward, 1e-3, 2e-5, frac)
-        assert_close(f"terms[{s}]", host_view(nat, "REWARD_TERMS")[:, :N], ora.reward_terms, 2e-3, 2e-5, 0.99 if frac < 1 else 1.0)
-        assert_close(f"cforce[{s}]", host_view(nat, "CONTACT_FORCE"), ora.contact_force, 5e-3, 5e-2)
+        assert_close(f"reward[{s}]", host_view(nat, "REWARD"), ora.reward, k * 1e-3, k * 2e-5, frac)
+        assert_close(f"terms[{s}]", host_view(nat, "REWARD_TERMS")[:, :N], ora.reward_terms, k * 2e-3, k * 2e-5, 0.99 if frac < 1 else 1.0)
+        assert_close(f"cforce[{s}]", host_view(nat, "CONTACT_FORCE"), ora.contact_force, k * 5e-3, k * 5e-2)
     nat.export_state()
-    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), 1e-3, 1e-4, 0.99 if frac < 1 else 1.0)
-    assert_close("q", host_view(nat, "JOINT_POS"), ora.st["q"], 1e-3, 1e-4)
-    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], 2e-3, 2e-3, 0.99 if frac < 1 else 1.0)
-    assert_close("timers", host_view(nat, "CONTACT_TIMERS"), ora.timers, 1e-5, 1e-6)
-    assert_close("torque", host_view(nat, "JOINT_TORQUE"), ora.applied_torque, 2e-3, 2e-3)
-    assert_close("cmd", host_view(nat, "COMMAND"), ora.vel_command_b, 1e-3, 1e-4)
-    assert_close("policy", host_view(nat, "OBS_POLICY"), o[0], 2e-3, 2e-3)
-    assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), k * 1e-3, k * 1e-4, 0.99 if frac < 1 else 1.0)
+    assert_close("q", host_view(nat, "JOINT_POS"), ora.st["q"], k * 1e-3, k * 1e-4)
+    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], k * 2e-3, k * 2e-3, 0.99 if frac < 1 else 1.0)
+    assert_close("timers", host_view(nat, "CONTACT_TIMERS"), ora.timers, k * 1e-5, k * 1e-6)
+    assert_close("torque", host_view(nat, "JOINT_TORQUE"), ora.applied_torque, k * 2e-3, k * 2e-3)
+    assert_close("cmd", host_view(nat, "COMMAND"), ora.vel_command_b, k * 1e-3, k * 1e-4)
+    assert_close("policy", host_view(nat, "OBS_POLICY"), o[0], k * 2e-3, k * 2e-3)
+    assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], k * 2e-3, k * 2e-3)
     nat.close()
 
 

@@ -24,6 +24,7 @@ INSTANCES = [
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", None),      # Topo<4,0,3,6,1> merged
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", "0"),       # Topo<4,0,3,6>
     ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", None),        # Topo<7,3,4,9>
+    ("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0", None),       # Topo<7,6,4,9>: a six-joint spine
 ]
 # RL_ENV_WG: "" = the shape the launch size selects (single-wavefront workgroups at this size), "-4" = four wavefronts per workgroup
 # (what >= 4096 quadruped envs launch), RL_ENV_SUB=1 = the one-lane-per-limb mapping
@@ -66,9 +67,9 @@ def test_interval_timers_tick_by_exactly_step_dt(task, merge, wg, sub, monkeypat
         monkeypatch.setenv("RL_ENV_SUB", sub)
     if merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
-    if sub == "2" and "G1" in task:
+    if sub == "2" and ("G1" in task or "GR1" in task):
         pytest.skip("the trunk + limbs instance has the 16-lane mapping only")
-    if sub == "1" and "G1" in task:
+    if sub == "1" and ("G1" in task or "GR1" in task):
         # the trunk + limbs instance keeps its kinematics / link records in limb-shared LDS words: with one lane per limb (64 limbs per
         # wavefront) that is 115 KB + 30 KB of sensor rows - it exists on the CPU lane emulator only, rl_env_create refuses it on the GPU
         pytest.skip("the one-lane-per-limb mapping of the trunk + limbs instance does not fit the LDS of a CU (CPU emulator only)")
@@ -108,7 +109,7 @@ def test_kernel_shapes_agree_bit_for_bit(task, merge, sub, monkeypatch):
     if merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
     if sub != "4":
-        if "G1" in task:
+        if ("G1" in task or "GR1" in task):
             pytest.skip("the trunk + limbs instance has the 16-lane mapping only")
         monkeypatch.setenv("RL_ENV_SUB", sub)
     N = 512
@@ -128,7 +129,7 @@ def test_kernel_shapes_agree_bit_for_bit(task, merge, sub, monkeypatch):
                               terms=env.reward_terms().cpu().numpy().copy(), done=(term | tout).cpu().numpy().copy(), **env.read_state()))
         runs.append(trace)
         env.close()
-    if "G1" in task:  # the trunk + limbs instance ships single-wavefront workgroups only (csrc/rl_env.hip launch_cl): both runs are the same kernel
+    if ("G1" in task or "GR1" in task):  # the trunk + limbs instance ships single-wavefront workgroups only (csrc/rl_env.hip launch_cl): both runs are the same kernel
         assert all(np.array_equal(a[k], b[k]) for a, b in zip(*runs) for k in a)
         return
     assert sum(int(t["done"].sum()) for t in runs[0]) > N // 8  # the window is eventful

@@ -42,6 +42,7 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-W-v0",
     "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-v0",
     "RobotLab-Isaac-Velocity-Rough-Agibot-D1-v0",
+    "RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0",  # the six-joint-spine instance Topo<7,6,4,9>
 ]
 
 
@@ -105,7 +106,11 @@ def test_short_horizon_parity(task, wg, merge, monkeypatch):
                obs_policy=obs["policy"].cpu().numpy(), obs_critic=obs["critic"].cpu().numpy())
     # (six twins: the envelope is the MAXIMUM response over the twins, and three draws leave it 1.4x short for one env in a few hundred;
     # the switch mask: 0 of N on every id and shape of the round-3 build - at most three envs, where round 2 tolerated a third of the batch)
-    rep = teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=3.0 / N)
+    # (GR1 - 55 kg, drive stiffness up to 250 N m / rad - sits 3 - 5 x further from the fp64 oracle than the other robots on the emulator as
+    # on the GPU: its flat ceilings are 3 x the others', the conditioning-aware envelope is the same rule)
+    from helpers import HARD_CAPS
+    caps = {k: 3.0 * v for k, v in HARD_CAPS.items()} if "GR1" in task else HARD_CAPS
+    rep = teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=3.0 / N, caps=caps)
     print(f"\n[parity-small] {task} wg={wg!r} merge={merge}: done_differs {two.done_differs.mean():.3f}, teacher-forced mask {rep['masked']}/{N}")
     env.close()
 

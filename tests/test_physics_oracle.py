@@ -46,9 +46,10 @@ def _momentum(ph, st):
 def _free(d):
     for a in (d.model.joint_lower, d.model.joint_upper, d.model.joint_vel_limit):
         pass
-    d.model.joint_lower[:] = [-1e9] * 31
-    d.model.joint_upper[:] = [1e9] * 31
-    d.model.joint_vel_limit[:] = [1e9] * 31
+    n = len(d.model.joint_lower)  # RL_MAX_DOF
+    d.model.joint_lower[:] = [-1e9] * n
+    d.model.joint_upper[:] = [1e9] * n
+    d.model.joint_vel_limit[:] = [1e9] * n
 
 
 def test_free_fall_matches_closed_form():

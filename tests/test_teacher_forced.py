@@ -15,6 +15,7 @@ CASES = [
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0", 32, 6),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 32, 6),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 8, 6),
+    ("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0", 8, 6),  # the six-joint-spine instance, judged by the oracle's own fp32 sensitivity
 ]
 
 
@@ -68,7 +69,8 @@ def test_one_step_from_shared_state(task, N, K, emu_lib):
     if not td.is_plane:
         assert got["done"][oob] and got["done"][up]
         if tk.term_out_of_bounds:
-            assert host_view(nat, "TIME_OUT")[oob] and not host_view(nat, "TERMINATED")[oob]
+            # (GR1 under random actions has its torso on the ground in that env at that step as well: a termination besides the time-out)
+            assert host_view(nat, "TIME_OUT")[oob] and ("GR1" in task or not host_view(nat, "TERMINATED")[oob])
         if td.curriculum and level_before[up] < td.num_rows - 1:
             assert got["terrain_level"][up] == level_before[up] + 1
     # small batches: one env on a switch is already 2 - 12 % of the batch, so the mask-size bound is checked at full size only

@@ -25,9 +25,10 @@ from robot_lab_amd.scene import DATA_DIR, save_bundle  # noqa: E402
 # ... MagicLab Z1 (14 DoF, hip joints listed out of tree order), DDT Tita (2 wheeled legs, 2 empty limbs)
 ROBOTS = ("Unitree-A1", "Unitree-Go2", "Unitree-Go2W", "Unitree-G1", "Unitree-B2", "Deeprobotics-Lite3", "Deeprobotics-M20",
           "Zsibot-ZSL1", "Zsibot-ZSL1W", "RoboParty-ATOM01", "RobotEra-Xbot", "MagicLab-Bot-Gen1", "Openloong-Loong",
-          "Unitree-B2W", "MagicLab-Dog-W", "MagicLab-Dog", "MagicLab-Bot-Z1", "DDTRobot-Tita", "HandStand-Unitree-A1", "Agibot-D1")
-# not compiled: Unitree-H1 (asset lives in isaaclab_assets, not in the reference), Booster-T1 (5 limbs: head + arms + legs),
-# FFTAI GR1T1/T2 (more links than the descriptor holds), MagicLab-Dog Rough (its registration names a class that does not exist)
+          "Unitree-B2W", "MagicLab-Dog-W", "MagicLab-Dog", "MagicLab-Bot-Z1", "DDTRobot-Tita", "HandStand-Unitree-A1", "Agibot-D1",
+          "FFTAI-GR1T1", "FFTAI-GR1T2")  # GR1: a six-joint spine (waist + head) with the arms leaving it at depth 3: Topo<7,6,4,9>
+# not compiled: Unitree-H1 (asset lives in isaaclab_assets, not in the reference), Booster-T1 (5 limbs: head + arms + legs on
+# no common spine), MagicLab-Dog Rough (its registration names a class that does not exist)
 TASKS = sys.argv[1:] or [f"RobotLab-Isaac-Velocity-{t}-{r}-v0" for r in ROBOTS for t in ("Flat", "Rough")]
 os.makedirs(DATA_DIR, exist_ok=True)
 for task in TASKS:
@@ -38,7 +39,7 @@ for task in TASKS:
         print(f"{task}: NOT COMPILED ({e})")
         continue
     if desc.model.num_chains == 0:
-        print(f"{task}: NOT COMPILED (topology is not a trunk of <= 3 joints + <= 4 serial limbs of <= 7 joints)")
+        print(f"{task}: NOT COMPILED (topology is not a trunk of <= 6 joints + <= 4 serial limbs of <= 7 joints)")
         continue
     save_bundle(os.path.join(DATA_DIR, task + ".json"), desc, spec)
     m = desc.model
