@@ -64,6 +64,28 @@ def test_other_bundles(task, dims, bodies, mass):
     assert d.model.num_chains == 4 and 3 <= d.model.chain_len <= 7
 
 
+def test_gr1_is_a_six_joint_spine_with_the_arms_leaving_it_at_the_torso():
+    """FFTAI GR1T1 (`GR1T1.urdf`): legs on the base; waist yaw / pitch / roll; on the waist's last link the head's three joints AND the
+    two 7-joint arms - five candidate limbs.  The builder lets the trunk continue into the shortest terminal child chain (the head):
+    trunk = waist + head, the arms attach at depth 3 (model/build.py), which the trunk + limbs program already supports."""
+    d, _ = load_bundle("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0")
+    m = d.model
+    assert (m.num_dof, m.num_links, m.num_chains, m.chain_len, m.num_trunk) == (32, 33, 4, 7, 6)
+    assert [d.joint_names[m.trunk_link[i] - 1] for i in range(6)] == ["waist_yaw", "waist_pitch", "waist_roll", "head_yaw", "head_roll", "head_pitch"]
+    assert sorted(m.chain_nj) == [6, 6, 7, 7]
+    arms = [k for k in range(4) if m.chain_nj[k] == 7]
+    legs = [k for k in range(4) if m.chain_nj[k] == 6]
+    assert all(m.chain_attach[k] == 3 for k in arms) and all(m.chain_attach[k] == 0 for k in legs)
+    assert all("shoulder_pitch" in d.joint_names[m.chain_link[k][0] - 1] for k in arms)
+    # the spine links nothing hangs off (inner waist links, head) carry no collision spheres: no lane could host them
+    hosted = {0, m.trunk_link[2]}
+    spine = {m.trunk_link[i] for i in range(6)}
+    for g in range(m.num_spheres):
+        link = m.body_link[m.sphere_body[g]]
+        assert link not in spine or link in hosted
+    assert m.self_collision == 0 and m.num_self_pairs == 0  # assets/fftai.py:41: enabled_self_collisions=False
+
+
 def test_g1_census():
     """Known-answer facts of SURVEY.md 8(c): 29 joints, trunk = 3 waist joints carrying the arms, per-joint
     action scale 0.25 * effort / stiffness (unitree.py:625-636), torso-mounted events and scanner."""

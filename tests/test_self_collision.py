@@ -68,6 +68,32 @@ def test_capsules_and_pairs_of_g1():
     assert min(g for g, _, _ in capsule_gaps(ora, q0)) >= 0.01 - 1e-6
 
 
+def test_atom01_pairs_start_apart_and_its_lane_program_matches_the_oracle(emu_lib):
+    """The other cfg with self-collisions on (assets/roboparty.py:33): its pair list obeys the same rules, and with the left arm rolled
+    1.2 rad inwards - the arm pressed against the base capsule - the lane program and the oracle agree with the pass running."""
+    task = "RobotLab-Isaac-Velocity-Flat-RoboParty-ATOM01-v0"
+    desc, ora, nat = make_pair(task, 4, 3, emu_lib)
+    m = desc.model
+    assert m.self_collision == 1 and 10 <= m.num_capsules <= 16 and 20 <= m.num_self_pairs <= 80
+    ora.reset()
+    nat.reset()
+    q0 = np.array(m.default_joint_pos[: m.num_dof], dtype=np.float64)[None].repeat(4, 0)
+    assert min(g for g, _, _ in capsule_gaps(ora, q0)) >= 0.01 - 1e-6
+    j = list(desc.joint_names).index("left_arm_roll_joint")
+    a = np.zeros((4, m.num_dof), dtype=np.float32)
+    a[:, j] = -1.2 / m.action_scale[j]
+    closest = np.inf
+    for _ in range(12):
+        ora.step(a)
+        nat.step(a.ctypes.data)
+        closest = min(closest, min(g for g, _, _ in capsule_gaps(ora)))
+    nat.export_state()
+    assert -0.04 < closest < -0.002, closest  # touched, and stopped
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), 2e-3, 2e-4)
+    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], 5e-3, 5e-3)
+    nat.close()
+
+
 def test_segment_closest_points():
     rng = np.random.default_rng(0)
     for i in range(400):
