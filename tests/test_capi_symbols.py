@@ -82,3 +82,39 @@ def test_descriptor_errors_are_reported(emu_lib):
     desc.model.num_chains = 3  # not the star topology the lane program is written for
     with pytest.raises(capi.RlEnvError, match="limb chains"):
         capi.NativeEnv(desc, h, to, eo, 16, 1, 0, emu_lib)
+
+
+def test_self_collision_descriptor_errors_are_reported(emu_lib):
+    """Malformed self-collision data (include/rl_env.h rl_model_desc.self_pair) is refused by rl_env_create with a reason, not simulated."""
+    from robot_lab_amd.scene import build_world, load_bundle
+
+    def create(task, mutate):
+        desc, extra = load_bundle(task)
+        h, to, eo = build_world(desc, extra, 4, 0)
+        mutate(desc.model)
+        return capi.NativeEnv(desc, h, to, eo, 4, 1, 0, emu_lib)
+
+    g1 = "RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0"
+    create(g1, lambda m: None).close()  # as shipped: fine
+
+    def pair_out_of_range(m):
+        m.self_pair[0][1] = m.num_capsules
+
+    def link_out_of_range(m):
+        m.capsule_link[1] = m.num_links + 3
+
+    def too_many_on_a_limb(m):  # five capsules on the links of one limb: a limb has four virtual lanes
+        for i, c in enumerate(range(1, 6)):
+            m.capsule_link[c] = m.chain_link[0][i]
+
+    for mutate, what in ((pair_out_of_range, "pair index"), (link_out_of_range, "capsule link"), (too_many_on_a_limb, "four capsules")):
+        with pytest.raises(capi.RlEnvError, match=what):
+            create(g1, mutate)
+
+    def pairs_on_a_quadruped(m):
+        m.num_capsules, m.num_self_pairs = 2, 1
+        m.capsule_link[0], m.capsule_link[1] = 0, 1
+        m.self_pair[0][0], m.self_pair[0][1] = 0, 1
+
+    with pytest.raises(capi.RlEnvError, match="trunk \\+ limbs instance"):
+        create("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", pairs_on_a_quadruped)
