@@ -13,7 +13,8 @@ from robot_lab_amd.scene import build_world, load_bundle
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("task,N,steps", [("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 48, 100), ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 16, 60)])
+@pytest.mark.parametrize("task,N,steps", [("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 48, 100), ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 16, 60),
+                                          ("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0", 16, 60)])  # (GR1: the six-joint-spine instance)
 def test_lane_program_episode_statistics(task, N, steps, emu_lib):
     from robot_lab_amd.capi import NativeEnv
 
