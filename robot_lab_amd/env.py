@@ -251,11 +251,16 @@ class ManagerBasedRLEnv(_EnvBase):
         self.render_mode = render_mode
         self.num_envs = int(num_envs or 4096)
         self._seed = 42 if seed is None else int(seed)
-        dev = torch.device(device or "cuda:0")
+        from .dist import physical_device
+
+        dev = physical_device(device or "cuda:0")  # identity, except under the RL_SHARE_GPU=1 self-test aid (robot_lab_amd/dist.py)
         if dev.type != "cuda":
             raise RlEnvError(f"robot_lab_amd runs on MI355X only (device={dev}); there is no CPU path")
         if not torch.cuda.is_available():
             raise RlEnvError("no HIP device visible: robot_lab_amd has no CPU path")
+        if dev.index is not None and dev.index >= torch.cuda.device_count():
+            raise RlEnvError(f"device {dev} requested but {torch.cuda.device_count()} HIP device(s) are visible (one process per GPU: "
+                             f"launch as many ranks as there are devices)")
         self.device = str(dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device()))
         self._dev_index = torch.device(self.device).index
         heights, terrain_origins, env_origins = build_world(desc, extra or {}, self.num_envs, terrain_seed)

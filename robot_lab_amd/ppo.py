@@ -63,8 +63,10 @@ class PPO:
     the HIP storage; advantages already normalised over the batch by `rl_rollout_compute_returns`)."""
 
     def __init__(self, policy: ActorCritic, value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01,
-                 num_learning_epochs=5, num_mini_batches=4, learning_rate=1.0e-3, schedule="adaptive", desired_kl=0.01, max_grad_norm=1.0):
+                 num_learning_epochs=5, num_mini_batches=4, learning_rate=1.0e-3, schedule="adaptive", desired_kl=0.01, max_grad_norm=1.0,
+                 group=None):
         self.policy = policy
+        self.group = group  # robot_lab_amd.dist.LearnerGroup of a multi-GPU run (rsl_rl's gradient all-reduce); None = single learner
         self.value_loss_coef, self.use_clipped_value_loss, self.clip_param, self.entropy_coef = value_loss_coef, use_clipped_value_loss, clip_param, entropy_coef
         self.num_learning_epochs, self.num_mini_batches = num_learning_epochs, num_mini_batches
         self.learning_rate, self.schedule, self.desired_kl, self.max_grad_norm = learning_rate, schedule, desired_kl, max_grad_norm
@@ -80,17 +82,21 @@ class PPO:
         mb = B // self.num_mini_batches
         stats = dict(value_loss=0.0, surrogate_loss=0.0, entropy=0.0, kl=0.0)
         n_updates = 0
+        # rsl_rl's `mini_batch_generator` draws ONE permutation per update and walks it once per epoch
+        perm = torch.randperm(B, device=obs.device, generator=generator)
         for _ in range(self.num_learning_epochs):
-            perm = torch.randperm(B, device=obs.device, generator=generator)
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
                 mean, std = self.policy.distribution(obs[idx])
+                std = std.clamp_min(1e-6)  # a standard deviation pushed to (or through) zero would put NaN into the log below
                 logp = gaussian_log_prob(actions[idx], mean, std)
                 value = self.policy.critic(cobs[idx]).view(-1)
                 entropy = gaussian_entropy(std)
                 if self.schedule == "adaptive" and self.desired_kl is not None:
                     with torch.inference_mode():
                         kl = gaussian_kl(mu_old[idx], sigma_old[idx], mean, std).mean()
+                        if self.group is not None:
+                            kl = self.group.mean(kl)  # the same statistic on every rank -> the same learning rate on every rank
                         if kl > 2.0 * self.desired_kl:
                             self.learning_rate = max(1e-5, self.learning_rate / 1.5)
                         elif 0.0 < kl < self.desired_kl / 2.0:
@@ -109,6 +115,8 @@ class PPO:
                 loss = surrogate + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
                 self.optimizer.zero_grad(set_to_none=True)
                 loss.backward()
+                if self.group is not None:
+                    self.group.reduce_gradients(self.policy)  # SUM / world, one flat all-reduce (rsl_rl `reduce_parameters`)
                 nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
                 self.optimizer.step()
                 stats["value_loss"] += float(value_loss.detach())
@@ -124,7 +132,7 @@ class Trainer:
     """collect (HIP, one graph launch) -> update (torch) -> push parameters, repeated: `OnPolicyRunner.learn` in miniature."""
 
     def __init__(self, env, num_steps_per_env=24, gamma=0.99, lam=0.95, seed=1, use_graph=True, actor_hidden=(512, 256, 128),
-                 critic_hidden=(512, 256, 128), init_noise_std=1.0, clip_actions=None, **ppo_kw):
+                 critic_hidden=(512, 256, 128), init_noise_std=1.0, clip_actions=None, group=None, **ppo_kw):
         from .collect import Collector
         from .policy import MlpPolicy
         from .rollout import RolloutStorage
@@ -134,7 +142,9 @@ class Trainer:
         torch.manual_seed(seed)
         self.env, self.device = env, obs["policy"].device
         self.policy = ActorCritic(od, cd, A, tuple(actor_hidden), tuple(critic_hidden), init_noise_std).to(self.device)
-        self.alg = PPO(self.policy, **ppo_kw)
+        self.alg = PPO(self.policy, group=group, **ppo_kw)
+        if group is not None:
+            group.broadcast_parameters(self.policy)  # before the inference images are built from them
         lin = lambda m: [x for x in m if isinstance(x, nn.Linear)]  # noqa: E731
         host = lambda t: t.detach().cpu().numpy()  # noqa: E731
         self.actor = MlpPolicy([host(x.weight) for x in lin(self.policy.actor)], [host(x.bias) for x in lin(self.policy.actor)], "elu", device=str(self.device))

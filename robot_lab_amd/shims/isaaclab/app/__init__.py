@@ -1,8 +1,8 @@
 """[UPSTREAM isaaclab.app] `AppLauncher` boots Omniverse Kit upstream
-(`scripts/reinforcement_learning/rsl_rl/train.py:54`); on MI355X there is nothing to boot."""
+(`scripts/reinforcement_learning/rsl_rl/train.py:54`); on MI355X there is nothing to boot.  What it still owns is the rank of the
+process: `train.py:143-150` reads `app_launcher.local_rank` for the device (`cuda:{local_rank}`) and the seed offset of a
+`--distributed` run (`README.md:323-337`: `python -m torch.distributed.run --nproc_per_node=N ... train.py --distributed`)."""
 import argparse
-
-
 import os
 
 
@@ -25,10 +25,25 @@ class _App:
 
 
 class AppLauncher:
+    """[UPSTREAM] `launcher_args` is the script's parsed `argparse.Namespace` (or a dict), `kwargs` override it.  With `distributed`
+    set - the flag the reference's train.py defines itself (train.py:33-35) and hands over inside the namespace - the ranks come from
+    the environment `torch.distributed.run` exports (`LOCAL_RANK`, `RANK`; upstream also adds the JAX twins), otherwise the process
+    is rank 0 of a world of one whatever the environment says, as upstream."""
+
     def __init__(self, launcher_args=None, **kwargs):
+        args = dict(vars(launcher_args)) if isinstance(launcher_args, argparse.Namespace) else dict(launcher_args or {})
+        args.update(kwargs)
         self.app = _App()
         self.local_rank = 0
         self.global_rank = 0
+        self.device_id = 0
+        if args.get("distributed"):
+            self.local_rank = int(os.getenv("LOCAL_RANK", "0")) + int(os.getenv("JAX_LOCAL_RANK", "0"))
+            self.global_rank = int(os.getenv("RANK", "0")) + int(os.getenv("JAX_RANK", "0"))
+            self.device_id = self.local_rank
+        else:
+            dev = str(args.get("device") or "cuda:0")
+            self.device_id = int(dev.split(":")[1]) if ":" in dev and dev.split(":")[1].isdigit() else 0
 
     @staticmethod
     def add_app_launcher_args(parser: argparse.ArgumentParser):

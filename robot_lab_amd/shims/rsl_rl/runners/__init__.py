@@ -27,12 +27,28 @@ class OnPolicyRunner:
             raise NotImplementedError("stand-in runner: ELU networks without observation normalisation (what every robot_lab agent cfg uses)")
         if alg.get("symmetry_cfg") or alg.get("rnd_cfg"):
             raise NotImplementedError("stand-in runner: symmetry augmentation / RND are not wired into the update")
+        # options this stand-in does not implement are refused, never ignored (a silently different learner is worse than none)
+        groups = dict(train_cfg.get("obs_groups") or {})
+        actor_set = groups.get("policy", groups.get("actor", ["policy"]))
+        if list(actor_set) != ["policy"] or list(groups.get("critic", ["critic"])) != ["critic"]:
+            raise NotImplementedError(f"stand-in runner: obs_groups {groups} - only policy <- ['policy'], critic <- ['critic'] (what every "
+                                      f"robot_lab velocity cfg but ANYmal-D's uses) is wired to the fused inference kernels")
+        if pol.get("noise_std_type", "scalar") != "scalar":
+            raise NotImplementedError(f"stand-in runner: noise_std_type={pol.get('noise_std_type')!r}; the sampling kernel reads a scalar-type std vector")
+        if train_cfg.get("empirical_normalization") or alg.get("normalize_advantage_per_mini_batch"):
+            raise NotImplementedError("stand-in runner: empirical_normalization / normalize_advantage_per_mini_batch are not implemented")
+        # one process per GPU (README.md:323-337, train.py:143-150): rsl_rl's multi-GPU contract lives in robot_lab_amd/dist.py.  A world of
+        # N ranks whose learners were not tied together would be N unrelated trainings writing over each other's logs - never run that.
+        from robot_lab_amd.dist import LearnerGroup
+
+        self.group = LearnerGroup(device)
         keys = ("value_loss_coef", "use_clipped_value_loss", "clip_param", "entropy_coef", "num_learning_epochs", "num_mini_batches",
                 "learning_rate", "schedule", "desired_kl", "max_grad_norm")
         self.trainer = Trainer(env.unwrapped, num_steps_per_env=int(train_cfg.get("num_steps_per_env", 24)), gamma=float(alg.get("gamma", 0.99)),
                                lam=float(alg.get("lam", 0.95)), seed=int(train_cfg.get("seed", 42)), actor_hidden=pol.get("actor_hidden_dims", (512, 256, 128)),
                                critic_hidden=pol.get("critic_hidden_dims", (512, 256, 128)), init_noise_std=float(pol.get("init_noise_std", 1.0)),
-                               clip_actions=getattr(env, "clip_actions", None), **{k: alg[k] for k in keys if k in alg})
+                               clip_actions=getattr(env, "clip_actions", None), group=self.group if self.group.enabled else None,
+                               **{k: alg[k] for k in keys if k in alg})
         self.alg = self.trainer.alg
         self.alg.policy.reset = lambda dones=None: None  # feed-forward policy: nothing to reset (play.py:246)
         self.save_interval = int(train_cfg.get("save_interval", 50))
@@ -46,20 +62,23 @@ class OnPolicyRunner:
         env = self.env.unwrapped
         if init_at_random_ep_len:
             env.episode_length_buf = torch.randint(0, int(env.max_episode_length), (env.num_envs,))
-        if self.log_dir:
+        main = self.group.is_main  # rank 0 logs and writes checkpoints, the other ranks train silently (rsl_rl `disable_logs`)
+        if self.log_dir and main:
             os.makedirs(self.log_dir, exist_ok=True)
         start = self.current_learning_iteration
         t0 = time.time()
         for it in range(start, start + num_learning_iterations):
             out = self.trainer.iterate()
             self.current_learning_iteration = it + 1
-            steps = self.trainer.storage.num_transitions_per_env * env.num_envs
+            steps = self.trainer.storage.num_transitions_per_env * env.num_envs * self.group.world_size
+            if not main:
+                continue
             print(f"[rsl_rl stand-in] iteration {it + 1}/{start + num_learning_iterations}  mean reward/step {out['mean_reward']:+.4f}  value loss {out['value_loss']:.4f}  "
                   f"surrogate {out['surrogate_loss']:+.4f}  std {out['action_std']:.3f}  lr {out['learning_rate']:.1e}  "
                   f"{steps * (it + 1 - start) / max(time.time() - t0, 1e-9):.0f} steps/s", flush=True)
             if self.log_dir and (it + 1) % self.save_interval == 0:
                 self.save(os.path.join(self.log_dir, f"model_{it + 1}.pt"))
-        if self.log_dir:
+        if self.log_dir and main:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
 
     def save(self, path: str, infos=None):
