@@ -18,10 +18,9 @@ re-executes itself under `torch.distributed.run` with N ranks; with it, a mismat
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch
 (3.4 KB per env-step x 4096 envs) / mean kernel duration measured with HIP events
-on the launch stream; `cpu_baseline` = the same lane program compiled for the host (tests/emu: the source
-hipcc compiles, g++ -O3 -march=native) as a CPU program - one environment per core, its four lanes as fibers of one
-thread - over all host cores on a bounded sample (rank 0, N=1 only), with the round-2 lane-emulator figure and the fp64
-numpy oracle's next to it.
+on the launch stream; `cpu_baseline` = the same env-step program compiled for the host (tests/emu: the source
+hipcc compiles, g++ -O3 -march=native) as a CPU program - one environment per thread, one pinned thread per physical
+core - on a bounded sample timed twice (rank 0, N=1 only), with the fp64 numpy oracle's figure next to it.
 """
 from __future__ import annotations
 
@@ -47,6 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--num-envs", type=int, default=4096)
     ap.add_argument("--task", type=str, default="RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0")
+    ap.add_argument("--preroll", type=int, default=300, help="untimed steps before the warm-up, after the episode clocks were randomised")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--large-batch-envs", type=int, default=65536, help="0: skip the large-batch legs (rank 0 of a 1-GPU run, after the timed region)")
     ap.add_argument("--mid-batch-envs", type=int, default=8192, help="second such leg (two sub-lanes per limb at this size); skipped with --large-batch-envs 0")
@@ -131,6 +131,12 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     ring = [torch.rand(N, A, device=dev, generator=gen) * 2 - 1 for _ in range(32)]  # synthetic actions, resident in HBM
     env.reset()
+    # Steady state before the driver's warm-up: a window right after reset() is a cold one (robots still falling, no resets for 1000
+    # steps).  As rsl_rl's `init_at_random_ep_len` (train.py:224) the episode clocks are spread over [0, max), then `--preroll` untimed
+    # steps bring contacts, commands and curricula to where a training run keeps them; every later window sees ~N/1000 time-outs per step.
+    env.episode_length_buf = torch.randint(0, int(env.max_episode_length), (N,), device=dev, generator=gen)
+    for i in range(args.preroll):
+        env.step(ring[i % 32])
 
     def barrier():
         if use_dist:
@@ -212,7 +218,8 @@ def main():
         "rccl_ranks": dist.get_world_size() if use_dist else 1, "collective_backend": ("gloo (RL_BENCH_SHARE_GPU self-test)" if share else "nccl (RCCL)") if use_dist else None,
         "per_rank_env_steps_per_s": per_rank, "envs_behind_reduced_log": float(log_vec[7]),
         "window": {"envs_reset_in_window": envs_reset, "mean_bodies_in_contact_at_end": bodies_in_contact,
-                   "note": "rank 0; episodes last 1000 steps, so a short window right after reset() is a cold one"},
+                   "preroll_steps": args.preroll,
+                   "note": "rank 0; episode clocks randomised over [0, 1000) and `preroll_steps` untimed steps before the warm-up: steady state"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
                      "kernel_only_env_steps_per_s": N / (kernel_ms * 1e-3), "wavefront_cycle_breakdown": sq,
@@ -287,57 +294,70 @@ def build_host_port() -> str:
     return cache
 
 
+def physical_cores() -> list[int]:
+    """One logical CPU per PHYSICAL core this process may run on (the first hardware thread of every sibling set): two hardware
+    threads of a core share its FP units, so a second thread per core adds little for this fp32 chain - and choosing the count by a
+    probe made the round-3 figure swing 1.75x between boxes."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = list(range(os.cpu_count() or 1))
+    firsts, seen = [], set()
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                sib = f.read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            firsts.append(c)
+    return firsts
+
+
 def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
     """CPU figures on this box's host cores, same task and env count as the GPU line:
-    (i) `value` (kind "port"): the env-step lane program compiled for the host as a CPU PROGRAM - one environment per core, the four
-        lanes of an environment (one per limb) as fibers of ONE thread that hand the core over at every collective
-        (tests/emu/rl_env_emu.cpp FiberSet: no inter-core barrier anywhere), one pinned thread per core, environments dealt round
-        robin - SURVEY.md 8(d)'s "scalar restatement with one env per iteration over all cores";
-    (ii) `lane_emulator`: the same library with a host THREAD per lane and spin barriers between them (what round 2 reported: a
-        test harness, barrier bound, not a tuned CPU path);
-    (iii) `oracle`: the fp64 numpy oracle (oracle/env.py, single process) on a smaller sample."""
+    (i) `value` (kind "port"): the env-step program compiled for the host (g++ -O3 -march=native of the source hipcc compiles) as a
+        CPU PROGRAM - ONE ENVIRONMENT PER THREAD: a thread walks its environments one after the other, the four limbs of an
+        environment are coroutines of that thread that hand over at every cross-limb sum (a user-space switch of six registers: no
+        barrier, no second core, tests/emu/rl_env_emu.cpp FiberSet), one pinned thread per PHYSICAL core (fixed, not probed), every
+        thread owning whole state tiles (no cache line is written by two cores) - SURVEY.md 8(d)'s "scalar restatement with one env
+        per iteration over all cores".  Timed twice; `repeats` carries both and their relative difference.
+    (ii) `oracle`: the fp64 numpy oracle (oracle/env.py, single process) on a smaller sample."""
     import numpy as np
 
     from oracle.env import OracleEnv
     from robot_lab_amd.scene import build_world, load_bundle
 
-    cores = os.cpu_count() or 4
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
+    cpus = physical_cores()
+    cores = len(cpus)
     rng = np.random.default_rng(0)
     desc, extra = load_bundle(task)
     D = desc.model.num_dof
     lib = build_host_port()
 
-    def run(teams, steps, fibers):
-        """env-steps/s of `teams` teams (fibers: one pinned thread each; else 4 pinned lane threads each), a fresh pool per setting"""
+    def run(steps):
+        """env-steps/s with one pinned thread per physical core, a fresh process (and pool) per measurement"""
         code = ("import sys, time, numpy as np\nsys.path.insert(0, %r)\n"
                 "from robot_lab_amd.capi import NativeEnv\nfrom robot_lab_amd.scene import build_world, load_bundle\n"
                 "desc, extra = load_bundle(%r)\nh, to, eo = build_world(desc, extra, %d, 0)\n"
                 "nat = NativeEnv(desc, h, to, eo, %d, 42, 0, %r)\nnat.reset()\n"
-                "a = np.random.default_rng(0).uniform(-1, 1, (8, %d, %d)).astype(np.float32)\nnat.step(a[0].ctypes.data)\n"
+                "a = np.random.default_rng(0).uniform(-1, 1, (8, %d, %d)).astype(np.float32)\nnat.step(a[0].ctypes.data)\nnat.step(a[1].ctypes.data)\n"
                 "t0 = time.perf_counter()\nfor s in range(%d): nat.step(a[s %% 8].ctypes.data)\nprint(time.perf_counter() - t0)\n"
                 % (ROOT, task, n_envs, n_envs, lib, n_envs, D, steps))
-        env = dict(os.environ, RL_EMU_TEAMS=str(teams), RL_EMU_PIN="1", RL_EMU_FIBERS="1" if fibers else "0")
+        env = dict(os.environ, RL_EMU_TEAMS=str(cores), RL_EMU_CPUS=",".join(map(str, cpus)), RL_EMU_FIBERS="1")
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         if p.returncode != 0:
             return 0.0, 0.0
         dt = float(p.stdout.strip().splitlines()[-1])
         return n_envs * steps / dt, dt
 
-    # (i) one env per core: all cores, or half of them where two hardware threads share a core's FP units - probe, keep the better
-    probes = {t: run(t, 2, True)[0] for t in sorted({cores, max(1, cores // 2)}, reverse=True)}
-    teams = max(probes, key=probes.get)
-    steps = int(max(3, min(4000, budget_s * probes[teams] / n_envs))) if probes[teams] > 0 else 3
-    port, dt = run(teams, steps, True)
-    # (ii) the round-2 figure, for continuity: a thread per lane, spin barriers (bounded: a third of the budget)
-    lt = max(1, cores // 4)
-    lprobe = run(lt, 2, False)[0]
-    lsteps = int(max(3, min(100, budget_s / 3 * lprobe / n_envs))) if lprobe > 0 else 3
-    lane_emu, ldt = run(lt, lsteps, False)
-    # (iii) fp64 numpy oracle (one process; numpy's own threading aside)
+    probe = run(3)[0]  # sizes the sample only; the thread count is fixed
+    steps = int(max(5, min(4000, 0.5 * budget_s * probe / n_envs))) if probe > 0 else 5
+    reps = [run(steps), run(steps)]
+    port = sum(r[0] for r in reps) / len(reps)
+    spread = abs(reps[0][0] - reps[1][0]) / max(port, 1e-9)
+    # (ii) fp64 numpy oracle (one process; numpy's own threading aside)
     h, to, eo = build_world(desc, extra, oracle_envs, 0)
     ora = OracleEnv(desc, h, to, oracle_envs, 42, eo)
     ora.reset()
@@ -347,15 +367,12 @@ def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
     for s in range(oracle_steps):
         ora.step(oa[s + 1])
     odt = time.perf_counter() - t0
-    return {"value": port, "unit": "env-steps/s", "cores": teams, "kind": "port", "per_core": port / teams,
-            "sample": f"{n_envs} envs x {steps} steps of the same task ({dt:.1f} s): the env-step lane program compiled for the host "
-                      f"(g++ -O3 -march=native), one environment per core - {teams} pinned threads, each running the 4 lanes of its "
-                      f"environment as fibers (no inter-core barriers); probed thread counts "
-                      f"{ {k: round(v) for k, v in probes.items()} } env-steps/s",
-            "host_cores_available": cores,
-            "lane_emulator": {"value": lane_emu, "unit": "env-steps/s", "cores": lt * 4, "kind": "lane-emulator", "per_core": lane_emu / (lt * 4),
-                              "sample": f"{n_envs} envs x {lsteps} steps ({ldt:.1f} s): a host thread per lane, {lt} teams x 4 pinned threads, "
-                                        f"spin barriers at every collective (the round-2 baseline: barrier bound)"},
+    return {"value": port, "unit": "env-steps/s", "cores": cores, "kind": "port", "per_core": port / max(cores, 1),
+            "sample": f"{n_envs} envs x {steps} steps of the same task, timed twice ({reps[0][1]:.1f} s + {reps[1][1]:.1f} s): the env-step program "
+                      f"compiled for the host (g++ -O3 -march=native), one environment per thread - {cores} threads pinned one per physical "
+                      f"core, each walking its own state tiles, the four limbs of an environment as coroutines of that thread",
+            "repeats": {"values": [r[0] for r in reps], "relative_difference": spread},
+            "logical_cpus_available": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
             "oracle": {"value": oracle_envs * oracle_steps / odt, "unit": "env-steps/s", "cores": 1, "kind": "oracle",
                        "sample": f"{oracle_envs} envs x {oracle_steps} steps, fp64 numpy oracle (oracle/env.py), single process"}}
 

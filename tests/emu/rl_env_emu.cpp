@@ -183,7 +183,22 @@ class Pool {
 
  private:
   void worker(int id) {
-    if (const char* v = std::getenv("RL_EMU_PIN")) {  // RL_EMU_PIN=<stride>: lane thread i of the pool on allowed CPU (i * stride) mod n -
+    if (const char* v = std::getenv("RL_EMU_CPUS")) {  // RL_EMU_CPUS=<c0,c1,...>: pool thread i on logical CPU c[i mod n] (bench.py: one per physical core)
+      std::vector<int> cpus;
+      for (const char* q = v; *q;) {
+        char* end;
+        const long c = std::strtol(q, &end, 10);
+        if (end == q) break;
+        cpus.push_back((int)c);
+        q = *end == ',' ? end + 1 : end;
+      }
+      if (!cpus.empty()) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(cpus[(size_t)id % cpus.size()], &one);
+        pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+      }
+    } else if (const char* v = std::getenv("RL_EMU_PIN")) {  // RL_EMU_PIN=<stride>: lane thread i of the pool on allowed CPU (i * stride) mod n -
       const int stride = std::max(1, std::atoi(v));   // the 4 lanes of a team on neighbouring CPUs (a barrier every few hundred instructions)
       cpu_set_t allowed;
       if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
@@ -352,7 +367,11 @@ void run(const rl::KState& S_launch, const void* Tv) {
   using Ctx = HostCtx<SUB>;
   int teams = 1;
   if (const char* v = std::getenv("RL_EMU_TEAMS")) teams = std::max(1, std::atoi(v));
-  teams = std::min(teams, (int)S.Npad);
+  // A team owns whole state TILES (EPT consecutive environments): every field of a tile is one 256-byte row in which neighbouring
+  // environments share cache lines, so dealing single environments round robin made 16 cores write the same lines at once (false
+  // sharing: 2.5 k env-steps/s per core on a 128-core box against 15 k on one core alone - round 3's cpu_baseline).
+  const int tiles = ((int)S.Npad + Ctx::EPT - 1) / Ctx::EPT;
+  teams = std::min(teams, tiles);
   std::vector<std::unique_ptr<Team<Ctx::LPE>>> team(teams);
   for (auto& t : team) {
     t.reset(new Team<Ctx::LPE>());
@@ -362,16 +381,17 @@ void run(const rl::KState& S_launch, const void* Tv) {
   const auto lane_loop = [&](int tm, int l) {
     Ctx ctx;
     ctx.team = team[tm].get(); ctx.T = T; ctx.k_ = l / SUB; ctx.sub_ = l % SUB; ctx.e_ = 0;
-    for (int e = tm; e < S.Npad; e += teams) {
-      ctx.e_ = e;
-      rl::EnvProgram<Ctx, TP> prog(ctx, S);
-      if (S.mode == rl::KMODE_RESET || S.mode == rl::KMODE_STEP_TAIL)
-        prog.reset_entry();
-      else if (S.mode == rl::KMODE_STEP_HEAD)
-        prog.step_head();
-      else
-        prog.step();
-    }
+    for (int tile = tm; tile < tiles; tile += teams)
+      for (int e = tile * Ctx::EPT; e < std::min((tile + 1) * Ctx::EPT, (int)S.Npad); ++e) {
+        ctx.e_ = e;
+        rl::EnvProgram<Ctx, TP> prog(ctx, S);
+        if (S.mode == rl::KMODE_RESET || S.mode == rl::KMODE_STEP_TAIL)
+          prog.reset_entry();
+        else if (S.mode == rl::KMODE_STEP_HEAD)
+          prog.step_head();
+        else
+          prog.step();
+      }
   };
   if (RL_HAVE_FIBERS && std::getenv("RL_EMU_FIBERS") && std::atoi(std::getenv("RL_EMU_FIBERS")) != 0) {
     // one host thread per team, the team's lanes as fibers of that thread: an environment never leaves its core
@@ -387,16 +407,17 @@ void run(const rl::KState& S_launch, const void* Tv) {
     const int tm = id / Ctx::LPE, l = id % Ctx::LPE;
     Ctx ctx;
     ctx.team = team[tm].get(); ctx.T = T; ctx.k_ = l / SUB; ctx.sub_ = l % SUB; ctx.e_ = 0;
-    for (int e = tm; e < S.Npad; e += teams) {
-      ctx.e_ = e;
-      rl::EnvProgram<Ctx, TP> prog(ctx, S);
-      if (S.mode == rl::KMODE_RESET || S.mode == rl::KMODE_STEP_TAIL)
-        prog.reset_entry();
-      else if (S.mode == rl::KMODE_STEP_HEAD)
-        prog.step_head();
-      else
-        prog.step();
-    }
+    for (int tile = tm; tile < tiles; tile += teams)
+      for (int e = tile * Ctx::EPT; e < std::min((tile + 1) * Ctx::EPT, (int)S.Npad); ++e) {
+        ctx.e_ = e;
+        rl::EnvProgram<Ctx, TP> prog(ctx, S);
+        if (S.mode == rl::KMODE_RESET || S.mode == rl::KMODE_STEP_TAIL)
+          prog.reset_entry();
+        else if (S.mode == rl::KMODE_STEP_HEAD)
+          prog.step_head();
+        else
+          prog.step();
+      }
   };
   Pool::get().run(teams * Ctx::LPE, job);
 }

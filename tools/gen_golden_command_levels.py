@@ -80,7 +80,7 @@ def make_cases():
 
 if __name__ == "__main__":
     cases = make_cases()
-    out = os.path.join(ROOT, "tests", "golden", "command_levels.npz")
+    out = os.path.join(os.environ.get("RL_GOLDEN_DIR", os.path.join(ROOT, "tests", "golden")), "command_levels.npz")
     np.savez_compressed(out, cases=np.array(cases, dtype=object))
     for c in cases:
         print(c["name"], c["trace"][0], "->", c["trace"][-1])

@@ -51,7 +51,7 @@ def main():
                 out[f"{name}/{k}"] = v.astype(np.float64)
             print(f"{key} {name}: {N} envs x {steps} steps in {time.time() - t0:.0f} s; reward/step {st['reward'].mean():+.5f}, "
                   f"terminated/step {st['terminated'].mean():.4f}, time-out/step {st['time_out'].mean():.4f}, contacts {st['contacts'].mean():.3f}, level {st['level'].mean():.3f}", flush=True)
-        path = os.path.join(ROOT, "tests", "golden", f"episode_stats_{key}.npz")
+        path = os.path.join(os.environ.get("RL_GOLDEN_DIR", os.path.join(ROOT, "tests", "golden")), f"episode_stats_{key}.npz")
         np.savez_compressed(path, task=task, n_envs=N, steps=steps, seed=SEED, action_seed=ACTION_SEED, **out)
         print("wrote", path, os.path.getsize(path), "bytes")
 

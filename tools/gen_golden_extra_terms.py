@@ -30,7 +30,7 @@ def main():
         "feet_contact": mdp.feet_contact(env, command_name="base_velocity", expect_contact_num=p["expect_contact_num"], sensor_cfg=feet_sensor),
         "feet_height": mdp.feet_height(env, command_name="base_velocity", asset_cfg=feet_asset, target_height=p["target_height"], tanh_mult=p["tanh_mult"]),
     }
-    out = os.path.join(ROOT, "tests", "golden", "terms_extra.npz")
+    out = os.path.join(os.environ.get("RL_GOLDEN_DIR", os.path.join(ROOT, "tests", "golden")), "terms_extra.npz")
     np.savez(out, source="terms_go2.npz", names=np.array(list(vals)), values=np.stack([v.double().numpy() for v in vals.values()]),
              expect_contact_num=p["expect_contact_num"], target_height=p["target_height"], tanh_mult=p["tanh_mult"])
     for k, v in vals.items():

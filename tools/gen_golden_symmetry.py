@@ -37,6 +37,6 @@ actions = torch.randn(B, 12, generator=g)
 env = types.SimpleNamespace(unwrapped=None)
 obs_aug, act_aug = mod.compute_symmetric_states(env, obs, actions)
 assert torch.equal(obs_aug["critic"], obs["critic"].repeat(4, 1))  # other groups are only replicated (anymal.py:52)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "symmetry_anymal.npz"), obs=obs["policy"].numpy(), actions=actions.numpy(),
+np.savez_compressed(os.path.join(os.environ.get("RL_GOLDEN_DIR", os.path.join(ROOT, "tests", "golden")), "symmetry_anymal.npz"), obs=obs["policy"].numpy(), actions=actions.numpy(),
                     obs_aug=obs_aug["policy"].numpy(), actions_aug=act_aug.numpy())
 print("wrote symmetry_anymal.npz", tuple(obs_aug["policy"].shape), tuple(act_aug.shape))

@@ -160,7 +160,7 @@ def snapshot(ora):
 
 
 def main():
-    out_dir = os.path.join(ROOT, "tests", "golden")
+    out_dir = os.environ.get("RL_GOLDEN_DIR", os.path.join(ROOT, "tests", "golden"))
     os.makedirs(out_dir, exist_ok=True)
     todo = [a for a in sys.argv[1:]] or ["A1", "Go2", "G1", "A1_HandStand", "Tita", "Go2W"]
     for robot, seed, task in (("A1", 3, None), ("Go2", 4, None), ("G1", 6, None),
