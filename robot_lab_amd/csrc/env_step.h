@@ -297,9 +297,11 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
 // T_jx from its owner with nine quad broadcasts.  What stays per lane and joint is R_j = R_parent * T_j, the joint origin and the
 // world axis (axis_w = R_j * axis: Rodrigues(axis, .) leaves its own axis where it is, so this equals rot-frame * axis).  About
 // 60 instead of 110 instructions per joint of the 10-joint chain, five times per step.
+// (SUB here is the DEALING width: the sub-lanes of a DPP quad - with eight sub-lanes per limb each of the limb's two quads deals among
+// its own four lanes, `sub` = the lane's index in its quad, and the broadcasts stay single quad_perm moves: Ctx::deal_bcast_m3.)
 template <class TP, int SUB, class Ctx, class CT>
 RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C) {
-  static_assert(TP::ROT && SUB > 1, "trunk + limbs instance, several sub-lanes per limb");
+  static_assert(TP::ROT && SUB > 1 && SUB <= 4, "trunk + limbs instance, several sub-lanes per limb");
   constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NS = (JX + SUB - 1) / SUB;
   M3 Tl[NS];
   static_for<0, NS>([&](auto ic) __attribute__((always_inline)) {  // this sub-lane's joint of round i: SUB * i + sub (a partial last round is clamped, unused)
@@ -318,7 +320,7 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
   // (the bodies must be inlined at all three call sites: a lambda left as a function takes its captures - the lane object - by address)
   static_for<0, NW>([&](auto ic) __attribute__((always_inline)) {  // trunk joints (same in every lane)
     constexpr int i = decltype(ic)::value, jx = CL + i;
-    const M3 Tj = ctx.template leg_bcast_m3<jx % SUB>(Tl[jx / SUB]);
+    const M3 Tj = ctx.template deal_bcast_m3<jx % SUB>(Tl[jx / SUB]);
     const V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
     const M3 Rj = mul(Rp, Tj);
     C.setw(i, Rj, pj, mul(Rj, ld3(L.axis[jx])));
@@ -330,7 +332,7 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
   pp = pa;
   static_for<0, CL>([&](auto jc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
-    const M3 Tj = ctx.template leg_bcast_m3<j % SUB>(Tl[j / SUB]);
+    const M3 Tj = ctx.template deal_bcast_m3<j % SUB>(Tl[j / SUB]);
     const V3 pj = pp + mul(Rp, ld3(L.origin[j]));
     const M3 Rj = mul(Rp, Tj);
     C.set(j, Rj, pj, mul(Rj, ld3(L.axis[j])));
@@ -435,7 +437,7 @@ struct EnvLane {
   RL_FN void kinematics(ChainTP& C) {
 #ifndef RL_KIN_REPLICATED  // (A/B switch: every sub-lane computes every joint transform)
     if constexpr (NW > 0 && SUB > 1) {
-      chain_kinematics_dealt<TP, SUB>(ctx, sub, L, q, C);
+      chain_kinematics_dealt<TP, (SUB < 4 ? SUB : 4)>(ctx, SUB > 4 ? (sub & 3) : sub, L, q, C);
       return;
     }
 #endif
@@ -479,7 +481,10 @@ struct EnvLane {
     li = k * SUB + sub;
     Np = S.Npad;
 #pragma unroll
-    for (int i = 0; i < MAXOWN; ++i) own[i] = SUB == 1 ? i : (SUB == 2 ? L.own_slot2[sub & 1][i < LaneTabT<TP>::MAXOWN2 ? i : 0] : L.own_slot[sub & 3][i < LaneTabT<TP>::MAXOWN ? i : 0]);
+    for (int i = 0; i < MAXOWN; ++i) {
+      if constexpr (SUB == 8) own[i] = L.own_slot8[sub & (LaneTabT<TP>::NOWN8 - 1)][i < LaneTabT<TP>::MAXOWN8 ? i : 0];
+      else own[i] = SUB == 1 ? i : (SUB == 2 ? L.own_slot2[sub & 1][i < LaneTabT<TP>::MAXOWN2 ? i : 0] : L.own_slot[sub & 3][i < LaneTabT<TP>::MAXOWN ? i : 0]);
+    }
     tim.set_own(own); hist_n.set_own(own); cf.set_own(own); fric.set_own(own);
     lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
     et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
@@ -1146,7 +1151,7 @@ struct EnvLane {
   // Dealt to the env's 16 virtual lanes (env_tables.h SelfLaneTab): each places at most one capsule - centre and half axis in base
   // coordinates into 8 env-shared words, ahead of the group_sync the link records need anyway - and, once the records are
   // complete, tests at most five pairs; a hit ds_adds dt * [x cross F; F] into the bias of the two links' records.
-  static constexpr int SELF_V = 4 / SUB;  // virtual lanes this lane plays: v = 4 k + sub + SUB * i
+  static constexpr int SELF_V = SUB >= 4 ? 1 : 4 / SUB;  // virtual lanes this lane plays: v = 4 k + sub + SUB * i (eight sub-lanes per limb: the first four play one each)
   SelfLaneTab self_tab[NW > 0 ? SELF_V : 1];
   RL_FN bool self_on() const { return NW > 0 && S.self_k > 0.f; }
   RL_FN float* cap_words(int c) const { return ctx.env_scratch() + (NW + 1) * LINK_REC + c * SELF_CAP_WORDS; }
@@ -1155,7 +1160,14 @@ struct EnvLane {
       if (!self_on()) return;
       const auto& Tg = ctx.template tables_global<TablesT<TP>>();
 #pragma unroll
-      for (int i = 0; i < SELF_V; ++i) self_tab[i] = Tg.self_lane[4 * k + sub + SUB * i];
+      for (int i = 0; i < SELF_V; ++i) {
+        self_tab[i] = Tg.self_lane[4 * k + ((sub + SUB * i) & 3)];
+        if (SUB > 4 && sub >= 4) {  // no virtual lane of its own: nothing to place, no pair to test
+          self_tab[i].cap = -1;
+#pragma unroll
+          for (int p = 0; p < SELF_PPL; ++p) self_tab[i].pair[p] = -1;
+        }
+      }
     }
   }
   RL_FN void self_place(const ChainTP& C) {

@@ -85,8 +85,13 @@ struct LaneTabT {
   int32_t own_slot[4][MAXOWN];         // 16-lanes-per-env mapping: the body slots sub-lane s updates (ascending, -1 padded)
   static constexpr int MAXOWN2 = 4;
   int32_t own_slot2[2][MAXOWN2];       // 8-lanes-per-env mapping (two sub-lanes per limb; quadrupeds): likewise
+  // 32-lanes-per-env mapping (eight sub-lanes per limb; trunk + limbs instances: CL = 7, so sub-lane s evaluates exactly link group
+  // s - group 0, the lane's share of a trunk link plus the sphere-less trunk bodies parked with it, on sub-lane 0)
+  static constexpr int MAXOWN8 = 3;
+  static constexpr int NOWN8 = TP::NW > 0 ? 8 : 1;  // (quadruped instances do not have the mapping: their LDS image stays as it was)
+  int32_t own_slot8[NOWN8][MAXOWN8];
   template <int SUB>
-  static constexpr int maxown() { return SUB == 2 ? MAXOWN2 : MAXOWN; }
+  static constexpr int maxown() { return SUB == 8 ? MAXOWN8 : (SUB == 2 ? MAXOWN2 : MAXOWN); }
 };
 using LaneTab = LaneTabT<TopoMax>;
 
@@ -144,6 +149,7 @@ struct TaskTab {  // everything that is not per limb
   int32_t nw_used;      // trunk joints the model really has (<= NW; the rest are inert padding)
   uint32_t slot_valid;  // bit g*SPL+s: some lane has a collision sphere in slot (g, s)
   int32_t merged;       // 1: tables built for a Topo<..., M0 = 1> instance (base-share spheres in limb slots, LaneTabT::sph_base_mask)
+  int32_t sub8_ok;      // 1: the model fits the 32-lanes-per-env mapping (trunk + limbs instances; LaneTabT::own_slot8 holds every slot)
   int32_t wrench_depth; // trunk link (0 = base, i = after i trunk joints) carrying the body the wrench / COM events address
   int32_t scan_depth;   // trunk link carrying the height-scanner body
   float scan_pos[3];    // scanner body origin in that link's frame
@@ -259,6 +265,8 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
       for (int i = 0; i < LaneTabT<TP>::MAXOWN; ++i) b.own_slot[q][i] = a.own_slot[q][i];
     for (int q = 0; q < 2; ++q)
       for (int i = 0; i < LaneTabT<TP>::MAXOWN2; ++i) b.own_slot2[q][i] = a.own_slot2[q][i];
+    for (int q = 0; q < LaneTabT<TP>::NOWN8; ++q)
+      for (int i = 0; i < LaneTabT<TP>::MAXOWN8; ++i) b.own_slot8[q][i] = a.own_slot8[q][i];
   }
 }
 
@@ -268,7 +276,7 @@ enum { CMD_VX = 0, CMD_VY, CMD_WZ, CMD_HEADING, CMD_TIME_LEFT, CMD_METRIC_XY, CM
 constexpr int INERTIA_NF = 10;
 
 // ---- HBM state layout: wave-tiled structure-of-arrays -------------------------------------------
-// A tile is the state of one wavefront (16 envs, or 4 envs in the 16-lanes-per-env mapping).  Rows are
+// A tile is the state of one wavefront (16 envs; 8 / 4 / 2 envs in the 8- / 16- / 32-lanes-per-env mappings).  Rows are
 // laid out for the MAX_* shape (unused rows are never touched, so they cost address space only).  Inside a
 // tile every field is one contiguous row: one float per leg for lane fields, one per env for env fields.  A wavefront therefore
 // reads/writes whole coalesced rows, and - the reason for tiling rather than [field][N] planes - every
@@ -339,7 +347,7 @@ enum KMode { KMODE_STEP = 0, KMODE_RESET = 1, KMODE_STEP_HEAD = 2, KMODE_STEP_TA
 struct KState {
   int32_t N;      // environments the caller sees
   int32_t Npad;   // simulated (multiple of ENVS_PER_WAVE)
-  int32_t ept;    // environments per tile / wavefront (16 or 4)
+  int32_t ept;    // environments per tile / wavefront (16, 8, 4 or 2)
   float* lane_state;  // [Npad/ept][NF_LANE][4*ept]
   float* env_state;   // [Npad/ept][NF_ENV][ept]
   int32_t* flags;    // [Npad] bit0 is_heading_env, bit1 is_standing_env

@@ -677,7 +677,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // Height-scan rays of this lane: yaw-aligned grid, x fastest [UPSTREAM B6]; SCAN_RB rays per lane per trip so that all their
   // 8-byte loads overlap (187 rays = ONE trip of 12 x 16 lanes).  The gather costs ~5 us of the A1 Rough step at 4096 envs
   // (tools/ablate.sh): two cache lines per ray through the CU's vector L1, 6 k line requests per CU and step.
-  static constexpr int SCAN_RB = 12;
+  static constexpr int SCAN_RB = LPE >= 32 ? 6 : 12;  // (32 lanes per env: 6 x 32 = 192 rays in the one trip)
   struct ScanPatches {
     TerrainPatch tp[SCAN_RB];
     bool single_trip;

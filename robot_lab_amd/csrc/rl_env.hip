@@ -13,11 +13,15 @@
 // launchers of the other two lane mappings (rl_env_sub.inl: their own translation units unless RL_ENV_SINGLE_TU)
 extern "C" __attribute__((visibility("hidden"))) int rl_env_launch_sub1(const void* cfg, const void* S, const void* T, int inst, size_t lds1, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl_env_launch_sub2(const void* cfg, const void* S, const void* T, int inst, size_t lds1, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int rl_env_launch_sub8(const void* cfg, const void* S, const void* T, int inst, size_t lds1, void* stream);
 #ifdef RL_ENV_SINGLE_TU
 #define RL_ENV_TU_SUB 1
 #include "rl_env_sub.inl"
 #undef RL_ENV_TU_SUB
 #define RL_ENV_TU_SUB 2
+#include "rl_env_sub.inl"
+#undef RL_ENV_TU_SUB
+#define RL_ENV_TU_SUB 8
 #include "rl_env_sub.inl"
 #undef RL_ENV_TU_SUB
 #endif
@@ -93,7 +97,24 @@ struct Backend {
     if (T.cur_lin || T.cur_ang) {
       sub = 4;  // command-range curricula: the split step's head kernel is built for the 16-lane mapping only (no shipped cfg has them)
     } else if (const char* v = std::getenv("RL_ENV_SUB")) {
-      sub = atoi(v) == 1 ? 1 : (atoi(v) == 2 && T.NW == 0 ? 2 : 4);
+      sub = atoi(v) == 1 ? 1 : (atoi(v) == 2 && T.NW == 0 ? 2 : (atoi(v) == 8 && T.NW > 0 && T.sub8_ok ? 8 : 4));
+    } else if (T.NW > 0) {
+      // trunk + limbs instances: 16 lanes per env (4 envs per wavefront, ~80 KB of LDS: two wavefronts per CU) or 32 (2 envs per
+      // wavefront, ~32 KB: four per CU).  Rounds x the cost of a round, as below; RL_ENV_COST8 = cost of a 32-lane round relative to a
+      // 16-lane one (measured: profiles/r04*_g1_sub8*.txt)
+      sub = 4;
+      if (T.sub8_ok) {
+        const size_t n4 = T.NW > 3 ? lds_need<TopoGR, 4>(T) : lds_need<TopoG1, 4>(T), n8 = T.NW > 3 ? lds_need<TopoGR, 8>(T) : lds_need<TopoG1, 8>(T);
+        const size_t tb = staged_bytes(T);
+        const double slots4 = (double)n_cu * (double)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / n4));
+        const double slots8 = (double)n_cu * (double)((tb + 4 * (n8 - tb) <= 160 * 1024) ? 4 : std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / n8)));
+        double cost8 = 0.80;
+        if (const char* c = std::getenv("RL_ENV_COST8")) cost8 = atof(c);
+        const double t4 = std::ceil((double)(Npad / 4) / slots4), t8 = cost8 * std::ceil((double)(Npad / 2) / slots8);
+        if (t8 < t4) sub = 8;
+        if (std::getenv("RL_ENV_DEBUG"))
+          fprintf(stderr, "rl_env: %d envs: rounds x cost of 16 / 32 lanes per env = %.2f / %.2f (LDS per wavefront %zu / %zu B, tables %zu B) -> %d lanes per limb\n", Npad, t4, t8, n4, n8, tb, sub);
+      }
     } else if (T.NW == 0) {
       const size_t tb = staged_bytes(T);
       size_t need[3] = {0, 0, 0};  // LDS of a single-wavefront workgroup, mappings 4 / 2 / 1
@@ -157,6 +178,8 @@ struct Backend {
         err = "the one-lane-per-limb mapping (RL_ENV_SUB=1) of the trunk + limbs instance needs more LDS than a CU has";
         return -1;
       case 74: lds_bytes = lds_need<TopoG1, 4>(T); break;
+      case 78: lds_bytes = lds_need<TopoG1, 8>(T); break;
+      case 2078: lds_bytes = lds_need<TopoGR, 8>(T); break;
       case 2071: err = "the one-lane-per-limb mapping (RL_ENV_SUB=1) of the trunk + limbs instance needs more LDS than a CU has"; return -1;
       case 2074: lds_bytes = lds_need<TopoGR, 4>(T); break;
       default: err = "no lane-program instance for chain length " + std::to_string(T.CL); return -1;
@@ -176,7 +199,8 @@ struct Backend {
 #endif
     const std::string missing = "this build does not carry the lane-program instance for chain length " + std::to_string(CL) + " / " + std::to_string(sub) + " lanes per limb";
     if (sub != 4) {  // the 8- and 4-lane mappings: kernels of their own translation units (rl_env_sub.inl)
-      const int rc = sub == 2 ? rl_env_launch_sub2(&cfg, &S, T, CL, lds_bytes, stream) : rl_env_launch_sub1(&cfg, &S, T, CL, lds_bytes, stream);
+      const int rc = sub == 8 ? rl_env_launch_sub8(&cfg, &S, T, CL, lds_bytes, stream)
+                              : (sub == 2 ? rl_env_launch_sub2(&cfg, &S, T, CL, lds_bytes, stream) : rl_env_launch_sub1(&cfg, &S, T, CL, lds_bytes, stream));
       if (rc == -2) { err = missing; return -1; }
       return check((hipError_t)rc);
     }

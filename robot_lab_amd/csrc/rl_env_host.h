@@ -319,6 +319,22 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
       }
     }
   }
+  // ... and with eight (trunk + limbs instances: a wavefront then holds two envs instead of four, half the limb-shared LDS, and a
+  // 2048-env launch puts a wavefront on every SIMD).  A model that needs more rows than MAXOWN8 keeps the 16-lane mapping (sub8_ok).
+  T.sub8_ok = NW > 0 && !merge ? 1 : 0;
+  for (int k = 0; k < NLANE; ++k) {
+    LaneTab& L = T.lane[k];
+    for (int q = 0; q < 8; ++q) {
+      int n = 0;
+      for (int i = 0; i < LaneTab::MAXOWN8; ++i) L.own_slot8[q][i] = -1;
+      for (int sl = 0; sl < NBS && NW > 0; ++sl) {
+        const bool used = L.slot_body[sl] >= 0 || (sl == 0 && L.base_body_local >= 0);
+        if (!used || L.slot_grp[sl] % 8 != q) continue;
+        if (n >= LaneTab::MAXOWN8) { T.sub8_ok = 0; break; }
+        L.own_slot8[q][n++] = sl;
+      }
+    }
+  }
   // bodies the events / the scanner address
   {
     const int wl = m.body_link[d.task.base_body], sl = m.body_link[d.task.scan_body];

@@ -34,6 +34,7 @@ constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15 - i of a 16-lane row
 constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7 - i of each half row
 
 // Wavefront context.  SUB_ = 1: a lane per leg, 4 lanes per env (a DPP quad), 16 envs per wavefront.
+// SUB_ = 8 (trunk + limbs instances): two DPP quads per limb, 32 lanes per env, 2 envs per wavefront -> 2048 envs fill 1024 wavefronts.
 // SUB_ = 4: a DPP quad per leg, 16 lanes per env (a DPP row), 4 envs per wavefront -> 4096 envs fill
 // 1024 wavefronts = one per SIMD of the chip, and each lane's instruction stream is ~half as long.
 template <int SUB_>
@@ -76,8 +77,14 @@ struct WaveCtx {
   // lanes of different legs, and a + b == b + a bitwise, so all 16 lanes end with identical bits)
   // (SUB == 2: a limb is a lane pair, an env a half row of 8 lanes - the quad xor-2 pairs limbs 0 / 1 and 2 / 3, the half mirror
   // i <-> 7 - i then pairs those sums across the quads)
+  // (SUB == 8: a limb is two DPP quads, an env two DPP rows - 32 lanes, 2 envs per wavefront: the row mirror pairs limbs 0 / 1 and
+  // 2 / 3, then the two rows of the env are exchanged with a ds_swizzle in 32-lane bit mode, xor 16: no LDS memory is touched)
+  __device__ static float swap_rows(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); }  // and 0x1F, or 0, xor 0x10
   __device__ float gsum(float v) const {
-    if (SUB == 1) {
+    if (SUB == 8) {
+      v += dpp<DPP_ROW_MIRROR>(v);
+      v += swap_rows(v);
+    } else if (SUB == 1) {
       v += dpp<DPP_QUAD_XOR1>(v);
       v += dpp<DPP_QUAD_XOR2>(v);
     } else if (SUB == 2) {
@@ -92,7 +99,8 @@ struct WaveCtx {
   __device__ float leg_sum(float v) const {
     if (SUB == 1) return v;
     v += dpp<DPP_QUAD_XOR1>(v);
-    if (SUB == 4) v += dpp<DPP_QUAD_XOR2>(v);
+    if (SUB >= 4) v += dpp<DPP_QUAD_XOR2>(v);
+    if (SUB == 8) v += dpp<DPP_ROW_HALF_MIRROR>(v);  // the limb's other quad (lane i <-> 7 - i of the limb's eight)
     return v;
   }
   __device__ float esum(float v) const { return gsum(leg_sum(v)); }
@@ -102,6 +110,7 @@ struct WaveCtx {
     v = fminf(v, dpp<DPP_QUAD_XOR2>(v));
     if (SUB > 1) v = fminf(v, dpp<DPP_ROW_HALF_MIRROR>(v));
     if (SUB > 2) v = fminf(v, dpp<DPP_ROW_MIRROR>(v));
+    if (SUB > 4) v = fminf(v, swap_rows(v));
     return v;
   }
   // value held by sub-lane J of this lane's leg (DPP quad_perm broadcast; SUB == 4)
@@ -109,7 +118,20 @@ struct WaveCtx {
   __device__ float leg_bcast(float v) const {
     if constexpr (SUB == 1) return v;  // a lane is the whole leg
     else if constexpr (SUB == 2) return dpp_move<J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);  // lane pairs: [J, J, 2 + J, 2 + J]
-    else return dpp_move<J | (J << 2) | (J << 4) | (J << 6)>(v);
+    else if constexpr (SUB == 8) {  // sub-lane J & 3 of both quads, then the other quad's copy where J sits there
+      constexpr int J4 = J & 3;
+      const float t = dpp_move<J4 | (J4 << 2) | (J4 << 4) | (J4 << 6)>(v);
+      const float o = dpp_move<DPP_ROW_HALF_MIRROR>(t);
+      return ((lane >> 2) & 1) == (J >> 2) ? t : o;
+    } else return dpp_move<J | (J << 2) | (J << 4) | (J << 6)>(v);
+  }
+  // the dealing of per-joint work (chain_kinematics_dealt) is among the four lanes of a DPP quad in every mapping with SUB >= 4
+  template <int J>
+  __device__ __forceinline__ M3 deal_bcast_m3(const M3& m) const {
+    if constexpr (SUB == 8) {
+      auto b = [](float v) { return dpp_move<J | (J << 2) | (J << 4) | (J << 6)>(v); };
+      return M3{{b(m.r0.x), b(m.r0.y), b(m.r0.z)}, {b(m.r1.x), b(m.r1.y), b(m.r1.z)}, {b(m.r2.x), b(m.r2.y), b(m.r2.z)}};
+    } else return leg_bcast_m3<J>(m);
   }
   // a 3 x 3 matrix held by sub-lane J of this lane's leg (nine quad broadcasts)
   template <int J>
@@ -307,7 +329,9 @@ hipError_t launch_w(const LaunchCfg& cfg, const KState& S, const void* T, size_t
 }
 template <class TP, int SUB>
 hipError_t launch_cl(const LaunchCfg& cfg, const KState& S, const void* T, size_t lds1, hipStream_t st) {
-  if constexpr (TP::NW == 0) {  // (the trunk + limbs instance gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup)
+  // (the trunk + limbs instance with 16 lanes per env gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup - and its 80 KB
+  // per wavefront leave no room; with 32 lanes per env four ~32 KB wavefronts and ONE table image are what lets a CU hold four)
+  if constexpr (TP::NW == 0 || SUB == 8) {
     const int tiles = S.Npad / (16 / SUB);
     const size_t lds4 = S.table_bytes + 4 * (lds1 - S.table_bytes);
     // (only the step kernel exists in the four-wavefront shape: resets and the halves of a split step are off the hot path)

@@ -82,7 +82,7 @@ rl_fiber_switch:
 struct FiberSet {
   static constexpr size_t STACK = 512 * 1024;
   int n = 0, cur = -1;
-  void* sp[17] = {};     // saved stack pointers of the lanes; [n] = the host thread's own context
+  void* sp[33] = {};     // saved stack pointers of the lanes (up to 32: eight sub-lanes per limb); [n] = the host thread's own context
   std::vector<std::unique_ptr<char[]>> stacks;
   std::function<void(int)> body;
   static thread_local FiberSet* active;
@@ -291,6 +291,7 @@ struct HostCtx {
     team->barrier(li());
     const float* p = team->slot + k_ * SUB;
     float s = SUB == 2 ? p[0] + p[1] : (p[0] + p[1]) + (p[2 % SUB] + p[3 % SUB]);
+    if (SUB == 8) s += (p[4 % SUB] + p[5 % SUB]) + (p[6 % SUB] + p[7 % SUB]);  // the limb's second quad (the kernel: one more half-row mirror; a + b == b + a bitwise)
     team->barrier(li());
     return s;
   }
@@ -329,6 +330,17 @@ struct HostCtx {
     w[0] = m.r0.x; w[1] = m.r0.y; w[2] = m.r0.z; w[3] = m.r1.x; w[4] = m.r1.y; w[5] = m.r1.z; w[6] = m.r2.x; w[7] = m.r2.y; w[8] = m.r2.z;
     team->barrier(li());
     const float* r = team->slot9[k_ * SUB + (J < SUB ? J : 0)];
+    const rl::M3 out{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, {r[6], r[7], r[8]}};
+    team->barrier(li());
+    return out;
+  }
+  template <int J>
+  rl::M3 deal_bcast_m3(const rl::M3& m) {  // the dealing quad: the limb's four sub-lanes, or - eight sub-lanes per limb - the lane's half of them
+    if (SUB <= 4) return leg_bcast_m3<J>(m);
+    float* w = team->slot9[li()];
+    w[0] = m.r0.x; w[1] = m.r0.y; w[2] = m.r0.z; w[3] = m.r1.x; w[4] = m.r1.y; w[5] = m.r1.z; w[6] = m.r2.x; w[7] = m.r2.y; w[8] = m.r2.z;
+    team->barrier(li());
+    const float* r = team->slot9[k_ * SUB + (sub_ & 4) + J];
     const rl::M3 out{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, {r[6], r[7], r[8]}};
     team->barrier(li());
     return out;
@@ -425,14 +437,14 @@ void run(const rl::KState& S_launch, const void* Tv) {
 struct Backend {
   std::string err;
   const std::string& error() const { return err; }
-  int sub = 1;  // RL_EMU_SUB=4 selects the 16-lanes-per-env mapping (16 host threads per env: slow)
+  int sub = 1;  // RL_EMU_SUB=4 selects the 16-lanes-per-env mapping (16 host threads per env: slow), 8 the 32-lane one of the trunk + limbs instances
   int activate() { return 0; }
   int init(int) {
-    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : (std::atoi(v) == 2 ? 2 : 1);
+    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 8 ? 8 : (std::atoi(v) == 4 ? 4 : (std::atoi(v) == 2 ? 2 : 1));
     return 0;
   }
   int envs_per_wave(const rl::Tables&, int) {
-    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 4 ? 4 : (std::atoi(v) == 2 ? 2 : 1);
+    if (const char* v = std::getenv("RL_EMU_SUB")) sub = std::atoi(v) == 8 ? 8 : (std::atoi(v) == 4 ? 4 : (std::atoi(v) == 2 ? 2 : 1));
     return 16 / sub;
   }
   int configure(const rl::Tables&) { return 0; }
@@ -454,6 +466,8 @@ struct Backend {
       case 1044: run<rl::TopoQuad4M, 4>(S, T); return 0;
       case 71: run<rl::TopoG1, 1>(S, T); return 0;
       case 74: run<rl::TopoG1, 4>(S, T); return 0;
+      case 78: run<rl::TopoG1, 8>(S, T); return 0;
+      case 2078: run<rl::TopoGR, 8>(S, T); return 0;
       case 2071: run<rl::TopoGR, 1>(S, T); return 0;
       case 2074: run<rl::TopoGR, 4>(S, T); return 0;
       default: err = "unsupported chain length"; return -1;

@@ -138,6 +138,39 @@ def test_sixteen_lane_mapping_matches_oracle(task, N, steps, merge, sub, emu_lib
     nat.close()
 
 
+# The 32-lanes-per-env mapping of the trunk + limbs instances (eight sub-lanes per limb - sub-lane s evaluates link group s -, two envs
+# per wavefront: what a <= 2048-env G1 launch runs on the GPU since round 4): G1 Rough and Flat, a padded humanoid, a biped with two
+# empty limbs, the six-joint-spine instance.  32 lanes per env as fibers of one host thread.
+@pytest.mark.parametrize("task,k", [(TASKS[5], 1.0), (TASKS[4], 1.0), ("RobotLab-Isaac-Velocity-Flat-RobotEra-Xbot-v0", 1.0),
+                                    ("RobotLab-Isaac-Velocity-Rough-Openloong-Loong-v0", 1.0), ("RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0", 6.0)])
+def test_thirty_two_lane_mapping_matches_oracle(task, k, emu_lib, monkeypatch):
+    monkeypatch.setenv("RL_EMU_SUB", "8")
+    monkeypatch.setenv("RL_EMU_FIBERS", "1")
+    N, steps = 4, 4
+    desc, ora, nat = make_pair(task, N, 21, emu_lib)
+    assert nat.envs_per_wavefront() == 2
+    o = ora.reset()
+    nat.reset()
+    assert_close("critic0", host_view(nat, "OBS_CRITIC"), o[1], k * 1e-3, k * 1e-4)
+    rng = np.random.default_rng(5)
+    for s in range(steps):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        o = ora.step(a)
+        nat.step(a.ctypes.data)
+        assert_close(f"reward[{s}]", host_view(nat, "REWARD"), ora.reward, k * 1e-3, k * 2e-5)
+        assert_close(f"cforce[{s}]", host_view(nat, "CONTACT_FORCE"), ora.contact_force, k * 5e-3, k * 5e-2)
+    nat.export_state()
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), k * 1e-3, k * 1e-4)
+    assert_close("q", host_view(nat, "JOINT_POS"), ora.st["q"], k * 1e-3, k * 1e-4)
+    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], k * 2e-3, k * 2e-3)
+    assert_close("terms", host_view(nat, "REWARD_TERMS")[:, :N], ora.reward_terms, k * 2e-3, k * 2e-5)
+    assert_close("timers", host_view(nat, "CONTACT_TIMERS"), ora.timers, k * 1e-5, k * 1e-6)
+    assert_close("torque", host_view(nat, "JOINT_TORQUE"), ora.applied_torque, k * 2e-3, k * 2e-3)
+    assert_close("policy", host_view(nat, "OBS_POLICY"), o[0], k * 2e-3, k * 2e-3)
+    assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], k * 2e-3, k * 2e-3)
+    nat.close()
+
+
 def _switch_kinds(desc):
     """The reward kinds no shipped cfg gives a weight: `feet_height` (world frame, rewards.py:507-524) in place of A1's
     `feet_height_body`, `feet_contact` (rewards.py:399-413, expects 2 feet down) in place of `feet_contact_without_cmd`, and

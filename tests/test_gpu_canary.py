@@ -28,7 +28,7 @@ INSTANCES = [
 ]
 # RL_ENV_WG: "" = the shape the launch size selects (single-wavefront workgroups at this size), "-4" = four wavefronts per workgroup
 # (what >= 4096 quadruped envs launch), RL_ENV_SUB=1 = the one-lane-per-limb mapping
-SHAPES = [("", "4"), ("-4", "4"), ("", "1"), ("-4", "1"), ("", "2"), ("-4", "2")]
+SHAPES = [("", "4"), ("-4", "4"), ("", "1"), ("-4", "1"), ("", "2"), ("-4", "2"), ("", "8"), ("-4", "8")]  # 8: the 32-lane mapping of the trunk + limbs instances
 
 
 def timers_tick_exactly(env, torch, steps=3):
@@ -63,12 +63,16 @@ def test_interval_timers_tick_by_exactly_step_dt(task, merge, wg, sub, monkeypat
 
     if wg:
         monkeypatch.setenv("RL_ENV_WG", wg)
-    if sub != "4":
-        monkeypatch.setenv("RL_ENV_SUB", sub)
+    trunk = "G1" in task or "GR1" in task
+    monkeypatch.setenv("RL_ENV_SUB", sub)
     if merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
-    if sub == "2" and ("G1" in task or "GR1" in task):
-        pytest.skip("the trunk + limbs instance has the 16-lane mapping only")
+    if sub == "8" and not trunk:
+        pytest.skip("eight sub-lanes per limb: trunk + limbs instances only")
+    if sub == "4" and wg == "-4" and trunk:
+        pytest.skip("the 16-lane mapping of the trunk + limbs instance ships single-wavefront workgroups only")
+    if sub == "2" and trunk:
+        pytest.skip("the trunk + limbs instance has the 16- and 32-lane mappings only")
     if sub == "1" and ("G1" in task or "GR1" in task):
         # the trunk + limbs instance keeps its kinematics / link records in limb-shared LDS words: with one lane per limb (64 limbs per
         # wavefront) that is 115 KB + 30 KB of sensor rows - it exists on the CPU lane emulator only, rl_env_create refuses it on the GPU
@@ -93,7 +97,7 @@ def _eventful_state(env, seed):
     env.load_state({"task_state": ts, "episode_length": ep})
 
 
-@pytest.mark.parametrize("sub", ["4", "1", "2"])
+@pytest.mark.parametrize("sub", ["4", "1", "2", "8"])
 @pytest.mark.parametrize("task,merge", INSTANCES)
 def test_kernel_shapes_agree_bit_for_bit(task, merge, sub, monkeypatch):
     """The SAME lane program is compiled into several kernels (workgroup of one / of four wavefronts; step / reset entry): different
@@ -108,10 +112,10 @@ def test_kernel_shapes_agree_bit_for_bit(task, merge, sub, monkeypatch):
 
     if merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
-    if sub != "4":
-        if ("G1" in task or "GR1" in task):
-            pytest.skip("the trunk + limbs instance has the 16-lane mapping only")
-        monkeypatch.setenv("RL_ENV_SUB", sub)
+    trunk = "G1" in task or "GR1" in task
+    if (sub in ("1", "2") and trunk) or (sub == "8" and not trunk):
+        pytest.skip("the trunk + limbs instance has the 16- and 32-lane mappings, the quadrupeds the 16-, 8- and 4-lane ones")
+    monkeypatch.setenv("RL_ENV_SUB", sub)
     N = 512
     runs = []
     for wg in ("1", "-4"):
@@ -129,7 +133,7 @@ def test_kernel_shapes_agree_bit_for_bit(task, merge, sub, monkeypatch):
                               terms=env.reward_terms().cpu().numpy().copy(), done=(term | tout).cpu().numpy().copy(), **env.read_state()))
         runs.append(trace)
         env.close()
-    if ("G1" in task or "GR1" in task):  # the trunk + limbs instance ships single-wavefront workgroups only (csrc/rl_env.hip launch_cl): both runs are the same kernel
+    if trunk and sub == "4":  # the 16-lane mapping of the trunk + limbs instance ships single-wavefront workgroups only (csrc/rl_env_kernels.h launch_cl): both runs are the same kernel
         assert all(np.array_equal(a[k], b[k]) for a, b in zip(*runs) for k in a)
         return
     assert sum(int(t["done"].sum()) for t in runs[0]) > N // 8  # the window is eventful

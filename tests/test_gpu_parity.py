@@ -57,22 +57,27 @@ def _pair(task, N, seed):
     return env, OracleWithTwin(lambda: OracleEnv(desc, h, to, N, seed, eo)), torch
 
 
-TRUNK_LIMBS = ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1")  # robots on the trunk + limbs instance (single-wavefront workgroups only)
+TRUNK_LIMBS = ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1")  # robots on the trunk + limbs instance
 # Kernel shapes.  Production launches of >= 4096 quadruped envs run env_kernel<..., WGW = 4> (four wavefronts
 # per workgroup sharing one staged table image); 64 envs would take the single-wavefront variant, so every quadruped id is run in
 # BOTH: "" = what the launch size selects (WGW = 1 here), "-4" = RL_ENV_WG=-4 forces the four-wavefront shape at this size.  The
 # wheeled ids whose tables merge are also run on the unmerged 4-joint instance (RL_ENV_MERGE=0), in both shapes.
-SHAPES = [(t, wg, None) for t in TASKS for wg in (("", "-4") if not any(r in t for r in TRUNK_LIMBS) else ("",))]
+# Trunk + limbs robots: the 16-lane mapping in single-wavefront workgroups ("sub4") and the 32-lane mapping of round 4 (eight sub-lanes
+# per limb, two envs per wavefront) in single- and four-wavefront workgroups ("sub8", "sub8-4": what a >= 2048-env launch runs).
+SHAPES = [(t, wg, None) for t in TASKS for wg in (("", "-4") if not any(r in t for r in TRUNK_LIMBS + ("GR1",)) else ("sub4", "sub8", "sub8-4"))]
 SHAPES += [(t, wg, "0") for t in (TASKS[3], TASKS[8]) for wg in ("", "-4")]  # Go2W, M20
 
 
 @pytest.mark.parametrize("task,wg,merge", SHAPES)
 def test_short_horizon_parity(task, wg, merge, monkeypatch):
+    if wg.startswith("sub"):
+        monkeypatch.setenv("RL_ENV_SUB", wg[3])
+        wg = wg[4:]
     if wg:
         monkeypatch.setenv("RL_ENV_WG", wg)
     if merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
-    N = 32 if any(r in task for r in TRUNK_LIMBS) else 64
+    N = 32 if any(r in task for r in TRUNK_LIMBS + ("GR1",)) else 64
     env, two, torch = _pair(task, N, 11)
     ora = two.ora
     obs, _ = env.reset()

@@ -31,7 +31,9 @@ def _native_after(state, a, N, steps, monkeypatch=None, self_off=False):
     return env.read_state()
 
 
-def test_hip_matches_oracle_in_self_contact(monkeypatch):
+@pytest.mark.parametrize("sub", ["4", "8"])
+def test_hip_matches_oracle_in_self_contact(sub, monkeypatch):
+    monkeypatch.setenv("RL_ENV_SUB", sub)  # both lane mappings of the trunk + limbs instance
     _, src, a = _drive_arm_into_torso(True, steps=25)
     assert min(g for g, _, _ in capsule_gaps(src)) < -0.005
     state = src.read_state()

@@ -39,6 +39,11 @@ CONFIGS = [
     # two sub-lanes per limb (8 envs per wavefront: what 5 - 11 k quadruped envs per GPU launch), likewise forced at this size
     ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", 4096, "sub2"),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 4096, "sub2"),
+    # trunk + limbs instances: rows 3 and 7 above run what rl_env_create picks at 2048 envs (since round 4 the 32-lane mapping: eight
+    # sub-lanes per limb, two envs per wavefront, four wavefronts per workgroup); here both mappings are forced - and GR1's spine instance
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 2048, "sub8"),
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 2048, "sub4"),
+    ("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0", 1024, "sub8"),
 ]
 
 
@@ -55,9 +60,11 @@ def test_one_step_from_shared_state_full_size(task, N, merge, monkeypatch):
 
     from robot_lab_amd.env import ManagerBasedRLEnv
 
-    if merge in ("sub1", "sub2"):
+    if merge in ("sub1", "sub2", "sub8"):
         monkeypatch.setenv("RL_ENV_SUB", merge[-1])
         monkeypatch.setenv("RL_ENV_WG", "-4")
+    elif merge == "sub4":
+        monkeypatch.setenv("RL_ENV_SUB", "4")
     elif merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
     K, seed = 30, 42

@@ -153,10 +153,13 @@ def test_an_arm_does_not_pass_through_the_torso():
     assert np.isfinite(ora.st["qd"]).all() and np.abs(ora.st["qd"]).max() < 30.0  # an explicit spring: it must not ring up
 
 
-@pytest.mark.parametrize("sub", ["1", "4"])
+@pytest.mark.parametrize("sub", ["1", "4", "8"])
 def test_lane_program_matches_oracle_in_self_contact(sub, emu_lib, monkeypatch):
-    """Both sides step from a state in which the upper arm presses on the torso (and the push goes on): same end state."""
+    """Both sides step from a state in which the upper arm presses on the torso (and the push goes on): same end state.
+    (sub 8: the 32-lane mapping - the first four sub-lanes of a limb play the 16 virtual lanes the pairs are dealt to.)"""
     monkeypatch.setenv("RL_EMU_SUB", sub)
+    if sub == "8":
+        monkeypatch.setenv("RL_EMU_FIBERS", "1")
     _, src, a = _drive_arm_into_torso(True, steps=25)
     state = src.read_state()
     gaps0 = capsule_gaps(src)

@@ -81,14 +81,18 @@ def test_one_step_from_shared_state(task, N, K, emu_lib):
 
 @pytest.mark.parametrize("task,merge", [("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", None), ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", "0"),
                                         ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", None), ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", None),
-                                        ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", None)])  # G1: torso on the ground = illegal_contact -> terminated, is_terminated reward
+                                        ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", None),  # G1: torso on the ground = illegal_contact -> terminated, is_terminated reward
+                                        ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", "sub8")])  # ... and in the 32-lane mapping (group 0 = the trunk share, sub-lane 0)
 def test_one_step_with_the_trunk_on_the_ground(task, merge, emu_lib, monkeypatch):
     """Robots lying on their backs in the 16-lanes-per-env mapping: the TRUNK's collision spheres carry the robot - the contacts
     random-action warm-ups rarely reach.  On the merged 4-joint instance those spheres sit in flagged slots
     of limb link groups (Go2W: hip groups, with the sub-lane that owns the trunk body's slot; M20: wheel groups, with another
     sub-lane - separate base record, twist, friction row and force sum); RL_ENV_MERGE=0 and A1 take the group-0 path."""
     monkeypatch.setenv("RL_EMU_SUB", "4")
-    if merge is not None:
+    if merge == "sub8":
+        monkeypatch.setenv("RL_EMU_SUB", "8")
+        monkeypatch.setenv("RL_EMU_FIBERS", "1")
+    elif merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
     N = 8
     desc, ora, nat = make_pair(task, N, 5, emu_lib)
