@@ -312,7 +312,31 @@ def physical_cores() -> list[int]:
         if sib not in seen:
             seen.add(sib)
             firsts.append(c)
+    # ... capped by the CPU time the container may use: a cgroup quota below the core count makes every thread beyond it time-share
+    # (the GPU boxes of this pool show 256 logical CPUs and `cpu.max = 1600000 100000`, i.e. 16 CPUs: 16 pinned threads run at
+    # 34.7 k env-steps/s each, 128 at 2.6 k each - profiles/r04b_cpu_scaling.txt; round 3's "2.5 k per core" was the quota, not the program)
+    quota = cpu_quota()
+    if quota is not None and quota < len(firsts):
+        firsts = firsts[:max(1, int(quota))]
     return firsts
+
+
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
@@ -370,9 +394,11 @@ def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
     return {"value": port, "unit": "env-steps/s", "cores": cores, "kind": "port", "per_core": port / max(cores, 1),
             "sample": f"{n_envs} envs x {steps} steps of the same task, timed twice ({reps[0][1]:.1f} s + {reps[1][1]:.1f} s): the env-step program "
                       f"compiled for the host (g++ -O3 -march=native), one environment per thread - {cores} threads pinned one per physical "
-                      f"core, each walking its own state tiles, the four limbs of an environment as coroutines of that thread",
+                      f"core (as many as the container's CPU quota grants), each walking its own state tiles, the four limbs of an environment as "
+                      f"coroutines of that thread",
             "repeats": {"values": [r[0] for r in reps], "relative_difference": spread},
             "logical_cpus_available": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+            "cgroup_cpu_quota": cpu_quota(),
             "oracle": {"value": oracle_envs * oracle_steps / odt, "unit": "env-steps/s", "cores": 1, "kind": "oracle",
                        "sample": f"{oracle_envs} envs x {oracle_steps} steps, fp64 numpy oracle (oracle/env.py), single process"}}
 

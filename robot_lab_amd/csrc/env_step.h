@@ -482,8 +482,18 @@ struct EnvLane {
     Np = S.Npad;
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) {
-      if constexpr (SUB == 8) own[i] = L.own_slot8[sub & (LaneTabT<TP>::NOWN8 - 1)][i < LaneTabT<TP>::MAXOWN8 ? i : 0];
+      if constexpr (SUB == 8) own[i] = -1;
       else own[i] = SUB == 1 ? i : (SUB == 2 ? L.own_slot2[sub & 1][i < LaneTabT<TP>::MAXOWN2 ? i : 0] : L.own_slot[sub & 3][i < LaneTabT<TP>::MAXOWN ? i : 0]);
+    }
+    if constexpr (SUB == 8) {  // the used slots of link group `sub`, ascending (the host has checked that they are at most MAXOWN: TaskTab::sub8_ok)
+      int n = 0;
+#pragma unroll
+      for (int sl = 0; sl < NBS; ++sl) {
+        const bool mine = (L.slot_body[sl] >= 0 || (sl == 0 && L.base_body_local >= 0)) && (L.slot_grp[sl] & 7) == sub;
+#pragma unroll
+        for (int i = 0; i < MAXOWN; ++i) own[i] = (mine && n == i) ? sl : own[i];
+        n += mine ? 1 : 0;
+      }
     }
     tim.set_own(own); hist_n.set_own(own); cf.set_own(own); fric.set_own(own);
     lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);

@@ -86,10 +86,10 @@ struct LaneTabT {
   static constexpr int MAXOWN2 = 4;
   int32_t own_slot2[2][MAXOWN2];       // 8-lanes-per-env mapping (two sub-lanes per limb; quadrupeds): likewise
   // 32-lanes-per-env mapping (eight sub-lanes per limb; trunk + limbs instances: CL = 7, so sub-lane s evaluates exactly link group
-  // s - group 0, the lane's share of a trunk link plus the sphere-less trunk bodies parked with it, on sub-lane 0)
+  // s - group 0, the lane's share of a trunk link plus the sphere-less trunk bodies parked with it, on sub-lane 0): at most MAXOWN8
+  // slots per sub-lane (TaskTab::sub8_ok), found by the lane itself from slot_grp[] at kernel start - a table of them would have
+  // pushed the 16-lane mapping's LDS image past the 80 KB that let two workgroups share a CU
   static constexpr int MAXOWN8 = 3;
-  static constexpr int NOWN8 = TP::NW > 0 ? 8 : 1;  // (quadruped instances do not have the mapping: their LDS image stays as it was)
-  int32_t own_slot8[NOWN8][MAXOWN8];
   template <int SUB>
   static constexpr int maxown() { return SUB == 8 ? MAXOWN8 : (SUB == 2 ? MAXOWN2 : MAXOWN); }
 };
@@ -115,6 +115,7 @@ RL_FN int rew_tab_words(int D, int n_bodies, uint64_t ext_mask) { return REW_JS_
 // word offset of body b's row in the body table
 RL_FN int rew_bt_row(uint64_t ext_mask, int b) { return REW_BT_NS * b + REW_BT_NX * popcount64(ext_mask & ((1ull << b) - 1ull)); }
 constexpr int IDX_POOL = 48;
+constexpr int RESET_RAND_WORDS = 160;  // LDS words of an env's table of reset uniforms: Philox blocks 0 .. 39 of stream STREAM_RESET (rl_math.h IDX_*: the last index is IDX_LEVEL = 156)
 
 struct ObsTab {
   int32_t kind;
@@ -265,8 +266,6 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
       for (int i = 0; i < LaneTabT<TP>::MAXOWN; ++i) b.own_slot[q][i] = a.own_slot[q][i];
     for (int q = 0; q < 2; ++q)
       for (int i = 0; i < LaneTabT<TP>::MAXOWN2; ++i) b.own_slot2[q][i] = a.own_slot2[q][i];
-    for (int q = 0; q < LaneTabT<TP>::NOWN8; ++q)
-      for (int i = 0; i < LaneTabT<TP>::MAXOWN8; ++i) b.own_slot8[q][i] = a.own_slot8[q][i];
   }
 }
 

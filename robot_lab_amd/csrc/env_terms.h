@@ -391,16 +391,18 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   }
 
   // UniformVelocityCommand._resample_command [UPSTREAM B7] + threshold (VEL/mdp/commands.py:43-47)
-  RL_FN void resample_command(uint32_t stream, uint32_t idx) {
+  // `RT`: the env's table of this step's STREAM_RESET uniforms (reset_uniforms) when the draws are a reset's, else nullptr
+  RL_FN void resample_command(uint32_t stream, uint32_t idx, const float* RT = nullptr) {
     // ranges: the table's, or the live ones of the command_levels_* curricula (VEL/mdp/curriculums.py:21-94)
     const float* lv = S.cmd_levels;
     const bool cl = T.cur_lin != 0, ca = T.cur_ang != 0;
-    float vx = U(stream, idx + 0, cl ? lv[CL_LIN_X] : T.cmd_range[0][0], cl ? lv[CL_LIN_X + 1] : T.cmd_range[0][1]);
-    float vy = U(stream, idx + 1, cl ? lv[CL_LIN_Y] : T.cmd_range[1][0], cl ? lv[CL_LIN_Y + 1] : T.cmd_range[1][1]);
-    float wz = U(stream, idx + 2, ca ? lv[CL_ANG_Z] : T.cmd_range[2][0], ca ? lv[CL_ANG_Z + 1] : T.cmd_range[2][1]);
-    float hd = U(stream, idx + 3, T.cmd_range[3][0], T.cmd_range[3][1]);
-    bool ih = U(stream, idx + 4, 0.f, 1.f) <= T.cmd_rel_heading;
-    bool is = U(stream, idx + 5, 0.f, 1.f) <= T.cmd_rel_standing;
+    auto UU = [&](uint32_t i, float lo, float hi) __attribute__((always_inline)) { return RT != nullptr ? lo + (hi - lo) * RT[i] : U(stream, i, lo, hi); };
+    float vx = UU(idx + 0, cl ? lv[CL_LIN_X] : T.cmd_range[0][0], cl ? lv[CL_LIN_X + 1] : T.cmd_range[0][1]);
+    float vy = UU(idx + 1, cl ? lv[CL_LIN_Y] : T.cmd_range[1][0], cl ? lv[CL_LIN_Y + 1] : T.cmd_range[1][1]);
+    float wz = UU(idx + 2, ca ? lv[CL_ANG_Z] : T.cmd_range[2][0], ca ? lv[CL_ANG_Z + 1] : T.cmd_range[2][1]);
+    float hd = UU(idx + 3, T.cmd_range[3][0], T.cmd_range[3][1]);
+    bool ih = UU(idx + 4, 0.f, 1.f) <= T.cmd_rel_heading;
+    bool is = UU(idx + 5, 0.f, 1.f) <= T.cmd_rel_standing;
     float keep = fsqrt(vx * vx + vy * vy) > T.cmd_small_threshold ? 1.f : 0.f;
     cmd = {vx * keep, vy * keep, wz};
     if (T.cmd_heading) { heading_target = hd; is_heading = ih; }
@@ -408,7 +410,38 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   }
 
   // ---------------------------------------------------------------- reset of one env (all its lanes) [UPSTREAM B1]
+  // The uniforms a reset draws (stream STREAM_RESET of this env and step; indices IDX_WRENCH .. IDX_LEVEL, < RESET_RAND_WORDS) as a
+  // table in LDS, computed ONCE per env by its lanes together: lane l takes Philox blocks l, l + LPE, ... of the needed ones (the
+  // env-level blocks and ceil(D / 4) blocks per joint stream) and stores their four words; a draw is then `lo + (hi - lo) * RT[index]`.
+  // Same numbers as one uniform_range() per draw (what a lane per limb still does): a Philox4x32-10 block is ~900 cycles of
+  // quarter-rate integer multiplies, a reset evaluated ~20 (A1) / ~50 (G1) of them per lane one after the other - and in steady
+  // state some env of the launch resets on EVERY step, so that tail (8 us on A1 Rough 4096, profiles/r04b_cold_vs_steady.txt) was
+  // part of every step's kernel time: the launch ends with its slowest wavefront.
+  RL_FN const float* reset_uniforms() {
+    if constexpr (SUB == 1) return nullptr;
+    else {
+      float* RT = ctx.rand_tab();
+      const int nb = (ctx.uniform_i(T.D) + 3) >> 2, n_need = 8 + 4 * nb;
+      for (int n = li; n < n_need; n += LPE) {
+        int b = n < 2 ? n : 34 + (n - 2 - 4 * nb);  // blocks 0, 1: wrench; 34 .. 39: pose, velocity, command, timers, level
+        if (n >= 2 && n < 2 + 4 * nb) {              // 2 + 8 s + i: block i of joint stream s (IDX_JPOS, IDX_JVEL, IDX_KP, IDX_KD: 32 indices each)
+          const int m = n - 2, st = (m >= nb ? 1 : 0) + (m >= 2 * nb ? 1 : 0) + (m >= 3 * nb ? 1 : 0);
+          b = 2 + 8 * st + (m - st * nb);
+        }
+        float un[4];
+        uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_RESET, (uint32_t)b, un);
+        RT[4 * b + 0] = un[0]; RT[4 * b + 1] = un[1]; RT[4 * b + 2] = un[2]; RT[4 * b + 3] = un[3];
+      }
+      ctx.group_sync();
+      return RT;
+    }
+  }
+
   RL_FN void reset_env(bool log_episode) {
+    const float* RT = reset_uniforms();
+    auto UR = [&](uint32_t idx, float lo, float hi) __attribute__((always_inline)) {
+      return RT != nullptr ? lo + (hi - lo) * RT[idx] : U(STREAM_RESET, idx, lo, hi);
+    };
     // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671)
     if (T.curriculum && !T.is_plane) {
       float dx = pos.x - origin.x, dy = pos.y - origin.y;
@@ -416,7 +449,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       bool up = dist > T.tile_size * 0.5f;
       bool down = (dist < fsqrt(cmd.x * cmd.x + cmd.y * cmd.y) * T.max_episode_length_s * 0.5f) && !up;
       int lv = level + (up ? 1 : 0) - (down ? 1 : 0);
-      int rnd = (int)fminf(floorf(U(STREAM_RESET, IDX_LEVEL, 0.f, 1.f) * (float)T.num_rows), (float)(T.num_rows - 1));
+      int rnd = (int)fminf(floorf(UR(IDX_LEVEL, 0.f, 1.f) * (float)T.num_rows), (float)(T.num_rows - 1));
       level = lv >= T.num_rows ? rnd : (lv < 0 ? 0 : lv);
       const float* o = S.terrain_origins + ((size_t)level * T.num_cols + ttype) * 3;
       origin = {o[0], o[1], o[2]};
@@ -434,24 +467,24 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     extT = {0.f, 0.f, 0.f};
     // reset events in declaration order (velocity_env_cfg.py:316-363)
     if (T.ev_wrench) {
-      extF = {U(STREAM_RESET, IDX_WRENCH + 0, T.wrench_force[0], T.wrench_force[1]), U(STREAM_RESET, IDX_WRENCH + 1, T.wrench_force[0], T.wrench_force[1]),
-              U(STREAM_RESET, IDX_WRENCH + 2, T.wrench_force[0], T.wrench_force[1])};
-      extT = {U(STREAM_RESET, IDX_WRENCH + 3, T.wrench_torque[0], T.wrench_torque[1]), U(STREAM_RESET, IDX_WRENCH + 4, T.wrench_torque[0], T.wrench_torque[1]),
-              U(STREAM_RESET, IDX_WRENCH + 5, T.wrench_torque[0], T.wrench_torque[1])};
+      extF = {UR(IDX_WRENCH + 0, T.wrench_force[0], T.wrench_force[1]), UR(IDX_WRENCH + 1, T.wrench_force[0], T.wrench_force[1]),
+              UR(IDX_WRENCH + 2, T.wrench_force[0], T.wrench_force[1])};
+      extT = {UR(IDX_WRENCH + 3, T.wrench_torque[0], T.wrench_torque[1]), UR(IDX_WRENCH + 4, T.wrench_torque[0], T.wrench_torque[1]),
+              UR(IDX_WRENCH + 5, T.wrench_torque[0], T.wrench_torque[1])};
     }
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       uint32_t ji = (uint32_t)((NW > 0 && L.joint_id[j] < 0) ? 0 : L.joint_id[j]);  // padding joints: q0 = qd0 = kp0 = kd0 = 0
       float qn = L.q0[j], qdn = L.qd0[j];
       if (T.ev_reset_joints) {  // reset_joints_by_scale [UPSTREAM B8]
-        qn = clampf(L.q0[j] * U(STREAM_RESET, IDX_JPOS + ji, T.reset_jpos[0], T.reset_jpos[1]), L.soft_lo[j], L.soft_hi[j]);
-        qdn = clampf(L.qd0[j] * U(STREAM_RESET, IDX_JVEL + ji, T.reset_jvel[0], T.reset_jvel[1]), -L.vel_limit[j], L.vel_limit[j]);
+        qn = clampf(L.q0[j] * UR(IDX_JPOS + ji, T.reset_jpos[0], T.reset_jpos[1]), L.soft_lo[j], L.soft_hi[j]);
+        qdn = clampf(L.qd0[j] * UR(IDX_JVEL + ji, T.reset_jvel[0], T.reset_jvel[1]), -L.vel_limit[j], L.vel_limit[j]);
       }
       q[j] = qn;
       qd[j] = qdn;
       if (T.ev_gains) {  // randomize_actuator_gains(operation="scale") [UPSTREAM B4]
-        kp[j] = L.kp0[j] * U(STREAM_RESET, IDX_KP + ji, T.gain_kp[0], T.gain_kp[1]);
-        kd[j] = L.kd0[j] * U(STREAM_RESET, IDX_KD + ji, T.gain_kd[0], T.gain_kd[1]);
+        kp[j] = L.kp0[j] * UR(IDX_KP + ji, T.gain_kp[0], T.gain_kp[1]);
+        kd[j] = L.kd0[j] * UR(IDX_KD + ji, T.gain_kd[0], T.gain_kd[1]);
       }
       act[j] = 0.f;
       prev_act[j] = 0.f;
@@ -462,8 +495,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       float ps[6], vs[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        ps[a] = T.ev_reset_base ? U(STREAM_RESET, IDX_POSE + a, T.reset_pose[a][0], T.reset_pose[a][1]) : 0.f;
-        vs[a] = T.ev_reset_base ? U(STREAM_RESET, IDX_VEL + a, T.reset_vel[a][0], T.reset_vel[a][1]) : 0.f;
+        ps[a] = T.ev_reset_base ? UR(IDX_POSE + a, T.reset_pose[a][0], T.reset_pose[a][1]) : 0.f;
+        vs[a] = T.ev_reset_base ? UR(IDX_VEL + a, T.reset_vel[a][0], T.reset_vel[a][1]) : 0.f;
       }
       pos = V3{T.default_root_pos[0], T.default_root_pos[1], T.default_root_pos[2]} + origin + V3{ps[0], ps[1], ps[2]};
       Q4 q0{T.default_root_quat[0], T.default_root_quat[1], T.default_root_quat[2], T.default_root_quat[3]};
@@ -486,9 +519,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     metric_xy = 0.f;
     metric_yaw = 0.f;
-    cmd_time_left = U(STREAM_RESET, IDX_CMD_TIME, T.cmd_resample[0], T.cmd_resample[1]);
-    resample_command(STREAM_RESET, IDX_CMD);
-    if (T.ev_push) push_left = U(STREAM_RESET, IDX_PUSH_TIME, T.push_interval[0], T.push_interval[1]);
+    cmd_time_left = UR(IDX_CMD_TIME, T.cmd_resample[0], T.cmd_resample[1]);
+    resample_command(STREAM_RESET, IDX_CMD, RT);
+    if (T.ev_push) push_left = UR(IDX_PUSH_TIME, T.push_interval[0], T.push_interval[1]);
     ep_len = 0;
   }
 

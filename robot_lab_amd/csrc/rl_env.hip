@@ -108,7 +108,7 @@ struct Backend {
         const size_t tb = staged_bytes(T);
         const double slots4 = (double)n_cu * (double)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / n4));
         const double slots8 = (double)n_cu * (double)((tb + 4 * (n8 - tb) <= 160 * 1024) ? 4 : std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / n8)));
-        double cost8 = 0.80;
+        double cost8 = 0.93;  // G1 Rough, one call: 143 us per round of 512 wavefronts (2048 envs) against 125 - 135 us per round of 1024 (2048 envs): profiles/r04b_g1_sweep.txt
         if (const char* c = std::getenv("RL_ENV_COST8")) cost8 = atof(c);
         const double t4 = std::ceil((double)(Npad / 4) / slots4), t8 = cost8 * std::ceil((double)(Npad / 2) / slots8);
         if (t8 < t4) sub = 8;
@@ -154,6 +154,7 @@ struct Backend {
     if (s0w + s1w < need) s1w = need - s0w;
     int region = s0w + s1w + Ctx::EPT * feat_count(T.D);
     region = std::max(region, Ctx::EPT * rew_tab_words(T.D, T.n_bodies, T.rew_ext_mask));
+    if (SUB > 1) region = std::max(region, Ctx::EPT * RESET_RAND_WORDS);
     constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
     constexpr int LB_FREE = TP::NW > 0 ? (LbLayout<TP>::WORDS - LbLayout<TP>::REC) * Ctx::LB_STRIDE : 0;
     const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;

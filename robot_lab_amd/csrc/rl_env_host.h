@@ -324,14 +324,11 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   T.sub8_ok = NW > 0 && !merge ? 1 : 0;
   for (int k = 0; k < NLANE; ++k) {
     LaneTab& L = T.lane[k];
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 8; ++q) {  // (the lanes find their slots themselves, by the same rule: env_step.h EnvLane constructor)
       int n = 0;
-      for (int i = 0; i < LaneTab::MAXOWN8; ++i) L.own_slot8[q][i] = -1;
       for (int sl = 0; sl < NBS && NW > 0; ++sl) {
         const bool used = L.slot_body[sl] >= 0 || (sl == 0 && L.base_body_local >= 0);
-        if (!used || L.slot_grp[sl] % 8 != q) continue;
-        if (n >= LaneTab::MAXOWN8) { T.sub8_ok = 0; break; }
-        L.own_slot8[q][n++] = sl;
+        if (used && L.slot_grp[sl] % 8 == q && ++n > LaneTab::MAXOWN8) T.sub8_ok = 0;
       }
     }
   }

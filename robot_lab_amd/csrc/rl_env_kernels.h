@@ -146,6 +146,7 @@ struct WaveCtx {
   __device__ float* rew_stage() const { return rstage + env_in_tile() * MAX_T; }
   __device__ float* feat_stage() const { return fstage + env_in_tile() * fdim; }
   __device__ float* rew_tab() const { return stage[0] + env_in_tile() * rtdim; }
+  __device__ float* rand_tab() const { return stage[0] + env_in_tile() * RESET_RAND_WORDS; }  // reset uniforms: between the reward tables' death and the observation rows' birth
   // Ordering point for LDS traffic between the lanes of the WAVEFRONT (its LDS region is its own, whatever the workgroup width - only
   // the table image is shared, and that is read-only after the staging barrier).  A wavefront's LDS
   // instructions execute in issue order, so a later ds_read of any lane sees an earlier ds_write of any lane without a hardware
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   // reward stage | [ observation rows + feature vectors ] = [ reward tables ] (the tables die before the rows are written)
   int region = s0w + s1w + Ctx::EPT * ctx.fdim;
   if (region < Ctx::EPT * ctx.rtdim) s1w += Ctx::EPT * ctx.rtdim - region, region = Ctx::EPT * ctx.rtdim;
+  if (SUB > 1 && region < Ctx::EPT * RESET_RAND_WORDS) s1w += Ctx::EPT * RESET_RAND_WORDS - region, region = Ctx::EPT * RESET_RAND_WORDS;  // ... or the reset uniforms (env_terms.h reset_uniforms)
   // Where they live (same rule as Backend::configure): quadrupeds - on the contact stash of the lane scratchpad, dead once the
   // substeps are over; trunk + limbs instance - on the link-record / elimination words of the limb-shared area, dead likewise
   // (its kinematics words stay: rewards and the scanner pose recompute the chain into them); else behind everything.

@@ -140,6 +140,7 @@ struct alignas(64) Team {
   float lb[rl::NLANE][rl::LbLayout<rl::TopoGR>::WORDS + 1];  // limb-shared words (really shared by the limb's sub-lane threads)
   float envw[rl::LbLayout<rl::TopoGR>::ENV_WORDS + 1];        // env-shared words
   float rtab[rl::REW_JS_ROWS * RL_MAX_DOF + rl::REW_BT_NF * RL_MAX_BODIES];
+  float rand[rl::RESET_RAND_WORDS];
   std::vector<float> stage[2];
   Team() { bar.n = LPE; }
   void barrier(int lane) {
@@ -363,6 +364,7 @@ struct HostCtx {
   float* rew_stage() { return team->rstage; }
   float* feat_stage() { return team->feat; }
   float* rew_tab() { return team->rtab; }
+  float* rand_tab() { return team->rand; }
   void group_sync() { team->barrier(li()); }
   void flush_obs(float* out, int dim, int g) {
     team->barrier(li());
