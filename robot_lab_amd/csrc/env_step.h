@@ -183,6 +183,28 @@ RL_FN void terrain_sample(const Uni& u, const float* __restrict__ hf, float bx, 
 
 RL_FN M3 ld_m3(const float* p) { return M3{{p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}}; }
 
+// Four consecutive, 16-byte aligned words of LDS (the limb-shared records of the trunk + limbs instance): ONE ds_read_b128 /
+// ds_write_b128 on the GPU instead of four ds_read_b32 / ds_write_b32 - a quarter of the LDS instructions of a kernel whose four
+// wavefronts per CU queue on the one LDS pipe (4.2 k LDS instructions per wavefront and step before: profiles/r04a_g1_pmc_sq.txt).
+struct F4 {
+  float x, y, z, w;
+};
+RL_FN F4 ld4(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return {v.x, v.y, v.z, v.w};
+#else
+  return {p[0], p[1], p[2], p[3]};
+#endif
+}
+RL_FN void st4(float* p, F4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  *reinterpret_cast<float4*>(p) = make_float4(v.x, v.y, v.z, v.w);
+#else
+  p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+#endif
+}
+
 // Kinematics in base coordinates: the lane's limb (R, p, ax per joint) and the trunk joints (Rw, pw, axw).
 // Two storage modes behind one accessor interface:
 //   * registers (quadrupeds: 3-4 joints, everything stays in VGPRs);
@@ -212,23 +234,36 @@ struct ChainT<TP, false, STRIDE> {
 
 template <class TP, int STRIDE>
 struct ChainT<TP, true, STRIDE> {
-  static constexpr int CL = TP::CL, NW = TP::NW;
-  static constexpr int WORDS = (CL + NW) * 15;
+  // LIMB-MAJOR: the limb's block is contiguous, a joint is 16 words - [ax.x ax.y ax.z p.x | p.y p.z R00 R01 | R02 R10 R11 R12 | R20 R21 R22 -]
+  // - so that (axis, origin), what the velocity pass, the elimination and the outward pass read, is two 16-byte vectors and a whole
+  // joint four.  (Until round 4 word w of limb l sat at b[w * limbs + l]: 15 ds_write_b32 + 6 .. 12 ds_read_b32 per joint and use.)
+  static constexpr int CL = TP::CL, NW = TP::NW, JW = 16;
   float* b;
   RL_FN explicit ChainT(float* base) : b(base) {}
-  RL_FN float w(int i) const { return b[i * STRIDE]; }
-  RL_FN V3 v3(int o) const { return {w(o), w(o + 1), w(o + 2)}; }
-  RL_FN M3 m3(int o) const { return M3{v3(o), v3(o + 3), v3(o + 6)}; }
-  RL_FN void put3(int o, V3 v) { b[o * STRIDE] = v.x; b[(o + 1) * STRIDE] = v.y; b[(o + 2) * STRIDE] = v.z; }
-  RL_FN void putj(int o, const M3& R, V3 p, V3 ax) { put3(o, R.r0); put3(o + 3, R.r1); put3(o + 6, R.r2); put3(o + 9, p); put3(o + 12, ax); }
-  RL_FN M3 R(int j) const { return m3(j * 15); }
-  RL_FN V3 p(int j) const { return v3(j * 15 + 9); }
-  RL_FN V3 ax(int j) const { return v3(j * 15 + 12); }
-  RL_FN M3 Rw(int i) const { return m3((CL + i) * 15); }
-  RL_FN V3 pw(int i) const { return v3((CL + i) * 15 + 9); }
-  RL_FN V3 axw(int i) const { return v3((CL + i) * 15 + 12); }
-  RL_FN void set(int j, const M3& R, V3 p, V3 ax) { putj(j * 15, R, p, ax); }
-  RL_FN void setw(int i, const M3& R, V3 p, V3 ax) { putj((CL + i) * 15, R, p, ax); }
+  RL_FN void axp(int slot, V3& ax, V3& p) const {
+    const F4 a = ld4(b + slot * JW), c = ld4(b + slot * JW + 4);
+    ax = {a.x, a.y, a.z};
+    p = {a.w, c.x, c.y};
+  }
+  RL_FN void frame(int slot, M3& R, V3& p) const {
+    const F4 a = ld4(b + slot * JW), c = ld4(b + slot * JW + 4), d = ld4(b + slot * JW + 8), e = ld4(b + slot * JW + 12);
+    R = M3{{c.z, c.w, d.x}, {d.y, d.z, d.w}, {e.x, e.y, e.z}};
+    p = {a.w, c.x, c.y};
+  }
+  RL_FN void put(int slot, const M3& R, V3 p, V3 ax) {
+    st4(b + slot * JW, F4{ax.x, ax.y, ax.z, p.x});
+    st4(b + slot * JW + 4, F4{p.y, p.z, R.r0.x, R.r0.y});
+    st4(b + slot * JW + 8, F4{R.r0.z, R.r1.x, R.r1.y, R.r1.z});
+    st4(b + slot * JW + 12, F4{R.r2.x, R.r2.y, R.r2.z, 0.f});
+  }
+  RL_FN M3 R(int j) const { M3 r; V3 q; frame(j, r, q); return r; }
+  RL_FN V3 p(int j) const { V3 a, q; axp(j, a, q); return q; }
+  RL_FN V3 ax(int j) const { V3 a, q; axp(j, a, q); return a; }
+  RL_FN M3 Rw(int i) const { return R(CL + i); }
+  RL_FN V3 pw(int i) const { return p(CL + i); }
+  RL_FN V3 axw(int i) const { return ax(CL + i); }
+  RL_FN void set(int j, const M3& R, V3 p, V3 ax) { put(j, R, p, ax); }
+  RL_FN void setw(int i, const M3& R, V3 p, V3 ax) { put(CL + i, R, p, ax); }
 };
 
 // Closest points of the segments a0-a1 and b0-b1 (Ericson, Real-Time Collision Detection 5.1.9), branch-free: the same case order
@@ -391,11 +426,16 @@ struct LsMat {
 // accumulator per trunk link (base, waist links, torso) that the limbs and the trunk links' owners ds_add into, and 8 words per
 // self-collision capsule (centre, half axis, radius, bounding radius in base coordinates: EnvLane::self_place).
 constexpr int LINK_REC = 27;  // 21 (6 x 6 symmetric) + 6
+constexpr int REC_STRIDE = 28; // ... stored as seven 16-byte vectors
+// a limb's block padded to 4 (mod 32) words: the blocks of the 8 / 16 limbs of a wavefront then start in different banks (b32: 32 banks,
+// b128: 64), so that the same word of every limb - what a wavefront instruction touches - is conflict free
+constexpr int pad_limb_block(int w) { return ((w - 4 + 31) / 32) * 32 + 4; }
 template <class TP>
 struct LbLayout {
-  enum { CHAIN = 0, REC = TP::JX * 15, VA = REC + (TP::CL + 1) * LINK_REC, WORDS = TP::NW > 0 ? VA + TP::CL * 12 : 0,
-         AUX_WORDS = 0,
-         ENV_WORDS = TP::NW > 0 ? (TP::NW + 1) * LINK_REC + SELF_CAPS * SELF_CAP_WORDS : 0 };  // trunk accumulators | placed self-collision capsules
+  enum { JW = 16, CHAINW = TP::NW > 0 ? pad_limb_block(TP::JX * JW) : 0,          // the limb's kinematics: one block per limb, all limbs' blocks together
+         REC = 0, VA = TP::CL * REC_STRIDE, RECW = TP::NW > 0 ? pad_limb_block(TP::CL * REC_STRIDE + TP::CL * 12) : 0,  // records of links 1 .. CL | per-joint words
+         WORDS = CHAINW + RECW, AUX_WORDS = 0,
+         ENV_WORDS = TP::NW > 0 ? (TP::NW + 1) * REC_STRIDE + SELF_CAPS * SELF_CAP_WORDS : 0 };  // trunk accumulators | placed self-collision capsules
 };
 
 // STASH > 0: room for the contacts of one link group (x, n, bias, d_n, d_t per sphere slot) so that the sensor
@@ -431,9 +471,8 @@ struct EnvLane {
   // VGPRs (hipcc otherwise spills ~3.5 KB per lane to scratch: 0.9 GB of HBM traffic per step at 2048 envs)
   static constexpr Layout LY{CL, NW, NBS};  // field rows of this instance's HBM tiles
   static constexpr bool LDSU = TP::NW > 0;
-  static constexpr int LBS = Ctx::LB_STRIDE;
-  using ChainTP = ChainT<TP, LDSU, LBS>;
-  enum { LB_CHAIN = LbLayout<TP>::CHAIN, LB_REC = LbLayout<TP>::REC, LB_VA = LbLayout<TP>::VA, LB_WORDS = LbLayout<TP>::WORDS };
+  using ChainTP = ChainT<TP, LDSU, 1>;
+  enum { LB_REC = LbLayout<TP>::REC, LB_VA = LbLayout<TP>::VA };
   RL_FN void kinematics(ChainTP& C) {
 #ifndef RL_KIN_REPLICATED  // (A/B switch: every sub-lane computes every joint transform)
     if constexpr (NW > 0 && SUB > 1) {
@@ -443,7 +482,7 @@ struct EnvLane {
 #endif
     chain_kinematics<TP>(L, q, C);
   }
-  RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_scratch() + LB_CHAIN * LBS : nullptr); }
+  RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_chain() : nullptr); }
 
   Ctx& ctx;
   const KState& S;
@@ -1150,9 +1189,29 @@ struct EnvLane {
   // link records and the per-joint elimination results live in limb-shared LDS words (the 4 sub-lanes of a limb hold identical
   // values: same word, a broadcast), and the limbs meet in 27-word per-trunk-link accumulators of the ENV (ds_add_f32), which
   // every lane then reads to eliminate the trunk joints and solve the 6 x 6 base system redundantly.
-  RL_FN float* rec_words(int g) const { return ctx.limb_scratch() + (LB_REC + g * LINK_REC) * LBS; }
-  RL_FN float* va_words(int j) const { return ctx.limb_scratch() + (LB_VA + j * 12) * LBS; }
-  RL_FN float* trunk_words(int d) const { return ctx.env_scratch() + d * LINK_REC; }
+  RL_FN float* rec_words(int g) const { return ctx.limb_rec() + LB_REC + (g - 1) * REC_STRIDE; }  // link group g = limb link g - 1 (1 .. CL)
+  RL_FN float* va_words(int j) const { return ctx.limb_rec() + LB_VA + j * 12; }
+  RL_FN float* trunk_words(int d) const { return ctx.env_scratch() + d * REC_STRIDE; }
+  // a link record <-> its seven vectors
+  RL_FN static void st_rec(float* w, const LinkRec& r) {
+#pragma unroll
+    for (int v = 0; v < 5; ++v) st4(w + 4 * v, F4{r.A[4 * v], r.A[4 * v + 1], r.A[4 * v + 2], r.A[4 * v + 3]});
+    st4(w + 20, F4{r.A[20], r.r[0], r.r[1], r.r[2]});
+    st4(w + 24, F4{r.r[3], r.r[4], r.r[5], 0.f});
+  }
+  RL_FN static void add_rec(const float* w, LinkRec& P) {
+    F4 v[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] = ld4(w + 4 * i);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { P.A[4 * i] += v[i].x; P.A[4 * i + 1] += v[i].y; P.A[4 * i + 2] += v[i].z; P.A[4 * i + 3] += v[i].w; }
+    P.A[20] += v[5].x; P.r[0] += v[5].y; P.r[1] += v[5].z; P.r[2] += v[5].w;
+    P.r[3] += v[6].x; P.r[4] += v[6].y; P.r[5] += v[6].z;
+  }
+  RL_FN static SV ld_sv(const float* w) {  // six words, the first two vectors of a record / per-joint block
+    const F4 a = ld4(w), c = ld4(w + 4);
+    return SV{{a.x, a.y, a.z}, {a.w, c.x, c.y}};
+  }
 
   // ------------------------------------------------------------------ self-collision (trunk + limbs instance)
   // enabled_self_collisions of the reference's ArticulationCfg (assets/unitree.py:482 G1, assets/roboparty.py:33 ATOM01): up to 16
@@ -1164,7 +1223,7 @@ struct EnvLane {
   static constexpr int SELF_V = SUB >= 4 ? 1 : 4 / SUB;  // virtual lanes this lane plays: v = 4 k + sub + SUB * i (eight sub-lanes per limb: the first four play one each)
   SelfLaneTab self_tab[NW > 0 ? SELF_V : 1];
   RL_FN bool self_on() const { return NW > 0 && S.self_k > 0.f; }
-  RL_FN float* cap_words(int c) const { return ctx.env_scratch() + (NW + 1) * LINK_REC + c * SELF_CAP_WORDS; }
+  RL_FN float* cap_words(int c) const { return ctx.env_scratch() + (NW + 1) * REC_STRIDE + c * SELF_CAP_WORDS; }
   RL_FN void self_load() {  // once per launch: this lane's share of the dealing, from the table image in HBM into registers
     if constexpr (NW > 0) {
       if (!self_on()) return;
@@ -1188,21 +1247,21 @@ struct EnvLane {
         if (t.cap < 0) continue;
         M3 Rf = identity3();
         V3 pf{0.f, 0.f, 0.f};
-        if (t.frame >= 0) { Rf = C.m3(t.frame * 15); pf = C.v3(t.frame * 15 + 9); }
+        if (t.frame >= 0) C.frame(t.frame, Rf, pf);
         const V3 p0 = pf + mul(Rf, ld3(t.p0)), p1 = pf + mul(Rf, ld3(t.p1));
         const V3 c = 0.5f * (p0 + p1), h = 0.5f * (p1 - p0);
         float* w = cap_words(t.cap);  // centre, half axis, radius, radius of the bounding sphere
-        w[0] = c.x; w[1] = c.y; w[2] = c.z; w[3] = h.x; w[4] = h.y; w[5] = h.z; w[6] = t.r; w[7] = t.r + fsqrt(dot(h, h));
+        st4(w, F4{c.x, c.y, c.z, h.x});
+        st4(w + 4, F4{h.y, h.z, t.r, t.r + fsqrt(dot(h, h))});
       }
     }
   }
   RL_FN void self_add(int kk, int gg, V3 x, V3 F) {  // dt * [x cross F; F] onto the bias of a link record (limb kk's group gg; kk = 7: trunk depth gg)
     const V3 m = u.dt * cross(x, F), f = u.dt * F;
     const float v6[6] = {m.x, m.y, m.z, f.x, f.y, f.z};
-    float* w = kk == 7 ? trunk_words(gg) + B6::size : ctx.limb_scratch_of(kk) + (LB_REC + gg * LINK_REC + B6::size) * LBS;
-    const int stride = kk == 7 ? 1 : LBS;
+    float* w = (kk == 7 ? trunk_words(gg) : ctx.limb_rec_of(kk) + LB_REC + (gg - 1) * REC_STRIDE) + B6::size;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + i * stride, v6[i]);
+    for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + i, v6[i]);
   }
   RL_FN void self_apply() {
     if constexpr (NW > 0) {
@@ -1218,8 +1277,9 @@ struct EnvLane {
           const int wd = self_tab[i].pair[p];
           const float* wa = cap_words(wd >= 0 ? (wd & 15) : 0);
           const float* wb = cap_words(wd >= 0 ? ((wd >> 4) & 15) : 0);
-          const V3 dc = V3{wa[0], wa[1], wa[2]} - V3{wb[0], wb[1], wb[2]};
-          const float rb = wa[7] + wb[7];
+          const F4 a0 = ld4(wa), a1 = ld4(wa + 4), b0 = ld4(wb), b1 = ld4(wb + 4);
+          const V3 dc = V3{a0.x, a0.y, a0.z} - V3{b0.x, b0.y, b0.z};
+          const float rb = a1.w + b1.w;
           near[i * SELF_PPL + p] = wd >= 0 && dot(dc, dc) < rb * rb;
         }
 #pragma unroll
@@ -1230,11 +1290,12 @@ struct EnvLane {
           const int wd = self_tab[i].pair[p];
           const float* wa = cap_words(wd >= 0 ? (wd & 15) : 0);
           const float* wb = cap_words(wd >= 0 ? ((wd >> 4) & 15) : 0);
-          const V3 ca{wa[0], wa[1], wa[2]}, cb{wb[0], wb[1], wb[2]}, ha{wa[3], wa[4], wa[5]}, hb{wb[3], wb[4], wb[5]};
+          const F4 a0 = ld4(wa), a1 = ld4(wa + 4), b0 = ld4(wb), b1 = ld4(wb + 4);
+          const V3 ca{a0.x, a0.y, a0.z}, cb{b0.x, b0.y, b0.z}, ha{a0.w, a1.x, a1.y}, hb{b0.w, b1.x, b1.y};
           V3 xa, xb;
           segment_closest(ca - ha, ca + ha, cb - hb, cb + hb, xa, xb);
           const V3 dv = xa - xb;
-          const float d2 = dot(dv, dv), rr = wa[6] + wb[6];
+          const float d2 = dot(dv, dv), rr = a1.z + b1.z;
           const bool hit = near[i * SELF_PPL + p] && d2 < rr * rr;
           if (!ctx.any(hit)) continue;  // the usual case: nothing of this trip touches anywhere in the wavefront
           if (hit) {
@@ -1315,7 +1376,9 @@ struct EnvLane {
       SV Vp = V0, ap = a0;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
-        Sw[i] = SV{C.axw(i), cross(C.pw(i), C.axw(i))};
+        V3 axi, pi;
+        C.axp(CL + i, axi, pi);
+        Sw[i] = SV{axi, cross(pi, axi)};
         const SV vj = Sw[i] * qd[CL + i];
         Vw[i] = Vp + vj;
         aw[i] = ap + crm(Vw[i], vj);
@@ -1331,18 +1394,20 @@ struct EnvLane {
         if (L.attach == i + 1) { Vp = Vw[i]; ap = aw[i]; }
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
-        const V3 ax = C.ax(j);
-        const SV Sj{ax, cross(C.p(j), ax)};
+        V3 ax, pj;
+        C.axp(j, ax, pj);
+        const SV Sj{ax, cross(pj, ax)};
         const SV vj = Sj * qd[j];
         const SV Vj = Vp + vj;
         const SV aj = ap + crm(Vj, vj);
         float* w = va_words(j);
-        w[0 * LBS] = Vj.a.x; w[1 * LBS] = Vj.a.y; w[2 * LBS] = Vj.a.z; w[3 * LBS] = Vj.l.x; w[4 * LBS] = Vj.l.y; w[5 * LBS] = Vj.l.z;
-        w[6 * LBS] = aj.a.x; w[7 * LBS] = aj.a.y; w[8 * LBS] = aj.a.z; w[9 * LBS] = aj.l.x; w[10 * LBS] = aj.l.y; w[11 * LBS] = aj.l.z;
+        st4(w, F4{Vj.a.x, Vj.a.y, Vj.a.z, Vj.l.x});
+        st4(w + 4, F4{Vj.l.y, Vj.l.z, aj.a.x, aj.a.y});
+        st4(w + 8, F4{aj.a.z, aj.l.x, aj.l.y, aj.l.z});
         Vp = Vj;
         ap = aj;
       }
-      for (int i = li; i < (NW + 1) * LINK_REC; i += LPE) ctx.env_scratch()[i] = 0.f;
+      for (int i = li; i < (NW + 1) * REC_STRIDE; i += LPE) ctx.env_scratch()[i] = 0.f;
     }
     ctx.group_sync();
     // ---- per link group this lane owns: contacts + rigid record -> the limb's record words (group 0 = the lane's share of a
@@ -1367,8 +1432,9 @@ struct EnvLane {
         const int lc = has ? l : 0;
         const M3 Rl = C.R(lc);
         const float* w = va_words(lc);
-        const SV Vl{{w[0 * LBS], w[1 * LBS], w[2 * LBS]}, {w[3 * LBS], w[4 * LBS], w[5 * LBS]}};
-        const SV al{{w[6 * LBS], w[7 * LBS], w[8 * LBS]}, {w[9 * LBS], w[10 * LBS], w[11 * LBS]}};
+        const F4 w0 = ld4(w), w1 = ld4(w + 4), w2 = ld4(w + 8);
+        const SV Vl{{w0.x, w0.y, w0.z}, {w0.w, w1.x, w1.y}};
+        const SV al{{w1.z, w1.w, w2.x}, {w2.y, w2.z, w2.w}};
         const uint32_t fi = (uint32_t)(LY.LF_INERTIA + lc * INERTIA_NF);
         const float mass = has ? LF(fi) : 0.f;
         const V3 cb = C.p(lc) + mul(Rl, V3{LF(fi + 1), LF(fi + 2), LF(fi + 3)});
@@ -1380,19 +1446,14 @@ struct EnvLane {
       if (fetched) {
         SV Vg = V0;  // twist of the link the group's spheres ride on: limb link l, or the trunk link of the lane's share
         if (has) {
-          const float* w = va_words(l);
-          Vg = SV{{w[0 * LBS], w[1 * LBS], w[2 * LBS]}, {w[3 * LBS], w[4 * LBS], w[5 * LBS]}};
+          Vg = ld_sv(va_words(l));
         } else {
           Vg = pick_trunk(V0, Vw, L.grp0_depth);
         }
         group_contacts<it.value>(Rwb, Vg, gf, rec, active_mask);
       }
       if (has) {
-        float* w = rec_words(g);
-#pragma unroll
-        for (int i = 0; i < B6::size; ++i) w[i * LBS] = rec.A[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w[(B6::size + i) * LBS] = rec.r[i];
+        st_rec(rec_words(g), rec);
       } else if (g == 0 && active_mask != before) {  // contacts of the trunk-link share
         float* w = trunk_words(L.grp0_depth);
 #pragma unroll
@@ -1415,21 +1476,17 @@ struct EnvLane {
     for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
 #pragma unroll
     for (int j = CL - 1; j >= 0; --j) {
-      const float* w = rec_words(j + 1);
-#pragma unroll
-      for (int i = 0; i < B6::size; ++i) P.A[i] += w[i * LBS];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) P.r[i] += w[(B6::size + i) * LBS];
-      const V3 ax = C.ax(j);
-      const V3 lx = cross(C.p(j), ax);
+      add_rec(rec_words(j + 1), P);
+      V3 ax, pj;
+      C.axp(j, ax, pj);
+      const V3 lx = cross(pj, ax);
       const float s6[6] = {ax.x, ax.y, ax.z, lx.x, lx.y, lx.z};
       float D, uu, Uh[6], ui;
       joint_terms(j, j >= L.nj, tau_e, pd_diag, pd_rhs, D, uu);
       eliminate(P, s6, D, uu, Uh, ui);
       float* o = va_words(j);  // (the link velocities parked here are no longer needed)
-#pragma unroll
-      for (int r = 0; r < 6; ++r) o[r * LBS] = Uh[r];
-      o[6 * LBS] = ui;
+      st4(o, F4{Uh[0], Uh[1], Uh[2], Uh[3]});
+      st4(o + 4, F4{Uh[4], Uh[5], ui, 0.f});
     }
     // the limb as seen from its attachment link, and the trunk links' own rigid records, into the env's accumulators
     if (sub == 0) {
@@ -1480,19 +1537,13 @@ struct EnvLane {
     float Uhw[NW][6], uiw[NW];
 #pragma unroll
     for (int d = NW; d >= 1; --d) {
-      const float* w = trunk_words(d);
-#pragma unroll
-      for (int i = 0; i < LINK_REC; ++i) (i < B6::size ? P.A[i] : P.r[i - B6::size]) += w[i];
+      add_rec(trunk_words(d), P);
       const float s6[6] = {Sw[d - 1].a.x, Sw[d - 1].a.y, Sw[d - 1].a.z, Sw[d - 1].l.x, Sw[d - 1].l.y, Sw[d - 1].l.z};
       float D, uu;
       joint_terms(CL + d - 1, d - 1 >= T.nw_used, tau_e, pd_diag, pd_rhs, D, uu);
       eliminate(P, s6, D, uu, Uhw[d - 1], uiw[d - 1]);
     }
-    {
-      const float* w = trunk_words(0);
-#pragma unroll
-      for (int i = 0; i < LINK_REC; ++i) (i < B6::size ? P.A[i] : P.r[i - B6::size]) += w[i];
-    }
+    add_rec(trunk_words(0), P);
     RL_PHASE(11, "sub.trunk_solve");
     float nu0[NB], qdn[JX];
     {
@@ -1529,27 +1580,26 @@ struct EnvLane {
       vc = vca;
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
-        const float* o = va_words(j);
-        float t = o[6 * LBS];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) t -= o[r * LBS] * va[r];
+        const F4 o0 = ld4(va_words(j)), o1 = ld4(va_words(j) + 4);
+        const float t = o1.z - (o0.x * va[0] + o0.y * va[1] + o0.z * va[2] + o0.w * va[3] + o1.x * va[4] + o1.y * va[5]);
         qdn[j] = t;
-        const V3 ax = C.ax(j);
-        const V3 lx = cross(C.p(j), ax);
+        V3 ax, pj;
+        C.axp(j, ax, pj);
+        const V3 lx = cross(pj, ax);
         va[0] += ax.x * t; va[1] += ax.y * t; va[2] += ax.z * t;
         va[3] += lx.x * t; va[4] += lx.y * t; va[5] += lx.z * t;
         const float tc = clampf(t, -L.vel_limit[j], L.vel_limit[j]);
         vc.a += tc * ax; vc.l += tc * lx;
         float* nw = rec_words(j + 1);  // (the record of link j was consumed by the elimination)
-        nw[0 * LBS] = vc.a.x; nw[1 * LBS] = vc.a.y; nw[2 * LBS] = vc.a.z; nw[3 * LBS] = vc.l.x; nw[4 * LBS] = vc.l.y; nw[5 * LBS] = vc.l.z;
+        st4(nw, F4{vc.a.x, vc.a.y, vc.a.z, vc.l.x});
+        st4(nw + 4, F4{vc.l.y, vc.l.z, 0.f, 0.f});
       }
       ctx.group_sync();
       static_for<0, NIT>([&](auto it) {
         const int g = sub + SUB * it.value;
         Vnew[it.value] = vca;  // group 0: the trunk link the limb hangs off (grp0_depth == attach)
         if (g >= 1 && g <= CL) {
-          const float* w = rec_words(g);
-          Vnew[it.value] = SV{{w[0 * LBS], w[1 * LBS], w[2 * LBS]}, {w[3 * LBS], w[4 * LBS], w[5 * LBS]}};
+          Vnew[it.value] = ld_sv(rec_words(g));
         }
       });
     }

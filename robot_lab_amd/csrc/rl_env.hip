@@ -150,16 +150,14 @@ struct Backend {
     using LS = typename LsFor<TP, SUB>::type;
     const int s0w = (SUB == 1 && direct_group(T, 0)) ? 0 : (Ctx::EPT * T.policy_dim + 3) & ~3;
     int s1w = (SUB == 1 && direct_group(T, 1)) ? 0 : (Ctx::EPT * T.critic_dim + 3) & ~3;
-    const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
-    if (s0w + s1w < need) s1w = need - s0w;
     int region = s0w + s1w + Ctx::EPT * feat_count(T.D);
     region = std::max(region, Ctx::EPT * rew_tab_words(T.D, T.n_bodies, T.rew_ext_mask));
     if (SUB > 1) region = std::max(region, Ctx::EPT * RESET_RAND_WORDS);
     constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
-    constexpr int LB_FREE = TP::NW > 0 ? (LbLayout<TP>::WORDS - LbLayout<TP>::REC) * Ctx::LB_STRIDE : 0;
+    constexpr int LB_FREE = TP::NW > 0 ? LbLayout<TP>::RECW * Ctx::LIMBS : 0;
     const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;
     const bool alias_lb = TP::NW > 0 && Ctx::EPT * MAX_T + region <= LB_FREE;
-    size_t words = (size_t)LS::WORDS * 64 + (size_t)LbLayout<TP>::WORDS * Ctx::LB_STRIDE + (size_t)Ctx::EPT * LbLayout<TP>::ENV_WORDS;
+    size_t words = (size_t)LS::WORDS * 64 + (size_t)LbLayout<TP>::WORDS * Ctx::LIMBS + (size_t)Ctx::EPT * LbLayout<TP>::ENV_WORDS;
     if (!alias && !alias_lb) words += (size_t)Ctx::EPT * MAX_T + region;
     return staged_bytes(T) + words * 4;
   }

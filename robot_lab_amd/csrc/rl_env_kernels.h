@@ -41,13 +41,15 @@ template <int SUB_>
 struct WaveCtx {
   static constexpr int LS_STRIDE = 64;
   static constexpr int SUB = SUB_;
-  static constexpr int LB_STRIDE = 64 / SUB_;  // limb-shared words: one per limb of the wavefront
+  static constexpr int LIMBS = 64 / SUB_;      // limbs of the wavefront's envs: limb-shared LDS blocks (trunk + limbs instance)
   static constexpr bool LIMB_ATOMICS = true;   // limb-shared words are real shared LDS: sub-lanes can ds_add into them
   __device__ static void limb_atomic_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   static constexpr int LPE = NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
   float* lscratch;
-  float* lbscratch;
+  float* lbchain;  // this lane's limb: its kinematics block (LbLayout::CHAINW words; the blocks of the wavefront's limbs follow each other)
+  float* lbrec;    // ... and its block of link records / per-joint words (LbLayout::RECW words), behind all the kinematics blocks
+  int lbrec_stride;
   float* envs;  // this env's words shared by all its lanes (trunk + limbs instance: per-trunk-link accumulators)
   const void* T;  // TablesT<TP> staged in LDS
   float* stage[2];
@@ -56,8 +58,9 @@ struct WaveCtx {
   int dim[2], fdim, rtdim;  // rtdim: words of an env's reward tables (they share LDS with the observation rows + features)
   int lane;
   __device__ float* lane_scratch() const { return lscratch + lane; }
-  __device__ float* limb_scratch() const { return lbscratch + lane / SUB; }
-  __device__ float* limb_scratch_of(int k2) const { return lbscratch + (lane / LPE) * 4 + k2; }  // limb k2 of this lane's env
+  __device__ float* limb_chain() const { return lbchain; }
+  __device__ float* limb_rec() const { return lbrec; }
+  __device__ float* limb_rec_of(int k2) const { return lbrec + (k2 - ((lane / SUB) & 3)) * lbrec_stride; }  // limb k2 of this lane's env
   __device__ float* env_scratch() const { return envs; }
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
@@ -240,16 +243,17 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   // (one lane per limb: a group without noise has no staging row - env_terms.h write_group<DIRECT>)
   const int s0w = (SUB == 1 && direct_group(*Tl, 0)) ? 0 : (Ctx::EPT * ctx.dim[0] + 3) & ~3;
   int s1w = (SUB == 1 && direct_group(*Tl, 1)) ? 0 : (Ctx::EPT * ctx.dim[1] + 3) & ~3;
-  {  // the staging rows double as limb-shared scratch inside the substeps (streaming CRBA): at least that big
-    const int need = LbLayout<TP>::AUX_WORDS * Ctx::LB_STRIDE;
-    if (s0w + s1w < need) s1w = need - s0w;
-  }
   ctx.lscratch = smem + TAB_F + (WGW > 1 ? wv * wave_words : 0u);  // wave_words: LDS words of one wavefront behind the shared tables
   ctx.wtile = (int)blockIdx.x * WGW + wv;
   if (WGW > 1 && ctx.wtile >= S.Npad / Ctx::EPT) return;
-  ctx.lbscratch = ctx.lscratch + LS::WORDS * 64;
-  ctx.envs = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + (lane / Ctx::LPE) * LbLayout<TP>::ENV_WORDS;
-  float* tail = ctx.lbscratch + LbLayout<TP>::WORDS * Ctx::LB_STRIDE + Ctx::EPT * LbLayout<TP>::ENV_WORDS;
+  // limb-shared words (trunk + limbs instance): [kinematics block of every limb] [record block of every limb] [env words of every env]
+  float* lb0 = ctx.lscratch + LS::WORDS * 64;
+  float* lbrec0 = lb0 + LbLayout<TP>::CHAINW * Ctx::LIMBS;
+  ctx.lbchain = lb0 + (lane / SUB) * LbLayout<TP>::CHAINW;
+  ctx.lbrec = lbrec0 + (lane / SUB) * LbLayout<TP>::RECW;
+  ctx.lbrec_stride = LbLayout<TP>::RECW;
+  ctx.envs = lb0 + LbLayout<TP>::WORDS * Ctx::LIMBS + (lane / Ctx::LPE) * LbLayout<TP>::ENV_WORDS;
+  float* tail = lb0 + LbLayout<TP>::WORDS * Ctx::LIMBS + Ctx::EPT * LbLayout<TP>::ENV_WORDS;
   // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
   ctx.fdim = feat_count(Tl->D);
   ctx.rtdim = rew_tab_words(Tl->D, Tl->n_bodies, Tl->rew_ext_mask);
@@ -260,10 +264,10 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   // Where they live (same rule as Backend::configure): quadrupeds - on the contact stash of the lane scratchpad, dead once the
   // substeps are over; trunk + limbs instance - on the link-record / elimination words of the limb-shared area, dead likewise
   // (its kinematics words stay: rewards and the scanner pose recompute the chain into them); else behind everything.
-  constexpr int LB_FREE = TP::NW > 0 ? (LbLayout<TP>::WORDS - LbLayout<TP>::REC) * Ctx::LB_STRIDE : 0;
+  constexpr int LB_FREE = TP::NW > 0 ? LbLayout<TP>::RECW * Ctx::LIMBS : 0;  // the record blocks of all limbs: one contiguous region
   const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;
   const bool alias_lb = TP::NW > 0 && Ctx::EPT * MAX_T + region <= LB_FREE;
-  float* base = alias ? ctx.lscratch + LS::CT * 64 : (alias_lb ? ctx.lbscratch + LbLayout<TP>::REC * Ctx::LB_STRIDE : tail);
+  float* base = alias ? ctx.lscratch + LS::CT * 64 : (alias_lb ? lbrec0 : tail);
   ctx.rstage = base;
   ctx.stage[0] = base + Ctx::EPT * MAX_T;
   ctx.stage[1] = ctx.stage[0] + s0w;

@@ -137,8 +137,9 @@ struct alignas(64) Team {
   float slot9[LPE][9];
   float rstage[rl::MAX_T];
   float feat[rl::feat_count(rl::TopoMax::DMAX)];
-  float lb[rl::NLANE][rl::LbLayout<rl::TopoGR>::WORDS + 1];  // limb-shared words (really shared by the limb's sub-lane threads)
-  float envw[rl::LbLayout<rl::TopoGR>::ENV_WORDS + 1];        // env-shared words
+  alignas(16) float lbchain[rl::NLANE][rl::LbLayout<rl::TopoGR>::CHAINW + 4];  // limb-shared words (really shared by the limb's sub-lane threads): kinematics
+  alignas(16) float lbrec[rl::NLANE][rl::LbLayout<rl::TopoGR>::RECW + 4];      // ... link records and per-joint words
+  alignas(16) float envw[rl::LbLayout<rl::TopoGR>::ENV_WORDS + 4];             // env-shared words
   float rtab[rl::REW_JS_ROWS * RL_MAX_DOF + rl::REW_BT_NF * RL_MAX_BODIES];
   float rand[rl::RESET_RAND_WORDS];
   std::vector<float> stage[2];
@@ -251,14 +252,14 @@ struct HostCtx {
     *p += v;
     lock.clear(std::memory_order_release);
   }
-  static constexpr int LB_STRIDE = 1;  // "limb-shared" words are private per lane thread here (the sub-lanes hold identical values)
   static constexpr int SUB = SUB_;
   static constexpr int LPE = rl::NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
   float scratch[rl::LsLayout<rl::MAX_NBS, rl::MAX_SPL>::WORDS];
   float* lane_scratch() { return scratch; }
-  float* limb_scratch() { return team->lb[k_]; }
-  float* limb_scratch_of(int k2) { return team->lb[k2]; }
+  float* limb_chain() { return team->lbchain[k_]; }
+  float* limb_rec() { return team->lbrec[k_]; }
+  float* limb_rec_of(int k2) { return team->lbrec[k2]; }
   float* env_scratch() { return team->envw; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
