@@ -1,6 +1,7 @@
 """`-m gpu`: the lane mapping `rl_env_create` picks from the launch size (csrc/rl_env.hip envs_per_wave): three mappings of the one lane
 program - 16, 8 or 4 lanes per env (4, 8 or 16 envs per wavefront) - chosen by rounds x cost; `RL_ENV_SUB` forces one; the trunk + limbs
-instance has the 16-lane mapping only.  The mappings themselves are held to the oracle at full size by tests/test_gpu_teacher_forced.py
+instances have a 16- and a 32-lane mapping (4 or 2 envs per wavefront) and take the 32-lane one at every size (same envs per round,
+shorter round: profiles/r04b_g1_sweep.txt).  The mappings themselves are held to the oracle at full size by tests/test_gpu_teacher_forced.py
 ("sub1" / "sub2" configs) and to bit-equality across workgroup shapes by tests/test_gpu_canary.py; here: the choice, and that the three
 mappings agree with each other to fp32 round-off on the first steps (they differ by the order of the cross-limb sums only)."""
 import numpy as np
@@ -11,7 +12,7 @@ A1 = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
 
 
 @pytest.mark.parametrize("task,N,want", [(A1, 4096, 4), (A1, 8192, 8), (A1, 16384, 16), (A1, 24576, 8), (A1, 65536, 16),
-                                         ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 8192, 4)])
+                                         ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 8192, 2), ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 256, 2)])
 def test_mapping_chosen_from_launch_size(task, N, want, monkeypatch):
     from robot_lab_amd.env import ManagerBasedRLEnv
 
