@@ -172,6 +172,11 @@ typedef struct rl_model_desc {
   float capsule_radius[RL_MAX_CAPSULES];
   int32_t num_self_pairs;
   int32_t self_pair[RL_MAX_SELF_PAIRS][2]; /* capsule indices a < b */
+  /* Collision spheres of a trunk link are evaluated by the lanes whose "link group 0" rides on that link - by default the lanes of the
+     limbs that hang off it (chain_attach).  A spine link nothing hangs off (FFTAI GR1: the head, behind the torso the arms leave from)
+     gets the group 0 of a lane that shares its own attachment link with another lane: chain_grp0[k] = 1 + trunk depth of the link
+     chain k's group 0 rides on, 0 = the default (the chain's attachment link). */
+  int32_t chain_grp0[4];
 } rl_model_desc;
 
 /* ---- simulator constants (ours; the reference delegates these to PhysX) ------------------ */

@@ -295,8 +295,14 @@ RL_FN void trunk_frame(const CT& C, int depth, M3& Rf, V3& pf) {
     if (depth == i + 1) { Rf = C.Rw(i); pf = C.pw(i); }
 }
 
-template <class TP, class CT>
-RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C) {
+// `on_trunk(i, axis, origin)` / `on_limb(j, axis, origin)`: called with the joint's axis and origin (base coordinates) while they are in
+// registers - the substep of the trunk + limbs instance builds the link velocities / bias accelerations there instead of reading
+// the chain words back (two LDS round trips per joint less); NoJoint = nothing to do
+struct NoJoint {
+  RL_FN void operator()(int, V3, V3) const {}
+};
+template <class TP, class CT, class FT = NoJoint, class FL = NoJoint>
+RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
   constexpr int CL = TP::CL, NW = TP::NW;
   M3 Rp = identity3(), Ra = identity3();
   V3 pp{0.f, 0.f, 0.f}, pa{0.f, 0.f, 0.f};
@@ -307,7 +313,9 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
     M3 Rj0 = mul(Rp, ld_m3(L.rot0[TP::ROT ? jx : 0]));
     V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
     M3 Rj = mul(Rj0, rodrigues(al, q[jx]));
-    C.setw(i, Rj, pj, mul(Rj0, al));
+    const V3 aw = mul(Rj0, al);
+    C.setw(i, Rj, pj, aw);
+    on_trunk(i, aw, pj);
     Rp = Rj;
     pp = pj;
     if (L.attach == i + 1) { Ra = Rj; pa = pj; }
@@ -320,7 +328,9 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
     V3 pj = pp + mul(Rp, ld3(L.origin[j]));
     if (TP::ROT) Rp = mul(Rp, ld_m3(L.rot0[TP::ROT ? j : 0]));
     M3 Rj = mul(Rp, rodrigues(al, q[j]));
-    C.set(j, Rj, pj, mul(Rp, al));
+    const V3 aw = mul(Rp, al);
+    C.set(j, Rj, pj, aw);
+    on_limb(j, aw, pj);
     Rp = Rj;
     pp = pj;
   }
@@ -334,8 +344,8 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
 // 60 instead of 110 instructions per joint of the 10-joint chain, five times per step.
 // (SUB here is the DEALING width: the sub-lanes of a DPP quad - with eight sub-lanes per limb each of the limb's two quads deals among
 // its own four lanes, `sub` = the lane's index in its quad, and the broadcasts stay single quad_perm moves: Ctx::deal_bcast_m3.)
-template <class TP, int SUB, class Ctx, class CT>
-RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C) {
+template <class TP, int SUB, class Ctx, class CT, class FT = NoJoint, class FL = NoJoint>
+RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
   static_assert(TP::ROT && SUB > 1 && SUB <= 4, "trunk + limbs instance, several sub-lanes per limb");
   constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NS = (JX + SUB - 1) / SUB;
   M3 Tl[NS];
@@ -358,7 +368,9 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
     const M3 Tj = ctx.template deal_bcast_m3<jx % SUB>(Tl[jx / SUB]);
     const V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
     const M3 Rj = mul(Rp, Tj);
-    C.setw(i, Rj, pj, mul(Rj, ld3(L.axis[jx])));
+    const V3 aw = mul(Rj, ld3(L.axis[jx]));
+    C.setw(i, Rj, pj, aw);
+    on_trunk(i, aw, pj);
     Rp = Rj;
     pp = pj;
     if (L.attach == i + 1) { Ra = Rj; pa = pj; }
@@ -370,7 +382,9 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
     const M3 Tj = ctx.template deal_bcast_m3<j % SUB>(Tl[j / SUB]);
     const V3 pj = pp + mul(Rp, ld3(L.origin[j]));
     const M3 Rj = mul(Rp, Tj);
-    C.set(j, Rj, pj, mul(Rj, ld3(L.axis[j])));
+    const V3 aw = mul(Rj, ld3(L.axis[j]));
+    C.set(j, Rj, pj, aw);
+    on_limb(j, aw, pj);
     Rp = Rj;
     pp = pj;
   });
@@ -473,14 +487,15 @@ struct EnvLane {
   static constexpr bool LDSU = TP::NW > 0;
   using ChainTP = ChainT<TP, LDSU, 1>;
   enum { LB_REC = LbLayout<TP>::REC, LB_VA = LbLayout<TP>::VA };
-  RL_FN void kinematics(ChainTP& C) {
+  template <class FT = NoJoint, class FL = NoJoint>
+  RL_FN void kinematics(ChainTP& C, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
 #ifndef RL_KIN_REPLICATED  // (A/B switch: every sub-lane computes every joint transform)
     if constexpr (NW > 0 && SUB > 1) {
-      chain_kinematics_dealt<TP, (SUB < 4 ? SUB : 4)>(ctx, SUB > 4 ? (sub & 3) : sub, L, q, C);
+      chain_kinematics_dealt<TP, (SUB < 4 ? SUB : 4)>(ctx, SUB > 4 ? (sub & 3) : sub, L, q, C, on_trunk, on_limb);
       return;
     }
 #endif
-    chain_kinematics<TP>(L, q, C);
+    chain_kinematics<TP>(L, q, C, on_trunk, on_limb);
   }
   RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_chain() : nullptr); }
 
@@ -1368,10 +1383,46 @@ struct EnvLane {
     const SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
     const SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
     ChainTP C = new_chain();
+    // Kinematics, and - while a joint's axis and origin are in registers - the motion subspaces, link velocities and bias accelerations
+    // along the chain (trunk joints: redundant in all lanes, kept in registers; limb joints: identical in the limb's sub-lanes, parked
+    // in the limb-shared words for the owners of the link groups).  RL_VEL_SEPARATE: the round-3 form, a second pass that reads the
+    // chain words back (A/B).
+    SV Sw[NW], Vw[NW], aw[NW];
+#ifndef RL_VEL_SEPARATE
+    {
+      SV Vp = V0, ap = a0;
+      kinematics(C,
+                 [&](int i, V3 ax, V3 pj) __attribute__((always_inline)) {
+                   Sw[i] = SV{ax, cross(pj, ax)};
+                   const SV vj = Sw[i] * qd[CL + i];
+                   Vw[i] = Vp + vj;
+                   aw[i] = ap + crm(Vw[i], vj);
+                   Vp = Vw[i];
+                   ap = aw[i];
+                   if (i == NW - 1) {  // the limb starts from the link it hangs off
+                     Vp = pick_trunk(V0, Vw, L.attach);
+                     ap = pick_trunk(a0, aw, L.attach);
+                   }
+                 },
+                 [&](int j, V3 ax, V3 pj) __attribute__((always_inline)) {
+                   const SV Sj{ax, cross(pj, ax)};
+                   const SV vj = Sj * qd[j];
+                   const SV Vj = Vp + vj;
+                   const SV aj = ap + crm(Vj, vj);
+                   float* w = va_words(j);
+                   st4(w, F4{Vj.a.x, Vj.a.y, Vj.a.z, Vj.l.x});
+                   st4(w + 4, F4{Vj.l.y, Vj.l.z, aj.a.x, aj.a.y});
+                   st4(w + 8, F4{aj.a.z, aj.l.x, aj.l.y, aj.l.z});
+                   Vp = Vj;
+                   ap = aj;
+                 });
+    }
+    if (self_on()) self_place(C);  // (a lane reads frames of its own limb's words only: written by itself, identically in every sub-lane)
+    for (int i = li; i < (NW + 1) * REC_STRIDE; i += LPE) ctx.env_scratch()[i] = 0.f;
+#else
     kinematics(C);
     if (self_on()) self_place(C);  // (a lane reads frames of its own limb's words only: written by itself, identically in every sub-lane)
     // trunk joints: motion subspaces, link velocities and bias accelerations (redundant in all lanes)
-    SV Sw[NW], Vw[NW], aw[NW];
     {
       SV Vp = V0, ap = a0;
 #pragma unroll
@@ -1409,6 +1460,7 @@ struct EnvLane {
       }
       for (int i = li; i < (NW + 1) * REC_STRIDE; i += LPE) ctx.env_scratch()[i] = 0.f;
     }
+#endif
     ctx.group_sync();
     // ---- per link group this lane owns: contacts + rigid record -> the limb's record words (group 0 = the lane's share of a
     // trunk link's spheres: straight into that trunk link's accumulator)
@@ -1559,7 +1611,7 @@ struct EnvLane {
       float va[6] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5]};  // velocity of the link this limb hangs off
       // the contact sensor sees the velocity-LIMITED joint velocities (limit applied to the solution, then the forces -
       // oracle/physics.py): a second running twist built from the clamped values, kept per link for the sensor pass
-      SV vc{{vp[0], vp[1], vp[2]}, {vp[3], vp[4], vp[5]}}, vca = vc;
+      SV vc{{vp[0], vp[1], vp[2]}, {vp[3], vp[4], vp[5]}}, vca = vc, vcg = vc;  // vcg: the trunk link the lane's group 0 rides on (LaneTab::grp0_depth)
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
         float t = uiw[i];
@@ -1576,6 +1628,7 @@ struct EnvLane {
           for (int r = 0; r < 6; ++r) va[r] = vp[r];
           vca = vc;
         }
+        if (L.grp0_depth == i + 1) vcg = vc;
       }
       vc = vca;
 #pragma unroll
@@ -1597,7 +1650,7 @@ struct EnvLane {
       ctx.group_sync();
       static_for<0, NIT>([&](auto it) {
         const int g = sub + SUB * it.value;
-        Vnew[it.value] = vca;  // group 0: the trunk link the limb hangs off (grp0_depth == attach)
+        Vnew[it.value] = vcg;  // group 0: the trunk link its spheres ride on (usually the one the limb hangs off)
         if (g >= 1 && g <= CL) {
           Vnew[it.value] = ld_sv(rec_words(g));
         }

@@ -113,7 +113,10 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     L.base_body_local = -1;
     L.nj = m.chain_nj[k];
     L.attach = m.chain_attach[k];
-    L.grp0_depth = L.attach;  // a lane's link group 0 is a share of the trunk link its limb hangs off
+    // a lane's link group 0 is a share of the trunk link its limb hangs off - or of the spine link the model compiler gave it
+    // (rl_model_desc.chain_grp0: GR1's head, which no limb hangs off)
+    L.grp0_depth = m.chain_grp0[k] > 0 ? m.chain_grp0[k] - 1 : L.attach;
+    if (L.grp0_depth < 0 || L.grp0_depth > m.num_trunk) return fail("chain_grp0 names a trunk link the model does not have");
     if (L.nj > CL || L.attach < 0 || L.attach > m.num_trunk) return fail("bad chain description");
     for (int jx = 0; jx < MAX_JX; ++jx) {  // padding joints: inert (axis 0, no gains), velocity limit > 0 so clamps are no-ops
       L.joint_id[jx] = -1; L.joint_own[jx] = 0; L.vel_limit[jx] = 1e9f; L.act_vlim[jx] = 1e9f; L.lower[jx] = -1e9f; L.upper[jx] = 1e9f;

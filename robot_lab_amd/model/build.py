@@ -134,11 +134,37 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
     if ok:
         # a trunk link's spheres are hosted by the lanes whose limb hangs off it (their link group 0): a trunk link nothing hangs off
         # (G1's two inner waist links have no geometry anyway; GR1's inner waist links and its head do) cannot touch the ground here
-        hosts = {0 if a == 0 else trunk[a - 1] for a, _ in limbs}
-        unhosted = set(trunk) - hosts
-        if unhosted:
-            model.spheres = [s for s in model.spheres if model.bodies[s.body].link not in unhosted]
         cap_spheres(model, [0] + list(trunk), per_link=3 if quad else 4)
+        # Which lane's group 0 rides on which trunk link (depth 0 = the base).  Default: the link the lane's limb hangs off (spare lanes
+        # of a biped: the base).  A spine link with collision geometry that nothing hangs off - FFTAI GR1's head, whose contact the cfg
+        # terminates on (fftai_gr1t1/rough_env_cfg.py:133-139) - takes the group 0 of a lane that shares its own link with another lane,
+        # deepest link first, as long as the donor link's spheres still fit the lanes it keeps (SPL = 4 sphere slots per group).
+        lane_depth = [a for a, _ in limbs] + [0] * (4 - len(limbs))
+        nsph = lambda link: sum(1 for sp_ in model.spheres if model.bodies[sp_.body].link == link)  # noqa: E731
+        link_at = lambda d: 0 if d == 0 else trunk[d - 1]  # noqa: E731
+        for dep in sorted((x for x in range(1, len(trunk) + 1) if x not in lane_depth and nsph(trunk[x - 1]) > 0), reverse=True):
+            donors = [dd for dd in set(lane_depth) if lane_depth.count(dd) >= 2 and nsph(link_at(dd)) <= 4 * (lane_depth.count(dd) - 1)]
+            if not donors or quad:
+                break
+            dd = max(donors, key=lambda x: (lane_depth.count(x), x))
+            k = max(i for i in range(4) if lane_depth[i] == dd)
+            lane_depth[k] = dep
+        for k in range(4):
+            attach = limbs[k][0] if k < len(limbs) else 0
+            m.chain_grp0[k] = 0 if lane_depth[k] == attach else lane_depth[k] + 1
+        # what is still unhosted cannot touch the ground here (G1's two inner waist links have no geometry anyway; GR1's inner waist
+        # links do): their spheres are dropped, LOUDLY - the bundle records the links, and a termination / reward term that names a
+        # body of such a link is inert
+        unhosted = {l for i, l in enumerate(trunk) if (i + 1) not in lane_depth}
+        dropped = sorted({model.bodies[s.body].link for s in model.spheres if model.bodies[s.body].link in unhosted})
+        if dropped:
+            model.spheres = [s for s in model.spheres if model.bodies[s.body].link not in unhosted]
+            names = [bn[b] for b, body in enumerate(model.bodies) if body.link in dropped]
+            spec["dropped_contact_bodies"] = names
+            import warnings
+
+            warnings.warn(f"collision spheres of trunk links nothing rides on were dropped: bodies {names} cannot touch the ground in this "
+                          f"simulator (illegal_contact / undesired_contacts on them are inert)")
     G = len(model.spheres)
     if G > RL_MAX_SPHERES:
         raise ValueError("model exceeds descriptor capacity (collision spheres)")

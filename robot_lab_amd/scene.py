@@ -21,6 +21,8 @@ TERRAIN_HSCALE = 0.05
 def save_bundle(path: str, desc: EnvDesc, spec: dict):
     blob = dict(desc=json.loads(desc_to_json(desc)), terrain_generator=spec.get("terrain_generator"),
                 env_spacing=spec.get("env_spacing", 2.5))
+    if spec.get("dropped_contact_bodies"):  # bodies whose collision geometry the lane program cannot host (model/build.py): they never touch the ground
+        blob["dropped_contact_bodies"] = list(spec["dropped_contact_bodies"])
     with open(path, "w") as f:
         json.dump(blob, f)
 

@@ -235,3 +235,59 @@ def test_partial_reset_by_env_ids(task, emu_lib):
     with pytest.raises(Exception):
         nat.reset([N])
     nat.close()
+
+
+@pytest.mark.parametrize("sub", ["4", "8"])
+def test_a_hosted_spine_link_carries_the_robot(sub, emu_lib, monkeypatch):
+    """`rl_model_desc.chain_grp0`: a spine link nothing hangs off - GR1's head - rides in the group 0 of a spared lane.  The
+    shipped GR1 URDF has no head geometry, so the descriptor is edited the way model/build.py would compile one that has: a sphere on
+    the head body, the second arm lane's group 0 moved from the torso (depth 3) to the head link (depth 6).  Robots dropped on their
+    heads: the head sphere carries load, and the lane program (frame, twist and trunk accumulator of a group 0 that is NOT the limb's
+    attachment link) agrees with the oracle, which knows nothing of lanes."""
+    from helpers import emu_load_state, emu_read_state
+
+    monkeypatch.setenv("RL_EMU_SUB", sub)
+    monkeypatch.setenv("RL_EMU_FIBERS", "1")
+    task, N = "RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0", 4
+
+    def add_head_sphere(desc):
+        m = desc.model
+        head = desc.body_names.index("head_pitch")
+        g = m.num_spheres
+        m.sphere_body[g], m.sphere_radius[g] = head, 0.10
+        m.sphere_center[g][0] = m.sphere_center[g][1] = m.sphere_center[g][2] = 0.0
+        m.num_spheres = g + 1
+        depth = [int(m.trunk_link[i]) for i in range(m.num_trunk)].index(int(m.body_link[head])) + 1
+        assert list(m.chain_attach) == [0, 0, 3, 3] and depth > 3
+        m.chain_grp0[3] = depth + 1
+        desc.task.term_illegal_contact = 0  # (the cfg terminates on head contact - which is the point of hosting it; here the contact itself is watched)
+
+    desc, ora, nat = make_pair(task, N, 5, emu_lib, mutate=add_head_sphere)
+    head = desc.body_names.index("head_pitch")
+    ora.reset()
+    nat.reset()
+    state = emu_read_state(nat)
+    rs = state["root_state"].copy()
+    rs[:, 2] = 5.0
+    rs[:, 3:7] = [0.0, 1.0, 0.0, 0.0]         # upside down (a half turn about x)
+    rs[:, 7:13] = 0.0
+    state["root_state"] = rs
+    ora.load_state(state)
+    head_z = ora.phys.body_kinematics(ora.st)[0][:, head, 2]  # where that puts the head: lower the robots until its sphere is 1 - 4 cm in the plane
+    rs[:, 2] = 5.0 - (head_z - 0.10) - np.linspace(0.01, 0.04, N)
+    state["root_state"] = rs
+    emu_load_state(nat, state)
+    state = emu_read_state(nat)
+    ora.load_state(state)
+    a = np.zeros((N, desc.model.num_dof), dtype=np.float32)
+    k = 6.0  # (GR1's bands: test_lane_program_matches_oracle)
+    for s in range(2):  # (two steps = eight substeps of a 55 kg robot landing on its head: beyond that the free runs drift apart like any stiff contact)
+        ora.step(a)
+        nat.step(a.ctypes.data)
+        assert_close(f"cforce[{s}]", host_view(nat, "CONTACT_FORCE"), ora.contact_force, k * 5e-3, k * 5e-2)
+    assert (np.linalg.norm(ora.contact_force[:, head], axis=1) > 20.0).sum() >= 2, ora.contact_force[:, head]  # the head carries load
+    nat.export_state()
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), k * 1e-3, k * 1e-4)
+    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], k * 2e-3, k * 2e-3)
+    assert_close("timers", host_view(nat, "CONTACT_TIMERS"), ora.timers, k * 1e-5, k * 1e-6)
+    nat.close()

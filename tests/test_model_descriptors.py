@@ -230,3 +230,62 @@ def test_no_bundle_freezes_a_joint():
         assert (vl > 0.1).all(), (path, vl)
         assert all(m.joint_upper[i] > m.joint_lower[i] for i in range(D)), path
         assert sum(m.body_mass[i] for i in range(m.num_bodies)) > 1.0, path
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# spine links nothing hangs off: hosted where a lane can be spared, dropped LOUDLY otherwise
+# ------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference's cfg classes and URDFs")
+def test_a_spine_link_without_a_limb_is_hosted_or_dropped_loudly(monkeypatch):
+    """FFTAI GR1: waist(3) + head(3) spine, legs on the base, arms on the torso (depth 3).  The shipped URDF puts collision geometry on
+    the torso only.  Give the HEAD and an INNER WAIST link a sphere: the head (deepest) takes the group 0 of the second arm lane (the
+    torso's one sphere fits the first), the waist link the second leg lane's (the base has no spheres to host) - nothing is dropped.
+    With a third orphan (waist_pitch) there is no lane left: its body is dropped with a warning and listed in the bundle."""
+    import warnings
+
+    import numpy as np
+
+    from robot_lab_amd import shims
+
+    shims.install(shims.REFERENCE_SOURCE)
+    import robot_lab.tasks  # noqa: F401
+    from isaaclab_tasks.utils import parse_env_cfg
+
+    import robot_lab_amd.model.cfg_compile as cc
+    from robot_lab_amd.model.urdf import Sphere
+
+    task = "RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0"
+    real_load = cc.load_urdf
+
+    def with_orphans(names):
+        def load(path, **kw):
+            model = real_load(path, **kw)
+            for n in names:
+                b = model.body_names.index(n)
+                model.spheres.append(Sphere(body=b, center=np.zeros(3), radius=0.08))
+            return model
+        return load
+
+    monkeypatch.setattr(cc, "load_urdf", with_orphans(["head_pitch", "waist_yaw"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # nothing may be dropped
+        desc, spec = cc.compile_cfg(parse_env_cfg(task, device="cpu", num_envs=4))
+    m = desc.model
+    depth = {int(m.trunk_link[i]): i + 1 for i in range(m.num_trunk)}
+    head_link, waist_link = int(m.body_link[desc.body_names.index("head_pitch")]), int(m.body_link[desc.body_names.index("waist_yaw")])
+    assert list(m.chain_attach) == [0, 0, 3, 3]
+    assert list(m.chain_grp0) == [0, depth[waist_link] + 1, 0, depth[head_link] + 1] and "dropped_contact_bodies" not in spec
+    hosted = {desc.body_names[m.sphere_body[g]] for g in range(m.num_spheres)}
+    assert {"head_pitch", "waist_yaw", "waist_roll"} <= hosted
+
+    monkeypatch.setattr(cc, "load_urdf", with_orphans(["head_pitch", "waist_yaw", "waist_pitch"]))
+    with pytest.warns(UserWarning, match="cannot touch the ground"):
+        desc, spec = cc.compile_cfg(parse_env_cfg(task, device="cpu", num_envs=4))
+    assert spec["dropped_contact_bodies"] == ["waist_yaw"]  # deepest first: head, then waist_pitch get the two spare lanes
+    assert "waist_yaw" not in {desc.body_names[desc.model.sphere_body[g]] for g in range(desc.model.num_spheres)}
+    # the shipped robots: nothing to host, nothing dropped
+    monkeypatch.setattr(cc, "load_urdf", real_load)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        desc, spec = cc.compile_cfg(parse_env_cfg(task, device="cpu", num_envs=4))
+    assert list(desc.model.chain_grp0) == [0, 0, 0, 0] and "dropped_contact_bodies" not in spec
