@@ -132,7 +132,7 @@ typedef struct rl_model_desc {
   int32_t chain_nj[4];                  /* joints of chain k (G1: legs 6, arms 7) */
   int32_t chain_attach[4];
   int32_t num_trunk;
-  int32_t trunk_link[8];                /* <= 6 in use (GR1: waist 3 + head 3, the arms leaving the spine at depth 3) */
+  int32_t trunk_link[8];                /* <= 6 in use (GR1: waist 3 + head 3, the arms leaving the spine at depth 3); see trunk_parent */
   int32_t link_parent[RL_MAX_LINKS];
   float link_origin[RL_MAX_LINKS][3];   /* joint origin in parent link frame */
   float link_quat[RL_MAX_LINKS][4];     /* joint frame orientation in the parent link frame, (w,x,y,z) (URDF joint rpy) */
@@ -177,6 +177,11 @@ typedef struct rl_model_desc {
      gets the group 0 of a lane that shares its own attachment link with another lane: chain_grp0[k] = 1 + trunk depth of the link
      chain k's group 0 rides on, 0 = the default (the chain's attachment link). */
   int32_t chain_grp0[4];
+  /* The trunk is a serial spine (G1: the waist; GR1: waist + neck) or several serial PIECES that each start at the base (Booster T1:
+     the waist, which carries the legs, and the two-joint neck both hang off the trunk body).  trunk_parent[i]: 0 = trunk joint i hangs
+     off its predecessor in trunk_link[] (joint 0: off the base) - the serial spine, and what a zeroed field means; -1 = it hangs off
+     the base and starts a new piece.  Nothing else. */
+  int32_t trunk_parent[8];
 } rl_model_desc;
 
 /* ---- simulator constants (ours; the reference delegates these to PhysX) ------------------ */

@@ -73,6 +73,7 @@ struct Uni {
   float inv_hscale, x0, y0;
   int is_plane, nx, ny;
   double x0d, y0d, inv_hd;  // the grid transform of the heightfield in fp64 (terrain_fetch)
+  uint32_t trunk_restart;   // bit i: trunk joint i hangs off the BASE, not off trunk joint i - 1 (TaskTab::trunk_restart)
 };
 template <class Ctx>
 RL_FN Uni make_uni(const Ctx& ctx, const TaskTab& T) {
@@ -91,6 +92,7 @@ RL_FN Uni make_uni(const Ctx& ctx, const TaskTab& T) {
   };
   u.x0d = uni_d((double)T.x0); u.y0d = uni_d((double)T.y0);
   u.inv_hd = uni_d(T.is_plane ? 1.0 : 1.0 / (double)T.hscale);
+  u.trunk_restart = (uint32_t)ctx.uniform_i((int)T.trunk_restart);
   return u;
 }
 
@@ -301,14 +303,17 @@ RL_FN void trunk_frame(const CT& C, int depth, M3& Rf, V3& pf) {
 struct NoJoint {
   RL_FN void operator()(int, V3, V3) const {}
 };
+// `restart`: bit i = trunk joint i hangs off the base (the trunk is one serial spine, or - Booster T1: a waist and a neck on the base -
+// several serial pieces that each start at the base; a piece is a run of consecutive trunk joints)
 template <class TP, class CT, class FT = NoJoint, class FL = NoJoint>
-RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
+RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C, uint32_t restart = 0u, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
   constexpr int CL = TP::CL, NW = TP::NW;
   M3 Rp = identity3(), Ra = identity3();
   V3 pp{0.f, 0.f, 0.f}, pa{0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NW; ++i) {  // trunk joints (same in every lane)
     const int jx = CL + i;
+    if (i > 0 && ((restart >> i) & 1u)) { Rp = identity3(); pp = {0.f, 0.f, 0.f}; }
     V3 al = ld3(L.axis[jx]);
     M3 Rj0 = mul(Rp, ld_m3(L.rot0[TP::ROT ? jx : 0]));
     V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
@@ -345,7 +350,7 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
 // (SUB here is the DEALING width: the sub-lanes of a DPP quad - with eight sub-lanes per limb each of the limb's two quads deals among
 // its own four lanes, `sub` = the lane's index in its quad, and the broadcasts stay single quad_perm moves: Ctx::deal_bcast_m3.)
 template <class TP, int SUB, class Ctx, class CT, class FT = NoJoint, class FL = NoJoint>
-RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
+RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C, uint32_t restart = 0u, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
   static_assert(TP::ROT && SUB > 1 && SUB <= 4, "trunk + limbs instance, several sub-lanes per limb");
   constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NS = (JX + SUB - 1) / SUB;
   M3 Tl[NS];
@@ -365,6 +370,7 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
   // (the bodies must be inlined at all three call sites: a lambda left as a function takes its captures - the lane object - by address)
   static_for<0, NW>([&](auto ic) __attribute__((always_inline)) {  // trunk joints (same in every lane)
     constexpr int i = decltype(ic)::value, jx = CL + i;
+    if (i > 0 && ((restart >> i) & 1u)) { Rp = identity3(); pp = {0.f, 0.f, 0.f}; }
     const M3 Tj = ctx.template deal_bcast_m3<jx % SUB>(Tl[jx / SUB]);
     const V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
     const M3 Rj = mul(Rp, Tj);
@@ -390,14 +396,14 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
   });
 }
 
-// velocity (base coords) of the point x rigidly attached to a link that is moved by the first `wd` trunk
-// joints and the first `lg` limb joints
+// velocity (base coords) of the point x rigidly attached to a link that is moved by the trunk joints of `anc` (bit i: trunk joint i -
+// TaskTab::trunk_anc[depth]: the joints between the base and that trunk link) and the first `lg` limb joints
 template <class TP, class CT>
-RL_FN V3 point_velocity(const CT& C, int wd, int lg, V3 x, SV V0, const float (&qd)[TP::JX]) {
+RL_FN V3 point_velocity(const CT& C, uint32_t anc, int lg, V3 x, SV V0, const float (&qd)[TP::JX]) {
   V3 u = V0.l + cross(V0.a, x);
 #pragma unroll
   for (int i = 0; i < TP::NW; ++i)
-    if (i < wd) u += qd[TP::CL + i] * cross(C.axw(i), x - C.pw(i));
+    if ((anc >> i) & 1u) u += qd[TP::CL + i] * cross(C.axw(i), x - C.pw(i));
 #pragma unroll
   for (int i = 0; i < TP::CL; ++i)
     if (i < lg) u += qd[i] * cross(C.ax(i), x - C.p(i));
@@ -491,11 +497,11 @@ struct EnvLane {
   RL_FN void kinematics(ChainTP& C, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
 #ifndef RL_KIN_REPLICATED  // (A/B switch: every sub-lane computes every joint transform)
     if constexpr (NW > 0 && SUB > 1) {
-      chain_kinematics_dealt<TP, (SUB < 4 ? SUB : 4)>(ctx, SUB > 4 ? (sub & 3) : sub, L, q, C, on_trunk, on_limb);
+      chain_kinematics_dealt<TP, (SUB < 4 ? SUB : 4)>(ctx, SUB > 4 ? (sub & 3) : sub, L, q, C, u.trunk_restart, on_trunk, on_limb);
       return;
     }
 #endif
-    chain_kinematics<TP>(L, q, C, on_trunk, on_limb);
+    chain_kinematics<TP>(L, q, C, u.trunk_restart, on_trunk, on_limb);
   }
   RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_chain() : nullptr); }
 
@@ -710,6 +716,7 @@ struct EnvLane {
   };
   // joints that move link group g: the first wdepth(g) trunk joints and the first g limb joints
   RL_FN int wdepth(int g) const { return NW == 0 ? 0 : (g == 0 ? L.grp0_depth : L.attach); }
+  RL_FN uint32_t trunk_anc(int g) const { return NW == 0 ? 0u : T.trunk_anc[wdepth(g)]; }  // the trunk joints that move link group g
   // sphere centre in base coordinates (cb) and world (cw: x, y as OFFSETS from the root position - the terrain lookup adds the
   // root in fp64 -, z the world height); empty slots (radius <= 0) sit at the group's link origin
   // frame (base coordinates) of link group g: the trunk link of group 0, else limb link g - 1.  Selected once
@@ -777,10 +784,10 @@ struct EnvLane {
   RL_FN SV link_twist(const ChainTP& C, int g, int s, SV V0, const float (&qdv)[JX]) const {
     SV V = V0;
     if (M0 && on_base(g, s)) return V;
-    const int wd = wdepth(g);
+    const uint32_t anc = trunk_anc(g);
 #pragma unroll
     for (int i = 0; i < NW; ++i)
-      if (i < wd) { V.a += qdv[CL + i] * C.axw(i); V.l += qdv[CL + i] * cross(C.pw(i), C.axw(i)); }
+      if ((anc >> i) & 1u) { V.a += qdv[CL + i] * C.axw(i); V.l += qdv[CL + i] * cross(C.pw(i), C.axw(i)); }
 #pragma unroll
     for (int i = 0; i < CL; ++i)
       if (i < g) { V.a += qdv[i] * C.ax(i); V.l += qdv[i] * cross(C.p(i), C.ax(i)); }
@@ -1393,6 +1400,7 @@ struct EnvLane {
       SV Vp = V0, ap = a0;
       kinematics(C,
                  [&](int i, V3 ax, V3 pj) __attribute__((always_inline)) {
+                   if (i > 0 && ((u.trunk_restart >> i) & 1u)) { Vp = V0; ap = a0; }  // a trunk piece that starts at the base
                    Sw[i] = SV{ax, cross(pj, ax)};
                    const SV vj = Sw[i] * qd[CL + i];
                    Vw[i] = Vp + vj;
@@ -1429,6 +1437,7 @@ struct EnvLane {
       for (int i = 0; i < NW; ++i) {
         V3 axi, pi;
         C.axp(CL + i, axi, pi);
+        if (i > 0 && ((u.trunk_restart >> i) & 1u)) { Vp = V0; ap = a0; }
         Sw[i] = SV{axi, cross(pi, axi)};
         const SV vj = Sw[i] * qd[CL + i];
         Vw[i] = Vp + vj;
@@ -1587,6 +1596,11 @@ struct EnvLane {
 #pragma unroll
     for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
     float Uhw[NW][6], uiw[NW];
+    LinkRec Pb;  // what the trunk pieces already eliminated hand to the base (a piece ends where its first joint hangs off the base)
+#pragma unroll
+    for (int i = 0; i < B6::size; ++i) Pb.A[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Pb.r[i] = 0.f;
 #pragma unroll
     for (int d = NW; d >= 1; --d) {
       add_rec(trunk_words(d), P);
@@ -1594,8 +1608,18 @@ struct EnvLane {
       float D, uu;
       joint_terms(CL + d - 1, d - 1 >= T.nw_used, tau_e, pd_diag, pd_rhs, D, uu);
       eliminate(P, s6, D, uu, Uhw[d - 1], uiw[d - 1]);
+      if (d > 1 && ((u.trunk_restart >> (d - 1)) & 1u)) {  // (wave-uniform) joint d - 1 hangs off the base: park the piece, the next joint starts another
+#pragma unroll
+        for (int i = 0; i < B6::size; ++i) { Pb.A[i] += P.A[i]; P.A[i] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { Pb.r[i] += P.r[i]; P.r[i] = 0.f; }
+      }
     }
     add_rec(trunk_words(0), P);
+#pragma unroll
+    for (int i = 0; i < B6::size; ++i) P.A[i] += Pb.A[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) P.r[i] += Pb.r[i];
     RL_PHASE(11, "sub.trunk_solve");
     float nu0[NB], qdn[JX];
     {
@@ -1612,8 +1636,14 @@ struct EnvLane {
       // the contact sensor sees the velocity-LIMITED joint velocities (limit applied to the solution, then the forces -
       // oracle/physics.py): a second running twist built from the clamped values, kept per link for the sensor pass
       SV vc{{vp[0], vp[1], vp[2]}, {vp[3], vp[4], vp[5]}}, vca = vc, vcg = vc;  // vcg: the trunk link the lane's group 0 rides on (LaneTab::grp0_depth)
+      const SV vc0 = vc;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
+        if (i > 0 && ((u.trunk_restart >> i) & 1u)) {  // a trunk piece that starts at the base: its parent's velocity is the base's
+#pragma unroll
+          for (int r = 0; r < 6; ++r) vp[r] = nu0[r];
+          vc = vc0;
+        }
         float t = uiw[i];
 #pragma unroll
         for (int r = 0; r < 6; ++r) t -= Uhw[i][r] * vp[r];

@@ -150,7 +150,9 @@ struct TaskTab {  // everything that is not per limb
   int32_t nw_used;      // trunk joints the model really has (<= NW; the rest are inert padding)
   uint32_t slot_valid;  // bit g*SPL+s: some lane has a collision sphere in slot (g, s)
   int32_t merged;       // 1: tables built for a Topo<..., M0 = 1> instance (base-share spheres in limb slots, LaneTabT::sph_base_mask)
-  int32_t sub8_ok;      // 1: the model fits the 32-lanes-per-env mapping (trunk + limbs instances; LaneTabT::own_slot8 holds every slot)
+  int32_t sub8_ok;      // 1: the model fits the 32-lanes-per-env mapping (trunk + limbs instances: at most MAXOWN8 body slots per link group)
+  uint32_t trunk_restart;          // bit i: trunk joint i hangs off the base (bit 0 always; Booster T1: waist AND neck on the base - two pieces)
+  uint32_t trunk_anc[MAX_NW + 1];  // [d]: the trunk joints between the base and the trunk link at depth d (bit i = trunk joint i); [0] = 0
   int32_t wrench_depth; // trunk link (0 = base, i = after i trunk joints) carrying the body the wrench / COM events address
   int32_t scan_depth;   // trunk link carrying the height-scanner body
   float scan_pos[3];    // scanner body origin in that link's frame

@@ -549,7 +549,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     for (int j = 0; j < CL; ++j)
       if (g == j + 1) x = C.p(j) + mul(C.R(j), bp);
     relp = x;
-    relv = point_velocity<TP, ChainTP>(C, this->wdepth(g), g, x, SV{ang_b, cross(base_com, ang_b)}, qd);  // relative to the root COM velocity
+    relv = point_velocity<TP, ChainTP>(C, this->trunk_anc(g), g, x, SV{ang_b, cross(base_com, ang_b)}, qd);  // relative to the root COM velocity
   }
 
   // Reward evaluation: LANE PER TERM.  The lanes that own joints / body slots first publish two small per-env tables in LDS -

@@ -87,10 +87,16 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   link_k.assign(m.num_links, -2);
   link_j.assign(m.num_links, -1);
   link_k[0] = -1; link_j[0] = 0;
+  T.trunk_restart = 1u;
+  for (int d = 0; d <= MAX_NW; ++d) T.trunk_anc[d] = 0u;
   for (int i = 0; i < m.num_trunk; ++i) {
     int link = m.trunk_link[i];
-    if (link < 1 || link >= m.num_links || m.link_parent[link] != (i == 0 ? 0 : m.trunk_link[i - 1])) return fail("trunk_link does not describe a serial chain off the base");
+    if (m.trunk_parent[i] != 0 && m.trunk_parent[i] != -1) return fail("trunk_parent: 0 (hangs off its predecessor in trunk_link) or -1 (hangs off the base)");
+    const int pd = (i == 0 || m.trunk_parent[i] == -1) ? 0 : i;  // trunk depth of the parent link
+    if (link < 1 || link >= m.num_links || m.link_parent[link] != (pd == 0 ? 0 : m.trunk_link[pd - 1])) return fail("trunk_link does not describe serial chains off the base");
     link_k[link] = -1; link_j[link] = i + 1;
+    if (pd == 0) T.trunk_restart |= 1u << i;
+    T.trunk_anc[i + 1] = (pd == 0 ? 0u : T.trunk_anc[pd]) | (1u << i);
   }
   auto fill_joint = [&](LaneTab& L, int jx, int link) {
     const int jt = link - 1;

@@ -105,7 +105,7 @@ class ModelDesc(C.Structure):
         ("self_collision", i32), ("num_capsules", i32), ("capsule_link", i32 * RL_MAX_CAPSULES),
         ("capsule_p0", (f32 * 3) * RL_MAX_CAPSULES), ("capsule_p1", (f32 * 3) * RL_MAX_CAPSULES), ("capsule_radius", f32 * RL_MAX_CAPSULES),
         ("num_self_pairs", i32), ("self_pair", (i32 * 2) * RL_MAX_SELF_PAIRS),
-        ("chain_grp0", i32 * 4),
+        ("chain_grp0", i32 * 4), ("trunk_parent", i32 * 8),
     ]
 
 

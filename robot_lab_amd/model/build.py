@@ -93,28 +93,45 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
             ch.append(cur)
         return ch, children[cur]
 
-    limbs, trunk = [], []  # limbs: (attach depth, [links])
-    for r in children[0]:
-        ch, tail = serial(r)
-        if not tail:
-            limbs.append((0, ch))
-        elif not trunk:  # one branching serial chain = the trunk (G1 waist -> torso -> arms)
-            trunk = ch
-            subs = [serial(rr) for rr in tail]
-            attach = len(trunk)
-            # a spine that goes on past the branching link (FFTAI GR1: waist -> torso -> head, `GR1T1.urdf`; the arms leave it at the
-            # torso): with more than four limb candidates the shortest terminal child chain continues the trunk
-            others = len(children[0]) - 1
-            if others + len(subs) > 4 and all(not t2 for _, t2 in subs):
-                k = min(range(len(subs)), key=lambda i: len(subs[i][0]))
-                trunk = trunk + subs[k][0]
-                subs = subs[:k] + subs[k + 1:]
-            for ch2, tail2 in subs:
-                limbs.append((attach, ch2) if not tail2 else (None, ch2))
-        else:
-            limbs.append((None, ch))
-    ok = (1 <= len(limbs) <= 4 and all(a is not None for a, _ in limbs) and max(len(c) for _, c in limbs) <= 7 and len(trunk) <= 6
-          and sum(len(c) for _, c in limbs) + len(trunk) == D)
+    def discover(continue_spine: bool):
+        limbs, trunk = [], []  # limbs: (attach depth, [links])
+        for r in children[0]:
+            ch, tail = serial(r)
+            if not tail:
+                limbs.append((0, ch))
+            elif not trunk:  # one branching serial chain = the trunk (G1 waist -> torso -> arms)
+                trunk = ch
+                subs = [serial(rr) for rr in tail]
+                attach = len(trunk)
+                # a spine that goes on past the branching link (FFTAI GR1: waist -> torso -> head, `GR1T1.urdf`; the arms leave it at the
+                # torso): with more than four limb candidates the shortest terminal child chain continues the trunk
+                others = len(children[0]) - 1
+                if continue_spine and others + len(subs) > 4 and all(not t2 for _, t2 in subs):
+                    k = min(range(len(subs)), key=lambda i: len(subs[i][0]))
+                    trunk = trunk + subs[k][0]
+                    subs = subs[:k] + subs[k + 1:]
+                for ch2, tail2 in subs:
+                    limbs.append((attach, ch2) if not tail2 else (None, ch2))
+            else:
+                limbs.append((None, ch))
+        # more than four limb candidates with some of them on the base itself (Booster T1, `t1_description/urdf/robot.urdf`: a two-joint
+        # neck and the arms on the trunk body, the legs behind a one-joint waist): the shortest chain on the base becomes a second PIECE
+        # of the trunk - trunk joints that start again at the base (rl_model_desc.trunk_parent = -1) -, simulated redundantly by all lanes
+        piece_starts = []
+        while len(limbs) > 4 and any(a == 0 for a, _ in limbs):
+            k = min((i for i, (a, _) in enumerate(limbs) if a == 0), key=lambda i: len(limbs[i][1]))
+            if len(trunk) + len(limbs[k][1]) > 6:
+                break
+            piece_starts.append(len(trunk))
+            trunk = trunk + limbs[k][1]
+            limbs = limbs[:k] + limbs[k + 1:]
+        ok = (1 <= len(limbs) <= 4 and all(a is not None for a, _ in limbs) and max(len(c) for _, c in limbs) <= 7 and len(trunk) <= 6
+              and sum(len(c) for _, c in limbs) + len(trunk) == D)
+        return ok, limbs, trunk, piece_starts
+
+    ok, limbs, trunk, piece_starts = discover(True)
+    if not ok:  # (GR1's rule first: it is what the committed bundles were compiled with)
+        ok, limbs, trunk, piece_starts = discover(False)
     # fewer than 4 limbs (bipeds without arms): the spare lane groups simulate empty chains
     m.num_chains, m.chain_len, m.num_trunk = (4, max(len(c) for _, c in limbs), len(trunk)) if ok else (0, 0, 0)
     for k in range(4):
@@ -127,6 +144,7 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
                 m.chain_link[k][j] = l
         for i, l in enumerate(trunk):
             m.trunk_link[i] = l
+            m.trunk_parent[i] = -1 if (i in piece_starts and i > 0) else 0
     # quadruped instances (Topo<3|4,0,3,6>) need 4 equal chains of <= 4 joints and no trunk; everything else that fits
     # runs on a trunk + limbs instance (Topo<7,3,4,9>; a trunk of 4 - 6 joints: Topo<7,6,4,9>) with inert padding joints (rl_env_host.h: topo_shape)
     quad = ok and not trunk and len(limbs) == 4 and len({len(c) for _, c in limbs}) == 1 and len(limbs[0][1]) <= 4

@@ -34,12 +34,15 @@ TASKS = [
     # a six-joint spine (waist, then head) with the arms leaving it at depth 3: the Topo<7,6,4,9> instance, 32 DoF
     "RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0",
     "RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T2-v0",
+    # a trunk of two PIECES on the base - the waist (carrying the legs) and a two-joint neck - with the arms on the base as well: Booster T1
+    "RobotLab-Isaac-Velocity-Flat-Booster-T1-v0",
+    "RobotLab-Isaac-Velocity-Rough-Booster-T1-v0",
 ]
 
 
 @pytest.mark.parametrize("task", TASKS)
 def test_lane_program_matches_oracle(task, emu_lib):
-    N = 8 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1", "GR1")) else 16  # big models: the fp64 oracle is the slow side
+    N = 8 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1", "GR1", "T1")) else 16  # big models: the fp64 oracle is the slow side
     # GR1 (55 kg on two feet, drive stiffness up to 250 N m / rad): the fp32 program sits 3 - 5 x further from the fp64 oracle than on
     # the 35 kg G1 - root state to 3e-4, joint velocities to 1.4e-2, contact forces to 0.4 N over these six steps, not growing -
     # so its bands are 6 x the others'
@@ -142,7 +145,8 @@ def test_sixteen_lane_mapping_matches_oracle(task, N, steps, merge, sub, emu_lib
 # per wavefront: what a <= 2048-env G1 launch runs on the GPU since round 4): G1 Rough and Flat, a padded humanoid, a biped with two
 # empty limbs, the six-joint-spine instance.  32 lanes per env as fibers of one host thread.
 @pytest.mark.parametrize("task,k", [(TASKS[5], 1.0), (TASKS[4], 1.0), ("RobotLab-Isaac-Velocity-Flat-RobotEra-Xbot-v0", 1.0),
-                                    ("RobotLab-Isaac-Velocity-Rough-Openloong-Loong-v0", 1.0), ("RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0", 6.0)])
+                                    ("RobotLab-Isaac-Velocity-Rough-Openloong-Loong-v0", 1.0), ("RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0", 6.0),
+                                    ("RobotLab-Isaac-Velocity-Rough-Booster-T1-v0", 1.0)])
 def test_thirty_two_lane_mapping_matches_oracle(task, k, emu_lib, monkeypatch):
     monkeypatch.setenv("RL_EMU_SUB", "8")
     monkeypatch.setenv("RL_EMU_FIBERS", "1")

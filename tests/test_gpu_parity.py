@@ -43,6 +43,7 @@ TASKS = [
     "RobotLab-Isaac-Velocity-Flat-MagicLab-Dog-v0",
     "RobotLab-Isaac-Velocity-Rough-Agibot-D1-v0",
     "RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0",  # the six-joint-spine instance Topo<7,6,4,9>
+    "RobotLab-Isaac-Velocity-Rough-Booster-T1-v0",  # a trunk of two pieces on the base (waist + neck), the head's sphere hosted by a leg lane's group 0
 ]
 
 
@@ -57,7 +58,7 @@ def _pair(task, N, seed):
     return env, OracleWithTwin(lambda: OracleEnv(desc, h, to, N, seed, eo)), torch
 
 
-TRUNK_LIMBS = ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1")  # robots on the trunk + limbs instance
+TRUNK_LIMBS = ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1", "Booster")  # robots on the trunk + limbs instance
 # Kernel shapes.  Production launches of >= 4096 quadruped envs run env_kernel<..., WGW = 4> (four wavefronts
 # per workgroup sharing one staged table image); 64 envs would take the single-wavefront variant, so every quadruped id is run in
 # BOTH: "" = what the launch size selects (WGW = 1 here), "-4" = RL_ENV_WG=-4 forces the four-wavefront shape at this size.  The

@@ -289,3 +289,24 @@ def test_a_spine_link_without_a_limb_is_hosted_or_dropped_loudly(monkeypatch):
         warnings.simplefilter("error")
         desc, spec = cc.compile_cfg(parse_env_cfg(task, device="cpu", num_envs=4))
     assert list(desc.model.chain_grp0) == [0, 0, 0, 0] and "dropped_contact_bodies" not in spec
+
+
+def test_booster_t1_is_a_trunk_of_two_pieces():
+    """`assets/booster.py:10-109`, `t1_description/urdf/robot.urdf`: a two-joint neck, two four-joint arms and a one-joint waist on the
+    trunk body, the six-joint legs behind the waist - five chains on the base.  The neck becomes a second piece of the trunk (joints all
+    lanes simulate redundantly, restarting at the base), the arms hang off the base, the legs off the waist; the head's collision sphere
+    rides in the group 0 of a leg lane (the waist link, which both leg lanes would otherwise share, has no geometry)."""
+    d, _ = load_bundle("RobotLab-Isaac-Velocity-Rough-Booster-T1-v0")
+    m = d.model
+    assert (m.num_links, m.num_dof, m.num_chains, m.chain_len, m.num_trunk) == (24, 23, 4, 6, 3)
+    trunk_joints = [d.joint_names[m.trunk_link[i] - 1] for i in range(m.num_trunk)]
+    assert trunk_joints == ["Waist", "AAHead_yaw", "Head_pitch"] and list(m.trunk_parent)[:3] == [0, -1, 0]
+    assert sorted(zip(m.chain_nj, m.chain_attach)) == [(4, 0), (4, 0), (6, 1), (6, 1)]
+    legs = [k for k in range(4) if m.chain_nj[k] == 6]
+    assert sorted(m.chain_grp0[k] for k in legs) == [0, 4] and all(m.chain_grp0[k] == 0 for k in range(4) if k not in legs)  # depth 3 = the head link
+    hosted = {d.body_names[m.sphere_body[g]] for g in range(m.num_spheres)}
+    assert {"Trunk", "H2", "left_foot_link", "right_foot_link"} <= hosted
+    # the head joints have no actuator group (assets/booster.py: legs / feet / arms): passive hinges
+    for n in ("AAHead_yaw", "Head_pitch"):
+        j = d.joint_names.index(n)
+        assert m.act_kp[j] == 0.0 and m.act_kd[j] == 0.0

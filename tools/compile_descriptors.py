@@ -26,9 +26,9 @@ from robot_lab_amd.scene import DATA_DIR, save_bundle  # noqa: E402
 ROBOTS = ("Unitree-A1", "Unitree-Go2", "Unitree-Go2W", "Unitree-G1", "Unitree-B2", "Deeprobotics-Lite3", "Deeprobotics-M20",
           "Zsibot-ZSL1", "Zsibot-ZSL1W", "RoboParty-ATOM01", "RobotEra-Xbot", "MagicLab-Bot-Gen1", "Openloong-Loong",
           "Unitree-B2W", "MagicLab-Dog-W", "MagicLab-Dog", "MagicLab-Bot-Z1", "DDTRobot-Tita", "HandStand-Unitree-A1", "Agibot-D1",
-          "FFTAI-GR1T1", "FFTAI-GR1T2")  # GR1: a six-joint spine (waist + head) with the arms leaving it at depth 3: Topo<7,6,4,9>
-# not compiled: Unitree-H1 (asset lives in isaaclab_assets, not in the reference), Booster-T1 (5 limbs: head + arms + legs on
-# no common spine), MagicLab-Dog Rough (its registration names a class that does not exist)
+          "FFTAI-GR1T1", "FFTAI-GR1T2",  # GR1: a six-joint spine (waist + head) with the arms leaving it at depth 3: Topo<7,6,4,9>
+          "Booster-T1")                  # T1: waist (carrying the legs) and a two-joint neck both on the trunk body - a trunk of two pieces
+# not compiled: Unitree-H1 (asset lives in isaaclab_assets, not in the reference), MagicLab-Dog Rough (its registration names a class that does not exist)
 TASKS = sys.argv[1:] or [f"RobotLab-Isaac-Velocity-{t}-{r}-v0" for r in ROBOTS for t in ("Flat", "Rough")]
 os.makedirs(DATA_DIR, exist_ok=True)
 for task in TASKS:
