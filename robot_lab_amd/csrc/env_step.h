@@ -562,7 +562,7 @@ struct EnvLane {
 #ifdef RL_PHASE_CLOCK_ON
   long long ph_t0 = 0;
   int ph_cur = 0;
-  __device__ void phase_stamp(int id) {
+  __device__ __forceinline__ void phase_stamp(int id) {
     __builtin_amdgcn_s_waitcnt(0);
     const long long t = (long long)__builtin_readcyclecounter();
     if (ctx.lane == 0) {

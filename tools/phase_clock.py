@@ -26,7 +26,7 @@ env = ManagerBasedRLEnv(task, num_envs=N, seed=42, device="cuda:0")
 env.reset()
 A = env.num_actions
 g = torch.Generator(device="cuda:0").manual_seed(1)
-nwave = N * 16 // 64 if os.environ.get("RL_ENV_SUB", "4") != "1" else N * 4 // 64
+nwave = -(-N // int(env._native.envs_per_wavefront()))  # one row of SLOTS per wavefront (the lane mapping decides how many envs it holds)
 rt = env._bufs["REWARD_TERMS"]
 Np = rt.shape[1]
 assert nwave * SLOTS <= (40 - ROW0) * Np, "the borrowed reward-term rows are too short for this many wavefronts"
