@@ -16,6 +16,7 @@ CASES = [
     ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", 32, 6),
     ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 8, 6),
     ("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0", 8, 6),  # the six-joint-spine instance, judged by the oracle's own fp32 sensitivity
+    ("RobotLab-Isaac-Velocity-Rough-Booster-T1-v0", 8, 6),   # a trunk of two pieces, passive neck joints (no saturation switch: the mask must not flag them)
 ]
 
 
