@@ -277,7 +277,7 @@ def large_batch(task: str, n_envs: int, dev: str) -> dict:
             "envs_per_wavefront": ept, "note": "same task and loop as `value`, larger launch; the lane mapping is chosen from the launch size"}
 
 
-def build_host_port() -> str:
+def build_host_port(only: int | None = None) -> str:
     """The lane program (robot_lab_amd/csrc/env_step.h + env_terms.h, the source hipcc compiles) built for THIS box's CPU:
     g++ -O3 -march=native of tests/emu/rl_env_emu.cpp into a per-box cache (a -march=native object must not travel)."""
     import hashlib
@@ -287,9 +287,10 @@ def build_host_port() -> str:
     h = hashlib.sha1()
     for p in [src] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".inl"))) + [os.path.join(ROOT, "include", "rl_env.h")]:
         h.update(open(p, "rb").read())
-    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rl_env_host_port_{h.hexdigest()[:12]}.so")
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rl_env_host_port_{h.hexdigest()[:12]}_{only or 'all'}.so")
     if not os.path.isfile(cache):
-        subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", cache + ".tmp", src], check=True)
+        flags = [f"-DRL_EMU_ONLY={only}"] if only else []  # one lane-program instance: seconds instead of minutes of g++
+        subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-pthread", "-shared", "-fPIC", *flags, "-o", cache + ".tmp", src], check=True)
         os.replace(cache + ".tmp", cache)
     return cache
 
@@ -358,7 +359,10 @@ def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
     rng = np.random.default_rng(0)
     desc, extra = load_bundle(task)
     D = desc.model.num_dof
-    lib = build_host_port()
+    # the one-lane-per-limb instance of a 3-joint-leg quadruped (A1, Go2: key 31) when that is the task; everything else: all instances
+    m = desc.model
+    quad3 = m.num_trunk == 0 and m.chain_len == 3 and all(m.chain_nj[k] == 3 for k in range(4))
+    lib = build_host_port(31 if quad3 else None)
 
     def run(steps):
         """env-steps/s with one pinned thread per physical core, a fresh process (and pool) per measurement"""

@@ -470,7 +470,12 @@ template <class TP, int SUB>
 struct LsFor {  // lane scratchpad layout of an instance
   // link groups a sub-lane evaluates: g = sub + SUB * it over the groups 0 .. CL (merged instances: 1 .. CL, g = 1 + sub + SUB * it)
   static constexpr int NIT = (TP::CL + SUB - TP::M0) / SUB;
-  static constexpr int STASH = SUB > 1 ? NIT * TP::SPL : 0;  // every contact of pass 1 is kept for the sensor pass (slot it * SPL + s)
+  // every contact of pass 1 is kept for the sensor pass (slot it * SPL + s): in the lane scratchpad - or, with eight sub-lanes per limb
+  // (ONE link group per sub-lane: 4 slots x 9 words), in REGISTERS: 9.2 KB of LDS per wavefront less, which is what lets four
+  // wavefronts of the six-joint-spine instance (GR1) share a CU (2048 envs: 236 -> one round), and 72 scratchpad instructions per
+  // touching lane and substep
+  static constexpr bool STASH_REG = SUB == 8;
+  static constexpr int STASH = (SUB > 1 && !STASH_REG) ? NIT * TP::SPL : 0;
   static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::template maxown<SUB>();  // 16- / 8-lane mappings: rows for the owned slots only
   using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::template maxown<SUB>()), STASH>;
 };
@@ -479,7 +484,9 @@ template <class Ctx, class TP>
 struct EnvLane {
   static constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NB = TP::NB, SPL = TP::SPL, NBS = TP::NBS, NGRP = TP::CL + 1;
   using LS = typename LsFor<TP, Ctx::SUB>::type;
-  static constexpr bool STASH = LsFor<TP, Ctx::SUB>::STASH > 0;
+  static constexpr bool STASH_REG = LsFor<TP, Ctx::SUB>::STASH_REG;
+  static constexpr bool STASH = LsFor<TP, Ctx::SUB>::STASH > 0 || STASH_REG;
+  float stash_r[STASH_REG ? LsFor<TP, Ctx::SUB>::NIT * TP::SPL : 1][CONTACT_WORDS];  // the register stash (static indices only)
   static constexpr int LSS = Ctx::LS_STRIDE;
   static constexpr int SUB = Ctx::SUB;          // sub-lanes per leg (1: one lane per leg; 4: a DPP quad per leg)
   static constexpr int LPE = NLANE * SUB;       // lanes per environment
@@ -881,7 +888,10 @@ struct EnvLane {
       Contact c = contact_from_phi(Rwb, Vs, gi, s, rad_s, cb_s, phi_s, nw_s);
       if (c.act) {
         active_mask |= 1u << (gi * SPL + s);
-        if (STASH) {  // keep the contact for the sensor pass
+        if constexpr (STASH_REG) {  // keep the contact for the sensor pass (s is a compile-time constant at every call: the slots are unrolled)
+          float (&st)[CONTACT_WORDS] = stash_r[IT * SPL + s];
+          st[0] = c.x.x; st[1] = c.x.y; st[2] = c.x.z; st[3] = c.n.x; st[4] = c.n.y; st[5] = c.n.z; st[6] = c.bias; st[7] = c.dn; st[8] = c.dt;
+        } else if (STASH) {
           float* st = ctx.lane_scratch() + (LS::CT + (IT * SPL + s) * CONTACT_WORDS) * LSS;
           st[0 * LSS] = c.x.x; st[1 * LSS] = c.x.y; st[2 * LSS] = c.x.z; st[3 * LSS] = c.n.x; st[4 * LSS] = c.n.y; st[5 * LSS] = c.n.z;
           st[6 * LSS] = c.bias; st[7 * LSS] = c.dn; st[8 * LSS] = c.dt;
@@ -1768,11 +1778,18 @@ struct EnvLane {
         int slot[SPL];
 #pragma unroll
         for (int s2 = 0; s2 < SPL; ++s2) {
-          const float* st = ctx.lane_scratch() + (LS::CT + (it.value * SPL + s2) * CONTACT_WORDS) * LSS;
           c[s2].act = (bits >> s2) & 1u;
-          c[s2].x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
-          c[s2].n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
-          c[s2].bias = st[6 * LSS]; c[s2].dn = st[7 * LSS]; c[s2].dt = st[8 * LSS];
+          if constexpr (STASH_REG) {
+            const float (&st)[CONTACT_WORDS] = stash_r[it.value * SPL + s2];
+            c[s2].x = {st[0], st[1], st[2]};
+            c[s2].n = {st[3], st[4], st[5]};
+            c[s2].bias = st[6]; c[s2].dn = st[7]; c[s2].dt = st[8];
+          } else {
+            const float* st = ctx.lane_scratch() + (LS::CT + (it.value * SPL + s2) * CONTACT_WORDS) * LSS;
+            c[s2].x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
+            c[s2].n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
+            c[s2].bias = st[6 * LSS]; c[s2].dn = st[7 * LSS]; c[s2].dt = st[8 * LSS];
+          }
           slot[s2] = L.sph_slot[gi][s2];
         }
 #pragma unroll

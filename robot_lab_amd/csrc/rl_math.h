@@ -186,8 +186,10 @@ RL_FN uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a 
 RL_FN U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    // ONE 64-bit product per multiplier (v_mad_u64_u32): written as mulhi + mullo hipcc emits v_mul_hi_u32 AND v_mul_lo_u32 - forty
+    // quarter-rate multiplies per block instead of twenty
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c.x, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c.z;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;

@@ -457,22 +457,54 @@ struct Backend {
   void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
   void h2d_stream(void* d, const void* s, size_t n, void*) { std::memcpy(d, s, n); }
   int launch(const rl::KState& S, const void* T, int CL, void*) {
+    // -DRL_EMU_ONLY=<CL * 10 + sub> (+ 1000 merged, + 2000 six-joint trunk): instantiate that one lane program only (bench.py's CPU baseline
+    // builds the A1 one-lane-per-limb instance in 20 s instead of all fifteen in minutes)
     switch (CL * 10 + sub) {
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 31
       case 31: run<rl::TopoQuad3, 1>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 41
       case 41: run<rl::TopoQuad4, 1>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 34
       case 34: run<rl::TopoQuad3, 4>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 32
       case 32: run<rl::TopoQuad3, 2>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 42
       case 42: run<rl::TopoQuad4, 2>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 1042
       case 1042: run<rl::TopoQuad4M, 2>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 44
       case 44: run<rl::TopoQuad4, 4>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 1041
       case 1041: run<rl::TopoQuad4M, 1>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 1044
       case 1044: run<rl::TopoQuad4M, 4>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 71
       case 71: run<rl::TopoG1, 1>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 74
       case 74: run<rl::TopoG1, 4>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 78
       case 78: run<rl::TopoG1, 8>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 2078
       case 2078: run<rl::TopoGR, 8>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 2071
       case 2071: run<rl::TopoGR, 1>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 2074
       case 2074: run<rl::TopoGR, 4>(S, T); return 0;
+#endif
       default: err = "unsupported chain length"; return -1;
     }
   }
