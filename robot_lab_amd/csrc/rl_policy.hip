@@ -763,8 +763,12 @@ extern "C" {
 int rl_mlp_set_weights(rl_mlp* m, const float* const* weights, const float* const* biases, void* stream) {
   if (!m || !weights || !biases) return fail("null argument");
   if (hipSetDevice(m->device) != hipSuccess) return fail("hipSetDevice failed");
-  // launches in flight on the caller's stream read the old images: let them finish (the copies below are synchronous)
-  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail("stream synchronisation failed");
+  // launches in flight read the old images - on the caller's stream or on any other (a captured graph replaying on a second stream):
+  // let ALL of them finish (synchronising `stream` alone left a forward on another non-blocking stream reading
+  // half-updated weights); the copies below are synchronous, and a forward launched after this call returns sees the new f32 AND
+  // split-bf16 images, never a mix
+  (void)stream;
+  if (hipDeviceSynchronize() != hipSuccess) return fail("device synchronisation failed");
   for (int l = 0; l < m->P.n_layers; ++l)
     if (upload_layer(m, l, weights[l], biases[l])) return -1;
   return 0;

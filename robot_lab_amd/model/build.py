@@ -225,6 +225,18 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
 
         caps, pairs = fit(model, dq, list(trunk), [ch for _, ch in limbs], RL_MAX_CAPSULES, RL_MAX_SELF_PAIRS)
         m.num_capsules, m.num_self_pairs = len(caps), len(pairs)
+        # the pair force is an EXPLICIT spring (csrc/env_step.h self_apply): stable only while self_k dt^2 stays well below the inertia it
+        # acts on - checked against the lightest link that carries a capsule of a listed pair
+        sim_ = dict(DEFAULT_SIM)
+        sim_.update(spec.get("sim", {}))
+        k_dt2 = float(sim_["self_k"]) * float(sim_["dt"]) ** 2
+        in_pairs = {caps[i][0] for ab in pairs for i in ab}
+        link_mass = {l: sum(b.mass for b in model.bodies if b.link == l) for l in in_pairs}
+        if link_mass and k_dt2 > 0.5 * min(link_mass.values()):
+            import warnings
+
+            light = min(link_mass, key=link_mass.get)
+            warnings.warn(f"self-collision: self_k dt^2 = {k_dt2:.3f} kg against {link_mass[light]:.3f} kg of link '{model.links[light].name}': the explicit penalty spring may ring")
         for c, (link, p0, p1, r) in enumerate(caps):
             m.capsule_link[c], m.capsule_radius[c] = link, r
             set_arr(m.capsule_p0[c], p0)

@@ -106,11 +106,23 @@ def fit(model: RobotModel, default_q, trunk_links, limbs, max_capsules: int, max
     # which links: the base and the trunk links that have geometry; per limb its outermost link with geometry (hand, foot) and its
     # two largest others (G1: thigh + shin, upper arm + forearm)
     chosen = [l for l in [0] + list(trunk_links) if l in caps]
+    per_limb = []
     for chain in limbs:
         have = [l for l in chain if l in caps]
-        if have:
-            chosen.append(have[-1])
-            chosen += sorted(have[:-1], key=size, reverse=True)[:2]
+        per_limb.append(([have[-1]] + sorted(have[:-1], key=size, reverse=True)[:2]) if have else [])
+    # Over budget: drop the SMALLEST limb link of the limb that has the most left, round robin - never "whatever comes last", which took
+    # the capsules of the last limb(s) only and left self-collision acting on one side of the body.  Loudly.
+    chosen = list(dict.fromkeys(chosen))  # (a link listed twice would have taken two capsule slots)
+    total = len(chosen) + sum(len(x) for x in per_limb)
+    if total > max_capsules:
+        import warnings
+
+        warnings.warn(f"self-collision: {total} candidate links for {max_capsules} capsule slots - the smallest limb links are dropped, evenly over the limbs")
+        while len(chosen) + sum(len(x) for x in per_limb) > max_capsules and any(len(x) > 1 for x in per_limb):
+            k = max(range(len(per_limb)), key=lambda i: len(per_limb[i]))
+            per_limb[k].remove(min(per_limb[k][1:], key=size))  # ([0] is the outermost link - hand, foot: kept)
+    for x in per_limb:
+        chosen += [l for l in x if l not in chosen]
     chosen = sorted(chosen[:max_capsules])
     capsules = [(l, *caps[l]) for l in chosen]
     R, p = forward_kinematics(model, np.asarray(default_q, dtype=np.float64))

@@ -295,3 +295,39 @@ def test_a_hosted_spine_link_carries_the_robot(sub, emu_lib, monkeypatch):
     assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], k * 2e-3, k * 2e-3)
     assert_close("timers", host_view(nat, "CONTACT_TIMERS"), ora.timers, k * 1e-5, k * 1e-6)
     nat.close()
+
+
+@pytest.mark.parametrize("sub", ["1", "4", "8"])
+def test_six_joint_spine_without_contacts_meets_the_standard_bands(sub, emu_lib, monkeypatch):
+    """GR1's wider bands (k = 6 above) are calibrated to what its stiff two-foot contacts do to an fp32 step, not to an
+    independent estimate - a defect of the NW = 6 code paths (trunk links k and k + 4 sharing an owner, the dealt kinematics with 13
+    chain slots, the packed tables) could hide inside them.  So the same robot, same actions, in FREE FALL: kinematics, velocities,
+    elimination, trunk pieces and the outward pass are all exercised, the contact conditioning is not - held to the bands every other
+    robot gets (k = 1), in every lane mapping."""
+    from helpers import emu_load_state, emu_read_state
+
+    monkeypatch.setenv("RL_EMU_SUB", sub)
+    monkeypatch.setenv("RL_EMU_FIBERS", "1")
+    task, N = "RobotLab-Isaac-Velocity-Flat-FFTAI-GR1T1-v0", 4
+    desc, ora, nat = make_pair(task, N, 3, emu_lib)
+    ora.reset()
+    nat.reset()
+    state = emu_read_state(nat)
+    rs = state["root_state"].copy()
+    rs[:, 2] += 6.0  # six steps of 20 ms: it falls 7 cm
+    state["root_state"] = rs
+    emu_load_state(nat, state)
+    state = emu_read_state(nat)
+    ora.load_state(state)
+    rng = np.random.default_rng(9)
+    for s in range(6):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        ora.step(a)
+        nat.step(a.ctypes.data)
+        assert np.abs(ora.contact_force).max() == 0.0
+        assert_close(f"torque[{s}]", host_view(nat, "JOINT_TORQUE"), ora.applied_torque, 2e-3, 2e-3)
+    nat.export_state()
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), 1e-3, 1e-4)
+    assert_close("q", host_view(nat, "JOINT_POS"), ora.st["q"], 1e-3, 1e-4)
+    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], 2e-3, 2e-3)
+    nat.close()
