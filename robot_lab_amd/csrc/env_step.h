@@ -474,7 +474,11 @@ struct LsFor {  // lane scratchpad layout of an instance
   // (ONE link group per sub-lane: 4 slots x 9 words), in REGISTERS: 9.2 KB of LDS per wavefront less, which is what lets four
   // wavefronts of the six-joint-spine instance (GR1) share a CU (2048 envs: 236 -> one round), and 72 scratchpad instructions per
   // touching lane and substep
+#ifdef RL_STASH_REG_QUAD  // (A/B switch: the 16-lane quadruped kernels keep their 3-slot stash in registers as well)
+  static constexpr bool STASH_REG = SUB == 8 || (SUB == 4 && TP::NW == 0);
+#else
   static constexpr bool STASH_REG = SUB == 8;
+#endif
   static constexpr int STASH = (SUB > 1 && !STASH_REG) ? NIT * TP::SPL : 0;
   static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::template maxown<SUB>();  // 16- / 8-lane mappings: rows for the owned slots only
   using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::template maxown<SUB>()), STASH>;
