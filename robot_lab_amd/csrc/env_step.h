@@ -446,7 +446,19 @@ struct LsMat {
 // accumulator per trunk link (base, waist links, torso) that the limbs and the trunk links' owners ds_add into, and 8 words per
 // self-collision capsule (centre, half axis, radius, bounding radius in base coordinates: EnvLane::self_place).
 constexpr int LINK_REC = 27;  // 21 (6 x 6 symmetric) + 6
-constexpr int REC_STRIDE = 28; // ... stored as seven 16-byte vectors
+// How a link record sits in LDS.  Default: the packed upper triangle + rho as seven 16-byte vectors, every sub-lane of a limb eliminating
+// the whole record.  -DRL_ELIM_ROWS: six rows of 8 words [A[r][0..5], rho_r, 0] - the FULL matrix - so that the sub-lanes of a DPP quad
+// can each take rows of it (distributed elimination, EnvLane::eliminate_rows).  Measured in one call (profiles/r04h_elim_ab.txt): 1.2 k
+// fewer vector instructions per step and 20 more LDS words per record buy nothing - G1 107.5 against 107.7 us, GR1T1 126.4 against
+// 125.8 us: the elimination is a latency chain (reciprocal, quad sums and broadcasts per joint), not an issue-bound block.  Kept as an
+// analysis switch.
+#ifdef RL_ELIM_ROWS
+constexpr bool REC_ROWS = true;
+constexpr int REC_STRIDE = 48;
+#else
+constexpr bool REC_ROWS = false;
+constexpr int REC_STRIDE = 28;
+#endif
 // a limb's block padded to 4 (mod 32) words: the blocks of the 8 / 16 limbs of a wavefront then start in different banks (b32: 32 banks,
 // b128: 64), so that the same word of every limb - what a wavefront instruction touches - is conflict free
 constexpr int pad_limb_block(int w) { return ((w - 4 + 31) / 32) * 32 + 4; }
@@ -524,8 +536,37 @@ struct EnvLane {
   int e, k, sub, li, Np;  // env, leg, sub-lane of the leg, lane index inside the env (k * SUB + sub)
   static constexpr int MAXOWN = SUB == 1 ? NBS : LaneTabT<TP>::template maxown<SUB>();
   int own[MAXOWN];        // body slots this lane updates every substep (all of them when a lane is a whole leg)
+  // HBM state tiles.  Two address forms, picked per lane mapping (one-call A/B of both on three instances: profiles/r04i_state_buf_ab.txt):
+  //  * per-lane column pointers (lt / et; field f at lt[f * ROW]) - 16 / 8 / 32 lanes per env.  The compiler hoists the loop-invariant
+  //    loads of the substeps (link inertias, friction) out of the loop.
+  //  * BUFFERS - one lane per limb: a wave-uniform descriptor of the wavefront's tile (scalar registers), the lane's byte offset in a
+  //    field row (ONE vector register for all fields) and the field's row offset as the instruction's scalar offset
+  //    (buffer_load_dword v, v_off, s[rsrc], s_field offen).  With column pointers that instance - 512 registers in use - materialised
+  //    a separate vector address pair for every field beyond the 4 KB immediate range of global_load, hoisted the 27 of them out of the
+  //    substep loop and spilled them: 260 B of scratch.  Buffers: no scratch, 44 fewer registers, 108.4 -> 97.6 us at 16384 envs.
+  //    (The other mappings LOSE with buffers - A1 42.7 -> 50.5 us, G1 107.4 -> 127.6 us: buffer loads are not hoisted, every substep
+  //    re-reads its constants from HBM on the critical path of a lone wavefront.)
+#ifdef RL_STATE_BUF_ALL  // buffers in every mapping (A/B)
+  static constexpr bool STATE_BUF = true;
+#else
+  static constexpr bool STATE_BUF = SUB == 1;
+#endif
   float* lt;  // this leg's column of the wave tile:   field f -> lt[f * ROW]
   float* et;  // this env's column of the env tile:    field f -> et[f * EPT]
+  typename Ctx::StateBuf lt_b, et_b;  // the wavefront's lane-state / env-state tile
+  uint32_t lt_off, et_off;            // byte offset of this leg's / this env's column in a field row
+  // what LF(f) / EF(f) hand out: reads as a float, assigns as one
+  struct BufRef {
+    const typename Ctx::StateBuf& b;
+    uint32_t voff, soff;
+    RL_FN operator float() const { return Ctx::buf_ld(b, voff, soff); }
+    RL_FN float operator=(float v) const { Ctx::buf_st(b, voff, soff, v); return v; }
+  };
+  struct PtrRef {
+    float* p;
+    RL_FN operator float() const { return *p; }
+    RL_FN float operator=(float v) const { *p = v; return v; }
+  };
   // persistent state in registers
   V3 pos, vlin, vang;
   Q4 quat;
@@ -567,8 +608,15 @@ struct EnvLane {
       }
     }
     tim.set_own(own); hist_n.set_own(own); cf.set_own(own); fric.set_own(own);
-    lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
-    et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
+    if constexpr (STATE_BUF) {
+      lt_b = Ctx::state_buf(ctx.uniform_ptr(S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW)), (uint32_t)LY.NF_LANE * ROW * 4u);
+      et_b = Ctx::state_buf(ctx.uniform_ptr(S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT)), (uint32_t)LY.NF_ENV * (uint32_t)EPT * 4u);
+      lt_off = 4u * (uint32_t)(ctx.env_in_tile() * NLANE + k);
+      et_off = 4u * (uint32_t)ctx.env_in_tile();
+    } else {
+      lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
+      et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
+    }
   }
 #ifdef RL_PHASE_CLOCK_ON
   long long ph_t0 = 0;
@@ -585,8 +633,20 @@ struct EnvLane {
     ph_t0 = (long long)__builtin_readcyclecounter();
   }
 #endif
-  RL_FN float& LF(int f) const { return lt[(uint32_t)f * ROW]; }
-  RL_FN float& EF(int f) const { return et[(uint32_t)f * (uint32_t)EPT]; }
+  // (a field index known at compile time rides in the scalar offset; one that differs between lanes - the link of a lane's group, 16 / 32
+  // lanes per env - must go into the vector offset: a divergent scalar offset is a waterfall loop per load)
+  RL_FN auto LF(int f) const {
+    if constexpr (STATE_BUF) {
+      const uint32_t o = (uint32_t)f * ROW * 4u;
+      return __builtin_constant_p(f) ? BufRef{lt_b, lt_off, o} : BufRef{lt_b, lt_off + o, 0u};
+    } else return PtrRef{lt + (uint32_t)f * ROW};
+  }
+  RL_FN auto EF(int f) const {
+    if constexpr (STATE_BUF) {
+      const uint32_t o = (uint32_t)f * (uint32_t)EPT * 4u;
+      return __builtin_constant_p(f) ? BufRef{et_b, et_off, o} : BufRef{et_b, et_off + o, 0u};
+    } else return PtrRef{et + (uint32_t)f * (uint32_t)EPT};
+  }
   // link group g (0 = base share, 1.. = chain links) is evaluated by sub-lane g % SUB of the leg; merged instances (Topo::M0) have
   // no group 0 - their base-share spheres sit in flagged slots of group 1 -, group g is sub-lane (g - 1) % SUB's and the trunk
   // body's slot (group 0) belongs to sub-lane 0
@@ -1228,21 +1288,124 @@ struct EnvLane {
   RL_FN float* rec_words(int g) const { return ctx.limb_rec() + LB_REC + (g - 1) * REC_STRIDE; }  // link group g = limb link g - 1 (1 .. CL)
   RL_FN float* va_words(int j) const { return ctx.limb_rec() + LB_VA + j * 12; }
   RL_FN float* trunk_words(int d) const { return ctx.env_scratch() + d * REC_STRIDE; }
-  // a link record <-> its seven vectors
+  // a link record <-> LDS (REC_ROWS: six rows of [A[r][0..5], rho_r, 0]; else seven vectors of the packed upper triangle + rho)
   RL_FN static void st_rec(float* w, const LinkRec& r) {
+    if constexpr (REC_ROWS) {
 #pragma unroll
-    for (int v = 0; v < 5; ++v) st4(w + 4 * v, F4{r.A[4 * v], r.A[4 * v + 1], r.A[4 * v + 2], r.A[4 * v + 3]});
-    st4(w + 20, F4{r.A[20], r.r[0], r.r[1], r.r[2]});
-    st4(w + 24, F4{r.r[3], r.r[4], r.r[5], 0.f});
+      for (int q = 0; q < 6; ++q) {
+        st4(w + 8 * q, F4{r.A[B6::at(q, 0)], r.A[B6::at(q, 1)], r.A[B6::at(q, 2)], r.A[B6::at(q, 3)]});
+        st4(w + 8 * q + 4, F4{r.A[B6::at(q, 4)], r.A[B6::at(q, 5)], r.r[q], 0.f});
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < 5; ++v) st4(w + 4 * v, F4{r.A[4 * v], r.A[4 * v + 1], r.A[4 * v + 2], r.A[4 * v + 3]});
+      st4(w + 20, F4{r.A[20], r.r[0], r.r[1], r.r[2]});
+      st4(w + 24, F4{r.r[3], r.r[4], r.r[5], 0.f});
+    }
   }
-  RL_FN static void add_rec(const float* w, LinkRec& P) {
-    F4 v[7];
+  RL_FN static void add_rec(const float* w, LinkRec& P) {  // (the replicated elimination: the whole record into every lane)
+    if constexpr (REC_ROWS) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) v[i] = ld4(w + 4 * i);
+      for (int q = 0; q < 6; ++q) {
+        const F4 a = ld4(w + 8 * q), c = ld4(w + 8 * q + 4);
+        const float row[6] = {a.x, a.y, a.z, a.w, c.x, c.y};
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { P.A[4 * i] += v[i].x; P.A[4 * i + 1] += v[i].y; P.A[4 * i + 2] += v[i].z; P.A[4 * i + 3] += v[i].w; }
-    P.A[20] += v[5].x; P.r[0] += v[5].y; P.r[1] += v[5].z; P.r[2] += v[5].w;
-    P.r[3] += v[6].x; P.r[4] += v[6].y; P.r[5] += v[6].z;
+        for (int cc = q; cc < 6; ++cc) P.A[B6::at(q, cc)] += row[cc];
+        P.r[q] += c.z;
+      }
+    } else {
+      F4 v[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) v[i] = ld4(w + 4 * i);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { P.A[4 * i] += v[i].x; P.A[4 * i + 1] += v[i].y; P.A[4 * i + 2] += v[i].z; P.A[4 * i + 3] += v[i].w; }
+      P.A[20] += v[5].x; P.r[0] += v[5].y; P.r[1] += v[5].z; P.r[2] += v[5].w;
+      P.r[3] += v[6].x; P.r[4] += v[6].y; P.r[5] += v[6].z;
+    }
+  }
+  RL_FN static float* rho_word(float* w, int r) { return REC_ROWS ? w + 8 * r + 6 : w + B6::size + r; }  // rho_r of a record at w
+  RL_FN static void atomic_add_rec(float* w, const LinkRec& r) {  // ds_add_f32 of a whole record (several lanes of an env add into one)
+    if constexpr (REC_ROWS) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Ctx::limb_atomic_add(w + 8 * q + c, r.A[B6::at(q, c)]);
+        Ctx::limb_atomic_add(w + 8 * q + 6, r.r[q]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(w + i, r.A[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + B6::size + i, r.r[i]);
+    }
+  }
+
+  // ---- DISTRIBUTED elimination (trunk + limbs instances, SUB >= 4): the four lanes of a DPP quad hold identical copies of everything the
+  // limb recursion needs, so they SHARE a joint's 6 x 6 work by rows instead of each repeating it: quad lane q carries row q of the
+  // articulated inertia (and row q + 4 where q < 2; the other two lanes a zero phantom row) and its rho entries.  Per joint: the lane's
+  // one or two rows of the link record from LDS (2 - 4 vectors instead of 7), U_r = P_r . s (12 FMA instead of 36), D and u as two quad
+  // sums, U / D gathered into every lane with six quad broadcasts, the rank-1 update of the lane's rows (14 FMA instead of 27).
+  // ~60 vector instructions per joint instead of ~140; same linear system, the sums in tree order.
+  static constexpr bool ELIM_DIST = REC_ROWS && SUB >= 4 && NW > 0;
+  struct Rows {
+    float a[6], ra, b[6], rb;
+  };
+  RL_FN static void rows_zero(Rows& P) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) P.a[c] = P.b[c] = 0.f;
+    P.ra = P.rb = 0.f;
+  }
+  RL_FN void rows_add(const float* w, Rows& P) const {
+    const int q = sub & 3, rb = q < 2 ? q + 4 : 5;
+    const float wb = q < 2 ? 1.f : 0.f;
+    const F4 a0 = ld4(w + 8 * q), a1 = ld4(w + 8 * q + 4), b0 = ld4(w + 8 * rb), b1 = ld4(w + 8 * rb + 4);
+    P.a[0] += a0.x; P.a[1] += a0.y; P.a[2] += a0.z; P.a[3] += a0.w; P.a[4] += a1.x; P.a[5] += a1.y; P.ra += a1.z;
+    P.b[0] += wb * b0.x; P.b[1] += wb * b0.y; P.b[2] += wb * b0.z; P.b[3] += wb * b0.w; P.b[4] += wb * b1.x; P.b[5] += wb * b1.y; P.rb += wb * b1.z;
+  }
+  RL_FN static void rows_acc(Rows& P, const Rows& Q) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { P.a[c] += Q.a[c]; P.b[c] += Q.b[c]; }
+    P.ra += Q.ra; P.rb += Q.rb;
+  }
+  RL_FN void eliminate_rows(Rows& P, const float (&s6)[6], float D0, float u0, float (&Uh)[6], float& ui) const {
+    const int q = sub & 3;
+    float Ua = 0.f, Ub = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { Ua += P.a[c] * s6[c]; Ub += P.b[c] * s6[c]; }
+    // the lane's own entries of s: a 0/1-weighted sum (a select chain on q is lowered to a jump table of exec-masked blocks)
+    const float e0 = q == 0 ? 1.f : 0.f, e1 = q == 1 ? 1.f : 0.f, e2 = q == 2 ? 1.f : 0.f, e3 = q == 3 ? 1.f : 0.f;
+    const float sa = e0 * s6[0] + e1 * s6[1] + e2 * s6[2] + e3 * s6[3], sb = e0 * s6[4] + e1 * s6[5];
+    const float D = D0 + ctx.quad_sum(sa * Ua + sb * Ub), uu = u0 + ctx.quad_sum(sa * P.ra + sb * P.rb);
+    const float inv = frcp(D);
+    ui = uu * inv;
+    const float Uha = Ua * inv, Uhb = Ub * inv;
+    Uh[0] = ctx.template quad_bcast<0>(Uha); Uh[1] = ctx.template quad_bcast<1>(Uha); Uh[2] = ctx.template quad_bcast<2>(Uha);
+    Uh[3] = ctx.template quad_bcast<3>(Uha); Uh[4] = ctx.template quad_bcast<0>(Uhb); Uh[5] = ctx.template quad_bcast<1>(Uhb);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { P.a[c] -= Ua * Uh[c]; P.b[c] -= Ub * Uh[c]; }
+    P.ra -= Ua * ui;
+    P.rb -= Ub * ui;
+  }
+  RL_FN void rows_atomic_add(float* w, const Rows& P) const {  // the lane's rows into an accumulator record (every row by exactly one lane)
+    const int q = sub & 3;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Ctx::limb_atomic_add(w + 8 * q + c, P.a[c]);
+    Ctx::limb_atomic_add(w + 8 * q + 6, P.ra);
+    if (q < 2) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Ctx::limb_atomic_add(w + 8 * (q + 4) + c, P.b[c]);
+      Ctx::limb_atomic_add(w + 8 * (q + 4) + 6, P.rb);
+    }
+  }
+  RL_FN void rows_gather(const Rows& P, float (&A)[B6::size], float (&r)[6]) const {  // the whole (symmetric) system into every lane of the quad
+    static_for<0, 6>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int R = decltype(rc)::value, Q = R & 3;
+      static_for<R, 6>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int Cc = decltype(cc)::value;
+        A[B6::at(R, Cc)] = ctx.template quad_bcast<Q>(R < 4 ? P.a[Cc] : P.b[Cc]);
+      });
+      r[R] = ctx.template quad_bcast<Q>(R < 4 ? P.ra : P.rb);
+    });
   }
   RL_FN static SV ld_sv(const float* w) {  // six words, the first two vectors of a record / per-joint block
     const F4 a = ld4(w), c = ld4(w + 4);
@@ -1295,9 +1458,9 @@ struct EnvLane {
   RL_FN void self_add(int kk, int gg, V3 x, V3 F) {  // dt * [x cross F; F] onto the bias of a link record (limb kk's group gg; kk = 7: trunk depth gg)
     const V3 m = u.dt * cross(x, F), f = u.dt * F;
     const float v6[6] = {m.x, m.y, m.z, f.x, f.y, f.z};
-    float* w = (kk == 7 ? trunk_words(gg) : ctx.limb_rec_of(kk) + LB_REC + (gg - 1) * REC_STRIDE) + B6::size;
+    float* w = kk == 7 ? trunk_words(gg) : ctx.limb_rec_of(kk) + LB_REC + (gg - 1) * REC_STRIDE;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + i, v6[i]);
+    for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(rho_word(w, i), v6[i]);
   }
   RL_FN void self_apply() {
     if constexpr (NW > 0) {
@@ -1440,7 +1603,6 @@ struct EnvLane {
                  });
     }
     if (self_on()) self_place(C);  // (a lane reads frames of its own limb's words only: written by itself, identically in every sub-lane)
-    for (int i = li; i < (NW + 1) * REC_STRIDE; i += LPE) ctx.env_scratch()[i] = 0.f;
 #else
     kinematics(C);
     if (self_on()) self_place(C);  // (a lane reads frames of its own limb's words only: written by itself, identically in every sub-lane)
@@ -1481,9 +1643,39 @@ struct EnvLane {
         Vp = Vj;
         ap = aj;
       }
-      for (int i = li; i < (NW + 1) * REC_STRIDE; i += LPE) ctx.env_scratch()[i] = 0.f;
     }
 #endif
+    // The env's accumulator records (one per trunk link, 0 = the base link) start as the trunk links' own rigid records - plain stores,
+    // no clearing pass: the first sub-lane of lane group k owns the trunk links k, k + 4 (a spine of more than three joints has more
+    // trunk links than limbs); the persistent external wrench [UPSTREAM B8] rides on its link's record.  Contacts of trunk-link spheres,
+    // self-collision forces and the eliminated limbs are ADDED behind the fence below.
+    if (sub == 0) {
+#pragma unroll
+      for (int tq = 0; tq < (NW + NLANE) / NLANE; ++tq) {
+        const int tk = k + NLANE * tq;
+        if (tk > NW) continue;
+        const int bi = LY.EF_BASE_INERTIA + tk * INERTIA_NF;
+        M3 Rf;
+        V3 pf;
+        trunk_frame<TP>(C, tk, Rf, pf);
+        const SV Vl = pick_trunk(V0, Vw, tk), al = pick_trunk(a0, aw, tk);
+        const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
+        const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
+        SV fx{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (tk == T.wrench_depth) {
+          const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
+          fx.a = -(mul(Rf, extT) + cross(xc, Fb));
+          fx.l = -Fb;
+        }
+        LinkRec tr;
+#pragma unroll
+        for (int i = 0; i < B6::size; ++i) tr.A[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tr.r[i] = 0.f;
+        add_rigid(tr, I0, Vl, al, fx);
+        st_rec(trunk_words(tk), tr);
+      }
+    }
     ctx.group_sync();
     // ---- per link group this lane owns: contacts + rigid record -> the limb's record words (group 0 = the lane's share of a
     // trunk link's spheres: straight into that trunk link's accumulator)
@@ -1530,11 +1722,7 @@ struct EnvLane {
       if (has) {
         st_rec(rec_words(g), rec);
       } else if (g == 0 && active_mask != before) {  // contacts of the trunk-link share
-        float* w = trunk_words(L.grp0_depth);
-#pragma unroll
-        for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(w + i, rec.A[i]);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + B6::size + i, rec.r[i]);
+        atomic_add_rec(trunk_words(L.grp0_depth), rec);
       }
     });
     ctx.group_sync();
@@ -1542,101 +1730,108 @@ struct EnvLane {
       self_apply();
       ctx.group_sync();
     }
-    // ---- limb elimination, tip -> attachment (every sub-lane: same values; results parked for the outward pass)
+    // ---- limb elimination, tip -> attachment (results parked for the outward pass), the limb as seen from its attachment link into the
+    // env's accumulator; then the trunk elimination, trunk pieces that hang off the base parked on the way, and the base solve.
+    // ELIM_DIST: the 6 x 6 work of a joint shared by rows among the lanes of a DPP quad (see eliminate_rows); otherwise every sub-lane
+    // eliminates whole records.
     RL_PHASE(9, "sub.aba");
-    LinkRec P;
-#pragma unroll
-    for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
-#pragma unroll
-    for (int j = CL - 1; j >= 0; --j) {
-      add_rec(rec_words(j + 1), P);
-      V3 ax, pj;
-      C.axp(j, ax, pj);
-      const V3 lx = cross(pj, ax);
-      const float s6[6] = {ax.x, ax.y, ax.z, lx.x, lx.y, lx.z};
-      float D, uu, Uh[6], ui;
-      joint_terms(j, j >= L.nj, tau_e, pd_diag, pd_rhs, D, uu);
-      eliminate(P, s6, D, uu, Uh, ui);
-      float* o = va_words(j);  // (the link velocities parked here are no longer needed)
-      st4(o, F4{Uh[0], Uh[1], Uh[2], Uh[3]});
-      st4(o + 4, F4{Uh[4], Uh[5], ui, 0.f});
-    }
-    // the limb as seen from its attachment link, and the trunk links' own rigid records, into the env's accumulators
-    if (sub == 0) {
-      float* w = trunk_words(L.attach);
-#pragma unroll
-      for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(w + i, P.A[i]);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + B6::size + i, P.r[i]);
-      // lane group k also owns the trunk links k, k + 4 (0 = the base link; a spine of more than three joints has more trunk links
-      // than limbs); the persistent external wrench [UPSTREAM B8]
-#pragma unroll
-      for (int tq = 0; tq < (NW + NLANE) / NLANE; ++tq) {
-        const int tk = k + NLANE * tq;
-        if (tk > NW) continue;
-        const int bi = LY.EF_BASE_INERTIA + tk * INERTIA_NF;
-        M3 Rf;
-        V3 pf;
-        trunk_frame<TP>(C, tk, Rf, pf);
-        const SV Vl = pick_trunk(V0, Vw, tk), al = pick_trunk(a0, aw, tk);
-        const V3 cbl = pf + mul(Rf, V3{EF(bi + 1), EF(bi + 2), EF(bi + 3)});
-        const SI I0 = make_si(EF(bi), cbl, rotate(Rf, S3{EF(bi + 4), EF(bi + 5), EF(bi + 6), EF(bi + 7), EF(bi + 8), EF(bi + 9)}));
-        SV fx{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-        if (tk == T.wrench_depth) {
-          const V3 Fb = mul(Rf, extF), xc = pf + mul(Rf, wr_com);
-          fx.a = -(mul(Rf, extT) + cross(xc, Fb));
-          fx.l = -Fb;
-        }
-        LinkRec tr;
-#pragma unroll
-        for (int i = 0; i < B6::size; ++i) tr.A[i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) tr.r[i] = 0.f;
-        add_rigid(tr, I0, Vl, al, fx);
-        float* wt = trunk_words(tk);
-#pragma unroll
-        for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(wt + i, tr.A[i]);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(wt + B6::size + i, tr.r[i]);
-      }
-    }
-    ctx.group_sync();
-    // ---- trunk elimination (every lane), base solve, velocities outwards
-    RL_PHASE(10, "sub.cross_leg_sum");
-#pragma unroll
-    for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
     float Uhw[NW][6], uiw[NW];
-    LinkRec Pb;  // what the trunk pieces already eliminated hand to the base (a piece ends where its first joint hangs off the base)
-#pragma unroll
-    for (int i = 0; i < B6::size; ++i) Pb.A[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Pb.r[i] = 0.f;
-#pragma unroll
-    for (int d = NW; d >= 1; --d) {
-      add_rec(trunk_words(d), P);
-      const float s6[6] = {Sw[d - 1].a.x, Sw[d - 1].a.y, Sw[d - 1].a.z, Sw[d - 1].l.x, Sw[d - 1].l.y, Sw[d - 1].l.z};
-      float D, uu;
-      joint_terms(CL + d - 1, d - 1 >= T.nw_used, tau_e, pd_diag, pd_rhs, D, uu);
-      eliminate(P, s6, D, uu, Uhw[d - 1], uiw[d - 1]);
-      if (d > 1 && ((u.trunk_restart >> (d - 1)) & 1u)) {  // (wave-uniform) joint d - 1 hangs off the base: park the piece, the next joint starts another
-#pragma unroll
-        for (int i = 0; i < B6::size; ++i) { Pb.A[i] += P.A[i]; P.A[i] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { Pb.r[i] += P.r[i]; P.r[i] = 0.f; }
-      }
-    }
-    add_rec(trunk_words(0), P);
-#pragma unroll
-    for (int i = 0; i < B6::size; ++i) P.A[i] += Pb.A[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) P.r[i] += Pb.r[i];
-    RL_PHASE(11, "sub.trunk_solve");
     float nu0[NB], qdn[JX];
-    {
+    if constexpr (ELIM_DIST) {
+      Rows P;
+      rows_zero(P);
+#pragma unroll
+      for (int j = CL - 1; j >= 0; --j) {
+        rows_add(rec_words(j + 1), P);
+        V3 ax, pj;
+        C.axp(j, ax, pj);
+        const V3 lx = cross(pj, ax);
+        const float s6[6] = {ax.x, ax.y, ax.z, lx.x, lx.y, lx.z};
+        float D, uu, Uh[6], ui;
+        joint_terms(j, j >= L.nj, tau_e, pd_diag, pd_rhs, D, uu);
+        eliminate_rows(P, s6, D, uu, Uh, ui);
+        float* o = va_words(j);  // (the link velocities parked here are no longer needed)
+        st4(o, F4{Uh[0], Uh[1], Uh[2], Uh[3]});
+        st4(o + 4, F4{Uh[4], Uh[5], ui, 0.f});
+      }
+      if (sub < 4) rows_atomic_add(trunk_words(L.attach), P);  // (eight sub-lanes per limb: its second quad holds a copy)
+      ctx.group_sync();
+      RL_PHASE(10, "sub.cross_leg_sum");
+      rows_zero(P);
+      Rows Pb;  // what the trunk pieces already eliminated hand to the base (a piece ends where its first joint hangs off the base)
+      rows_zero(Pb);
+#pragma unroll
+      for (int d = NW; d >= 1; --d) {
+        rows_add(trunk_words(d), P);
+        const float s6[6] = {Sw[d - 1].a.x, Sw[d - 1].a.y, Sw[d - 1].a.z, Sw[d - 1].l.x, Sw[d - 1].l.y, Sw[d - 1].l.z};
+        float D, uu;
+        joint_terms(CL + d - 1, d - 1 >= T.nw_used, tau_e, pd_diag, pd_rhs, D, uu);
+        eliminate_rows(P, s6, D, uu, Uhw[d - 1], uiw[d - 1]);
+        if (d > 1 && ((u.trunk_restart >> (d - 1)) & 1u)) {  // (wave-uniform) joint d - 1 hangs off the base: park the piece, the next joint starts another
+          rows_acc(Pb, P);
+          rows_zero(P);
+        }
+      }
+      rows_add(trunk_words(0), P);
+      rows_acc(P, Pb);
+      RL_PHASE(11, "sub.trunk_solve");
+      float A6[B6::size], r6[6], n6[6];
+      rows_gather(P, A6, r6);
+      solve6(A6, r6, n6);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) nu0[i] = n6[i];
+    } else {
+      LinkRec P;
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
+#pragma unroll
+      for (int j = CL - 1; j >= 0; --j) {
+        add_rec(rec_words(j + 1), P);
+        V3 ax, pj;
+        C.axp(j, ax, pj);
+        const V3 lx = cross(pj, ax);
+        const float s6[6] = {ax.x, ax.y, ax.z, lx.x, lx.y, lx.z};
+        float D, uu, Uh[6], ui;
+        joint_terms(j, j >= L.nj, tau_e, pd_diag, pd_rhs, D, uu);
+        eliminate(P, s6, D, uu, Uh, ui);
+        float* o = va_words(j);  // (the link velocities parked here are no longer needed)
+        st4(o, F4{Uh[0], Uh[1], Uh[2], Uh[3]});
+        st4(o + 4, F4{Uh[4], Uh[5], ui, 0.f});
+      }
+      if (sub == 0) atomic_add_rec(trunk_words(L.attach), P);
+      ctx.group_sync();
+      RL_PHASE(10, "sub.cross_leg_sum");
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
+      LinkRec Pb;  // what the trunk pieces already eliminated hand to the base (a piece ends where its first joint hangs off the base)
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) Pb.A[i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Pb.r[i] = 0.f;
+#pragma unroll
+      for (int d = NW; d >= 1; --d) {
+        add_rec(trunk_words(d), P);
+        const float s6[6] = {Sw[d - 1].a.x, Sw[d - 1].a.y, Sw[d - 1].a.z, Sw[d - 1].l.x, Sw[d - 1].l.y, Sw[d - 1].l.z};
+        float D, uu;
+        joint_terms(CL + d - 1, d - 1 >= T.nw_used, tau_e, pd_diag, pd_rhs, D, uu);
+        eliminate(P, s6, D, uu, Uhw[d - 1], uiw[d - 1]);
+        if (d > 1 && ((u.trunk_restart >> (d - 1)) & 1u)) {  // (wave-uniform) joint d - 1 hangs off the base: park the piece, the next joint starts another
+#pragma unroll
+          for (int i = 0; i < B6::size; ++i) { Pb.A[i] += P.A[i]; P.A[i] = 0.f; }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { Pb.r[i] += P.r[i]; P.r[i] = 0.f; }
+        }
+      }
+      add_rec(trunk_words(0), P);
+#pragma unroll
+      for (int i = 0; i < B6::size; ++i) P.A[i] += Pb.A[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) P.r[i] += Pb.r[i];
+      RL_PHASE(11, "sub.trunk_solve");
       float n6[6];
       solve6(P.A, P.r, n6);
 #pragma unroll

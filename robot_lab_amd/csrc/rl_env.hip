@@ -85,11 +85,11 @@ struct Backend {
   //   2 (a lane pair per limb, 8 envs per wavefront): 1.15x the instructions per wavefront for twice the envs;
   //   1 (a lane per limb, 16 envs per wavefront): the throughput mapping, ~2x the instructions for 4x the envs.
   // A wavefront owns its SIMD (300 - 500 registers), so every mapping runs in ROUNDS of `slots` wavefronts (4 per CU when the LDS
-  // allows it - four wavefronts of a workgroup share one staged table image), and a round costs 1 : 1.45 : 2.48 (43.5 / 62.5 / 107
-  // us on A1 Rough with the chip full; Go2W 49.5 / 69.5 / 132: profiles/r03j_sweep_three_mappings.txt).  The choice is the mapping
+  // allows it - four wavefronts of a workgroup share one staged table image), and a round costs 1 : 1.45 : 2.29 (42.6 / 61.6 / 97.6
+  // us on A1 Rough with the chip full, round 4; round 3: 43.5 / 62.5 / 107; Go2W 49.5 / 69.5 / 132: profiles/r03j_sweep_three_mappings.txt).  The choice is the mapping
   // with the cheapest ceil(wavefronts / slots) x cost; on a near-tie the one with more lanes per env (shorter step latency).
   // A1 Rough: <= 4096 envs 16 lanes (43 us), 4097 - 8192 envs 8 lanes (8192: 62.5 us = 131 M env-steps/s against 95 M), ~8.5 k - 16 k
-  // envs one lane per limb (16384: 107 us = 153 M), and so on by the same rule.  RL_ENV_SUB=4|2|1 forces a mapping; the trunk + limbs
+  // envs one lane per limb (16384: 97.6 us = 168 M), and so on by the same rule.  RL_ENV_SUB=4|2|1 forces a mapping; the trunk + limbs
   // instance has 4 only.
   int sub = 4;
   int envs_per_wave(const Tables& T, int Npad) {
@@ -125,7 +125,7 @@ struct Backend {
         default: break;
       }
       const int subs[3] = {4, 2, 1};
-      const double cost[3] = {1.0, 1.45, 2.48};
+      const double cost[3] = {1.0, 1.45, 2.29};  // (one lane per limb: 97.6 us since its state tiles are addressed as buffers, profiles/r04i_state_buf_ab.txt)
       double best = 0.0, t[3] = {0.0, 0.0, 0.0};
       for (int i = 0; i < 3; ++i) {
         if (need[i] == 0 || need[i] > 160 * 1024) continue;

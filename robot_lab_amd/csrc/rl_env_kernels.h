@@ -64,6 +64,23 @@ struct WaveCtx {
   __device__ float* env_scratch() const { return envs; }
   __device__ float uniform(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
   __device__ int uniform_i(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+  // a tile of the HBM state as a raw buffer (stride 0, `bytes` long: reads beyond it return 0, writes are dropped)
+  struct StateBuf {
+    __amdgpu_buffer_rsrc_t rs;
+  };
+  __device__ static StateBuf state_buf(float* uniform_base, uint32_t bytes) { return StateBuf{__builtin_amdgcn_make_buffer_rsrc(uniform_base, 0, (int)bytes, 0x00020000)}; }
+  __device__ static float buf_ld(const StateBuf& b, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.rs, (int)voff, (int)soff, 0));
+  }
+  __device__ static void buf_st(const StateBuf& b, uint32_t voff, uint32_t soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), b.rs, (int)voff, (int)soff, 0);
+  }
+  template <class P>
+  __device__ static P* uniform_ptr(P* p) {  // a pointer every lane holds the same value of: into scalar registers
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<P*>(((uint64_t)hi << 32) | lo);
+  }
   __device__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
   template <class TT>
   __device__ const TT& tables() const { return *static_cast<const TT*>(T); }
@@ -128,6 +145,15 @@ struct WaveCtx {
       return ((lane >> 2) & 1) == (J >> 2) ? t : o;
     } else return dpp_move<J | (J << 2) | (J << 4) | (J << 6)>(v);
   }
+  // the lane's DPP quad (SUB >= 4: four sub-lanes of one limb): sum over it (identical bits in its four lanes: (x0 + x1) + (x2 + x3) either
+  // way round) and the value of its lane J
+  __device__ static float quad_sum(float v) {
+    v += dpp<DPP_QUAD_XOR1>(v);
+    v += dpp<DPP_QUAD_XOR2>(v);
+    return v;
+  }
+  template <int J>
+  __device__ static float quad_bcast(float v) { return dpp_move<J | (J << 2) | (J << 4) | (J << 6)>(v); }
   // the dealing of per-joint work (chain_kinematics_dealt) is among the four lanes of a DPP quad in every mapping with SUB >= 4
   template <int J>
   __device__ __forceinline__ M3 deal_bcast_m3(const M3& m) const {

@@ -263,6 +263,17 @@ struct HostCtx {
   float* env_scratch() { return team->envw; }
   float uniform(float v) const { return v; }
   int uniform_i(int v) const { return v; }
+  template <class P>
+  static P* uniform_ptr(P* p) { return p; }
+  struct StateBuf {
+    char* p = nullptr;
+    uint32_t bytes = 0;
+  };
+  static StateBuf state_buf(float* base, uint32_t bytes) { return StateBuf{reinterpret_cast<char*>(base), bytes}; }
+  static float buf_ld(const StateBuf& b, uint32_t voff, uint32_t soff) { return voff + soff < b.bytes ? *reinterpret_cast<const float*>(b.p + voff + soff) : 0.f; }
+  static void buf_st(const StateBuf& b, uint32_t voff, uint32_t soff, float v) {
+    if (voff + soff < b.bytes) *reinterpret_cast<float*>(b.p + voff + soff) = v;
+  }
   Team<LPE>* team;
   const void* T;
   int k_, sub_, e_, sense_ = 0;
@@ -322,6 +333,24 @@ struct HostCtx {
     team->slot[li()] = v;
     team->barrier(li());
     float r = team->slot[k_ * SUB + (J < SUB ? J : 0)];
+    team->barrier(li());
+    return r;
+  }
+  // the lane's DPP quad (SUB >= 4): the four sub-lanes sub_ & ~3 .. of its limb
+  float quad_sum(float v) {
+    team->slot[li()] = v;
+    team->barrier(li());
+    const float* p = team->slot + k_ * SUB + (sub_ & ~3);
+    const float a = p[0] + p[1], b = p[2 % SUB] + p[3 % SUB];
+    const float s = (sub_ & 2) ? b + a : a + b;
+    team->barrier(li());
+    return s;
+  }
+  template <int J>
+  float quad_bcast(float v) {
+    team->slot[li()] = v;
+    team->barrier(li());
+    const float r = team->slot[k_ * SUB + (((sub_ & ~3) + J) % SUB)];
     team->barrier(li());
     return r;
   }
