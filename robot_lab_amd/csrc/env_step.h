@@ -624,7 +624,7 @@ struct EnvLane {
   __device__ __forceinline__ void phase_stamp(int id) {
     __builtin_amdgcn_s_waitcnt(0);
     const long long t = (long long)__builtin_readcyclecounter();
-    if (ctx.lane == 0) {
+    if (ctx.lane == 0 && ph_t0 != 0) {  // (the first stamp has no predecessor)
       float* row = S.rew_terms + (size_t)RL_PHASE_ROW0 * (size_t)S.Npad + (size_t)ctx.tile() * RL_PHASE_SLOTS;
       row[ph_cur] += (float)(t - ph_t0);
     }
