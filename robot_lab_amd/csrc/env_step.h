@@ -207,6 +207,14 @@ RL_FN void st4(float* p, F4 v) {
 #endif
 }
 
+// a joint's packed constants (LaneTabT::jc): origin and axis in the parent link frame
+template <class LT>
+RL_FN void joint_origin_axis(const LT& L, int j, V3& origin, V3& axis) {
+  const F4 c0 = ld4(L.jc[j]), c1 = ld4(L.jc[j] + 4);
+  origin = {c0.x, c0.y, c0.z};
+  axis = {c0.w, c1.x, c1.y};
+}
+
 // Kinematics in base coordinates: the lane's limb (R, p, ax per joint) and the trunk joints (Rw, pw, axw).
 // Two storage modes behind one accessor interface:
 //   * registers (quadrupeds: 3-4 joints, everything stays in VGPRs);
@@ -314,9 +322,10 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
   for (int i = 0; i < NW; ++i) {  // trunk joints (same in every lane)
     const int jx = CL + i;
     if (i > 0 && ((restart >> i) & 1u)) { Rp = identity3(); pp = {0.f, 0.f, 0.f}; }
-    V3 al = ld3(L.axis[jx]);
+    V3 al, oj;
+    joint_origin_axis(L, jx, oj, al);
     M3 Rj0 = mul(Rp, ld_m3(L.rot0[TP::ROT ? jx : 0]));
-    V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
+    V3 pj = pp + mul(Rp, oj);
     M3 Rj = mul(Rj0, rodrigues(al, q[jx]));
     const V3 aw = mul(Rj0, al);
     C.setw(i, Rj, pj, aw);
@@ -329,8 +338,9 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
   pp = pa;
 #pragma unroll
   for (int j = 0; j < CL; ++j) {
-    V3 al = ld3(L.axis[j]);
-    V3 pj = pp + mul(Rp, ld3(L.origin[j]));
+    V3 al, oj;
+    joint_origin_axis(L, j, oj, al);
+    V3 pj = pp + mul(Rp, oj);
     if (TP::ROT) Rp = mul(Rp, ld_m3(L.rot0[TP::ROT ? j : 0]));
     M3 Rj = mul(Rp, rodrigues(al, q[j]));
     const V3 aw = mul(Rp, al);
@@ -363,7 +373,8 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
       qi = sub == s2 ? cand : qi;
     });
     const int jx = imin(SUB * i + sub, JX - 1);
-    Tl[i] = mul(ld_m3(L.rot0[jx]), rodrigues(ld3(L.axis[jx]), qi));
+    const F4 r0 = ld4(L.rota[jx]), r1 = ld4(L.rota[jx] + 4), r2 = ld4(L.rota[jx] + 8);  // rot0 (row-major) and the axis: three vectors
+    Tl[i] = mul(M3{{r0.x, r0.y, r0.z}, {r0.w, r1.x, r1.y}, {r1.z, r1.w, r2.x}}, rodrigues(V3{r2.y, r2.z, r2.w}, qi));
   });
   M3 Rp = identity3(), Ra = identity3();
   V3 pp{0.f, 0.f, 0.f}, pa{0.f, 0.f, 0.f};
@@ -372,9 +383,11 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
     constexpr int i = decltype(ic)::value, jx = CL + i;
     if (i > 0 && ((restart >> i) & 1u)) { Rp = identity3(); pp = {0.f, 0.f, 0.f}; }
     const M3 Tj = ctx.template deal_bcast_m3<jx % SUB>(Tl[jx / SUB]);
-    const V3 pj = pp + mul(Rp, ld3(L.origin[jx]));
+    V3 oj, al;
+    joint_origin_axis(L, jx, oj, al);
+    const V3 pj = pp + mul(Rp, oj);
     const M3 Rj = mul(Rp, Tj);
-    const V3 aw = mul(Rj, ld3(L.axis[jx]));
+    const V3 aw = mul(Rj, al);
     C.setw(i, Rj, pj, aw);
     on_trunk(i, aw, pj);
     Rp = Rj;
@@ -386,9 +399,11 @@ RL_FN void chain_kinematics_dealt(Ctx& ctx, int sub, const LaneTabT<TP>& L, cons
   static_for<0, CL>([&](auto jc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
     const M3 Tj = ctx.template deal_bcast_m3<j % SUB>(Tl[j / SUB]);
-    const V3 pj = pp + mul(Rp, ld3(L.origin[j]));
+    V3 oj, al;
+    joint_origin_axis(L, j, oj, al);
+    const V3 pj = pp + mul(Rp, oj);
     const M3 Rj = mul(Rp, Tj);
-    const V3 aw = mul(Rj, ld3(L.axis[j]));
+    const V3 aw = mul(Rj, al);
     C.set(j, Rj, pj, aw);
     on_limb(j, aw, pj);
     Rp = Rj;
@@ -755,11 +770,13 @@ struct EnvLane {
     const float dt = u.dt;
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
-      float qt = L.action_is_vel[j] ? q[j] : q_tgt[j];
+      const F4 c1 = ld4(L.jc[j] + 4), c2 = ld4(L.jc[j] + 8);  // [. . eff sat | act_vlim flags . .]
+      const int flags = (int)c2.y;
+      float qt = (flags & 2) ? q[j] : q_tgt[j];
       float er = qt - q[j], ed = qd_tgt[j] - qd[j];
       float tc = kp[j] * er + kd[j] * ed;
-      float eff = L.eff[j];
-      if (L.act_implicit[j]) {
+      float eff = c1.z;
+      if (flags & 1) {
         float est = clampf(tc, -eff, eff);
         bool sat = fabsf(tc) > eff;
         tau_app[j] = est;
@@ -767,9 +784,9 @@ struct EnvLane {
         pd_diag[j] = sat ? 0.f : dt * (kd[j] + kp[j] * dt);
         pd_rhs[j] = sat ? 0.f : dt * (kp[j] * er + kd[j] * qd_tgt[j]);
       } else {  // DCMotor torque-speed clip (unitree.py:55-63)
-        float vr = qd[j] * frcp(L.act_vlim[j]);
-        float tmax = clampf(L.sat[j] * (1.0f - vr), 0.f, eff);
-        float tmin = clampf(L.sat[j] * (-1.0f - vr), -eff, 0.f);
+        float vr = qd[j] * frcp(c2.x);
+        float tmax = clampf(c1.w * (1.0f - vr), 0.f, eff);
+        float tmin = clampf(c1.w * (-1.0f - vr), -eff, 0.f);
         float t = clampf(tc, tmin, tmax);
         tau_app[j] = t;
         tau_e[j] = t;
@@ -1167,8 +1184,9 @@ struct EnvLane {
       for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<so>(rec[io].r[i]);
       const float s6[6] = {Sj[j].a.x, Sj[j].a.y, Sj[j].a.z, Sj[j].l.x, Sj[j].l.y, Sj[j].l.z};
       // joint-local terms: armature, implicit PD, limit spring-damper (hard limits in the reference, a1.urdf:369,411,439)
-      const float arm = L.armature[j];
-      const float below = L.lower[j] - q[j], above = q[j] - L.upper[j];
+      const F4 c2 = ld4(L.jc[j] + 8), c3 = ld4(L.jc[j] + 12);  // [. . armature lower | upper . . .]
+      const float arm = c2.z;
+      const float below = c2.w - q[j], above = q[j] - c3.x;
       const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
       const bool lim = (below > 0.f) || (above > 0.f);
       float D = arm + pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
@@ -1548,8 +1566,9 @@ struct EnvLane {
   // joint-local terms of joint jx (limb joint j or trunk joint CL + i): armature, implicit PD, limit spring-damper, and the
   // identity row of an inert padding joint
   RL_FN void joint_terms(int jx, bool padding, const float (&tau_e)[JX], const float (&pd_diag)[JX], const float (&pd_rhs)[JX], float& D, float& uu) const {
-    const float dt = u.dt, arm = L.armature[jx];
-    const float below = L.lower[jx] - q[jx], above = q[jx] - L.upper[jx];
+    const F4 c2 = ld4(L.jc[jx] + 8), c3 = ld4(L.jc[jx] + 12);  // [. . armature lower | upper . . .]
+    const float dt = u.dt, arm = c2.z;
+    const float below = c2.w - q[jx], above = q[jx] - c3.x;
     const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
     const bool lim = (below > 0.f) || (above > 0.f);
     D = arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f) + (padding ? 1.0f : 0.f);

@@ -58,6 +58,13 @@ using TopoMax = Topo<MAX_CL, MAX_NW, MAX_SPL, MAX_NBS>;  // shape of the host-si
 template <class TP>
 struct LaneTabT {
   static constexpr int JXA = TP::JX, RXA = TP::ROT ? TP::JX : 1, NG = TP::CL + 1;
+  // What the SUBSTEP reads of a joint, packed as 16-byte vectors (pack_tables builds them from the arrays below): one ds_read_b128 per
+  // vector where the arrays cost a ds_read_b32 / ds_read2_b32 per word - a lone wavefront pays an LDS round trip per dependent read.
+  //   jc[j]   = [origin.x origin.y origin.z axis.x | axis.y axis.z eff sat | act_vlim flags armature lower | upper vel_limit - -]
+  //             (flags: 1 = implicit actuator, 2 = velocity action)
+  //   rota[j] = [rot0, row-major (9) | axis.x axis.y axis.z]   (trunk + limbs instances: read with a per-lane j by the dealt kinematics)
+  alignas(16) float jc[JXA][16];
+  alignas(16) float rota[RXA][12];
   float origin[JXA][3], axis[JXA][3];
   float rot0[RXA][9];                  // joint frame axes in the parent link frame, row-major (only read when TP::ROT)
   float lower[JXA], upper[JXA], vel_limit[JXA], armature[JXA];
@@ -252,6 +259,14 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
       b.act_vlim[j] = a.act_vlim[j]; b.action_is_vel[j] = a.action_is_vel[j];
       b.a_scale[j] = a.a_scale[j]; b.a_off[j] = a.a_off[j]; b.a_lo[j] = a.a_lo[j]; b.a_hi[j] = a.a_hi[j];
       b.joint_id[j] = a.joint_id[j]; b.joint_own[j] = a.joint_own[j];
+      const float jc[16] = {a.origin[j][0], a.origin[j][1], a.origin[j][2], a.axis[j][0], a.axis[j][1], a.axis[j][2], a.eff[j], a.sat[j],
+                            a.act_vlim[j], (float)((a.act_implicit[j] ? 1 : 0) + (a.action_is_vel[j] ? 2 : 0)), a.armature[j], a.lower[j],
+                            a.upper[j], a.vel_limit[j], 0.f, 0.f};
+      for (int c = 0; c < 16; ++c) b.jc[j][c] = jc[c];
+      if (TP::ROT) {
+        for (int c = 0; c < 9; ++c) b.rota[TP::ROT ? j : 0][c] = a.rot0[j][c];
+        for (int c = 0; c < 3; ++c) b.rota[TP::ROT ? j : 0][9 + c] = a.axis[j][c];
+      }
     }
     b.nj = a.nj; b.attach = a.attach; b.grp0_depth = a.grp0_depth;
     for (int g = 0; g <= TP::CL; ++g)
