@@ -425,21 +425,21 @@ RL_FN V3 point_velocity(const CT& C, uint32_t anc, int lg, V3 x, SV V0, const fl
   return u;
 }
 
-// Lane-private LDS scratchpad: word f of a lane lives at base[f * STRIDE] (STRIDE = 64 on the GPU, so
-// a wavefront access hits 64 different banks).  It holds the per-body contact-sensor state (timers,
-// force history, last force) and friction - ~80 values that would otherwise sit in VGPRs all step.
-template <int STRIDE, int W>
-struct LsRow {
-  float* p;
-  RL_FN float& operator[](int t) const { return p[t * STRIDE]; }
-};
+// Lane-private LDS scratchpad in 16-byte GRANULES: granule g of a lane lives at base[(g * STRIDE + lane) * 4] (STRIDE = 64 on the GPU:
+// a ds_read_b128 / ds_write_b128 of the wavefront touches 64 consecutive 16-byte pieces).  It holds the per-body contact-sensor state -
+// timers (4 words), force history (3), last force (3) - and friction (3), one granule each per body-slot row, and the contact stash
+// (9 words in three granules per sphere slot): ~80 values that would otherwise sit in VGPRs all step.  (Until round 4 the layout was
+// word-major - word f at base[f * 64 + lane], one ds_read_b32 / ds_write_b32 per word: 16 LDS instructions per owned slot and substep
+// in the sensor pass alone, 18 per stashed contact.)
 // Rows are indexed by BODY SLOT.  In the 16-lane mapping a lane only ever touches the <= NOWN slots it owns (the
 // slots of the link groups it evaluates), so the scratchpad holds NOWN rows and `at` turns a slot into its place in
 // the lane's ascending `own[]` list (rows of slots the lane does not own alias row 0: they are only read under a mask).
 // NOWN == 0: one row per slot (a lane is a whole leg).
-template <int STRIDE, int W, int NOWN>
+// (One lane per limb - GRAN false: that mapping keeps the word-major layout, word f of a lane at base[f * STRIDE + lane] and W words
+// per row: its four-wavefront workgroup sits at the 160 KB of a CU's LDS, and 16 instead of 13 words per body-slot row do not fit.)
+template <int STRIDE, int NOWN, int W, bool GRAN>
 struct LsMat {
-  float* p;
+  float* p;  // row 0 (this lane's granule / first word)
   int own[NOWN > 0 ? NOWN : 1];  // copy of the lane's own[] (by value: a pointer into the lane object would pin it in memory)
   RL_FN void set_own(const int* o) {
 #pragma unroll
@@ -452,7 +452,21 @@ struct LsMat {
     for (int j = 1; j < NOWN; ++j) i += (own[j] == b) ? j : 0;
     return i;
   }
-  RL_FN LsRow<STRIDE, W> operator[](int b) const { return {p + at(b) * W * STRIDE}; }
+  RL_FN F4 ld(int b) const {
+    if constexpr (GRAN) return ld4(p + at(b) * 4 * STRIDE);
+    else {
+      const float* r = p + at(b) * W * STRIDE;
+      return F4{r[0], r[STRIDE], r[2 * STRIDE], W > 3 ? r[(W > 3 ? 3 : 0) * STRIDE] : 0.f};
+    }
+  }
+  RL_FN void st(int b, F4 v) const {
+    if constexpr (GRAN) st4(p + at(b) * 4 * STRIDE, v);
+    else {
+      float* r = p + at(b) * W * STRIDE;
+      r[0] = v.x; r[STRIDE] = v.y; r[2 * STRIDE] = v.z;
+      if (W > 3) r[(W > 3 ? 3 : 0) * STRIDE] = v.w;
+    }
+  }
 };
 // words of limb-shared LDS an instance needs (0 when it keeps everything in registers)
 // Trunk + limbs instance (articulated-body form, substeps_aba_trunk): per limb the kinematics (15 words per joint), one 27-word
@@ -489,9 +503,11 @@ struct LbLayout {
 // pass after the solve does not re-evaluate them (quadrupeds in the 16-lane mapping; 4 workgroups x 40 KB of LDS
 // still share a CU)
 constexpr int CONTACT_WORDS = 9;  // x (3), n (3), bias, d_n, d_t
-template <int ROWS, int STASH = 0>
-struct LsLayout {  // ROWS sensor rows (timers 4, force history 3, last force 3, friction 3 words each) + the contact stash
-  enum { TIM = 0, HIST = TIM + ROWS * 4, CF = HIST + ROWS * 3, FRIC = CF + ROWS * 3, CT = FRIC + ROWS * 3, WORDS = CT + STASH * CONTACT_WORDS };
+constexpr int STASH_SLOT_WORDS = 12;  // ... in the lane scratchpad: three granules
+template <int ROWS, int STASH = 0, bool GRAN = true, bool STASH_GRAN = true>
+struct LsLayout {  // word offsets: ROWS sensor rows (timers 4, force history 3, last force 3, friction 3: a granule each, or - word-major - W words) + the contact stash
+  enum { RW = GRAN ? 4 : 3, SSW = STASH_GRAN ? STASH_SLOT_WORDS : CONTACT_WORDS, TIM = 0, HIST = TIM + ROWS * 4, CF = HIST + ROWS * RW, FRIC = CF + ROWS * RW, CT = FRIC + ROWS * RW,
+         WORDS = CT + STASH * SSW };
 };
 template <class TP, int SUB>
 struct LsFor {  // lane scratchpad layout of an instance
@@ -508,7 +524,12 @@ struct LsFor {  // lane scratchpad layout of an instance
 #endif
   static constexpr int STASH = (SUB > 1 && !STASH_REG) ? NIT * TP::SPL : 0;
   static constexpr int NOWN = SUB == 1 ? 0 : LaneTabT<TP>::template maxown<SUB>();  // 16- / 8-lane mappings: rows for the owned slots only
-  using type = LsLayout<(SUB == 1 ? TP::NBS : LaneTabT<TP>::template maxown<SUB>()), STASH>;
+  static constexpr bool GRAN = SUB != 1;  // 16-byte granules (see LsMat)
+  static constexpr int ROWS = SUB == 1 ? TP::NBS : LaneTabT<TP>::template maxown<SUB>();
+  // the stash as granules (12 instead of 9 words per slot) where four wavefronts of the instance still fit a CU's LDS next to the
+  // tables (not the 4-joint quadruped with nine stash slots per lane in the 8-lane mapping: it keeps a word-major stash)
+  static constexpr bool STASH_GRAN = GRAN && 4 * (16 * ROWS + STASH_SLOT_WORDS * STASH) * 256 <= 140 * 1024;
+  using type = LsLayout<ROWS, STASH, GRAN, STASH_GRAN>;
 };
 
 template <class Ctx, class TP>
@@ -594,14 +615,15 @@ struct EnvLane {
   float tau_app[JX], qacc[JX];
   // contact-sensor state + friction in the lane-private LDS scratchpad
   static constexpr int NOWN = LsFor<TP, Ctx::SUB>::NOWN;
-  LsMat<LSS, 4, NOWN> tim;     // [slot][current_air, current_contact, last_air, last_contact]
-  LsMat<LSS, 3, NOWN> hist_n;  // [slot][|F| of the last three substeps, newest first]
-  LsMat<LSS, 3, NOWN> cf;      // [slot][net contact force of the last substep, world]
-  LsMat<LSS, 3, NOWN> fric;    // [slot][mu_s, mu_d, restitution]
+  static constexpr bool GRAN = LsFor<TP, Ctx::SUB>::GRAN;
+  LsMat<LSS, NOWN, 4, GRAN> tim;     // [slot] (current_air, current_contact, last_air, last_contact)
+  LsMat<LSS, NOWN, 3, GRAN> hist_n;  // [slot] (|F| of the last three substeps, newest first; -)
+  LsMat<LSS, NOWN, 3, GRAN> cf;      // [slot] (net contact force of the last substep, world; -)
+  LsMat<LSS, NOWN, 3, GRAN> fric;    // [slot] (mu_s, mu_d, restitution; -)
 
   RL_FN EnvLane(Ctx& c, const KState& s)
-      : ctx(c), S(s), T(c.template tables<TablesT<TP>>()), L(c.template tables<TablesT<TP>>().lane[c.k()]), u(make_uni(c, c.template tables<TablesT<TP>>())), tim{c.lane_scratch() + LS::TIM * LSS, {}}, hist_n{c.lane_scratch() + LS::HIST * LSS, {}},
-        cf{c.lane_scratch() + LS::CF * LSS, {}}, fric{c.lane_scratch() + LS::FRIC * LSS, {}} {
+      : ctx(c), S(s), T(c.template tables<TablesT<TP>>()), L(c.template tables<TablesT<TP>>().lane[c.k()]), u(make_uni(c, c.template tables<TablesT<TP>>())), tim{c.template lane_scratch<GRAN>() + LS::TIM * LSS, {}}, hist_n{c.template lane_scratch<GRAN>() + LS::HIST * LSS, {}},
+        cf{c.template lane_scratch<GRAN>() + LS::CF * LSS, {}}, fric{c.template lane_scratch<GRAN>() + LS::FRIC * LSS, {}} {
     e = ctx.env();
     k = ctx.k();
     sub = ctx.sub();
@@ -719,12 +741,10 @@ struct EnvLane {
     for (int i = 0; i < MAXOWN; ++i) {  // sensor state + material of the body slots this lane owns (the others are never read unmasked)
       const int s = own[i];
       if (s < 0) continue;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) tim[s][t] = LF(LY.LF_TIMERS + s * 4 + t);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) fric[s][t] = LF(LY.LF_FRICTION + s * 3 + t);
-      cf[s][0] = cf[s][1] = cf[s][2] = 0.f;
-      hist_n[s][0] = hist_n[s][1] = hist_n[s][2] = 0.f;
+      tim.st(s, F4{LF(LY.LF_TIMERS + s * 4 + 0), LF(LY.LF_TIMERS + s * 4 + 1), LF(LY.LF_TIMERS + s * 4 + 2), LF(LY.LF_TIMERS + s * 4 + 3)});
+      fric.st(s, F4{LF(LY.LF_FRICTION + s * 3 + 0), LF(LY.LF_FRICTION + s * 3 + 1), LF(LY.LF_FRICTION + s * 3 + 2), 0.f});
+      cf.st(s, F4{0.f, 0.f, 0.f, 0.f});
+      hist_n.st(s, F4{0.f, 0.f, 0.f, 0.f});
     }
   }
 
@@ -759,8 +779,8 @@ struct EnvLane {
     for (int i = 0; i < MAXOWN; ++i) {
       const int s = own[i];
       if (s < 0 || (s == 0 && SUB > 1 && L.slot_body[0] < 0)) continue;  // slot 0 of a lane that only shares a trunk body's spheres
-#pragma unroll
-      for (int t = 0; t < 4; ++t) LF(LY.LF_TIMERS + s * 4 + t) = tim[s][t];
+      const F4 t4 = tim.ld(s);
+      LF(LY.LF_TIMERS + s * 4 + 0) = t4.x; LF(LY.LF_TIMERS + s * 4 + 1) = t4.y; LF(LY.LF_TIMERS + s * 4 + 2) = t4.z; LF(LY.LF_TIMERS + s * 4 + 3) = t4.w;
     }
   }
 
@@ -818,8 +838,9 @@ struct EnvLane {
       if (g == j + 1) { Rg = C.R(j); pg = C.p(j); }
   }
   RL_FN void sphere_center_in(const M3& Rg, V3 pg, const M3& Rwb, int g, int s, float& rad, V3& cb, V3& cw) const {
-    rad = L.sph_r[g][s];
-    const V3 c = ld3(L.sph_c[g][s]);
+    const F4 sp = ld4(L.sph[g][s]);  // centre (link frame), radius
+    rad = sp.w;
+    const V3 c{sp.x, sp.y, sp.z};
     cb = pg + mul(Rg, c);
     if (M0 && on_base(g, s)) cb = c;  // a base-share sphere hosted by this group's slots: base frame
     const V3 ow = mul(Rwb, cb);
@@ -850,7 +871,8 @@ struct EnvLane {
       V3 ut = uu - un * nb;
       float utn = norm(ut);
       int slot = L.sph_slot[g][s];
-      float mus = fric[slot][0], mud = fric[slot][1], rest = fric[slot][2];
+      const F4 fr = fric.ld(slot);
+      float mus = fr.x, mud = fr.y, rest = fr.z;
       if (M0) {
         const bool ob = on_base(g, s);
         mus = ob ? fric0[0] : mus; mud = ob ? fric0[1] : mud; rest = ob ? fric0[2] : rest;
@@ -973,9 +995,16 @@ struct EnvLane {
           float (&st)[CONTACT_WORDS] = stash_r[IT * SPL + s];
           st[0] = c.x.x; st[1] = c.x.y; st[2] = c.x.z; st[3] = c.n.x; st[4] = c.n.y; st[5] = c.n.z; st[6] = c.bias; st[7] = c.dn; st[8] = c.dt;
         } else if (STASH) {
-          float* st = ctx.lane_scratch() + (LS::CT + (IT * SPL + s) * CONTACT_WORDS) * LSS;
-          st[0 * LSS] = c.x.x; st[1 * LSS] = c.x.y; st[2 * LSS] = c.x.z; st[3 * LSS] = c.n.x; st[4 * LSS] = c.n.y; st[5 * LSS] = c.n.z;
-          st[6 * LSS] = c.bias; st[7 * LSS] = c.dn; st[8 * LSS] = c.dt;
+          if constexpr (LsFor<TP, SUB>::STASH_GRAN) {
+            float* st = ctx.template lane_scratch<true>() + (LS::CT + (IT * SPL + s) * STASH_SLOT_WORDS) * LSS;
+            st4(st, F4{c.x.x, c.x.y, c.x.z, c.n.x});
+            st4(st + 4 * LSS, F4{c.n.y, c.n.z, c.bias, c.dn});
+            st4(st + 8 * LSS, F4{c.dt, 0.f, 0.f, 0.f});
+          } else {
+            float* st = ctx.template lane_scratch<false>() + (LS::CT + (IT * SPL + s) * CONTACT_WORDS) * LSS;
+            st[0 * LSS] = c.x.x; st[1 * LSS] = c.x.y; st[2 * LSS] = c.x.z; st[3 * LSS] = c.n.x; st[4 * LSS] = c.n.y; st[5 * LSS] = c.n.z;
+            st[6 * LSS] = c.bias; st[7 * LSS] = c.dn; st[8 * LSS] = c.dt;
+          }
         }
         // point velocity = P [omega; v] of the link, P = [ [x]x^T | 1 ]:  dt (d_t P^T P + (d_n - d_t) g g^T), g = P^T n = [x x n; n]
         const V3 x = c.x, n = c.n;
@@ -2003,10 +2032,18 @@ struct EnvLane {
             c[s2].n = {st[3], st[4], st[5]};
             c[s2].bias = st[6]; c[s2].dn = st[7]; c[s2].dt = st[8];
           } else {
-            const float* st = ctx.lane_scratch() + (LS::CT + (it.value * SPL + s2) * CONTACT_WORDS) * LSS;
-            c[s2].x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
-            c[s2].n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
-            c[s2].bias = st[6 * LSS]; c[s2].dn = st[7 * LSS]; c[s2].dt = st[8 * LSS];
+            if constexpr (LsFor<TP, SUB>::STASH_GRAN) {
+              const float* st = ctx.template lane_scratch<true>() + (LS::CT + (it.value * SPL + s2) * STASH_SLOT_WORDS) * LSS;
+              const F4 g0 = ld4(st), g1 = ld4(st + 4 * LSS), g2 = ld4(st + 8 * LSS);
+              c[s2].x = {g0.x, g0.y, g0.z};
+              c[s2].n = {g0.w, g1.x, g1.y};
+              c[s2].bias = g1.z; c[s2].dn = g1.w; c[s2].dt = g2.x;
+            } else {
+              const float* st = ctx.template lane_scratch<false>() + (LS::CT + (it.value * SPL + s2) * CONTACT_WORDS) * LSS;
+              c[s2].x = {st[0 * LSS], st[1 * LSS], st[2 * LSS]};
+              c[s2].n = {st[3 * LSS], st[4 * LSS], st[5 * LSS]};
+              c[s2].bias = st[6 * LSS]; c[s2].dn = st[7 * LSS]; c[s2].dt = st[8 * LSS];
+            }
           }
           slot[s2] = L.sph_slot[gi][s2];
         }
@@ -2052,29 +2089,24 @@ struct EnvLane {
   // compiler cannot move a read above an earlier write on its own and every read-modify-write became its own LDS round trip.
   RL_FN void sensor_timers(const V3 (&fown)[MAXOWN]) {
     const float dt = u.dt;
-    float h0[MAXOWN], h1[MAXOWN], t0[MAXOWN], t1[MAXOWN], t2[MAXOWN], t3[MAXOWN];
+    F4 h[MAXOWN], t[MAXOWN];
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) {
       const int b = own[i] < 0 ? 0 : own[i];
-      h0[i] = hist_n[b][0]; h1[i] = hist_n[b][1];
-      t0[i] = tim[b][0]; t1[i] = tim[b][1]; t2[i] = tim[b][2]; t3[i] = tim[b][3];
+      h[i] = hist_n.ld(b);
+      t[i] = tim.ld(b);
     }
 #pragma unroll
     for (int i = 0; i < MAXOWN; ++i) {
       const int b = own[i];
       if (b < 0) continue;
-      cf[b][0] = fown[i].x; cf[b][1] = fown[i].y; cf[b][2] = fown[i].z;
+      cf.st(b, F4{fown[i].x, fown[i].y, fown[i].z, 0.f});
       const float fn = norm(fown[i]);
-      hist_n[b][2] = h1[i];
-      hist_n[b][1] = h0[i];
-      hist_n[b][0] = fn;
+      hist_n.st(b, F4{fn, h[i].x, h[i].y, 0.f});
       const bool contact = fn > u.force_threshold;
-      const float ca = t0[i], cc = t1[i];
+      const float ca = t[i].x, cc = t[i].y;
       const bool first_contact = (ca > 0.f) && contact, first_detach = (cc > 0.f) && !contact;
-      tim[b][2] = first_contact ? ca + dt : t2[i];
-      tim[b][0] = contact ? 0.f : ca + dt;
-      tim[b][3] = first_detach ? cc + dt : t3[i];
-      tim[b][1] = contact ? cc + dt : 0.f;
+      tim.st(b, F4{contact ? 0.f : ca + dt, contact ? cc + dt : 0.f, first_contact ? ca + dt : t[i].z, first_detach ? cc + dt : t[i].w});
     }
   }
 

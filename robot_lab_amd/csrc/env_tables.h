@@ -65,6 +65,7 @@ struct LaneTabT {
   //   rota[j] = [rot0, row-major (9) | axis.x axis.y axis.z]   (trunk + limbs instances: read with a per-lane j by the dealt kinematics)
   alignas(16) float jc[JXA][16];
   alignas(16) float rota[RXA][12];
+  alignas(16) float sph[NG][TP::SPL][4];  // collision spheres of a link group as vectors: [centre.xyz (link frame), radius (<= 0: empty slot)] (pack_tables, from sph_c / sph_r)
   float origin[JXA][3], axis[JXA][3];
   float rot0[RXA][9];                  // joint frame axes in the parent link frame, row-major (only read when TP::ROT)
   float lower[JXA], upper[JXA], vel_limit[JXA], armature[JXA];
@@ -273,6 +274,8 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
       for (int q = 0; q < TP::SPL; ++q) {
         for (int c = 0; c < 3; ++c) b.sph_c[g][q][c] = a.sph_c[g][q][c];
         b.sph_r[g][q] = a.sph_r[g][q]; b.sph_slot[g][q] = a.sph_slot[g][q];
+        for (int c = 0; c < 3; ++c) b.sph[g][q][c] = a.sph_c[g][q][c];
+        b.sph[g][q][3] = a.sph_r[g][q];
       }
     for (int q = 0; q < TP::NBS; ++q) {
       b.slot_body[q] = a.slot_body[q]; b.slot_grp[q] = a.slot_grp[q];

@@ -459,9 +459,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     for (int i = 0; i < Base::MAXOWN; ++i) {
       const int b = this->own[i];
       if (b < 0) continue;
-      tim[b][0] = tim[b][1] = tim[b][2] = tim[b][3] = 0.f;
-      cf[b][0] = cf[b][1] = cf[b][2] = 0.f;
-      hist_n[b][0] = hist_n[b][1] = hist_n[b][2] = 0.f;
+      tim.st(b, F4{0.f, 0.f, 0.f, 0.f});
+      cf.st(b, F4{0.f, 0.f, 0.f, 0.f});
+      hist_n.st(b, F4{0.f, 0.f, 0.f, 0.f});
     }
     extF = {0.f, 0.f, 0.f};
     extT = {0.f, 0.f, 0.f};
@@ -532,7 +532,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     if (slot == 0 && !L.owns_base_body) return false;
     return (mask >> b) & 1ull;
   }
-  RL_FN float hist_max(int slot) const { return fmaxf(hist_n[slot][0], fmaxf(hist_n[slot][1], hist_n[slot][2])); }
+  RL_FN float hist_max(int slot) const {
+    const F4 h = hist_n.ld(slot);
+    return fmaxf(h.x, fmaxf(h.y, h.z));
+  }
 
   // position (base coords) and velocity relative to the root COM velocity (base coords) of body slot s
   RL_FN void body_rel(const ChainTP& C, int s, V3& relp, V3& relv) const {
@@ -612,9 +615,13 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         const int b = L.slot_body[s];
         if (b < 0 || (s == 0 && !L.owns_base_body)) continue;
         float* r = BT + rew_bt_row(ext_mask, b);
-        r[BT_HMAX] = fmaxf(hist_n[s][0], fmaxf(hist_n[s][1], hist_n[s][2]));
-        r[BT_CA] = tim[s][0]; r[BT_CC] = tim[s][1]; r[BT_LA] = tim[s][2]; r[BT_LC] = tim[s][3];
-        if ((ext_mask >> b) & 1ull) { r[BT_FX] = cf[s][0]; r[BT_FY] = cf[s][1]; r[BT_FZ] = cf[s][2]; }
+        const F4 hs = hist_n.ld(s), ts = tim.ld(s);
+        r[BT_HMAX] = fmaxf(hs.x, fmaxf(hs.y, hs.z));
+        r[BT_CA] = ts.x; r[BT_CC] = ts.y; r[BT_LA] = ts.z; r[BT_LC] = ts.w;
+        if ((ext_mask >> b) & 1ull) {
+          const F4 fs = cf.ld(s);
+          r[BT_FX] = fs.x; r[BT_FY] = fs.y; r[BT_FZ] = fs.z;
+        }
         if (any_rel && ((rel_mask >> b) & 1ull)) {
           V3 relp, relv;
           body_rel(C, s, relp, relv);
@@ -889,7 +896,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       int b = L.slot_body[s];
       if (b >= 0 && (s != 0 || L.owns_base_body) && this->owns_slot(s)) {
         float* o = S.dbg_cforce + ((size_t)e * T.n_bodies + b) * 3;
-        o[0] = live * cf[s][0]; o[1] = live * cf[s][1]; o[2] = live * cf[s][2];
+        const F4 fs = cf.ld(s);
+        o[0] = live * fs.x; o[1] = live * fs.y; o[2] = live * fs.z;
       }
     }
   }

@@ -57,7 +57,9 @@ struct WaveCtx {
   float* fstage;  // feature vectors of the tile's envs (observations)
   int dim[2], fdim, rtdim;  // rtdim: words of an env's reward tables (they share LDS with the observation rows + features)
   int lane;
-  __device__ float* lane_scratch() const { return lscratch + lane; }
+  // this lane's place in the scratchpad: GRAN - its 16-byte piece of granule 0 (granule g: + g * 4 * LS_STRIDE words); else its word of row 0 (word f: + f * LS_STRIDE)
+  template <bool GRAN>
+  __device__ float* lane_scratch() const { return lscratch + (GRAN ? lane * 4 : lane); }
   __device__ float* limb_chain() const { return lbchain; }
   __device__ float* limb_rec() const { return lbrec; }
   __device__ float* limb_rec_of(int k2) const { return lbrec + (k2 - ((lane / SUB) & 3)) * lbrec_stride; }  // limb k2 of this lane's env
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   // touches the rows.  26 KB -> 20 KB per workgroup = 8 instead of 6 workgroups per CU.
   const int TAB_F = (int)(S.table_bytes >> 2);
   using LS = typename LsFor<TP, SUB>::type;
-  constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * CONTACT_WORDS * 64;
+  constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * LsFor<TP, SUB>::type::SSW * 64;
   Ctx ctx;
   ctx.T = Tl;
   ctx.Tg = Tgv;

@@ -255,7 +255,8 @@ struct HostCtx {
   static constexpr int SUB = SUB_;
   static constexpr int LPE = rl::NLANE * SUB_;
   static constexpr int EPT = 64 / LPE;
-  float scratch[rl::LsLayout<rl::MAX_NBS, rl::MAX_SPL>::WORDS];
+  alignas(16) float scratch[rl::LsLayout<rl::MAX_NBS, rl::MAX_NGRP * rl::MAX_SPL>::WORDS];  // (rows for every body slot + a stash slot for every sphere slot: more than any instance / mapping uses)
+  template <bool GRAN>
   float* lane_scratch() { return scratch; }
   float* limb_chain() { return team->lbchain[k_]; }
   float* limb_rec() { return team->lbrec[k_]; }
