@@ -9,6 +9,7 @@
 // HBM layout: wave-tiled structure-of-arrays (see "HBM state layout" below).
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 
 #include "rl_math.h"
 
@@ -55,8 +56,23 @@ using TopoMax = Topo<MAX_CL, MAX_NW, MAX_SPL, MAX_NBS>;  // shape of the host-si
 // One per limb chain k.  Joint arrays: [0, CL) the limb, [CL, CL+NW) the trunk joints (same in all lanes).
 // Sized by the Topo so that the LDS copy of a quadruped instance stays small: the workgroup's LDS
 // footprint decides whether all 4 SIMDs of a CU get a wavefront (4 x 37 KB fit in 160 KB, 4 x 45 KB do not).
+// The arrays the HOST fills per joint / sphere and pack_tables turns into the packed vectors below (jc, rota, sph): only the unpacked
+// tables (TablesT<TopoMax>) carry them - in an instance's LDS image they would be dead weight (1.4 KB on a 3-joint quadruped: the
+// one-lane-per-limb mapping's four-wavefront workgroup sits within 2 KB of a CU's 160 KB).
+template <class TP, bool HOST>
+struct LaneSrcT {};
 template <class TP>
-struct LaneTabT {
+struct LaneSrcT<TP, true> {
+  float origin[TP::JX][3], axis[TP::JX][3];
+  float lower[TP::JX], upper[TP::JX], armature[TP::JX];
+  int32_t act_implicit[TP::JX];
+  float eff[TP::JX], sat[TP::JX], act_vlim[TP::JX];
+  float sph_c[TP::CL + 1][TP::SPL][3];
+  float sph_r[TP::CL + 1][TP::SPL];            // <= 0: empty slot
+};
+template <class TP>
+struct LaneTabT : LaneSrcT<TP, std::is_same<TP, TopoMax>::value> {
+  static constexpr bool HOST = std::is_same<TP, TopoMax>::value;
   static constexpr int JXA = TP::JX, RXA = TP::ROT ? TP::JX : 1, NG = TP::CL + 1;
   // What the SUBSTEP reads of a joint, packed as 16-byte vectors (pack_tables builds them from the arrays below): one ds_read_b128 per
   // vector where the arrays cost a ds_read_b32 / ds_read2_b32 per word - a lone wavefront pays an LDS round trip per dependent read.
@@ -66,12 +82,10 @@ struct LaneTabT {
   alignas(16) float jc[JXA][16];
   alignas(16) float rota[RXA][12];
   alignas(16) float sph[NG][TP::SPL][4];  // collision spheres of a link group as vectors: [centre.xyz (link frame), radius (<= 0: empty slot)] (pack_tables, from sph_c / sph_r)
-  float origin[JXA][3], axis[JXA][3];
   float rot0[RXA][9];                  // joint frame axes in the parent link frame, row-major (only read when TP::ROT)
-  float lower[JXA], upper[JXA], vel_limit[JXA], armature[JXA];
+  float vel_limit[JXA];
   float q0[JXA], qd0[JXA], soft_lo[JXA], soft_hi[JXA];
-  int32_t act_implicit[JXA];
-  float kp0[JXA], kd0[JXA], eff[JXA], sat[JXA], act_vlim[JXA];
+  float kp0[JXA], kd0[JXA];
   int32_t action_is_vel[JXA];
   float a_scale[JXA], a_off[JXA], a_lo[JXA], a_hi[JXA];
   int32_t joint_id[JXA];               // task joint index (bit in joint masks, column in action/obs); -1 = padding (chain shorter than CL)
@@ -80,8 +94,6 @@ struct LaneTabT {
   int32_t nj;                          // joints of this limb (<= CL)
   int32_t attach;                      // trunk joints that move the limb (0: hangs off the base, NW: off the last trunk link)
   int32_t grp0_depth;                  // trunk joints that move link group 0 of this lane
-  float sph_c[NG][TP::SPL][3];
-  float sph_r[NG][TP::SPL];            // <= 0: empty slot
   int32_t sph_slot[NG][TP::SPL];       // body slot the sphere reports to
   int32_t slot_body[TP::NBS];          // global body index (bit in body masks), -1 = empty
   int32_t slot_grp[TP::NBS];           // link group the body is attached to
@@ -122,6 +134,7 @@ RL_FN int popcount64(uint64_t m) { return __builtin_popcountll(m); }
 RL_FN int rew_tab_words(int D, int n_bodies, uint64_t ext_mask) { return REW_JS_ROWS * D + REW_BT_NS * n_bodies + REW_BT_NX * popcount64(ext_mask); }
 // word offset of body b's row in the body table
 RL_FN int rew_bt_row(uint64_t ext_mask, int b) { return REW_BT_NS * b + REW_BT_NX * popcount64(ext_mask & ((1ull << b) - 1ull)); }
+RL_FN int rew_stage_words(int n_rewards) { return (n_rewards + 3) & ~3; }  // an env's row of the reward stage (per-term values of the step)
 constexpr int IDX_POOL = 48;
 constexpr int RESET_RAND_WORDS = 160;  // LDS words of an env's table of reset uniforms: Philox blocks 0 .. 39 of stream STREAM_RESET (rl_math.h IDX_*: the last index is IDX_LEVEL = 156)
 
@@ -252,12 +265,15 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
     const LaneTab& a = s.lane[k];
     LaneTabT<TP>& b = d.lane[k];
     for (int j = 0; j < TP::JX; ++j) {
-      for (int c = 0; c < 3; ++c) { b.origin[j][c] = a.origin[j][c]; b.axis[j][c] = a.axis[j][c]; }
+      if constexpr (LaneTabT<TP>::HOST) {
+        for (int c = 0; c < 3; ++c) { b.origin[j][c] = a.origin[j][c]; b.axis[j][c] = a.axis[j][c]; }
+        b.lower[j] = a.lower[j]; b.upper[j] = a.upper[j]; b.armature[j] = a.armature[j];
+        b.act_implicit[j] = a.act_implicit[j]; b.eff[j] = a.eff[j]; b.sat[j] = a.sat[j]; b.act_vlim[j] = a.act_vlim[j];
+      }
       if (TP::ROT) for (int c = 0; c < 9; ++c) b.rot0[TP::ROT ? j : 0][c] = a.rot0[j][c];
-      b.lower[j] = a.lower[j]; b.upper[j] = a.upper[j]; b.vel_limit[j] = a.vel_limit[j]; b.armature[j] = a.armature[j];
+      b.vel_limit[j] = a.vel_limit[j];
       b.q0[j] = a.q0[j]; b.qd0[j] = a.qd0[j]; b.soft_lo[j] = a.soft_lo[j]; b.soft_hi[j] = a.soft_hi[j];
-      b.act_implicit[j] = a.act_implicit[j]; b.kp0[j] = a.kp0[j]; b.kd0[j] = a.kd0[j]; b.eff[j] = a.eff[j]; b.sat[j] = a.sat[j];
-      b.act_vlim[j] = a.act_vlim[j]; b.action_is_vel[j] = a.action_is_vel[j];
+      b.kp0[j] = a.kp0[j]; b.kd0[j] = a.kd0[j]; b.action_is_vel[j] = a.action_is_vel[j];
       b.a_scale[j] = a.a_scale[j]; b.a_off[j] = a.a_off[j]; b.a_lo[j] = a.a_lo[j]; b.a_hi[j] = a.a_hi[j];
       b.joint_id[j] = a.joint_id[j]; b.joint_own[j] = a.joint_own[j];
       const float jc[16] = {a.origin[j][0], a.origin[j][1], a.origin[j][2], a.axis[j][0], a.axis[j][1], a.axis[j][2], a.eff[j], a.sat[j],
@@ -272,8 +288,11 @@ inline void pack_tables(const Tables& s, TablesT<TP>& d) {
     b.nj = a.nj; b.attach = a.attach; b.grp0_depth = a.grp0_depth;
     for (int g = 0; g <= TP::CL; ++g)
       for (int q = 0; q < TP::SPL; ++q) {
-        for (int c = 0; c < 3; ++c) b.sph_c[g][q][c] = a.sph_c[g][q][c];
-        b.sph_r[g][q] = a.sph_r[g][q]; b.sph_slot[g][q] = a.sph_slot[g][q];
+        if constexpr (LaneTabT<TP>::HOST) {
+          for (int c = 0; c < 3; ++c) b.sph_c[g][q][c] = a.sph_c[g][q][c];
+          b.sph_r[g][q] = a.sph_r[g][q];
+        }
+        b.sph_slot[g][q] = a.sph_slot[g][q];
         for (int c = 0; c < 3; ++c) b.sph[g][q][c] = a.sph_c[g][q][c];
         b.sph[g][q][3] = a.sph_r[g][q];
       }

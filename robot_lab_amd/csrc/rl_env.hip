@@ -155,10 +155,11 @@ struct Backend {
     if (SUB > 1) region = std::max(region, Ctx::EPT * RESET_RAND_WORDS);
     constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * LsFor<TP, SUB>::type::SSW * 64;
     constexpr int LB_FREE = TP::NW > 0 ? LbLayout<TP>::RECW * Ctx::LIMBS : 0;
-    const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;
-    const bool alias_lb = TP::NW > 0 && Ctx::EPT * MAX_T + region <= LB_FREE;
+    const int rsdim = rew_stage_words(T.n_rewards);
+    const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * rsdim + region <= STASH_WORDS;
+    const bool alias_lb = TP::NW > 0 && Ctx::EPT * rsdim + region <= LB_FREE;
     size_t words = (size_t)LS::WORDS * 64 + (size_t)LbLayout<TP>::WORDS * Ctx::LIMBS + (size_t)Ctx::EPT * LbLayout<TP>::ENV_WORDS;
-    if (!alias && !alias_lb) words += (size_t)Ctx::EPT * MAX_T + region;
+    if (!alias && !alias_lb) words += (size_t)Ctx::EPT * rsdim + region;
     words = (words + 3) & ~(size_t)3;  // the next wavefront's scratchpad granules start 16-byte aligned
     return staged_bytes(T) + words * 4;
   }

@@ -55,7 +55,7 @@ struct WaveCtx {
   float* stage[2];
   float* rstage;
   float* fstage;  // feature vectors of the tile's envs (observations)
-  int dim[2], fdim, rtdim;  // rtdim: words of an env's reward tables (they share LDS with the observation rows + features)
+  int dim[2], fdim, rtdim, rsdim;  // rtdim: words of an env's reward tables (they share LDS with the observation rows + features); rsdim: of its reward-stage row
   int lane;
   // this lane's place in the scratchpad: GRAN - its 16-byte piece of granule 0 (granule g: + g * 4 * LS_STRIDE words); else its word of row 0 (word f: + f * LS_STRIDE)
   template <bool GRAN>
@@ -174,7 +174,7 @@ struct WaveCtx {
   __device__ float gshfl(float v, int leg) const { return __shfl(v, (lane & ~(LPE - 1)) | (leg * SUB) | (lane & (SUB - 1))); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
   __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }
-  __device__ float* rew_stage() const { return rstage + env_in_tile() * MAX_T; }
+  __device__ float* rew_stage() const { return rstage + env_in_tile() * rsdim; }
   __device__ float* feat_stage() const { return fstage + env_in_tile() * fdim; }
   __device__ float* rew_tab() const { return stage[0] + env_in_tile() * rtdim; }
   __device__ float* rand_tab() const { return stage[0] + env_in_tile() * RESET_RAND_WORDS; }  // reset uniforms: between the reward tables' death and the observation rows' birth
@@ -293,11 +293,12 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   // substeps are over; trunk + limbs instance - on the link-record / elimination words of the limb-shared area, dead likewise
   // (its kinematics words stay: rewards and the scanner pose recompute the chain into them); else behind everything.
   constexpr int LB_FREE = TP::NW > 0 ? LbLayout<TP>::RECW * Ctx::LIMBS : 0;  // the record blocks of all limbs: one contiguous region
-  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * MAX_T + region <= STASH_WORDS;
-  const bool alias_lb = TP::NW > 0 && Ctx::EPT * MAX_T + region <= LB_FREE;
+  ctx.rsdim = rew_stage_words(Tl->n_rewards);  // a row of the reward stage: the task's terms (not MAX_T: 16 envs x 20 unused words were 5 KB of a one-lane-per-limb workgroup)
+  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * ctx.rsdim + region <= STASH_WORDS;
+  const bool alias_lb = TP::NW > 0 && Ctx::EPT * ctx.rsdim + region <= LB_FREE;
   float* base = alias ? ctx.lscratch + LS::CT * 64 : (alias_lb ? lbrec0 : tail);
   ctx.rstage = base;
-  ctx.stage[0] = base + Ctx::EPT * MAX_T;
+  ctx.stage[0] = base + Ctx::EPT * ctx.rsdim;
   ctx.stage[1] = ctx.stage[0] + s0w;
   ctx.fstage = ctx.stage[1] + s1w;
   ctx.lane = lane;
