@@ -183,13 +183,11 @@ def main():
     torch.cuda.synchronize()
     kernel_ms = e0.elapsed_time(e1) / KREP
 
-    # the one collective of the path: packed episode-metric vector, off the timed region
-    k = native.log_slot()
-    log = env._bufs["LOG"]
-    log_vec = torch.where(log[k][0] > 0, log[k], log[(k - 1) % log.shape[0]]).clone().to(coll)  # most recent step that reset an env
-    log_vec[7] = float(N)  # spare slot: envs behind this vector, so the reduced vector carries the global env count
-    if use_dist:
-        dist.all_reduce(log_vec, op=dist.ReduceOp.SUM)
+    # the one collective of the path: the packed episode-metric vector, SUM all-reduced on a side stream, off the
+    # timed region (robot_lab_amd/dist.py reduce_episode_log - what a --distributed training run's rank-0 log uses, too)
+    from robot_lab_amd.dist import LOG_SLOT_NUM_ENVS, reduce_episode_log
+
+    log_vec = reduce_episode_log(env).vector()  # word LOG_SLOT_NUM_ENVS: the envs behind the reduced vector
 
     traffic = sq = prof_src = None
     try:  # measured separately with rocprofv3 PMC passes (cannot be collected inside this process)
@@ -216,7 +214,7 @@ def main():
         "config": {"workload": f"{args.task}, {N} envs/GPU, random actions U(-1,1), seed 42+rank", "envs_per_gpu": N,
                    "parallelism": f"env-shard x{world}"},
         "rccl_ranks": dist.get_world_size() if use_dist else 1, "collective_backend": ("gloo (RL_BENCH_SHARE_GPU self-test)" if share else "nccl (RCCL)") if use_dist else None,
-        "per_rank_env_steps_per_s": per_rank, "envs_behind_reduced_log": float(log_vec[7]),
+        "per_rank_env_steps_per_s": per_rank, "envs_behind_reduced_log": float(log_vec[LOG_SLOT_NUM_ENVS]),
         "window": {"envs_reset_in_window": envs_reset, "mean_bodies_in_contact_at_end": bodies_in_contact,
                    "preroll_steps": args.preroll,
                    "note": "rank 0; episode clocks randomised over [0, 1000) and `preroll_steps` untimed steps before the warm-up: steady state"},

@@ -401,6 +401,11 @@ int32_t rl_env_max_episode_length(const rl_env* env);
  * the launch size (csrc/rl_env.hip envs_per_wave; RL_ENV_SUB=4|1 forces either); results do not depend on it beyond fp32 round-off.
  * No counterpart in the reference (PhysX picks its own launch geometry): informational. */
 int32_t rl_env_envs_per_wavefront(const rl_env* env);
+/* The step kernel this env runs: 0 = the term-stack interpreter (reward / observation descriptors read from the table image - every
+ * task), > 0 = the id of a kernel SPECIALISED on the task (csrc/env_spec.h: the task's reward terms as compile-time constants), picked
+ * by rl_env_create when the compiled tables equal, bit for bit, the constants that kernel was generated from (RL_ENV_SPEC=0: never).
+ * Same results up to fp32 summation order.  No counterpart in the reference: informational. */
+int32_t rl_env_spec_id(const rl_env* env);
 
 int rl_env_destroy(rl_env* env);
 const char* rl_env_last_error(void);

@@ -18,7 +18,7 @@ HIP_LIB = os.path.join(_HERE, "csrc", "librl_env_hip.so")
 
 EXPORTS = [
     "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_step_record", "rl_env_get_buffer", "rl_env_export_state", "rl_env_commit_state",
-    "rl_env_import_state", "rl_env_read_log", "rl_env_log_slot", "rl_env_obs_slot", "rl_env_step_count", "rl_env_set_step_count", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length", "rl_env_envs_per_wavefront",
+    "rl_env_import_state", "rl_env_read_log", "rl_env_log_slot", "rl_env_obs_slot", "rl_env_step_count", "rl_env_set_step_count", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length", "rl_env_envs_per_wavefront", "rl_env_spec_id",
     "rl_env_destroy", "rl_env_last_error", "rl_env_desc_size", "rl_env_graph_begin", "rl_env_graph_end", "rl_env_graph_launching",
 ]
 
@@ -57,7 +57,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rl_env_read_log.argtypes = [C.c_void_p, fp, C.c_void_p]
     lib.rl_env_log_slot.argtypes = [C.c_void_p]
     lib.rl_env_log_slot.restype = C.c_int32
-    for n in ("rl_env_num_envs", "rl_env_num_actions", "rl_env_max_episode_length", "rl_env_envs_per_wavefront"):
+    for n in ("rl_env_num_envs", "rl_env_num_actions", "rl_env_max_episode_length", "rl_env_envs_per_wavefront", "rl_env_spec_id"):
         getattr(lib, n).argtypes = [C.c_void_p]
         getattr(lib, n).restype = C.c_int32
     lib.rl_env_obs_dim.argtypes = [C.c_void_p, C.c_int32]
@@ -101,6 +101,10 @@ class NativeEnv:
 
     def envs_per_wavefront(self) -> int:
         return int(self.lib.rl_env_envs_per_wavefront(self.handle))
+
+    def spec_id(self) -> int:
+        """0: the term-stack interpreter; > 0: the step kernel specialised on this task (csrc/env_spec.h)."""
+        return int(self.lib.rl_env_spec_id(self.handle))
 
     def error(self) -> str:
         return (self.lib.rl_env_last_error() or b"").decode()

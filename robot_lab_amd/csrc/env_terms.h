@@ -3,6 +3,7 @@
 // the reference function it restates; the same arithmetic in fp64 numpy is oracle/env.py, which is
 // pinned to the reference's own functions by tests/golden/.
 #pragma once
+#include "env_spec.h"
 #include "env_step.h"
 
 namespace rl {
@@ -317,7 +318,7 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
 }
 
 
-template <class Ctx, class TP>
+template <class Ctx, class TP, class SP = NoSpec>
 struct EnvProgram : EnvLane<Ctx, TP> {
   using Base = EnvLane<Ctx, TP>;
   using ChainTP = typename Base::ChainTP;
@@ -684,6 +685,230 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     return total;
   }
 
+  // ---------------------------------------------------------------- rewards, SPECIALISED on the task (env_spec.h)
+  // The same terms - term for term the arithmetic of term_value() above - with the task's term list a constant expression: every lane
+  // evaluates every term from its own registers.  Joint kinds: one pass over the lane's own joints (the sub-lanes of a limb hold them
+  // redundantly; a term's joint mask is a compile-time constant per limb), one DPP sum over the four limbs per term.  Body kinds: each
+  // lane over the body slots it owns (contact-sensor rows from its scratchpad), one DPP sum over the env's lanes per term.  Scalar
+  // kinds: replicated.  No statistics published to LDS, no descriptor reads, no dispatch; the per-term values end in registers of
+  // every lane, and the lane that writes term t back picks it with a select chain.
+  template <uint64_t MASK>
+  RL_FN static bool in_body_mask(int b) {  // b: a valid body index (< SP::N_BODIES)
+    if constexpr (MASK == 0ull) return false;
+    else if constexpr (SP::N_BODIES <= 32) return (((uint32_t)MASK >> (uint32_t)b) & 1u) != 0u;
+    else return ((MASK >> (uint64_t)b) & 1ull) != 0ull;
+  }
+  RL_FN float compute_rewards_spec(bool terminated) {
+    constexpr int NT = SP::N_REW;
+    constexpr int NACC = (NT + LPE - 1) / LPE;
+    Ctx& cx = ctx;                  // (plain locals for the nested generic lambdas below: g++ does not find names that come from
+    const int my_k = k, my_li = li; // using-declarations of the dependent base inside them)
+    float acc[NACC];  // episode sums of the terms this lane writes back: loaded now, consumed after the terms
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const int t = li + LPE * i;
+      acc[i] = t < NT ? S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] : 0.f;
+    }
+    RewEnv E;
+    E.gate = clampf(-grav_b.z, 0.f, 0.7f) * (1.0f / 0.7f);
+    E.cmd_norm = norm(cmd);
+    E.bv = fsqrt(lin_b.x * lin_b.x + lin_b.y * lin_b.y);
+    E.fc_hi = T.step_dt + 1e-8f;
+    E.moving = E.cmd_norm > 0.1f ? 1.f : 0.f;
+    E.terminated = terminated;
+    E.JT = nullptr; E.BT = nullptr; E.D = SP::D; E.ext_mask = 0ull;
+    E.cmd = cmd; E.lin_b = lin_b; E.ang_b = ang_b; E.lin_w = lin_w; E.vang = vang; E.grav_b = grav_b; E.pos = pos;
+    E.yaw_c = yaw_c; E.yaw_s = yaw_s; E.Rwb = Rwb;
+    const float gate = E.gate, cmd_norm = E.cmd_norm, bv = E.bv, moving = E.moving, fc_hi = E.fc_hi;
+    // partial sums of this lane: a0 a term's main accumulator, ax its extra ones (variance: four moments; biped: the minimum)
+    float a0[NT], ax[NT][4];
+    float gait_air[4] = {0.f, 0.f, 0.f, 0.f}, gait_con[4] = {0.f, 0.f, 0.f, 0.f};  // the four feet of a gait term (one such term at most is specialised)
+    static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      a0[t] = 0.f;
+      ax[t][0] = SP::REW[t].kind == REW_FEET_AIR_TIME_POSITIVE_BIPED ? 1e30f : 0.f;
+      ax[t][1] = ax[t][2] = ax[t][3] = 0.f;
+    });
+    // ---- joint kinds: this limb's share (identical in the limb's sub-lanes)
+    static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int kd = SP::REW[t].kind;
+      constexpr bool joint_kind = kd == REW_JOINT_TORQUES_L2 || kd == REW_JOINT_ACC_L2 || kd == REW_JOINT_VEL_L2 || kd == REW_JOINT_POS_LIMITS ||
+                                  kd == REW_JOINT_POWER || kd == REW_JOINT_DEVIATION_L1 || kd == REW_STAND_STILL || kd == REW_JOINT_POS_PENALTY ||
+                                  kd == REW_ACTION_RATE_L2;
+      if constexpr (joint_kind) {
+        constexpr uint32_t m0 = spec_lmask<SP>(t, 0), m1 = spec_lmask<SP>(t, 1), m2 = spec_lmask<SP>(t, 2), m3 = spec_lmask<SP>(t, 3);
+        constexpr uint32_t m_any = m0 | m1 | m2 | m3, m_all = m0 & m1 & m2 & m3;
+        const uint32_t lm = my_k == 0 ? m0 : (my_k == 1 ? m1 : (my_k == 2 ? m2 : m3));
+        float part = 0.f;
+        static_for<0, JX>([&](auto jc) __attribute__((always_inline)) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (((m_any >> j) & 1u) != 0u) {
+            float st;  // (this->: see above)
+            if constexpr (kd == REW_JOINT_TORQUES_L2) st = this->tau_app[j] * this->tau_app[j];
+            else if constexpr (kd == REW_JOINT_ACC_L2) st = this->qacc[j] * this->qacc[j];
+            else if constexpr (kd == REW_JOINT_VEL_L2) st = this->qd[j] * this->qd[j];
+            else if constexpr (kd == REW_JOINT_POS_LIMITS) st = fmaxf(this->L.soft_lo[j] - this->q[j], 0.f) + fmaxf(this->q[j] - this->L.soft_hi[j], 0.f);
+            else if constexpr (kd == REW_JOINT_POWER) st = fabsf(this->qd[j] * this->tau_app[j]);
+            else if constexpr (kd == REW_JOINT_DEVIATION_L1 || kd == REW_STAND_STILL) st = fabsf(this->q[j] - this->L.q0[j]);
+            else if constexpr (kd == REW_JOINT_POS_PENALTY) { const float dq = this->q[j] - this->L.q0[j]; st = dq * dq; }
+            else { const float da = this->act[j] - this->prev_act[j]; st = da * da; }
+            if constexpr (((m_all >> j) & 1u) != 0u) part += st;
+            else part += ((lm >> j) & 1u) != 0u ? st : 0.f;
+          }
+        });
+        a0[t] = part;
+      } else if constexpr (kd == REW_JOINT_MIRROR) {  // rewards.py:259-278: a pair is counted by the limb of its first joint; the partner's angle comes over by DPP
+        float part = 0.f;
+        static_for<0, SP::REW[t].n_idx>([&](auto pc) __attribute__((always_inline)) {
+          constexpr int pi = decltype(pc)::value;
+          constexpr int ja_id = SP::REW[t].idx_a[pi], jb_id = SP::REW[t].idx_b[pi];
+          constexpr int ka = SP::JOINT_K[ja_id], ja = SP::JOINT_J[ja_id], kb = SP::JOINT_K[jb_id], jb = SP::JOINT_J[jb_id];
+          float other = this->q[jb];
+          if constexpr (jb < CL && (ka ^ kb) != 0) other = cx.template limb_xor<(ka ^ kb)>(this->q[jb]);  // (a trunk joint sits in every lane)
+          const float d = this->q[ja] - other;
+          part += my_k == ka ? d * d : 0.f;
+        });
+        a0[t] = part;
+      }
+    });
+    // ---- body kinds: the body slots this lane owns
+    {
+      constexpr uint64_t REL = spec_rel_mask<SP>();
+      ChainTP C = this->new_chain();
+      // (trunk + limbs instance: the chain words in LDS already hold the kinematics of the final joint positions, step() stage 3)
+      if constexpr (REL != 0ull && NW == 0) chain_kinematics<TP>(L, q, C);
+#pragma unroll
+      for (int i = 0; i < Base::MAXOWN; ++i) {
+        const int so = this->own[i];
+        const int s = so < 0 ? 0 : so;
+        const int bo = L.slot_body[s];
+        const bool valid = so >= 0 && bo >= 0 && !(s == 0 && !L.owns_base_body);
+        const int b = valid ? bo : 0;
+        const F4 hs = hist_n.ld(s), ts = tim.ld(s);
+        const float hm = fmaxf(hs.x, fmaxf(hs.y, hs.z));
+        const float ca = ts.x, cc = ts.y, la = ts.z, lc = ts.w;
+        V3 relp{0.f, 0.f, 0.f}, relv{0.f, 0.f, 0.f};
+        if constexpr (REL != 0ull) {
+          if (valid && in_body_mask<REL>(b)) body_rel(C, s, relp, relv);
+        }
+        static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int kd = SP::REW[t].kind;
+          constexpr uint64_t BM = SP::REW[t].body_mask;
+          constexpr float p0 = SP::REW[t].p[0], p1 = SP::REW[t].p[1];
+          if constexpr (kd == REW_FEET_GAIT) {  // the four feet's timers, each into its own accumulator: the sum over the env below is a broadcast
+            static_for<0, 4>([&](auto fc) __attribute__((always_inline)) {
+              constexpr int f = decltype(fc)::value;
+              const bool is = valid && b == SP::REW[t].idx_a[f];
+              gait_air[f] += is ? ca : 0.f;
+              gait_con[f] += is ? cc : 0.f;
+            });
+          } else if constexpr (BM != 0ull) {
+            const bool on = valid && in_body_mask<BM>(b);
+            if constexpr (kd == REW_UNDESIRED_CONTACTS) a0[t] += on && hm > p0 ? 1.f : 0.f;                      // rewards.py:665-675
+            else if constexpr (kd == REW_CONTACT_FORCES) a0[t] += on ? fmaxf(hm - p0, 0.f) : 0.f;                 // [UPSTREAM] contact_forces
+            else if constexpr (kd == REW_FEET_CONTACT_WITHOUT_CMD || kd == REW_FEET_CONTACT) a0[t] += on && cc > 0.f && cc < fc_hi ? 1.f : 0.f;  // rewards.py:416-425, 399-413
+            else if constexpr (kd == REW_FEET_AIR_TIME) a0[t] += on && cc > 0.f && cc < fc_hi ? la - p0 : 0.f;    // rewards.py:340-360
+            else if constexpr (kd == REW_FEET_AIR_TIME_POSITIVE_BIPED) {                                          // rewards.py:363-383
+              const bool inc = cc > 0.f;
+              a0[t] += on && inc ? 1.f : 0.f;
+              ax[t][0] = on ? fminf(ax[t][0], inc ? cc : ca) : ax[t][0];
+            } else if constexpr (kd == REW_FEET_AIR_TIME_VARIANCE) {                                              // rewards.py:386-397
+              const float xa = fminf(la, 0.5f), xc = fminf(lc, 0.5f), o = on ? 1.f : 0.f;
+              a0[t] += o; ax[t][0] += o * xa; ax[t][1] += o * xa * xa; ax[t][2] += o * xc; ax[t][3] += o * xc * xc;
+            } else if constexpr (kd == REW_FEET_STUMBLE) {                                                        // rewards.py:428-436
+              const F4 fs = cf.ld(s);
+              a0[t] += on && fsqrt(fs.x * fs.x + fs.y * fs.y) > 4.f * fabsf(fs.z) ? 1.f : 0.f;
+            } else if constexpr (kd == REW_FEET_HEIGHT_BODY) {                                                    // rewards.py:527-554
+              const float er = relp.z - p0;
+              a0[t] += on ? er * er * ftanh(p1 * fsqrt(relv.x * relv.x + relv.y * relv.y)) : 0.f;
+            } else if constexpr (kd == REW_FEET_SLIDE) {                                                          // rewards.py:557-587
+              a0[t] += on && hm > 1.0f ? fsqrt(relv.x * relv.x + relv.y * relv.y) : 0.f;
+            } else if constexpr (kd == REW_FEET_HEIGHT) {                                                         // rewards.py:507-524
+              const V3 vw = lin_w + mul(Rwb, relv);
+              const float er = pos.z + dot(Rwb.r2, relp) - p0;
+              a0[t] += on ? er * er * ftanh(p1 * fsqrt(vw.x * vw.x + vw.y * vw.y)) : 0.f;
+            }
+          }
+        });
+      }
+    }
+    // ---- the env's sums (every lane ends with the same bits: gsum / esum pair identical values) and the terms' own arithmetic
+    RL_PHASE(17, "rewards.terms");
+    const float step_dt = ctx.uniform(T.step_dt);
+    float v[NT];
+    float total = 0.f;
+    static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int kd = SP::REW[t].kind;
+      constexpr float p0 = SP::REW[t].p[0], p1 = SP::REW[t].p[1], p2 = SP::REW[t].p[2], p3 = SP::REW[t].p[3];
+      float f = 0.f;
+      if constexpr (is_scalar_reward_kind(kd)) {
+        RewTab R{};
+        R.kind = kd; R.p[0] = p0; R.p[1] = p1; R.p[2] = p2; R.p[3] = p3;
+        f = scalar_term_value(R, E);
+      } else if constexpr (kd == REW_JOINT_TORQUES_L2 || kd == REW_JOINT_ACC_L2 || kd == REW_JOINT_VEL_L2 || kd == REW_JOINT_POS_LIMITS || kd == REW_JOINT_POWER ||
+                           kd == REW_JOINT_DEVIATION_L1 || kd == REW_ACTION_RATE_L2) {
+        f = cx.gsum(a0[t]);
+      } else if constexpr (kd == REW_STAND_STILL) {
+        f = cx.gsum(a0[t]) * (cmd_norm < p0 ? 1.f : 0.f) * gate;
+      } else if constexpr (kd == REW_JOINT_POS_PENALTY) {
+        const float run = fsqrt(cx.gsum(a0[t]));
+        f = ((cmd_norm > p2 || bv > p1) ? run : p0 * run) * gate;
+      } else if constexpr (kd == REW_JOINT_MIRROR) {
+        f = cx.gsum(a0[t]) * p0 * gate;
+      } else if constexpr (kd == REW_FEET_GAIT) {  // GaitReward, rewards.py:156-256
+        float air[4], con[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { air[i] = cx.esum(gait_air[i]); con[i] = cx.esum(gait_con[i]); }
+        const float inv_std = frcp(p0), me2 = p1 * p1;
+        auto se = [&](float a, float b) { float d = a - b; return fminf(d * d, me2); };
+        float sacc = se(air[0], air[1]) + se(con[0], con[1]) + se(air[2], air[3]) + se(con[2], con[3]);
+        sacc += se(air[0], con[2]) + se(con[0], air[2]) + se(air[1], con[3]) + se(con[1], air[3]);
+        sacc += se(air[0], con[3]) + se(con[0], air[3]) + se(air[2], con[1]) + se(con[2], air[1]);
+        f = ((cmd_norm > p3 || bv > p2) ? fexp(-sacc * inv_std) : 0.f) * gate;
+      } else {
+        const float s0 = cx.esum(a0[t]);
+        if constexpr (kd == REW_UNDESIRED_CONTACTS) f = s0 * gate;
+        else if constexpr (kd == REW_CONTACT_FORCES) f = s0;
+        else if constexpr (kd == REW_FEET_CONTACT_WITHOUT_CMD) f = s0 * (cmd_norm < 0.1f ? 1.f : 0.f) * gate;
+        else if constexpr (kd == REW_FEET_CONTACT) f = (s0 != p0 ? 1.f : 0.f) * moving * gate;
+        else if constexpr (kd == REW_FEET_AIR_TIME) f = s0 * moving * gate;
+        else if constexpr (kd == REW_FEET_STUMBLE) f = (s0 > 0.f ? 1.f : 0.f) * gate;
+        else if constexpr (kd == REW_FEET_HEIGHT_BODY || kd == REW_FEET_HEIGHT) f = s0 * moving * gate;
+        else if constexpr (kd == REW_FEET_SLIDE) f = s0 * gate;
+        else if constexpr (kd == REW_FEET_AIR_TIME_POSITIVE_BIPED) {
+          const float mn = cx.emin(ax[t][0]);  // (a collective: every lane, whatever s0 says)
+          f = (s0 == 1.f ? fminf(mn, p0) : 0.f) * moving * gate;
+        }
+        else if constexpr (kd == REW_FEET_AIR_TIME_VARIANCE) {
+          const float s1 = cx.esum(ax[t][0]), s2 = cx.esum(ax[t][1]), s3 = cx.esum(ax[t][2]), s4 = cx.esum(ax[t][3]);
+          const float inv_n = frcp(s0), inv_den = frcp(fmaxf(s0 - 1.f, 1.f));
+          f = ((s2 - s1 * s1 * inv_n) + (s4 - s3 * s3 * inv_n)) * inv_den * gate;
+        }
+      }
+      v[t] = f * SP::REW[t].weight * step_dt;  // RewardManager [UPSTREAM B2]
+      total += v[t];
+    });
+    // ---- per-term outputs + episode sums: term t by lane t % LPE
+    RL_PHASE(18, "rewards.writeback");
+    static_for<0, NACC>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      float mine = 0.f;
+      static_for<0, LPE>([&](auto cc2) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc2)::value, tt = i * LPE + c;
+        if constexpr (tt < NT) mine = my_li == c ? v[tt] : mine;
+      });
+      const int t = my_li + LPE * i;
+      if (t < NT) {
+        S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = mine;
+        S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = acc[i] + mine;
+      }
+    });
+    return total;
+  }
+
   // ---------------------------------------------------------------- observations [UPSTREAM B2 / B6]
   // pose of the height scanner: the root link on the quadrupeds, the torso on G1 (rides on trunk link scan_depth).  `scan_p`: x, y
   // as offsets from the root position (the terrain lookup adds the root in fp64, env_step.h terrain_fetch), z the world height
@@ -992,7 +1217,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #ifdef RL_ABL_NO_REWARDS  // analysis builds: what the kernel costs without this stage (tools/ablate.sh)
     float rew = 0.f;
 #else
-    float rew = compute_rewards(terminated);
+    float rew;
+    if constexpr (SP::ON) rew = compute_rewards_spec(terminated);
+    else rew = compute_rewards(terminated);
 #endif
     RL_PHASE(19, "resets+commands+push");
     if (li == 0) {

@@ -14,6 +14,21 @@
 extern "C" __attribute__((visibility("hidden"))) int rl_env_launch_sub1(const void* cfg, const void* S, const void* T, int inst, size_t lds1, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl_env_launch_sub2(const void* cfg, const void* S, const void* T, int inst, size_t lds1, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl_env_launch_sub8(const void* cfg, const void* S, const void* T, int inst, size_t lds1, void* stream);
+// ... and of the step kernels specialised on one task (rl_env_spec.inl; one translation unit per Spec under csrc/spec/)
+#ifndef RL_ENV_SINGLE_TU
+#define RL_SPEC_DECL(NAME, ID) extern "C" __attribute__((visibility("hidden"))) int rl_env_launch_spec##ID(const void* cfg, const void* S, const void* T, int sub, size_t lds1, void* stream);
+#else  // one-instance builds: no specialised kernels, or (-DRL_ENV_SPEC_ONLY=<id>) that one Spec's
+#ifndef RL_ENV_SPEC_ONLY
+#define RL_ENV_SPEC_ONLY 0
+#endif
+#define RL_SPEC_DECL(NAME, ID)                                                                                                            \
+  static int rl_env_launch_spec##ID(const void* cfg, const void* S, const void* T, int sub, size_t lds1, void* stream) {                      \
+    if constexpr (ID == RL_ENV_SPEC_ONLY) return launch_spec<rl::NAME>(*static_cast<const LaunchCfg*>(cfg), *static_cast<const rl::KState*>(S), T, sub, lds1, (hipStream_t)stream); \
+    else return -2;                                                                                                                       \
+  }
+#endif
+RL_SPEC_LIST(RL_SPEC_DECL)
+#undef RL_SPEC_DECL
 #ifdef RL_ENV_SINGLE_TU
 #define RL_ENV_TU_SUB 1
 #include "rl_env_sub.inl"
@@ -192,8 +207,19 @@ struct Backend {
     }
     return 0;
   }
+  int spec_id = 0;  // env_spec.h: the Spec whose constants equal this env's tables (rl_env_host.h create), 0: the interpreter
   int launch(const KState& S, const void* T, int CL, void* stream) {  // CL: chain length, + 100 for a merged instance; S.mode: what to run
     hipStream_t st = (hipStream_t)stream;
+    if (spec_id != 0 && S.mode == KMODE_STEP) {  // the step kernel specialised on this task, when the build has it for the lane mapping
+      int rc = -2;
+      switch (spec_id) {
+#define RL_SPEC_CASE(NAME, ID) case ID: rc = rl_env_launch_spec##ID(&cfg, &S, T, sub, lds_bytes, stream); break;
+        RL_SPEC_LIST(RL_SPEC_CASE)
+#undef RL_SPEC_CASE
+        default: break;
+      }
+      if (rc != -2) return check((hipError_t)rc);
+    }
     // RL_ENV_ONLY=<CL * 10 + SUB> (e.g. 34; 1044: merged): build that one instance only - kernel experiments compile in 15 s instead of 80
 #ifndef RL_ENV_ONLY
 #define RL_ENV_ONLY 0

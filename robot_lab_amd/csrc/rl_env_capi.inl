@@ -126,6 +126,7 @@ int32_t rl_env_obs_dim(const rl_env* env, int32_t group) {
 }
 int32_t rl_env_max_episode_length(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->tables.max_episode_length; }
 int32_t rl_env_envs_per_wavefront(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->ept; }
+int32_t rl_env_spec_id(const rl_env* env) { return env ? reinterpret_cast<const Impl*>(env)->spec_id : -1; }
 
 int rl_env_destroy(rl_env* env) {
   if (!env) return 0;

@@ -12,6 +12,7 @@
 
 #include "../../include/rl_env.h"
 #include "env_aos.h"
+#include "env_spec.h"
 #include "env_tables.h"
 
 namespace rl {
@@ -479,6 +480,21 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   return 0;
 }
 
+// descriptor -> Tables as rl_env_create does it (tools/gen_specs.py compiles the specialised term stacks from the same call)
+inline int compile_tables(const rl_env_desc& d, Tables& tables, std::vector<int>& body_lane, std::vector<int>& body_slot, std::vector<int>& link_lane,
+                          std::vector<int>& link_pos) {
+  // wheeled quadrupeds (4-joint limbs): the merged instance when the trunk's spheres fit the free sphere slots of the limbs
+  // (Go2W, ZSL1W, M20, Dog-W), else the instance with a link group for the trunk share.  RL_ENV_MERGE=0: never merged, 2: whenever it fits.
+  const char* mv = std::getenv("RL_ENV_MERGE");
+  const bool want = d.model.num_trunk == 0 && d.model.chain_len == 4 && !(mv && atoi(mv) == 0);
+  bool merged = want && build_tables(d, tables, body_lane, body_slot, link_lane, link_pos, true) == 0;
+  // it pays when the last link group (the wheels) has spheres - the group that costs the unmerged instance a second contact
+  // pass; without (B2W) the unmerged instance skips that pass anyway and is 1 % faster (profiles/r02_merged_wheeled.txt)
+  if (merged && ((tables.slot_valid >> (tables.CL * tables.SPL)) & ((1u << tables.SPL) - 1u)) == 0u && !(mv && atoi(mv) == 2)) merged = false;
+  if (!merged && build_tables(d, tables, body_lane, body_slot, link_lane, link_pos, false)) return -1;
+  return 0;
+}
+
 // packed (per-instance) table image that the env kernels stage into LDS
 inline size_t packed_size(const TaskTab& T) {
   return T.NW > 3 ? sizeof(TablesT<TopoGR>) : T.NW > 0 ? sizeof(TablesT<TopoG1>) : (T.CL == 4 ? sizeof(TablesT<TopoQuad4>) : sizeof(TablesT<TopoQuad3>));
@@ -511,6 +527,7 @@ struct EnvImpl {
   void* packed_dev = nullptr;     // TablesT<Topo> image the env kernels stage into LDS
   KState S;
   CmdLevelParams cmd_level_params{};
+  int spec_id = 0;  // env_spec.h: the specialised step kernel this env runs (0: the interpreter)
   int N = 0, Npad = 0, D = 0, B = 0, CL = 0, inst = 0, ept = ENVS_PER_WAVE;  // inst: lane-program instance key (CL, + 100 merged, + 200 six-joint trunk)
   uint64_t seed = 0;
   uint32_t step_counter = 0;
@@ -554,17 +571,15 @@ struct EnvImpl {
     D = d->model.num_dof;
     B = d->model.num_bodies;
     if (N <= 0) return fail("num_envs must be positive");
-    {
-      // wheeled quadrupeds (4-joint limbs): the merged instance when the trunk's spheres fit the free sphere slots of the limbs
-      // (Go2W, ZSL1W, M20, Dog-W), else the instance with a link group for the trunk share.  RL_ENV_MERGE=0: never merged, 2: whenever it fits.
-      const char* mv = std::getenv("RL_ENV_MERGE");
-      const bool want = d->model.num_trunk == 0 && d->model.chain_len == 4 && !(mv && atoi(mv) == 0);
-      bool merged = want && build_tables(*d, tables, body_lane, body_slot, link_lane, link_pos, true) == 0;
-      // it pays when the last link group (the wheels) has spheres - the group that costs the unmerged instance a second contact
-      // pass; without (B2W) the unmerged instance skips that pass anyway and is 1 % faster (profiles/r02_merged_wheeled.txt)
-      if (merged && ((tables.slot_valid >> (tables.CL * tables.SPL)) & ((1u << tables.SPL) - 1u)) == 0u && !(mv && atoi(mv) == 2)) merged = false;
-      if (!merged && build_tables(*d, tables, body_lane, body_slot, link_lane, link_pos, false)) return -1;
+    if (compile_tables(*d, tables, body_lane, body_slot, link_lane, link_pos)) return -1;
+    // a step kernel specialised on exactly this task (env_spec.h)?  RL_ENV_SPEC=0: the interpreter (A/B runs, parity of the two paths)
+    spec_id = 0;
+    if (!(std::getenv("RL_ENV_SPEC") && atoi(std::getenv("RL_ENV_SPEC")) == 0)) {
+#define RL_SPEC_MATCH(NAME, ID) if (spec_id == 0 && spec_matches<NAME>(tables)) spec_id = ID;
+      RL_SPEC_LIST(RL_SPEC_MATCH)
+#undef RL_SPEC_MATCH
     }
+    be.spec_id = spec_id;
     CL = tables.CL;
     inst = tables.CL + (tables.merged ? 100 : 0) + (tables.NW > 3 ? 200 : 0);
     if (be.init(device)) return fail("device init failed: " + be.error());

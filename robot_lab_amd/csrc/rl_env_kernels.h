@@ -126,6 +126,27 @@ struct WaveCtx {
     return v;
   }
   __device__ float esum(float v) const { return gsum(leg_sum(v)); }
+  // the value held by the same sub-lane position of limb k ^ X of this env (X = 1, 2, 3): one DPP move, or two where the exchange is
+  // not a single pattern of the mapping (the specialised joint_mirror term, env_terms.h compute_rewards_spec).  Inputs are replicated
+  // over a limb's sub-lanes, so WHICH sub-lane of the partner limb a lane reads does not matter.
+  template <int X>
+  __device__ float limb_xor(float v) const {
+    static_assert(X >= 1 && X <= 3, "limb index xor");
+    constexpr int DPP_QUAD_REV = 0x1B;  // quad_perm:[3,2,1,0]
+    constexpr int DPP_ROW_ROR8 = 0x128; // row_ror:8
+    if constexpr (SUB == 1) return dpp_move<X == 1 ? DPP_QUAD_XOR1 : (X == 2 ? DPP_QUAD_XOR2 : DPP_QUAD_REV)>(v);  // a limb is a lane of the quad
+    else if constexpr (SUB == 2) {  // a limb is a lane pair, the env a half row
+      if constexpr (X == 1) return dpp_move<DPP_QUAD_XOR2>(v);
+      else if constexpr (X == 3) return dpp_move<DPP_ROW_HALF_MIRROR>(v);
+      else return dpp_move<DPP_ROW_HALF_MIRROR>(dpp_move<DPP_QUAD_XOR2>(v));
+    } else if constexpr (SUB == 4) {  // a limb is a quad, the env a row
+      return dpp_move<X == 1 ? DPP_ROW_HALF_MIRROR : (X == 3 ? DPP_ROW_MIRROR : DPP_ROW_ROR8)>(v);
+    } else {  // SUB == 8: a limb is half a row, the env two rows
+      if constexpr (X == 1) return dpp_move<DPP_ROW_MIRROR>(v);
+      else if constexpr (X == 2) return swap_rows(v);
+      else return swap_rows(dpp_move<DPP_ROW_MIRROR>(v));
+    }
+  }
   // min over the lanes of the env
   __device__ float emin(float v) const {
     v = fminf(v, dpp<DPP_QUAD_XOR1>(v));
@@ -226,7 +247,9 @@ extern __shared__ float4 smem4[];
 #ifndef RL_LB
 #define RL_LB(w) 256
 #endif
-template <class TP, int RESET, int SUB, int WGW>
+// SP: NoSpec - the term stack interpreted from the table image; a Spec of spec/env_specs_gen.h - the step kernel of ONE task, its reward
+// terms (and, RESET == 0 only) constant expressions (env_spec.h)
+template <class TP, int RESET, int SUB, int WGW, class SP = NoSpec>
 __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* __restrict__ Tgv, uint32_t wave_words) {
   using Ctx = WaveCtx<SUB>;
   using Tables = TablesT<TP>;
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   ctx.stage[1] = ctx.stage[0] + s0w;
   ctx.fstage = ctx.stage[1] + s1w;
   ctx.lane = lane;
-  EnvProgram<Ctx, TP> prog(ctx, S);
+  EnvProgram<Ctx, TP, SP> prog(ctx, S);
   if (RESET == 1)
     prog.reset_entry();  // (KMODE_RESET, and KMODE_STEP_TAIL: the second launch of a step split around the command-range decision)
   else if (RESET == 2)
@@ -323,13 +346,14 @@ struct LaunchCfg {
 // Kernels per (instance, mapping): step with one / four wavefronts per workgroup; the reset entry (+ the tail of a split step) with
 // one; the head of a split step - command-range curricula, which no shipped cfg has - with one and for the 16-lane mapping only
 // (rl_env_create keeps such tasks on it).
-template <class TP, int SUB, int WGW>
+template <class TP, int SUB, int WGW, class SP = NoSpec>
 hipError_t launch_w(const LaunchCfg& cfg, const KState& S, const void* T, size_t lds1, hipStream_t st) {
   const int tiles = S.Npad / (16 / SUB);
   dim3 grid((tiles + WGW - 1) / WGW), block(64 * WGW);
   const uint32_t wave_words = (uint32_t)((lds1 - S.table_bytes) >> 2);
   const size_t lds = S.table_bytes + (size_t)WGW * (lds1 - S.table_bytes);
-  constexpr bool HEAD = SUB == 4 && WGW == 1, RESET = WGW == 1;
+  // (a specialised instance is the step kernel only: resets and the halves of a split step run the interpreter's kernels)
+  constexpr bool HEAD = SUB == 4 && WGW == 1 && !SP::ON, RESET = WGW == 1 && !SP::ON;
   if (lds > 64 * 1024) {
     // opt in to the large LDS carve-out (160 KB per CU on gfx950).  The attribute belongs to the (kernel, device) pair and
     // must cover the LARGEST request: remember per device what was configured and raise it when an env needs more.
@@ -338,7 +362,7 @@ hipError_t launch_w(const LaunchCfg& cfg, const KState& S, const void* T, size_t
     std::lock_guard<std::mutex> lock(mu);
     size_t& have = configured[cfg.device & 63];
     if (lds > have) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 0, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 0, SUB, WGW, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       if constexpr (RESET) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&env_kernel<TP, 1, SUB, WGW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -358,11 +382,11 @@ hipError_t launch_w(const LaunchCfg& cfg, const KState& S, const void* T, size_t
     if constexpr (HEAD) hipLaunchKernelGGL((env_kernel<TP, 2, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
     else return hipErrorInvalidValue;
   } else {
-    hipLaunchKernelGGL((env_kernel<TP, 0, SUB, WGW>), grid, block, lds, st, S, T, wave_words);
+    hipLaunchKernelGGL((env_kernel<TP, 0, SUB, WGW, SP>), grid, block, lds, st, S, T, wave_words);
   }
   return hipGetLastError();
 }
-template <class TP, int SUB>
+template <class TP, int SUB, class SP = NoSpec>
 hipError_t launch_cl(const LaunchCfg& cfg, const KState& S, const void* T, size_t lds1, hipStream_t st) {
   // (the trunk + limbs instance with 16 lanes per env gains nothing: 174.4 vs 173.8 us with two wavefronts per workgroup - and its 80 KB
   // per wavefront leave no room; with 32 lanes per env four ~32 KB wavefronts and ONE table image are what lets a CU hold four)
@@ -371,9 +395,35 @@ hipError_t launch_cl(const LaunchCfg& cfg, const KState& S, const void* T, size_
     const size_t lds4 = S.table_bytes + 4 * (lds1 - S.table_bytes);
     // (only the step kernel exists in the four-wavefront shape: resets and the halves of a split step are off the hot path)
     if (cfg.wg_waves == 4 && (tiles >= 4 * cfg.n_cu || cfg.wg_force) && lds4 <= 160 * 1024 && S.mode == KMODE_STEP)
-      return launch_w<TP, SUB, 4>(cfg, S, T, lds1, st);
+      return launch_w<TP, SUB, 4, SP>(cfg, S, T, lds1, st);
   }
-  return launch_w<TP, SUB, 1>(cfg, S, T, lds1, st);
+  return launch_w<TP, SUB, 1, SP>(cfg, S, T, lds1, st);
+}
+
+// Launch of the step kernel SPECIALISED on the task of Spec SP (env_spec.h) in lane mapping `sub`; a hipError_t, or -2 when there is no
+// specialised kernel for the mapping / the launch mode (the caller then launches the interpreter's kernel).  Instantiated once per Spec:
+// in that Spec's own translation unit (csrc/spec/rl_env_spec_<id>.hip, so that hipcc compiles the specialised tasks side by side), or -
+// single-translation-unit builds of ONE instance (tools/build_variant.sh, tools/kbuild.sh) - in rl_env.hip for -DRL_ENV_SPEC_ONLY=<id>.
+template <class SP>
+int launch_spec(const LaunchCfg& cfg, const KState& S, const void* T, int sub, size_t lds1, hipStream_t st) {
+  using TP = typename SP::TP;
+  if (S.mode != KMODE_STEP) return -2;
+  if constexpr (TP::NW > 0) {  // trunk + limbs instances: the 32-lanes-per-env mapping (what every launch size picks when the model fits it)
+    if (sub == 8) return (int)launch_cl<TP, 8, SP>(cfg, S, T, lds1, st);
+    return -2;
+  } else {
+#ifdef RL_ENV_SPEC_SUB  // (variant builds: one lane mapping only)
+    if (sub == RL_ENV_SPEC_SUB) return (int)launch_cl<TP, RL_ENV_SPEC_SUB, SP>(cfg, S, T, lds1, st);
+    return -2;
+#else
+    switch (sub) {
+      case 4: return (int)launch_cl<TP, 4, SP>(cfg, S, T, lds1, st);
+      case 2: return (int)launch_cl<TP, 2, SP>(cfg, S, T, lds1, st);
+      case 1: return (int)launch_cl<TP, 1, SP>(cfg, S, T, lds1, st);
+      default: return -2;
+    }
+#endif
+  }
 }
 
 }  // namespace

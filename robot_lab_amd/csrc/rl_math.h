@@ -13,7 +13,10 @@ namespace rl {
 
 // Fast reciprocal / square root: one hardware instruction (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32, 1 ulp)
 // on gfx950 instead of the IEEE division / sqrt expansion (~10 instructions each); exact on the host.
-#if defined(__HIP_DEVICE_COMPILE__)
+// -DRL_EXACT_MATH (analysis builds, tools/build_variant.sh): the correctly rounded division / square root and libm's expf / sinf / cosf
+// on the device as well - what the teacher-forced parity tier's tolerance floor is made of (the share of entries
+// inside a flat 1e-5 with and without the hardware approximations, profiles/r05_exact_math_*).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RL_EXACT_MATH)
 RL_FN float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 RL_FN float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 RL_FN float frsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -23,7 +26,7 @@ RL_FN float fsqrt(float x) { return sqrtf(x); }
 RL_FN float frsqrt(float x) { return 1.0f / sqrtf(x); }
 #endif
 RL_FN float fdiv(float a, float b) { return a * frcp(b); }
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RL_EXACT_MATH)
 RL_FN float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }  // v_exp_f32: ~1 ulp, fine at reward tolerances
 #else
 RL_FN float fexp(float x) { return expf(x); }
@@ -91,7 +94,7 @@ RL_FN S3 rotate(const M3& R, const S3& s) {
 }
 
 // rotation about unit axis by angle (child -> parent coordinates)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RL_EXACT_MATH)
 // v_sin_f32 / v_cos_f32 take revolutions; |error| ~1e-6 for the joint-angle range, two instructions each
 // (the libm sinf / cosf expand to ~50 instructions apiece and sat in every substep's kinematics)
 RL_FN void fsincos(float x, float& s, float& c) {

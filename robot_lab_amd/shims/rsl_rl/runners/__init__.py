@@ -54,6 +54,7 @@ class OnPolicyRunner:
         self.save_interval = int(train_cfg.get("save_interval", 50))
         self.current_learning_iteration = 0
         self.git_status_repos = []
+        self.last_episode_log = None  # rank 0: extras["log"] with the means over every rank's envs (robot_lab_amd/dist.py reduce_episode_log)
 
     def add_git_repo_to_log(self, path):
         self.git_status_repos.append(path)
@@ -71,11 +72,19 @@ class OnPolicyRunner:
             out = self.trainer.iterate()
             self.current_learning_iteration = it + 1
             steps = self.trainer.storage.num_transitions_per_env * env.num_envs * self.group.world_size
+            # the episode log of the JOB, not of rank 0's envs: the packed episode-metric vector SUM all-reduced over the ranks on a side
+            # stream (every rank takes part in the collective, rank 0 alone reads the result)
+            from robot_lab_amd.dist import reduce_episode_log
+
+            episode_log = reduce_episode_log(env)
             if not main:
                 continue
+            self.last_episode_log = ep = episode_log.result()
             print(f"[rsl_rl stand-in] iteration {it + 1}/{start + num_learning_iterations}  mean reward/step {out['mean_reward']:+.4f}  value loss {out['value_loss']:.4f}  "
                   f"surrogate {out['surrogate_loss']:+.4f}  std {out['action_std']:.3f}  lr {out['learning_rate']:.1e}  "
-                  f"{steps * (it + 1 - start) / max(time.time() - t0, 1e-9):.0f} steps/s", flush=True)
+                  f"{steps * (it + 1 - start) / max(time.time() - t0, 1e-9):.0f} steps/s  "
+                  f"episode log over {int(ep['num_envs'])} envs ({int(ep['episodes'])} episodes ended)"
+                  + (f"  terrain level {float(ep['Curriculum/terrain_levels']):.2f}" if "Curriculum/terrain_levels" in ep else ""), flush=True)
             if self.log_dir and (it + 1) % self.save_interval == 0:
                 self.save(os.path.join(self.log_dir, f"model_{it + 1}.pt"))
         if self.log_dir and main:

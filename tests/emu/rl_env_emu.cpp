@@ -22,6 +22,7 @@
 #include "../../robot_lab_amd/csrc/env_aos.h"
 #include "../../robot_lab_amd/csrc/env_terms.h"
 #include "../../robot_lab_amd/csrc/rl_env_host.h"
+#include "../../robot_lab_amd/csrc/rl_env_specgen.h"
 
 namespace {
 
@@ -377,6 +378,8 @@ struct HostCtx {
     team->barrier(li());
     return out;
   }
+  template <int X>
+  float limb_xor(float v) { return gshfl(v, k_ ^ X); }
   float gshfl(float v, int leg) {
     team->slot[li()] = v;
     team->barrier(li());
@@ -404,7 +407,7 @@ struct HostCtx {
   }
 };
 
-template <class TP, int SUB>
+template <class TP, int SUB, class SP = rl::NoSpec>
 void run(const rl::KState& S_launch, const void* Tv) {
   rl::KState S = S_launch;
   S.step_counter += *S.step_base;  // as the kernel entry does
@@ -429,7 +432,7 @@ void run(const rl::KState& S_launch, const void* Tv) {
     for (int tile = tm; tile < tiles; tile += teams)
       for (int e = tile * Ctx::EPT; e < std::min((tile + 1) * Ctx::EPT, (int)S.Npad); ++e) {
         ctx.e_ = e;
-        rl::EnvProgram<Ctx, TP> prog(ctx, S);
+        rl::EnvProgram<Ctx, TP, SP> prog(ctx, S);
         if (S.mode == rl::KMODE_RESET || S.mode == rl::KMODE_STEP_TAIL)
           prog.reset_entry();
         else if (S.mode == rl::KMODE_STEP_HEAD)
@@ -455,7 +458,7 @@ void run(const rl::KState& S_launch, const void* Tv) {
     for (int tile = tm; tile < tiles; tile += teams)
       for (int e = tile * Ctx::EPT; e < std::min((tile + 1) * Ctx::EPT, (int)S.Npad); ++e) {
         ctx.e_ = e;
-        rl::EnvProgram<Ctx, TP> prog(ctx, S);
+        rl::EnvProgram<Ctx, TP, SP> prog(ctx, S);
         if (S.mode == rl::KMODE_RESET || S.mode == rl::KMODE_STEP_TAIL)
           prog.reset_entry();
         else if (S.mode == rl::KMODE_STEP_HEAD)
@@ -486,7 +489,35 @@ struct Backend {
   void zero(void* p, size_t n) { std::memset(p, 0, n); }
   void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
   void h2d_stream(void* d, const void* s, size_t n, void*) { std::memcpy(d, s, n); }
+  int spec_id = 0;  // env_spec.h: the Spec whose constants equal the env's tables (0: the interpreter)
+  // the specialised lane programs the emulator carries: every Spec with one lane per limb and with the mapping its kernel runs at the
+  // BASELINE size (quadrupeds: 16 lanes per env; trunk + limbs: 32), A1 also with two sub-lanes per limb
+  template <class SP>
+  bool run_spec(const rl::KState& S, const void* T) {
+    using TP = typename SP::TP;
+    if constexpr (TP::NW > 0) {
+      if (sub == 1) { run<TP, 1, SP>(S, T); return true; }
+      if (sub == 8) { run<TP, 8, SP>(S, T); return true; }
+    } else {
+      if (sub == 1) { run<TP, 1, SP>(S, T); return true; }
+      if (sub == 4) { run<TP, 4, SP>(S, T); return true; }
+      if constexpr (SP::ID == 1) {
+        if (sub == 2) { run<TP, 2, SP>(S, T); return true; }
+      }
+    }
+    return false;
+  }
   int launch(const rl::KState& S, const void* T, int CL, void*) {
+#if !defined(RL_EMU_ONLY)
+    if (spec_id != 0 && S.mode == rl::KMODE_STEP) {
+      switch (spec_id) {
+#define RL_SPEC_CASE(NAME, ID) case ID: if (run_spec<rl::NAME>(S, T)) return 0; break;
+        RL_SPEC_LIST(RL_SPEC_CASE)
+#undef RL_SPEC_CASE
+        default: break;
+      }
+    }
+#endif
     // -DRL_EMU_ONLY=<CL * 10 + sub> (+ 1000 merged, + 2000 six-joint trunk): instantiate that one lane program only (bench.py's CPU baseline
     // builds the A1 one-lane-per-limb instance in 20 s instead of all fifteen in minutes)
     switch (CL * 10 + sub) {
@@ -563,6 +594,17 @@ struct Backend {
 }  // namespace
 
 #include "../../robot_lab_amd/csrc/rl_env_capi.inl"
+
+// build-time tooling (emulator library only): the C++ source of the Spec of a task (csrc/rl_env_specgen.h; tools/gen_specs.py).
+// Returns the length written (0: the task cannot be specialised - rl_env_last_error says why; -1: `cap` too small).
+extern "C" int rl_env_spec_source(const rl_env_desc* desc, const char* struct_name, const char* task, int id, char* out, int cap) {
+  if (!desc || !struct_name || !task || !out) return 0;
+  const std::string src = rl::spec_source(*desc, struct_name, task, id);
+  if (src.empty()) return 0;
+  if ((int)src.size() + 1 > cap) return -1;
+  std::memcpy(out, src.c_str(), src.size() + 1);
+  return (int)src.size();
+}
 
 // test hook (emulator library only): the lane program's randomness primitive, for tests/test_philox.py
 extern "C" float rl_test_uniform01(uint64_t seed, uint32_t env, uint32_t counter, uint32_t stream, uint32_t index) {

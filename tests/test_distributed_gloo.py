@@ -114,3 +114,88 @@ def test_bench_spawns_the_ranks_itself(monkeypatch):
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
     assert cmd[-4:] == ["--gpus", "2", "--steps", "3"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+# ------------------------------------------------------------------------------------------------
+# robot_lab_amd.dist.reduce_episode_log: the collective itself, as product code (SURVEY.md 8(e) "Collective")
+# ------------------------------------------------------------------------------------------------
+class _EmuEnvView:
+    """What reduce_episode_log reads of a `ManagerBasedRLEnv`, over a NativeEnv of the CPU lane emulator (host pointers)."""
+
+    def __init__(self, nat, desc, N):
+        from helpers import host_view
+
+        self._native, self.desc, self.num_envs, self.unwrapped = nat, desc, N, self
+        self._bufs = {"LOG": torch.from_numpy(host_view(nat, "LOG"))}
+        self.max_episode_length_s = float(desc.task.episode_length_s)
+        self._levels = host_view(nat, "TERRAIN_LEVEL")
+
+    @property
+    def terrain_levels(self):
+        return torch.from_numpy(self._levels[: self.num_envs].copy())
+
+
+def _log_shard(rank, emu_lib):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import host_view
+    from robot_lab_amd.capi import NativeEnv
+    from robot_lab_amd.scene import build_world, load_bundle
+
+    desc, extra = load_bundle(TASK)
+    h, to, eo = build_world(desc, extra, N, 0)
+    nat = NativeEnv(desc, h, to, eo, N, 42 + rank, 0, emu_lib)
+    nat.reset()
+    ep = np.zeros(N, dtype=np.int64)
+    ep[: 3 + 2 * rank] = nat.max_episode_length - 1  # 3 envs of rank 0, 5 of rank 1 time out on the first step
+    host_view(nat, "EPISODE_LENGTH")[:] = ep
+    rng = np.random.default_rng(7 + rank)
+    for _ in range(2):  # the second step resets nobody: the log a caller sees is still the first step's
+        nat.step(rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32).ctypes.data)
+    return _EmuEnvView(nat, desc, N)
+
+
+def _log_worker(rank, world, port, emu_lib, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from robot_lab_amd.dist import pack_episode_log, reduce_episode_log
+
+    env = _log_shard(rank, emu_lib)
+    local = pack_episode_log(env).numpy().copy()
+    fut = reduce_episode_log(env)
+    res = {k: float(v) for k, v in fut.result().items()}
+    q.put((rank, local, fut.vector().numpy().copy(), res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_episode_log_gives_the_jobs_means(emu_lib):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_log_worker, args=(r, world, 29519, emu_lib, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    total = got[0][1] + got[1][1]
+    assert got[0][1][0] == 3 and got[1][1][0] == 5 and got[0][1][7] == N  # each rank's own vector: its resets, its env count
+    for rank, local, reduced, res in got:
+        np.testing.assert_allclose(reduced, total, rtol=1e-6)          # every rank holds the same reduced vector = the sum over the shards
+        assert res["episodes"] == 8 and res["num_envs"] == world * N
+        assert res["Episode_Termination/time_out"] == 8
+        # a mean over the job's 8 ended episodes, not over one rank's: (sum_0 + sum_1) / 8 / 20 s
+        want = total[8] / 8.0 / 20.0
+        first = [k for k in res if k.startswith("Episode_Reward/")][0]
+        assert abs(res[first] - want) <= 1e-6 * max(1.0, abs(want))
+        assert abs(res["Curriculum/terrain_levels"] - total[6] / (world * N)) < 1e-6
+    # without a process group (a single-GPU run) the same call is the local log, no collective
+    from robot_lab_amd.dist import reduce_episode_log
+
+    env = _log_shard(0, emu_lib)
+    r = reduce_episode_log(env).result()
+    assert float(r["episodes"]) == 3 and float(r["num_envs"]) == N

@@ -47,11 +47,31 @@ def test_two_ranks_train_one_model(tmp_path):
     assert a["param_sha"] == b["param_sha"], "the two learners drifted apart: the gradient all-reduce is not tying them together"
     assert a["learning_rate"] == b["learning_rate"]
     assert a["reward_sha"] != b["reward_sha"]  # ... while every rank simulated its own environments (seed 42 + rank)
+    assert a["episode_log_envs"] == 2 * 256 and b["episode_log_envs"] is None  # rank 0's log stands for both ranks' envs
     # rank 0 alone logs and checkpoints
     assert os.path.isfile(os.path.join(str(tmp_path), "logs", "model_3.pt"))
     assert p.stdout.count("[rsl_rl stand-in] iteration 3/3") == 1
     d = torch.load(os.path.join(str(tmp_path), "logs", "model_3.pt"), map_location="cpu", weights_only=False)
     assert d["iter"] == 3
+
+
+def test_eight_ranks_on_one_node(tmp_path):
+    """The launch line the reference documents for a node (README.md:323-337: --nproc_per_node=8): eight ranks - on a box with fewer GPUs they
+    share what there is (RL_SHARE_GPU=1) -, eight distinct seeds and env sets, ONE model, ONE log whose episode statistics stand for all
+    8 x 128 environments (the episode-metric all-reduce of SURVEY.md 8(e))."""
+    import torch
+
+    share = torch.cuda.device_count() < 8
+    recs, p = _launch(8, tmp_path, ["--distributed", "--num_envs", "128", "--max_iterations", "1", "--headless"], share)
+    assert sorted(r["env_seed"] for r in recs) == [42 + r for r in range(8)]
+    assert len({r["param_sha"] for r in recs}) == 1 and len({r["reward_sha"] for r in recs}) == 8
+    assert all(r["world"] == 8 and r["iterations"] == 1 and r["finite"] for r in recs)
+    assert recs[0]["episode_log_envs"] == 8 * 128 and all(r["episode_log_envs"] is None for r in recs[1:])
+    assert p.stdout.count("[rsl_rl stand-in] iteration 1/1") == 1 and "episode log over 1024 envs" in p.stdout
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "train_distributed_8ranks.json"), "w") as f:
+            json.dump(dict(ranks=recs, rank0_log=[l for l in p.stdout.splitlines() if "rsl_rl stand-in" in l]), f, indent=1)
 
 
 def test_a_second_rank_without_the_flag_is_refused(tmp_path):

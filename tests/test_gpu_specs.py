@@ -1,0 +1,78 @@
+"""`-m gpu`: the step kernels SPECIALISED on a task (robot_lab_amd/csrc/env_spec.h) against the interpreter's kernels of the same
+library, on the GPU, in every lane mapping a specialised kernel is built for: both envs take every step from the SAME state (the
+interpreter env adopts the specialised env's state through the C-ABI exchange before each step), so what is compared is one step of
+the two kernels - per-term rewards, the reward, dones, both observation groups, the state they leave.  The oracle tiers
+(tests/test_gpu_teacher_forced.py, test_gpu_parity.py, test_gpu_canary.py) run the specialised kernels for these tasks by default."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+A1, GO2, GO2W, G1 = (f"RobotLab-Isaac-Velocity-Rough-Unitree-{r}-v0" for r in ("A1", "Go2", "Go2W", "G1"))
+# (task, spec id, RL_ENV_SUB, RL_ENV_WG)
+CASES = [
+    (A1, 1, "4", ""), (A1, 1, "4", "-4"), (A1, 1, "2", "-4"), (A1, 1, "1", "-4"), (A1, 1, "1", ""),
+    (GO2, 2, "4", "-4"), (GO2, 2, "2", ""), (GO2, 2, "1", "-4"),
+    (GO2W, 3, "4", "-4"), (GO2W, 3, "2", "-4"), (GO2W, 3, "1", ""),
+    (G1, 4, "8", "-4"), (G1, 4, "8", ""),
+]
+
+
+@pytest.mark.parametrize("task,sid,sub,wg", CASES)
+def test_specialised_kernel_equals_interpreter_kernel(task, sid, sub, wg, monkeypatch):
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+
+    N, steps = 512, 24
+    monkeypatch.setenv("RL_ENV_SUB", sub)
+    if wg:
+        monkeypatch.setenv("RL_ENV_WG", wg)
+    monkeypatch.setenv("RL_ENV_SPEC", "1")
+    a = ManagerBasedRLEnv(task, num_envs=N, seed=11, device="cuda:0")
+    monkeypatch.setenv("RL_ENV_SPEC", "0")
+    b = ManagerBasedRLEnv(task, num_envs=N, seed=11, device="cuda:0")
+    assert a._native.spec_id() == sid and b._native.spec_id() == 0
+    assert a._native.envs_per_wavefront() == 16 // int(sub)
+    a.reset(); b.reset()
+    ep = torch.randint(0, a.max_episode_length, (N,), generator=torch.Generator().manual_seed(5))
+    ep[::9] = a.max_episode_length - 1 - (torch.arange(len(ep[::9])) % steps)  # time-out resets all along the run
+    a.episode_length_buf = ep
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n_terms = a.reward_terms().shape[0]
+    seen = np.zeros(n_terms, bool)
+    worst = dict(obs=0.0, term_rel=0.0, state=0.0, bit_different_obs_entries=0)
+    for s in range(steps):
+        b.load_state(a.read_state())  # one step of each kernel from the same state
+        act = torch.rand(N, a.num_actions, device="cuda", generator=g) * 2 - 1
+        if s % 5 == 3:
+            act.zero_()
+        oa, ra, ta, toa, _ = a.step(act)
+        ob, rb, tb, tob, _ = b.step(act)
+        assert torch.equal(ta, tb) and torch.equal(toa, tob), (task, s)
+        for grp in ("policy", "critic"):
+            d = (oa[grp] - ob[grp]).abs()
+            worst["obs"] = max(worst["obs"], float(d.max()))
+            worst["bit_different_obs_entries"] += int((d != 0).sum())
+        xa, xb = a.reward_terms()[:, :N].double().cpu().numpy(), b.reward_terms()[:, :N].double().cpu().numpy()
+        seen |= (xb != 0).any(axis=1)
+        err = np.abs(xa - xb) / (np.abs(xb) + 1e-7)
+        worst["term_rel"] = max(worst["term_rel"], float(err.max()))
+        assert np.all(np.abs(xa - xb) <= 5e-6 * np.abs(xb) + 2e-9), (task, s, np.abs(xa - xb).max(axis=1))
+        assert torch.allclose(ra, rb, rtol=5e-6, atol=2e-8), (task, s)
+        sa, sb = a.read_state(), b.read_state()
+        for k2 in ("root_state", "joint_pos", "joint_vel", "task_state", "contact_timers"):
+            worst["state"] = max(worst["state"], float(np.abs(np.asarray(sa[k2], dtype=np.float64) - np.asarray(sb[k2], dtype=np.float64)).max()))
+        assert np.array_equal(sa["episode_length"], sb["episode_length"])
+    # the physics and the observation stage are the same source in both kernels: what they leave must agree to round-off of ONE step
+    assert worst["obs"] <= 1e-5 and worst["state"] <= 1e-5, worst
+    assert seen.sum() >= len(seen) - 2, f"only {seen.sum()} of {len(seen)} terms ever non-zero"
+    print("\n[spec-vs-interpreter]", json.dumps(dict(task=task, sub=sub, wg=wg, **worst)))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "spec_vs_interpreter.jsonl"), "a") as f:
+            f.write(json.dumps(dict(task=task, sub=sub, wg=wg, **worst)) + "\n")
+    a.close(); b.close()

@@ -121,7 +121,8 @@ def test_one_step_from_shared_state_full_size(task, N, merge, monkeypatch):
     print("\n[teacher-forced]", json.dumps(rep))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "teacher_forced_" + task.split("-")[-2] + ".json"), "w") as f:
+        # (RL_REPORT_TAG: analysis runs of this test on another build of the library, e.g. the exact-math variant - RL_ENV_LIB)
+        with open(os.path.join(out_dir, "teacher_forced_" + os.environ.get("RL_REPORT_TAG", "") + task.split("-")[-2] + ".json"), "w") as f:
             json.dump(rep, f, indent=1)
     env.close()
     env2.close()

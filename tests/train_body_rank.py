@@ -60,7 +60,9 @@ def main():
                sim_device=sim_device, env_device=env.unwrapped.device, env_seed=env_seed, agent_device=agent["device"], backend=getattr(runner.group, "backend", None),
                param_sha=hashlib.sha256(flat.numpy().tobytes()).hexdigest(), finite=bool(torch.isfinite(flat).all()), learning_rate=float(runner.alg.learning_rate),
                iterations=runner.current_learning_iteration, mean_reward=float(runner.trainer.storage.rewards.mean()),
-               reward_sha=hashlib.sha256(runner.trainer.storage.rewards.cpu().numpy().tobytes()).hexdigest())
+               reward_sha=hashlib.sha256(runner.trainer.storage.rewards.cpu().numpy().tobytes()).hexdigest(),
+               # rank 0: the episode log of the last iteration, reduced over every rank's envs (robot_lab_amd/dist.py reduce_episode_log)
+               episode_log_envs=None if runner.last_episode_log is None else float(runner.last_episode_log["num_envs"]))
     env.close()
     with open(os.path.join(os.environ["RL_TEST_OUT"], f"rank{rank}.json"), "w") as f:
         json.dump(rec, f)
