@@ -62,7 +62,8 @@ def test_specialised_kernel_equals_interpreter_kernel(task, sid, sub, wg, monkey
         err = np.abs(xa - xb) / (np.abs(xb) + 1e-7)
         worst["term_rel"] = max(worst["term_rel"], float(err.max()))
         assert np.all(np.abs(xa - xb) <= 5e-6 * np.abs(xb) + 2e-9), (task, s, np.abs(xa - xb).max(axis=1))
-        assert torch.allclose(ra, rb, rtol=5e-6, atol=2e-8), (task, s)
+        # the reward is a sum of terms of both signs: its error is bounded by the terms' magnitudes, not by its own
+        assert np.all(np.abs(ra.double().cpu().numpy() - rb.double().cpu().numpy()) <= 5e-6 * np.abs(xb).sum(axis=0) + 2e-8), (task, s)
         sa, sb = a.read_state(), b.read_state()
         for k2 in ("root_state", "joint_pos", "joint_vel", "task_state", "contact_timers"):
             worst["state"] = max(worst["state"], float(np.abs(np.asarray(sa[k2], dtype=np.float64) - np.asarray(sb[k2], dtype=np.float64)).max()))
