@@ -81,6 +81,11 @@ enum rl_reward_kind {
                                                  pairs (idx_a = wheel body, idx_b = wheel joint), n_idx of them */
   RL_REW_FEET_DISTANCE_Y_EXP = 37,            /* rewards.py:439-461 ; p0 std^2 p1 stance_width ; idx_a = feet in asset_cfg order */
   RL_REW_FEET_DISTANCE_XY_EXP = 38,           /* rewards.py:464-505 ; p0 std^2 p1 stance_width p2 stance_length ; idx_a = the 4 feet */
+  RL_REW_ACTION_MIRROR = 39,                  /* rewards.py:281-302 ; pairs of ACTION columns in idx_a/idx_b (the reference indexes the action vector
+                                                 with the joints' indices), p0 = 1/len(mirror_joints): sum (|a_i| - |a_j|)^2 */
+  RL_REW_ACTION_SYNC = 40,                    /* rewards.py:305-337 ; idx_a = the action columns of all joint groups one after the other, idx_b = the group
+                                                 of each entry (groups of fewer than two joints are not listed), p0 = 1/len(joint_groups):
+                                                 sum over the groups of the (biased) variance of |a| inside the group */
   RL_REW_NUM_KINDS
 };
 
@@ -406,6 +411,14 @@ int32_t rl_env_envs_per_wavefront(const rl_env* env);
  * by rl_env_create when the compiled tables equal, bit for bit, the constants that kernel was generated from (RL_ENV_SPEC=0: never).
  * Same results up to fp32 summation order.  No counterpart in the reference: informational. */
 int32_t rl_env_spec_id(const rl_env* env);
+
+/* The launch geometry rl_env_create + rl_env_step arrive at for `num_envs` environments of this task on a device with `n_cu` compute
+ * units (<= 0: 256, MI355X), without creating anything - no device is touched:
+ *   out[0] lanes per limb (4 / 2 / 1 quadrupeds, 8 / 4 trunk + limbs), out[1] wavefronts per workgroup of the step launch (4 or 1),
+ *   out[2] LDS bytes of a single-wavefront workgroup (table image + one wavefront's region), out[3] LDS bytes of the launched workgroup.
+ * Fails (as rl_env_create would) when no lane mapping fits a CU's 160 KiB of LDS.  Informational - tests/test_launch_plan.py pins the
+ * choice for the BASELINE robots with it, so that table growth which pushes a mapping off a CU fails a test, not a benchmark sweep. */
+int rl_env_plan(const rl_env_desc* desc, int32_t num_envs, int32_t n_cu, int32_t out[4]);
 
 int rl_env_destroy(rl_env* env);
 const char* rl_env_last_error(void);

@@ -18,7 +18,7 @@ HIP_LIB = os.path.join(_HERE, "csrc", "librl_env_hip.so")
 
 EXPORTS = [
     "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_step_record", "rl_env_get_buffer", "rl_env_export_state", "rl_env_commit_state",
-    "rl_env_import_state", "rl_env_read_log", "rl_env_log_slot", "rl_env_obs_slot", "rl_env_step_count", "rl_env_set_step_count", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length", "rl_env_envs_per_wavefront", "rl_env_spec_id",
+    "rl_env_import_state", "rl_env_read_log", "rl_env_log_slot", "rl_env_obs_slot", "rl_env_step_count", "rl_env_set_step_count", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length", "rl_env_envs_per_wavefront", "rl_env_spec_id", "rl_env_plan",
     "rl_env_destroy", "rl_env_last_error", "rl_env_desc_size", "rl_env_graph_begin", "rl_env_graph_end", "rl_env_graph_launching",
 ]
 
@@ -60,6 +60,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     for n in ("rl_env_num_envs", "rl_env_num_actions", "rl_env_max_episode_length", "rl_env_envs_per_wavefront", "rl_env_spec_id"):
         getattr(lib, n).argtypes = [C.c_void_p]
         getattr(lib, n).restype = C.c_int32
+    lib.rl_env_plan.argtypes = [C.POINTER(EnvDesc), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.rl_env_obs_dim.argtypes = [C.c_void_p, C.c_int32]
     lib.rl_env_obs_dim.restype = C.c_int32
     lib.rl_env_destroy.argtypes = [C.c_void_p]
@@ -76,6 +77,15 @@ def _fptr(a):
         return None
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def plan(desc: EnvDesc, num_envs: int, n_cu: int = 256, lib_path: str | None = None) -> dict:
+    """`rl_env_plan`: the launch geometry `rl_env_create` would pick (no device needed)."""
+    lib = load_library(lib_path)
+    out = (C.c_int32 * 4)()
+    if lib.rl_env_plan(C.byref(desc), num_envs, n_cu, out) != 0:
+        raise RlEnvError((lib.rl_env_last_error() or b"").decode())
+    return dict(lanes_per_limb=out[0], wavefronts_per_workgroup=out[1], lds_bytes_per_wavefront=out[2], lds_bytes_per_workgroup=out[3])
 
 
 class NativeEnv:

@@ -16,7 +16,7 @@ enum RewKind {
   REW_IS_TERMINATED, REW_JOINT_DEVIATION_L1, REW_JOINT_VEL_L2, REW_FEET_CONTACT, REW_FEET_STUMBLE, REW_FEET_HEIGHT,
   REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP, REW_TRACK_ANG_VEL_Z_WORLD_EXP, REW_FEET_AIR_TIME_POSITIVE_BIPED,
   REW_HANDSTAND_FEET_HEIGHT_EXP, REW_HANDSTAND_FEET_ON_AIR, REW_HANDSTAND_FEET_AIR_TIME, REW_HANDSTAND_ORIENTATION_L2, REW_BASE_HEIGHT_L2, REW_WHEEL_VEL_PENALTY,
-  REW_FEET_DISTANCE_Y_EXP, REW_FEET_DISTANCE_XY_EXP
+  REW_FEET_DISTANCE_Y_EXP, REW_FEET_DISTANCE_XY_EXP, REW_ACTION_MIRROR, REW_ACTION_SYNC
 };
 enum ObsKind {
   OBS_BASE_LIN_VEL = 0, OBS_BASE_ANG_VEL, OBS_PROJECTED_GRAVITY, OBS_VELOCITY_COMMANDS, OBS_JOINT_POS_REL,
@@ -37,6 +37,7 @@ struct RewEnv {
   uint64_t ext_mask;
   RL_FN const float* row(int b) const { return BT + rew_bt_row(ext_mask, b); }
   int D;
+  const float* action;  // this env's row of the action buffer (the raw action of this step, [D]); nullptr: a padding env (all zero)
   // the env's own scalars a term may read (the lane program's registers, or the record of the split path)
   V3 cmd, lin_b, ang_b, lin_w, vang, grav_b, pos;
   float yaw_c, yaw_s;
@@ -155,6 +156,29 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
           const float d = qa[w] - qb[w];
           part += i0 + w < R.n_idx ? d * d : 0.f;
         }
+      }
+      f = part * R.p[0] * gate;
+    } break;
+    case REW_ACTION_MIRROR: {  // rewards.py:281-302: joint_mirror's form on |action| (weight 0 in every shipped cfg: straight from the action buffer)
+      float part = 0.f;
+      for (int i = 0; i < R.n_idx; ++i) {
+        const float d = E.action != nullptr ? fabsf(E.action[ia[i]]) - fabsf(E.action[ib[i]]) : 0.f;
+        part += d * d;
+      }
+      f = part * R.p[0] * gate;
+    } break;
+    case REW_ACTION_SYNC: {  // rewards.py:305-337: per joint group the (biased) variance of |action| - mean first, then the squared deviations, as the reference
+      float part = 0.f;
+      for (int g = 0; g < 8; ++g) {
+        float s1 = 0.f, n = 0.f;
+        for (int i = 0; i < R.n_idx; ++i)
+          if (ib[i] == g) { s1 += E.action != nullptr ? fabsf(E.action[ia[i]]) : 0.f; n += 1.f; }
+        if (n < 2.f) continue;
+        const float mean = s1 / n;
+        float s2 = 0.f;
+        for (int i = 0; i < R.n_idx; ++i)
+          if (ib[i] == g) { const float d = (E.action != nullptr ? fabsf(E.action[ia[i]]) : 0.f) - mean; s2 += d * d; }
+        part += s2 / n;
       }
       f = part * R.p[0] * gate;
     } break;
@@ -642,6 +666,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     E.moving = E.cmd_norm > 0.1f ? 1.f : 0.f;
     E.terminated = terminated;
     E.JT = JT; E.BT = BT; E.D = D;
+    E.action = e < S.N ? S.action_in + (size_t)e * (size_t)D : nullptr;
     E.ext_mask = uniform_u64(T.rew_ext_mask);
     E.cmd = cmd; E.lin_b = lin_b; E.ang_b = ang_b; E.lin_w = lin_w; E.vang = vang; E.grav_b = grav_b; E.pos = pos;
     E.yaw_c = yaw_c; E.yaw_s = yaw_s; E.Rwb = Rwb;
@@ -716,7 +741,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     E.fc_hi = T.step_dt + 1e-8f;
     E.moving = E.cmd_norm > 0.1f ? 1.f : 0.f;
     E.terminated = terminated;
-    E.JT = nullptr; E.BT = nullptr; E.D = SP::D; E.ext_mask = 0ull;
+    E.JT = nullptr; E.BT = nullptr; E.D = SP::D; E.ext_mask = 0ull; E.action = nullptr;
     E.cmd = cmd; E.lin_b = lin_b; E.ang_b = ang_b; E.lin_w = lin_w; E.vang = vang; E.grav_b = grav_b; E.pos = pos;
     E.yaw_c = yaw_c; E.yaw_s = yaw_s; E.Rwb = Rwb;
     const float gate = E.gate, cmd_norm = E.cmd_norm, bv = E.bv, moving = E.moving, fc_hi = E.fc_hi;

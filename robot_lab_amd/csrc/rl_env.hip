@@ -73,11 +73,26 @@ struct Backend {
   LaunchCfg cfg;
   int& device = cfg.device;
   int& n_cu = cfg.n_cu;
+  void read_env() {
+    if (const char* v = std::getenv("RL_ENV_WG")) { cfg.wg_waves = atoi(v) == 1 ? 1 : 4; cfg.wg_force = atoi(v) < 0; }  // -4: four-wavefront workgroups whatever the launch size (tests)
+  }
   int init(int dev) {
     device = dev;
     if (check(hipSetDevice(dev))) return -1;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    if (const char* v = std::getenv("RL_ENV_WG")) { cfg.wg_waves = atoi(v) == 1 ? 1 : 4; cfg.wg_force = atoi(v) < 0; }  // -4: four-wavefront workgroups whatever the launch size (tests)
+    read_env();
+    return 0;
+  }
+  // include/rl_env.h rl_env_plan: the launch geometry create() + launch() arrive at, without a device
+  int plan(const Tables& T, int Npad, int n_cu_in, int32_t out[4]) {
+    n_cu = n_cu_in > 0 ? n_cu_in : 256;
+    read_env();
+    const int ept = envs_per_wave(T, Npad);
+    if (configure(T)) return -1;
+    const size_t tb = staged_bytes(T), lds4 = tb + 4 * (lds_bytes - tb);
+    const int tiles = Npad / ept;
+    const bool four = (T.NW == 0 || sub == 8) && cfg.wg_waves == 4 && (tiles >= 4 * n_cu || cfg.wg_force) && lds4 <= 160 * 1024;  // launch_cl
+    out[0] = sub; out[1] = four ? 4 : 1; out[2] = (int32_t)lds_bytes; out[3] = (int32_t)(four ? lds4 : lds_bytes);
     return 0;
   }
   // every entry point runs on the env's device, whatever the calling thread's current device is
@@ -157,26 +172,12 @@ struct Backend {
     return 16 / sub;
   }
   size_t lds_bytes = 0;
-  // dynamic LDS of an instance: the SAME layout arithmetic as env_kernel (tables | lane scratchpad | limb-shared words | per-env
-  // words | staging rows + reward stage unless they alias the contact stash / the record words)
+  // dynamic LDS of a single-wavefront workgroup of an instance: the staged tables + the wavefront's region, by the layout function the
+  // kernel itself uses (rl_env_kernels.h lds_plan)
   template <class TP, int SUB>
   static size_t lds_need(const Tables& T) {
-    using Ctx = WaveCtx<SUB>;
-    using LS = typename LsFor<TP, SUB>::type;
-    const int s0w = (SUB == 1 && direct_group(T, 0)) ? 0 : (Ctx::EPT * T.policy_dim + 3) & ~3;
-    int s1w = (SUB == 1 && direct_group(T, 1)) ? 0 : (Ctx::EPT * T.critic_dim + 3) & ~3;
-    int region = s0w + s1w + Ctx::EPT * feat_count(T.D);
-    region = std::max(region, Ctx::EPT * rew_tab_words(T.D, T.n_bodies, T.rew_ext_mask));
-    if (SUB > 1) region = std::max(region, Ctx::EPT * RESET_RAND_WORDS);
-    constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * LsFor<TP, SUB>::type::SSW * 64;
-    constexpr int LB_FREE = TP::NW > 0 ? LbLayout<TP>::RECW * Ctx::LIMBS : 0;
-    const int rsdim = rew_stage_words(T.n_rewards);
-    const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * rsdim + region <= STASH_WORDS;
-    const bool alias_lb = TP::NW > 0 && Ctx::EPT * rsdim + region <= LB_FREE;
-    size_t words = (size_t)LS::WORDS * 64 + (size_t)LbLayout<TP>::WORDS * Ctx::LIMBS + (size_t)Ctx::EPT * LbLayout<TP>::ENV_WORDS;
-    if (!alias && !alias_lb) words += (size_t)Ctx::EPT * rsdim + region;
-    words = (words + 3) & ~(size_t)3;  // the next wavefront's scratchpad granules start 16-byte aligned
-    return staged_bytes(T) + words * 4;
+    const LdsPlan P = lds_plan<TP, SUB>(T.policy_dim, T.critic_dim, direct_group(T, 0), direct_group(T, 1), T.D, T.n_bodies, T.rew_ext_mask, T.n_rewards);
+    return staged_bytes(T) + (size_t)P.words * 4;
   }
   int configure(const Tables& T) {
     const int key = (T.CL + (T.merged ? 100 : 0) + (T.NW > 3 ? 200 : 0)) * 10 + sub;

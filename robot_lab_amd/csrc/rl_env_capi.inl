@@ -128,6 +128,22 @@ int32_t rl_env_max_episode_length(const rl_env* env) { return reinterpret_cast<c
 int32_t rl_env_envs_per_wavefront(const rl_env* env) { return reinterpret_cast<const Impl*>(env)->ept; }
 int32_t rl_env_spec_id(const rl_env* env) { return env ? reinterpret_cast<const Impl*>(env)->spec_id : -1; }
 
+int rl_env_plan(const rl_env_desc* desc, int32_t num_envs, int32_t n_cu, int32_t out[4]) {
+  if (!desc || !out) return rl::fail("null argument");
+  if (num_envs <= 0) return rl::fail("num_envs must be positive");
+  std::vector<int> bl, bs, ll, lp;
+  rl::Tables* T = new rl::Tables();
+  int rc = rl::compile_tables(*desc, *T, bl, bs, ll, lp);
+  if (rc == 0) {
+    Backend be;
+    const int Npad = (num_envs + rl::ENVS_PER_WAVE - 1) / rl::ENVS_PER_WAVE * rl::ENVS_PER_WAVE;
+    rc = be.plan(*T, Npad, n_cu, out);
+    if (rc) rl::fail("kernel configuration failed: " + be.error());
+  }
+  delete T;
+  return rc;
+}
+
 int rl_env_destroy(rl_env* env) {
   if (!env) return 0;
   Impl* I = reinterpret_cast<Impl*>(env);

@@ -450,6 +450,9 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     R.joint_mask &= m.num_dof >= 32 ? 0xffffffffu : ((1u << m.num_dof) - 1u);  // the lane that sums a row reads 8 columns per trip
     for (int q = 0; q < nidx; ++q)  // index lists address the tables directly: validate them here, not in the kernel (and before any shift by them)
       if (r.idx_a[q] < 0 || r.idx_a[q] >= RL_MAX_BODIES || r.idx_a[q] >= 64 || r.idx_b[q] < 0 || r.idx_b[q] >= RL_MAX_BODIES) return fail("reward term index list out of range");
+    if (r.kind == RL_REW_ACTION_MIRROR || r.kind == RL_REW_ACTION_SYNC)  // the lists index the action buffer (and, action_sync: name one of 8 groups)
+      for (int q = 0; q < nidx; ++q)
+        if (r.idx_a[q] >= m.num_dof || (r.kind == RL_REW_ACTION_MIRROR ? r.idx_b[q] >= m.num_dof : r.idx_b[q] >= 8)) return fail("action_mirror / action_sync index list out of range");
     if (r.kind == RL_REW_FEET_HEIGHT_BODY || r.kind == RL_REW_FEET_SLIDE || r.kind == RL_REW_FEET_HEIGHT || r.kind == RL_REW_HANDSTAND_FEET_HEIGHT_EXP)
       T.rew_rel_mask |= r.body_mask;
     if (r.kind == RL_REW_FEET_DISTANCE_Y_EXP || r.kind == RL_REW_FEET_DISTANCE_XY_EXP)

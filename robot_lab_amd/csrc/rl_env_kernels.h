@@ -229,6 +229,49 @@ struct WaveCtx {
   }
 };
 
+// LDS of ONE wavefront behind the staged table image, in words from the wavefront's base - the one place that decides it: env_kernel lays
+// its pointers out with it and the host sizes the launch with it (rl_env.hip lds_need), so the two cannot drift apart.
+//   lane scratchpad | limb-shared words (kinematics blocks, record blocks) | per-env words | [ reward stage | observation rows + feature vectors ]
+// The bracketed part shares its words with the reward tables and the reset uniforms (both dead before the rows are written) and lives ON
+// words that are dead after the substeps where it fits: the contact stash of the lane scratchpad (quadrupeds), the record blocks of the
+// limb-shared area (trunk + limbs instances; their kinematics words stay: rewards and the scanner pose recompute the chain into them).
+struct LdsPlan {
+  int s0w, s1w;                   // staging-row words of the two observation groups (0: one lane per limb, a group without noise goes straight to HBM)
+  int fdim, rtdim, rsdim;         // words of an env's feature vector, of its reward tables, of its reward-stage row
+  int lb0, lbrec0, envs, tail;    // limb kinematics blocks, limb record blocks, env words, first word behind them
+  int rstage, stage0, stage1, fstage;
+  int words;                      // the wavefront's region (a multiple of 4: the next wavefront's granules start 16-byte aligned)
+};
+template <class TP, int SUB>
+RL_FN LdsPlan lds_plan(int policy_dim, int critic_dim, bool direct0, bool direct1, int D, int n_bodies, uint64_t rew_ext_mask, int n_rewards) {
+  constexpr int EPT = 64 / (NLANE * SUB), LIMBS = 64 / SUB;
+  using LS = typename LsFor<TP, SUB>::type;
+  constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * LsFor<TP, SUB>::type::SSW * 64;
+  constexpr int LB_FREE = TP::NW > 0 ? LbLayout<TP>::RECW * LIMBS : 0;  // the record blocks of all limbs: one contiguous region
+  LdsPlan P;
+  P.s0w = (SUB == 1 && direct0) ? 0 : (EPT * policy_dim + 3) & ~3;
+  P.s1w = (SUB == 1 && direct1) ? 0 : (EPT * critic_dim + 3) & ~3;
+  P.fdim = feat_count(D);
+  P.rtdim = rew_tab_words(D, n_bodies, rew_ext_mask);
+  P.rsdim = rew_stage_words(n_rewards);  // the task's terms (not MAX_T: 16 envs x 20 unused words were 5 KB of a one-lane-per-limb workgroup)
+  int region = P.s0w + P.s1w + EPT * P.fdim;
+  if (region < EPT * P.rtdim) P.s1w += EPT * P.rtdim - region, region = EPT * P.rtdim;
+  if (SUB > 1 && region < EPT * RESET_RAND_WORDS) P.s1w += EPT * RESET_RAND_WORDS - region, region = EPT * RESET_RAND_WORDS;  // ... or the reset uniforms (env_terms.h reset_uniforms)
+  P.lb0 = LS::WORDS * 64;
+  P.lbrec0 = P.lb0 + LbLayout<TP>::CHAINW * LIMBS;
+  P.envs = P.lb0 + LbLayout<TP>::WORDS * LIMBS;
+  P.tail = P.envs + EPT * LbLayout<TP>::ENV_WORDS;
+  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && EPT * P.rsdim + region <= STASH_WORDS;
+  const bool alias_lb = TP::NW > 0 && EPT * P.rsdim + region <= LB_FREE;
+  P.rstage = alias ? LS::CT * 64 : (alias_lb ? P.lbrec0 : P.tail);
+  P.stage0 = P.rstage + EPT * P.rsdim;
+  P.stage1 = P.stage0 + P.s0w;
+  P.fstage = P.stage1 + P.s1w;
+  P.words = (alias || alias_lb) ? P.tail : P.tail + EPT * P.rsdim + region;
+  P.words = (P.words + 3) & ~3;
+  return P;
+}
+
 extern __shared__ float4 smem4[];
 
 // WGW wavefronts per workgroup share ONE staged table image in LDS; apart from that staging (and its one s_barrier) the wavefronts
@@ -278,52 +321,29 @@ __global__ __launch_bounds__(RL_LB(WGW)) void env_kernel(KState S, const void* _
   }
   if (WGW > 1) __syncthreads();
   else Ctx::wave_sync();
-  // LDS after the tables (only the staged bytes take room: the unused tail of the reward table is never touched):
-  //   lane scratchpad | limb-shared words | observation staging rows | reward stage
-  // On the instances with a contact stash (quadrupeds, 16 lanes per env) the staging rows and the reward stage live ON the
-  // stash words of the scratchpad when they fit: the stash is dead once the substeps are over and nothing before them
-  // touches the rows.  26 KB -> 20 KB per workgroup = 8 instead of 6 workgroups per CU.
+  // LDS after the tables (only the staged bytes take room: the unused tail of the reward table is never touched): lds_plan above
   const int TAB_F = (int)(S.table_bytes >> 2);
-  using LS = typename LsFor<TP, SUB>::type;
-  constexpr int STASH_WORDS = LsFor<TP, SUB>::STASH * LsFor<TP, SUB>::type::SSW * 64;
+  const LdsPlan P = lds_plan<TP, SUB>(Tl->policy_dim, Tl->critic_dim, direct_group(*Tl, 0), direct_group(*Tl, 1), Tl->D, Tl->n_bodies, Tl->rew_ext_mask, Tl->n_rewards);
   Ctx ctx;
   ctx.T = Tl;
   ctx.Tg = Tgv;
   ctx.dim[0] = Tl->policy_dim;
   ctx.dim[1] = Tl->critic_dim;
-  // (one lane per limb: a group without noise has no staging row - env_terms.h write_group<DIRECT>)
-  const int s0w = (SUB == 1 && direct_group(*Tl, 0)) ? 0 : (Ctx::EPT * ctx.dim[0] + 3) & ~3;
-  int s1w = (SUB == 1 && direct_group(*Tl, 1)) ? 0 : (Ctx::EPT * ctx.dim[1] + 3) & ~3;
   ctx.lscratch = smem + TAB_F + (WGW > 1 ? wv * wave_words : 0u);  // wave_words: LDS words of one wavefront behind the shared tables
   ctx.wtile = (int)blockIdx.x * WGW + wv;
   if (WGW > 1 && ctx.wtile >= S.Npad / Ctx::EPT) return;
   // limb-shared words (trunk + limbs instance): [kinematics block of every limb] [record block of every limb] [env words of every env]
-  float* lb0 = ctx.lscratch + LS::WORDS * 64;
-  float* lbrec0 = lb0 + LbLayout<TP>::CHAINW * Ctx::LIMBS;
-  ctx.lbchain = lb0 + (lane / SUB) * LbLayout<TP>::CHAINW;
-  ctx.lbrec = lbrec0 + (lane / SUB) * LbLayout<TP>::RECW;
+  ctx.lbchain = ctx.lscratch + P.lb0 + (lane / SUB) * LbLayout<TP>::CHAINW;
+  ctx.lbrec = ctx.lscratch + P.lbrec0 + (lane / SUB) * LbLayout<TP>::RECW;
   ctx.lbrec_stride = LbLayout<TP>::RECW;
-  ctx.envs = lb0 + LbLayout<TP>::WORDS * Ctx::LIMBS + (lane / Ctx::LPE) * LbLayout<TP>::ENV_WORDS;
-  float* tail = lb0 + LbLayout<TP>::WORDS * Ctx::LIMBS + Ctx::EPT * LbLayout<TP>::ENV_WORDS;
-  // (not on the trunk + limbs instance: its staging rows double as limb-shared scratch during the substeps, when the stash is live)
-  ctx.fdim = feat_count(Tl->D);
-  ctx.rtdim = rew_tab_words(Tl->D, Tl->n_bodies, Tl->rew_ext_mask);
-  // reward stage | [ observation rows + feature vectors ] = [ reward tables ] (the tables die before the rows are written)
-  int region = s0w + s1w + Ctx::EPT * ctx.fdim;
-  if (region < Ctx::EPT * ctx.rtdim) s1w += Ctx::EPT * ctx.rtdim - region, region = Ctx::EPT * ctx.rtdim;
-  if (SUB > 1 && region < Ctx::EPT * RESET_RAND_WORDS) s1w += Ctx::EPT * RESET_RAND_WORDS - region, region = Ctx::EPT * RESET_RAND_WORDS;  // ... or the reset uniforms (env_terms.h reset_uniforms)
-  // Where they live (same rule as Backend::configure): quadrupeds - on the contact stash of the lane scratchpad, dead once the
-  // substeps are over; trunk + limbs instance - on the link-record / elimination words of the limb-shared area, dead likewise
-  // (its kinematics words stay: rewards and the scanner pose recompute the chain into them); else behind everything.
-  constexpr int LB_FREE = TP::NW > 0 ? LbLayout<TP>::RECW * Ctx::LIMBS : 0;  // the record blocks of all limbs: one contiguous region
-  ctx.rsdim = rew_stage_words(Tl->n_rewards);  // a row of the reward stage: the task's terms (not MAX_T: 16 envs x 20 unused words were 5 KB of a one-lane-per-limb workgroup)
-  const bool alias = TP::NW == 0 && STASH_WORDS > 0 && Ctx::EPT * ctx.rsdim + region <= STASH_WORDS;
-  const bool alias_lb = TP::NW > 0 && Ctx::EPT * ctx.rsdim + region <= LB_FREE;
-  float* base = alias ? ctx.lscratch + LS::CT * 64 : (alias_lb ? lbrec0 : tail);
-  ctx.rstage = base;
-  ctx.stage[0] = base + Ctx::EPT * ctx.rsdim;
-  ctx.stage[1] = ctx.stage[0] + s0w;
-  ctx.fstage = ctx.stage[1] + s1w;
+  ctx.envs = ctx.lscratch + P.envs + (lane / Ctx::LPE) * LbLayout<TP>::ENV_WORDS;
+  ctx.fdim = P.fdim;
+  ctx.rtdim = P.rtdim;
+  ctx.rsdim = P.rsdim;
+  ctx.rstage = ctx.lscratch + P.rstage;
+  ctx.stage[0] = ctx.lscratch + P.stage0;
+  ctx.stage[1] = ctx.lscratch + P.stage1;
+  ctx.fstage = ctx.lscratch + P.fstage;
   ctx.lane = lane;
   EnvProgram<Ctx, TP, SP> prog(ctx, S);
   if (RESET == 1)

@@ -33,7 +33,7 @@ REWARD_KINDS = [
     "feet_stumble", "feet_height", "track_lin_vel_xy_yaw_frame_exp", "track_ang_vel_z_world_exp",
     "feet_air_time_positive_biped", "handstand_feet_height_exp", "handstand_feet_on_air", "handstand_feet_air_time",
     "handstand_orientation_l2", "base_height_l2", "wheel_vel_penalty", "feet_distance_y_exp",
-    "feet_distance_xy_exp",
+    "feet_distance_xy_exp", "action_mirror", "action_sync",
 ]
 REW = {n: i for i, n in enumerate(REWARD_KINDS)}
 OBS_KINDS = [

@@ -347,7 +347,23 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
             r.joint_mask = (1 << D) - 1
         if rt.get("body_names") is not None:
             r.body_mask = mask_of(find_names(rt["body_names"], bn))
-        if rt["func"] == "joint_mirror":
+        if rt["func"] == "action_sync":  # every group's action columns one after the other, the group of each beside it (rewards.py:305-337)
+            ia, ib = [], []
+            for gi, grp in enumerate(rt["joint_groups"]):
+                per_name = [find_names(name, jn) for name in grp]  # (the reference resolves every name on its own: asset.find_joints(joint_name))
+                if any(len(c) != 1 for c in per_name):
+                    raise ValueError("action_sync: a joint name of a group must match exactly one joint (the reference stacks one action column per name)")
+                cols = [c[0] for c in per_name]
+                if len(cols) >= 2:
+                    ia += cols
+                    ib += [gi] * len(cols)
+            if len(ia) > 16 or len(rt["joint_groups"]) > 8:
+                raise ValueError("action_sync: more than 16 joints / 8 groups")
+            set_arr(r.idx_a, ia)
+            set_arr(r.idx_b, ib)
+            r.n_idx = len(ia)
+            r.p[0] = 1.0 / len(rt["joint_groups"]) if rt["joint_groups"] else 0.0
+        if rt["func"] in ("joint_mirror", "action_mirror"):
             ia, ib = [], []
             for pa, pb in rt["mirror_joints"]:
                 a, b = find_names(pa, jn), find_names(pb, jn)

@@ -166,8 +166,10 @@ def compile_spec(cfg) -> tuple[dict, str]:
             e["p"] = [p.get("command_threshold", 0.06)]
         elif fn == "joint_pos_penalty":
             e["p"] = [p["stand_still_scale"], p["velocity_threshold"], p["command_threshold"]]
-        elif fn == "joint_mirror":
+        elif fn in ("joint_mirror", "action_mirror"):
             e["mirror_joints"] = [list(pair) for pair in p["mirror_joints"]]
+        elif fn == "action_sync":
+            e["joint_groups"] = [list(grp) for grp in p["joint_groups"]]
         elif fn == "wheel_vel_penalty":
             e["p"] = [p["velocity_threshold"], p["command_threshold"]]
         elif fn == "feet_distance_y_exp":

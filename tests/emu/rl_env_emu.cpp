@@ -484,6 +484,11 @@ struct Backend {
     return 16 / sub;
   }
   int configure(const rl::Tables&) { return 0; }
+  int plan(const rl::Tables& T, int Npad, int, int32_t out[4]) {  // (the emulator has no launch geometry beyond its lane mapping)
+    envs_per_wave(T, Npad);
+    out[0] = sub; out[1] = 1; out[2] = 0; out[3] = 0;
+    return 0;
+  }
   void* alloc(size_t n) { return std::malloc(n ? n : 1); }
   void free(void* p) { std::free(p); }
   void zero(void* p, size_t n) { std::memset(p, 0, n); }

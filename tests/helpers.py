@@ -22,6 +22,26 @@ def make_pair(task, N, seed, lib_path=None, device=0, mutate=None):
     return desc, ora, nat
 
 
+def set_action_sync(desc, host_term, joint_groups):
+    """Turn reward term `host_term` of the descriptor into `action_sync` (rewards.py:305-337) over `joint_groups` (lists of joint names),
+    with the index lists robot_lab_amd/model/build.py writes: idx_a the action columns, idx_b the group of each."""
+    from robot_lab_amd.desc import REW
+    from robot_lab_amd.model.build import find_names
+
+    r = desc.task.rewards[list(desc.reward_names).index(host_term)]
+    n = 0
+    for gi, group in enumerate(joint_groups):
+        for name in group:
+            (c,) = find_names(str(name), list(desc.joint_names))
+            r.idx_a[n], r.idx_b[n] = c, gi
+            n += 1
+    r.kind, r.n_idx, r.p[0] = REW["action_sync"], n, 1.0 / len(joint_groups)
+    return r
+
+
+A1_SYNC_GROUPS = [[f"{leg}_{part}_joint" for leg in ("FR", "FL", "RL", "RR")] for part in ("hip", "thigh", "calf")]  # velocity_env_cfg.py:492-496
+
+
 def host_view(nat, name):
     """numpy view of an env buffer of the CPU lane emulator (host pointers)."""
     p, shp, dt = nat.buffer(name)

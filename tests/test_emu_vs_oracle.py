@@ -3,7 +3,7 @@ emulator) against the fp64 oracle.  This is the no-GPU stand-in for tests/test_g
 import numpy as np
 import pytest
 
-from helpers import assert_close, host_view, make_pair, oracle_root_state
+from helpers import A1_SYNC_GROUPS, assert_close, host_view, make_pair, oracle_root_state, set_action_sync
 
 TASKS = [
     "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0",
@@ -177,8 +177,9 @@ def test_thirty_two_lane_mapping_matches_oracle(task, k, emu_lib, monkeypatch):
 
 def _switch_kinds(desc):
     """The reward kinds no shipped cfg gives a weight: `feet_height` (world frame, rewards.py:507-524) in place of A1's
-    `feet_height_body`, `feet_contact` (rewards.py:399-413, expects 2 feet down) in place of `feet_contact_without_cmd`, and
-    `joint_vel_l2` in place of `joint_acc_l2` - same body / joint masks, the kind and its parameters swapped."""
+    `feet_height_body`, `feet_contact` (rewards.py:399-413, expects 2 feet down) in place of `feet_contact_without_cmd`,
+    `joint_vel_l2` in place of `joint_acc_l2` - same body / joint masks, the kind and its parameters swapped -, `action_mirror` and
+    `action_sync` (rewards.py:281-337) with the parameters velocity_env_cfg.py:478-498 declares."""
     from robot_lab_amd.desc import REW as REW_KINDS
 
     t, names = desc.task, list(desc.reward_names)
@@ -188,6 +189,11 @@ def _switch_kinds(desc):
     r.kind, r.p[0], r.weight = REW_KINDS["feet_contact"], 2.0, -0.1
     r = t.rewards[names.index("joint_acc_l2")]
     r.kind, r.weight = REW_KINDS["joint_vel_l2"], -1e-3
+    # action_mirror (rewards.py:281-302) in place of joint_mirror - A1's cfg pairs the same joints -, action_sync (rewards.py:305-337)
+    # over the reference's three joint groups in place of joint_power
+    r = t.rewards[names.index("joint_mirror")]
+    r.kind, r.weight = REW_KINDS["action_mirror"], -0.05
+    set_action_sync(desc, "joint_power", A1_SYNC_GROUPS).weight = -0.1
     return desc
 
 
@@ -197,15 +203,15 @@ def test_reward_kinds_without_a_cfg(emu_lib):
     nat.reset()
     rng = np.random.default_rng(2)
     names = list(desc.reward_names)
-    seen = np.zeros(3)
+    seen = np.zeros(5)
     for s in range(6):
         a = rng.uniform(-1, 1, (16, desc.model.num_dof)).astype(np.float32)
         ora.step(a)
         nat.step(a.ctypes.data)
         got, want = host_view(nat, "REWARD_TERMS")[:, :16], ora.reward_terms
         assert_close(f"terms[{s}]", got, want, 2e-3, 2e-5)
-        seen += [np.abs(want[names.index(n)]).max() for n in ("feet_height_body", "feet_contact_without_cmd", "joint_acc_l2")]
-    assert (seen > 0).all(), seen  # the three swapped terms really produced something
+        seen += [np.abs(want[names.index(n)]).max() for n in ("feet_height_body", "feet_contact_without_cmd", "joint_acc_l2", "joint_mirror", "joint_power")]
+    assert (seen > 0).all(), seen  # the five swapped terms really produced something
     nat.close()
 
 

@@ -194,3 +194,42 @@ def test_full_size_properties(task, N):
     torch.testing.assert_close(quat.norm(dim=1), torch.ones(N, device="cuda"), rtol=1e-4, atol=1e-4)
     env.close()
     env2.close()
+
+
+def test_reward_kinds_without_a_cfg():
+    """The reward kinds no shipped cfg gives a weight (`feet_height`, `feet_contact`, `joint_vel_l2`, and the reference's `action_mirror` /
+    `action_sync`, rewards.py:281-337) in place of five of A1's terms: the HIP interpreter against the oracle (the CPU twin of this
+    test: tests/test_emu_vs_oracle.py; the oracle itself is pinned to the reference's functions by tests/golden/terms_extra.npz)."""
+    import torch
+
+    from robot_lab_amd.env import ManagerBasedRLEnv
+    from test_emu_vs_oracle import _switch_kinds
+
+    N, seed = 64, 8
+    desc, extra = load_bundle(TASKS[1])
+    _switch_kinds(desc)
+    env = ManagerBasedRLEnv(desc=desc, extra=extra, num_envs=N, seed=seed, device="cuda:0")
+    assert env._native.spec_id() == 0  # an edited term list is not the task the specialised kernel was compiled for
+    desc2, extra2 = load_bundle(TASKS[1])
+    _switch_kinds(desc2)
+    h, to, eo = build_world(desc2, extra2, N, 0)
+    ora = OracleEnv(desc2, h, to, N, seed, eo)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(2)
+    names = list(desc.reward_names)
+    swapped = ("feet_height_body", "feet_contact_without_cmd", "joint_acc_l2", "joint_mirror", "joint_power")
+    seen = np.zeros(len(swapped))
+    for s in range(6):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        ora.step(a)
+        env.step(torch.from_numpy(a).cuda())
+        got, want = env.reward_terms()[:, :N].cpu().numpy(), ora.reward_terms
+        assert_close(f"terms[{s}]", got, want, 2e-3, 2e-5)
+        # the two action kinds read nothing but this step's action and the gravity gate: tight
+        for n in ("joint_mirror", "joint_power"):
+            i = names.index(n)
+            np.testing.assert_allclose(got[i], want[i], rtol=2e-5, atol=1e-8, err_msg=f"{n} (step {s})")
+        seen += [np.abs(want[names.index(n)]).max() for n in swapped]
+    assert (seen > 0).all(), seen
+    env.close()

@@ -104,7 +104,8 @@ def test_observation_rows_match_reference_cfg(robot):
 
 
 def test_reward_functions_without_a_cfg_match_reference():
-    """`feet_contact` (rewards.py:399-413) and `feet_height` (rewards.py:507-524): no shipped robot cfg gives them a weight, so the
+    """`feet_contact` (rewards.py:399-413), `feet_height` (rewards.py:507-524), `action_mirror` (rewards.py:281-302) and `action_sync`
+    (rewards.py:305-337): no shipped robot cfg gives them a weight, so the
     per-robot fixtures never see them.  tests/golden/terms_extra.npz = the reference's functions on the recorded Go2 state
     (tools/gen_golden_extra_terms.py); here the same two kinds take the place of Go2's `feet_contact_without_cmd` /
     `feet_height_body` terms (same feet) in the descriptor and the oracle must reproduce them."""
@@ -115,12 +116,28 @@ def test_reward_functions_without_a_cfg_match_reference():
     desc, extra = load_bundle(str(g["task"]))
     t, names = desc.task, list(desc.reward_names)
     swap = {"feet_contact": ("feet_contact_without_cmd", (float(x["expect_contact_num"]),)),
-            "feet_height": ("feet_height_body", (float(x["target_height"]), float(x["tanh_mult"])))}
+            "feet_height": ("feet_height_body", (float(x["target_height"]), float(x["tanh_mult"]))),
+            # action_mirror (rewards.py:281-302) takes joint_mirror's place: Go2's cfg pairs the same joints (FR <-> RL, FL <-> RR), p0 = 1/2;
+            # action_sync (rewards.py:305-337) joint_power's, with the index lists the model compiler writes for the reference's groups
+            "action_mirror": ("joint_mirror", ()),
+            "action_sync": ("joint_power", ())}
     for kind, (host, params) in swap.items():
         r = t.rewards[names.index(host)]
         r.kind = REW[kind]
         for i, p in enumerate(params):
             r.p[i] = p
+    from robot_lab_amd.model.build import find_names
+
+    assert [[str(n) for n in pair] for pair in x["mirror_joints"]] == [["FR.*", "RL.*"], ["FL.*", "RR.*"]]
+    r, cols, grp = t.rewards[names.index("joint_power")], [], []
+    for gi, group in enumerate(x["joint_groups"]):
+        for name in group:
+            (c,) = find_names(str(name), list(desc.joint_names))
+            cols.append(c)
+            grp.append(gi)
+    for i, (c, gi) in enumerate(zip(cols, grp)):
+        r.idx_a[i], r.idx_b[i] = c, gi
+    r.n_idx, r.p[0] = len(cols), 1.0 / len(x["joint_groups"])
     N = int(g["N"])
     h, to, eo = build_world(desc, extra, N, 0)
     ora = OracleEnv(desc, h, to, N, int(g["seed"]), eo)
