@@ -345,7 +345,7 @@ def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
         environment are coroutines of that thread that hand over at every cross-limb sum (a user-space switch of six registers: no
         barrier, no second core, tests/emu/rl_env_emu.cpp FiberSet), one pinned thread per PHYSICAL core (fixed, not probed), every
         thread owning whole state tiles (no cache line is written by two cores) - SURVEY.md 8(d)'s "scalar restatement with one env
-        per iteration over all cores".  Timed twice; `repeats` carries both and their relative difference.
+        per iteration over all cores".  Timed three times (`value` = the median); `repeats` carries all three and their relative spread.
     (ii) `oracle`: the fp64 numpy oracle (oracle/env.py, single process) on a smaller sample."""
     import numpy as np
 

@@ -38,7 +38,8 @@ int rl_mlp_create(const int32_t* dims, int32_t n_layers, int32_t activation, con
  * optimiser step so that the next rollout runs the updated actor / critic (train.py:224 -> rsl_rl OnPolicyRunner.learn: `alg.update()`
  * is followed by `alg.act()` on the same modules).  The device images keep their addresses, so a captured graph that launches this
  * network stays valid.  Waits for EVERY launch queued on the device (any stream), then copies synchronously: when the call returns no
- * forward can be reading a half-updated image; the caller must not launch this network from another thread while the call runs. */
+ * forward can be reading a half-updated image; the caller must not launch this network from another thread while the call runs.
+ * Not capturable: fails (without disturbing the capture) when `stream` is being captured - push parameters between graph replays. */
 int rl_mlp_set_weights(rl_mlp* m, const float* const* weights, const float* const* biases, void* stream);
 
 /* y[n_rows][dims[n_layers]] = MLP(x[n_rows][dims[0]]); x, y: device pointers, row-major; stream-ordered. */

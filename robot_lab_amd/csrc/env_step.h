@@ -30,9 +30,13 @@
 #define RL_PHASE(id, name) asm volatile("; PHASE " name)
 #elif defined(RL_PHASE_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
 #define RL_PHASE(id, name) this->phase_stamp(id)
+#define RL_PHASE_START() (this->ph_t0 = 0, this->ph_cur = 0)  // (explicitly: round 4's tables carried a raw time stamp in the first row)
 #define RL_PHASE_CLOCK_ON 1
 #else
 #define RL_PHASE(id, name) ((void)0)
+#endif
+#ifndef RL_PHASE_START
+#define RL_PHASE_START() ((void)0)
 #endif
 constexpr int RL_PHASE_ROW0 = 24;   // first reward-term row the clock build borrows (A1 .. G1 tasks have <= 22 reward terms)
 constexpr int RL_PHASE_SLOTS = 32;

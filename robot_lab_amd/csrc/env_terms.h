@@ -1188,6 +1188,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         for (int i = li; i < LOG_SIZE; i += LPE) nx[i] = 0.f;
       }
     }
+    RL_PHASE_START();
     RL_PHASE(0, "load");
     this->load();
     load_task();  // same batch of HBM loads as the state: one round trip instead of a second one after the substeps

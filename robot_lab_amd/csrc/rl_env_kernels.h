@@ -1,7 +1,8 @@
 // rl_env_kernels.h - the gfx950 wavefront context, the env kernel and its launch helpers: what every translation unit of the env
-// library shares.  The library is built from three of them so that hipcc compiles the kernels of the three lane mappings side by side
-// (rl_env.hip: 16 lanes per env + the C-ABI; rl_env_sub2.hip / rl_env_sub1.hip: 8 and 4 lanes per env - 33 kernels of ~10 s each);
-// -DRL_ENV_SINGLE_TU puts everything into rl_env.hip (tools/build_variant.sh, tools/kbuild.sh).
+// library shares.  The library is built from one translation unit per lane mapping (rl_env.hip: 16 lanes per env + the C-ABI; rl_env_sub8 /
+// _sub2 / _sub1.hip: 32, 8 and 4 lanes per env - 33 interpreter kernels of ~10 s each) plus one per task-specialised step kernel set
+// (spec/rl_env_spec_<id>.hip), so that hipcc compiles them side by side; -DRL_ENV_SINGLE_TU puts ONE instance into rl_env.hip
+// (tools/build_variant.sh, tools/kbuild.sh).
 #pragma once
 #include <hip/hip_runtime.h>
 

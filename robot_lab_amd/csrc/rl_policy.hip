@@ -767,7 +767,11 @@ int rl_mlp_set_weights(rl_mlp* m, const float* const* weights, const float* cons
   // let ALL of them finish (synchronising `stream` alone left a forward on another non-blocking stream reading
   // half-updated weights); the copies below are synchronous, and a forward launched after this call returns sees the new f32 AND
   // split-bf16 images, never a mix
-  (void)stream;
+  // A device-wide wait is illegal while a stream capture is open (it would fail AND invalidate the capture - ADVICE r4): refuse up front when
+  // the caller's stream is capturing; parameters are pushed between replays of a collection graph, never inside its capture.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail("rl_mlp_set_weights inside a stream capture: the upload is a device-wide wait + synchronous copies; push parameters before hipStreamBeginCapture or between graph replays");
   if (hipDeviceSynchronize() != hipSuccess) return fail("device synchronisation failed");
   for (int l = 0; l < m->P.n_layers; ++l)
     if (upload_layer(m, l, weights[l], biases[l])) return -1;

@@ -130,8 +130,13 @@ def build_desc(model: RobotModel, spec: dict) -> EnvDesc:
         return ok, limbs, trunk, piece_starts
 
     ok, limbs, trunk, piece_starts = discover(True)
+    rule = "continue_spine"
     if not ok:  # (GR1's rule first: it is what the committed bundles were compiled with)
         ok, limbs, trunk, piece_starts = discover(False)
+        rule = "branching_trunk"
+    # which rule decomposed the tree, and into what - recorded with the compiled descriptor (the choice used to be silent: ADVICE r4)
+    spec["topology"] = dict(rule=rule if ok else None, trunk_links=[model.links[l].name for l in trunk],
+                            piece_starts=list(piece_starts), limb_lengths=[len(c) for _, c in limbs], limb_attach=[a for a, _ in limbs])
     # fewer than 4 limbs (bipeds without arms): the spare lane groups simulate empty chains
     m.num_chains, m.chain_len, m.num_trunk = (4, max(len(c) for _, c in limbs), len(trunk)) if ok else (0, 0, 0)
     for k in range(4):

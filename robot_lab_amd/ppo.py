@@ -88,7 +88,6 @@ class PPO:
             for i in range(self.num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
                 mean, std = self.policy.distribution(obs[idx])
-                std = std.clamp_min(1e-6)  # a standard deviation pushed to (or through) zero would put NaN into the log below
                 logp = gaussian_log_prob(actions[idx], mean, std)
                 value = self.policy.critic(cobs[idx]).view(-1)
                 entropy = gaussian_entropy(std)
@@ -119,6 +118,11 @@ class PPO:
                     self.group.reduce_gradients(self.policy)  # SUM / world, one flat all-reduce (rsl_rl `reduce_parameters`)
                 nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
                 self.optimizer.step()
+                # a standard deviation pushed to (or through) zero would put NaN into the log-densities: the PARAMETER is floored, so that the
+                # collector's sampling kernel, the stored sigma and this update all see the same distribution (rsl_rl 3.0.1 does not
+                # clamp at all and fails with torch's Normal on a non-positive std; 1e-6 is far below any std training reaches)
+                with torch.no_grad():
+                    self.policy.std.clamp_(min=1e-6)
                 stats["value_loss"] += float(value_loss.detach())
                 stats["surrogate_loss"] += float(surrogate.detach())
                 stats["entropy"] += float(entropy.detach().mean())

@@ -23,6 +23,8 @@ def save_bundle(path: str, desc: EnvDesc, spec: dict):
                 env_spacing=spec.get("env_spacing", 2.5))
     if spec.get("dropped_contact_bodies"):  # bodies whose collision geometry the lane program cannot host (model/build.py): they never touch the ground
         blob["dropped_contact_bodies"] = list(spec["dropped_contact_bodies"])
+    if spec.get("topology"):  # how model/build.py decomposed the link tree into trunk pieces + limb chains (which of its rules, and the result)
+        blob["topology"] = spec["topology"]
     with open(path, "w") as f:
         json.dump(blob, f)
 

@@ -310,3 +310,36 @@ def test_booster_t1_is_a_trunk_of_two_pieces():
     for n in ("AAHead_yaw", "Head_pitch"):
         j = d.joint_names.index(n)
         assert m.act_kp[j] == 0.0 and m.act_kd[j] == 0.0
+
+
+def test_feet_sit_on_limbs_and_the_topology_rule_is_recorded():
+    """topology discovery tries two rules and takes the first decomposition that fits; the choice is recorded with the bundle
+    (`topology`: rule, trunk links, pieces, limbs), and whatever rule won, a body a FEET term names - the contact-sensor feet of the
+    task's reward terms - rides on a limb chain, never on a trunk link (a leg absorbed into the spine would be simulated redundantly by
+    every lane and its foot contacts hosted by a borrowed lane)."""
+    import glob
+    import json
+
+    from robot_lab_amd.desc import REW
+    from robot_lab_amd.scene import DATA_DIR, load_bundle
+
+    feet_kinds = {REW[k] for k in ("feet_air_time", "feet_air_time_variance_penalty", "feet_slide", "feet_contact_without_cmd", "feet_height_body",
+                                   "feet_air_time_positive_biped", "feet_stumble", "feet_contact", "feet_height", "contact_forces")}
+    seen_rules = set()
+    for path in sorted(glob.glob(os.path.join(DATA_DIR, "*.json"))):
+        blob = json.load(open(path))
+        topo = blob.get("topology")
+        assert topo and topo["rule"] in ("continue_spine", "branching_trunk"), path
+        seen_rules.add(topo["rule"])
+        desc, _ = load_bundle(path)
+        m, t = desc.model, desc.task
+        assert len(topo["trunk_links"]) == m.num_trunk and len(topo["limb_lengths"]) <= 4
+        limb_links = {m.chain_link[k][j] for k in range(4) for j in range(m.chain_nj[k])}
+        for i in range(t.n_rewards):
+            r = t.rewards[i]
+            if r.kind not in feet_kinds:
+                continue
+            for b in range(m.num_bodies):
+                if (r.body_mask >> b) & 1:
+                    assert m.body_link[b] in limb_links, (os.path.basename(path), desc.reward_names[i], desc.body_names[b])
+    assert seen_rules == {"continue_spine", "branching_trunk"}

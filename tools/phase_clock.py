@@ -4,8 +4,8 @@
 Needs a `-DRL_PHASE_CLOCK` build of the HIP library (csrc/env_step.h RL_PHASE): lane 0 of every wavefront accumulates the
 ticks it spends in each phase into float row [wavefront][phase id] behind the reward-term rows.
 
-    hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -shared -fPIC -DRL_PHASE_CLOCK [-DRL_ENV_ONLY=34] -o robot_lab_amd/csrc/variants/clock.so robot_lab_amd/csrc/rl_env.hip
-    RL_ENV_LIB=robot_lab_amd/csrc/variants/clock.so python tools/phase_clock.py [task] [num_envs]
+    bash tools/build_variant.sh clock 34 - -DRL_PHASE_CLOCK [-DRL_ENV_SPEC_ONLY=1 -DRL_ENV_SPEC_SUB=4]   (the library's own flags, incl. -mllvm -amdgpu-remove-redundant-endcf=false)
+    RL_ENV_LIB=robot_lab_amd/csrc/variants/clock_34.so python tools/phase_clock.py [task] [num_envs]
 """
 import os
 import sys
@@ -39,7 +39,10 @@ for s in range(STEPS):
     env.step(torch.rand(N, A, device="cuda:0", generator=g) * 2 - 1)
 torch.cuda.synchronize()
 acc = buf.cpu().numpy().astype(np.float64).mean(axis=0) / STEPS
+bogus = acc > 1e9  # a row that holds a raw time stamp instead of a sum of intervals (seen in round 4's `load` row): left out, and said so
+acc[bogus] = 0.0
 tot = acc.sum()
+print(f"spec id {env._native.spec_id()}, {int(env._native.envs_per_wavefront())} envs per wavefront" + (f"; rows left out as bogus: {[PHASES[i] for i in np.nonzero(bogus)[0]]}" if bogus.any() else ""))
 print(f"{task} N={N}: mean shader-clock ticks per wavefront per step by phase (sub.* = the 4 substeps together), total {tot:.0f}")
 for n, v in zip(PHASES, acc):
     if v > 0:
