@@ -446,12 +446,18 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     if constexpr (SUB == 1) return nullptr;
     else {
       float* RT = ctx.rand_tab();
-      const int nb = (ctx.uniform_i(T.D) + 3) >> 2, n_need = 8 + 4 * nb;
+      // the joint streams whose range is a single point are not drawn (reset_joints_by_scale of every shipped cfg: position x U(1, 1),
+      // velocity x U(0, 0) - half of the blocks; a draw is `lo` then, whatever the table holds: UR below): the needed blocks of A1 / Go2W /
+      // G1 then fit ONE round over the env's lanes (14 / 16 / 24 blocks on 16 / 16 / 32 lanes) instead of two
+      const bool skip_jpos = !T.ev_reset_joints || !(T.reset_jpos[1] > T.reset_jpos[0]), skip_jvel = !T.ev_reset_joints || !(T.reset_jvel[1] > T.reset_jvel[0]);
+      const int first_js = ctx.uniform_i(skip_jpos ? (skip_jvel ? 2 : 1) : 0);  // joint streams are dropped from the front only (JPOS, then JVEL): the usual case
+      const int n_js = 4 - first_js;
+      const int nb = (ctx.uniform_i(T.D) + 3) >> 2, n_need = 8 + n_js * nb;
       for (int n = li; n < n_need; n += LPE) {
-        int b = n < 2 ? n : 34 + (n - 2 - 4 * nb);  // blocks 0, 1: wrench; 34 .. 39: pose, velocity, command, timers, level
-        if (n >= 2 && n < 2 + 4 * nb) {              // 2 + 8 s + i: block i of joint stream s (IDX_JPOS, IDX_JVEL, IDX_KP, IDX_KD: 32 indices each)
-          const int m = n - 2, st = (m >= nb ? 1 : 0) + (m >= 2 * nb ? 1 : 0) + (m >= 3 * nb ? 1 : 0);
-          b = 2 + 8 * st + (m - st * nb);
+        int b = n < 2 ? n : 34 + (n - 2 - n_js * nb);  // blocks 0, 1: wrench; 34 .. 39: pose, velocity, command, timers, level
+        if (n >= 2 && n < 2 + n_js * nb) {             // 2 + 8 s + i: block i of joint stream s (IDX_JPOS, IDX_JVEL, IDX_KP, IDX_KD: 32 indices each)
+          const int m = n - 2, st = first_js + (m >= nb ? 1 : 0) + (m >= 2 * nb ? 1 : 0) + (m >= 3 * nb ? 1 : 0);
+          b = 2 + 8 * st + (m - (st - first_js) * nb);
         }
         float un[4];
         uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_RESET, (uint32_t)b, un);
@@ -465,7 +471,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   RL_FN void reset_env(bool log_episode) {
     const float* RT = reset_uniforms();
     auto UR = [&](uint32_t idx, float lo, float hi) __attribute__((always_inline)) {
-      return RT != nullptr ? lo + (hi - lo) * RT[idx] : U(STREAM_RESET, idx, lo, hi);
+      // (hi > lo: a single-point range is `lo` without a look at the table - reset_uniforms does not fill the blocks of such streams)
+      return RT != nullptr ? (hi > lo ? lo + (hi - lo) * RT[idx] : lo) : U(STREAM_RESET, idx, lo, hi);
     };
     // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671)
     if (T.curriculum && !T.is_plane) {
@@ -1068,16 +1075,31 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
   }
 
-  RL_FN void observations(bool chain_fresh) {
-    derive();
-    // the height-scan loads go out first and are consumed by the group(s) that carry the scan, after the feature vector and the
-    // non-scan columns.  (Issuing them before the reward stage was tried: the 72 patch registers do not survive it - the compiler
-    // parks them in AGPRs, which needs the data, i.e. waits for the loads on the spot: 52.6 us either way.)
+  // the height-scan loads of the final pose: issued as early as the pose is final (see step_back) and consumed by the group(s) that carry
+  // the scan, after everything else of the observation stage
+  struct ScanAhead {
     ScanPatches sp;
     float cy, sy;
     V3 scan_p;
-    scanner_pose(cy, sy, scan_p, chain_fresh);
-    scan_fetch(cy, sy, scan_p, sp);
+  };
+  RL_FN void scan_ahead(bool chain_fresh, ScanAhead& A) {
+    derive();
+    scanner_pose(A.cy, A.sy, A.scan_p, chain_fresh);
+    scan_fetch(A.cy, A.sy, A.scan_p, A.sp);
+  }
+  RL_FN void observations(bool chain_fresh) {
+    ScanAhead A;
+    scan_ahead(chain_fresh, A);
+    observations(A);
+  }
+  RL_FN void observations(const ScanAhead& A) {
+    derive();
+    // the height-scan loads went out first and are consumed by the group(s) that carry the scan, after the feature vector and the
+    // non-scan columns.  (Issuing them before the reward stage was tried: the 72 patch registers do not survive it - the compiler
+    // parks them in AGPRs, which needs the data, i.e. waits for the loads on the spot: 52.6 us either way.)
+    const ScanPatches& sp = A.sp;
+    const float cy = A.cy, sy = A.sy;
+    const V3 scan_p = A.scan_p;
     // the env's feature vector -> LDS (env_tables.h FEAT_*): lane 0 the base block, the first sub-lane of a limb its joints
     float* F = ctx.feat_stage();
     const int D = ctx.uniform_i(T.D);
@@ -1280,6 +1302,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       derive();
     }
     if constexpr (!TAIL) write_dbg_views((terminated || time_out) ? 0.f : 1.f);  // (a split step wrote them in its first launch)
+#ifdef RL_SCAN_EARLY  // (A/B switch) the scan's loads go out HERE: the pose is final (commands and the push below touch velocities only), and the
+    // command update, the push and the write-back of the state then run under their latency
+    ScanAhead scanA;
+    scan_ahead(!TAIL && !ctx.any(terminated || time_out), scanA);
+#endif
     // 7 CommandManager.compute [UPSTREAM B7]
     {
       const float inv_max_step = T.step_dt * frcp(T.cmd_resample[1]);
@@ -1322,7 +1349,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // 9 observations
     RL_PHASE(20, "observations");
 #ifndef RL_ABL_NO_OBS
+#ifdef RL_SCAN_EARLY
+    observations(scanA);
+#else
     observations(!TAIL && !ctx.any(terminated || time_out));  // (a tail launch starts without the chain words of the trunk + limbs instance)
+#endif
 #endif
     RL_PHASE(24, "end");
   }

@@ -176,6 +176,18 @@ def teacher_forced_check(ora, state, action, got, n_twins=3, gain=32.0, base=1e-
         sens["reward"] = np.maximum(sens["reward"], np.abs(ora.reward - want["reward"]))
         sens["reward_terms"] = np.maximum(sens["reward_terms"], np.abs(ora.reward_terms - want["reward_terms"]))
     ok = ~mask
+    # What an fp32 implementation of THIS step can agree to at best: the oracle itself with nothing changed but the dtype of its linear
+    # solves (no input perturbation, libm everywhere) against its fp64 self - the share of entries inside the flat `base`.  The tolerance
+    # floor of the tested side is this, not its hardware sin / cos / rcp approximations (profiles/r05a_exact_math_teacher_forced_*.json:
+    # an exact-math build of the kernels moves the share by 1 - 3 points).  Reported, not asserted.
+    ora.load_state(state)
+    ora.phys.solve_dtype = np.float32
+    o32 = ora.step(action)
+    ora.phys.solve_dtype = None
+    t32 = ora.read_state()
+    t32.update(obs_policy=o32[0], obs_critic=o32[1])
+    fp32_solve = {f: dict(frac_within_base=float(np.mean(rel_err(t32[f], want[f], 1.0)[ok] <= base)), p50=float(np.median(rel_err(t32[f], want[f], 1.0))),
+                          max_err=float(rel_err(t32[f], want[f], 1.0)[ok].max())) for f in fields}
     report = dict(n=N, masked=int(mask.sum()), masked_frac=float(mask.mean()), margins_min={k: float(np.min(v)) for k, v in margins.items()},
                   masked_by_margin={k: int((np.asarray(v) < SWITCH_EPS[k]).sum()) for k, v in margins.items()})  # envs each margin flags (they overlap)
     bad = {}
@@ -221,6 +233,7 @@ def teacher_forced_check(ora, state, action, got, n_twins=3, gain=32.0, base=1e-
     if (te[ok] > 1e-6).any():
         bad["contact_timers"] = np.nonzero((te > 1e-6) & ok)[0][:8].tolist()
     report["done_count"] = int(want["done"].sum())
+    report["oracle_with_fp32_solves"] = fp32_solve
     report["bad"] = bad
     assert report["masked_frac"] <= max_mask, f"{report['masked']} of {N} envs sit on a switch (> {max_mask:.1%}): {report}"
     if max_outliers > 0 and bad:

@@ -55,4 +55,65 @@ import json
 for n in ('bench_default','bench_host_bound_64envs'):
     d=json.load(open('$OUT/%s.json'%n)); print(n, 'value %.2f M  ms_per_step %.4f  kernel_ms %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms']), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'))"
   ;;
+b)
+  # 1. one-call A/Bs on the specialised A1 kernel (steady-state windows): the scan's loads issued before the command update / state write-back,
+  #    and the stage ablations (a stage's cost = the difference to the full kernel); the same switch on G1
+  timeout 600 python tools/ab_bench.py --steady --rounds 2 $V/ablfull_34.so $V/scanearly_34.so $V/ablnorewards_34.so $V/ablnoobs_34.so $V/ablnoscan_34.so $V/ablsub0_34.so $V/ablskeleton_34.so > $OUT/a1_spec_stage_ablation.txt 2>&1
+  cat $OUT/a1_spec_stage_ablation.txt
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $G1 --num-envs 2048 $V/full_78.so $V/scanearly_78.so > $OUT/g1_scan_early_ab.txt 2>&1
+  cat $OUT/g1_scan_early_ab.txt
+  # 2. in-kernel phase clock of the specialised kernels (a clock build: every stamp drains the memory pipelines - shares, not ticks)
+  RL_ENV_LIB=$V/clockspec_34.so timeout 200 python tools/phase_clock.py $A1 4096 > $OUT/phase_clock_a1.txt 2>&1
+  RL_ENV_LIB=$V/clockspec_78.so timeout 200 python tools/phase_clock.py $G1 2048 > $OUT/phase_clock_g1.txt 2>&1
+  cat $OUT/phase_clock_a1.txt $OUT/phase_clock_g1.txt
+  # 3. bench lines with `roofline` for the BASELINE configs 2 - 5 (A1 default line incl. the large-batch legs and the CPU baseline)
+  timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_driver_flags.json 2> /dev/null
+  for t in $GO2 $GO2W; do timeout 200 python bench.py --task $t --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_$(echo $t | cut -d- -f6).json 2>/dev/null; done
+  timeout 200 python bench.py --task $G1 --num-envs 2048 --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_G1.json 2>/dev/null
+  python - <<PY | tee $OUT/baseline_configs.txt
+import json
+for n in ("bench_default", "bench_driver_flags", "bench_Go2", "bench_Go2W", "bench_G1"):
+    d = json.load(open("$OUT/%s.json" % n))
+    print("%-20s %-62s value %7.2f M env-steps/s  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f  resets in window %d" % (n, d["config"]["workload"].split(",")[0], d["value"] / 1e6, d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["window"]["envs_reset_in_window"]))
+d = json.load(open("$OUT/bench_default.json"))
+for leg in ("mid_batch", "large_batch"):
+    print(leg, {k: d.get(leg, {}).get(k) for k in ("envs_per_gpu", "value", "ms_per_step", "roofline_frac", "envs_per_wavefront")})
+print("cpu_baseline", {k: d["cpu_baseline"][k] for k in ("value", "cores", "kind", "per_core")})
+PY
+  # 4. kernel traces + counter passes on the final tree (separate --pmc passes, no other trace domain)
+  A1S="python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0"
+  A1FULL="python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline"
+  G1S="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --large-batch-envs 0 --task $G1 --num-envs 2048"
+  A8K="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --large-batch-envs 0 --num-envs 8192"
+  A64K="python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --preroll 100 --no-cpu-baseline --large-batch-envs 0 --num-envs 65536"
+  SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+  WAIT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"
+  prof a1_kernel_stats "$A1FULL" --kernel-trace --stats
+  prof g1_kernel_stats "$G1S" --kernel-trace --stats
+  for cfg in "a1:$A1S" "g1:$G1S" "a1_8192:$A8K" "a1_65536:$A64K"; do
+    name=${cfg%%:*}; cmd=${cfg#*:}
+    prof ${name}_pmc_fetch "$cmd" --pmc FETCH_SIZE
+    prof ${name}_pmc_write "$cmd" --pmc WRITE_SIZE
+    prof ${name}_pmc_sq "$cmd" --pmc $SQ
+    prof ${name}_pmc_wait "$cmd" --pmc $WAIT
+  done
+  head -9 $OUT/a1_kernel_stats.txt; head -6 $OUT/g1_kernel_stats.txt
+  grep "env_kernel" $OUT/*_pmc_fetch.txt $OUT/*_pmc_write.txt | grep mean | cut -c1-40,100-240
+  # 5. the collection phase of a PPO iteration as one hipGraph (24 x (actor + critic, act, env) + GAE)
+  timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -2 > $OUT/collect.txt
+  timeout 300 python tools/bench_collect.py $G1 2048 20 2>/dev/null | tail -1 >> $OUT/collect.txt
+  cat $OUT/collect.txt
+  # 6. the tolerance floor again, now with the oracle's own fp32-solve twin in the report (tests/helpers.py `oracle_with_fp32_solves`)
+  RL_ENV_LIB=$V/exact_34.so RL_REPORT_TAG=exact_ timeout 300 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "A1-v0-4096-None" > $OUT/pytest_exact_a1.log 2>&1; echo "rc=$?" >> $OUT/pytest_exact_a1.log
+  RL_ENV_LIB=$V/exact_78.so RL_REPORT_TAG=exact_ timeout 300 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "G1-v0-2048-None" > $OUT/pytest_exact_g1.log 2>&1; echo "rc=$?" >> $OUT/pytest_exact_g1.log
+  RL_ENV_LIB=$V/exact_2078.so RL_REPORT_TAG=exact_ timeout 300 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "GR1T1-v0-1024-sub8" > $OUT/pytest_exact_gr1.log 2>&1; echo "rc=$?" >> $OUT/pytest_exact_gr1.log
+  tail -n 2 $OUT/pytest_exact_*.log
+  mv gpurun_out/teacher_forced_exact_*.json $OUT/ 2>/dev/null
+  # 7. the whole GPU tier on the final tree
+  timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -8 $OUT/pytest_gpu.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  mv gpurun_out/spec_vs_interpreter.jsonl gpurun_out/train_distributed_8ranks.json $OUT/ 2>/dev/null
+  ;;
 esac

@@ -9,6 +9,18 @@ import sys
 from collections import defaultdict
 
 
+def short(name, width=70):
+    """70 columns of a kernel name; the step kernels specialised on a task (csrc/env_spec.h) carry the task as their LAST template argument,
+    which the cut would drop: it is appended as a tag (`... [Spec_A1_Rough]`)."""
+    import re
+
+    m = re.search(r"rl::(Spec_\w+)", name)
+    if m:
+        tag = " [" + m.group(1) + "]"
+        return name[: width - len(tag)] + tag
+    return name[:width]
+
+
 def main(path):
     con = sqlite3.connect(path)
     cur = con.cursor()
@@ -33,7 +45,7 @@ def main(path):
     for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1])):
         g, w, lds, scr = meta[k]
         r = regs.get(k, (0, 0, 0, 0, 0))
-        print(f"{names.get(k, str(k))[:70]:70s} {len(v):6d} {sum(v) / 1e6:10.3f} {sum(v) / len(v) / 1e3:9.2f} {min(v) / 1e3:9.2f} {max(v) / 1e3:9.2f} "
+        print(f"{short(names.get(k, str(k))):70s} {len(v):6d} {sum(v) / 1e6:10.3f} {sum(v) / len(v) / 1e3:9.2f} {min(v) / 1e3:9.2f} {max(v) / 1e3:9.2f} "
               f"{100 * sum(v) / total:6.2f}  {g} {w} {lds} {scr} {r[0]} {r[1]} {r[2]}")
     npmc = cur.execute(f"select count(*) from {T('rocpd_pmc_event')}").fetchone()[0]
     if npmc:
@@ -45,7 +57,7 @@ def main(path):
         print("\n# PMC counters: mean per dispatch (summed over instances as reported)")
         for k, d in acc.items():
             for n, v in sorted(d.items()):
-                print(f"{names.get(k, str(k))[:70]:70s} {n:24s} mean {sum(v) / len(v):16.2f} n={len(v)}")
+                print(f"{short(names.get(k, str(k))):70s} {n:24s} mean {sum(v) / len(v):16.2f} n={len(v)}")
 
 
 if __name__ == "__main__":
