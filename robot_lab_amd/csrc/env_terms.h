@@ -421,7 +421,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // ranges: the table's, or the live ones of the command_levels_* curricula (VEL/mdp/curriculums.py:21-94)
     const float* lv = S.cmd_levels;
     const bool cl = T.cur_lin != 0, ca = T.cur_ang != 0;
-    auto UU = [&](uint32_t i, float lo, float hi) __attribute__((always_inline)) { return RT != nullptr ? lo + (hi - lo) * RT[i] : U(stream, i, lo, hi); };
+    auto UU = [&](uint32_t i, float lo, float hi) __attribute__((always_inline)) { return RT != nullptr ? lerp_draw(lo, hi, RT[i]) : U(stream, i, lo, hi); };
     float vx = UU(idx + 0, cl ? lv[CL_LIN_X] : T.cmd_range[0][0], cl ? lv[CL_LIN_X + 1] : T.cmd_range[0][1]);
     float vy = UU(idx + 1, cl ? lv[CL_LIN_Y] : T.cmd_range[1][0], cl ? lv[CL_LIN_Y + 1] : T.cmd_range[1][1]);
     float wz = UU(idx + 2, ca ? lv[CL_ANG_Z] : T.cmd_range[2][0], ca ? lv[CL_ANG_Z + 1] : T.cmd_range[2][1]);
@@ -453,6 +453,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       const int first_js = ctx.uniform_i(skip_jpos ? (skip_jvel ? 2 : 1) : 0);  // joint streams are dropped from the front only (JPOS, then JVEL): the usual case
       const int n_js = 4 - first_js;
       const int nb = (ctx.uniform_i(T.D) + 3) >> 2, n_need = 8 + n_js * nb;
+      // (not unrolled: left to itself the compiler unrolled this loop in the single-wavefront kernel and not in the four-wavefront one, and
+      // the two then contracted the draws' multiply-adds differently - one ulp in a reset env's heading target, caught by the bit-equality
+      // canary of tests/test_gpu_canary.py; tools/isa_shape_arith.py compares the arithmetic of the kernel shapes at build time)
+#pragma unroll 1
       for (int n = li; n < n_need; n += LPE) {
         int b = n < 2 ? n : 34 + (n - 2 - n_js * nb);  // blocks 0, 1: wrench; 34 .. 39: pose, velocity, command, timers, level
         if (n >= 2 && n < 2 + n_js * nb) {             // 2 + 8 s + i: block i of joint stream s (IDX_JPOS, IDX_JVEL, IDX_KP, IDX_KD: 32 indices each)
@@ -472,7 +476,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     const float* RT = reset_uniforms();
     auto UR = [&](uint32_t idx, float lo, float hi) __attribute__((always_inline)) {
       // (hi > lo: a single-point range is `lo` without a look at the table - reset_uniforms does not fill the blocks of such streams)
-      return RT != nullptr ? (hi > lo ? lo + (hi - lo) * RT[idx] : lo) : U(STREAM_RESET, idx, lo, hi);
+      return RT != nullptr ? (hi > lo ? lerp_draw(lo, hi, RT[idx]) : lo) : U(STREAM_RESET, idx, lo, hi);
     };
     // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671)
     if (T.curriculum && !T.is_plane) {
@@ -1059,6 +1063,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     if (corrupt) {
       ctx.group_sync();
       const int nblk = (dim + 3) >> 2;
+#pragma unroll 1
       for (int b = li; b < nblk; b += LPE) {
         float un[4];
         uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_NOISE, (noise_base >> 2) + (uint32_t)b, un);
@@ -1069,7 +1074,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
           const bool in_scan = col >= scan_off && col < scan_off + scan_n;
           const int n = col < scan_off ? col : col - scan_n;
           const ObsColTab& dc = in_scan ? G.scan : G.col[in_scan ? 0 : n];
-          stage[col] = clampf(stage[col] + dc.noise_lo + dc.noise_rng * un[c], dc.clip_lo, dc.clip_hi) * dc.scale;
+          stage[col] = clampf(stage[col] + fmaf(dc.noise_rng, un[c], dc.noise_lo), dc.clip_lo, dc.clip_hi) * dc.scale;  // (explicit fma: rl_math.h lerp_draw)
         }
       }
     }

@@ -210,8 +210,13 @@ RL_FN void uniform01x4(uint64_t seed, uint32_t env, uint32_t counter, uint32_t s
   U4 r = philox4x32_10(U4{env, counter, stream, blk}, (uint32_t)seed, (uint32_t)(seed >> 32));
   u[0] = u24(r.x); u[1] = u24(r.y); u[2] = u24(r.z); u[3] = u24(r.w);
 }
+// lo + (hi - lo) u as ONE fused multiply-add, said explicitly: left to -ffp-contract=fast the compiler fuses it or not depending on
+// whether the product has other uses after its unrolling / CSE decisions, which differ between the kernels one source is compiled
+// into (single- and four-wavefront workgroups, specialised and interpreted term stacks) - one ulp of difference in a draw, and the
+// bit-equality canary of tests/test_gpu_canary.py can no longer tell a benign rounding from a clobbered register
+RL_FN float lerp_draw(float lo, float hi, float u) { return fmaf(hi - lo, u, lo); }
 RL_FN float uniform_range(uint64_t seed, uint32_t env, uint32_t counter, uint32_t stream, uint32_t index, float lo, float hi) {
-  return lo + (hi - lo) * uniform01(seed, env, counter, stream, index);
+  return lerp_draw(lo, hi, uniform01(seed, env, counter, stream, index));
 }
 
 enum : uint32_t { STREAM_RESET = 1, STREAM_COMMAND = 2, STREAM_PUSH = 3, STREAM_NOISE = 4, STREAM_STARTUP = 5, STREAM_ACTION = 6 };

@@ -116,4 +116,16 @@ PY
   mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
   mv gpurun_out/spec_vs_interpreter.jsonl gpurun_out/train_distributed_8ranks.json $OUT/ 2>/dev/null
   ;;
+c)
+  # after the draws' multiply-adds became explicit fmas and the shape canaries learnt to tell contraction round-off from a clobbered register:
+  # the canaries (verbose: which shapes are bit-equal), the kernel-vs-kernel test, smoke(), and the bench line (no regression)
+  timeout 900 python -m pytest tests/test_gpu_canary.py tests/test_gpu_specs.py -m gpu -q -s > $OUT/pytest_canary_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary_specs.log
+  grep -E "canary\]|passed|failed|rc=" $OUT/pytest_canary_specs.log | cut -c1-400 | tail -30
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
+  grep -E "smoke|rc=|Error" $OUT/smoke.log | tail -12
+  timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_default.json 2> /dev/null
+  python -c "
+import json
+d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  ms_per_step %.4f  kernel_ms %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms']), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'))"
+  ;;
 esac
