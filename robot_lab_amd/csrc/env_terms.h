@@ -1037,45 +1037,50 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         if (n < n_cols) stage[n < scan_off ? n : n + scan_n] = corrupt ? f[i] : clampf(f[i], d[i].clip_lo, d[i].clip_hi) * d[i].scale;
       }
     }
-    if (scan_n > 0) {  // z_sensor - hit_z - offset per ray; the heightfield patches were fetched by scan_fetch()
-      const float s_scale = ctx.uniform(G.scan.scale), s_lo = ctx.uniform(G.scan.clip_lo), s_hi = ctx.uniform(G.scan.clip_hi);
-      const float soff = T.scan_offset;
-      if (sp.single_trip) {
+    if (scan_n > 0) write_scan(stage, scan_off, scan_n, corrupt, ctx.uniform(G.scan.scale), ctx.uniform(G.scan.clip_lo), ctx.uniform(G.scan.clip_hi), cy, sy, scan_p, sp);
+    if (corrupt) noise_pass(G, stage, noise_base, dim, scan_off, scan_n);
+  }
+  // the scan's columns of a row: z_sensor - hit_z - offset per ray; the heightfield patches were fetched by scan_fetch()
+  RL_FN void write_scan(float* stage, int scan_off, int scan_n, bool corrupt, float s_scale, float s_lo, float s_hi, float cy, float sy, V3 scan_p,
+                        const ScanPatches& sp) {
+    const float soff = T.scan_offset;
+    if (sp.single_trip) {
+#pragma unroll
+      for (int i = 0; i < SCAN_RB; ++i) {
+        const int r = li + i * LPE;
+        const float v = scan_p.z - terrain_height(sp.tp[i]) - soff;
+        if (r < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
+      }
+    } else {
+      for (int r0 = li; r0 < scan_n; r0 += SCAN_RB * LPE) {
+        ScanPatches one;
+        scan_fetch_trip(r0, scan_n, cy, sy, scan_p, one);
 #pragma unroll
         for (int i = 0; i < SCAN_RB; ++i) {
-          const int r = li + i * LPE;
-          const float v = scan_p.z - terrain_height(sp.tp[i]) - soff;
+          const int r = r0 + i * LPE;
+          const float v = scan_p.z - terrain_height(one.tp[i]) - soff;
           if (r < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
-        }
-      } else {
-        for (int r0 = li; r0 < scan_n; r0 += SCAN_RB * LPE) {
-          ScanPatches one;
-          scan_fetch_trip(r0, scan_n, cy, sy, scan_p, one);
-#pragma unroll
-          for (int i = 0; i < SCAN_RB; ++i) {
-            const int r = r0 + i * LPE;
-            const float v = scan_p.z - terrain_height(one.tp[i]) - soff;
-            if (r < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
-          }
         }
       }
     }
-    if (corrupt) {
-      ctx.group_sync();
-      const int nblk = (dim + 3) >> 2;
+  }
+  // second pass of a group that corrupts: noise -> clip -> scale on the staged raw row, four consecutive columns (one Philox block) per lane
+  template <class GT>
+  RL_FN void noise_pass(const GT& G, float* stage, uint32_t noise_base, int dim, int scan_off, int scan_n) {
+    ctx.group_sync();
+    const int nblk = (dim + 3) >> 2;
 #pragma unroll 1
-      for (int b = li; b < nblk; b += LPE) {
-        float un[4];
-        uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_NOISE, (noise_base >> 2) + (uint32_t)b, un);
+    for (int b = li; b < nblk; b += LPE) {
+      float un[4];
+      uniform01x4(S.seed, (uint32_t)e, S.step_counter, STREAM_NOISE, (noise_base >> 2) + (uint32_t)b, un);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int col = 4 * b + c;
-          if (col >= dim) continue;
-          const bool in_scan = col >= scan_off && col < scan_off + scan_n;
-          const int n = col < scan_off ? col : col - scan_n;
-          const ObsColTab& dc = in_scan ? G.scan : G.col[in_scan ? 0 : n];
-          stage[col] = clampf(stage[col] + fmaf(dc.noise_rng, un[c], dc.noise_lo), dc.clip_lo, dc.clip_hi) * dc.scale;  // (explicit fma: rl_math.h lerp_draw)
-        }
+      for (int c = 0; c < 4; ++c) {
+        const int col = 4 * b + c;
+        if (col >= dim) continue;
+        const bool in_scan = col >= scan_off && col < scan_off + scan_n;
+        const int n = col < scan_off ? col : col - scan_n;
+        const ObsColTab& dc = in_scan ? G.scan : G.col[in_scan ? 0 : n];
+        stage[col] = clampf(stage[col] + fmaf(dc.noise_rng, un[c], dc.noise_lo), dc.clip_lo, dc.clip_hi) * dc.scale;  // (explicit fma: rl_math.h lerp_draw)
       }
     }
   }
@@ -1097,7 +1102,69 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     scan_ahead(chain_fresh, A);
     observations(A);
   }
+  // The observation stage on a Spec (env_spec.h), lane mappings that stage both rows in LDS: every value goes from its owner's registers
+  // straight to its column of the row - lane 0 of the env the base terms, the first sub-lane of a limb its joints, the scan's rays as
+  // above - with the term's offset, clip and scale constant expressions: no feature vector in LDS, no per-column descriptors, one fence
+  // less.  The noise pass of a group that corrupts is the interpreter's (a Philox block per four columns; its per-column constants still
+  // come from the table image).  Same values, same bits.  (What this stage costs is the scan's gather and the noise, DESIGN.md section 3:
+  // this saves two dependent LDS round trips and ~60 vector instructions of it.)
+  RL_FN void observations_spec(const ScanAhead& A) {
+    derive();
+    Ctx& cx = ctx;  // (plain locals for the nested generic lambdas: see compute_rewards_spec)
+    const int my_li = li, my_sub = sub;
+    const uint32_t wheel = T.wheel_joint_mask;
+    static_for<0, 2>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      float* stage = cx.obs_stage(g);
+      constexpr bool corrupt = SP::OBS_CORRUPT[g] != 0;
+      static_for<0, SP::N_OBS[g]>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int tm = decltype(tc)::value;
+        constexpr ObsSpec O = SP::OBS[g][tm];
+        auto fin = [&](float v) __attribute__((always_inline)) { return corrupt ? v : clampf(v, O.clip_lo, O.clip_hi) * O.scale; };
+        if constexpr (O.kind == OBS_BASE_LIN_VEL || O.kind == OBS_BASE_ANG_VEL || O.kind == OBS_PROJECTED_GRAVITY || O.kind == OBS_VELOCITY_COMMANDS) {
+          const V3 v = O.kind == OBS_BASE_LIN_VEL ? this->lin_b : (O.kind == OBS_BASE_ANG_VEL ? this->ang_b : (O.kind == OBS_PROJECTED_GRAVITY ? this->grav_b : this->cmd));
+          if (my_li == 0) {
+            stage[O.offset + 0] = fin(v.x);
+            stage[O.offset + 1] = fin(v.y);
+            stage[O.offset + 2] = fin(v.z);
+          }
+        } else if constexpr (O.kind == OBS_HEIGHT_SCAN) {
+#ifndef RL_ABL_NO_SCAN
+          this->write_scan(stage, O.offset, cx.uniform_i(this->T.scan_nx * this->T.scan_ny), corrupt, O.scale, O.clip_lo, O.clip_hi, A.cy, A.sy, A.scan_p, A.sp);
+#endif
+        } else {
+          if (my_sub == 0) {
+            static_for<0, JX>([&](auto jc) __attribute__((always_inline)) {
+              constexpr int j = decltype(jc)::value;
+              const int jid = (NW == 0 || this->L.joint_own[j]) ? this->L.joint_id[j] : -1;
+              if (jid >= 0) {
+                const float qr = this->q[j] - this->L.q0[j];
+                float v;
+                if constexpr (O.kind == OBS_JOINT_POS_REL) v = qr;
+                else if constexpr (O.kind == OBS_JOINT_VEL_REL) v = this->qd[j] - this->L.qd0[j];
+                else if constexpr (O.kind == OBS_LAST_ACTION) v = this->act[j];
+                else v = ((wheel >> (jid & 31)) & 1u) ? 0.f : qr;  // OBS_JOINT_POS_REL_NO_WHEEL (observations.py:17-27)
+                stage[O.offset + jid] = fin(v);
+              }
+            });
+          }
+        }
+      });
+      if constexpr (corrupt) {
+        const auto& G = this->T.obs[g];
+        this->noise_pass(G, stage, g == 0 ? 0u : 1024u, cx.uniform_i(G.dim), cx.uniform_i(G.scan_off), cx.uniform_i(G.scan_n));
+      }
+      if constexpr (g == 0) RL_PHASE(21, "obs.policy_done");
+    });
+    RL_PHASE(22, "obs.flush");
+    ctx.flush_obs(S.obs_policy, T.policy_dim, 0);
+    ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
+  }
   RL_FN void observations(const ScanAhead& A) {
+    if constexpr (SP::ON && SUB > 1) {  // (one lane per limb: a group without noise goes straight to HBM - the interpreter's write_group<DIRECT>)
+      observations_spec(A);
+      return;
+    }
     derive();
     // the height-scan loads went out first and are consumed by the group(s) that carry the scan, after the feature vector and the
     // non-scan columns.  (Issuing them before the reward stage was tried: the 72 patch registers do not survive it - the compiler

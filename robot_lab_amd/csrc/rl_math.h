@@ -134,8 +134,12 @@ RL_FN Q4 quat_normalize(Q4 q) {
   return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
 RL_FN Q4 quat_from_euler_xyz(float roll, float pitch, float yaw) {
-  float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f), cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
-  float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
+  // (fsincos: v_sin_f32 / v_cos_f32 on the device, 1e-6 absolute - the same primitives the kinematics of every substep use.  libm's sinf / cosf
+  // were ~300 instructions of every reset, and the wavefronts that reset an env are the ones a steady-state launch waits for)
+  float cy, sy, cr, sr, cp, sp;
+  fsincos(yaw * 0.5f, sy, cy);
+  fsincos(roll * 0.5f, sr, cr);
+  fsincos(pitch * 0.5f, sp, cp);
   return {cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp};
 }
 

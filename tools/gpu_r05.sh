@@ -128,4 +128,19 @@ c)
 import json
 d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  ms_per_step %.4f  kernel_ms %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms']), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'))"
   ;;
+d)
+  # the observation stage on a Spec (owner-writes from registers) + hardware sin / cos in the reset pose: one-call A/B against the build before
+  # them (ablfull_34 / full_78: call b's kernels), then the parity tiers that cover the change
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 $V/ablfull_34.so $V/specobs_34.so > $OUT/spec_obs_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $G1 --num-envs 2048 $V/full_78.so $V/specobs_78.so >> $OUT/spec_obs_ab.txt 2>&1
+  cat $OUT/spec_obs_ab.txt
+  timeout 900 python -m pytest tests/test_gpu_canary.py tests/test_gpu_specs.py tests/test_gpu_edge_cases.py -m gpu -q -s > $OUT/pytest_canary_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary_specs.log
+  grep -E "canary\]|passed|failed|rc=" $OUT/pytest_canary_specs.log | cut -c1-400 | tail -12
+  timeout 900 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "(A1-v0-4096-None or Go2-v0-4096-None or G1-v0-2048-None or Go2W-v0-4096-None or A1-v0-4096-sub2)" > $OUT/pytest_teacher_forced.log 2>&1; echo "rc=$?" >> $OUT/pytest_teacher_forced.log
+  tail -3 $OUT/pytest_teacher_forced.log
+  timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_default.json 2> /dev/null
+  python -c "
+import json
+d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  ms_per_step %.4f  kernel_ms %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms']), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'))"
+  ;;
 esac
