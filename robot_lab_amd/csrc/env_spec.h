@@ -64,7 +64,9 @@ constexpr bool spec_kind_supported(int kd) {
 template <class SP>
 inline bool spec_matches(const TablesT<TopoMax>& T) {
   auto same = [](float a, float b) { return memcmp(&a, &b, 4) == 0; };
-  if (T.CL != SP::TP::CL || T.NW != SP::TP::NW || (T.merged != 0) != (SP::TP::M0 != 0) || T.D != SP::D || T.n_bodies != SP::N_BODIES) return false;
+  if (T.CL != SP::TP::CL || T.NW != SP::TP::NW || (T.merged != 0) != (SP::TP::M0 != 0) || (T.rotpad != 0) != (SP::TP::NW == 0 && SP::TP::PAD) || T.D != SP::D ||
+      T.n_bodies != SP::N_BODIES)
+    return false;
   if (T.n_rewards != SP::N_REW || T.cur_lin || T.cur_ang) return false;
   // the joint map: task joint jid = slot JOINT_J[jid] of limb JOINT_K[jid], and nothing else is owned
   int owned = 0;

@@ -1223,6 +1223,7 @@ struct EnvLane {
       const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
       const bool lim = (below > 0.f) || (above > 0.f);
       float D = arm + pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+      if (TP::PAD) D += j >= L.nj ? 1.0f : 0.f;  // an inert padding joint (zero axis, no gains): the identity row, as joint_terms() of the trunk + limbs instances
       float uu = arm * qd[j] + dt * tau_e[j] + pd_rhs[j] + dt * u.limit_k * viol;
       float U6[6];
 #pragma unroll

@@ -29,17 +29,22 @@ constexpr int MAX_NBS = 9;  // body slots per lane: 0 = a trunk-link body (or em
 // M0 = 1 ("merged"): the lane's share of the base link's spheres has no link group of its own - its spheres sit in free sphere
 // slots of the limb link groups, flagged in LaneTabT::sph_base_mask (frame, twist and record of the BASE link for those slots).
 // A 4-joint limb then has 4 link groups for its 4 sub-lanes instead of 5: one contact pass per substep instead of two.
-template <int CL_, int NW_, int SPL_, int NBS_, int M0_ = 0>
+// RP = 1 ("rotated / padded", quadruped instances): joint frames may be rotated against the parent link and a limb may have fewer than CL
+// joints (inert padding joints; a limb may be empty) - what the trunk + limbs instances support anyway.  DDT Tita: two wheeled 4-joint
+// legs with rotated hip frames, two empty limbs (round 5; it ran on the trunk + limbs instance before: 185 us at 2048 envs).
+template <int CL_, int NW_, int SPL_, int NBS_, int M0_ = 0, int RP_ = 0>
 struct Topo {
   static constexpr int CL = CL_, NW = NW_, SPL = SPL_, NBS = NBS_, JX = CL_ + NW_, NB = 6 + NW_, M0 = M0_;
   static_assert(M0_ == 0 || NW_ == 0, "merged base share: quadruped instances only");
-  static constexpr bool ROT = NW_ > 0;  // joint frames may be rotated w.r.t. the parent link (URDF joint rpy)
+  static constexpr bool ROT = NW_ > 0 || RP_ != 0;  // joint frames may be rotated w.r.t. the parent link (URDF joint rpy)
+  static constexpr bool PAD = NW_ > 0 || RP_ != 0;  // a limb may have fewer than CL joints: joint_id -1 = inert padding (identity row in the elimination)
   static constexpr int DMAX = NLANE_ * CL_ + NW_;  // joints a model of this shape can have
   static constexpr int OBS_NC = 12 + 3 * DMAX;     // non-scan columns of an observation group (ObsGroupTabT)
 };
 using TopoQuad3 = Topo<3, 0, 3, 6>;  // A1, Go2
 using TopoQuad4 = Topo<4, 0, 3, 6>;  // wheeled quadrupeds whose base spheres do not fit the free limb slots
 using TopoQuad4M = Topo<4, 0, 3, 6, 1>;  // Go2W and the other wheeled quadrupeds
+using TopoQuad4R = Topo<4, 0, 3, 6, 0, 1>;  // <= 4-joint limbs with rotated joint frames and / or limbs of unequal length (DDT Tita)
 using TopoG1 = Topo<7, 3, 4, 9>;     // G1 29-DoF
 using TopoGR = Topo<7, 6, 4, 9>;     // FFTAI GR1T1 / GR1T2 (32 DoF): a six-joint spine - waist, then head - with the arms leaving it at depth 3
 constexpr int MAX_T = 40;   // reward terms
@@ -171,6 +176,7 @@ struct TaskTab {  // everything that is not per limb
   int32_t nw_used;      // trunk joints the model really has (<= NW; the rest are inert padding)
   uint32_t slot_valid;  // bit g*SPL+s: some lane has a collision sphere in slot (g, s)
   int32_t merged;       // 1: tables built for a Topo<..., M0 = 1> instance (base-share spheres in limb slots, LaneTabT::sph_base_mask)
+  int32_t rotpad;       // 1: a quadruped-shaped model (no trunk joints, limbs of <= 4 joints) with rotated joint frames or unequal limbs: Topo<4,0,3,6,0,1>
   int32_t sub8_ok;      // 1: the model fits the 32-lanes-per-env mapping (trunk + limbs instances: at most MAXOWN8 body slots per link group)
   uint32_t trunk_restart;          // bit i: trunk joint i hangs off the base (bit 0 always; Booster T1: waist AND neck on the base - two pieces)
   uint32_t trunk_anc[MAX_NW + 1];  // [d]: the trunk joints between the base and the trunk link at depth d (bit i = trunk joint i); [0] = 0

@@ -510,7 +510,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
-      uint32_t ji = (uint32_t)((NW > 0 && L.joint_id[j] < 0) ? 0 : L.joint_id[j]);  // padding joints: q0 = qd0 = kp0 = kd0 = 0
+      uint32_t ji = (uint32_t)((TP::PAD && L.joint_id[j] < 0) ? 0 : L.joint_id[j]);  // padding joints: q0 = qd0 = kp0 = kd0 = 0
       float qn = L.q0[j], qdn = L.qd0[j];
       if (T.ev_reset_joints) {  // reset_joints_by_scale [UPSTREAM B8]
         qn = clampf(L.q0[j] * UR(IDX_JPOS + ji, T.reset_jpos[0], T.reset_jpos[1]), L.soft_lo[j], L.soft_hi[j]);
@@ -620,7 +620,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #endif
 #pragma unroll
       for (int j = 0; j < JX; ++j) {
-        const int jid = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1;
+        const int jid = (!TP::PAD || L.joint_own[j]) ? L.joint_id[j] : -1;
         if (jid < 0) continue;
         const float dq = q[j] - L.q0[j], da = act[j] - prev_act[j];
         JT[JS_TAU2 * D + jid] = tau_app[j] * tau_app[j];
@@ -1136,7 +1136,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
           if (my_sub == 0) {
             static_for<0, JX>([&](auto jc) __attribute__((always_inline)) {
               constexpr int j = decltype(jc)::value;
-              const int jid = (NW == 0 || this->L.joint_own[j]) ? this->L.joint_id[j] : -1;
+              const int jid = (!TP::PAD || this->L.joint_own[j]) ? this->L.joint_id[j] : -1;
               if (jid >= 0) {
                 const float qr = this->q[j] - this->L.q0[j];
                 float v;
@@ -1161,10 +1161,15 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     ctx.flush_obs(S.obs_critic, T.critic_dim, 1);
   }
   RL_FN void observations(const ScanAhead& A) {
-    if constexpr (SP::ON && SUB > 1) {  // (one lane per limb: a group without noise goes straight to HBM - the interpreter's write_group<DIRECT>)
+#ifndef RL_SPEC_OBS_OFF  // (A/B switch)
+    // quadruped instances with several sub-lanes per limb.  (One lane per limb: a group without noise goes straight to HBM - the interpreter's
+    // write_group<DIRECT>.  Trunk + limbs instances: the owner-writes are 10 joints x 3 terms x 2 groups by the limb's first sub-lane - more
+    // LDS instructions per wavefront than the column tables spread over 32 lanes: G1 102.3 -> 104.3 us, profiles/r05d_spec_obs_ab.txt.)
+    if constexpr (SP::ON && SUB > 1 && NW == 0) {
       observations_spec(A);
       return;
     }
+#endif
     derive();
     // the height-scan loads went out first and are consumed by the group(s) that carry the scan, after the feature vector and the
     // non-scan columns.  (Issuing them before the reward stage was tried: the 72 patch registers do not survive it - the compiler
@@ -1185,7 +1190,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       const uint32_t wheel = T.wheel_joint_mask;
 #pragma unroll
       for (int j = 0; j < JX; ++j) {
-        const int jid = (NW == 0 || L.joint_own[j]) ? L.joint_id[j] : -1;
+        const int jid = (!TP::PAD || L.joint_own[j]) ? L.joint_id[j] : -1;
         if (jid < 0) continue;  // padding / trunk joints accounted for by limb 0
         const float qr = q[j] - L.q0[j];
         F[FEAT_JOINT + jid] = qr;
@@ -1231,7 +1236,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     if (sub == 0)
 #pragma unroll
       for (int j = 0; j < JX; ++j) {
-        if (NW > 0 && !L.joint_own[j]) continue;
+        if (TP::PAD && !L.joint_own[j]) continue;
         S.dbg_torque[(size_t)e * T.D + L.joint_id[j]] = live * tau_app[j];
         S.dbg_acc[(size_t)e * T.D + L.joint_id[j]] = live * qacc[j];
       }
@@ -1292,7 +1297,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       prev_act[j] = act[j];
-      float a = (e < S.N && (NW == 0 || L.joint_id[j] >= 0)) ? S.action_in[(size_t)e * T.D + L.joint_id[j]] : 0.f;
+      float a = (e < S.N && (!TP::PAD || L.joint_id[j] >= 0)) ? S.action_in[(size_t)e * T.D + L.joint_id[j]] : 0.f;
       act[j] = a;
       float pr = clampf(a * L.a_scale[j] + L.a_off[j], L.a_lo[j], L.a_hi[j]);
       q_tgt[j] = L.action_is_vel[j] ? 0.f : pr;

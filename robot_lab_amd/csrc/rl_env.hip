@@ -148,7 +148,8 @@ struct Backend {
     } else if (T.NW == 0) {
       const size_t tb = staged_bytes(T);
       size_t need[3] = {0, 0, 0};  // LDS of a single-wavefront workgroup, mappings 4 / 2 / 1
-      switch (T.CL + (T.merged ? 100 : 0)) {
+      switch (T.CL + (T.merged ? 100 : 0) + (T.rotpad ? 400 : 0)) {
+        case 404: need[0] = lds_need<TopoQuad4R, 4>(T); need[1] = lds_need<TopoQuad4R, 2>(T); need[2] = lds_need<TopoQuad4R, 1>(T); break;
         case 3: need[0] = lds_need<TopoQuad3, 4>(T); need[1] = lds_need<TopoQuad3, 2>(T); need[2] = lds_need<TopoQuad3, 1>(T); break;
         case 4: need[0] = lds_need<TopoQuad4, 4>(T); need[1] = lds_need<TopoQuad4, 2>(T); need[2] = lds_need<TopoQuad4, 1>(T); break;
         case 104: need[0] = lds_need<TopoQuad4M, 4>(T); need[1] = lds_need<TopoQuad4M, 2>(T); need[2] = lds_need<TopoQuad4M, 1>(T); break;
@@ -180,7 +181,7 @@ struct Backend {
     return staged_bytes(T) + (size_t)P.words * 4;
   }
   int configure(const Tables& T) {
-    const int key = (T.CL + (T.merged ? 100 : 0) + (T.NW > 3 ? 200 : 0)) * 10 + sub;
+    const int key = (T.CL + (T.merged ? 100 : 0) + (T.NW > 3 ? 200 : 0) + (T.rotpad ? 400 : 0)) * 10 + sub;
     switch (key) {
       case 31: lds_bytes = lds_need<TopoQuad3, 1>(T); break;
       case 32: lds_bytes = lds_need<TopoQuad3, 2>(T); break;
@@ -191,6 +192,9 @@ struct Backend {
       case 1041: lds_bytes = lds_need<TopoQuad4M, 1>(T); break;
       case 1042: lds_bytes = lds_need<TopoQuad4M, 2>(T); break;
       case 1044: lds_bytes = lds_need<TopoQuad4M, 4>(T); break;
+      case 4041: lds_bytes = lds_need<TopoQuad4R, 1>(T); break;
+      case 4042: lds_bytes = lds_need<TopoQuad4R, 2>(T); break;
+      case 4044: lds_bytes = lds_need<TopoQuad4R, 4>(T); break;
       case 71:  // 64 limbs per wavefront: 115 KB of limb-shared words + 30 KB of sensor rows.  The CPU lane emulator runs it (tests/emu); no kernel is built for it
         err = "the one-lane-per-limb mapping (RL_ENV_SUB=1) of the trunk + limbs instance needs more LDS than a CU has";
         return -1;
@@ -209,7 +213,7 @@ struct Backend {
     return 0;
   }
   int spec_id = 0;  // env_spec.h: the Spec whose constants equal this env's tables (rl_env_host.h create), 0: the interpreter
-  int launch(const KState& S, const void* T, int CL, void* stream) {  // CL: chain length, + 100 for a merged instance; S.mode: what to run
+  int launch(const KState& S, const void* T, int CL, void* stream) {  // CL: chain length, + 100 for a merged instance, + 400 for the rot / pad quadruped; S.mode: what to run
     hipStream_t st = (hipStream_t)stream;
     if (spec_id != 0 && S.mode == KMODE_STEP) {  // the step kernel specialised on this task, when the build has it for the lane mapping
       int rc = -2;
@@ -241,6 +245,9 @@ struct Backend {
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 1044
       case 104: return check(launch_cl<TopoQuad4M, 4>(cfg, S, T, lds_bytes, st));
+#endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 4044
+      case 404: return check(launch_cl<TopoQuad4R, 4>(cfg, S, T, lds_bytes, st));
 #endif
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 74
       case 7: return check(launch_cl<TopoG1, 4>(cfg, S, T, lds_bytes, st));

@@ -50,7 +50,7 @@ inline void quat_to_rows(const float q[4], float R[9]) {
 }
 
 // shape of the lane-program instance that simulates this model (env_tables.h Topo<>)
-inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& NBS) {
+inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& NBS, int& rotpad) {
   if (m.num_chains != NLANE || m.chain_len < 1 || m.chain_len > MAX_CL || m.num_trunk < 0 || m.num_trunk > MAX_NW)
     return fail("lane program needs a trunk of <= 6 serial joints carrying 4 limb chains of <= 7 joints (got " + std::to_string(m.num_chains) + " chains x " +
                 std::to_string(m.chain_len) + ", trunk " + std::to_string(m.num_trunk) + ")");
@@ -63,8 +63,13 @@ inline int topo_shape(const rl_model_desc& m, int& CL, int& NW, int& SPL, int& N
     const float n = fabsf(q[0]) + fabsf(q[1]) + fabsf(q[2]) + fabsf(q[3]);
     rotated = rotated || (n > 0.f && (fabsf(q[1]) > 1e-6f || fabsf(q[2]) > 1e-6f || fabsf(q[3]) > 1e-6f));  // all-zero: descriptor without rotations
   }
+  rotpad = 0;
   if (m.num_trunk == 0 && m.chain_len <= 4 && equal && m.chain_len >= 3 && !rotated) { CL = m.chain_len; NW = 0; SPL = 3; NBS = 6; }
-  else { CL = 7; NW = m.num_trunk > 3 ? 6 : 3; SPL = 4; NBS = 9; }
+  else if (m.num_trunk == 0 && m.chain_len <= 4 && !(std::getenv("RL_ENV_ROTPAD") && atoi(std::getenv("RL_ENV_ROTPAD")) == 0)) {
+    // quadruped-shaped, but with rotated joint frames or limbs of unequal length (DDT Tita: two wheeled 4-joint legs, two empty limbs): the
+    // 4-joint quadruped instance with rot0 and padding joints, Topo<4,0,3,6,0,1>.  (RL_ENV_ROTPAD=0: the trunk + limbs instance, as until round 4)
+    CL = 4; NW = 0; SPL = 3; NBS = 6; rotpad = 1;
+  } else { CL = 7; NW = m.num_trunk > 3 ? 6 : 3; SPL = 4; NBS = 9; }
   // a shorter trunk (ATOM01: one waist joint) or none runs on the NW = 3 instance with inert padding trunk joints; a longer one
   // (GR1: waist + head) on the NW = 6 instance
   return 0;
@@ -74,11 +79,11 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
                         std::vector<int>& link_pos_out, bool merge = false) {
   memset(&T, 0, sizeof(T));
   const rl_model_desc& m = d.model;
-  int CL, NW, SPL, NBS;
-  if (topo_shape(m, CL, NW, SPL, NBS)) return -1;
+  int CL, NW, SPL, NBS, rotpad;
+  if (topo_shape(m, CL, NW, SPL, NBS, rotpad)) return -1;
   const int NGRP = CL + 1;
-  if (merge && !(NW == 0 && CL == 4)) return fail("merged base share: 4-joint quadruped limbs only");
-  T.CL = CL; T.NW = NW; T.SPL = SPL; T.NBS = NBS; T.nw_used = m.num_trunk; T.merged = merge ? 1 : 0;
+  if (merge && !(NW == 0 && CL == 4 && !rotpad)) return fail("merged base share: 4-joint quadruped limbs (same length, unrotated joint frames) only");
+  T.CL = CL; T.NW = NW; T.SPL = SPL; T.NBS = NBS; T.nw_used = m.num_trunk; T.merged = merge ? 1 : 0; T.rotpad = rotpad;
   T.D = m.num_dof;
   T.n_bodies = m.num_bodies;
   body_lane.assign(m.num_bodies, -1);
@@ -489,7 +494,9 @@ inline int compile_tables(const rl_env_desc& d, Tables& tables, std::vector<int>
   // wheeled quadrupeds (4-joint limbs): the merged instance when the trunk's spheres fit the free sphere slots of the limbs
   // (Go2W, ZSL1W, M20, Dog-W), else the instance with a link group for the trunk share.  RL_ENV_MERGE=0: never merged, 2: whenever it fits.
   const char* mv = std::getenv("RL_ENV_MERGE");
-  const bool want = d.model.num_trunk == 0 && d.model.chain_len == 4 && !(mv && atoi(mv) == 0);
+  int cl_, nw_, spl_, nbs_, rotpad_ = 0;
+  if (topo_shape(d.model, cl_, nw_, spl_, nbs_, rotpad_)) return -1;
+  const bool want = d.model.num_trunk == 0 && d.model.chain_len == 4 && !rotpad_ && !(mv && atoi(mv) == 0);
   bool merged = want && build_tables(d, tables, body_lane, body_slot, link_lane, link_pos, true) == 0;
   // it pays when the last link group (the wheels) has spheres - the group that costs the unmerged instance a second contact
   // pass; without (B2W) the unmerged instance skips that pass anyway and is 1 % faster (profiles/r02_merged_wheeled.txt)
@@ -500,19 +507,20 @@ inline int compile_tables(const rl_env_desc& d, Tables& tables, std::vector<int>
 
 // packed (per-instance) table image that the env kernels stage into LDS
 inline size_t packed_size(const TaskTab& T) {
-  return T.NW > 3 ? sizeof(TablesT<TopoGR>) : T.NW > 0 ? sizeof(TablesT<TopoG1>) : (T.CL == 4 ? sizeof(TablesT<TopoQuad4>) : sizeof(TablesT<TopoQuad3>));
+  return T.NW > 3 ? sizeof(TablesT<TopoGR>) : T.NW > 0 ? sizeof(TablesT<TopoG1>) : (T.rotpad ? sizeof(TablesT<TopoQuad4R>) : T.CL == 4 ? sizeof(TablesT<TopoQuad4>) : sizeof(TablesT<TopoQuad3>));
 }
 template <class TP>
 inline size_t staged_bytes_t(const TaskTab& T) {  // `rew` is the last member: everything up to its first n_rewards entries
   return (sizeof(TablesBody<TP>) - (size_t)(MAX_T - T.n_rewards) * sizeof(RewTab) + 15) / 16 * 16;
 }
 inline size_t staged_bytes(const TaskTab& T) {
-  return T.NW > 3 ? staged_bytes_t<TopoGR>(T) : T.NW > 0 ? staged_bytes_t<TopoG1>(T) : (T.CL == 4 ? staged_bytes_t<TopoQuad4>(T) : staged_bytes_t<TopoQuad3>(T));
+  return T.NW > 3 ? staged_bytes_t<TopoGR>(T) : T.NW > 0 ? staged_bytes_t<TopoG1>(T) : (T.rotpad ? staged_bytes_t<TopoQuad4R>(T) : T.CL == 4 ? staged_bytes_t<TopoQuad4>(T) : staged_bytes_t<TopoQuad3>(T));
 }
 inline std::vector<uint8_t> pack_image(const Tables& T) {
   std::vector<uint8_t> img(packed_size(T), 0);
   if (T.NW > 3) pack_tables<TopoGR>(T, *reinterpret_cast<TablesT<TopoGR>*>(img.data()));
   else if (T.NW > 0) pack_tables<TopoG1>(T, *reinterpret_cast<TablesT<TopoG1>*>(img.data()));
+  else if (T.rotpad) pack_tables<TopoQuad4R>(T, *reinterpret_cast<TablesT<TopoQuad4R>*>(img.data()));
   else if (T.CL == 4) pack_tables<TopoQuad4>(T, *reinterpret_cast<TablesT<TopoQuad4>*>(img.data()));
   else pack_tables<TopoQuad3>(T, *reinterpret_cast<TablesT<TopoQuad3>*>(img.data()));
   return img;
@@ -531,7 +539,7 @@ struct EnvImpl {
   KState S;
   CmdLevelParams cmd_level_params{};
   int spec_id = 0;  // env_spec.h: the specialised step kernel this env runs (0: the interpreter)
-  int N = 0, Npad = 0, D = 0, B = 0, CL = 0, inst = 0, ept = ENVS_PER_WAVE;  // inst: lane-program instance key (CL, + 100 merged, + 200 six-joint trunk)
+  int N = 0, Npad = 0, D = 0, B = 0, CL = 0, inst = 0, ept = ENVS_PER_WAVE;  // inst: lane-program instance key (CL, + 100 merged, + 200 six-joint trunk, + 400 rot / pad quadruped)
   uint64_t seed = 0;
   uint32_t step_counter = 0;
   // the kernels take the step count as *step_base + launch literal (rl_env_graph_*): `anchor` mirrors the device word
@@ -584,10 +592,10 @@ struct EnvImpl {
     }
     be.spec_id = spec_id;
     CL = tables.CL;
-    inst = tables.CL + (tables.merged ? 100 : 0) + (tables.NW > 3 ? 200 : 0);
+    inst = tables.CL + (tables.merged ? 100 : 0) + (tables.NW > 3 ? 200 : 0) + (tables.rotpad ? 400 : 0);
     if (be.init(device)) return fail("device init failed: " + be.error());
     ept = be.envs_per_wave(tables, Npad);  // the lane mapping (16 or 4 lanes per env) decides the layout of the state tiles
-    if (std::getenv("RL_ENV_DEBUG")) fprintf(stderr, "rl_env: lane program CL %d NW %d merged %d, %d envs per wavefront\n", tables.CL, tables.NW, tables.merged, ept);
+    if (std::getenv("RL_ENV_DEBUG")) fprintf(stderr, "rl_env: lane program CL %d NW %d merged %d rot/pad %d, %d envs per wavefront\n", tables.CL, tables.NW, tables.merged, tables.rotpad, ept);
     if (be.configure(tables)) return fail("kernel configuration failed: " + be.error());
     const size_t Np = Npad, ntile = Npad / ept;
     const Layout ly(tables.CL, tables.NW, tables.NBS);

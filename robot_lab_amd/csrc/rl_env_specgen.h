@@ -32,8 +32,8 @@ inline std::string spec_source(const rl_env_desc& d, const char* struct_name, co
   };
   if (compile_tables(d, T, bl, bs, ll, lp)) return done(last_error());
   if (T.cur_lin || T.cur_ang) return done("command_levels_* curricula: the split step runs the interpreter");
-  const char* topo = T.NW > 3 ? "TopoGR" : T.NW > 0 ? "TopoG1" : (T.CL == 4 ? (T.merged ? "TopoQuad4M" : "TopoQuad4") : "TopoQuad3");
-  const int inst = T.CL + (T.merged ? 100 : 0) + (T.NW > 3 ? 200 : 0);
+  const char* topo = T.NW > 3 ? "TopoGR" : T.NW > 0 ? "TopoG1" : (T.rotpad ? "TopoQuad4R" : T.CL == 4 ? (T.merged ? "TopoQuad4M" : "TopoQuad4") : "TopoQuad3");
+  const int inst = T.CL + (T.merged ? 100 : 0) + (T.NW > 3 ? 200 : 0) + (T.rotpad ? 400 : 0);
   int jk[RL_MAX_DOF], jj[RL_MAX_DOF];
   for (int i = 0; i < RL_MAX_DOF; ++i) jk[i] = jj[i] = -1;
   for (int k = 0; k < NLANE; ++k)

@@ -33,6 +33,9 @@ extern "C" __attribute__((visibility("hidden"))) int RL_SUB_CAT(rl_env_launch_su
 #if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 1040 + RL_ENV_TU_SUB
     case 104: return (int)launch_cl<TopoQuad4M, SUB>(cfg, S, T, lds1, st);
 #endif
+#if RL_ENV_ONLY == 0 || RL_ENV_ONLY == 4040 + RL_ENV_TU_SUB
+    case 404: return (int)launch_cl<TopoQuad4R, SUB>(cfg, S, T, lds1, st);
+#endif
     default: return -2;
   }
 }

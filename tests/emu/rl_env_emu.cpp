@@ -553,6 +553,15 @@ struct Backend {
 #if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 1044
       case 1044: run<rl::TopoQuad4M, 4>(S, T); return 0;
 #endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 4041
+      case 4041: run<rl::TopoQuad4R, 1>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 4042
+      case 4042: run<rl::TopoQuad4R, 2>(S, T); return 0;
+#endif
+#if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 4044
+      case 4044: run<rl::TopoQuad4R, 4>(S, T); return 0;
+#endif
 #if !defined(RL_EMU_ONLY) || RL_EMU_ONLY == 71
       case 71: run<rl::TopoG1, 1>(S, T); return 0;
 #endif

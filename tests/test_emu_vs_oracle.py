@@ -113,7 +113,9 @@ def test_resets_and_logs(emu_lib):
 @pytest.mark.parametrize("task,N,steps,merge", [(TASKS[1], 16, 2, None), (TASKS[3], 8, 2, None), (TASKS[5], 4, 3, None),
                                                 (TASKS[3], 8, 2, "0"), ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", 8, 2, None),
                                                 # Go2 (21 terms incl. the gait kind) and the HandStand task's own kinds
-                                                (TASKS[2], 8, 2, None), ("RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0", 8, 2, None)])
+                                                (TASKS[2], 8, 2, None), ("RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0", 8, 2, None),
+                                                # DDT Tita: the rot / pad quadruped instance (rotated joint frames, two empty limbs)
+                                                ("RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0", 8, 2, None)])
 @pytest.mark.parametrize("sub", ["4", "2"])
 def test_sixteen_lane_mapping_matches_oracle(task, N, steps, merge, sub, emu_lib, monkeypatch):
     """The 16-lanes-per-env mapping (a DPP quad per limb; the default on the GPU: link groups dealt to the sub-lanes, contact
@@ -336,4 +338,28 @@ def test_six_joint_spine_without_contacts_meets_the_standard_bands(sub, emu_lib,
     assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), 1e-3, 1e-4)
     assert_close("q", host_view(nat, "JOINT_POS"), ora.st["q"], 1e-3, 1e-4)
     assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], 2e-3, 2e-3)
+    nat.close()
+
+
+def test_tita_on_the_trunk_and_limbs_instance(emu_lib, monkeypatch):
+    """RL_ENV_ROTPAD=0: DDT Tita back on the trunk + limbs instance it ran on until round 4 (what a quadruped-shaped robot with self-collision
+    pairs or more than three spheres on a link would still need); the default - the rot / pad quadruped instance - is in the lists above."""
+    monkeypatch.setenv("RL_ENV_ROTPAD", "0")
+    monkeypatch.setenv("RL_EMU_SUB", "8")
+    monkeypatch.setenv("RL_EMU_FIBERS", "1")
+    N = 4
+    desc, ora, nat = make_pair("RobotLab-Isaac-Velocity-Flat-DDTRobot-Tita-v0", N, 21, emu_lib)
+    assert nat.envs_per_wavefront() == 2
+    o = ora.reset()
+    nat.reset()
+    rng = np.random.default_rng(5)
+    for s in range(3):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        o = ora.step(a)
+        nat.step(a.ctypes.data)
+        assert_close(f"reward[{s}]", host_view(nat, "REWARD"), ora.reward, 1e-3, 2e-5)
+    nat.export_state()
+    assert_close("root", host_view(nat, "ROOT_STATE"), oracle_root_state(ora), 1e-3, 1e-4)
+    assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], 2e-3, 2e-3)
+    assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
     nat.close()

@@ -58,7 +58,10 @@ def _pair(task, N, seed):
     return env, OracleWithTwin(lambda: OracleEnv(desc, h, to, N, seed, eo)), torch
 
 
-TRUNK_LIMBS = ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1", "Booster")  # robots on the trunk + limbs instance
+TRUNK_LIMBS = ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Z1", "Booster")  # robots on the trunk + limbs instance
+# (DDT Tita - two wheeled 4-joint legs with rotated joint frames, two empty limbs - runs on the rot / pad quadruped instance Topo<4,0,3,6,0,1>
+# since round 5; RL_ENV_ROTPAD=0 puts it back on the trunk + limbs instance: one shape of that below)
+TITA = "RobotLab-Isaac-Velocity-Flat-DDTRobot-Tita-v0"
 # Kernel shapes.  Production launches of >= 4096 quadruped envs run env_kernel<..., WGW = 4> (four wavefronts
 # per workgroup sharing one staged table image); 64 envs would take the single-wavefront variant, so every quadruped id is run in
 # BOTH: "" = what the launch size selects (WGW = 1 here), "-4" = RL_ENV_WG=-4 forces the four-wavefront shape at this size.  The
@@ -67,6 +70,7 @@ TRUNK_LIMBS = ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1", "Booster")
 # per limb, two envs per wavefront) in single- and four-wavefront workgroups ("sub8", "sub8-4": what a >= 2048-env launch runs).
 SHAPES = [(t, wg, None) for t in TASKS for wg in (("", "-4") if not any(r in t for r in TRUNK_LIMBS + ("GR1",)) else ("sub4", "sub8", "sub8-4"))]
 SHAPES += [(t, wg, "0") for t in (TASKS[3], TASKS[8]) for wg in ("", "-4")]  # Go2W, M20
+SHAPES += [(TITA, "sub2", None), (TITA, "sub1", None), (TITA, "sub8", "rotpad0")]
 
 
 @pytest.mark.parametrize("task,wg,merge", SHAPES)
@@ -76,9 +80,11 @@ def test_short_horizon_parity(task, wg, merge, monkeypatch):
         wg = wg[4:]
     if wg:
         monkeypatch.setenv("RL_ENV_WG", wg)
-    if merge is not None:
+    if merge == "rotpad0":
+        monkeypatch.setenv("RL_ENV_ROTPAD", "0")
+    elif merge is not None:
         monkeypatch.setenv("RL_ENV_MERGE", merge)
-    N = 32 if any(r in task for r in TRUNK_LIMBS + ("GR1",)) else 64
+    N = 32 if any(r in task for r in TRUNK_LIMBS + ("GR1",)) or merge == "rotpad0" else 64
     env, two, torch = _pair(task, N, 11)
     ora = two.ora
     obs, _ = env.reset()

@@ -45,6 +45,10 @@ CONFIGS = [
     ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", 2048, "sub4"),
     ("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0", 1024, "sub8"),
     ("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0", 1024, "sub4"),
+    # the rot / pad quadruped instance Topo<4,0,3,6,0,1> (rotated joint frames, limbs shorter than four joints): DDT Tita - what the launch
+    # picks at 4096 envs, and the one-lane-per-limb mapping
+    ("RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0", 4096, None),
+    ("RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0", 4096, "sub1"),
 ]
 
 

@@ -19,6 +19,7 @@ PLANS = {
     "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0": QUADRUPED,
     "RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0": QUADRUPED,
     "RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0": QUADRUPED,
+    "RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0": QUADRUPED,  # the rot / pad quadruped instance
     "RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0": TRUNK,
     "RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0": TRUNK,
 }

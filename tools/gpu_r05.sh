@@ -13,6 +13,7 @@ GO2=RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0
 GO2W=RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0
 G1=RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0
 GR1=RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0
+TITA=RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0
 prof() {  # name, cmd, rocprofv3 args...
   local name=$1; local cmd=$2; shift; shift
   ( cd /tmp && timeout 300 rocprofv3 "$@" -d $GRAFT_REPO_ROOT/$OUT/prof_$name -- $cmd > $GRAFT_REPO_ROOT/$OUT/under_$name.json 2> $GRAFT_REPO_ROOT/$OUT/$name.err )
@@ -142,5 +143,22 @@ d)
   python -c "
 import json
 d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  ms_per_step %.4f  kernel_ms %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms']), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'))"
+  ;;
+e)
+  # 1. the observation stage on a Spec, on / off (the same tree, -DRL_SPEC_OBS_OFF), quadrupeds: A1 and Go2W (merged instance)
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 $V/obsoff_34.so $V/obson_34.so > $OUT/spec_obs_onoff.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GO2W $V/obsoff_1044.so $V/obson_1044.so >> $OUT/spec_obs_onoff.txt 2>&1
+  cat $OUT/spec_obs_onoff.txt
+  # 2. DDT Tita on the rot / pad quadruped instance Topo<4,0,3,6,0,1> (until now: the trunk + limbs instance, RL_ENV_ROTPAD=0): parity in
+  #    every shape, one step from a shared state at 4096 envs, and the two instances timed in one call
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "Tita" > $OUT/pytest_tita_parity.log 2>&1; echo "rc=$?" >> $OUT/pytest_tita_parity.log
+  tail -4 $OUT/pytest_tita_parity.log
+  timeout 900 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "Tita" > $OUT/pytest_tita_teacher_forced.log 2>&1; echo "rc=$?" >> $OUT/pytest_tita_teacher_forced.log
+  tail -4 $OUT/pytest_tita_teacher_forced.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  for n in 4096 16384; do
+    timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $TITA --num-envs $n trunk_limbs:RL_ENV_ROTPAD=0 rot_pad_quadruped:RL_ENV_ROTPAD=1 >> $OUT/tita_instances.txt 2>&1
+  done
+  cat $OUT/tita_instances.txt
   ;;
 esac
