@@ -309,6 +309,12 @@ RL_FN void trunk_frame(const CT& C, int depth, M3& Rf, V3& pf) {
     if (depth == i + 1) { Rf = C.Rw(i); pf = C.pw(i); }
 }
 
+// The same frame straight from the joint positions - the trunk loop of chain_kinematics() below alone, nothing stored: what the scanner
+// pose of a freshly reset env needs of the new posture (the full kinematics through the limb-shared chain words was 5.5 k ticks = 2.9 us
+// of a resetting G1 wavefront, profiles/r05g_phase_clock_clockspec_78_reset_env0.txt)
+template <class TP, class LT>
+RL_FN void trunk_frame_of_pose(const LT& L, const float (&q)[TP::JX], uint32_t restart, int depth, M3& Rf, V3& pf);
+
 // `on_trunk(i, axis, origin)` / `on_limb(j, axis, origin)`: called with the joint's axis and origin (base coordinates) while they are in
 // registers - the substep of the trunk + limbs instance builds the link velocities / bias accelerations there instead of reading
 // the chain words back (two LDS round trips per joint less); NoJoint = nothing to do
@@ -352,6 +358,28 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
     on_limb(j, aw, pj);
     Rp = Rj;
     pp = pj;
+  }
+}
+
+template <class TP, class LT>
+RL_FN void trunk_frame_of_pose(const LT& L, const float (&q)[TP::JX], uint32_t restart, int depth, M3& Rf, V3& pf) {
+  constexpr int CL = TP::CL, NW = TP::NW;
+  Rf = identity3();
+  pf = {0.f, 0.f, 0.f};
+  M3 Rp = identity3();
+  V3 pp{0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int jx = CL + i;
+    if (i > 0 && ((restart >> i) & 1u)) { Rp = identity3(); pp = {0.f, 0.f, 0.f}; }
+    V3 al, oj;
+    joint_origin_axis(L, jx, oj, al);
+    const M3 Rj0 = mul(Rp, ld_m3(L.rot0[TP::ROT ? jx : 0]));
+    const V3 pj = pp + mul(Rp, oj);
+    const M3 Rj = mul(Rj0, rodrigues(al, q[jx]));
+    Rp = Rj;
+    pp = pj;
+    if (depth == i + 1) { Rf = Rj; pf = pj; }
   }
 }
 

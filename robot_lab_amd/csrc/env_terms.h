@@ -416,15 +416,24 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   }
 
   // UniformVelocityCommand._resample_command [UPSTREAM B7] + threshold (VEL/mdp/commands.py:43-47)
-  // `RT`: the env's table of this step's STREAM_RESET uniforms (reset_uniforms) when the draws are a reset's, else nullptr
+  // TABLE: the draws are a reset's - words of `RT`, the env's table of this step's STREAM_RESET uniforms (reset_uniforms)
+  template <bool TABLE = false>
   RL_FN void resample_command(uint32_t stream, uint32_t idx, const float* RT = nullptr) {
-    // ranges: the table's, or the live ones of the command_levels_* curricula (VEL/mdp/curriculums.py:21-94)
-    const float* lv = S.cmd_levels;
-    const bool cl = T.cur_lin != 0, ca = T.cur_ang != 0;
-    auto UU = [&](uint32_t i, float lo, float hi) __attribute__((always_inline)) { return RT != nullptr ? lerp_draw(lo, hi, RT[i]) : U(stream, i, lo, hi); };
-    float vx = UU(idx + 0, cl ? lv[CL_LIN_X] : T.cmd_range[0][0], cl ? lv[CL_LIN_X + 1] : T.cmd_range[0][1]);
-    float vy = UU(idx + 1, cl ? lv[CL_LIN_Y] : T.cmd_range[1][0], cl ? lv[CL_LIN_Y + 1] : T.cmd_range[1][1]);
-    float wz = UU(idx + 2, ca ? lv[CL_ANG_Z] : T.cmd_range[2][0], ca ? lv[CL_ANG_Z + 1] : T.cmd_range[2][1]);
+    // ranges: the table's, or the live ones of the command_levels_* curricula (VEL/mdp/curriculums.py:21-94) - read under ONE branch, so
+    // that without the curricula (every shipped cfg) the six table words and the six draws are straight-line code
+    float rx0 = T.cmd_range[0][0], rx1 = T.cmd_range[0][1], ry0 = T.cmd_range[1][0], ry1 = T.cmd_range[1][1], rz0 = T.cmd_range[2][0], rz1 = T.cmd_range[2][1];
+    if (T.cur_lin != 0 || T.cur_ang != 0) {
+      const float* lv = S.cmd_levels;
+      if (T.cur_lin) { rx0 = lv[CL_LIN_X]; rx1 = lv[CL_LIN_X + 1]; ry0 = lv[CL_LIN_Y]; ry1 = lv[CL_LIN_Y + 1]; }
+      if (T.cur_ang) { rz0 = lv[CL_ANG_Z]; rz1 = lv[CL_ANG_Z + 1]; }
+    }
+    auto UU = [&](uint32_t i, float lo, float hi) __attribute__((always_inline)) {
+      if constexpr (TABLE) return lerp_draw(lo, hi, RT[i]);
+      else return U(stream, i, lo, hi);
+    };
+    float vx = UU(idx + 0, rx0, rx1);
+    float vy = UU(idx + 1, ry0, ry1);
+    float wz = UU(idx + 2, rz0, rz1);
     float hd = UU(idx + 3, T.cmd_range[3][0], T.cmd_range[3][1]);
     bool ih = UU(idx + 4, 0.f, 1.f) <= T.cmd_rel_heading;
     bool is = UU(idx + 5, 0.f, 1.f) <= T.cmd_rel_standing;
@@ -472,23 +481,43 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
   }
 
-  RL_FN void reset_env(bool log_episode) {
+  // With the table of uniforms (every mapping but one lane per limb) the body below is STRAIGHT-LINE code: event flags and single-point
+  // ranges select results instead of guarding loads.  Written with a branch per event and per draw (`hi > lo ? table word : lo`) the
+  // compiler put every LDS read - a range, then the word - into a block of its own, behind the read it depended on: 93 reads, 77 waits,
+  // one after the other in a lone wavefront (A1: 7.5 k ticks of the resetting wavefront = 4 us, G1: 12.8 k = 6.8 us,
+  // profiles/r05g_phase_clock_*_reset_env0.txt) - and a launch ends with its slowest wavefront, which in steady state is one that resets
+  // an env.  Same draws, same arithmetic.  `sums_folded`: the reward stage has logged and zeroed the episode sums already (compute_rewards).
+  RL_FN void reset_env(bool log_episode, bool sums_folded = false) {
+    RL_PHASE(26, "reset.uniforms");
     const float* RT = reset_uniforms();
+    RL_PHASE(27, "reset.state");
+    constexpr bool TAB = SUB > 1;  // draws are table words (reset_uniforms); else a Philox block per draw, worth a branch
     auto UR = [&](uint32_t idx, float lo, float hi) __attribute__((always_inline)) {
-      // (hi > lo: a single-point range is `lo` without a look at the table - reset_uniforms does not fill the blocks of such streams)
-      return RT != nullptr ? (hi > lo ? lerp_draw(lo, hi, RT[idx]) : lo) : U(STREAM_RESET, idx, lo, hi);
+      if constexpr (TAB) {
+        // (hi > lo: a single-point range is `lo` - reset_uniforms does not fill the blocks of such streams; the word is read all the same)
+        const float uw = RT[idx];
+        return hi > lo ? lerp_draw(lo, hi, uw) : lo;
+      } else {
+        return U(STREAM_RESET, idx, lo, hi);
+      }
     };
-    // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671)
-    if (T.curriculum && !T.is_plane) {
+    // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671).  The origin of the new tile is the one HBM read
+    // of a reset: issued first, consumed last (the root position below)
+    const bool cur = T.curriculum && !T.is_plane;
+    V3 origin_new = origin;
+    if (TAB || cur) {
       float dx = pos.x - origin.x, dy = pos.y - origin.y;
       float dist = fsqrt(dx * dx + dy * dy);
       bool up = dist > T.tile_size * 0.5f;
       bool down = (dist < fsqrt(cmd.x * cmd.x + cmd.y * cmd.y) * T.max_episode_length_s * 0.5f) && !up;
       int lv = level + (up ? 1 : 0) - (down ? 1 : 0);
       int rnd = (int)fminf(floorf(UR(IDX_LEVEL, 0.f, 1.f) * (float)T.num_rows), (float)(T.num_rows - 1));
-      level = lv >= T.num_rows ? rnd : (lv < 0 ? 0 : lv);
-      const float* o = S.terrain_origins + ((size_t)level * T.num_cols + ttype) * 3;
-      origin = {o[0], o[1], o[2]};
+      const int lv_new = lv >= T.num_rows ? rnd : (lv < 0 ? 0 : lv);
+      level = cur ? lv_new : level + 0;
+      // (a plane has a one-tile origin table of zeros: rl_env_host.h create)
+      const float* o = S.terrain_origins + (cur ? ((size_t)level * T.num_cols + ttype) * 3 : (size_t)0);
+      const V3 ot{o[0], o[1], o[2]};
+      origin_new = select3(cur, ot, origin);  // (a plane, or no curriculum: the env keeps its origin)
     }
     // scene.reset: sensor / wrench buffers
 #pragma unroll
@@ -502,25 +531,32 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     extF = {0.f, 0.f, 0.f};
     extT = {0.f, 0.f, 0.f};
     // reset events in declaration order (velocity_env_cfg.py:316-363)
-    if (T.ev_wrench) {
-      extF = {UR(IDX_WRENCH + 0, T.wrench_force[0], T.wrench_force[1]), UR(IDX_WRENCH + 1, T.wrench_force[0], T.wrench_force[1]),
-              UR(IDX_WRENCH + 2, T.wrench_force[0], T.wrench_force[1])};
-      extT = {UR(IDX_WRENCH + 3, T.wrench_torque[0], T.wrench_torque[1]), UR(IDX_WRENCH + 4, T.wrench_torque[0], T.wrench_torque[1]),
-              UR(IDX_WRENCH + 5, T.wrench_torque[0], T.wrench_torque[1])};
+    const bool ev_wrench = T.ev_wrench != 0, ev_joints = T.ev_reset_joints != 0, ev_gains = T.ev_gains != 0, ev_base = T.ev_reset_base != 0;
+    if (TAB || ev_wrench) {
+      const float f0 = T.wrench_force[0], f1 = T.wrench_force[1], t0 = T.wrench_torque[0], t1 = T.wrench_torque[1];
+      const V3 wf{UR(IDX_WRENCH + 0, f0, f1), UR(IDX_WRENCH + 1, f0, f1), UR(IDX_WRENCH + 2, f0, f1)};
+      const V3 wt{UR(IDX_WRENCH + 3, t0, t1), UR(IDX_WRENCH + 4, t0, t1), UR(IDX_WRENCH + 5, t0, t1)};
+      extF = select3(ev_wrench, wf, extF);
+      extT = select3(ev_wrench, wt, extT);
     }
+    const float jp0 = T.reset_jpos[0], jp1 = T.reset_jpos[1], jv0 = T.reset_jvel[0], jv1 = T.reset_jvel[1];
+    const float gp0 = T.gain_kp[0], gp1 = T.gain_kp[1], gd0 = T.gain_kd[0], gd1 = T.gain_kd[1];
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       uint32_t ji = (uint32_t)((TP::PAD && L.joint_id[j] < 0) ? 0 : L.joint_id[j]);  // padding joints: q0 = qd0 = kp0 = kd0 = 0
       float qn = L.q0[j], qdn = L.qd0[j];
-      if (T.ev_reset_joints) {  // reset_joints_by_scale [UPSTREAM B8]
-        qn = clampf(L.q0[j] * UR(IDX_JPOS + ji, T.reset_jpos[0], T.reset_jpos[1]), L.soft_lo[j], L.soft_hi[j]);
-        qdn = clampf(L.qd0[j] * UR(IDX_JVEL + ji, T.reset_jvel[0], T.reset_jvel[1]), -L.vel_limit[j], L.vel_limit[j]);
+      if (TAB || ev_joints) {  // reset_joints_by_scale [UPSTREAM B8]
+        const float qa = clampf(L.q0[j] * UR(IDX_JPOS + ji, jp0, jp1), L.soft_lo[j], L.soft_hi[j]);
+        const float qb = clampf(L.qd0[j] * UR(IDX_JVEL + ji, jv0, jv1), -L.vel_limit[j], L.vel_limit[j]);
+        qn = select1(ev_joints, qa, qn);
+        qdn = select1(ev_joints, qb, qdn);
       }
       q[j] = qn;
       qd[j] = qdn;
-      if (T.ev_gains) {  // randomize_actuator_gains(operation="scale") [UPSTREAM B4]
-        kp[j] = L.kp0[j] * UR(IDX_KP + ji, T.gain_kp[0], T.gain_kp[1]);
-        kd[j] = L.kd0[j] * UR(IDX_KD + ji, T.gain_kd[0], T.gain_kd[1]);
+      if (TAB || ev_gains) {  // randomize_actuator_gains(operation="scale") [UPSTREAM B4]
+        const float ka = L.kp0[j] * UR(IDX_KP + ji, gp0, gp1), kb = L.kd0[j] * UR(IDX_KD + ji, gd0, gd1);
+        kp[j] = select1(ev_gains, ka, kp[j]);
+        kd[j] = select1(ev_gains, kb, kd[j]);
       }
       act[j] = 0.f;
       prev_act[j] = 0.f;
@@ -531,9 +567,14 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       float ps[6], vs[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        ps[a] = T.ev_reset_base ? UR(IDX_POSE + a, T.reset_pose[a][0], T.reset_pose[a][1]) : 0.f;
-        vs[a] = T.ev_reset_base ? UR(IDX_VEL + a, T.reset_vel[a][0], T.reset_vel[a][1]) : 0.f;
+        ps[a] = vs[a] = 0.f;
+        if (TAB || ev_base) {
+          const float pa = UR(IDX_POSE + a, T.reset_pose[a][0], T.reset_pose[a][1]), va = UR(IDX_VEL + a, T.reset_vel[a][0], T.reset_vel[a][1]);
+          ps[a] = ev_base ? pa : 0.f;
+          vs[a] = ev_base ? va : 0.f;
+        }
       }
+      origin = origin_new;
       pos = V3{T.default_root_pos[0], T.default_root_pos[1], T.default_root_pos[2]} + origin + V3{ps[0], ps[1], ps[2]};
       Q4 q0{T.default_root_quat[0], T.default_root_quat[1], T.default_root_quat[2], T.default_root_quat[3]};
       quat = quat_mul(q0, quat_from_euler_xyz(ps[3], ps[4], ps[5]));
@@ -543,10 +584,14 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // manager resets: episode-sum log + zero, command metrics log + resample, interval timer
     // (command_levels_* curricula: the live ranges read by resample_command were decided between the two launches of this step,
     // from the sums collect_cmd_levels gathered in the first one - step_head)
-    for (int t = li; t < T.n_rewards; t += LPE) {
-      float* p = S.ep_sums + (size_t)t * Np + e;
-      if (log_episode && e < S.N) ctx.atomic_add(log_slot() + LOG_EP_SUM0 + t, *p);
-      *p = 0.f;
+    if (!sums_folded) {
+      RL_PHASE(28, "reset.log");
+      for (int t = li; t < T.n_rewards; t += LPE) {
+        float* p = S.ep_sums + (size_t)t * Np + e;
+        if (log_episode && e < S.N) ctx.atomic_add(log_slot() + LOG_EP_SUM0 + t, *p);
+        *p = 0.f;
+      }
+      RL_PHASE(27, "reset.state");
     }
     if (li == 0 && log_episode && e < S.N) {
       ctx.atomic_add(log_slot() + LOG_RESET_COUNT, 1.0f);
@@ -556,8 +601,11 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     metric_xy = 0.f;
     metric_yaw = 0.f;
     cmd_time_left = UR(IDX_CMD_TIME, T.cmd_resample[0], T.cmd_resample[1]);
-    resample_command(STREAM_RESET, IDX_CMD, RT);
-    if (T.ev_push) push_left = UR(IDX_PUSH_TIME, T.push_interval[0], T.push_interval[1]);
+    resample_command<TAB>(STREAM_RESET, IDX_CMD, RT);
+    if (TAB || T.ev_push) {
+      const float pl = UR(IDX_PUSH_TIME, T.push_interval[0], T.push_interval[1]);
+      push_left = select1(T.ev_push != 0, pl, push_left);
+    }
     ep_len = 0;
   }
 
@@ -599,7 +647,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // executes each reward KIND that occurs once, for all environments and all terms of that kind), instead of one after the other
   // with a descriptor pinned into SGPRs, a scalar dispatch and a cross-lane reduction per term (round 1: ~1100 cycles per term,
   // 20 k of a 125 k-cycle step).  Every term cites the reference function it restates; oracle/env.py has the same arithmetic in fp64.
-  RL_FN float compute_rewards(bool terminated) {
+  // `fold_done`: the env is done and this launch resets it (step(): not the head launch of a split step) - the write-back then logs the
+  // final episode sums and stores zeros, from the registers that hold them; reset_env() would read them back from HBM first (a dependent
+  // round trip on the resetting wavefront's critical path)
+  RL_FN float compute_rewards(bool terminated, bool fold_done = false) {
     const int D = ctx.uniform_i(T.D), n_rewards = ctx.uniform_i(T.n_rewards);
     float* JT = ctx.rew_tab();
     float* BT = JT + JS_ROWS * D;
@@ -714,7 +765,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       if (t < n_rewards) {
         const float v = rstage[t];
         S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = v;
-        S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = acc[i] + v;
+        const float ns = acc[i] + v;
+        S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = fold_done ? 0.f : ns;
+        if (fold_done && e < S.N) ctx.atomic_add(log_slot() + LOG_EP_SUM0 + t, ns);
       }
     }
     ctx.group_sync();  // the tables share LDS with the observation rows written next
@@ -734,7 +787,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     else if constexpr (SP::N_BODIES <= 32) return (((uint32_t)MASK >> (uint32_t)b) & 1u) != 0u;
     else return ((MASK >> (uint64_t)b) & 1ull) != 0ull;
   }
-  RL_FN float compute_rewards_spec(bool terminated) {
+  RL_FN float compute_rewards_spec(bool terminated, bool fold_done = false) {
     constexpr int NT = SP::N_REW;
     constexpr int NACC = (NT + LPE - 1) / LPE;
     Ctx& cx = ctx;                  // (plain locals for the nested generic lambdas below: g++ does not find names that come from
@@ -939,7 +992,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       const int t = my_li + LPE * i;
       if (t < NT) {
         S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = mine;
-        S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = acc[i] + mine;
+        const float ns = acc[i] + mine;
+        S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = fold_done ? 0.f : ns;
+        if (fold_done && e < S.N) cx.atomic_add(this->log_slot() + LOG_EP_SUM0 + t, ns);
       }
     });
     return total;
@@ -955,14 +1010,16 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       cy = yaw_c; sy = yaw_s; scan_p = {0.f, 0.f, pos.z};
       return;
     }
-    ChainTP C = this->new_chain();
-    if (!chain_fresh) {
-      this->kinematics(C);
-      ctx.group_sync();
-    }
     M3 Rf;
     V3 pf;
-    trunk_frame<TP>(C, T.scan_depth, Rf, pf);
+    if (chain_fresh) {  // the chain words of the final joint positions are in place (step_front)
+      ChainTP C = this->new_chain();
+      trunk_frame<TP>(C, T.scan_depth, Rf, pf);
+    } else {  // some env of the wavefront has a new posture: the trunk joints alone, in registers
+      RL_PHASE(31, "obs.kinematics");
+      trunk_frame_of_pose<TP>(L, q, this->u.trunk_restart, T.scan_depth, Rf, pf);
+      RL_PHASE(20, "observations");
+    }
     const M3 Rs = mul(Rwb, Rf);
     const float hn = frsqrt(fmaxf(Rs.r0.x * Rs.r0.x + Rs.r1.x * Rs.r1.x, 1e-30f));
     cy = Rs.r0.x * hn; sy = Rs.r1.x * hn;
@@ -1341,10 +1398,12 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     RL_PHASE(16, "rewards");
 #ifdef RL_ABL_NO_REWARDS  // analysis builds: what the kernel costs without this stage (tools/ablate.sh)
     float rew = 0.f;
+    const bool fold_done = false;
 #else
     float rew;
-    if constexpr (SP::ON) rew = compute_rewards_spec(terminated);
-    else rew = compute_rewards(terminated);
+    const bool fold_done = !HEAD && (terminated || time_out);  // the episode sums' log + zero ride in the write-back (compute_rewards)
+    if constexpr (SP::ON) rew = compute_rewards_spec(terminated, fold_done);
+    else rew = compute_rewards(terminated, fold_done);
 #endif
     RL_PHASE(19, "resets+commands+push");
     if (li == 0) {
@@ -1362,12 +1421,12 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       this->store();
       store_task();
     } else {
-      step_back<false>(terminated, time_out, t_timeout, t_oob, t_illegal);
+      step_back<false>(terminated, time_out, t_timeout, t_oob, t_illegal, fold_done);
     }
   }
 
   template <bool TAIL>
-  RL_FN void step_back(const bool terminated, const bool time_out, const bool t_timeout, const bool t_oob, const bool t_illegal) {
+  RL_FN void step_back(const bool terminated, const bool time_out, const bool t_timeout, const bool t_oob, const bool t_illegal, const bool sums_folded = false) {
     // 6 reset done envs
     if (terminated || time_out) {
       if (li == 0 && e < S.N) {
@@ -1375,8 +1434,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         if (t_oob) ctx.atomic_add(log_slot() + LOG_TERM_OOB, 1.f);
         if (t_illegal) ctx.atomic_add(log_slot() + LOG_TERM_ILLEGAL, 1.f);
       }
-      reset_env(true);
+      reset_env(true, sums_folded);
       derive();
+      RL_PHASE(19, "resets+commands+push");
     }
     if constexpr (!TAIL) write_dbg_views((terminated || time_out) ? 0.f : 1.f);  // (a split step wrote them in its first launch)
 #ifdef RL_SCAN_EARLY  // (A/B switch) the scan's loads go out HERE: the pose is final (commands and the push below touch velocities only), and the
@@ -1385,6 +1445,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     scan_ahead(!TAIL && !ctx.any(terminated || time_out), scanA);
 #endif
     // 7 CommandManager.compute [UPSTREAM B7]
+    RL_PHASE(29, "commands");
     {
       const float inv_max_step = T.step_dt * frcp(T.cmd_resample[1]);
       float ex = cmd.x - lin_b.x, ey = cmd.y - lin_b.y;
@@ -1404,6 +1465,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       // the "pits" branch of commands.py:61-85 never fires: ROUGH_TERRAINS_CFG has no sub-terrain of that name (utils.py:27-28)
     }
     // 8 interval event: push_by_setting_velocity (velocity_env_cfg.py:366-371) [UPSTREAM B2/B8]
+    RL_PHASE(30, "push");
     if (T.ev_push) {
       push_left -= T.step_dt;
       if (push_left < 1e-6f) {

@@ -477,6 +477,8 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
     T.n_main = t.n_rewards <= LPE16 ? t.n_rewards : std::max(LPE16, t.n_rewards - n_scalar);
   }
   T.term_time_out = t.term_time_out; T.term_oob = t.term_out_of_bounds; T.term_illegal = t.term_illegal_contact;
+  if (const char* tv = std::getenv("RL_ENV_TERMS"))  // RL_ENV_TERMS=0: no termination term, so no env ever resets inside step() (timing A/Bs: what the reset path costs a launch)
+    if (atoi(tv) == 0) T.term_time_out = T.term_oob = T.term_illegal = 0;
   T.oob_buffer = t.oob_buffer; T.illegal_threshold = t.illegal_threshold; T.illegal_body_mask = t.illegal_body_mask;
   T.ev_wrench = t.ev_wrench; T.ev_reset_joints = t.ev_reset_joints; T.ev_gains = t.ev_gains; T.ev_reset_base = t.ev_reset_base; T.ev_push = t.ev_push;
   memcpy(T.wrench_force, t.wrench_force, 8); memcpy(T.wrench_torque, t.wrench_torque, 8);
@@ -485,6 +487,8 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   memcpy(T.reset_pose, t.reset_pose, sizeof(T.reset_pose)); memcpy(T.reset_vel, t.reset_vel, sizeof(T.reset_vel));
   memcpy(T.push_interval, t.push_interval, 8); memcpy(T.push_vel, t.push_vel, sizeof(T.push_vel));
   memcpy(T.default_root_pos, m.default_root_pos, 12); memcpy(T.default_root_quat, m.default_root_quat, 16);
+  if (const char* iv = std::getenv("RL_ENV_INTERVALS"))  // RL_ENV_INTERVALS=0: no push event, no command resampling between resets (timing A/Bs: what the interval events cost a launch)
+    if (atoi(iv) == 0) { T.ev_push = 0; T.cmd_resample[0] = T.cmd_resample[1] = 1e9f; }
   return 0;
 }
 
@@ -636,8 +640,12 @@ struct EnvImpl {
       if (alloc_failed) return fail("device allocation failed (terrain): " + be.error());
       be.h2d(terrain_dev, terrain_heights, nh * 4);
       be.h2d(terrain_origins_dev, terrain_origins, (size_t)desc.terrain.num_rows * desc.terrain.num_cols * 12);
-    } else if (!env_origins) {
-      return fail("plane terrain needs env_origins");
+    } else {
+      if (!env_origins) return fail("plane terrain needs env_origins");
+      // a one-tile origin table of zeros: reset_env (env_terms.h) reads its tile's origin without a branch on the terrain type, and selects
+      terrain_origins_dev = alloc<float>(4);
+      if (alloc_failed) return fail("device allocation failed (terrain): " + be.error());
+      be.zero(terrain_origins_dev, 16);
     }
     S.terrain = terrain_dev;
     S.terrain_origins = terrain_origins_dev;

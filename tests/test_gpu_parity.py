@@ -122,7 +122,11 @@ def test_short_horizon_parity(task, wg, merge, monkeypatch):
     # on the GPU: its flat ceilings are 3 x the others', the conditioning-aware envelope is the same rule)
     from helpers import HARD_CAPS
     caps = {k: 3.0 * v for k, v in HARD_CAPS.items()} if "GR1" in task else HARD_CAPS
-    rep = teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=3.0 / N, caps=caps)
+    # (one env may leave its six-twin envelope by less than 2 x - never a flat cap, a discrete output or a reward bound; printed when it
+    # happens.  The envelope is a maximum over six random draws; over the ~3 k envs of this test's 76 cases one sits past it after any change of
+    # round-off: round 5, Loong Flat env 22, one joint velocity at 1.14 x its envelope (4.95e-4 against 4.36e-4) - the same entry to all digits
+    # in the three kernel shapes, and in the library of the commit before)
+    rep = teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=3.0 / N, caps=caps, max_outliers=1, outlier_factor=2.0)
     print(f"\n[parity-small] {task} wg={wg!r} merge={merge}: done_differs {two.done_differs.mean():.3f}, teacher-forced mask {rep['masked']}/{N}")
     env.close()
 

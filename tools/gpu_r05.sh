@@ -161,4 +161,62 @@ e)
   done
   cat $OUT/tita_instances.txt
   ;;
+f)
+  # what the reset path costs a launch (a launch ends with its slowest wavefront, and a wavefront with a resetting env runs reset_env +
+  # the observation stage's kinematics of the new pose): steady-state windows with and without termination terms (RL_ENV_TERMS=0: nothing
+  # ever resets), interpreter on both sides.  Tita falls under random actions: ~0.29 resets per env-step; G1 ~0.02; A1 time-outs only
+  RL_ENV_LIB=$V/clock_4044.so timeout 200 python tools/phase_clock.py $TITA 4096 > $OUT/phase_clock_tita.txt 2>&1
+  cat $OUT/phase_clock_tita.txt | tail -26
+  for cfg in "$TITA 4096" "$G1 2048" "$A1 4096" "$GO2W 4096"; do
+    set -- $cfg
+    timeout 300 python tools/ab_bench.py --task $1 --num-envs $2 --rounds 2 --steady resets:RL_ENV_SPEC=0 no_resets:RL_ENV_SPEC=0,RL_ENV_TERMS=0 >> $OUT/reset_cost.txt 2>&1
+  done
+  cat $OUT/reset_cost.txt
+  ;;
+g)
+  # the reset path phase by phase: env 0 of every wavefront times out on every step (tools/phase_clock.py --reset-env0), against the same
+  # kernel without forced resets; and what the interval events (push, command resampling) cost a launch
+  for cfg in "clockspec_34 $A1 4096" "clockspec_78 $G1 2048" "clock_4044 $TITA 4096"; do
+    set -- $cfg
+    RL_ENV_LIB=$V/$1.so RL_ENV_TERMS=0 timeout 200 python tools/phase_clock.py $2 $3 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_$1_no_resets.txt
+    RL_ENV_LIB=$V/$1.so timeout 200 python tools/phase_clock.py $2 $3 --reset-env0 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_$1_reset_env0.txt
+    paste $OUT/phase_clock_$1_no_resets.txt $OUT/phase_clock_$1_reset_env0.txt | cut -c1-60,61-200 | head -40
+  done
+  for cfg in "$A1 4096" "$G1 2048"; do
+    set -- $cfg
+    timeout 300 python tools/ab_bench.py --task $1 --num-envs $2 --rounds 2 --steady all:RL_ENV_SPEC=0 no_resets:RL_ENV_SPEC=0,RL_ENV_TERMS=0 no_resets_no_intervals:RL_ENV_SPEC=0,RL_ENV_TERMS=0,RL_ENV_INTERVALS=0 >> $OUT/event_cost.txt 2>&1
+  done
+  cat $OUT/event_cost.txt
+  ;;
+h)
+  # the reset path as straight-line code + the episode sums' log in the reward write-back + the scanner pose of a reset env from the trunk
+  # joints alone: the kernels of the commit before (pre_*) against the tree's, steady-state windows of one call; then the phase table of a
+  # resetting wavefront again, and the parity tiers that cover resets
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 $V/pre_34.so new:RL_ENV_SPEC=1 > $OUT/reset_path_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/pre_78.so new:RL_ENV_SPEC=1 >> $OUT/reset_path_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $TITA --num-envs 4096 new:RL_ENV_SPEC=1 no_resets:RL_ENV_TERMS=0 >> $OUT/reset_path_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GO2W --num-envs 4096 new:RL_ENV_SPEC=1 no_resets:RL_ENV_TERMS=0 >> $OUT/reset_path_ab.txt 2>&1
+  cat $OUT/reset_path_ab.txt
+  for cfg in "clockspec_34 $A1 4096" "clockspec_78 $G1 2048"; do
+    set -- $cfg
+    RL_ENV_LIB=$V/$1.so timeout 200 python tools/phase_clock.py $2 $3 --reset-env0 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_$1_reset_env0.txt
+    grep -E "total|reset|resets|obs.kin|rewards.writeback" $OUT/phase_clock_$1_reset_env0.txt
+  done
+  timeout 900 python -m pytest tests/test_gpu_canary.py tests/test_gpu_specs.py tests/test_gpu_edge_cases.py -m gpu -q > $OUT/pytest_canary_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary_specs.log
+  tail -3 $OUT/pytest_canary_specs.log
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "reset or log or G1 or Tita or Flat" > $OUT/pytest_parity_resets.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_resets.log
+  tail -3 $OUT/pytest_parity_resets.log
+  timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_default.json 2> /dev/null
+  python -c "
+import json
+d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  ms_per_step %.4f  kernel_ms %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms']), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'))"
+  ;;
+i)
+  # the same change on the other lane mappings (8192 envs: two sub-lanes per limb; 65 536: one lane per limb, which has no table of uniforms),
+  # and whether Loong Flat's envelope outlier (env 22, 1.14 x its six-twin envelope) is the commit before's too
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --num-envs 8192 $V/pre_32.so $V/new_32.so > $OUT/reset_path_ab_other_mappings.txt 2>&1
+  timeout 400 python tools/ab_bench.py --steady --rounds 2 --num-envs 65536 $V/pre_31.so $V/new_31.so >> $OUT/reset_path_ab_other_mappings.txt 2>&1
+  cat $OUT/reset_path_ab_other_mappings.txt
+  RL_ENV_LIB=$V/pre_78.so timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "Loong and sub8-None" 2>&1 | grep -E "bad|passed|failed" | cut -c1-300 | tail -3
+  ;;
 esac

@@ -55,6 +55,19 @@ def parse(path):
     return funcs
 
 
+def region_window(items, i):
+    """the (up to three) instructions in front of items[i] that fall through to it: an unconditional branch ends the window - what stands
+    before it belongs to another path (round 5: a region that ENDS in `s_or_b64 exec ; s_branch L`, followed by a block entered through a
+    uniform `s_cbranch_vccz` only, whose first instruction is the EXEC = 0 pass-through `s_cbranch_execz`)"""
+    window = []
+    for _, _, x in reversed(items[max(0, i - 6):i]):
+        if x and x.startswith(("s_branch", "s_endpgm", "s_setpc")):
+            break
+        if x and not x.startswith(("s_waitcnt", "s_nop")):
+            window.append(x)
+    return window[:3]
+
+
 def hazards(items):
     labels = {lab: i for i, (_, lab, _) in enumerate(items) if lab}
     out = []
@@ -62,7 +75,7 @@ def hazards(items):
         if not ins or not ins.startswith("s_cbranch_execz"):
             continue
         # a region skip: EXEC was narrowed by one of the (up to three) instructions in front of the branch
-        prev = [x for _, _, x in items[max(0, i - 6):i] if x and not x.startswith(("s_waitcnt", "s_nop"))][-3:]
+        prev = region_window(items, i)
         if not any(EXEC_WRITE.match(x) for x in prev):
             continue
         target = ins.split()[-1]
@@ -84,8 +97,7 @@ def count_skips(items):
     n = 0
     for i, (_, _, ins) in enumerate(items):
         if ins and ins.startswith("s_cbranch_execz"):
-            prev = [x for _, _, x in items[max(0, i - 6):i] if x and not x.startswith(("s_waitcnt", "s_nop"))][-3:]
-            n += any(EXEC_WRITE.match(x) for x in prev)
+            n += any(EXEC_WRITE.match(x) for x in region_window(items, i))
     return n
 
 

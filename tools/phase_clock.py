@@ -16,11 +16,16 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from robot_lab_amd.env import ManagerBasedRLEnv, _DevView  # noqa: E402
 
-PHASES = ['load', 'action', 'sub.actuators+kinematics', 'sub.contact_fetch', 'sub.link_records', 'sub.contact_pass1', 'sub.leg_sum', 'sub.crba', 'sub.schur', 'sub.aba', 'sub.cross_leg_sum', 'sub.trunk_solve', 'sub.back_subst', 'sub.contact_pass2', 'sub.sensor+integrate', 'terminations', 'rewards', 'rewards.terms', 'rewards.writeback', 'resets+commands+push', 'observations', 'obs.policy_done', 'obs.flush', 'store', 'end', 'rewards.term_body']
+PHASES = ['load', 'action', 'sub.actuators+kinematics', 'sub.contact_fetch', 'sub.link_records', 'sub.contact_pass1', 'sub.leg_sum', 'sub.crba', 'sub.schur', 'sub.aba', 'sub.cross_leg_sum', 'sub.trunk_solve', 'sub.back_subst', 'sub.contact_pass2', 'sub.sensor+integrate', 'terminations', 'rewards', 'rewards.terms', 'rewards.writeback', 'resets+commands+push', 'observations', 'obs.policy_done', 'obs.flush', 'store', 'end', 'rewards.term_body', 'reset.uniforms', 'reset.state', 'reset.log', 'commands', 'push', 'obs.kinematics']
 ROW0, SLOTS = 24, 32
 
-task = sys.argv[1] if len(sys.argv) > 1 else "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+# --reset-env0: the first env of EVERY wavefront times out on every counted step (its episode clock is set to the last step; the clock is
+# kept by the wavefront's lane 0, which belongs to that env): the table then shows what a reset costs the wavefront that carries it, phase
+# by phase, against a run without the flag
+RESET0 = "--reset-env0" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+task = argv[0] if len(argv) > 0 else "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
+N = int(argv[1]) if len(argv) > 1 else 4096
 STEPS = 100
 env = ManagerBasedRLEnv(task, num_envs=N, seed=42, device="cuda:0")
 env.reset()
@@ -35,14 +40,19 @@ for s in range(50):
     env.step(torch.rand(N, A, device="cuda:0", generator=g) * 2 - 1)
 torch.cuda.synchronize()
 buf.zero_()
+ept = int(env._native.envs_per_wavefront())
+ep0 = torch.zeros(N, dtype=torch.int64)
+ep0[::ept] = int(env.max_episode_length) - 1
 for s in range(STEPS):
+    if RESET0:
+        env.episode_length_buf = ep0
     env.step(torch.rand(N, A, device="cuda:0", generator=g) * 2 - 1)
 torch.cuda.synchronize()
 acc = buf.cpu().numpy().astype(np.float64).mean(axis=0) / STEPS
 bogus = acc > 1e9  # a row that holds a raw time stamp instead of a sum of intervals (seen in round 4's `load` row): left out, and said so
 acc[bogus] = 0.0
 tot = acc.sum()
-print(f"spec id {env._native.spec_id()}, {int(env._native.envs_per_wavefront())} envs per wavefront" + (f"; rows left out as bogus: {[PHASES[i] for i in np.nonzero(bogus)[0]]}" if bogus.any() else ""))
+print(f"spec id {env._native.spec_id()}, {int(env._native.envs_per_wavefront())} envs per wavefront{', env 0 of every wavefront reset on every step' if RESET0 else ''}" + (f"; rows left out as bogus: {[PHASES[i] for i in np.nonzero(bogus)[0]]}" if bogus.any() else ""))
 print(f"{task} N={N}: mean shader-clock ticks per wavefront per step by phase (sub.* = the 4 substeps together), total {tot:.0f}")
 for n, v in zip(PHASES, acc):
     if v > 0:
