@@ -415,32 +415,33 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     return uniform_range(S.seed, (uint32_t)e, S.step_counter, stream, idx, lo, hi);
   }
 
-  // UniformVelocityCommand._resample_command [UPSTREAM B7] + threshold (VEL/mdp/commands.py:43-47)
-  // TABLE: the draws are a reset's - words of `RT`, the env's table of this step's STREAM_RESET uniforms (reset_uniforms)
-  template <bool TABLE = false>
-  RL_FN void resample_command(uint32_t stream, uint32_t idx, const float* RT = nullptr) {
+  // UniformVelocityCommand._resample_command [UPSTREAM B7] + threshold (VEL/mdp/commands.py:43-47), from its six uniforms (indices idx .. idx + 5
+  // of the stream)
+  RL_FN void apply_command_draws(const float (&uw)[6]) {
     // ranges: the table's, or the live ones of the command_levels_* curricula (VEL/mdp/curriculums.py:21-94) - read under ONE branch, so
-    // that without the curricula (every shipped cfg) the six table words and the six draws are straight-line code
+    // that without the curricula (every shipped cfg) the table words and the draws are straight-line code
     float rx0 = T.cmd_range[0][0], rx1 = T.cmd_range[0][1], ry0 = T.cmd_range[1][0], ry1 = T.cmd_range[1][1], rz0 = T.cmd_range[2][0], rz1 = T.cmd_range[2][1];
+    float rh0 = T.cmd_range[3][0], rh1 = T.cmd_range[3][1], rel_h = T.cmd_rel_heading, rel_s = T.cmd_rel_standing, small = T.cmd_small_threshold;
+    int use_heading = T.cmd_heading;
+    rl_pin(rx0); rl_pin(rx1); rl_pin(ry0); rl_pin(ry1); rl_pin(rz0); rl_pin(rz1); rl_pin(rh0); rl_pin(rh1); rl_pin(rel_h); rl_pin(rel_s); rl_pin(small); rl_pin(use_heading);
     if (T.cur_lin != 0 || T.cur_ang != 0) {
       const float* lv = S.cmd_levels;
       if (T.cur_lin) { rx0 = lv[CL_LIN_X]; rx1 = lv[CL_LIN_X + 1]; ry0 = lv[CL_LIN_Y]; ry1 = lv[CL_LIN_Y + 1]; }
       if (T.cur_ang) { rz0 = lv[CL_ANG_Z]; rz1 = lv[CL_ANG_Z + 1]; }
     }
-    auto UU = [&](uint32_t i, float lo, float hi) __attribute__((always_inline)) {
-      if constexpr (TABLE) return lerp_draw(lo, hi, RT[i]);
-      else return U(stream, i, lo, hi);
-    };
-    float vx = UU(idx + 0, rx0, rx1);
-    float vy = UU(idx + 1, ry0, ry1);
-    float wz = UU(idx + 2, rz0, rz1);
-    float hd = UU(idx + 3, T.cmd_range[3][0], T.cmd_range[3][1]);
-    bool ih = UU(idx + 4, 0.f, 1.f) <= T.cmd_rel_heading;
-    bool is = UU(idx + 5, 0.f, 1.f) <= T.cmd_rel_standing;
-    float keep = fsqrt(vx * vx + vy * vy) > T.cmd_small_threshold ? 1.f : 0.f;
+    const float vx = lerp_draw(rx0, rx1, uw[0]), vy = lerp_draw(ry0, ry1, uw[1]), wz = lerp_draw(rz0, rz1, uw[2]), hd = lerp_draw(rh0, rh1, uw[3]);
+    const bool ih = lerp_draw(0.f, 1.f, uw[4]) <= rel_h, is = lerp_draw(0.f, 1.f, uw[5]) <= rel_s;
+    const float keep = fsqrt(vx * vx + vy * vy) > small ? 1.f : 0.f;
     cmd = {vx * keep, vy * keep, wz};
-    if (T.cmd_heading) { heading_target = hd; is_heading = ih; }
+    heading_target = select1(use_heading != 0, hd, heading_target);
+    is_heading = (use_heading != 0 && ih) || (use_heading == 0 && is_heading);
     is_standing = is;
+  }
+  RL_FN void resample_command(uint32_t stream, uint32_t idx) {
+    float uw[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) uw[i] = uniform01(S.seed, (uint32_t)e, S.step_counter, stream, idx + (uint32_t)i);
+    apply_command_draws(uw);
   }
 
   // ---------------------------------------------------------------- reset of one env (all its lanes) [UPSTREAM B1]
@@ -481,41 +482,64 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
   }
 
-  // With the table of uniforms (every mapping but one lane per limb) the body below is STRAIGHT-LINE code: event flags and single-point
-  // ranges select results instead of guarding loads.  Written with a branch per event and per draw (`hi > lo ? table word : lo`) the
-  // compiler put every LDS read - a range, then the word - into a block of its own, behind the read it depended on: 93 reads, 77 waits,
-  // one after the other in a lone wavefront (A1: 7.5 k ticks of the resetting wavefront = 4 us, G1: 12.8 k = 6.8 us,
-  // profiles/r05g_phase_clock_*_reset_env0.txt) - and a launch ends with its slowest wavefront, which in steady state is one that resets
-  // an env.  Same draws, same arithmetic.  `sums_folded`: the reward stage has logged and zeroed the episode sums already (compute_rewards).
+  // With the table of uniforms (every mapping but one lane per limb) a reset is ONE batch of LDS reads - the table words, the event ranges and
+  // the lane's joint constants, pinned in registers (rl_pin) - followed by arithmetic in which event flags and single-point ranges select
+  // results.  Written with a branch per event and a read per draw, every read sat in a block of its own behind the read its condition came
+  // from (the compiler sinks a load into the branch that uses it): 93 reads, 77 waits, one after the other in a lone wavefront - A1: 7.5 k
+  // ticks of the resetting wavefront = 4 us, G1: 12.8 k = 6.8 us (profiles/r05g_phase_clock_*_reset_env0.txt) - and a launch ends with its
+  // slowest wavefront, which in steady state is one that resets an env.  Same draws, same arithmetic.
+  // `sums_folded`: the reward stage has logged and zeroed the episode sums already (compute_rewards).
   RL_FN void reset_env(bool log_episode, bool sums_folded = false) {
     RL_PHASE(26, "reset.uniforms");
     const float* RT = reset_uniforms();
     RL_PHASE(27, "reset.state");
-    constexpr bool TAB = SUB > 1;  // draws are table words (reset_uniforms); else a Philox block per draw, worth a branch
-    auto UR = [&](uint32_t idx, float lo, float hi) __attribute__((always_inline)) {
-      if constexpr (TAB) {
-        // (hi > lo: a single-point range is `lo` - reset_uniforms does not fill the blocks of such streams; the word is read all the same)
-        const float uw = RT[idx];
-        return hi > lo ? lerp_draw(lo, hi, uw) : lo;
-      } else {
-        return U(STREAM_RESET, idx, lo, hi);
-      }
+    constexpr bool TAB = SUB > 1;  // the draws are table words; else (one lane per limb) a Philox block per draw, each worth its branch
+    // ---- the batch.  Uniforms: indices IDX_WRENCH .. + 5 and IDX_POSE .. IDX_LEVEL (contiguous), then four per joint
+    constexpr int NHI = (int)IDX_LEVEL - (int)IDX_POSE + 1;
+    float w_lo[6] = {}, w_hi[NHI] = {};
+    int jid[JX];
+#pragma unroll
+    for (int j = 0; j < JX; ++j) jid[j] = (TP::PAD && L.joint_id[j] < 0) ? 0 : L.joint_id[j];  // padding joints: q0 = qd0 = kp0 = kd0 = 0
+    if constexpr (TAB) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) w_lo[i] = RT[IDX_WRENCH + i];
+#pragma unroll
+      for (int i = 0; i < NHI; ++i) w_hi[i] = RT[IDX_POSE + i];
+    }
+    // the event ranges
+    float rng_w[4] = {T.wrench_force[0], T.wrench_force[1], T.wrench_torque[0], T.wrench_torque[1]};
+    float rng_j[8] = {T.reset_jpos[0], T.reset_jpos[1], T.reset_jvel[0], T.reset_jvel[1], T.gain_kp[0], T.gain_kp[1], T.gain_kd[0], T.gain_kd[1]};
+    float rng_t[4] = {T.cmd_resample[0], T.cmd_resample[1], T.push_interval[0], T.push_interval[1]};
+    float tile_half = T.tile_size * 0.5f, ep_half = T.max_episode_length_s * 0.5f;
+    int n_rows = T.num_rows, n_cols = T.num_cols;
+    int flags = (T.ev_wrench ? 1 : 0) | (T.ev_reset_joints ? 2 : 0) | (T.ev_gains ? 4 : 0) | (T.ev_reset_base ? 8 : 0) | (T.ev_push ? 16 : 0) | ((T.curriculum && !T.is_plane) ? 32 : 0);
+    if constexpr (TAB) {
+      rl_pin(w_lo); rl_pin(w_hi);
+      rl_pin(rng_w); rl_pin(rng_j); rl_pin(rng_t);
+      rl_pin(tile_half); rl_pin(ep_half); rl_pin(n_rows); rl_pin(n_cols); rl_pin(flags);
+    }
+    const bool ev_wrench = flags & 1, ev_joints = flags & 2, ev_gains = flags & 4, ev_base = flags & 8, ev_push = flags & 16, cur = flags & 32;
+    // a draw from its table word (TAB) / its index (else).  (hi > lo: a single-point range is `lo` - reset_uniforms does not fill the blocks
+    // of such streams, whatever the word holds)
+    auto UR = [&](uint32_t idx, float word, float lo, float hi) __attribute__((always_inline)) {
+      if constexpr (TAB) return hi > lo ? lerp_draw(lo, hi, word) : lo;
+      else return U(STREAM_RESET, idx, lo, hi);
     };
-    // curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671).  The origin of the new tile is the one HBM read
+    auto HI = [&](uint32_t idx) __attribute__((always_inline)) { return TAB ? w_hi[idx - IDX_POSE] : 0.f; };
+    // ---- curriculum: terrain_levels_vel [UPSTREAM isaaclab_tasks] (velocity_env_cfg.py:671).  The origin of the new tile is the one HBM read
     // of a reset: issued first, consumed last (the root position below)
-    const bool cur = T.curriculum && !T.is_plane;
     V3 origin_new = origin;
     if (TAB || cur) {
       float dx = pos.x - origin.x, dy = pos.y - origin.y;
       float dist = fsqrt(dx * dx + dy * dy);
-      bool up = dist > T.tile_size * 0.5f;
-      bool down = (dist < fsqrt(cmd.x * cmd.x + cmd.y * cmd.y) * T.max_episode_length_s * 0.5f) && !up;
+      bool up = dist > tile_half;
+      bool down = (dist < fsqrt(cmd.x * cmd.x + cmd.y * cmd.y) * ep_half) && !up;
       int lv = level + (up ? 1 : 0) - (down ? 1 : 0);
-      int rnd = (int)fminf(floorf(UR(IDX_LEVEL, 0.f, 1.f) * (float)T.num_rows), (float)(T.num_rows - 1));
-      const int lv_new = lv >= T.num_rows ? rnd : (lv < 0 ? 0 : lv);
+      int rnd = (int)fminf(floorf(UR(IDX_LEVEL, HI(IDX_LEVEL), 0.f, 1.f) * (float)n_rows), (float)(n_rows - 1));
+      const int lv_new = lv >= n_rows ? rnd : (lv < 0 ? 0 : lv);
       level = cur ? lv_new : level + 0;
       // (a plane has a one-tile origin table of zeros: rl_env_host.h create)
-      const float* o = S.terrain_origins + (cur ? ((size_t)level * T.num_cols + ttype) * 3 : (size_t)0);
+      const float* o = S.terrain_origins + (cur ? ((size_t)level * n_cols + ttype) * 3 : (size_t)0);
       const V3 ot{o[0], o[1], o[2]};
       origin_new = select3(cur, ot, origin);  // (a plane, or no curriculum: the env keeps its origin)
     }
@@ -531,58 +555,85 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     extF = {0.f, 0.f, 0.f};
     extT = {0.f, 0.f, 0.f};
     // reset events in declaration order (velocity_env_cfg.py:316-363)
-    const bool ev_wrench = T.ev_wrench != 0, ev_joints = T.ev_reset_joints != 0, ev_gains = T.ev_gains != 0, ev_base = T.ev_reset_base != 0;
     if (TAB || ev_wrench) {
-      const float f0 = T.wrench_force[0], f1 = T.wrench_force[1], t0 = T.wrench_torque[0], t1 = T.wrench_torque[1];
-      const V3 wf{UR(IDX_WRENCH + 0, f0, f1), UR(IDX_WRENCH + 1, f0, f1), UR(IDX_WRENCH + 2, f0, f1)};
-      const V3 wt{UR(IDX_WRENCH + 3, t0, t1), UR(IDX_WRENCH + 4, t0, t1), UR(IDX_WRENCH + 5, t0, t1)};
+      const V3 wf{UR(IDX_WRENCH + 0, w_lo[0], rng_w[0], rng_w[1]), UR(IDX_WRENCH + 1, w_lo[1], rng_w[0], rng_w[1]), UR(IDX_WRENCH + 2, w_lo[2], rng_w[0], rng_w[1])};
+      const V3 wt{UR(IDX_WRENCH + 3, w_lo[3], rng_w[2], rng_w[3]), UR(IDX_WRENCH + 4, w_lo[4], rng_w[2], rng_w[3]), UR(IDX_WRENCH + 5, w_lo[5], rng_w[2], rng_w[3])};
       extF = select3(ev_wrench, wf, extF);
       extT = select3(ev_wrench, wt, extT);
     }
-    const float jp0 = T.reset_jpos[0], jp1 = T.reset_jpos[1], jv0 = T.reset_jvel[0], jv1 = T.reset_jvel[1];
-    const float gp0 = T.gain_kp[0], gp1 = T.gain_kp[1], gd0 = T.gain_kd[0], gd1 = T.gain_kd[1];
+    // the joints, five at a time: a batch of their table words and the lane's constants (eleven reads per joint), then the arithmetic (all
+    // thirteen joints of the six-joint-trunk instance at once were 140 live values more than its registers hold)
+    constexpr int JB = 5;
+    static_for<0, (JX + JB - 1) / JB>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int j0 = decltype(cc)::value * JB, NJ = JX - j0 < JB ? JX - j0 : JB;
+      float wj[4][NJ] = {}, jq0[NJ], jqd0[NJ], jlo[NJ], jhi[NJ], jvl[NJ], jkp0[NJ], jkd0[NJ];
 #pragma unroll
-    for (int j = 0; j < JX; ++j) {
-      uint32_t ji = (uint32_t)((TP::PAD && L.joint_id[j] < 0) ? 0 : L.joint_id[j]);  // padding joints: q0 = qd0 = kp0 = kd0 = 0
-      float qn = L.q0[j], qdn = L.qd0[j];
-      if (TAB || ev_joints) {  // reset_joints_by_scale [UPSTREAM B8]
-        const float qa = clampf(L.q0[j] * UR(IDX_JPOS + ji, jp0, jp1), L.soft_lo[j], L.soft_hi[j]);
-        const float qb = clampf(L.qd0[j] * UR(IDX_JVEL + ji, jv0, jv1), -L.vel_limit[j], L.vel_limit[j]);
-        qn = select1(ev_joints, qa, qn);
-        qdn = select1(ev_joints, qb, qdn);
+      for (int i = 0; i < NJ; ++i) {
+        const int j = j0 + i;
+        if constexpr (TAB) {
+          wj[0][i] = RT[IDX_JPOS + (uint32_t)jid[j]]; wj[1][i] = RT[IDX_JVEL + (uint32_t)jid[j]];
+          wj[2][i] = RT[IDX_KP + (uint32_t)jid[j]]; wj[3][i] = RT[IDX_KD + (uint32_t)jid[j]];
+        }
+        jq0[i] = this->L.q0[j]; jqd0[i] = this->L.qd0[j]; jlo[i] = this->L.soft_lo[j]; jhi[i] = this->L.soft_hi[j]; jvl[i] = this->L.vel_limit[j];
+        jkp0[i] = this->L.kp0[j]; jkd0[i] = this->L.kd0[j];
       }
-      q[j] = qn;
-      qd[j] = qdn;
-      if (TAB || ev_gains) {  // randomize_actuator_gains(operation="scale") [UPSTREAM B4]
-        const float ka = L.kp0[j] * UR(IDX_KP + ji, gp0, gp1), kb = L.kd0[j] * UR(IDX_KD + ji, gd0, gd1);
-        kp[j] = select1(ev_gains, ka, kp[j]);
-        kd[j] = select1(ev_gains, kb, kd[j]);
+      if constexpr (TAB) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) rl_pin(wj[s4]);
+        rl_pin(jq0); rl_pin(jqd0); rl_pin(jlo); rl_pin(jhi); rl_pin(jvl); rl_pin(jkp0); rl_pin(jkd0);
       }
-      act[j] = 0.f;
-      prev_act[j] = 0.f;
-      tau_app[j] = 0.f;
-      qacc[j] = 0.f;
-    }
-    {  // reset_root_state_uniform (VEL/mdp/events.py:205-271), non-pit branch
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) {
+        const int j = j0 + i;
+        const uint32_t ji = (uint32_t)jid[j];
+        float qn = jq0[i], qdn = jqd0[i];
+        if (TAB || ev_joints) {  // reset_joints_by_scale [UPSTREAM B8]
+          const float qa = clampf(jq0[i] * UR(IDX_JPOS + ji, wj[0][i], rng_j[0], rng_j[1]), jlo[i], jhi[i]);
+          const float qb = clampf(jqd0[i] * UR(IDX_JVEL + ji, wj[1][i], rng_j[2], rng_j[3]), -jvl[i], jvl[i]);
+          qn = select1(ev_joints, qa, qn);
+          qdn = select1(ev_joints, qb, qdn);
+        }
+        this->q[j] = qn;
+        this->qd[j] = qdn;
+        if (TAB || ev_gains) {  // randomize_actuator_gains(operation="scale") [UPSTREAM B4]
+          const float ka = jkp0[i] * UR(IDX_KP + ji, wj[2][i], rng_j[4], rng_j[5]), kb = jkd0[i] * UR(IDX_KD + ji, wj[3][i], rng_j[6], rng_j[7]);
+          this->kp[j] = select1(ev_gains, ka, this->kp[j]);
+          this->kd[j] = select1(ev_gains, kb, this->kd[j]);
+        }
+        this->act[j] = 0.f;
+        this->prev_act[j] = 0.f;
+        this->tau_app[j] = 0.f;
+        this->qacc[j] = 0.f;
+      }
+    });
+    {  // reset_root_state_uniform (VEL/mdp/events.py:205-271), non-pit branch.  Its ranges: a batch of their own
+      float rng_p[12], rng_v[12], root0[7];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { rng_p[2 * a] = T.reset_pose[a][0]; rng_p[2 * a + 1] = T.reset_pose[a][1]; rng_v[2 * a] = T.reset_vel[a][0]; rng_v[2 * a + 1] = T.reset_vel[a][1]; }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) root0[a] = T.default_root_pos[a];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) root0[3 + a] = T.default_root_quat[a];
+      if constexpr (TAB) { rl_pin(rng_p); rl_pin(rng_v); rl_pin(root0); }
       float ps[6], vs[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         ps[a] = vs[a] = 0.f;
         if (TAB || ev_base) {
-          const float pa = UR(IDX_POSE + a, T.reset_pose[a][0], T.reset_pose[a][1]), va = UR(IDX_VEL + a, T.reset_vel[a][0], T.reset_vel[a][1]);
+          const float pa = UR(IDX_POSE + a, HI(IDX_POSE + a), rng_p[2 * a], rng_p[2 * a + 1]), va = UR(IDX_VEL + a, HI(IDX_VEL + a), rng_v[2 * a], rng_v[2 * a + 1]);
           ps[a] = ev_base ? pa : 0.f;
           vs[a] = ev_base ? va : 0.f;
         }
       }
       origin = origin_new;
-      pos = V3{T.default_root_pos[0], T.default_root_pos[1], T.default_root_pos[2]} + origin + V3{ps[0], ps[1], ps[2]};
-      Q4 q0{T.default_root_quat[0], T.default_root_quat[1], T.default_root_quat[2], T.default_root_quat[3]};
+      pos = V3{root0[0], root0[1], root0[2]} + origin + V3{ps[0], ps[1], ps[2]};
+      Q4 q0{root0[3], root0[4], root0[5], root0[6]};
       quat = quat_mul(q0, quat_from_euler_xyz(ps[3], ps[4], ps[5]));
       vlin = {vs[0], vs[1], vs[2]};
       vang = {vs[3], vs[4], vs[5]};
     }
     // manager resets: episode-sum log + zero, command metrics log + resample, interval timer
-    // (command_levels_* curricula: the live ranges read by resample_command were decided between the two launches of this step,
+    // (command_levels_* curricula: the live ranges read by the command resampling were decided between the two launches of this step,
     // from the sums collect_cmd_levels gathered in the first one - step_head)
     if (!sums_folded) {
       RL_PHASE(28, "reset.log");
@@ -600,11 +651,18 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     }
     metric_xy = 0.f;
     metric_yaw = 0.f;
-    cmd_time_left = UR(IDX_CMD_TIME, T.cmd_resample[0], T.cmd_resample[1]);
-    resample_command<TAB>(STREAM_RESET, IDX_CMD, RT);
-    if (TAB || T.ev_push) {
-      const float pl = UR(IDX_PUSH_TIME, T.push_interval[0], T.push_interval[1]);
-      push_left = select1(T.ev_push != 0, pl, push_left);
+    cmd_time_left = UR(IDX_CMD_TIME, HI(IDX_CMD_TIME), rng_t[0], rng_t[1]);
+    if constexpr (TAB) {
+      float uw[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) uw[i] = HI(IDX_CMD + i);
+      apply_command_draws(uw);
+    } else {
+      resample_command(STREAM_RESET, IDX_CMD);
+    }
+    if (TAB || ev_push) {
+      const float pl = UR(IDX_PUSH_TIME, HI(IDX_PUSH_TIME), rng_t[2], rng_t[3]);
+      push_left = select1(ev_push, pl, push_left);
     }
     ep_len = 0;
   }

@@ -11,6 +11,22 @@
 
 namespace rl {
 
+// rl_pin(x): the value is in its register HERE (device: an empty asm that takes it as an operand; host: nothing).  For a batch of LDS / HBM
+// loads whose uses are conditional: without it the compiler sinks each load into the branch that uses it, behind the load the condition
+// came from - a chain of dependent round trips in a lone wavefront where one batch would do (env_terms.h reset_env).
+#if defined(__HIP_DEVICE_COMPILE__)
+RL_FN void rl_pin(float& x) { asm volatile("" : "+v"(x)); }
+RL_FN void rl_pin(int& x) { asm volatile("" : "+v"(x)); }
+#else
+RL_FN void rl_pin(float&) {}
+RL_FN void rl_pin(int&) {}
+#endif
+template <int N>
+RL_FN void rl_pin(float (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) rl_pin(a[i]);
+}
+
 // Fast reciprocal / square root: one hardware instruction (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32, 1 ulp)
 // on gfx950 instead of the IEEE division / sqrt expansion (~10 instructions each); exact on the host.
 // -DRL_EXACT_MATH (analysis builds, tools/build_variant.sh): the correctly rounded division / square root and libm's expf / sinf / cosf

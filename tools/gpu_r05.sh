@@ -219,4 +219,31 @@ i)
   cat $OUT/reset_path_ab_other_mappings.txt
   RL_ENV_LIB=$V/pre_78.so timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "Loong and sub8-None" 2>&1 | grep -E "bad|passed|failed" | cut -c1-300 | tail -3
   ;;
+j)
+  # what a reset still costs the wavefront that carries it, without contention: every 64th wavefront resets its env 0 on every step
+  for cfg in "clockspec_34 $A1 4096" "clockspec_78 $G1 2048"; do
+    set -- $cfg
+    RL_ENV_LIB=$V/$1.so timeout 200 python tools/phase_clock.py $2 $3 --reset-env0=64 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_$1_reset_every64.txt
+    cut -c1-150 $OUT/phase_clock_$1_reset_every64.txt
+  done
+  ;;
+k)
+  # the reset as ONE batch of pinned reads (rl_pin): the commit before the reset work (pre_*), steady state, one call; the uncontended phase
+  # table of a resetting wavefront; parity of what resets touch
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 $V/pre_34.so new:RL_ENV_SPEC=1 > $OUT/reset_batch_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/pre_78.so new:RL_ENV_SPEC=1 >> $OUT/reset_batch_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --num-envs 8192 $V/pre_32.so $V/new_32.so >> $OUT/reset_batch_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $G1 --num-envs 2048 new:RL_ENV_SPEC=1 no_resets:RL_ENV_SPEC=1,RL_ENV_TERMS=0 >> $OUT/reset_batch_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 new:RL_ENV_SPEC=1 no_resets:RL_ENV_SPEC=1,RL_ENV_TERMS=0 >> $OUT/reset_batch_ab.txt 2>&1
+  cat $OUT/reset_batch_ab.txt
+  for cfg in "clockspec_34 $A1 4096" "clockspec_78 $G1 2048"; do
+    set -- $cfg
+    RL_ENV_LIB=$V/$1.so timeout 200 python tools/phase_clock.py $2 $3 --reset-env0=64 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_$1_reset_every64.txt
+    grep -E "reset|total|writeback|obs.kin|terminations|observations" $OUT/phase_clock_$1_reset_every64.txt | cut -c1-150
+  done
+  timeout 900 python -m pytest tests/test_gpu_canary.py tests/test_gpu_specs.py tests/test_gpu_edge_cases.py -m gpu -q > $OUT/pytest_canary_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary_specs.log
+  tail -3 $OUT/pytest_canary_specs.log
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "reset or log or G1 or Tita or Flat" > $OUT/pytest_parity_resets.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_resets.log
+  tail -3 $OUT/pytest_parity_resets.log
+  ;;
 esac

@@ -22,7 +22,10 @@ ROW0, SLOTS = 24, 32
 # --reset-env0: the first env of EVERY wavefront times out on every counted step (its episode clock is set to the last step; the clock is
 # kept by the wavefront's lane 0, which belongs to that env): the table then shows what a reset costs the wavefront that carries it, phase
 # by phase, against a run without the flag
-RESET0 = "--reset-env0" in sys.argv
+RESET0 = any(a.startswith("--reset-env0") for a in sys.argv)
+# --reset-env0=K: only every K-th wavefront (few resets per step: no contention on the log's atomics, as in a steady-state launch); the table
+# then has a second column, the wavefronts that did not reset
+STRIDE = max([int(a.split("=")[1]) for a in sys.argv if a.startswith("--reset-env0=")] + [1])
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 task = argv[0] if len(argv) > 0 else "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
 N = int(argv[1]) if len(argv) > 1 else 4096
@@ -42,18 +45,22 @@ torch.cuda.synchronize()
 buf.zero_()
 ept = int(env._native.envs_per_wavefront())
 ep0 = torch.zeros(N, dtype=torch.int64)
-ep0[::ept] = int(env.max_episode_length) - 1
+ep0[::ept * STRIDE] = int(env.max_episode_length) - 1
 for s in range(STEPS):
     if RESET0:
         env.episode_length_buf = ep0
     env.step(torch.rand(N, A, device="cuda:0", generator=g) * 2 - 1)
 torch.cuda.synchronize()
-acc = buf.cpu().numpy().astype(np.float64).mean(axis=0) / STEPS
+rows = buf.cpu().numpy().astype(np.float64) / STEPS
+others = rows[np.arange(nwave) % STRIDE != 0].mean(axis=0) if RESET0 and STRIDE > 1 else None
+acc = rows[::STRIDE].mean(axis=0) if RESET0 else rows.mean(axis=0)
 bogus = acc > 1e9  # a row that holds a raw time stamp instead of a sum of intervals (seen in round 4's `load` row): left out, and said so
 acc[bogus] = 0.0
 tot = acc.sum()
 print(f"spec id {env._native.spec_id()}, {int(env._native.envs_per_wavefront())} envs per wavefront{', env 0 of every wavefront reset on every step' if RESET0 else ''}" + (f"; rows left out as bogus: {[PHASES[i] for i in np.nonzero(bogus)[0]]}" if bogus.any() else ""))
 print(f"{task} N={N}: mean shader-clock ticks per wavefront per step by phase (sub.* = the 4 substeps together), total {tot:.0f}")
-for n, v in zip(PHASES, acc):
+for i, (n, v) in enumerate(zip(PHASES, acc)):
     if v > 0:
-        print(f"  {n:28s} {v:10.0f}  {100 * v / tot:5.1f} %")
+        print(f"  {n:28s} {v:10.0f}  {100 * v / tot:5.1f} %" + (f"   | wavefronts without a reset {others[i]:10.0f}   difference {v - others[i]:+9.0f}" if others is not None else ""))
+if others is not None:
+    print(f"  {'total':28s} {tot:10.0f}            | {others[others < 1e9].sum():10.0f}   difference {tot - others[others < 1e9].sum():+9.0f}   (every {STRIDE}th wavefront resets its env 0)")
