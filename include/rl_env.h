@@ -286,10 +286,14 @@ enum rl_buffer {
   RL_BUF_COMMAND = 11,     /* float [N, 3] */
   RL_BUF_CONTACT_FORCE = 12, /* float [N, B, 3] net_forces_w of the last substep (inspection view: see rl_env_get_buffer) */
   RL_BUF_CONTACT_TIMERS = 13, /* float [N, B, 4] current_air, current_contact, last_air, last_contact */
-  RL_BUF_LOG = 14,         /* float [RL_LOG_RING][RL_LOG_SIZE] device-side episode log: step k accumulates into slot
-                              k % RL_LOG_RING, which step k - 1 zeroed (see rl_env_log_slot); step k + 1 then lets a slot whose
-                              reset count (entry 0) is 0 inherit slot k - 1, so every slot but the newest reads as "the log of
-                              the most recent step that reset an env"; for the newest, a reader does that select itself */
+  RL_BUF_LOG = 14,         /* float [RL_LOG_RING][RL_LOG_PARTS][RL_LOG_SIZE] device-side episode log: step k accumulates into slot
+                              k % RL_LOG_RING, which step k - 1 zeroed (see rl_env_log_slot).  A slot is RL_LOG_PARTS partial rows
+                              - a reader SUMS them (the wavefronts of a launch spread their atomic adds over the rows: adds on one
+                              address are serialised, and a launch in which a third of the envs reset would spend half its time
+                              there).  Step k + 1 then lets a slot whose step reset nobody inherit slot k - 1 row by row, so every
+                              slot but the newest reads as "the log of the most recent step that reset an env"; for the newest, a
+                              reader does that select itself: summed entry 0 (the reset count) > 0 ? slot k : slot k - 1.  Entry
+                              RL_LOG_SIZE - 1 counts the resets of the slot's own step (not inherited) */
   RL_BUF_ACTION = 15,      /* float [N, A] last (raw) action */
   RL_BUF_JOINT_TORQUE = 16,/* float [N, D] applied torque of the last substep */
   RL_BUF_JOINT_ACC = 17,   /* float [N, D] */
@@ -316,6 +320,7 @@ enum rl_task_state_field {
 };
 
 #define RL_LOG_SIZE 64
+#define RL_LOG_PARTS 32 /* partial rows of a ring slot, summed by the reader */
 #define RL_LOG_RING 64 /* a step's log stays readable until RL_LOG_RING - 2 further steps have been launched */
 
 typedef struct rl_env rl_env; /* opaque */

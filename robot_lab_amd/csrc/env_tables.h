@@ -53,8 +53,14 @@ constexpr int MAX_BASE_BODIES = 4;
 constexpr int ENVS_PER_WAVE = 16;
 constexpr int LOG_SIZE = 64;
 constexpr int LOG_RING = 64;  // step k logs into slot k % LOG_RING (one slot = one step's extras["log"]); power of two
+// A slot is LOG_PARTS partial rows of LOG_SIZE words, summed by the reader: wavefront w adds into row w % LOG_PARTS.  All adds of a launch on
+// ONE row are serialised at ~44 ns each on the same address - nothing when four envs of 4096 reset in a step, 49 of 106 us when a third of
+// them do (DDT Tita under random actions: 30 k adds on 26 addresses; every robot early in training) - profiles/r05m_tita_log_atomics.txt
+constexpr int LOG_PARTS = 32;
 // log accumulator slots (device LOG buffer)
-enum { LOG_RESET_COUNT = 0, LOG_TERM_TIMEOUT = 1, LOG_TERM_OOB = 2, LOG_TERM_ILLEGAL = 3, LOG_METRIC_XY = 4, LOG_METRIC_YAW = 5, LOG_EP_SUM0 = 8 };
+enum { LOG_RESET_COUNT = 0, LOG_TERM_TIMEOUT = 1, LOG_TERM_OOB = 2, LOG_TERM_ILLEGAL = 3, LOG_METRIC_XY = 4, LOG_METRIC_YAW = 5, LOG_EP_SUM0 = 8,
+       LOG_FRESH = 63 };  // LOG_FRESH: the resets of THIS very step (LOG_RESET_COUNT is inherited by a slot whose step reset nobody, this word is not)
+static_assert(LOG_EP_SUM0 + MAX_T <= LOG_FRESH && LOG_SIZE == 64 && (LOG_PARTS & (LOG_PARTS - 1)) == 0, "log row: one word per lane of a wavefront");
 
 using TopoMax = Topo<MAX_CL, MAX_NW, MAX_SPL, MAX_NBS>;  // shape of the host-side (unpacked) tables
 
@@ -404,7 +410,7 @@ struct KState {
   uint8_t *terminated, *time_out;  // [Npad]
   float* rew_terms;                // [MAX_T][Npad]
   float* command_out;              // [Npad][3]
-  float* log;                      // [LOG_RING][LOG_SIZE]
+  float* log;                      // [LOG_RING][LOG_PARTS][LOG_SIZE]
   // optional inspection buffers (nullptr = skip)
   float *dbg_torque, *dbg_acc;     // [Npad][D]
   float* dbg_cforce;               // [Npad][B][3]

@@ -358,6 +358,14 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   // command / bookkeeping registers (identical in all lanes of an env)
   V3 cmd;
   float heading_target, cmd_time_left, metric_xy, metric_yaw, push_left;
+  // The episode log's atomic adds of a done env go out at the very END of step() (flush_log), from registers: nothing waits for them there.
+  // Issued where the values arise (reward write-back, reset) they sit in front of the observation stage's loads in the wavefront's memory
+  // queue, and the wait for those loads is a wait for the adds - ~1.3 k ticks of a resetting wavefront when few envs reset, and the whole
+  // same-address queue when many do (DDT Tita under random actions: 0.29 resets per env-step, 30 k adds on 26 addresses per launch, 49 of
+  // its 106 us; profiles/r05f_reset_cost.txt).  One lane per limb keeps the immediate form (ten more live registers in a kernel that has none).
+  static constexpr bool DEFER_LOG = SUB > 1;
+  static constexpr int NACC_M = (MAX_T + LPE - 1) / LPE;
+  float log_sum[NACC_M], log_mxy, log_myaw;
   bool is_heading, is_standing;
   int level, ttype;
   V3 origin;
@@ -644,8 +652,12 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       }
       RL_PHASE(27, "reset.state");
     }
-    if (li == 0 && log_episode && e < S.N) {
+    if (DEFER_LOG && sums_folded) {  // (flush_log)
+      log_mxy = metric_xy;
+      log_myaw = metric_yaw;
+    } else if (li == 0 && log_episode && e < S.N) {
       ctx.atomic_add(log_slot() + LOG_RESET_COUNT, 1.0f);
+      ctx.atomic_add(log_slot() + LOG_FRESH, 1.0f);
       ctx.atomic_add(log_slot() + LOG_METRIC_XY, metric_xy);
       ctx.atomic_add(log_slot() + LOG_METRIC_YAW, metric_yaw);
     }
@@ -825,7 +837,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = v;
         const float ns = acc[i] + v;
         S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = fold_done ? 0.f : ns;
-        if (fold_done && e < S.N) ctx.atomic_add(log_slot() + LOG_EP_SUM0 + t, ns);
+        if constexpr (DEFER_LOG) log_sum[i] = ns;
+        else if (fold_done && e < S.N) ctx.atomic_add(log_slot() + LOG_EP_SUM0 + t, ns);
       }
     }
     ctx.group_sync();  // the tables share LDS with the observation rows written next
@@ -1052,7 +1065,8 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         S.rew_terms[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = mine;
         const float ns = acc[i] + mine;
         S.ep_sums[(uint32_t)t * (uint32_t)Np + (uint32_t)e] = fold_done ? 0.f : ns;
-        if (fold_done && e < S.N) cx.atomic_add(this->log_slot() + LOG_EP_SUM0 + t, ns);
+        if constexpr (DEFER_LOG) this->log_sum[i] = ns;
+        else if (fold_done && e < S.N) cx.atomic_add(this->log_slot() + LOG_EP_SUM0 + t, ns);
       }
     });
     return total;
@@ -1328,7 +1342,10 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 
   // episode log of THIS step: slot step_counter % LOG_RING.  Every step starts from a slot the previous step zeroed, so a
   // slot is what the reference rebuilds as extras["log"] on every call - no snapshot + memset between steps on the host
-  RL_FN float* log_slot() const { return S.log + (S.step_counter & (uint32_t)(LOG_RING - 1)) * LOG_SIZE; }
+  // (the wavefront's partial row of the slot: env_tables.h LOG_PARTS)
+  RL_FN float* log_slot() const {
+    return S.log + ((size_t)(S.step_counter & (uint32_t)(LOG_RING - 1)) * LOG_PARTS + (size_t)(ctx.tile() & (LOG_PARTS - 1))) * LOG_SIZE;
+  }
 
   // command_levels_lin_vel / _ang_vel (VEL/mdp/curriculums.py:21-94) decide on the mean episode sum of a driving reward term over
   // the envs that the deciding step (count % max_episode_length == 0) resets - a reduction over the whole launch that the reference
@@ -1387,25 +1404,35 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 
   template <bool HEAD>
   RL_FN void step_front() {
-    {  // episode-log ring upkeep by the lanes of env 0 (nobody else touches these two slots during this launch)
-      // (a) the previous step's slot is final now: if that step reset nobody, it inherits its predecessor, so that every
-      //     slot reads as "the log of the most recent step that reset an env" - what a caller of the reference sees, which
-      //     rebuilds extras["log"] only inside _reset_idx [UPSTREAM B1];  (b) clear the next step's slot.
-      float* pv = S.log + ((S.step_counter - 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SIZE;
-      const float* pp = S.log + ((S.step_counter - 2u) & (uint32_t)(LOG_RING - 1)) * LOG_SIZE;
-      const bool inherit = pv[LOG_RESET_COUNT] == 0.f;
-      ctx.group_sync();  // every lane has read the count before lane 0 overwrites it
-      if (e == 0) {
-        if (inherit)
-          for (int i = li; i < LOG_SIZE; i += LPE) pv[i] = pp[i];
-        float* nx = S.log + ((S.step_counter + 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SIZE;
-        for (int i = li; i < LOG_SIZE; i += LPE) nx[i] = 0.f;
-      }
+    // episode-log ring upkeep, by the first LOG_PARTS wavefronts of the launch: wavefront p keeps partial row p, lane l its word l
+    // (a) the previous step's slot is final now: if that step reset nobody, it inherits its predecessor, so that every
+    //     slot reads as "the log of the most recent step that reset an env" - what a caller of the reference sees, which
+    //     rebuilds extras["log"] only inside _reset_idx [UPSTREAM B1];  (b) clear the next step's slot.
+    // (whether the step reset anybody is the sum of its rows' LOG_FRESH words, which no copy touches: every wavefront reads the same
+    // answer whatever the others have written by then.)  Its reads go out HERE, in one batch with the state's; the writes follow the state loads.
+    constexpr size_t LOG_SLOT_WORDS = (size_t)LOG_PARTS * LOG_SIZE;
+    const int log_tl = ctx.tile(), log_wl = ctx.env_in_tile() * LPE + li;  // wavefront of the launch, lane of the wavefront
+    float* log_pv = S.log + (size_t)((S.step_counter - 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SLOT_WORDS;
+    const float* log_pp = S.log + (size_t)((S.step_counter - 2u) & (uint32_t)(LOG_RING - 1)) * LOG_SLOT_WORDS;
+    float log_fresh = 0.f, log_word = 0.f;
+    if (log_tl < LOG_PARTS) {
+      for (int p = 0; p < LOG_PARTS; ++p) log_fresh += log_pv[p * LOG_SIZE + LOG_FRESH];
+      log_word = log_pp[log_tl * LOG_SIZE + log_wl];
     }
     RL_PHASE_START();
     RL_PHASE(0, "load");
     this->load();
     load_task();  // same batch of HBM loads as the state: one round trip instead of a second one after the substeps
+    if (log_tl < LOG_PARTS) {
+      float* nx = S.log + (size_t)((S.step_counter + 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SLOT_WORDS;
+      const bool inherit = log_fresh == 0.f;
+      if (inherit && log_wl != LOG_FRESH) log_pv[log_tl * LOG_SIZE + log_wl] = log_word;
+      nx[log_tl * LOG_SIZE + log_wl] = 0.f;
+      for (int p = log_tl + S.Npad / (64 / LPE); p < LOG_PARTS; p += S.Npad / (64 / LPE)) {  // (a launch of fewer than LOG_PARTS wavefronts)
+        if (inherit && log_wl != LOG_FRESH) log_pv[p * LOG_SIZE + log_wl] = log_pp[p * LOG_SIZE + log_wl];
+        nx[p * LOG_SIZE + log_wl] = 0.f;
+      }
+    }
     RL_PHASE(1, "action");
     // 1 ActionManager.process_action [UPSTREAM B2]; JointPosition/VelocityAction (velocity_env_cfg.py:124-126)
     float q_tgt[JX], qd_tgt[JX];
@@ -1487,7 +1514,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   RL_FN void step_back(const bool terminated, const bool time_out, const bool t_timeout, const bool t_oob, const bool t_illegal, const bool sums_folded = false) {
     // 6 reset done envs
     if (terminated || time_out) {
-      if (li == 0 && e < S.N) {
+      if (!(DEFER_LOG && sums_folded) && li == 0 && e < S.N) {
         if (t_timeout) ctx.atomic_add(log_slot() + LOG_TERM_TIMEOUT, 1.f);
         if (t_oob) ctx.atomic_add(log_slot() + LOG_TERM_OOB, 1.f);
         if (t_illegal) ctx.atomic_add(log_slot() + LOG_TERM_ILLEGAL, 1.f);
@@ -1551,6 +1578,31 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #else
     observations(!TAIL && !ctx.any(terminated || time_out));  // (a tail launch starts without the chain words of the trunk + limbs instance)
 #endif
+#endif
+    // 10 the episode log of a done env (see DEFER_LOG)
+#ifndef RL_ABL_NO_LOG  // analysis builds: what the log's same-address atomic adds cost a launch in which many envs reset (wrong logs)
+    if constexpr (DEFER_LOG) {
+      if (sums_folded && e < S.N) {
+        float* slot = log_slot();
+        int n_rew;
+        if constexpr (SP::ON) n_rew = SP::N_REW;
+        else n_rew = T.n_rewards;
+#pragma unroll
+        for (int i = 0; i < NACC_M; ++i) {
+          const int t = li + LPE * i;
+          if (t < n_rew) ctx.atomic_add(slot + LOG_EP_SUM0 + t, log_sum[i]);
+        }
+        if (li == 0) {
+          ctx.atomic_add(slot + LOG_RESET_COUNT, 1.0f);
+          ctx.atomic_add(slot + LOG_FRESH, 1.0f);
+          ctx.atomic_add(slot + LOG_METRIC_XY, log_mxy);
+          ctx.atomic_add(slot + LOG_METRIC_YAW, log_myaw);
+          if (t_timeout) ctx.atomic_add(slot + LOG_TERM_TIMEOUT, 1.f);
+          if (t_oob) ctx.atomic_add(slot + LOG_TERM_OOB, 1.f);
+          if (t_illegal) ctx.atomic_add(slot + LOG_TERM_ILLEGAL, 1.f);
+        }
+      }
+    }
 #endif
     RL_PHASE(24, "end");
   }

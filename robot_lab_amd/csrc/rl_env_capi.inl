@@ -64,7 +64,7 @@ int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[
     case RL_BUF_COMMAND: return set(I.S.command_out, 2, N, 3, 1, 4);
     case RL_BUF_CONTACT_FORCE: return set(I.S.dbg_cforce, 3, N, B, 3, 4);
     case RL_BUF_CONTACT_TIMERS: return set(I.ctimers, 3, N, B, 4, 4);
-    case RL_BUF_LOG: return set(I.S.log, 2, RL_LOG_RING, RL_LOG_SIZE, 1, 4);
+    case RL_BUF_LOG: return set(I.S.log, 3, RL_LOG_RING, RL_LOG_PARTS, RL_LOG_SIZE, 4);
     case RL_BUF_ACTION: return set(I.action_aos, 2, N, D, 1, 4);
     case RL_BUF_JOINT_TORQUE: return set(I.S.dbg_torque, 2, N, D, 1, 4);
     case RL_BUF_JOINT_ACC: return set(I.S.dbg_acc, 2, N, D, 1, 4);
@@ -94,10 +94,18 @@ int rl_env_read_log(rl_env* env, float* out_host, void* stream) {
   Impl& I = *reinterpret_cast<Impl*>(env);
   if (I.be.activate()) return rl::fail("device activation failed: " + I.be.error());
   // the last step's slot, or - if that step reset nobody - its predecessor, which the kernel has resolved the same way
+  // (a slot is RL_LOG_PARTS partial rows: summed here)
+  static_assert(RL_LOG_PARTS == rl::LOG_PARTS && RL_LOG_SIZE == rl::LOG_SIZE && RL_LOG_RING == rl::LOG_RING, "include/rl_env.h and csrc/env_tables.h disagree");
+  std::vector<float> rows((size_t)RL_LOG_PARTS * RL_LOG_SIZE);
   float two[2][RL_LOG_SIZE];
   for (int i = 0; i < 2; ++i) {
-    float* slot = I.S.log + (size_t)((I.step_counter - (uint32_t)i) & (uint32_t)(RL_LOG_RING - 1)) * RL_LOG_SIZE;
-    if (I.be.d2h_sync(two[i], slot, RL_LOG_SIZE * sizeof(float), stream)) return rl::fail("log read failed: " + I.be.error());
+    float* slot = I.S.log + (size_t)((I.step_counter - (uint32_t)i) & (uint32_t)(RL_LOG_RING - 1)) * RL_LOG_PARTS * RL_LOG_SIZE;
+    if (I.be.d2h_sync(rows.data(), slot, rows.size() * sizeof(float), stream)) return rl::fail("log read failed: " + I.be.error());
+    for (int w = 0; w < RL_LOG_SIZE; ++w) {
+      float a = 0.f;
+      for (int p = 0; p < RL_LOG_PARTS; ++p) a += rows[(size_t)p * RL_LOG_SIZE + w];
+      two[i][w] = a;
+    }
   }
   memcpy(out_host, two[0][0] > 0.f ? two[0] : two[1], RL_LOG_SIZE * sizeof(float));
   return 0;

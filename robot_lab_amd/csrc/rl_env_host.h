@@ -622,7 +622,7 @@ struct EnvImpl {
     S.obs_policy = obs_ring[0][0];
     S.obs_critic = obs_ring[1][0];
     S.reward = alloc<float>(Np); S.terminated = alloc<uint8_t>(Np); S.time_out = alloc<uint8_t>(Np);
-    S.rew_terms = alloc<float>(MAX_T * Np); S.command_out = alloc<float>(3 * Np); S.log = alloc<float>(LOG_RING * LOG_SIZE);
+    S.rew_terms = alloc<float>(MAX_T * Np); S.command_out = alloc<float>(3 * Np); S.log = alloc<float>((size_t)LOG_RING * LOG_PARTS * LOG_SIZE);
     root_state = alloc<float>(Np * 13); joint_pos = alloc<float>(Np * D); joint_vel = alloc<float>(Np * D);
     ctimers = alloc<float>(Np * B * 4); action_aos = alloc<float>(Np * D); env_origin_aos = alloc<float>(Np * 3);
     task_state = alloc<float>(Np * TASK_NF); gains = alloc<float>(Np * 2 * D);

@@ -23,6 +23,7 @@ RL_MAX_OBS_TERMS = 12
 RL_TERM_NPARAM = 8
 RL_LOG_SIZE = 64
 RL_LOG_RING = 64
+RL_LOG_PARTS = 32  # partial rows of a ring slot (include/rl_env.h RL_BUF_LOG): a reader sums them
 
 REWARD_KINDS = [
     "track_lin_vel_xy_exp", "track_ang_vel_z_exp", "lin_vel_z_l2", "ang_vel_xy_l2", "joint_torques_l2",

@@ -161,7 +161,8 @@ def pack_episode_log(env) -> torch.Tensor:
     e = env.unwrapped if hasattr(env, "unwrapped") else env
     k = e._native.log_slot()
     log = e._bufs["LOG"]
-    vec = torch.where(log[k][0] > 0, log[k], log[(k - 1) % log.shape[0]]).clone()
+    cur, prev = log[k].sum(0), log[(k - 1) % log.shape[0]].sum(0)  # (a slot is RL_LOG_PARTS partial rows)
+    vec = torch.where(cur[0] > 0, cur, prev).clone()
     if e.desc.terrain.curriculum and not e.desc.terrain.is_plane:
         vec[LOG_SLOT_TERRAIN_SUM] = e.terrain_levels.float().sum()
     vec[LOG_SLOT_NUM_ENVS] = float(e.num_envs)

@@ -94,7 +94,9 @@ class _LazyLog(dict):
                                f"the device keeps the last {RL_LOG_RING - 3} steps")
         self._done = True
         # this step's slot if it reset an env, else its predecessor (which the kernel has already resolved the same way)
-        s = torch.where(self._slot[0] > 0, self._slot, self._prev)
+        # (a slot is RL_LOG_PARTS partial rows: include/rl_env.h RL_BUF_LOG)
+        cur, prev = self._slot.sum(0), self._prev.sum(0)
+        s = torch.where(cur[0] > 0, cur, prev)
         self._slot = self._prev = None
         cnt = torch.clamp(s[0], min=1.0)
         for i, name in enumerate(e.desc.reward_names):

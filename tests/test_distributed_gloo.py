@@ -36,7 +36,7 @@ def _shard(rank, emu_lib):
     for _ in range(STEPS):
         a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
         nat.step(a.ctypes.data)
-        log += host_view(nat, "LOG")[nat.log_slot()]  # this step's own accumulators (rl_env_read_log would repeat the last reset's)
+        log += host_view(nat, "LOG")[nat.log_slot()].sum(axis=0)  # this step's own accumulators, its partial rows summed (rl_env_read_log would repeat the last reset's)
         rew += float(host_view(nat, "REWARD").sum())
     nat.close()
     return log, rew

@@ -363,3 +363,45 @@ def test_tita_on_the_trunk_and_limbs_instance(emu_lib, monkeypatch):
     assert_close("qd", host_view(nat, "JOINT_VEL"), ora.st["qd"], 2e-3, 2e-3)
     assert_close("critic", host_view(nat, "OBS_CRITIC"), o[1], 2e-3, 2e-3)
     nat.close()
+
+
+def test_log_partial_rows_and_inheritance(emu_lib, monkeypatch):
+    """The episode log over SEVERAL wavefronts: a ring slot is RL_LOG_PARTS partial rows (wavefront w adds into row w % RL_LOG_PARTS, readers
+    sum - include/rl_env.h RL_BUF_LOG), kept by the first RL_LOG_PARTS wavefronts of the next launch: a step that reset nobody inherits its
+    predecessor row by row, a step that did starts from zeros.  16 envs per wavefront x 5 wavefronts, a third of the envs timing out in steps
+    1 and 3, nobody in steps 2, 4, 5."""
+    from robot_lab_amd.desc import RL_LOG_PARTS, RL_LOG_SIZE
+
+    task, N = TASKS[1], 80
+    desc, ora, nat = make_pair(task, N, 9, emu_lib)
+    ora.reset()
+    nat.reset()
+    ep = np.zeros(N, dtype=np.int64)
+    ep[::3] = ora.max_episode_length - 1
+    ep[1::3] = ora.max_episode_length - 3
+    ora.episode_length_buf[:] = ep
+    host_view(nat, "EPISODE_LENGTH")[:] = ep
+    rng = np.random.default_rng(1)
+    ring = host_view(nat, "LOG")
+    assert ring.shape[1:] == (RL_LOG_PARTS, RL_LOG_SIZE)
+    last = None
+    for s in range(5):
+        a = rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32)
+        ora.step(a)
+        nat.step(a.ctypes.data)
+        done = ora.terminated | ora.time_outs
+        slot = ring[nat.log_slot()]
+        assert slot[:, RL_LOG_SIZE - 1].sum() == done.sum()  # the slot's own resets, spread over the rows of the wavefronts that had one
+        log = nat.read_log()
+        if done.any():
+            assert s in (0, 2) and (slot[:5, 0] > 0).sum() >= 4 and not slot[5:].any()  # five wavefronts, five rows
+            assert log[0] == done.sum() and log[1] == ora.time_outs_terms[0].sum()
+            for i, name in enumerate(desc.reward_names):
+                np.testing.assert_allclose(log[8 + i] / log[0] / ora.max_episode_length_s, ora.log["Episode_Reward/" + name], rtol=2e-3, atol=1e-7)
+            last = log.copy()
+        else:
+            np.testing.assert_array_equal(log[:RL_LOG_SIZE - 1], last[:RL_LOG_SIZE - 1])  # the most recent step that reset an env
+        if s >= 1:  # the slot of the step before is final: it holds its own log, or its predecessor's - never zeros after the first reset
+            prev = ring[(nat.log_slot() - 1) % ring.shape[0]].sum(axis=0)
+            assert prev[0] > 0
+    nat.close()

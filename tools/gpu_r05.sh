@@ -246,4 +246,43 @@ k)
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "reset or log or G1 or Tita or Flat" > $OUT/pytest_parity_resets.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_resets.log
   tail -3 $OUT/pytest_parity_resets.log
   ;;
+l)
+  # the episode log's atomic adds deferred to the end of the step: A1 / G1 against the commit before the reset work, Tita against itself
+  # without resets; then the tiers that read the log
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 $V/pre_34.so new:RL_ENV_SPEC=1 no_resets:RL_ENV_SPEC=1,RL_ENV_TERMS=0 > $OUT/deferred_log_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/pre_78.so new:RL_ENV_SPEC=1 no_resets:RL_ENV_SPEC=1,RL_ENV_TERMS=0 >> $OUT/deferred_log_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $TITA --num-envs 4096 new:RL_ENV_SPEC=1 no_resets:RL_ENV_TERMS=0 >> $OUT/deferred_log_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GO2 --num-envs 4096 new:RL_ENV_SPEC=1 no_resets:RL_ENV_TERMS=0 >> $OUT/deferred_log_ab.txt 2>&1
+  cat $OUT/deferred_log_ab.txt
+  timeout 900 python -m pytest tests/test_gpu_canary.py tests/test_gpu_specs.py tests/test_gpu_edge_cases.py tests/test_gpu_dropin.py -m gpu -q > $OUT/pytest_canary_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary_specs.log
+  tail -3 $OUT/pytest_canary_specs.log
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "reset or log or G1-v0 or Tita or A1-v0" > $OUT/pytest_parity_resets.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_resets.log
+  tail -3 $OUT/pytest_parity_resets.log
+  ;;
+m)
+  # Tita under random actions (0.29 resets per env-step): the launch with the log's atomic adds, without them (-DRL_ABL_NO_LOG), without resets
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $TITA --num-envs 4096 $V/full_4044.so $V/nolog_4044.so no_resets:RL_ENV_TERMS=0@$V/full_4044.so > $OUT/tita_log_atomics.txt 2>&1
+  cat $OUT/tita_log_atomics.txt
+  ;;
+n)
+  # the log ring's slots as 32 partial rows (wavefront w adds into row w % 32, readers sum): Tita under random actions, and the headline kernels
+  # against the commit before the reset work; then every tier that reads a log
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $TITA --num-envs 4096 new:RL_ENV_SPEC=1 no_resets:RL_ENV_TERMS=0 > $OUT/log_rows_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 $V/pre_34.so new:RL_ENV_SPEC=1 no_resets:RL_ENV_SPEC=1,RL_ENV_TERMS=0 >> $OUT/log_rows_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/pre_78.so new:RL_ENV_SPEC=1 no_resets:RL_ENV_SPEC=1,RL_ENV_TERMS=0 >> $OUT/log_rows_ab.txt 2>&1
+  cat $OUT/log_rows_ab.txt
+  timeout 900 python -m pytest tests/test_gpu_canary.py tests/test_gpu_specs.py tests/test_gpu_edge_cases.py tests/test_gpu_dropin.py tests/test_gpu_multirank.py tests/test_gpu_collect.py -m gpu -q > $OUT/pytest_log_readers.log 2>&1; echo "rc=$?" >> $OUT/pytest_log_readers.log
+  tail -3 $OUT/pytest_log_readers.log
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "reset or log or Tita" > $OUT/pytest_parity_resets.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_resets.log
+  tail -3 $OUT/pytest_parity_resets.log
+  ;;
+o)
+  # the log upkeep's reads in one batch with the state loads
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 $V/pre_34.so new:RL_ENV_SPEC=1 no_resets:RL_ENV_SPEC=1,RL_ENV_TERMS=0 > $OUT/log_upkeep_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/pre_78.so new:RL_ENV_SPEC=1 no_resets:RL_ENV_SPEC=1,RL_ENV_TERMS=0 >> $OUT/log_upkeep_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $TITA --num-envs 4096 new:RL_ENV_SPEC=1 no_resets:RL_ENV_TERMS=0 >> $OUT/log_upkeep_ab.txt 2>&1
+  cat $OUT/log_upkeep_ab.txt
+  timeout 600 python -m pytest tests/test_gpu_edge_cases.py tests/test_gpu_dropin.py tests/test_gpu_canary.py -m gpu -q > $OUT/pytest_log_readers.log 2>&1; echo "rc=$?" >> $OUT/pytest_log_readers.log
+  tail -3 $OUT/pytest_log_readers.log
+  ;;
 esac
