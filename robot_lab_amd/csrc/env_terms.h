@@ -1198,6 +1198,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
   RL_FN void noise_pass(const GT& G, float* stage, uint32_t noise_base, int dim, int scan_off, int scan_n) {
     ctx.group_sync();
     const int nblk = (dim + 3) >> 2;
+    // (tried in round 5, one call: a lane's 3 - 4 blocks with their Philox rounds side by side - spelled out per round, results pinned so that
+    // the compiler neither re-serialises the chains nor sinks them into the column branches - is SLOWER: A1 36.32 -> 36.88 us, Go2W 43.39 ->
+    // 43.98; profiles/r05q_noise_interleave_ab.txt.  One block at a time it stays.)
 #pragma unroll 1
     for (int b = li; b < nblk; b += LPE) {
       float un[4];
@@ -1419,10 +1422,24 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       for (int p = 0; p < LOG_PARTS; ++p) log_fresh += log_pv[p * LOG_SIZE + LOG_FRESH];
       log_word = log_pp[log_tl * LOG_SIZE + log_wl];
     }
+    // the actions: their loads go out with the state's, unconditionally (a padding env reads env 0's row, a padding joint column 0; the
+    // values are selected below).  Under `e < N && joint_id >= 0 ? load : 0` each load sat in a branch of its own behind the LDS read of
+    // its joint id, and the clamp that follows waited for it: ten HBM round trips one after the other on the trunk + limbs instances
+    // (G1: 5.5 k ticks of the step, profiles/r05k_phase_clock_g1_reset_every64.txt)
+    float a_in[JX];
+    {
+      const float* arow = S.action_in + (size_t)(e < S.N ? e : 0) * T.D;
+#pragma unroll
+      for (int j = 0; j < JX; ++j) {
+        const int jid = L.joint_id[j];
+        a_in[j] = arow[TP::PAD && jid < 0 ? 0 : jid];
+      }
+    }
     RL_PHASE_START();
     RL_PHASE(0, "load");
     this->load();
     load_task();  // same batch of HBM loads as the state: one round trip instead of a second one after the substeps
+    rl_pin(a_in);
     if (log_tl < LOG_PARTS) {
       float* nx = S.log + (size_t)((S.step_counter + 1u) & (uint32_t)(LOG_RING - 1)) * LOG_SLOT_WORDS;
       const bool inherit = log_fresh == 0.f;
@@ -1439,7 +1456,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       prev_act[j] = act[j];
-      float a = (e < S.N && (!TP::PAD || L.joint_id[j] >= 0)) ? S.action_in[(size_t)e * T.D + L.joint_id[j]] : 0.f;
+      const float a = (e < S.N && (!TP::PAD || L.joint_id[j] >= 0)) ? a_in[j] : 0.f;
       act[j] = a;
       float pr = clampf(a * L.a_scale[j] + L.a_off[j], L.a_lo[j], L.a_hi[j]);
       q_tgt[j] = L.action_is_vel[j] ? 0.f : pr;
@@ -1472,10 +1489,18 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     const bool t_oob = out_of_bounds();
     bool t_illegal = false;
     if (T.term_illegal) {
+      // over the slots this lane keeps (own[]: all of them when a lane is a whole limb), every read issued whether or not the slot counts:
+      // `bit && owns && hist > thr` over all NBS slots was up to three dependent LDS round trips per slot, nine slots in a row
+      const uint64_t ill_mask = T.illegal_body_mask;
+      const float ill_thr = T.illegal_threshold;
       float c = 0.f;
 #pragma unroll
-      for (int s = 0; s < NBS; ++s)
-        if (body_bit(T.illegal_body_mask, s) && this->owns_slot(s) && hist_max(s) > T.illegal_threshold) c += 1.f;
+      for (int i = 0; i < Base::MAXOWN; ++i) {
+        const int so = this->own[i], s = so < 0 ? 0 : so;
+        const float h = hist_max(s);
+        const bool bit = body_bit(ill_mask, s);
+        c += (so >= 0 && bit && h > ill_thr) ? 1.f : 0.f;
+      }
       t_illegal = ctx.esum(c) > 0.f;
     }
     bool terminated = t_illegal, time_out = t_timeout || t_oob;

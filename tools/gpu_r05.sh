@@ -285,4 +285,26 @@ o)
   timeout 600 python -m pytest tests/test_gpu_edge_cases.py tests/test_gpu_dropin.py tests/test_gpu_canary.py -m gpu -q > $OUT/pytest_log_readers.log 2>&1; echo "rc=$?" >> $OUT/pytest_log_readers.log
   tail -3 $OUT/pytest_log_readers.log
   ;;
+p)
+  # the action loads in one batch with the state's, the illegal-contact test over the owned slots: against the commit before
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/prev_78.so new:RL_ENV_SPEC=1 > $OUT/action_batch_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 $V/prev_34.so new:RL_ENV_SPEC=1 >> $OUT/action_batch_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GR1 --num-envs 1024 prev:RL_ENV_SPEC=1@$V/prev_2078.so new:RL_ENV_SPEC=1 >> $OUT/action_batch_ab.txt 2>&1
+  cat $OUT/action_batch_ab.txt
+  timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "G1-v0 or GR1 or Xbot" > $OUT/pytest_parity.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity.log
+  tail -3 $OUT/pytest_parity.log
+  ;;
+q)
+  # the noise pass: a lane's Philox blocks with their rounds side by side.  prev_* = HEAD (before the action batch, the owned-slot illegal
+  # test and this)
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 $V/prev_34.so new:RL_ENV_SPEC=1 > $OUT/noise_interleave_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/prev_78.so new:RL_ENV_SPEC=1 >> $OUT/noise_interleave_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GO2W --num-envs 4096 prev:RL_ENV_SPEC=1@$V/prev_1044.so new:RL_ENV_SPEC=1 >> $OUT/noise_interleave_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --num-envs 65536 prev:RL_ENV_SPEC=1@$V/new_31.so new:RL_ENV_SPEC=1 >> $OUT/noise_interleave_ab.txt 2>&1
+  cat $OUT/noise_interleave_ab.txt
+  timeout 600 python -m pytest tests/test_gpu_canary.py tests/test_gpu_specs.py -m gpu -q > $OUT/pytest_canary_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary_specs.log
+  tail -3 $OUT/pytest_canary_specs.log
+  timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "A1-v0 or Go2W or G1-v0" > $OUT/pytest_parity.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity.log
+  tail -3 $OUT/pytest_parity.log
+  ;;
 esac
