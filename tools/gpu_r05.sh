@@ -307,4 +307,13 @@ q)
   timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "A1-v0 or Go2W or G1-v0" > $OUT/pytest_parity.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity.log
   tail -3 $OUT/pytest_parity.log
   ;;
+r)
+  # the whole GPU tier + smoke() on the tree after the reset / log work
+  timeout 1700 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -8 $OUT/pytest_gpu.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  mv gpurun_out/spec_vs_interpreter.jsonl gpurun_out/train_distributed_8ranks.json $OUT/ 2>/dev/null
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
+  grep -E "smoke|rc=|Error" $OUT/smoke.log | tail -12
+  ;;
 esac
