@@ -820,14 +820,22 @@ struct EnvLane {
   // returns explicit torque; fills tau_app (applied torque estimate) and the implicit-PD diagonal terms
   RL_FN void actuators(const float (&q_tgt)[JX], const float (&qd_tgt)[JX], float (&tau_e)[JX], float (&pd_diag)[JX], float (&pd_rhs)[JX]) {
     const float dt = u.dt;
+    // the joints' actuator constants: one batch of LDS reads, in registers before the first branch on them (rl_pin) - read joint by joint,
+    // each read sat behind the branch of the joint before it (ten joints on the trunk + limbs instances: twenty dependent round trips)
+    float a_eff[JX], a_sat[JX], a_vlim[JX], a_flags[JX];
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       const F4 c1 = ld4(L.jc[j] + 4), c2 = ld4(L.jc[j] + 8);  // [. . eff sat | act_vlim flags . .]
-      const int flags = (int)c2.y;
+      a_eff[j] = c1.z; a_sat[j] = c1.w; a_vlim[j] = c2.x; a_flags[j] = c2.y;
+    }
+    rl_pin(a_eff); rl_pin(a_sat); rl_pin(a_vlim); rl_pin(a_flags);
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      const int flags = (int)a_flags[j];
       float qt = (flags & 2) ? q[j] : q_tgt[j];
       float er = qt - q[j], ed = qd_tgt[j] - qd[j];
       float tc = kp[j] * er + kd[j] * ed;
-      float eff = c1.z;
+      float eff = a_eff[j];
       if (flags & 1) {
         float est = clampf(tc, -eff, eff);
         bool sat = fabsf(tc) > eff;
@@ -836,9 +844,9 @@ struct EnvLane {
         pd_diag[j] = sat ? 0.f : dt * (kd[j] + kp[j] * dt);
         pd_rhs[j] = sat ? 0.f : dt * (kp[j] * er + kd[j] * qd_tgt[j]);
       } else {  // DCMotor torque-speed clip (unitree.py:55-63)
-        float vr = qd[j] * frcp(c2.x);
-        float tmax = clampf(c1.w * (1.0f - vr), 0.f, eff);
-        float tmin = clampf(c1.w * (-1.0f - vr), -eff, 0.f);
+        float vr = qd[j] * frcp(a_vlim[j]);
+        float tmax = clampf(a_sat[j] * (1.0f - vr), 0.f, eff);
+        float tmin = clampf(a_sat[j] * (-1.0f - vr), -eff, 0.f);
         float t = clampf(tc, tmin, tmax);
         tau_app[j] = t;
         tau_e[j] = t;
