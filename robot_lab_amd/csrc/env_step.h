@@ -821,14 +821,16 @@ struct EnvLane {
   RL_FN void actuators(const float (&q_tgt)[JX], const float (&qd_tgt)[JX], float (&tau_e)[JX], float (&pd_diag)[JX], float (&pd_rhs)[JX]) {
     const float dt = u.dt;
     // the joints' actuator constants: one batch of LDS reads, in registers before the first branch on them (rl_pin) - read joint by joint,
-    // each read sat behind the branch of the joint before it (ten joints on the trunk + limbs instances: twenty dependent round trips)
+    // each read sits behind the branch of the joint before it.  Quadrupeds: A1 36.29 -> 35.68 us.  The trunk + limbs instances lose by it
+    // (G1 94.83 -> 95.20: forty more live registers where the kernel has none to spare) and keep the joint-by-joint form
+    // (profiles/r05s_actuator_batch_ab.txt)
     float a_eff[JX], a_sat[JX], a_vlim[JX], a_flags[JX];
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       const F4 c1 = ld4(L.jc[j] + 4), c2 = ld4(L.jc[j] + 8);  // [. . eff sat | act_vlim flags . .]
       a_eff[j] = c1.z; a_sat[j] = c1.w; a_vlim[j] = c2.x; a_flags[j] = c2.y;
     }
-    rl_pin(a_eff); rl_pin(a_sat); rl_pin(a_vlim); rl_pin(a_flags);
+    if constexpr (NW == 0) { rl_pin(a_eff); rl_pin(a_sat); rl_pin(a_vlim); rl_pin(a_flags); }
 #pragma unroll
     for (int j = 0; j < JX; ++j) {
       const int flags = (int)a_flags[j];

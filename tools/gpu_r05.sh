@@ -316,4 +316,11 @@ r)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
   grep -E "smoke|rc=|Error" $OUT/smoke.log | tail -12
   ;;
+s)
+  # the actuator constants of all joints in one batch of LDS reads
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/prev2_78.so new:RL_ENV_SPEC=1 > $OUT/actuator_batch_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GR1 --num-envs 1024 prev:RL_ENV_SPEC=1@$V/prev2_2078.so new:RL_ENV_SPEC=1 >> $OUT/actuator_batch_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 prev:RL_ENV_SPEC=1@$V/prev_34.so new:RL_ENV_SPEC=1 >> $OUT/actuator_batch_ab.txt 2>&1
+  cat $OUT/actuator_batch_ab.txt
+  ;;
 esac
