@@ -912,6 +912,7 @@ struct EnvLane {
       float un = dot(nb, uu);
       V3 ut = uu - un * nb;
       float utn = norm(ut);
+      // (the friction row read ahead, under the penetration arithmetic of the group's slots, was tried: +0.6 % on A1 - profiles/r05t_substep_batches_ab.txt)
       int slot = L.sph_slot[g][s];
       const F4 fr = fric.ld(slot);
       float mus = fr.x, mud = fr.y, rest = fr.z;
@@ -1247,6 +1248,15 @@ struct EnvLane {
 #pragma unroll
     for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
     float Uh[CL][6], ui[CL];
+    // the joints' armature / limit words: one batch of LDS reads in front of the recursion (read joint by joint they were three round trips
+    // inside a chain that has nothing else to do meanwhile: A1 35.66 -> 35.45 us, profiles/r05t_substep_batches_ab.txt)
+    float jarm[CL], jlo[CL], jhi[CL];
+#pragma unroll
+    for (int j = 0; j < CL; ++j) {
+      const F4 c2 = ld4(L.jc[j] + 8), c3 = ld4(L.jc[j] + 12);
+      jarm[j] = c2.z; jlo[j] = c2.w; jhi[j] = c3.x;
+    }
+    rl_pin(jarm); rl_pin(jlo); rl_pin(jhi);
     static_for_down<CL - 1>([&](auto jc) {
       constexpr int j = jc.value, gq = j + 1 - G0, so = gq % SUB, io = gq / SUB;  // owner sub-lane / iteration of link group j + 1
 #pragma unroll
@@ -1255,9 +1265,8 @@ struct EnvLane {
       for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<so>(rec[io].r[i]);
       const float s6[6] = {Sj[j].a.x, Sj[j].a.y, Sj[j].a.z, Sj[j].l.x, Sj[j].l.y, Sj[j].l.z};
       // joint-local terms: armature, implicit PD, limit spring-damper (hard limits in the reference, a1.urdf:369,411,439)
-      const F4 c2 = ld4(L.jc[j] + 8), c3 = ld4(L.jc[j] + 12);  // [. . armature lower | upper . . .]
-      const float arm = c2.z;
-      const float below = c2.w - q[j], above = q[j] - c3.x;
+      const float arm = jarm[j];
+      const float below = jlo[j] - q[j], above = q[j] - jhi[j];
       const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
       const bool lim = (below > 0.f) || (above > 0.f);
       float D = arm + pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);

@@ -323,4 +323,9 @@ s)
   timeout 300 python tools/ab_bench.py --steady --rounds 2 prev:RL_ENV_SPEC=1@$V/prev_34.so new:RL_ENV_SPEC=1 >> $OUT/actuator_batch_ab.txt 2>&1
   cat $OUT/actuator_batch_ab.txt
   ;;
+t)
+  # two more batches inside the substep (A/B switches): the recursion's armature / limit words, the contact slots' friction rows
+  timeout 400 python tools/ab_bench.py --steady --rounds 3 $V/base_34.so $V/jcbatch_34.so $V/fricpre_34.so $V/both_34.so > $OUT/substep_batches_ab.txt 2>&1
+  cat $OUT/substep_batches_ab.txt
+  ;;
 esac
