@@ -586,6 +586,12 @@ struct EnvLane {
   enum { LB_REC = LbLayout<TP>::REC, LB_VA = LbLayout<TP>::VA };
   template <class FT = NoJoint, class FL = NoJoint>
   RL_FN void kinematics(ChainTP& C, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
+    if constexpr (KIN_SCAN && std::is_same<typename std::decay<FT>::type, NoJoint>::value && std::is_same<typename std::decay<FL>::type, NoJoint>::value) {
+      SV s0[NW > 0 ? NW : 1], s1[NW > 0 ? NW : 1], s2[NW > 0 ? NW : 1];
+      const SV z{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      kinematics_scan<false>(C, z, z, s0, s1, s2);
+      return;
+    }
 #ifndef RL_KIN_REPLICATED  // (A/B switch: every sub-lane computes every joint transform)
     if constexpr (NW > 0 && SUB > 1) {
       chain_kinematics_dealt<TP, (SUB < 4 ? SUB : 4)>(ctx, SUB > 4 ? (sub & 3) : sub, L, q, C, u.trunk_restart, on_trunk, on_limb);
@@ -595,6 +601,136 @@ struct EnvLane {
     chain_kinematics<TP>(L, q, C, u.trunk_restart, on_trunk, on_limb);
   }
   RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_chain() : nullptr); }
+
+  // ---- Kinematics with ONE LIMB JOINT PER SUB-LANE (round 5; eight sub-lanes per limb, a limb has at most seven joints).
+  // The dealt form above still walks the limb's chain in every sub-lane - ten joints x (nine broadcasts, R_j = R_parent T_j, origin, axis,
+  // twist, bias acceleration): 1.4 k of a substep's 6 k vector instructions on G1, eight times the same numbers.  Here sub-lane s owns limb
+  // joint s: its local transform A_s = (rot0_s Rodrigues(axis_s, q_s), origin_s), then an inclusive prefix product
+  // A_0 o ... o A_s over the limb's lanes in three DPP steps (row_shr 1, 2, 4: (R1, p1) o (R2, p2) = (R1 R2, p1 + R1 p2)), the limb's
+  // attachment frame in front, and the lane writes ITS joint's words of the limb-shared chain.  Link twists V_j = V_attach + sum_{i <= j}
+  // S_i qd_i and bias accelerations a_j = a_attach + sum_{i <= j} V_i x S_i qd_i are two prefix SUMS of six words (VEL).  The trunk joints
+  // (shared by all limbs) stay a chain in every lane, their local transforms dealt over the lane's DPP quad as before.
+  // Products and sums associate as a tree here and left to right there: round-off apart (the parity tiers' tolerances), not bits.
+  // Readers of another lane's words need the wave-local fence (ctx.group_sync) first.
+#ifdef RL_KIN_DEALT  // (A/B switch: the dealt chain of round 4)
+  static constexpr bool KIN_SCAN = false;
+#else
+  static constexpr bool KIN_SCAN = NW > 0 && SUB == 8 && CL <= 8;
+#endif
+  template <bool VEL>
+  RL_FN void kinematics_scan(ChainTP& C, const SV V0, const SV a0, SV (&Sw)[NW > 0 ? NW : 1], SV (&Vw)[NW > 0 ? NW : 1], SV (&aw)[NW > 0 ? NW : 1]) {
+    static_assert(NW > 0 && SUB == 8, "trunk + limbs instance, eight sub-lanes per limb");
+    const int sq = sub & 3;
+    // the trunk joints' local transforms, dealt over the lane's quad: trunk joint 4 i + sq in round i (a partial last round is clamped, unused)
+    constexpr int NT4 = (NW + 3) / 4;
+    M3 Tt[NT4];
+    static_for<0, NT4>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      float qi = opaque(q[CL + 4 * i]);  // (opaque: rl_math.h - a select over plain loads of q becomes one load through a selected address)
+      static_for<1, 4>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s2 = decltype(sc)::value, tq = 4 * i + s2 < NW ? 4 * i + s2 : NW - 1;
+        const float cand = opaque(q[CL + tq]);
+        qi = sq == s2 ? cand : qi;
+      });
+      const int jx = CL + imin(4 * i + sq, NW - 1);
+      const F4 r0 = ld4(L.rota[jx]), r1 = ld4(L.rota[jx] + 4), r2 = ld4(L.rota[jx] + 8);  // rot0 (row-major) and the axis: three vectors
+      Tt[i] = mul(M3{{r0.x, r0.y, r0.z}, {r0.w, r1.x, r1.y}, {r1.z, r1.w, r2.x}}, rodrigues(V3{r2.y, r2.z, r2.w}, qi));
+    });
+    // this lane's limb joint
+    const bool has = sub < CL;
+    const int js = has ? sub : CL - 1;
+    float qs = opaque(q[0]), qds = opaque(qd[0]);
+    static_for<1, CL>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      const float cq = opaque(q[j]), cd = opaque(qd[j]);
+      qs = js == j ? cq : qs;
+      qds = js == j ? cd : qds;
+    });
+    M3 Rl;
+    V3 pl, al_s;
+    {
+      const F4 r0 = ld4(L.rota[js]), r1 = ld4(L.rota[js] + 4), r2 = ld4(L.rota[js] + 8), c0 = ld4(L.jc[js]);
+      al_s = {r2.y, r2.z, r2.w};
+      const M3 Tl = mul(M3{{r0.x, r0.y, r0.z}, {r0.w, r1.x, r1.y}, {r1.z, r1.w, r2.x}}, rodrigues(al_s, qs));
+      Rl = select_m3(has, Tl, identity3());
+      pl = select3(has, V3{c0.x, c0.y, c0.z}, V3{0.f, 0.f, 0.f});
+    }
+    // trunk chain (the same in every lane)
+    M3 Rp = identity3(), Ra = identity3();
+    V3 pp{0.f, 0.f, 0.f}, pa{0.f, 0.f, 0.f};
+    SV Vp = V0, ap = a0, Va = V0, aa = a0;
+    static_for<0, NW>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value, jx = CL + i;
+      if (i > 0 && ((u.trunk_restart >> i) & 1u)) { Rp = identity3(); pp = {0.f, 0.f, 0.f}; Vp = V0; ap = a0; }  // a trunk piece that starts at the base
+      const M3 Tj = ctx.template deal_bcast_m3<i % 4>(Tt[i / 4]);
+      V3 oj, alj;
+      joint_origin_axis(L, jx, oj, alj);
+      const V3 pj = pp + mul(Rp, oj);
+      const M3 Rj = mul(Rp, Tj);
+      const V3 axj = mul(Rj, alj);
+      C.setw(i, Rj, pj, axj);
+      if constexpr (VEL) {
+        Sw[i] = SV{axj, cross(pj, axj)};
+        const SV vj = Sw[i] * qd[jx];
+        Vw[i] = Vp + vj;
+        aw[i] = ap + crm(Vw[i], vj);
+        Vp = Vw[i];
+        ap = aw[i];
+        if (L.attach == i + 1) { Va = Vw[i]; aa = aw[i]; }
+      }
+      Rp = Rj;
+      pp = pj;
+      if (L.attach == i + 1) { Ra = Rj; pa = pj; }
+    });
+    // inclusive prefix product of the local transforms over the limb's sub-lanes
+    static_for<0, 3>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int D = 1 << decltype(dc)::value;
+      float w[12] = {Rl.r0.x, Rl.r0.y, Rl.r0.z, Rl.r1.x, Rl.r1.y, Rl.r1.z, Rl.r2.x, Rl.r2.y, Rl.r2.z, pl.x, pl.y, pl.z};
+      ctx.template sub_shr<D>(w);
+      const M3 Rq{{w[0], w[1], w[2]}, {w[3], w[4], w[5]}, {w[6], w[7], w[8]}};
+      const V3 pq{w[9], w[10], w[11]};
+      const bool take = sub >= D;
+      const M3 Rn = mul(Rq, Rl);
+      const V3 pn = pq + mul(Rq, pl);
+      Rl = select_m3(take, Rn, Rl);
+      pl = select3(take, pn, pl);
+    });
+    const M3 Rj = mul(Ra, Rl);
+    const V3 pj = pa + mul(Ra, pl);
+    const V3 axj = mul(Rj, al_s);  // (Rodrigues(axis, .) leaves its own axis where it is: R_j axis = rot-frame axis)
+    if (has) C.set(js, Rj, pj, axj);
+    if constexpr (VEL) {
+      const SV Sj{axj, cross(pj, axj)};
+      const SV vj = Sj * (has ? qds : 0.f);
+      float vs[6] = {vj.a.x, vj.a.y, vj.a.z, vj.l.x, vj.l.y, vj.l.z};
+      static_for<0, 3>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int D = 1 << decltype(dc)::value;
+        float w[6] = {vs[0], vs[1], vs[2], vs[3], vs[4], vs[5]};
+        ctx.template sub_shr<D>(w);
+        const bool take = sub >= D;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vs[i] += take ? w[i] : 0.f;
+      });
+      const SV Vj = Va + SV{{vs[0], vs[1], vs[2]}, {vs[3], vs[4], vs[5]}};
+      const SV cj = crm(Vj, vj);
+      float cs[6] = {cj.a.x, cj.a.y, cj.a.z, cj.l.x, cj.l.y, cj.l.z};
+      static_for<0, 3>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int D = 1 << decltype(dc)::value;
+        float w[6] = {cs[0], cs[1], cs[2], cs[3], cs[4], cs[5]};
+        ctx.template sub_shr<D>(w);
+        const bool take = sub >= D;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cs[i] += take ? w[i] : 0.f;
+      });
+      const SV aj = aa + SV{{cs[0], cs[1], cs[2]}, {cs[3], cs[4], cs[5]}};
+      if (has) {
+        float* w = va_words(js);
+        st4(w, F4{Vj.a.x, Vj.a.y, Vj.a.z, Vj.l.x});
+        st4(w + 4, F4{Vj.l.y, Vj.l.z, aj.a.x, aj.a.y});
+        st4(w + 8, F4{aj.a.z, aj.l.x, aj.l.y, aj.l.z});
+      }
+    }
+  }
 
   Ctx& ctx;
   const KState& S;
@@ -1673,7 +1809,10 @@ struct EnvLane {
     // chain words back (A/B).
     SV Sw[NW], Vw[NW], aw[NW];
 #ifndef RL_VEL_SEPARATE
-    {
+    if constexpr (KIN_SCAN) {
+      kinematics_scan<true>(C, V0, a0, Sw, Vw, aw);
+      if (self_on()) ctx.group_sync();  // (self_place reads the limb's chain words: other sub-lanes wrote them)
+    } else {
       SV Vp = V0, ap = a0;
       kinematics(C,
                  [&](int i, V3 ax, V3 pj) __attribute__((always_inline)) {

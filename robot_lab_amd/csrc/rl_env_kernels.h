@@ -193,6 +193,14 @@ struct WaveCtx {
               {leg_bcast<J>(m.r1.x), leg_bcast<J>(m.r1.y), leg_bcast<J>(m.r1.z)},
               {leg_bcast<J>(m.r2.x), leg_bcast<J>(m.r2.y), leg_bcast<J>(m.r2.z)}};
   }
+  // w[] of sub-lane (sub - D) of this lane's limb, for the sub-lanes that have one (sub >= D; the others get something: their callers select).
+  // Eight sub-lanes per limb: a limb is half a DPP row, row_shr:D stays inside it for those lanes.  (kinematics_scan, env_step.h)
+  template <int D, int N>
+  __device__ __forceinline__ void sub_shr(float (&w)[N]) const {
+    static_assert(SUB == 8 && D >= 1 && D < 8, "eight sub-lanes per limb");
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = dpp_move<0x110 + D>(w[i]);  // row_shr:D
+  }
   __device__ float gshfl(float v, int leg) const { return __shfl(v, (lane & ~(LPE - 1)) | (leg * SUB) | (lane & (SUB - 1))); }
   __device__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
   __device__ float* obs_stage(int g) const { return stage[g] + env_in_tile() * dim[g]; }

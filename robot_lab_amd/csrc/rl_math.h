@@ -86,6 +86,7 @@ RL_FN float norm(V3 a) { return fsqrt(dot(a, a)); }
 struct M3 {
   V3 r0, r1, r2;
 };
+RL_FN M3 select_m3(bool c, const M3& a, const M3& b) { return {select3(c, a.r0, b.r0), select3(c, a.r1, b.r1), select3(c, a.r2, b.r2)}; }  // (by components: select3)
 RL_FN V3 mul(const M3& m, V3 v) { return {dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)}; }
 RL_FN V3 mulT(const M3& m, V3 v) { return v.x * m.r0 + v.y * m.r1 + v.z * m.r2; }
 RL_FN V3 col0(const M3& m) { return {m.r0.x, m.r1.x, m.r2.x}; }

@@ -136,6 +136,7 @@ struct alignas(64) Team {
   FiberSet* fibers = nullptr;  // set: the lanes are fibers of one thread
   alignas(64) float slot[LPE];
   float slot9[LPE][9];
+  float slot12[LPE][12];
   float rstage[rl::MAX_T];
   float feat[rl::feat_count(rl::TopoMax::DMAX)];
   alignas(16) float lbchain[rl::NLANE][rl::LbLayout<rl::TopoGR>::CHAINW + 4];  // limb-shared words (really shared by the limb's sub-lane threads): kinematics
@@ -377,6 +378,19 @@ struct HostCtx {
     const rl::M3 out{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, {r[6], r[7], r[8]}};
     team->barrier(li());
     return out;
+  }
+  // w[] of sub-lane (sub - D) of this lane's limb (the kernel: row_shr:D inside the limb's half row); lanes with sub < D keep theirs
+  template <int D, int N>
+  void sub_shr(float (&w)[N]) {
+    static_assert(N <= 12, "exchange scratch");
+    float* mine = team->slot12[li()];
+    for (int i = 0; i < N; ++i) mine[i] = w[i];
+    team->barrier(li());
+    if (sub_ >= D) {
+      const float* r = team->slot12[k_ * SUB + sub_ - D];
+      for (int i = 0; i < N; ++i) w[i] = r[i];
+    }
+    team->barrier(li());
   }
   template <int X>
   float limb_xor(float v) { return gshfl(v, k_ ^ X); }

@@ -328,4 +328,17 @@ t)
   timeout 400 python tools/ab_bench.py --steady --rounds 3 $V/base_34.so $V/jcbatch_34.so $V/fricpre_34.so $V/both_34.so > $OUT/substep_batches_ab.txt 2>&1
   cat $OUT/substep_batches_ab.txt
   ;;
+u)
+  # kinematics with one limb joint per sub-lane (prefix product / prefix sums over a limb's eight lanes) against the dealt chain of the commit before
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/prev3_78.so new:RL_ENV_SPEC=1 > $OUT/kin_scan_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GR1 --num-envs 1024 prev:RL_ENV_SPEC=1@$V/prev3_2078.so new:RL_ENV_SPEC=1 >> $OUT/kin_scan_ab.txt 2>&1
+  cat $OUT/kin_scan_ab.txt
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "sub8" > $OUT/pytest_parity_sub8.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_sub8.log
+  tail -3 $OUT/pytest_parity_sub8.log
+  timeout 900 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "G1-v0-2048-None or Xbot or GR1T1-v0-1024-sub8" > $OUT/pytest_teacher_forced_trunk.log 2>&1; echo "rc=$?" >> $OUT/pytest_teacher_forced_trunk.log
+  tail -3 $OUT/pytest_teacher_forced_trunk.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  timeout 300 python -m pytest tests/test_gpu_canary.py tests/test_gpu_self_collision.py -m gpu -q > $OUT/pytest_canary.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary.log
+  tail -2 $OUT/pytest_canary.log
+  ;;
 esac
