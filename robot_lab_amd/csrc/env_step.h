@@ -968,29 +968,32 @@ struct EnvLane {
     }
     if constexpr (NW == 0) { rl_pin(a_eff); rl_pin(a_sat); rl_pin(a_vlim); rl_pin(a_flags); }
 #pragma unroll
-    for (int j = 0; j < JX; ++j) {
-      const int flags = (int)a_flags[j];
-      float qt = (flags & 2) ? q[j] : q_tgt[j];
-      float er = qt - q[j], ed = qd_tgt[j] - qd[j];
-      float tc = kp[j] * er + kd[j] * ed;
-      float eff = a_eff[j];
-      if (flags & 1) {
-        float est = clampf(tc, -eff, eff);
-        bool sat = fabsf(tc) > eff;
-        tau_app[j] = est;
-        tau_e[j] = sat ? est : 0.f;
-        pd_diag[j] = sat ? 0.f : dt * (kd[j] + kp[j] * dt);
-        pd_rhs[j] = sat ? 0.f : dt * (kp[j] * er + kd[j] * qd_tgt[j]);
-      } else {  // DCMotor torque-speed clip (unitree.py:55-63)
-        float vr = qd[j] * frcp(a_vlim[j]);
-        float tmax = clampf(a_sat[j] * (1.0f - vr), 0.f, eff);
-        float tmin = clampf(a_sat[j] * (-1.0f - vr), -eff, 0.f);
-        float t = clampf(tc, tmin, tmax);
-        tau_app[j] = t;
-        tau_e[j] = t;
-        pd_diag[j] = 0.f;
-        pd_rhs[j] = 0.f;
-      }
+    for (int j = 0; j < JX; ++j)
+      actuator_one(q[j], qd[j], kp[j], kd[j], q_tgt[j], qd_tgt[j], a_eff[j], a_sat[j], a_vlim[j], (int)a_flags[j], tau_app[j], tau_e[j], pd_diag[j], pd_rhs[j]);
+  }
+  // one joint: applied torque estimate, explicit torque, the implicit PD's diagonal and right-hand-side terms
+  RL_FN void actuator_one(float qj, float qdj, float kpj, float kdj, float qtj, float qdtj, float eff, float satq, float vlim, int flags, float& t_app,
+                          float& t_e, float& p_diag, float& p_rhs) const {
+    const float dt = u.dt;
+    float qt = (flags & 2) ? qj : qtj;
+    float er = qt - qj, ed = qdtj - qdj;
+    float tc = kpj * er + kdj * ed;
+    if (flags & 1) {
+      float est = clampf(tc, -eff, eff);
+      bool sat = fabsf(tc) > eff;
+      t_app = est;
+      t_e = sat ? est : 0.f;
+      p_diag = sat ? 0.f : dt * (kdj + kpj * dt);
+      p_rhs = sat ? 0.f : dt * (kpj * er + kdj * qdtj);
+    } else {  // DCMotor torque-speed clip (unitree.py:55-63)
+      float vr = qdj * frcp(vlim);
+      float tmax = clampf(satq * (1.0f - vr), 0.f, eff);
+      float tmin = clampf(satq * (-1.0f - vr), -eff, 0.f);
+      float t = clampf(tc, tmin, tmax);
+      t_app = t;
+      t_e = t;
+      p_diag = 0.f;
+      p_rhs = 0.f;
     }
   }
 
@@ -1783,13 +1786,45 @@ struct EnvLane {
   // joint-local terms of joint jx (limb joint j or trunk joint CL + i): armature, implicit PD, limit spring-damper, and the
   // identity row of an inert padding joint
   RL_FN void joint_terms(int jx, bool padding, const float (&tau_e)[JX], const float (&pd_diag)[JX], const float (&pd_rhs)[JX], float& D, float& uu) const {
+    joint_terms_one(jx, q[jx], qd[jx], padding, tau_e[jx], pd_diag[jx], pd_rhs[jx], D, uu);
+  }
+  RL_FN void joint_terms_one(int jx, float qj, float qdj, bool padding, float t_e, float p_diag, float p_rhs, float& D, float& uu) const {
     const F4 c2 = ld4(L.jc[jx] + 8), c3 = ld4(L.jc[jx] + 12);  // [. . armature lower | upper . . .]
     const float dt = u.dt, arm = c2.z;
-    const float below = c2.w - q[jx], above = q[jx] - c3.x;
+    const float below = c2.w - qj, above = qj - c3.x;
     const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
     const bool lim = (below > 0.f) || (above > 0.f);
-    D = arm + pd_diag[jx] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f) + (padding ? 1.0f : 0.f);
-    uu = arm * qd[jx] + dt * tau_e[jx] + pd_rhs[jx] + dt * u.limit_k * viol;
+    D = arm + p_diag + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f) + (padding ? 1.0f : 0.f);
+    uu = arm * qdj + dt * t_e + p_rhs + dt * u.limit_k * viol;
+  }
+  // Eight sub-lanes per limb (KIN_SCAN): sub-lane s is also the one that evaluates limb joint s's ACTUATOR and joint-local terms (D, u of
+  // the elimination); the recursion fetches them with a limb broadcast per joint, the applied torques go back to every sub-lane (the reward
+  // stage and the write-back read their own copies).  The trunk joints stay in every lane.  Before: every sub-lane all ten joints - 500 + 105
+  // vector instructions per substep against 55 + 165 + 63 here.  Same arithmetic per joint, same bits.
+  RL_FN void actuators_owned(const float (&q_tgt)[JX], const float (&qd_tgt)[JX], float (&tau_e)[JX], float (&pd_diag)[JX], float (&pd_rhs)[JX], float& D_own,
+                             float& uu_own) {
+    static_assert(NW > 0 && SUB == 8, "trunk + limbs instance, eight sub-lanes per limb");
+#pragma unroll
+    for (int j = CL; j < JX; ++j) {
+      const F4 c1 = ld4(L.jc[j] + 4), c2 = ld4(L.jc[j] + 8);
+      actuator_one(q[j], qd[j], kp[j], kd[j], q_tgt[j], qd_tgt[j], c1.z, c1.w, c2.x, (int)c2.y, tau_app[j], tau_e[j], pd_diag[j], pd_rhs[j]);
+    }
+    const int js = sub < CL ? sub : CL - 1;
+    float qs = opaque(q[0]), qds = opaque(qd[0]), kps = opaque(kp[0]), kds = opaque(kd[0]), qts = opaque(q_tgt[0]), qdts = opaque(qd_tgt[0]);
+    static_for<1, CL>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      const float c0 = opaque(q[j]), c1 = opaque(qd[j]), c2 = opaque(kp[j]), c3 = opaque(kd[j]), c4 = opaque(q_tgt[j]), c5 = opaque(qd_tgt[j]);
+      const bool m = js == j;
+      qs = m ? c0 : qs; qds = m ? c1 : qds; kps = m ? c2 : kps; kds = m ? c3 : kds; qts = m ? c4 : qts; qdts = m ? c5 : qdts;
+    });
+    const F4 c1 = ld4(L.jc[js] + 4), c2 = ld4(L.jc[js] + 8);
+    float ta, te, pdg, prh;
+    actuator_one(qs, qds, kps, kds, qts, qdts, c1.z, c1.w, c2.x, (int)c2.y, ta, te, pdg, prh);
+    joint_terms_one(js, qs, qds, js >= L.nj, te, pdg, prh, D_own, uu_own);
+    static_for<0, CL>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      this->tau_app[j] = this->ctx.template leg_bcast<j>(ta);
+    });
   }
 
   RL_FN void substep_aba_trunk(const float (&q_tgt)[JX], const float (&qd_tgt)[JX]) {
@@ -1798,7 +1833,9 @@ struct EnvLane {
     RL_PHASE(2, "sub.actuators+kinematics");
     const float dt = u.dt;
     float tau_e[JX], pd_diag[JX], pd_rhs[JX];
-    actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
+    float D_own = 0.f, uu_own = 0.f;  // (KIN_SCAN) the elimination's joint-local terms of this sub-lane's limb joint
+    if constexpr (KIN_SCAN) actuators_owned(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs, D_own, uu_own);
+    else actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
     const M3 Rwb = quat_to_mat(quat);
     const SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
     const SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
@@ -1979,20 +2016,25 @@ struct EnvLane {
     if constexpr (ELIM_DIST) {
       Rows P;
       rows_zero(P);
-#pragma unroll
-      for (int j = CL - 1; j >= 0; --j) {
-        rows_add(rec_words(j + 1), P);
+      static_for_down<CL - 1>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        rows_add(this->rec_words(j + 1), P);
         V3 ax, pj;
         C.axp(j, ax, pj);
         const V3 lx = cross(pj, ax);
         const float s6[6] = {ax.x, ax.y, ax.z, lx.x, lx.y, lx.z};
         float D, uu, Uh[6], ui;
-        joint_terms(j, j >= L.nj, tau_e, pd_diag, pd_rhs, D, uu);
-        eliminate_rows(P, s6, D, uu, Uh, ui);
-        float* o = va_words(j);  // (the link velocities parked here are no longer needed)
+        if constexpr (KIN_SCAN) {
+          D = this->ctx.template leg_bcast<j>(D_own);
+          uu = this->ctx.template leg_bcast<j>(uu_own);
+        } else {
+          this->joint_terms(j, j >= this->L.nj, tau_e, pd_diag, pd_rhs, D, uu);
+        }
+        this->eliminate_rows(P, s6, D, uu, Uh, ui);
+        float* o = this->va_words(j);  // (the link velocities parked here are no longer needed)
         st4(o, F4{Uh[0], Uh[1], Uh[2], Uh[3]});
         st4(o + 4, F4{Uh[4], Uh[5], ui, 0.f});
-      }
+      });
       if (sub < 4) rows_atomic_add(trunk_words(L.attach), P);  // (eight sub-lanes per limb: its second quad holds a copy)
       ctx.group_sync();
       RL_PHASE(10, "sub.cross_leg_sum");
@@ -2025,20 +2067,25 @@ struct EnvLane {
       for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
-#pragma unroll
-      for (int j = CL - 1; j >= 0; --j) {
-        add_rec(rec_words(j + 1), P);
+      static_for_down<CL - 1>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        add_rec(this->rec_words(j + 1), P);
         V3 ax, pj;
         C.axp(j, ax, pj);
         const V3 lx = cross(pj, ax);
         const float s6[6] = {ax.x, ax.y, ax.z, lx.x, lx.y, lx.z};
         float D, uu, Uh[6], ui;
-        joint_terms(j, j >= L.nj, tau_e, pd_diag, pd_rhs, D, uu);
-        eliminate(P, s6, D, uu, Uh, ui);
-        float* o = va_words(j);  // (the link velocities parked here are no longer needed)
+        if constexpr (KIN_SCAN) {
+          D = this->ctx.template leg_bcast<j>(D_own);
+          uu = this->ctx.template leg_bcast<j>(uu_own);
+        } else {
+          this->joint_terms(j, j >= this->L.nj, tau_e, pd_diag, pd_rhs, D, uu);
+        }
+        this->eliminate(P, s6, D, uu, Uh, ui);
+        float* o = this->va_words(j);  // (the link velocities parked here are no longer needed)
         st4(o, F4{Uh[0], Uh[1], Uh[2], Uh[3]});
         st4(o + 4, F4{Uh[4], Uh[5], ui, 0.f});
-      }
+      });
       if (sub == 0) atomic_add_rec(trunk_words(L.attach), P);
       ctx.group_sync();
       RL_PHASE(10, "sub.cross_leg_sum");
