@@ -388,4 +388,17 @@ PY
   timeout 300 python tools/bench_collect.py $G1 2048 20 2>/dev/null | tail -1 >> $OUT/collect.txt
   cat $OUT/collect.txt
   ;;
+v)
+  # eight sub-lanes per limb: a limb joint's actuator and joint-local terms by the sub-lane that owns the joint (+ limb broadcasts), against call z's tree
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 --task $G1 --num-envs 2048 $V/prev4_78.so new:RL_ENV_SPEC=1 > $OUT/actuators_owned_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GR1 --num-envs 1024 prev:RL_ENV_SPEC=1@$V/prev4_2078.so new:RL_ENV_SPEC=1 >> $OUT/actuators_owned_ab.txt 2>&1
+  cat $OUT/actuators_owned_ab.txt
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "sub8" > $OUT/pytest_parity_sub8.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_sub8.log
+  tail -3 $OUT/pytest_parity_sub8.log
+  timeout 900 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "G1-v0-2048-None or Xbot or GR1T1-v0-1024-sub8" > $OUT/pytest_teacher_forced_trunk.log 2>&1; echo "rc=$?" >> $OUT/pytest_teacher_forced_trunk.log
+  tail -3 $OUT/pytest_teacher_forced_trunk.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  timeout 300 python -m pytest tests/test_gpu_canary.py tests/test_gpu_self_collision.py tests/test_gpu_specs.py -m gpu -q > $OUT/pytest_canary.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary.log
+  tail -2 $OUT/pytest_canary.log
+  ;;
 esac
