@@ -401,4 +401,29 @@ v)
   timeout 300 python -m pytest tests/test_gpu_canary.py tests/test_gpu_self_collision.py tests/test_gpu_specs.py -m gpu -q > $OUT/pytest_canary.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary.log
   tail -2 $OUT/pytest_canary.log
   ;;
+w)
+  # G1 / the trunk + limbs instances on the final tree (after call z: the owner-computes actuators): bench line, kernel trace, counter passes, phase clock,
+  # collection loop, and the other humanoids' step times
+  timeout 200 python bench.py --task $G1 --num-envs 2048 --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_G1.json 2>/dev/null
+  python -c "
+import json
+d=json.load(open('$OUT/bench_G1.json')); print('bench_G1 value %.2f M  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']))" | tee $OUT/bench_G1.txt
+  G1S="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --large-batch-envs 0 --task $G1 --num-envs 2048"
+  SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+  WAIT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"
+  prof g1_kernel_stats "$G1S" --kernel-trace --stats
+  prof g1_pmc_fetch "$G1S" --pmc FETCH_SIZE
+  prof g1_pmc_write "$G1S" --pmc WRITE_SIZE
+  prof g1_pmc_sq "$G1S" --pmc $SQ
+  prof g1_pmc_wait "$G1S" --pmc $WAIT
+  head -6 $OUT/g1_kernel_stats.txt
+  RL_ENV_LIB=$V/clockspec_78.so timeout 200 python tools/phase_clock.py $G1 2048 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_g1.txt
+  head -24 $OUT/phase_clock_g1.txt
+  timeout 300 python tools/bench_collect.py $G1 2048 20 2>/dev/null | tail -1 > $OUT/collect_g1.txt
+  cat $OUT/collect_g1.txt
+  for t in RobotLab-Isaac-Velocity-Rough-RobotEra-Xbot-v0 RobotLab-Isaac-Velocity-Rough-Booster-T1-v0 $GR1 RobotLab-Isaac-Velocity-Rough-RoboParty-ATOM01-v0; do
+    timeout 200 python tools/ab_bench.py --steady --rounds 1 --task $t --num-envs 2048 final:RL_ENV_SPEC=1 >> $OUT/trunk_sweep.txt 2>&1
+  done
+  cat $OUT/trunk_sweep.txt
+  ;;
 esac
