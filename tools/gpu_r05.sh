@@ -426,4 +426,17 @@ d=json.load(open('$OUT/bench_G1.json')); print('bench_G1 value %.2f M  ms_per_st
   done
   cat $OUT/trunk_sweep.txt
   ;;
+y)
+  # the whole GPU tier + smoke() + the default bench line on the LAST tree of the round (after call v's change to the trunk + limbs kernels)
+  timeout 1700 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -4 $OUT/pytest_gpu.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  mv gpurun_out/spec_vs_interpreter.jsonl gpurun_out/train_distributed_8ranks.json $OUT/ 2>/dev/null
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
+  grep -E "smoke|rc=|Error" $OUT/smoke.log | tail -8
+  timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  python -c "
+import json
+d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'), d['cpu_baseline']['value'])"
+  ;;
 esac
