@@ -2,6 +2,10 @@
 # Round 5: what each gpurun call of the round ran (one script, one section per call; results land in gpurun_out/r05<call>/ and the
 # summaries that are to be judged are copied into profiles/ by hand).
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_r05.sh a'
+# Calls: a, b the specialised term stack and the round's first evidence; c, d canaries after the explicit-fma draws, the observation stage on a Spec;
+# e Tita's quadruped instance; f, g, j what a reset costs (phase clocks of a resetting wavefront); h, i, k the reset path rewritten; l - o the episode
+# log (deferred adds, partial rows); p, s, t more batched reads; q the noise-pass interleave (dropped); r the GPU tier; u, v one limb joint per
+# sub-lane (kinematics, actuators); z the final evidence; w G1 after v; y the closing tier.  Variant libraries: tools/build_variant.sh.
 CALL=${1:-a}
 TAG=r05$CALL
 OUT=gpurun_out/$TAG
