@@ -443,4 +443,15 @@ y)
 import json
 d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'), d['cpu_baseline']['value'])"
   ;;
+x)
+  # last tree: step time vs envs per GPU (A1, Go2W, G1; cold windows), every compiled task id, and a short PPO run (the end-to-end check)
+  timeout 200 python tools/sweep_envs.py $A1 > $OUT/sweep_envs_a1.txt 2>/dev/null
+  timeout 200 python tools/sweep_envs.py $GO2W 4096,8192,16384,65536 > $OUT/sweep_envs_go2w.txt 2>/dev/null
+  timeout 200 python tools/sweep_envs.py $G1 512,1024,2048,4096,8192 > $OUT/sweep_envs_g1.txt 2>/dev/null
+  cat $OUT/sweep_envs_a1.txt $OUT/sweep_envs_go2w.txt $OUT/sweep_envs_g1.txt
+  timeout 120 python tools/train_demo.py --iterations 300 2>/dev/null | tail -4 > $OUT/train_demo_a1_flat_300.txt
+  cat $OUT/train_demo_a1_flat_300.txt
+  timeout 300 python tools/bench_every_task.py > $OUT/all_tasks.txt 2>/dev/null
+  tail -48 $OUT/all_tasks.txt | cut -c1-120
+  ;;
 esac
