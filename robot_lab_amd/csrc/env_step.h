@@ -1305,6 +1305,13 @@ struct EnvLane {
   // The decimation loop of the quadruped instances, software-pipelined over the terrain loads: the kinematics of substep s + 1
   // are computed right after substep s has moved the joints, its sphere centres follow and the heightfield loads are issued -
   // they fly (L2 / MALL: 300 - 900 cycles) while the sensor timers, the actuators and the rigid link records are worked on.
+  // quadrupeds, 16 lanes per env: sub-lane s of a limb also owns limb joint s's actuator and joint-local terms (actuators_owned: three or
+  // four joints on four sub-lanes) - what the trunk + limbs instances do with eight.  -DRL_ACT_REPLICATED: every sub-lane every joint (A/B)
+#ifdef RL_ACT_REPLICATED
+  static constexpr bool ACT_OWNED = false;
+#else
+  static constexpr bool ACT_OWNED = NW == 0 && SUB == 4 && CL <= 4;
+#endif
   RL_FN void substeps_aba(const float (&q_tgt)[JX], const float (&qd_tgt)[JX], int n) {
     const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
     ChainTP C = new_chain();
@@ -1318,13 +1325,15 @@ struct EnvLane {
       asm volatile("" ::: "memory");
       RL_PHASE(2, "sub.actuators+kinematics");
       float tau_e[JX], pd_diag[JX], pd_rhs[JX];
-      actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
+      float D_own = 0.f, uu_own = 0.f;  // (ACT_OWNED) the elimination's joint-local terms of this sub-lane's joint
+      if constexpr (ACT_OWNED) actuators_owned(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs, D_own, uu_own);
+      else actuators(q_tgt, qd_tgt, tau_e, pd_diag, pd_rhs);
       const SV V0{mulT(Rwb, vang), mulT(Rwb, vlin)};
       const SV a0{{0.f, 0.f, 0.f}, mulT(Rwb, V3{0.f, 0.f, u.gravity})};
       float nu0[NB], qdn[JX];
       uint32_t active_mask = 0;
       SV Vnew[NIT];
-      aba_solve(C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, gf, fetched, nu0, qdn, active_mask, Vnew);
+      aba_solve(C, Rwb, V0, a0, tau_e, pd_diag, pd_rhs, gf, fetched, nu0, qdn, active_mask, Vnew, D_own, uu_own);
       V3 fown[MAXOWN];
       sensor_forces(C, Rwb, V0, nu0, qdn, active_mask, Vnew, fown);
       integrate(Rwb, V0, nu0, qdn);
@@ -1341,7 +1350,7 @@ struct EnvLane {
 
   RL_FN void aba_solve(const ChainTP& C, const M3& Rwb, const SV V0, const SV a0, const float (&tau_e)[JX], const float (&pd_diag)[JX],
                        const float (&pd_rhs)[JX], const GroupFetch (&gf)[NIT], const bool (&fetched)[NIT], float (&nu0)[NB], float (&qdn)[JX],
-                       uint32_t& active_mask, SV (&Vnew)[NIT]) {
+                       uint32_t& active_mask, SV (&Vnew)[NIT], const float D_own = 0.f, const float uu_own = 0.f) {
     const float dt = u.dt;
     // ---- link velocities / bias accelerations (every sub-lane: cheap), rigid record of the owned link(s)
     RL_PHASE(4, "sub.link_records");
@@ -1390,12 +1399,14 @@ struct EnvLane {
     // the joints' armature / limit words: one batch of LDS reads in front of the recursion (read joint by joint they were three round trips
     // inside a chain that has nothing else to do meanwhile: A1 35.66 -> 35.45 us, profiles/r05t_substep_batches_ab.txt)
     float jarm[CL], jlo[CL], jhi[CL];
+    if constexpr (!ACT_OWNED) {
 #pragma unroll
-    for (int j = 0; j < CL; ++j) {
-      const F4 c2 = ld4(L.jc[j] + 8), c3 = ld4(L.jc[j] + 12);
-      jarm[j] = c2.z; jlo[j] = c2.w; jhi[j] = c3.x;
+      for (int j = 0; j < CL; ++j) {
+        const F4 c2 = ld4(L.jc[j] + 8), c3 = ld4(L.jc[j] + 12);
+        jarm[j] = c2.z; jlo[j] = c2.w; jhi[j] = c3.x;
+      }
+      rl_pin(jarm); rl_pin(jlo); rl_pin(jhi);
     }
-    rl_pin(jarm); rl_pin(jlo); rl_pin(jhi);
     static_for_down<CL - 1>([&](auto jc) {
       constexpr int j = jc.value, gq = j + 1 - G0, so = gq % SUB, io = gq / SUB;  // owner sub-lane / iteration of link group j + 1
 #pragma unroll
@@ -1404,13 +1415,19 @@ struct EnvLane {
       for (int i = 0; i < 6; ++i) P.r[i] += ctx.template leg_bcast<so>(rec[io].r[i]);
       const float s6[6] = {Sj[j].a.x, Sj[j].a.y, Sj[j].a.z, Sj[j].l.x, Sj[j].l.y, Sj[j].l.z};
       // joint-local terms: armature, implicit PD, limit spring-damper (hard limits in the reference, a1.urdf:369,411,439)
-      const float arm = jarm[j];
-      const float below = jlo[j] - q[j], above = q[j] - jhi[j];
-      const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
-      const bool lim = (below > 0.f) || (above > 0.f);
-      float D = arm + pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
-      if (TP::PAD) D += j >= L.nj ? 1.0f : 0.f;  // an inert padding joint (zero axis, no gains): the identity row, as joint_terms() of the trunk + limbs instances
-      float uu = arm * qd[j] + dt * tau_e[j] + pd_rhs[j] + dt * u.limit_k * viol;
+      float D, uu;
+      if constexpr (ACT_OWNED) {  // from the sub-lane that owns joint j (actuators_owned: the same expressions, once per limb)
+        D = ctx.template leg_bcast<j>(D_own);
+        uu = ctx.template leg_bcast<j>(uu_own);
+      } else {
+        const float arm = jarm[j];
+        const float below = jlo[j] - q[j], above = q[j] - jhi[j];
+        const float viol = below > 0.f ? below : (above > 0.f ? -above : 0.f);
+        const bool lim = (below > 0.f) || (above > 0.f);
+        D = arm + pd_diag[j] + (lim ? dt * (u.limit_k * dt + u.limit_c) : 0.f);
+        if (TP::PAD) D += j >= L.nj ? 1.0f : 0.f;  // an inert padding joint (zero axis, no gains): the identity row, as joint_terms() of the trunk + limbs instances
+        uu = arm * qd[j] + dt * tau_e[j] + pd_rhs[j] + dt * u.limit_k * viol;
+      }
       float U6[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
@@ -1803,7 +1820,7 @@ struct EnvLane {
   // vector instructions per substep against 55 + 165 + 63 here.  Same arithmetic per joint, same bits.
   RL_FN void actuators_owned(const float (&q_tgt)[JX], const float (&qd_tgt)[JX], float (&tau_e)[JX], float (&pd_diag)[JX], float (&pd_rhs)[JX], float& D_own,
                              float& uu_own) {
-    static_assert(NW > 0 && SUB == 8, "trunk + limbs instance, eight sub-lanes per limb");
+    static_assert((NW > 0 && SUB == 8) || (NW == 0 && SUB == 4 && CL <= 4), "a limb joint per sub-lane");
 #pragma unroll
     for (int j = CL; j < JX; ++j) {
       const F4 c1 = ld4(L.jc[j] + 4), c2 = ld4(L.jc[j] + 8);
@@ -1820,7 +1837,7 @@ struct EnvLane {
     const F4 c1 = ld4(L.jc[js] + 4), c2 = ld4(L.jc[js] + 8);
     float ta, te, pdg, prh;
     actuator_one(qs, qds, kps, kds, qts, qdts, c1.z, c1.w, c2.x, (int)c2.y, ta, te, pdg, prh);
-    joint_terms_one(js, qs, qds, js >= L.nj, te, pdg, prh, D_own, uu_own);
+    joint_terms_one(js, qs, qds, TP::PAD && js >= L.nj, te, pdg, prh, D_own, uu_own);
     static_for<0, CL>([&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
       this->tau_app[j] = this->ctx.template leg_bcast<j>(ta);

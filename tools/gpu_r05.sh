@@ -454,4 +454,37 @@ x)
   timeout 300 python tools/bench_every_task.py > $OUT/all_tasks.txt 2>/dev/null
   tail -48 $OUT/all_tasks.txt | cut -c1-120
   ;;
+aa)
+  # quadrupeds, 16 lanes per env: a limb joint's actuator and joint-local terms by the sub-lane that owns the joint, against the same tree with
+  # -DRL_ACT_REPLICATED; then the quadruped parity tiers
+  timeout 300 python tools/ab_bench.py --steady --rounds 3 $V/repl_34.so owned:RL_ENV_SPEC=1 > $OUT/quad_act_owned_ab.txt 2>&1
+  timeout 300 python tools/ab_bench.py --steady --rounds 2 --task $GO2W repl:RL_ENV_SPEC=1@$V/repl_1044.so owned:RL_ENV_SPEC=1 >> $OUT/quad_act_owned_ab.txt 2>&1
+  cat $OUT/quad_act_owned_ab.txt
+  timeout 300 python -m pytest tests/test_gpu_canary.py tests/test_gpu_specs.py tests/test_gpu_lane_mapping.py -m gpu -q > $OUT/pytest_canary_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_canary_specs.log
+  tail -2 $OUT/pytest_canary_specs.log
+  timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "not sub8 and not sub4" > $OUT/pytest_parity_quadrupeds.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_quadrupeds.log
+  tail -3 $OUT/pytest_parity_quadrupeds.log
+  timeout 600 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "A1-v0-4096-None or Go2-v0-4096-None or Go2W-v0-4096-None or B2W or M20 or Tita-v0-4096-None" > $OUT/pytest_teacher_forced_quadrupeds.log 2>&1; echo "rc=$?" >> $OUT/pytest_teacher_forced_quadrupeds.log
+  tail -3 $OUT/pytest_teacher_forced_quadrupeds.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  ;;
+ab)
+  # the bench lines after call aa (quadruped actuators by the owning sub-lane) + the tiers that consume the env's outputs end to end
+  timeout 300 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  for t in $GO2 $GO2W; do timeout 100 python bench.py --task $t --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_$(echo $t | cut -d- -f6).json 2>/dev/null; done
+  python - <<PY | tee $OUT/baseline_configs.txt
+import json
+for n in ("bench_default", "bench_Go2", "bench_Go2W"):
+    d = json.load(open("$OUT/%s.json" % n))
+    print("%-16s %-50s value %7.2f M env-steps/s  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f" % (n, d["config"]["workload"].split(",")[0], d["value"] / 1e6, d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"]))
+d = json.load(open("$OUT/bench_default.json"))
+for leg in ("mid_batch", "large_batch"):
+    print(leg, {k: d.get(leg, {}).get(k) for k in ("envs_per_gpu", "value", "ms_per_step", "roofline_frac")})
+print("cpu_baseline", {k: d["cpu_baseline"].get(k) for k in ("value", "cores", "kind")})
+PY
+  timeout 200 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_collect.py tests/test_gpu_edge_cases.py tests/test_gpu_episode_stats.py -m gpu -q -x > $OUT/pytest_consumers.log 2>&1; echo "rc=$?" >> $OUT/pytest_consumers.log
+  tail -2 $OUT/pytest_consumers.log
+  timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
+  grep -E "smoke|rc=" $OUT/smoke.log | tail -6
+  ;;
 esac
