@@ -487,4 +487,9 @@ PY
   timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
   grep -E "smoke|rc=" $OUT/smoke.log | tail -6
   ;;
+ac)
+  # the rest of the GPU tier on the last tree (what calls aa / ab did not run after the quadruped change)
+  timeout 330 python -m pytest tests/test_gpu_all_tasks.py tests/test_gpu_command_levels.py tests/test_gpu_train.py tests/test_gpu_multirank.py tests/test_gpu_distributed_train.py tests/test_gpu_self_collision.py -m gpu -q > $OUT/pytest_rest.log 2>&1; echo "rc=$?" >> $OUT/pytest_rest.log
+  tail -3 $OUT/pytest_rest.log
+  ;;
 esac
