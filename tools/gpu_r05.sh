@@ -492,4 +492,12 @@ ac)
   timeout 330 python -m pytest tests/test_gpu_all_tasks.py tests/test_gpu_command_levels.py tests/test_gpu_train.py tests/test_gpu_multirank.py tests/test_gpu_distributed_train.py tests/test_gpu_self_collision.py -m gpu -q > $OUT/pytest_rest.log 2>&1; echo "rc=$?" >> $OUT/pytest_rest.log
   tail -3 $OUT/pytest_rest.log
   ;;
+ad)
+  # last tree: the teacher-forced configs of the other quadruped lane mappings (their kernels share aba_solve with the changed 16-lane one) and the
+  # trunk + limbs parity shapes
+  timeout 200 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -k "sub1 or sub2" > $OUT/pytest_teacher_forced_sub12.log 2>&1; echo "rc=$?" >> $OUT/pytest_teacher_forced_sub12.log
+  tail -2 $OUT/pytest_teacher_forced_sub12.log
+  timeout 90 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "sub8 or sub4" > $OUT/pytest_parity_trunk.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_trunk.log
+  tail -2 $OUT/pytest_parity_trunk.log
+  ;;
 esac
