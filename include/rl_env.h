@@ -345,7 +345,10 @@ int rl_env_step(rl_env* env, const float* action_dev, void* stream);
  *     rewards_out[e] = reward[e] + gamma * values[e] * time_out[e]      (bootstrapping on time outs)
  *     dones_out[e]   = terminated[e] | time_out[e]
  * for e < N - normally straight into the current slot of an rl_rollout (rl_rollout_record_slots), which saves the
- * separate record launch.  values_dev: float [N] (the critic's V(s_t)); all three are device pointers. */
+ * separate record launch.  values_dev: float [N] (the critic's V(s_t)); all three are device pointers.
+ * values_dev == NULL defers the bootstrap (the critic of step t is not on the path to env step t: it may still be running on another
+ * stream, robot_lab_amd/collect.py): the kernel then writes the RAW reward and  dones_out[e] = (terminated | time_out) | time_out << 1;
+ * rl_rollout_compute_returns adds gamma * V(s_t) where bit 1 is set and clears the bit - the storage ends up with the same numbers. */
 int rl_env_step_record(rl_env* env, const float* action_dev, const float* values_dev, float* rewards_out_dev, uint8_t* dones_out_dev,
                        float gamma, void* stream);
 

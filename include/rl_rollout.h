@@ -15,6 +15,8 @@
  * `add_transitions` / `compute_returns`):
  *   act:      a = mu + sigma * eps, eps ~ N(0, 1);  log_prob = sum_j( -((a_j - mu_j)/sigma_j)^2 / 2 - log sigma_j - log sqrt(2 pi) )
  *   record:   r_t += gamma * V_t * time_out  (bootstrapping on time outs);  done_t = terminated | time_out
+ *             (deferred form: a producer that has no V_t yet - rl_env_step_record with values NULL - stores the raw reward and marks
+ *              the time out in bit 1 of the done byte; compute_returns adds gamma * V_t there and clears the bit: same numbers)
  *   returns:  for t = T-1 .. 0:  nt = 1 - done_t;  delta = r_t + nt * gamma * V_{t+1} - V_t;
  *             A = delta + nt * gamma * lam * A;  R_t = A + V_t;   adv = R - V;
  *             normalize: adv = (adv - mean(adv)) / (std(adv) + 1e-8)   (unbiased std over all T * N entries)
@@ -55,13 +57,24 @@ int rl_rollout_create(int32_t num_envs, int32_t num_steps, int32_t obs_dim, int3
 /* PPO.act + the first half of RolloutStorage.add_transitions, for the current step t:
  *   obs [N][obs_dim], critic_obs [N][critic_dim], mean [N][act_dim] (actor output), std [act_dim] (the policy's noise std),
  *   values [N] (critic output)  ->  actions_out [N][act_dim] (what env.step consumes); everything is copied into slot t.
- * Fails when the storage is full (num_steps transitions recorded and not cleared). */
+ * Fails when the storage is full (num_steps transitions recorded and not cleared).
+ * `values` and `critic_obs` may each be NULL: that part of slot t is then left to rl_rollout_values_slot / rl_rollout_store_critic_obs,
+ * i.e. to a critic that runs on ANOTHER stream while this stream goes on to env.step (the actor gates the env step, the critic does not:
+ * its value is needed by the storage, the time-out bootstrap and GAE only). */
 int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, const float* mean, const float* std, const float* values,
                    float* actions_out, void* stream);
 
 /* PPO.process_env_step + the second half of add_transitions: rewards [N] f32, terminated / time_outs [N] u8 (the
  * env's RL_BUF_TERMINATED / RL_BUF_TIME_OUT); closes step t and advances to t + 1. */
 int rl_rollout_record(rl_rollout* r, const float* rewards, const uint8_t* terminated, const uint8_t* time_outs, float gamma, void* stream);
+
+/* The critic's half of step t on its own stream (call both BEFORE the step is closed by rl_rollout_record / rl_rollout_record_slots):
+ *   rl_rollout_values_slot      values [N] of the current step - hand it to rl_mlp_forward as the critic's output (out_dim 1);
+ *   rl_rollout_store_critic_obs copies critic_obs [N][critic_dim] into the current step's slot, stream-ordered on `stream`.
+ * The caller orders the streams: the critic of step t must have finished before rl_rollout_compute_returns, and before whoever
+ * overwrites critic_obs (env step t + 1 with the env's two alternating observation buffers). */
+int rl_rollout_values_slot(rl_rollout* r, float** values);
+int rl_rollout_store_critic_obs(rl_rollout* r, const float* critic_obs, void* stream);
 
 /* The same second half without a launch of its own: hands out the current step's slots (values [N] as stored by
  * rl_rollout_act, rewards [N], dones [N] u8) for a producer that writes them itself - rl_env_step_record

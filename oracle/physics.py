@@ -107,8 +107,15 @@ class Physics:
                     done.add(i)
         self.origin = arr(m.link_origin, L).astype(np.float64)
         self.axis = arr(m.link_axis, L).astype(np.float64)
+        # unit axes (fp32 components of a tilted axis are off by ~2e-9: FFTAI GR1), as csrc/rl_env_host.h does; link 0 and fixed links: zero
+        an = np.linalg.norm(self.axis, axis=1, keepdims=True)
+        self.axis = np.where(an > 0, self.axis / np.where(an > 0, an, 1.0), 0.0)
         lq = arr(m.link_quat, L).astype(np.float64)
         lq[np.abs(lq).sum(1) == 0] = [1.0, 0.0, 0.0, 0.0]  # descriptors written before link_quat existed
+        # unit quaternions: the descriptor stores fp32 components (norm off by ~3e-8), and quat_to_mat is a rotation only for a unit
+        # quaternion.  csrc/rl_env_host.h quat_to_rows normalises too; found by the fp64 lane program (tests/test_fp64_lane_program.py), which
+        # differed from this oracle by 1e-8 on the robots with rotated joint frames (G1, GR1) and by 1e-12 on the others
+        lq /= np.linalg.norm(lq, axis=1, keepdims=True)
         self.rot0 = sp.quat_to_mat(lq)  # joint frame axes in the parent link frame (URDF joint rpy)
         self.wrench_link = int(m.body_link[desc.task.base_body])  # link carrying the body the wrench event addresses
         self.body_link = arr(m.body_link, B).astype(int)

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from .desc import BUF, EnvDesc, RL_LOG_SIZE
+from .desc import BUF, REAL_C, REAL_NP, EnvDesc, RL_LOG_SIZE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, "csrc", "librl_env_hip.so")
@@ -38,11 +38,11 @@ def load_library(path: str | None = None) -> C.CDLL:
             f"{path} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
             "robot_lab_amd has no CPU fallback.")
     lib = C.CDLL(path)
-    fp = C.POINTER(C.c_float)
+    fp = C.POINTER(REAL_C)
     lib.rl_env_create.argtypes = [C.POINTER(EnvDesc), fp, fp, fp, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]
     lib.rl_env_reset.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]
     lib.rl_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.rl_env_step_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    lib.rl_env_step_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, REAL_C, C.c_void_p]
     lib.rl_env_get_buffer.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.rl_env_export_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.rl_env_commit_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -75,8 +75,8 @@ def load_library(path: str | None = None) -> C.CDLL:
 def _fptr(a):
     if a is None:
         return None
-    a = np.ascontiguousarray(a, dtype=np.float32)
-    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+    a = np.ascontiguousarray(a, dtype=REAL_NP)
+    return a, a.ctypes.data_as(C.POINTER(REAL_C))
 
 
 def plan(desc: EnvDesc, num_envs: int, n_cu: int = 256, lib_path: str | None = None) -> dict:
@@ -144,7 +144,9 @@ class NativeEnv:
         nd, es = C.c_int32(), C.c_int32()
         self._check(self.lib.rl_env_get_buffer(self.handle, BUF[name], C.byref(ptr), shape, C.byref(nd), C.byref(es)))
         shp = tuple(int(shape[i]) for i in range(nd.value))
-        dt = {1: np.uint8, 8: np.int64}.get(es.value, np.int32 if name == "TERRAIN_LEVEL" else np.float32)
+        dt = {"TERMINATED": np.uint8, "TIME_OUT": np.uint8, "EPISODE_LENGTH": np.int64, "TERRAIN_LEVEL": np.int32}.get(name, REAL_NP)
+        if np.dtype(dt).itemsize != es.value:
+            raise RlEnvError(f"buffer {name}: the library reports {es.value}-byte elements, the binding expects {np.dtype(dt)}")
         return ptr.value, shp, dt
 
     def export_state(self, stream: int = 0):
@@ -182,8 +184,8 @@ class NativeEnv:
         self._check(self.lib.rl_env_import_state(self.handle, C.c_void_p(root_ptr), C.c_void_p(qpos_ptr), C.c_void_p(qvel_ptr), C.c_void_p(stream)))
 
     def read_log(self, stream: int = 0) -> np.ndarray:
-        out = np.zeros(RL_LOG_SIZE, dtype=np.float32)
-        self._check(self.lib.rl_env_read_log(self.handle, out.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(stream)))
+        out = np.zeros(RL_LOG_SIZE, dtype=REAL_NP)
+        self._check(self.lib.rl_env_read_log(self.handle, out.ctypes.data_as(C.POINTER(REAL_C)), C.c_void_p(stream)))
         return out
 
     def log_slot(self) -> int:

@@ -18,9 +18,23 @@ import torch
 
 
 class Collector:
+    """`overlap=True`: the actor gates the env step, the critic does not - V(s_t) is needed by the storage, the time-out
+    bootstrap and GAE only.  So per step the main stream runs  actor -> act (sampling, log-prob, storage) -> env step  and a second
+    stream runs the critic of step t (privileged observations into the slot, V straight into the values slot) UNDER env step t; the
+    env kernel records the raw reward and marks time outs (rl_env_step_record with values NULL), `compute_returns` bootstraps them.
+    Ordering: critic t reads the env's observation buffer t % 2, which env step t + 1 overwrites - the main stream waits for the
+    event of critic t - 1 before env step t; everything joins before the last critic call and GAE.  Captured as one hipGraph like
+    the serial form (cross-stream events become graph edges).  `overlap=False` (default): actor + critic as one launch in front of act.
+    Measured (profiles/r06a_collect_overlap_ab.txt, one call): A1 Rough 4096 84.4 us / step serial, 102.7 overlapped; G1 2048 138.5 / 141.0 -
+    the critic's workgroups (1024 threads, > 80 KB of LDS) do not fit on a CU beside the env kernel's workgroup (one wavefront per SIMD
+    at 300+ registers, 78 KB of LDS), so nothing overlaps and the pair launch's sharing of the chip between actor and critic is lost
+    (actor alone 22.3 us + critic alone 27.6 us against 36.6 us for the pair).  Same numbers bit for bit (tests/test_gpu_collect.py)."""
+
     def __init__(self, env, actor, critic, storage, action_std: torch.Tensor, gamma: float = 0.99, lam: float = 0.95,
-                 normalize_advantage: bool = True, use_graph: bool = True, clip_actions: float | None = None):
+                 normalize_advantage: bool = True, use_graph: bool = True, clip_actions: float | None = None, overlap: bool = False):
         self.env, self.actor, self.critic, self.storage = env, actor, critic, storage
+        self.overlap = overlap
+        self._side = torch.cuda.Stream(device=env.device) if overlap else None
         self.std, self.gamma, self.lam, self.normalize = action_std, gamma, lam, normalize_advantage
         self.T = storage.num_transitions_per_env
         self.clip_actions = clip_actions  # RslRlVecEnvWrapper.step clamps what the env sees; the storage keeps the sampled action
@@ -31,6 +45,8 @@ class Collector:
         self.obs = env.get_observations()
 
     def _iteration(self, obs):
+        if self.overlap:
+            return self._iteration_overlapped(obs)
         st, env = self.storage, self.env
         st.clear()
         for _ in range(self.T):
@@ -39,6 +55,29 @@ class Collector:
             if self.clip_actions is not None:
                 actions = actions.clamp(-self.clip_actions, self.clip_actions)
             obs, _, _, _, _ = env.step(actions, rollout=st, gamma=self.gamma)
+        st.compute_returns(self.critic(obs["critic"]), self.gamma, self.lam, self.normalize)
+        return obs
+
+    def _iteration_overlapped(self, obs):
+        st, env, side = self.storage, self.env, self._side
+        main = torch.cuda.current_stream(env.device)
+        st.clear()
+        critic_done = None  # event of the critic of the previous step
+        for _ in range(self.T):
+            side.wait_stream(main)  # the observations of this step (env step t - 1) and everything before it
+            with torch.cuda.stream(side):
+                st.critic_half(self.critic, obs["critic"])
+                ev = torch.cuda.Event()
+                ev.record(side)
+            mean = self.actor(obs["policy"])
+            actions = st.act(obs["policy"], None, mean, self.std, None)
+            if self.clip_actions is not None:
+                actions = actions.clamp(-self.clip_actions, self.clip_actions)
+            if critic_done is not None:
+                main.wait_event(critic_done)  # env step t writes the observation buffer the critic of step t - 1 read
+            obs, _, _, _, _ = env.step(actions, rollout=st, gamma=self.gamma, defer_bootstrap=True)
+            critic_done = ev
+        main.wait_stream(side)
         st.compute_returns(self.critic(obs["critic"]), self.gamma, self.lam, self.normalize)
         return obs
 

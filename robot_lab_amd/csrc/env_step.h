@@ -814,10 +814,10 @@ struct EnvLane {
     }
     tim.set_own(own); hist_n.set_own(own); cf.set_own(own); fric.set_own(own);
     if constexpr (STATE_BUF) {
-      lt_b = Ctx::state_buf(ctx.uniform_ptr(S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW)), (uint32_t)LY.NF_LANE * ROW * 4u);
-      et_b = Ctx::state_buf(ctx.uniform_ptr(S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT)), (uint32_t)LY.NF_ENV * (uint32_t)EPT * 4u);
-      lt_off = 4u * (uint32_t)(ctx.env_in_tile() * NLANE + k);
-      et_off = 4u * (uint32_t)ctx.env_in_tile();
+      lt_b = Ctx::state_buf(ctx.uniform_ptr(S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW)), (uint32_t)LY.NF_LANE * ROW * (uint32_t)sizeof(float));
+      et_b = Ctx::state_buf(ctx.uniform_ptr(S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT)), (uint32_t)LY.NF_ENV * (uint32_t)EPT * (uint32_t)sizeof(float));
+      lt_off = (uint32_t)sizeof(float) * (uint32_t)(ctx.env_in_tile() * NLANE + k);
+      et_off = (uint32_t)sizeof(float) * (uint32_t)ctx.env_in_tile();
     } else {
       lt = S.lane_state + (size_t)ctx.tile() * ((size_t)LY.NF_LANE * ROW) + (uint32_t)(ctx.env_in_tile() * NLANE + k);
       et = S.env_state + (size_t)ctx.tile() * ((size_t)LY.NF_ENV * EPT) + (uint32_t)ctx.env_in_tile();
@@ -842,13 +842,13 @@ struct EnvLane {
   // lanes per env - must go into the vector offset: a divergent scalar offset is a waterfall loop per load)
   RL_FN auto LF(int f) const {
     if constexpr (STATE_BUF) {
-      const uint32_t o = (uint32_t)f * ROW * 4u;
+      const uint32_t o = (uint32_t)f * ROW * (uint32_t)sizeof(float);
       return __builtin_constant_p(f) ? BufRef{lt_b, lt_off, o} : BufRef{lt_b, lt_off + o, 0u};
     } else return PtrRef{lt + (uint32_t)f * ROW};
   }
   RL_FN auto EF(int f) const {
     if constexpr (STATE_BUF) {
-      const uint32_t o = (uint32_t)f * (uint32_t)EPT * 4u;
+      const uint32_t o = (uint32_t)f * (uint32_t)EPT * (uint32_t)sizeof(float);
       return __builtin_constant_p(f) ? BufRef{et_b, et_off, o} : BufRef{et_b, et_off + o, 0u};
     } else return PtrRef{et + (uint32_t)f * (uint32_t)EPT};
   }
@@ -1996,9 +1996,14 @@ struct EnvLane {
         const SV Vl{{w0.x, w0.y, w0.z}, {w0.w, w1.x, w1.y}};
         const SV al{{w1.z, w1.w, w2.x}, {w2.y, w2.z, w2.w}};
         const uint32_t fi = (uint32_t)(LY.LF_INERTIA + lc * INERTIA_NF);
-        const float mass = has ? LF(fi) : 0.f;
+        // (a lane without a link in this iteration - its group 0, the share of a trunk link's spheres - adds NOTHING rigid: mass AND rotational
+        // inertia zero.  Until round 6 only the mass was: the record of a trunk-link share with an active contact carried the rotational
+        // inertia of limb link 0 onto the trunk link - ~1 % of the contact forces of a robot lying on its torso, inside every fp32 envelope;
+        // found by the fp64 lane program, tests/test_fp64_lane_program.py::test_fp64_robot_on_the_ground)
+        const float hm = has ? 1.f : 0.f;
+        const float mass = hm * LF(fi);
         const V3 cb = C.p(lc) + mul(Rl, V3{LF(fi + 1), LF(fi + 2), LF(fi + 3)});
-        const SI Il = make_si(mass, cb, rotate(Rl, S3{LF(fi + 4), LF(fi + 5), LF(fi + 6), LF(fi + 7), LF(fi + 8), LF(fi + 9)}));
+        const SI Il = make_si(mass, cb, rotate(Rl, S3{hm * LF(fi + 4), hm * LF(fi + 5), hm * LF(fi + 6), hm * LF(fi + 7), hm * LF(fi + 8), hm * LF(fi + 9)}));
         add_rigid(rec, Il, Vl, al, SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
       }
       RL_PHASE(5, "sub.contact_pass1");

@@ -1521,8 +1521,13 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       S.terminated[e] = terminated ? 1 : 0;
       S.time_out[e] = time_out ? 1 : 0;
       if (S.ro_rewards != nullptr && e < S.N) {  // rl_env_step_record: the transition's second half goes straight into the rollout storage
-        S.ro_rewards[e] = rew + (time_out ? S.ro_gamma * S.ro_values[e] : 0.f);  // bootstrapping on time outs (rsl_rl PPO.process_env_step)
-        S.ro_dones[e] = (terminated || time_out) ? 1 : 0;
+        if (S.ro_values != nullptr) {
+          S.ro_rewards[e] = time_out ? fmaf(S.ro_gamma, S.ro_values[e], rew) : rew;  // bootstrapping on time outs (rsl_rl PPO.process_env_step); one explicit fma, as record_kernel / gae_kernel
+          S.ro_dones[e] = (terminated || time_out) ? 1 : 0;
+        } else {  // deferred bootstrap (values_dev == NULL: the critic of this step may still be running on another stream): the raw
+          S.ro_rewards[e] = rew;  // reward, and the time-out flag in bit 1 of the done byte - rl_rollout_compute_returns applies gamma * V there
+          S.ro_dones[e] = ((terminated || time_out) ? 1 : 0) | (time_out ? 2 : 0);
+        }
       }
     }
     if constexpr (HEAD) {  // first launch of a split step: the decision's inputs, the views, the state; step_tail() goes on from here

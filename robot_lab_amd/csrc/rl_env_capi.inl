@@ -31,7 +31,7 @@ int rl_env_step(rl_env* env, const float* action_dev, void* stream) {
 int rl_env_step_record(rl_env* env, const float* action_dev, const float* values_dev, float* rewards_out_dev, uint8_t* dones_out_dev, float gamma,
                        void* stream) {
   if (!env) return rl::fail("null env");
-  if (!values_dev || !rewards_out_dev || !dones_out_dev) return rl::fail("rollout sink needs values, rewards and dones");
+  if (!rewards_out_dev || !dones_out_dev) return rl::fail("rollout sink needs rewards and dones");  // (values_dev NULL: deferred bootstrap, include/rl_env.h)
   return reinterpret_cast<Impl*>(env)->step(action_dev, stream, values_dev, rewards_out_dev, dones_out_dev, gamma);
 }
 
@@ -39,37 +39,38 @@ int rl_env_get_buffer(rl_env* env, int32_t which, void** dev_ptr, int64_t shape[
   if (!env || !dev_ptr || !shape || !ndim || !elem_size) return rl::fail("null argument");
   Impl& I = *reinterpret_cast<Impl*>(env);
   const int64_t N = I.N, Np = I.Npad, D = I.D, B = I.B;
+  constexpr int FS = (int)sizeof(float);  // element size of the real-valued buffers
   auto set = [&](void* p, int nd, int64_t a, int64_t b, int64_t c, int es) {
     *dev_ptr = p; *ndim = nd; shape[0] = a; shape[1] = b; shape[2] = c; *elem_size = es;
     return 0;
   };
   if ((which == RL_BUF_CONTACT_FORCE || which == RL_BUF_JOINT_TORQUE || which == RL_BUF_JOINT_ACC) && I.enable_inspection()) return -1;
   switch (which) {
-    case RL_BUF_OBS_POLICY: return set(I.S.obs_policy, 2, N, I.tables.policy_dim, 1, 4);  // the slot the last step()/reset() wrote
-    case RL_BUF_OBS_CRITIC: return set(I.S.obs_critic, 2, N, I.tables.critic_dim, 1, 4);
-    case RL_BUF_OBS_POLICY_RING: return set(I.obs_ring[0][0], 3, 2, Np, I.tables.policy_dim, 4);
-    case RL_BUF_OBS_CRITIC_RING: return set(I.obs_ring[1][0], 3, 2, Np, I.tables.critic_dim, 4);
-    case RL_BUF_TASK_STATE: return set(I.task_state, 2, N, RL_TASK_STATE_NF, 1, 4);
-    case RL_BUF_GAINS: return set(I.gains, 3, N, 2, D, 4);
-    case RL_BUF_CMD_LEVELS: return set(I.S.cmd_levels, 1, rl::CL_WORDS, 1, 1, 4);
-    case RL_BUF_REWARD: return set(I.S.reward, 1, N, 1, 1, 4);
+    case RL_BUF_OBS_POLICY: return set(I.S.obs_policy, 2, N, I.tables.policy_dim, 1, FS);  // the slot the last step()/reset() wrote
+    case RL_BUF_OBS_CRITIC: return set(I.S.obs_critic, 2, N, I.tables.critic_dim, 1, FS);
+    case RL_BUF_OBS_POLICY_RING: return set(I.obs_ring[0][0], 3, 2, Np, I.tables.policy_dim, FS);
+    case RL_BUF_OBS_CRITIC_RING: return set(I.obs_ring[1][0], 3, 2, Np, I.tables.critic_dim, FS);
+    case RL_BUF_TASK_STATE: return set(I.task_state, 2, N, RL_TASK_STATE_NF, 1, FS);
+    case RL_BUF_GAINS: return set(I.gains, 3, N, 2, D, FS);
+    case RL_BUF_CMD_LEVELS: return set(I.S.cmd_levels, 1, rl::CL_WORDS, 1, 1, FS);
+    case RL_BUF_REWARD: return set(I.S.reward, 1, N, 1, 1, FS);
     case RL_BUF_TERMINATED: return set(I.S.terminated, 1, N, 1, 1, 1);
     case RL_BUF_TIME_OUT: return set(I.S.time_out, 1, N, 1, 1, 1);
     case RL_BUF_EPISODE_LENGTH: return set(I.S.ep_len, 1, N, 1, 1, 8);
-    case RL_BUF_ROOT_STATE: return set(I.root_state, 2, N, 13, 1, 4);
-    case RL_BUF_JOINT_POS: return set(I.joint_pos, 2, N, D, 1, 4);
-    case RL_BUF_JOINT_VEL: return set(I.joint_vel, 2, N, D, 1, 4);
-    case RL_BUF_REWARD_TERMS: return set(I.S.rew_terms, 2, I.tables.n_rewards, Np, 1, 4);
-    case RL_BUF_EPISODE_SUMS: return set(I.S.ep_sums, 2, I.tables.n_rewards, Np, 1, 4);
-    case RL_BUF_COMMAND: return set(I.S.command_out, 2, N, 3, 1, 4);
-    case RL_BUF_CONTACT_FORCE: return set(I.S.dbg_cforce, 3, N, B, 3, 4);
-    case RL_BUF_CONTACT_TIMERS: return set(I.ctimers, 3, N, B, 4, 4);
-    case RL_BUF_LOG: return set(I.S.log, 3, RL_LOG_RING, RL_LOG_PARTS, RL_LOG_SIZE, 4);
-    case RL_BUF_ACTION: return set(I.action_aos, 2, N, D, 1, 4);
-    case RL_BUF_JOINT_TORQUE: return set(I.S.dbg_torque, 2, N, D, 1, 4);
-    case RL_BUF_JOINT_ACC: return set(I.S.dbg_acc, 2, N, D, 1, 4);
-    case RL_BUF_ENV_ORIGIN: return set(I.env_origin_aos, 2, N, 3, 1, 4);
-    case RL_BUF_TERRAIN_LEVEL: return set(I.S.level, 1, N, 1, 1, 4);
+    case RL_BUF_ROOT_STATE: return set(I.root_state, 2, N, 13, 1, FS);
+    case RL_BUF_JOINT_POS: return set(I.joint_pos, 2, N, D, 1, FS);
+    case RL_BUF_JOINT_VEL: return set(I.joint_vel, 2, N, D, 1, FS);
+    case RL_BUF_REWARD_TERMS: return set(I.S.rew_terms, 2, I.tables.n_rewards, Np, 1, FS);
+    case RL_BUF_EPISODE_SUMS: return set(I.S.ep_sums, 2, I.tables.n_rewards, Np, 1, FS);
+    case RL_BUF_COMMAND: return set(I.S.command_out, 2, N, 3, 1, FS);
+    case RL_BUF_CONTACT_FORCE: return set(I.S.dbg_cforce, 3, N, B, 3, FS);
+    case RL_BUF_CONTACT_TIMERS: return set(I.ctimers, 3, N, B, 4, FS);
+    case RL_BUF_LOG: return set(I.S.log, 3, RL_LOG_RING, RL_LOG_PARTS, RL_LOG_SIZE, FS);
+    case RL_BUF_ACTION: return set(I.action_aos, 2, N, D, 1, FS);
+    case RL_BUF_JOINT_TORQUE: return set(I.S.dbg_torque, 2, N, D, 1, FS);
+    case RL_BUF_JOINT_ACC: return set(I.S.dbg_acc, 2, N, D, 1, FS);
+    case RL_BUF_ENV_ORIGIN: return set(I.env_origin_aos, 2, N, 3, 1, FS);
+    case RL_BUF_TERRAIN_LEVEL: return set(I.S.level, 1, N, 1, 1, (int)sizeof(int32_t));
     default: return rl::fail("unknown buffer id");
   }
 }

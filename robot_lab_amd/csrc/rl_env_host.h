@@ -106,7 +106,10 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   }
   auto fill_joint = [&](LaneTab& L, int jx, int link) {
     const int jt = link - 1;
-    for (int c = 0; c < 3; ++c) { L.origin[jx][c] = m.link_origin[link][c]; L.axis[jx][c] = m.link_axis[link][c]; }
+    // (the axis as a UNIT vector: Rodrigues' formula and the motion subspace assume one; fp32 components of a tilted axis are off by ~2e-9 -
+    // FFTAI GR1 -, which the fp64 lane program sees against the oracle; in fp32 the normalised components round to the same numbers)
+    const double an = sqrt((double)m.link_axis[link][0] * m.link_axis[link][0] + (double)m.link_axis[link][1] * m.link_axis[link][1] + (double)m.link_axis[link][2] * m.link_axis[link][2]);
+    for (int c = 0; c < 3; ++c) { L.origin[jx][c] = m.link_origin[link][c]; L.axis[jx][c] = an > 0.0 ? (float)((double)m.link_axis[link][c] / an) : 0.f; }
     quat_to_rows(m.link_quat[link], L.rot0[jx]);
     L.lower[jx] = m.joint_lower[jt]; L.upper[jx] = m.joint_upper[jt]; L.vel_limit[jx] = m.joint_vel_limit[jt];
     L.armature[jx] = m.joint_armature[jt]; L.q0[jx] = m.default_joint_pos[jt]; L.qd0[jx] = m.default_joint_vel[jt];
@@ -478,17 +481,23 @@ inline int build_tables(const rl_env_desc& d, Tables& T, std::vector<int>& body_
   }
   T.term_time_out = t.term_time_out; T.term_oob = t.term_out_of_bounds; T.term_illegal = t.term_illegal_contact;
   if (const char* tv = std::getenv("RL_ENV_TERMS"))  // RL_ENV_TERMS=0: no termination term, so no env ever resets inside step() (timing A/Bs: what the reset path costs a launch)
-    if (atoi(tv) == 0) T.term_time_out = T.term_oob = T.term_illegal = 0;
+    if (atoi(tv) == 0) {
+      T.term_time_out = T.term_oob = T.term_illegal = 0;
+      fprintf(stderr, "[rl_env] WARNING: RL_ENV_TERMS=0 - every termination term of the task is DISABLED (timing ablation): no env resets on a fall or a time-out\n");
+    }
   T.oob_buffer = t.oob_buffer; T.illegal_threshold = t.illegal_threshold; T.illegal_body_mask = t.illegal_body_mask;
   T.ev_wrench = t.ev_wrench; T.ev_reset_joints = t.ev_reset_joints; T.ev_gains = t.ev_gains; T.ev_reset_base = t.ev_reset_base; T.ev_push = t.ev_push;
-  memcpy(T.wrench_force, t.wrench_force, 8); memcpy(T.wrench_torque, t.wrench_torque, 8);
-  memcpy(T.reset_jpos, t.reset_joint_pos_scale, 8); memcpy(T.reset_jvel, t.reset_joint_vel_scale, 8);
-  memcpy(T.gain_kp, t.gain_kp_scale, 8); memcpy(T.gain_kd, t.gain_kd_scale, 8);
+  memcpy(T.wrench_force, t.wrench_force, sizeof(T.wrench_force)); memcpy(T.wrench_torque, t.wrench_torque, sizeof(T.wrench_torque));
+  memcpy(T.reset_jpos, t.reset_joint_pos_scale, sizeof(T.reset_jpos)); memcpy(T.reset_jvel, t.reset_joint_vel_scale, sizeof(T.reset_jvel));
+  memcpy(T.gain_kp, t.gain_kp_scale, sizeof(T.gain_kp)); memcpy(T.gain_kd, t.gain_kd_scale, sizeof(T.gain_kd));
   memcpy(T.reset_pose, t.reset_pose, sizeof(T.reset_pose)); memcpy(T.reset_vel, t.reset_vel, sizeof(T.reset_vel));
-  memcpy(T.push_interval, t.push_interval, 8); memcpy(T.push_vel, t.push_vel, sizeof(T.push_vel));
-  memcpy(T.default_root_pos, m.default_root_pos, 12); memcpy(T.default_root_quat, m.default_root_quat, 16);
+  memcpy(T.push_interval, t.push_interval, sizeof(T.push_interval)); memcpy(T.push_vel, t.push_vel, sizeof(T.push_vel));
+  memcpy(T.default_root_pos, m.default_root_pos, sizeof(T.default_root_pos)); memcpy(T.default_root_quat, m.default_root_quat, sizeof(T.default_root_quat));
   if (const char* iv = std::getenv("RL_ENV_INTERVALS"))  // RL_ENV_INTERVALS=0: no push event, no command resampling between resets (timing A/Bs: what the interval events cost a launch)
-    if (atoi(iv) == 0) { T.ev_push = 0; T.cmd_resample[0] = T.cmd_resample[1] = 1e9f; }
+    if (atoi(iv) == 0) {
+      T.ev_push = 0; T.cmd_resample[0] = T.cmd_resample[1] = 1e9f;
+      fprintf(stderr, "[rl_env] WARNING: RL_ENV_INTERVALS=0 - the push event and the command resampling between resets are DISABLED (timing ablation)\n");
+    }
   return 0;
 }
 
@@ -638,8 +647,8 @@ struct EnvImpl {
       terrain_dev = alloc<float>(nh);
       terrain_origins_dev = alloc<float>((size_t)desc.terrain.num_rows * desc.terrain.num_cols * 3);
       if (alloc_failed) return fail("device allocation failed (terrain): " + be.error());
-      be.h2d(terrain_dev, terrain_heights, nh * 4);
-      be.h2d(terrain_origins_dev, terrain_origins, (size_t)desc.terrain.num_rows * desc.terrain.num_cols * 12);
+      be.h2d(terrain_dev, terrain_heights, nh * sizeof(float));
+      be.h2d(terrain_origins_dev, terrain_origins, (size_t)desc.terrain.num_rows * desc.terrain.num_cols * 3 * sizeof(float));
     } else {
       if (!env_origins) return fail("plane terrain needs env_origins");
       // a one-tile origin table of zeros: reset_env (env_terms.h) reads its tile's origin without a branch on the terrain type, and selects
@@ -777,9 +786,9 @@ struct EnvImpl {
       env[env_index(ly, e, ly.EF_ROOT + 3, ept)] = 1.f;  // identity quaternion until the first reset
       for (int a = 0; a < 3; ++a) env[env_index(ly, e, ly.EF_ROOT + a, ept)] = env[env_index(ly, e, ly.EF_ORIGIN + a, ept)] + m.default_root_pos[a];
     }
-    be.h2d(S.lane_state, lane.data(), lane.size() * 4);
-    be.h2d(S.env_state, env.data(), env.size() * 4);
-    be.h2d(S.level, level.data(), level.size() * 4); be.h2d(S.ttype, ttype.data(), ttype.size() * 4);
+    be.h2d(S.lane_state, lane.data(), lane.size() * sizeof(lane[0]));
+    be.h2d(S.env_state, env.data(), env.size() * sizeof(env[0]));
+    be.h2d(S.level, level.data(), level.size() * sizeof(level[0])); be.h2d(S.ttype, ttype.data(), ttype.size() * sizeof(ttype[0]));
   }
 
   // The inspection views (applied torque, joint acceleration, net contact force per body) cost 75 extra
@@ -827,7 +836,7 @@ struct EnvImpl {
   int step(const float* action_dev, void* stream, const float* ro_values = nullptr, float* ro_rewards = nullptr, uint8_t* ro_dones = nullptr,
            float ro_gamma = 0.f) {
     if (!action_dev) return fail("action pointer is null");
-    if ((ro_values || ro_rewards || ro_dones) && !(ro_values && ro_rewards && ro_dones)) return fail("rollout sink needs values, rewards and dones");
+    if ((ro_values || ro_rewards || ro_dones) && !(ro_rewards && ro_dones)) return fail("rollout sink needs rewards and dones (values may be NULL: deferred bootstrap)");
     if (be.activate()) return fail("device activation failed: " + be.error());
     KState s = S;
     s.step_counter = ++step_counter - anchor;
@@ -902,9 +911,9 @@ struct EnvImpl {
   // host arrays -> export, overwrite the given parts, commit (include/rl_env.h rl_env_import_state)
   int import_state(const float* r, const float* q, const float* qd, void* stream) {
     if (export_state(stream)) return -1;
-    if (r) be.h2d_stream(root_state, r, (size_t)N * 13 * 4, stream);
-    if (q) be.h2d_stream(joint_pos, q, (size_t)N * D * 4, stream);
-    if (qd) be.h2d_stream(joint_vel, qd, (size_t)N * D * 4, stream);
+    if (r) be.h2d_stream(root_state, r, (size_t)N * 13 * sizeof(float), stream);
+    if (q) be.h2d_stream(joint_pos, q, (size_t)N * D * sizeof(float), stream);
+    if (qd) be.h2d_stream(joint_vel, qd, (size_t)N * D * sizeof(float), stream);
     return commit_state(stream);
   }
 

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
     return;
   }
   b -= a.copy_blocks_obs;
-  if (b < a.copy_blocks_critic) {
+  if (b < a.copy_blocks_critic) {  // (0 blocks when critic_obs is NULL: rl_rollout_store_critic_obs copies the row on the critic's stream)
     stream_copy(a.critic_obs, a.s_critic, (size_t)a.N * a.critic_dim, b, a.copy_blocks_critic);
     return;
   }
@@ -129,8 +129,12 @@ __global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
     float s = 0.f;
     for (int i = 0; i < nblk; ++i) s += part[threadIdx.x + i];  // fixed order: blocks 0, 1, ...
     a.s_logp[e] = s;
-    a.s_values[e] = a.values[e];
+    if (a.values != nullptr) a.s_values[e] = a.values[e];  // (NULL: the critic writes the slot itself, rl_rollout_values_slot)
   }
+}
+
+__global__ __launch_bounds__(BLOCK) void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  stream_copy(src, dst, n, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(BLOCK) void record_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ terminated,
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void record_kernel(const float* __restrict__
   const int e = blockIdx.x * BLOCK + threadIdx.x;
   if (e >= N) return;
   const bool to = time_outs[e] != 0;
-  s_rewards[e] = rewards[e] + (to ? gamma * s_values[e] : 0.f);  // bootstrapping on time outs
+  s_rewards[e] = to ? fmaf(gamma, s_values[e], rewards[e]) : rewards[e];  // bootstrapping on time outs (one explicit fma in all three places that do it)
   s_dones[e] = (terminated[e] != 0 || to) ? 1 : 0;
 }
 
@@ -156,8 +160,8 @@ __device__ inline double block_sum(double v, double* sh) {
   return r;
 }
 
-__global__ __launch_bounds__(BLOCK) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
-                                                    const uint8_t* __restrict__ dones, const float* __restrict__ last_values,
+__global__ __launch_bounds__(BLOCK) void gae_kernel(float* __restrict__ rewards, const float* __restrict__ values,
+                                                    uint8_t* __restrict__ dones, const float* __restrict__ last_values,
                                                     float* __restrict__ returns, float* __restrict__ adv, double* __restrict__ partial, float gamma,
                                                     float lam, int T, int N) {
   __shared__ double sh[BLOCK];
@@ -168,8 +172,15 @@ __global__ __launch_bounds__(BLOCK) void gae_kernel(const float* __restrict__ re
     for (int t = T - 1; t >= 0; --t) {
       const size_t i = (size_t)t * N + e;
       const float v = values[i];
-      const float nt = dones[i] ? 0.f : 1.f;
-      const float delta = rewards[i] + nt * gamma * next_v - v;
+      const uint8_t d = dones[i];
+      float r = rewards[i];
+      if (d & 2) {  // deferred bootstrap on a time out (rl_env_step_record with values NULL): the same expression record_kernel / the env kernel evaluate
+        r = fmaf(gamma, v, r);
+        rewards[i] = r;
+        dones[i] = 1;
+      }
+      const float nt = d ? 0.f : 1.f;
+      const float delta = r + nt * gamma * next_v - v;
       a = delta + nt * gamma * lam * a;
       const float ret = a + v;
       returns[i] = ret;
@@ -302,7 +313,7 @@ int rl_rollout_create(int32_t num_envs, int32_t num_steps, int32_t obs_dim, int3
 
 int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, const float* mean, const float* std, const float* values,
                    float* actions_out, void* stream) {
-  if (!r || !obs || !critic_obs || !mean || !std || !values || !actions_out) return fail("NULL argument");
+  if (!r || !obs || !mean || !std || !actions_out) return fail("NULL argument");  // (critic_obs / values may be NULL: include/rl_rollout.h)
   if (r->step >= r->T) return fail("rollout storage overflow: call rl_rollout_clear after num_steps transitions");
   if (r->acted) return fail("rl_rollout_act called twice without rl_rollout_record");
   HIP_OK(hipSetDevice(r->device));
@@ -315,7 +326,7 @@ int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, con
   a.N = r->N; a.obs_dim = r->obs_dim; a.critic_dim = r->critic_dim; a.act_dim = r->act_dim; a.seed = r->seed; a.counter_base = r->counter_base; a.counter = r->counter - r->anchor;
   // 4 float4 per thread of the copy blocks
   a.copy_blocks_obs = std::max(1, blocks_for(((size_t)r->N * r->obs_dim) >> 4));
-  a.copy_blocks_critic = std::max(1, blocks_for(((size_t)r->N * r->critic_dim) >> 4));
+  a.copy_blocks_critic = critic_obs ? std::max(1, blocks_for(((size_t)r->N * r->critic_dim) >> 4)) : 0;
   const int envs_per_block = BLOCK / ((r->act_dim + 3) / 4);
   a.sample_blocks = (r->N + envs_per_block - 1) / envs_per_block;
   hipLaunchKernelGGL(act_kernel, dim3(a.copy_blocks_obs + a.copy_blocks_critic + a.sample_blocks), dim3(BLOCK), 0, (hipStream_t)stream, a);
@@ -335,6 +346,23 @@ int rl_rollout_record(rl_rollout* r, const float* rewards, const uint8_t* termin
   r->acted = false;
   r->step += 1;
   r->counter += 1;
+  return 0;
+}
+
+int rl_rollout_values_slot(rl_rollout* r, float** values) {
+  if (!r || !values) return fail("NULL argument");
+  if (r->step >= r->T) return fail("rollout storage overflow: call rl_rollout_clear after num_steps transitions");
+  *values = slot<float>(r, RL_RO_VALUES, r->step);
+  return 0;
+}
+
+int rl_rollout_store_critic_obs(rl_rollout* r, const float* critic_obs, void* stream) {
+  if (!r || !critic_obs) return fail("NULL argument");
+  if (r->step >= r->T) return fail("rollout storage overflow: call rl_rollout_clear after num_steps transitions");
+  HIP_OK(hipSetDevice(r->device));
+  const size_t n = (size_t)r->N * r->critic_dim;
+  hipLaunchKernelGGL(copy_kernel, dim3(std::max(1, blocks_for(n >> 4))), dim3(BLOCK), 0, (hipStream_t)stream, critic_obs, slot<float>(r, RL_RO_CRITIC_OBS, r->step), n);
+  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -358,8 +386,8 @@ int rl_rollout_compute_returns(rl_rollout* r, const float* last_values, float ga
   hipStream_t s = (hipStream_t)stream;
   const int nb = blocks_for((size_t)r->N);
   const size_t count = (size_t)r->T * r->N;
-  hipLaunchKernelGGL(gae_kernel, dim3(nb), dim3(BLOCK), 0, s, (const float*)r->buf[RL_RO_REWARDS], (const float*)r->buf[RL_RO_VALUES],
-                     (const uint8_t*)r->buf[RL_RO_DONES], last_values, (float*)r->buf[RL_RO_RETURNS], (float*)r->buf[RL_RO_ADVANTAGES], r->partial_sum,
+  hipLaunchKernelGGL(gae_kernel, dim3(nb), dim3(BLOCK), 0, s, (float*)r->buf[RL_RO_REWARDS], (const float*)r->buf[RL_RO_VALUES],
+                     (uint8_t*)r->buf[RL_RO_DONES], last_values, (float*)r->buf[RL_RO_RETURNS], (float*)r->buf[RL_RO_ADVANTAGES], r->partial_sum,
                      gamma, lam, r->T, r->N);
   if (normalize_advantage) {
     const int nbv = std::min(256, std::max(1, blocks_for(count >> 2)));  // every thread re-sums the partials: keep them few

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import os
 
 import numpy as np
 
@@ -54,7 +55,12 @@ TASK_STATE = dict(CMD=slice(0, 3), HEADING_TARGET=3, CMD_TIME_LEFT=4, METRIC_XY=
                   IS_HEADING_ENV=8, IS_STANDING_ENV=9, EXT_FORCE=slice(10, 13), EXT_TORQUE=slice(13, 16))
 RL_TASK_STATE_NF = 16
 
-f32, i32, u32, u64 = C.c_float, C.c_int32, C.c_uint32, C.c_uint64
+# The reals of the C-ABI are `float` (include/rl_env.h).  RL_ABI_REAL=f64 mirrors the header of the fp64 instantiation of the CPU lane
+# emulator instead (tests/emu/make_f64.py retypes a copy of the sources: test infrastructure, its own process).  The product library's
+# rl_env_desc_size() then disagrees with this mirror and capi.load_library refuses it.
+REAL_F64 = os.environ.get("RL_ABI_REAL", "f32") == "f64"
+REAL_C, REAL_NP = (C.c_double, np.float64) if REAL_F64 else (C.c_float, np.float32)
+f32, i32, u32, u64 = REAL_C, C.c_int32, C.c_uint32, C.c_uint64
 
 
 class RewardTerm(C.Structure):

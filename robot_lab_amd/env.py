@@ -328,10 +328,11 @@ class ManagerBasedRLEnv(_EnvBase):
         self.extras = {}
         return self._obs, self.extras
 
-    def step(self, action: torch.Tensor, rollout=None, gamma: float = 0.99):
+    def step(self, action: torch.Tensor, rollout=None, gamma: float = 0.99, defer_bootstrap: bool = False):
         """`rollout`: a `robot_lab_amd.rollout.RolloutStorage` whose `act()` produced `action` - the env kernel then also
         writes the transition's rewards (+ time-out bootstrap) and dones into its current slot (`rl_env_step_record`), i.e.
-        `rollout.process_env_step(...)` without a launch of its own."""
+        `rollout.process_env_step(...)` without a launch of its own.  `defer_bootstrap`: the values of this step are not
+        needed here (the critic may still be running on another stream); `rollout.compute_returns` bootstraps the time outs."""
         if action.device != self._bufs["REWARD"].device or action.dtype != torch.float32 or not action.is_contiguous():
             action = action.to(device=self.device, dtype=torch.float32).contiguous()
         if action.shape != (self.num_envs, self.num_actions):
@@ -340,7 +341,7 @@ class ManagerBasedRLEnv(_EnvBase):
             self._native.step(action.data_ptr(), self._stream())
         else:
             v, r, d = rollout.record_slots()
-            self._native.step_record(action.data_ptr(), v, r, d, gamma, self._stream())
+            self._native.step_record(action.data_ptr(), 0 if defer_bootstrap else v, r, d, gamma, self._stream())
         self.common_step_counter += 1
         self._obs = self._obs_slots[self._native.obs_slot()]
         if self.log_episodes:  # no snapshot, no memset: views of this step's ring slot and its predecessor, read only if somebody asks

@@ -136,6 +136,13 @@ class MlpPolicy:
             raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
         return self._out
 
+    def forward_into(self, obs, out_ptr: int):
+        """self(obs) written to the device address `out_ptr` ([N, out_dim] fp32, e.g. the values slot of a rollout storage)."""
+        obs, n = self._prepare(obs)
+        stream = self._torch.cuda.current_stream(self.device).cuda_stream
+        if self.lib.rl_mlp_forward(self.handle, C.c_void_p(obs.data_ptr()), C.c_void_p(out_ptr), n, C.c_void_p(stream)) != 0:
+            raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.rl_mlp_destroy(self.handle)

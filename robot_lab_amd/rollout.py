@@ -17,7 +17,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROLLOUT_LIB = os.path.join(_HERE, "csrc", "librl_rollout_hip.so")
-ROLLOUT_EXPORTS = ["rl_rollout_create", "rl_rollout_act", "rl_rollout_record", "rl_rollout_record_slots", "rl_rollout_compute_returns", "rl_rollout_clear",
+ROLLOUT_EXPORTS = ["rl_rollout_create", "rl_rollout_act", "rl_rollout_record", "rl_rollout_record_slots", "rl_rollout_values_slot", "rl_rollout_store_critic_obs", "rl_rollout_compute_returns", "rl_rollout_clear",
                    "rl_rollout_get_buffer", "rl_rollout_step", "rl_rollout_destroy", "rl_rollout_last_error",
                    "rl_rollout_graph_begin", "rl_rollout_graph_end", "rl_rollout_graph_launching"]
 # name -> (rl_rollout_buffer id, dtype, has a trailing feature dim)
@@ -45,6 +45,8 @@ def load_rollout_library(path: str | None = None) -> C.CDLL:
     lib.rl_rollout_act.argtypes = [vp] * 8
     lib.rl_rollout_record.argtypes = [vp, vp, vp, vp, C.c_float, vp]
     lib.rl_rollout_record_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.rl_rollout_values_slot.argtypes = [vp, C.POINTER(vp)]
+    lib.rl_rollout_store_critic_obs.argtypes = [vp, vp, vp]
     lib.rl_rollout_compute_returns.argtypes = [vp, vp, C.c_float, C.c_float, C.c_int32, vp]
     lib.rl_rollout_clear.argtypes = [vp]
     for n in ("rl_rollout_graph_begin", "rl_rollout_graph_end", "rl_rollout_graph_launching"):
@@ -113,12 +115,26 @@ class RolloutStorage:
 
     # -- PPO.act: actions = mean + std * eps; log-prob; first half of add_transitions
     def act(self, obs, privileged_obs, action_mean, action_std, values):
+        """`privileged_obs` / `values` None: the critic's half of the slot is written on the critic's own stream
+        (`critic_half`; include/rl_rollout.h)."""
         N, A = self.num_envs, self.actions.shape[-1]
-        args = [self._f32(obs, (N, self.observations.shape[-1])), self._f32(privileged_obs, (N, self.privileged_observations.shape[-1])),
-                self._f32(action_mean, (N, A)), self._f32(action_std, (A,)), self._f32(values.view(-1), (N,)), self._p(self._actions)]
+        args = [self._f32(obs, (N, self.observations.shape[-1])),
+                None if privileged_obs is None else self._f32(privileged_obs, (N, self.privileged_observations.shape[-1])),
+                self._f32(action_mean, (N, A)), self._f32(action_std, (A,)), None if values is None else self._f32(values.view(-1), (N,)), self._p(self._actions)]
         if self.lib.rl_rollout_act(self.handle, *args, self._stream()) != 0:
             raise RlRolloutError(self._err())
         return self._actions
+
+    def critic_half(self, critic, privileged_obs):
+        """The critic's half of the current step on the CURRENT torch stream (robot_lab_amd/collect.py calls it under a side stream):
+        the privileged observations go into the slot, `critic` (an MlpPolicy with one output) writes V straight into the values slot."""
+        N = self.num_envs
+        v = C.c_void_p()
+        if self.lib.rl_rollout_values_slot(self.handle, C.byref(v)) != 0:
+            raise RlRolloutError(self._err())
+        if self.lib.rl_rollout_store_critic_obs(self.handle, self._f32(privileged_obs, (N, self.privileged_observations.shape[-1])), self._stream()) != 0:
+            raise RlRolloutError(self._err())
+        critic.forward_into(privileged_obs, v.value)
 
     # -- PPO.process_env_step: time-out bootstrapping, dones; second half of add_transitions
     def process_env_step(self, rewards, terminated, time_outs, gamma: float):

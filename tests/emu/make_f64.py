@@ -1,0 +1,78 @@
+"""fp64 instantiation of the env-step lane program on the CPU lane emulator.  TEST INFRASTRUCTURE ONLY.
+
+The lane program (robot_lab_amd/csrc/env_step.h, env_terms.h, ...) is written in `float`.  This script retypes a COPY of the
+sources the emulator library is made of - every `float` becomes `double`, float literals lose their `f`, the libm calls lose theirs -
+into tests/emu/_f64/ (git-ignored) and builds tests/emu/librl_env_emu_f64.so from it with g++: the same program, statement for
+statement, evaluated in double precision, behind the same C-ABI with 8-byte reals (robot_lab_amd/desc.py mirrors it under
+RL_ABI_REAL=f64).  tests/test_fp64_lane_program.py steps it from a shared state against the fp64 oracle: what is left between the
+two is ALGORITHM (the articulated-body recursion in base coordinates vs the oracle's dense solve in link coordinates), not
+round-off - the question VERDICT r5 item 1 asks.  Nothing in the product path reads this file or its output.
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_f64")
+LIB = os.path.join(HERE, "librl_env_emu_f64.so")
+CSRC_FILES = ["rl_math.h", "env_tables.h", "env_step.h", "env_terms.h", "env_aos.h", "rl_env_host.h", "rl_env_capi.inl", "env_spec.h",
+              "rl_env_specgen.h", os.path.join("spec", "env_specs_gen.h")]
+SOURCES = [os.path.join("include", "rl_env.h"), os.path.join("tests", "emu", "rl_env_emu.cpp")] + [os.path.join("robot_lab_amd", "csrc", f) for f in CSRC_FILES]
+
+# libm's single-precision entry points the lane program calls -> their double forms
+LIBM = ["fminf", "fmaxf", "fabsf", "floorf", "ceilf", "fmaf", "atan2f", "sqrtf", "sinf", "cosf", "expf", "tanhf", "copysignf", "roundf", "truncf", "logf", "powf", "acosf", "asinf"]
+_DEC = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?)[fF]\b")
+_HEX = re.compile(r"(?<![\w.])(0[xX][0-9a-fA-F]*\.?[0-9a-fA-F]*[pP][-+]?\d+)[fF]\b")
+
+
+def retype(text: str) -> str:
+    text = _HEX.sub(r"\1", text)
+    text = _DEC.sub(lambda m: m.group(1) if re.search(r"[.eE]", m.group(1)) else m.group(1) + ".0", text)
+    text = re.sub(r"\bfloat\b", "double", text)
+    for f in LIBM:
+        text = re.sub(rf"\b{f}\b", f[:-1], text)
+    return text
+
+
+def generate() -> list[str]:
+    made = []
+    for rel in SOURCES:
+        src, dst = os.path.join(ROOT, rel), os.path.join(OUT, rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        new = retype(open(src).read())
+        if not os.path.isfile(dst) or open(dst).read() != new:
+            with open(dst, "w") as f:
+                f.write(new)
+        made.append(dst)
+    return made
+
+
+def stale() -> bool:
+    if not os.path.isfile(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(ROOT, rel)) > t for rel in SOURCES) or os.path.getmtime(__file__) > t
+
+
+def build(force: bool = False, only: str | None = None) -> str:
+    """-> path of the fp64 emulator library (built when missing or older than its sources).  `only`: RL_EMU_ONLY code of the one lane
+    program to instantiate (tests/emu/rl_env_emu.cpp), for a quick build."""
+    if not force and not stale():
+        return LIB
+    generate()
+    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-shared", "-fPIC", "-DRL_REAL_F64=1", "-ffp-contract=off"]
+    if only:
+        cmd.append(f"-DRL_EMU_ONLY={only}")
+    cmd += ["-o", LIB, os.path.join(OUT, "tests", "emu", "rl_env_emu.cpp")]
+    print("[f64]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, only=next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")), None))
+    print(LIB)

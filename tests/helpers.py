@@ -85,7 +85,7 @@ def emu_read_state(nat):
 def emu_load_state(nat, s):
     nat.export_state()
     for k in STATE_BUFFERS:
-        host_view(nat, k)[...] = np.asarray(s[k.lower()], dtype=np.float32).reshape(host_view(nat, k).shape)
+        host_view(nat, k)[...] = np.asarray(s[k.lower()], dtype=host_view(nat, k).dtype).reshape(host_view(nat, k).shape)  # (fp32; fp64 in the retyped emulator build)
     host_view(nat, "EPISODE_LENGTH")[...] = s["episode_length"]
     host_view(nat, "EPISODE_SUMS")[:, : nat.num_envs] = s["episode_sums"]
     host_view(nat, "TERRAIN_LEVEL")[...] = s["terrain_level"]

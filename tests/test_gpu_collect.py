@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 TASK = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
 
 
-def _setup(use_graph, N=256, T=24):
+def _setup(use_graph, N=256, T=24, overlap=False):
     import torch
 
     from robot_lab_amd.collect import Collector
@@ -29,14 +29,17 @@ def _setup(use_graph, N=256, T=24):
     actor, critic = net([od, 512, 256, 128, A]), net([cd, 512, 256, 128, 1])
     storage = RolloutStorage(N, T, od, cd, A, seed=3, device="cuda:0")
     std = torch.full((A,), 0.5, device="cuda:0")
-    return env, storage, Collector(env, actor, critic, storage, std, use_graph=use_graph)
+    return env, storage, Collector(env, actor, critic, storage, std, use_graph=use_graph, overlap=overlap)
 
 
-def test_graph_replay_matches_eager_iterations():
+@pytest.mark.parametrize("overlap", [True, False])
+def test_graph_replay_matches_eager_iterations(overlap):
+    """`overlap`: the critic of step t on a second stream under env step t, time outs bootstrapped by compute_returns (the default);
+    False: actor + critic as one launch in front of act."""
     import torch
 
-    env_e, st_e, eager = _setup(False)
-    env_g, st_g, graph = _setup(True)
+    env_e, st_e, eager = _setup(False, overlap=overlap)
+    env_g, st_g, graph = _setup(True, overlap=overlap)
     for it in range(4):  # iteration 0 of the graphed collector is eager + capture, 1.. are replays
         oe, og = eager.collect(), graph.collect()
         torch.cuda.synchronize()
@@ -63,4 +66,30 @@ def test_graph_replay_matches_eager_iterations():
     torch.cuda.synchronize()
     assert torch.equal(st_e.actions, st_g.actions) and torch.equal(st_e.advantages, st_g.advantages)
     for e in (env_e, env_g):
+        e.close()
+
+
+def test_overlapped_collection_equals_the_serial_one():
+    """The critic off the critical path changes WHEN things run, not what is computed: same seeds -> the storage of the overlapped
+    collector (graph replays included) equals the serial collector's bit for bit, time-out bootstraps included (N = 256 envs with
+    episode clocks spread so that several envs time out inside the 24 steps)."""
+    import torch
+
+    env_s, st_s, serial = _setup(True, overlap=False)
+    env_o, st_o, over = _setup(True, overlap=True)
+    for env in (env_s, env_o):
+        ep = torch.arange(env.num_envs) % 50
+        ep[::7] = env.max_episode_length - 1 - (torch.arange(len(ep[::7])) % 60)
+        env.episode_length_buf = ep
+    timeouts = 0
+    for it in range(3):
+        serial.collect(), over.collect()
+        torch.cuda.synchronize()
+        for name in ("observations", "privileged_observations", "actions", "mu", "actions_log_prob", "values", "rewards", "dones", "returns", "advantages"):
+            a, b = getattr(st_s, name), getattr(st_o, name)
+            assert torch.equal(a, b), f"iteration {it}: {name} differs (max |d| {float((a.float() - b.float()).abs().max()):.3e})"
+        assert int(st_o.dones.view(torch.uint8).max()) <= 1  # the time-out marks (bit 1) are gone after compute_returns
+        timeouts += int(st_o.dones.sum())
+    assert timeouts > 0
+    for e in (env_s, env_o):
         e.close()

@@ -111,7 +111,9 @@ def test_short_horizon_parity(task, wg, merge, monkeypatch):
     two.close("root", d.root_state_w.cpu().numpy(), oracle_root_state, kf * 2e-3, kf * 2e-4)
     two.close("q", d.joint_pos.cpu().numpy(), lambda e: e.st["q"], kf * 2e-3, kf * 2e-4)
     two.close("qd", d.joint_vel.cpu().numpy(), lambda e: e.st["qd"], kf * 5e-3, kf * 5e-3)
-    two.close("rew_terms", env.reward_terms().cpu().numpy(), lambda e: e.reward_terms, 2e-3, 2e-5)
+    # (round 6: GR1's factor on the reward terms as well - Flat GR1T1, sub8, one entry of 512 at 1.4e-4 against 1.0e-4 after the joint axes
+    # became unit vectors in the tables; the fp64 lane program agrees with the oracle to 1e-13 on this robot, tests/test_fp64_lane_program.py)
+    two.close("rew_terms", env.reward_terms().cpu().numpy(), lambda e: e.reward_terms, kf * 2e-3, kf * 2e-5)
     two.close("policy", obs["policy"].cpu().numpy(), lambda e: e.obs_policy, 5e-3, 5e-3)
     two.close("critic", obs["critic"].cpu().numpy(), lambda e: e.obs_critic, 5e-3, 5e-3)
     # teacher forced: one more step, both from the state the HIP env is in now

@@ -83,7 +83,9 @@ def test_one_step_from_shared_state(task, N, K, emu_lib):
 @pytest.mark.parametrize("task,merge", [("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", None), ("RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0", "0"),
                                         ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", None), ("RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0", None),
                                         ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", None),  # G1: torso on the ground = illegal_contact -> terminated, is_terminated reward
-                                        ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", "sub8")])  # ... and in the 32-lane mapping (group 0 = the trunk share, sub-lane 0)
+                                        ("RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0", "sub8"),  # ... and in the 32-lane mapping (group 0 = the trunk share, sub-lane 0)
+                                        ("RobotLab-Isaac-Velocity-Rough-Booster-T1-v0", "sub8"),     # the base body itself + the head on the second trunk piece
+                                        ("RobotLab-Isaac-Velocity-Rough-FFTAI-GR1T1-v0", "sub8")])
 def test_one_step_with_the_trunk_on_the_ground(task, merge, emu_lib, monkeypatch):
     """Robots lying on their backs in the 16-lanes-per-env mapping: the TRUNK's collision spheres carry the robot - the contacts
     random-action warm-ups rarely reach.  On the merged 4-joint instance those spheres sit in flagged slots
