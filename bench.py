@@ -212,7 +212,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.task}, {N} envs/GPU, random actions U(-1,1), seed 42+rank", "envs_per_gpu": N,
-                   "parallelism": f"env-shard x{world}"},
+                   "parallelism": f"env-shard x{world}",
+                   # which step kernel ran: the one specialised on this task (csrc/env_spec.h, id of tools/gen_specs.py) or the term-stack interpreter
+                   "step_kernel": env.step_kernel,
+                   "envs_per_wavefront": env._native.envs_per_wavefront()},
         "rccl_ranks": dist.get_world_size() if use_dist else 1, "collective_backend": ("gloo (RL_BENCH_SHARE_GPU self-test)" if share else "nccl (RCCL)") if use_dist else None,
         "per_rank_env_steps_per_s": per_rank, "envs_behind_reduced_log": float(log_vec[LOG_SLOT_NUM_ENVS]),
         "window": {"envs_reset_in_window": envs_reset, "mean_bodies_in_contact_at_end": bodies_in_contact,
@@ -403,7 +406,27 @@ def cpu_baseline(task, n_envs, budget_s, oracle_envs, oracle_steps):
             "logical_cpus_available": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
             "cgroup_cpu_quota": cpu_quota(),
             "oracle": {"value": oracle_envs * oracle_steps / odt, "unit": "env-steps/s", "cores": 1, "kind": "oracle",
-                       "sample": f"{oracle_envs} envs x {oracle_steps} steps, fp64 numpy oracle (oracle/env.py), single process"}}
+                       "sample": f"{oracle_envs} envs x {oracle_steps} steps, fp64 numpy oracle (oracle/env.py), single process"},
+            "reference_terms_cpu": reference_terms_offline(task)}
+
+
+def reference_terms_offline(task):
+    """The part of the REFERENCE that runs without IsaacLab - its own VEL/mdp reward + observation term functions on torch CPU, term stack
+    ONLY (no physics, sensors, managers) - timed in the build container by tools/time_reference_terms.py and committed: /root/reference does
+    not exist on the GPU box, so this figure is quoted from the file, never measured here, and it is an upper bound of a CPU reference path."""
+    import json
+
+    path = os.path.join(ROOT, "profiles", "r06_reference_terms_cpu.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if d.get("task") != task:
+        return None
+    return {"value": d["value"], "unit": d["unit"], "cores": d["threads"], "kind": "reference (term stack only)", "measured": "offline: " + d["host"],
+            "sample": f"{d['num_envs']} envs, {d['calls']} calls of the {d['reward_terms']} reward + {d['observation_terms']} observation term functions in {d['seconds']:.1f} s "
+                      f"({d['ms_per_term_stack_call']:.2f} ms per call), torch {d['torch']} CPU fp32", "source": "profiles/r06_reference_terms_cpu.json"}
 
 
 if __name__ == "__main__":

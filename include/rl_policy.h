@@ -45,6 +45,12 @@ int rl_mlp_set_weights(rl_mlp* m, const float* const* weights, const float* cons
 /* y[n_rows][dims[n_layers]] = MLP(x[n_rows][dims[0]]); x, y: device pointers, row-major; stream-ordered. */
 int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream);
 
+/* The same result from the SMALL-FOOTPRINT launch: 16 rows per workgroup of four wavefronts, exact-f32 MFMA (v_mfma_f32_16x16x4_f32), 140
+ * registers per lane and 64 KB of LDS - sized to run on a CU BESIDE another kernel's resident workgroup (the env-step kernel of 4096
+ * quadruped envs leaves 200 registers per SIMD and 83 KB of LDS per CU): the critic of a rollout step on a second stream under the env
+ * step (robot_lab_amd/collect.py).  Slower than rl_mlp_forward when it has the chip to itself; agrees with it to fp32 round-off. */
+int rl_mlp_forward_small(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream);
+
 /* Two networks over the same n_rows rows in one launch (the actor and the critic of a rollout step,
  * train.py:206-224 -> rsl_rl PPO.act: `policy.act(obs)` and `policy.evaluate(privileged_obs)` back to back):
  * ya = A(xa), yb = B(xb).  Same results as two rl_mlp_forward calls; the two networks' workgroups share the CUs. */

@@ -25,15 +25,19 @@ class Collector:
     Ordering: critic t reads the env's observation buffer t % 2, which env step t + 1 overwrites - the main stream waits for the
     event of critic t - 1 before env step t; everything joins before the last critic call and GAE.  Captured as one hipGraph like
     the serial form (cross-stream events become graph edges).  `overlap=False` (default): actor + critic as one launch in front of act.
-    Measured (profiles/r06a_collect_overlap_ab.txt, one call): A1 Rough 4096 84.4 us / step serial, 102.7 overlapped; G1 2048 138.5 / 141.0 -
-    the critic's workgroups (1024 threads, > 80 KB of LDS) do not fit on a CU beside the env kernel's workgroup (one wavefront per SIMD
-    at 300+ registers, 78 KB of LDS), so nothing overlaps and the pair launch's sharing of the chip between actor and critic is lost
-    (actor alone 22.3 us + critic alone 27.6 us against 36.6 us for the pair).  Same numbers bit for bit (tests/test_gpu_collect.py)."""
+    Measured, one call (profiles/r06b_collect.txt): A1 Rough 4096 envs 84.7 us / step serial; 107.0 overlapped with the critic through its
+    production kernel - its workgroups (512 - 1024 threads, > 83 KB of LDS) do not fit on a CU beside the env kernel's workgroup (one
+    wavefront per SIMD at 312 registers, 78 KB of LDS), so nothing overlaps and the pair launch's sharing of the chip between actor and
+    critic is lost (actor alone 22.3 us + critic alone 27.6 us against 36.6 us for the pair); 126.1 with the critic through the
+    small-footprint launch that DOES fit (`critic_small`, rl_mlp_forward_small: four wavefronts, 140 registers, 64 KB of LDS) - co-resident
+    MFMA wavefronts take issue slots from an env wavefront that is latency-bound with its SIMD to itself, and the env step slows by more
+    than the critic's time.  G1 2048: 138.6 / 140.6 / 153.1.  So the serial loop stays the default.  Same numbers bit for bit (tests/test_gpu_collect.py)."""
 
     def __init__(self, env, actor, critic, storage, action_std: torch.Tensor, gamma: float = 0.99, lam: float = 0.95,
-                 normalize_advantage: bool = True, use_graph: bool = True, clip_actions: float | None = None, overlap: bool = False):
+                 normalize_advantage: bool = True, use_graph: bool = True, clip_actions: float | None = None, overlap: bool = False, critic_small: bool = True):
         self.env, self.actor, self.critic, self.storage = env, actor, critic, storage
         self.overlap = overlap
+        self.critic_small = critic_small  # (overlap) the critic through the small-footprint launch that fits beside the env kernel's workgroups
         self._side = torch.cuda.Stream(device=env.device) if overlap else None
         self.std, self.gamma, self.lam, self.normalize = action_std, gamma, lam, normalize_advantage
         self.T = storage.num_transitions_per_env
@@ -66,7 +70,7 @@ class Collector:
         for _ in range(self.T):
             side.wait_stream(main)  # the observations of this step (env step t - 1) and everything before it
             with torch.cuda.stream(side):
-                st.critic_half(self.critic, obs["critic"])
+                st.critic_half(self.critic, obs["critic"], small=self.critic_small)
                 ev = torch.cuda.Event()
                 ev.record(side)
             mean = self.actor(obs["policy"])

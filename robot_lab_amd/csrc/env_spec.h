@@ -89,8 +89,8 @@ inline bool spec_matches(const TablesT<TopoMax>& T) {
       if (T.idx_pool_a[R.idx_off + i] != Q.idx_a[i] || T.idx_pool_b[R.idx_off + i] != Q.idx_b[i]) return false;
   }
   if (T.n_policy != SP::N_OBS[0] || T.n_critic != SP::N_OBS[1] || T.policy_dim != SP::OBS_DIM[0] || T.critic_dim != SP::OBS_DIM[1] ||
-      (T.policy_corrupt != 0) != (SP::OBS_CORRUPT[0] != 0) || (T.critic_corrupt != 0) != (SP::OBS_CORRUPT[1] != 0))
-    return false;
+      (T.policy_corrupt != 0 && SP::OBS_CORRUPT[0] == 0) || (T.critic_corrupt != 0 && SP::OBS_CORRUPT[1] == 0))  // (a group the Spec corrupts may
+    return false;                                                                                                  // run clean: the play variant)
   for (int g = 0; g < 2; ++g)
     for (int i = 0; i < SP::N_OBS[g]; ++i) {
       const ObsTab& O = g == 0 ? T.policy[i] : T.critic[i];

@@ -1112,6 +1112,24 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     TerrainPatch tp[SCAN_RB];
     bool single_trip;
   };
+  // Which ray does slot s (= lane + LPE * i: what a lane fetches in its i-th load) stand for?  The reference's order - ray s, local x
+  // fastest [UPSTREAM B6].  The heightfield is contiguous along WORLD y (hf[ix * ny + iy]), so that order puts the env's consecutive lanes next
+  // to each other in memory when the robot looks along world y and a grid ROW apart (16 KB) when it looks along world x, where every lane of a
+  // load touches cache lines of its own.  -DRL_SCAN_YAW_LANES (round 6) makes the slot -> ray map follow the yaw - heading
+  // nearer to world x (|cos| > |sin|): local y fastest - with the set of rays, the value of each ray and its column unchanged.  Measured and
+  // NOT kept: A1 Rough 4096 41.65 -> 43.25 us, Go2 43.87 -> 45.42 us (profiles/r06d_scan_lanes_ab.txt, one call; interpreter kernels of the same sources) - the specialised A1 kernel 35.45 -> 36.97 us with FETCH_SIZE unchanged (9.72 vs 9.74 MiB counted per launch): the lines are L2 hits either way, the two integer
+  // divisions per slot and the scattered LDS row writes cost more than the shared lines save.
+  RL_FN int scan_ray_of_slot(int s, int scan_n, float cy, float sy) const {
+    s = s < scan_n ? s : scan_n - 1;
+#ifndef RL_SCAN_YAW_LANES
+    return s;
+#else
+    const int snx = ctx.uniform_i(T.scan_nx);
+    const float inv_sny = ctx.uniform(1.0f / (float)T.scan_ny);
+    const int ixt = (int)(((float)s + 0.5f) * inv_sny), iyt = s - ixt * ctx.uniform_i(T.scan_ny);  // s = ixt * ny + iyt
+    return fabsf(cy) > fabsf(sy) ? iyt * snx + ixt : s;
+#endif
+  }
   RL_FN void scan_fetch_trip(int r0, int scan_n, float cy, float sy, V3 scan_p, ScanPatches& sp) const {
     const TerrainBase tb = terrain_base(this->u, pos.x, pos.y);  // the root in grid coordinates, once for all the lane's rays
     const int snx = ctx.uniform_i(T.scan_nx);
@@ -1119,8 +1137,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     const float res = T.scan_res, cx0 = 0.5f * (float)(T.scan_nx - 1), cy0 = 0.5f * (float)(T.scan_ny - 1);
 #pragma unroll
     for (int i = 0; i < SCAN_RB; ++i) {
-      int r = r0 + i * LPE;
-      r = r < scan_n ? r : scan_n - 1;
+      const int r = scan_ray_of_slot(r0 + i * LPE, scan_n, cy, sy);
       int iy = (int)(((float)r + 0.5f) * inv_snx), ix = r - iy * snx;  // exact for r < 2^20
       float lx = ((float)ix - cx0) * res, ly = ((float)iy - cy0) * res;
       sp.tp[i] = terrain_fetch(this->u, S.terrain, tb, scan_p.x + cy * lx - sy * ly, scan_p.y + sy * lx + cy * ly);
@@ -1176,9 +1193,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     if (sp.single_trip) {
 #pragma unroll
       for (int i = 0; i < SCAN_RB; ++i) {
-        const int r = li + i * LPE;
+        const int sl = li + i * LPE, r = scan_ray_of_slot(sl, scan_n, cy, sy);
         const float v = scan_p.z - terrain_height(sp.tp[i]) - soff;
-        if (r < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
+        if (sl < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
       }
     } else {
       for (int r0 = li; r0 < scan_n; r0 += SCAN_RB * LPE) {
@@ -1186,9 +1203,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         scan_fetch_trip(r0, scan_n, cy, sy, scan_p, one);
 #pragma unroll
         for (int i = 0; i < SCAN_RB; ++i) {
-          const int r = r0 + i * LPE;
+          const int sl = r0 + i * LPE, r = scan_ray_of_slot(sl, scan_n, cy, sy);
           const float v = scan_p.z - terrain_height(one.tp[i]) - soff;
-          if (r < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
+          if (sl < scan_n) stage[scan_off + r] = corrupt ? v : clampf(v, s_lo, s_hi) * s_scale;
         }
       }
     }
@@ -1248,7 +1265,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     static_for<0, 2>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
       float* stage = cx.obs_stage(g);
-      constexpr bool corrupt = SP::OBS_CORRUPT[g] != 0;
+      // (a group the Spec's task corrupts may run uncorrupted: play.py:134 switches `enable_corruption` off and nothing else a Spec holds,
+      // so the play variant of a task matches its Spec - env_spec.h spec_matches - and the flag is read from the table image)
+      const bool corrupt = SP::OBS_CORRUPT[g] != 0 && cx.uniform_i(this->T.obs[g].corrupt) != 0;
       static_for<0, SP::N_OBS[g]>([&](auto tc) __attribute__((always_inline)) {
         constexpr int tm = decltype(tc)::value;
         constexpr ObsSpec O = SP::OBS[g][tm];
@@ -1282,7 +1301,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
           }
         }
       });
-      if constexpr (corrupt) {
+      if (corrupt) {
         const auto& G = this->T.obs[g];
         this->noise_pass(G, stage, g == 0 ? 0u : 1024u, cx.uniform_i(G.dim), cx.uniform_i(G.scan_off), cx.uniform_i(G.scan_n));
       }

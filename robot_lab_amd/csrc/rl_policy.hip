@@ -914,6 +914,23 @@ int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, 
   return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
 }
 
+// include/rl_policy.h: the small-footprint launch (16 rows per workgroup of four wavefronts, 140 registers per lane, 64 KB of LDS)
+int rl_mlp_forward_small(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream) {
+  if (!m || !x_dev || !y_dev) return fail("null argument");
+  if (n_rows <= 0) return 0;
+  constexpr size_t lds = sizeof(float) * 2 * MT * KMAX;
+  if (hipSetDevice(m->device) != hipSuccess) return fail("hipSetDevice failed");
+  static bool attr_done[64] = {};
+  if (!attr_done[m->device & 63]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail("cannot reserve 64 KB of LDS");
+    attr_done[m->device & 63] = true;
+  }
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((n_rows + MT - 1) / MT), dim3(256), lds, (hipStream_t)stream, m->P, x_dev, y_dev, n_rows);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
+}
+
 int32_t rl_mlp_in_dim(const rl_mlp* m) { return m ? m->P.in_dim : 0; }
 int32_t rl_mlp_out_dim(const rl_mlp* m) { return m ? m->P.out_dim : 0; }
 

@@ -400,6 +400,18 @@ class ManagerBasedRLEnv(_EnvBase):
             self.extras = {"log": log}
             self._live_logs.append((self.common_step_counter, weakref.ref(log)))
 
+    @property
+    def step_kernel(self) -> str:
+        """Which step kernel this env launches: the one specialised on its task (csrc/env_spec.h; picked only when the env's compiled
+        tables equal the Spec's constants bit for bit) or the term-stack interpreter (any other task, any edited cfg)."""
+        sid = self._native.spec_id() if getattr(self, "_native", None) is not None else -1
+        return f"specialised (spec_id {sid})" if sid > 0 else ("interpreter" if sid == 0 else "closed")
+
+    def __repr__(self):
+        lanes = 64 // max(1, self._native.envs_per_wavefront()) if getattr(self, "_native", None) is not None else 0
+        return (f"<robot_lab_amd ManagerBasedRLEnv num_envs={self.num_envs} device={self.device} actions={self.num_actions} "
+                f"step_kernel={self.step_kernel} lanes_per_env={lanes}>")
+
     def close(self):
         if getattr(self, "_native", None) is not None:
             torch.cuda.synchronize(self._dev_index)

@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 POLICY_LIB = os.path.join(_HERE, "csrc", "librl_policy_hip.so")
-POLICY_EXPORTS = ["rl_mlp_create", "rl_mlp_set_weights", "rl_mlp_forward", "rl_mlp_forward_pair", "rl_mlp_in_dim", "rl_mlp_out_dim", "rl_mlp_destroy", "rl_mlp_last_error"]
+POLICY_EXPORTS = ["rl_mlp_create", "rl_mlp_set_weights", "rl_mlp_forward", "rl_mlp_forward_small", "rl_mlp_forward_pair", "rl_mlp_in_dim", "rl_mlp_out_dim", "rl_mlp_destroy", "rl_mlp_last_error"]
 ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2}
 _lib = None
 
@@ -37,6 +37,7 @@ def load_policy_library(path: str | None = None) -> C.CDLL:
     lib.rl_mlp_create.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, fpp, fpp, C.c_int32, C.POINTER(C.c_void_p)]
     lib.rl_mlp_set_weights.argtypes = [C.c_void_p, fpp, fpp, C.c_void_p]
     lib.rl_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rl_mlp_forward_small.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rl_mlp_forward_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rl_mlp_in_dim.argtypes = [C.c_void_p]
     lib.rl_mlp_out_dim.argtypes = [C.c_void_p]
@@ -136,11 +137,12 @@ class MlpPolicy:
             raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
         return self._out
 
-    def forward_into(self, obs, out_ptr: int):
-        """self(obs) written to the device address `out_ptr` ([N, out_dim] fp32, e.g. the values slot of a rollout storage)."""
+    def forward_into(self, obs, out_ptr: int, small: bool = False):
+        """self(obs) written to the device address `out_ptr` ([N, out_dim] fp32, e.g. the values slot of a rollout storage).
+        `small`: the small-footprint launch (`rl_mlp_forward_small`), which fits on a CU beside the env-step kernel's workgroup."""
         obs, n = self._prepare(obs)
         stream = self._torch.cuda.current_stream(self.device).cuda_stream
-        if self.lib.rl_mlp_forward(self.handle, C.c_void_p(obs.data_ptr()), C.c_void_p(out_ptr), n, C.c_void_p(stream)) != 0:
+        if (self.lib.rl_mlp_forward_small if small else self.lib.rl_mlp_forward)(self.handle, C.c_void_p(obs.data_ptr()), C.c_void_p(out_ptr), n, C.c_void_p(stream)) != 0:
             raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
 
     def close(self):

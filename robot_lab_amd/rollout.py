@@ -125,7 +125,7 @@ class RolloutStorage:
             raise RlRolloutError(self._err())
         return self._actions
 
-    def critic_half(self, critic, privileged_obs):
+    def critic_half(self, critic, privileged_obs, small: bool = False):
         """The critic's half of the current step on the CURRENT torch stream (robot_lab_amd/collect.py calls it under a side stream):
         the privileged observations go into the slot, `critic` (an MlpPolicy with one output) writes V straight into the values slot."""
         N = self.num_envs
@@ -134,7 +134,7 @@ class RolloutStorage:
             raise RlRolloutError(self._err())
         if self.lib.rl_rollout_store_critic_obs(self.handle, self._f32(privileged_obs, (N, self.privileged_observations.shape[-1])), self._stream()) != 0:
             raise RlRolloutError(self._err())
-        critic.forward_into(privileged_obs, v.value)
+        critic.forward_into(privileged_obs, v.value, small=small)
 
     # -- PPO.process_env_step: time-out bootstrapping, dones; second half of add_transitions
     def process_env_step(self, rewards, terminated, time_outs, gamma: float):

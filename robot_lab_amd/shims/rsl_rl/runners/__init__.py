@@ -74,10 +74,19 @@ class OnPolicyRunner:
             steps = self.trainer.storage.num_transitions_per_env * env.num_envs * self.group.world_size
             # the episode log of the JOB, not of rank 0's envs: the packed episode-metric vector SUM all-reduced over the ranks on a side
             # stream (every rank takes part in the collective, rank 0 alone reads the result)
+            # Only at the log interval (`self.log_interval`, default every iteration as rsl_rl prints every iteration), and every rank
+            # keeps its handle until the next collective and resolves it then (`vector()`: work.wait() + stream order) - a rank must not
+            # drop an async Work handle while its tensor is in flight.
             from robot_lab_amd.dist import reduce_episode_log
 
+            if getattr(self, "_log_in_flight", None) is not None:
+                self._log_in_flight.vector()
+                self._log_in_flight = None
+            if (it + 1 - start) % max(1, int(getattr(self, "log_interval", 1))) != 0 and it + 1 != start + num_learning_iterations:
+                continue
             episode_log = reduce_episode_log(env)
             if not main:
+                self._log_in_flight = episode_log
                 continue
             self.last_episode_log = ep = episode_log.result()
             print(f"[rsl_rl stand-in] iteration {it + 1}/{start + num_learning_iterations}  mean reward/step {out['mean_reward']:+.4f}  value loss {out['value_loss']:.4f}  "
@@ -87,6 +96,9 @@ class OnPolicyRunner:
                   + (f"  terrain level {float(ep['Curriculum/terrain_levels']):.2f}" if "Curriculum/terrain_levels" in ep else ""), flush=True)
             if self.log_dir and (it + 1) % self.save_interval == 0:
                 self.save(os.path.join(self.log_dir, f"model_{it + 1}.pt"))
+        if getattr(self, "_log_in_flight", None) is not None:
+            self._log_in_flight.vector()
+            self._log_in_flight = None
         if self.log_dir and main:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
 

@@ -133,7 +133,8 @@ def test_short_horizon_parity(task, wg, merge, monkeypatch):
     # happens.  The envelope is a maximum over six random draws; over the ~3 k envs of this test's 76 cases one sits past it after any change of
     # round-off: round 5, Loong Flat env 22, one joint velocity at 1.14 x its envelope (4.95e-4 against 4.36e-4) - the same entry to all digits
     # in the three kernel shapes, and in the library of the commit before)
-    rep = teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=3.0 / N, caps=caps, max_outliers=1, outlier_factor=2.0)
+    # (round 6, ADVICE r5: the allowance is for that one known case, not for every shape - no other env of the tier needed it)
+    rep = teacher_forced_check(ora, state, a, got, n_twins=6, max_mask=3.0 / N, caps=caps, max_outliers=1 if "Loong" in task else 0, outlier_factor=2.0)
     print(f"\n[parity-small] {task} wg={wg!r} merge={merge}: done_differs {two.done_differs.mean():.3f}, teacher-forced mask {rep['masked']}/{N}")
     env.close()
 

@@ -18,6 +18,10 @@ CASES = [
     (GO2, 2, "4", "-4"), (GO2, 2, "2", ""), (GO2, 2, "1", "-4"),
     (GO2W, 3, "4", "-4"), (GO2W, 3, "2", "-4"), (GO2W, 3, "1", ""),
     (G1, 4, "8", "-4"), (G1, 4, "8", ""),
+    # round 6: the Flat twins (BASELINE config 1 = A1 Flat) in the mapping a 4096-env (G1: 2048) launch runs + one more each
+    (A1.replace("Rough", "Flat"), 5, "4", "-4"), (A1.replace("Rough", "Flat"), 5, "1", ""),
+    (GO2.replace("Rough", "Flat"), 6, "4", "-4"), (GO2W.replace("Rough", "Flat"), 7, "4", "-4"), (GO2W.replace("Rough", "Flat"), 7, "2", ""),
+    (G1.replace("Rough", "Flat"), 8, "8", "-4"),
 ]
 
 

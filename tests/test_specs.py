@@ -19,6 +19,10 @@ SPECS = {  # id -> task (tools/gen_specs.py SPECS)
     2: "RobotLab-Isaac-Velocity-Rough-Unitree-Go2-v0",
     3: "RobotLab-Isaac-Velocity-Rough-Unitree-Go2W-v0",
     4: "RobotLab-Isaac-Velocity-Rough-Unitree-G1-v0",
+    5: "RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0",
+    6: "RobotLab-Isaac-Velocity-Flat-Unitree-Go2-v0",
+    7: "RobotLab-Isaac-Velocity-Flat-Unitree-Go2W-v0",
+    8: "RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0",
 }
 
 
@@ -40,9 +44,21 @@ def test_spec_is_picked_only_for_identical_tables(emu_lib, monkeypatch):
     monkeypatch.delenv("RL_ENV_SPEC", raising=False)
     for sid, task in SPECS.items():
         assert make(task, 4, 1, emu_lib).spec_id() == sid, task
-    # the Flat twin of a specialised task has other observation groups; another robot other terms: the interpreter
-    assert make("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", 4, 1, emu_lib).spec_id() == 0
+    # another robot has other terms: the interpreter
     assert make("RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0", 4, 1, emu_lib).spec_id() == 0
+
+    def play(desc):  # play.py:126-139: observation corruption, pushes, curricula off - the task's own Spec still fits
+        desc.task.policy_corrupt = 0
+        desc.task.ev_push = 0
+        desc.terrain.curriculum = 0
+
+    for sid, task in SPECS.items():
+        assert make(task, 4, 1, emu_lib, play).spec_id() == sid, task
+
+    def corrupt_critic(desc):  # ... but a group the Spec runs clean may not corrupt
+        desc.task.critic_corrupt = 1
+
+    assert make(SPECS[1], 4, 1, emu_lib, corrupt_critic).spec_id() == 0
 
     def heavier(desc):  # one edited weight: not the task the kernel was compiled for
         desc.task.rewards[0].weight = desc.task.rewards[0].weight * 2.0
@@ -59,12 +75,12 @@ def test_spec_is_picked_only_for_identical_tables(emu_lib, monkeypatch):
     assert make(SPECS[1], 4, 1, emu_lib).spec_id() == 0
 
 
-def spec_vs_interpreter(task, N, steps, lib, monkeypatch, sid):
+def spec_vs_interpreter(task, N, steps, lib, monkeypatch, sid, mutate=None):
     """Both paths from the same seed with the same actions: returns the worst differences."""
     monkeypatch.setenv("RL_ENV_SPEC", "1")
-    a = make(task, N, 5, lib)
+    a = make(task, N, 5, lib, mutate)
     monkeypatch.setenv("RL_ENV_SPEC", "0")
-    b = make(task, N, 5, lib)
+    b = make(task, N, 5, lib, mutate)
     assert a.spec_id() == sid and b.spec_id() == 0
     a.reset(); b.reset()
     rng = np.random.default_rng(0)
@@ -96,8 +112,21 @@ def test_specialised_program_equals_interpreter_one_lane_per_limb(sid, emu_lib, 
     assert seen.sum() >= len(seen) - 3, f"only {seen.sum()} of {len(seen)} terms were ever non-zero: the comparison is too quiet"
 
 
-@pytest.mark.parametrize("sid,sub", [(1, 4), (1, 2), (2, 4), (3, 4), (4, 8)])
+@pytest.mark.parametrize("sid,sub", [(1, 4), (1, 2), (2, 4), (3, 4), (4, 8), (5, 4), (6, 4), (7, 4), (8, 8)])
 def test_specialised_program_equals_interpreter_in_its_baseline_mapping(sid, sub, emu_lib, monkeypatch):
     monkeypatch.setenv("RL_EMU_FIBERS", "1")
     monkeypatch.setenv("RL_EMU_SUB", str(sub))
     spec_vs_interpreter(SPECS[sid], 4, 14, emu_lib, monkeypatch, sid)
+
+
+@pytest.mark.parametrize("sid,sub", [(1, 4), (5, 4), (3, 4)])
+def test_play_variant_runs_its_tasks_spec(sid, sub, emu_lib, monkeypatch):
+    """play.py's edits (no observation corruption): the specialised observation stage reads the flag at run time and equals the interpreter."""
+    monkeypatch.setenv("RL_EMU_FIBERS", "1")
+    monkeypatch.setenv("RL_EMU_SUB", str(sub))
+
+    def play(desc):
+        desc.task.policy_corrupt = 0
+        desc.task.ev_push = 0
+
+    spec_vs_interpreter(SPECS[sid], 4, 10, emu_lib, monkeypatch, sid, play)

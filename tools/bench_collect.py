@@ -41,11 +41,12 @@ storage = RolloutStorage(N, T, od, cd, A, seed=1, device="cuda:0")
 
 
 GRAPH = os.environ.get("RL_GRAPH", "1") == "1"  # the whole iteration as one hipGraph launch (robot_lab_amd/collect.py)
+SMALL = os.environ.get("RL_CRITIC_SMALL", "1") == "1"  # (overlap) the critic through rl_mlp_forward_small
 OVERLAP = os.environ.get("RL_OVERLAP", "1") == "1"  # the critic of step t on a second stream under env step t (0: actor + critic as one launch in front of act)
 if GRAPH and FUSED and PAIR:
     from robot_lab_amd.collect import Collector  # noqa: E402
 
-    col = Collector(env, actor, critic, storage, std, GAMMA, LAM, use_graph=True, overlap=OVERLAP)
+    col = Collector(env, actor, critic, storage, std, GAMMA, LAM, use_graph=True, overlap=OVERLAP, critic_small=SMALL)
     iteration = lambda obs: col.collect()  # noqa: E731
 else:
 
@@ -73,5 +74,5 @@ with torch.inference_mode():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 ok = bool(torch.isfinite(storage.advantages).all() and torch.isfinite(storage.returns).all())
-print(f"{task} N={N} graph={int(GRAPH and FUSED and PAIR)} overlap={int(OVERLAP and GRAPH and FUSED and PAIR)}: collection of {T} steps + GAE {1e3 * dt / ITERS:.3f} ms / iteration = {N * T * ITERS / dt / 1e6:.1f} M env-steps/s "
+print(f"{task} N={N} graph={int(GRAPH and FUSED and PAIR)} overlap={int(OVERLAP and GRAPH and FUSED and PAIR)} critic_small={int(SMALL)}: collection of {T} steps + GAE {1e3 * dt / ITERS:.3f} ms / iteration = {N * T * ITERS / dt / 1e6:.1f} M env-steps/s "
       f"({1e6 * dt / ITERS / T:.1f} us / step; finite: {ok}; adv mean {float(storage.advantages.mean()):+.2e} std {float(storage.advantages.std()):.4f})")

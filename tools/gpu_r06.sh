@@ -37,4 +37,44 @@ a)
   tail -15 $OUT/pytest_gpu.log
   mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
   ;;
+b)
+  # the critic through the small-footprint launch (fits beside the env kernel's workgroup) under env step t; the Flat twins' Specs;
+  # then the whole GPU tier
+  for cfg in "$A1 4096" "$G1 2048"; do
+    set -- $cfg
+    for mode in "0 0" "1 1" "1 0" "0 0" "1 1"; do set -- $1 $2 $mode; RL_OVERLAP=$3 RL_CRITIC_SMALL=$4 timeout 300 python tools/bench_collect.py $1 $2 40 >> $OUT/collect.txt 2>&1; done
+  done
+  grep -v amdgpu.ids $OUT/collect.txt
+  timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 400 $OUT/bench_default.json
+  timeout 300 python bench.py --task RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_A1_Flat.json 2> $OUT/bench_A1_Flat.err; head -c 900 $OUT/bench_A1_Flat.json
+  RL_ENV_SPEC=0 timeout 300 python bench.py --task RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_A1_Flat_interpreter.json 2> /dev/null; head -c 900 $OUT/bench_A1_Flat_interpreter.json
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "rc=$?" >> $OUT/pytest_gpu.log
+  tail -15 $OUT/pytest_gpu.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  mv gpurun_out/spec_vs_interpreter.jsonl $OUT/ 2>/dev/null
+  ;;
+c)
+  # scan rays dealt to the lanes by yaw quadrant (csrc/env_terms.h scan_ray_of_slot) against the reference's fixed order: kernel time and
+  # FETCH_SIZE, one call; then the host-side cost of enqueueing a step with 8 ranks alive
+  for cfg in "$A1 4096" "$GO2 4096"; do
+    set -- $cfg
+    timeout 400 python tools/ab_bench.py --task $1 --num-envs $2 --rounds 3 --steady $V/scanfixed_34.so $V/scanyaw_34.so >> $OUT/scan_lanes_ab.txt 2>&1
+  done
+  cat $OUT/scan_lanes_ab.txt
+  for v in scanfixed scanyaw; do
+    RL_ENV_LIB=$V/${v}_34.so prof ${v}_fetch "python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0" --pmc FETCH_SIZE
+    grep -A2 "env_kernel" $OUT/${v}_fetch.txt | head -6
+  done
+  timeout 600 python tools/host_enqueue.py --ranks 8 --out $OUT/host_enqueue_8ranks.json > $OUT/host_enqueue.log 2>&1; tail -c 1500 $OUT/host_enqueue.log
+  timeout 300 python tools/host_enqueue.py --ranks 1 --out $OUT/host_enqueue_1rank.json > $OUT/host_enqueue1.log 2>&1; tail -c 600 $OUT/host_enqueue1.log
+  ;;
+d)
+  # the scan-lane A/B again on the SPECIALISED A1 kernel (call c's variants carried the interpreter only), with FETCH_SIZE of both
+  timeout 400 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/scanfixed_34.so $V/scanyaw_34.so >> $OUT/scan_lanes_ab.txt 2>&1
+  grep -v amdgpu $OUT/scan_lanes_ab.txt
+  for v in scanfixed scanyaw; do
+    RL_ENV_LIB=$GRAFT_REPO_ROOT/$V/${v}_34.so prof ${v}_fetch "python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0" --pmc FETCH_SIZE
+    grep -A2 "env_kernel" $OUT/${v}_fetch.txt | head -6
+  done
+  ;;
 esac

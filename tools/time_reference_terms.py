@@ -35,7 +35,6 @@ def main():
     ap.add_argument("--out", default=os.path.join(HERE, "..", "profiles", "r06_reference_terms_cpu.json"))
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
-    gg.T = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)  # the reference's tensors are fp32
     cfg = gg.parse_env_cfg(a.task, device="cpu")
     desc, spec = gg.compile_cfg(cfg)
     N = a.num_envs
@@ -46,6 +45,24 @@ def main():
     for _ in range(a.warm_steps):
         ora.step(rng.uniform(-1, 1, (N, ora.D)))
     env = gg.duck_env(ora, desc)
+
+    def to_f32(obj, seen):  # the reference's tensors are fp32: every float64 tensor of the recorded state -> float32
+        if id(obj) in seen:
+            return
+        seen.add(id(obj))
+        items = obj.items() if isinstance(obj, dict) else (vars(obj).items() if hasattr(obj, "__dict__") else ())
+        for k, v in list(items):
+            if torch.is_tensor(v):
+                if v.dtype == torch.float64:
+                    (obj.__setitem__ if isinstance(obj, dict) else lambda kk, vv: setattr(obj, kk, vv))(k, v.float())
+            elif isinstance(v, (dict,)) or hasattr(v, "__dict__"):
+                if not callable(v) or hasattr(v, "data"):
+                    to_f32(v, seen)
+
+    to_f32(env, set())
+    cmd32, act32, prev32 = torch.tensor(ora.vel_command_b, dtype=torch.float32), torch.tensor(ora.action, dtype=torch.float32), torch.tensor(ora.prev_action, dtype=torch.float32)
+    env.command_manager.get_command = lambda name: cmd32
+    env.action_manager.action, env.action_manager.prev_action = act32, prev32
     # the reward terms the RewardManager would call every step (weight != 0), instantiated once as the manager does
     rewards = []
     for name, term in vars(cfg.rewards).items():

@@ -47,6 +47,7 @@ def main():
         env = ManagerBasedRLEnv(desc=desc, extra=extra, num_envs=a.num_envs, seed=a.seed, device="cuda:0")
     else:
         env = ManagerBasedRLEnv(a.task, num_envs=a.num_envs, seed=a.seed, device="cuda:0")
+    print(env, flush=True)  # (names the step kernel: specialised on the task, or the interpreter)
     tr = Trainer(env, seed=a.seed)
     # init_at_random_ep_len=True (train.py:224): the first time-outs are spread over an episode length
     env.episode_length_buf = torch.randint(0, env.max_episode_length, (a.num_envs,), generator=torch.Generator().manual_seed(a.seed))
@@ -86,7 +87,7 @@ def main():
                   f"lr {row['learning_rate']:.1e}  kl {row['kl']:.4f}  v_loss {row['value_loss']:.4f}  height {row.get('root_height', float('nan')):.3f}  upright {row.get('upright', float('nan')):+.3f}", flush=True)
     wall = time.perf_counter() - t_start
     n_steps = a.iterations * st.num_transitions_per_env * a.num_envs
-    summary = dict(task=a.task, num_envs=a.num_envs, iterations=a.iterations, wall_s=wall, env_steps=n_steps, env_steps_per_s=n_steps / wall,
+    summary = dict(task=a.task, step_kernel=env.step_kernel, num_envs=a.num_envs, iterations=a.iterations, wall_s=wall, env_steps=n_steps, env_steps_per_s=n_steps / wall,
                    collect_ms_per_iteration=1e3 * t_collect / a.iterations, update_ms_per_iteration=1e3 * t_update / a.iterations,
                    first=log[0], last=log[-1])
     print(json.dumps({k: v for k, v in summary.items() if k not in ("first", "last")}))
