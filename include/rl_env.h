@@ -420,6 +420,21 @@ int32_t rl_env_envs_per_wavefront(const rl_env* env);
  * Same results up to fp32 summation order.  No counterpart in the reference: informational. */
 int32_t rl_env_spec_id(const rl_env* env);
 
+/* ---- specialising ANY task at run time (robot_lab_amd/jit.py drives these; nothing of it in the reference) ---------------------------
+ * The library carries specialised step kernels for eight tasks (csrc/spec/).  Any other task - or an edited cfg - can get its own:
+ *   rl_env_spec_source   the C++ source of the task's Spec (`struct <struct_name>`, spec id `id` >= 1000) from its descriptor, through the
+ *                        same descriptor -> tables compile rl_env_create runs.  Host code, no device.  Returns the length written into
+ *                        `out` (0: the task cannot be specialised - rl_env_last_error says why; -1: `cap` too small).
+ *   (the caller compiles it with hipcc against this library's own csrc headers into a shared object exporting rl_spec_plugin_abi /
+ *    _id / _matches / _launch: robot_lab_amd/jit.py has the five-line translation unit)
+ *   rl_env_register_spec_plugin   dlopens that object and adds it to the process-wide list rl_env_create tries after the built-in Specs;
+ *                        refused unless it was compiled against the headers this library was (rl_env_abi_stamp: a digest of csrc/).
+ * An env created afterwards from tables that equal the plugin's constants bit for bit runs its kernels: rl_env_spec_id() = `id`. */
+int rl_env_spec_source(const rl_env_desc* desc, const char* struct_name, const char* task, int id, char* out, int cap);
+int rl_env_register_spec_plugin(const char* so_path);
+int32_t rl_env_spec_plugin_count(void);
+const char* rl_env_abi_stamp(void);
+
 /* The launch geometry rl_env_create + rl_env_step arrive at for `num_envs` environments of this task on a device with `n_cu` compute
  * units (<= 0: 256, MI355X), without creating anything - no device is touched:
  *   out[0] lanes per limb (4 / 2 / 1 quadrupeds, 8 / 4 trunk + limbs), out[1] wavefronts per workgroup of the step launch (4 or 1),

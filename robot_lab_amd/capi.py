@@ -19,6 +19,7 @@ HIP_LIB = os.path.join(_HERE, "csrc", "librl_env_hip.so")
 EXPORTS = [
     "rl_env_create", "rl_env_reset", "rl_env_step", "rl_env_step_record", "rl_env_get_buffer", "rl_env_export_state", "rl_env_commit_state",
     "rl_env_import_state", "rl_env_read_log", "rl_env_log_slot", "rl_env_obs_slot", "rl_env_step_count", "rl_env_set_step_count", "rl_env_num_envs", "rl_env_num_actions", "rl_env_obs_dim", "rl_env_max_episode_length", "rl_env_envs_per_wavefront", "rl_env_spec_id", "rl_env_plan",
+    "rl_env_spec_source", "rl_env_register_spec_plugin", "rl_env_spec_plugin_count", "rl_env_abi_stamp",
     "rl_env_destroy", "rl_env_last_error", "rl_env_desc_size", "rl_env_graph_begin", "rl_env_graph_end", "rl_env_graph_launching",
 ]
 
@@ -61,6 +62,11 @@ def load_library(path: str | None = None) -> C.CDLL:
         getattr(lib, n).argtypes = [C.c_void_p]
         getattr(lib, n).restype = C.c_int32
     lib.rl_env_plan.argtypes = [C.POINTER(EnvDesc), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    lib.rl_env_spec_source.argtypes = [C.POINTER(EnvDesc), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    lib.rl_env_spec_source.restype = C.c_int
+    lib.rl_env_register_spec_plugin.argtypes = [C.c_char_p]
+    lib.rl_env_spec_plugin_count.restype = C.c_int32
+    lib.rl_env_abi_stamp.restype = C.c_char_p
     lib.rl_env_obs_dim.argtypes = [C.c_void_p, C.c_int32]
     lib.rl_env_obs_dim.restype = C.c_int32
     lib.rl_env_destroy.argtypes = [C.c_void_p]

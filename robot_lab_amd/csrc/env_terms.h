@@ -159,6 +159,8 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
       }
       f = part * R.p[0] * gate;
     } break;
+    // (E.action is null for PADDING envs only - e >= N, compute_rewards - whose rewards nobody reads: the 0 below is theirs.  The specialised
+    // evaluation does not implement these two kinds (spec_kind_supported): a task that lists them runs this interpreter.)
     case REW_ACTION_MIRROR: {  // rewards.py:281-302: joint_mirror's form on |action| (weight 0 in every shipped cfg: straight from the action buffer)
       float part = 0.f;
       for (int i = 0; i < R.n_idx; ++i) {

@@ -7,8 +7,37 @@
 // bound at this size, so a wavefront gets a SIMD's whole register file and every cross-lane reduction is a DPP
 // move (quad_perm inside a limb, row mirrors across limbs - no LDS round trip).  Observation rows are staged in LDS and written
 // back as one linear, 16-byte-vectorised burst per wavefront.  DESIGN.md section 3 has the LDS budget.
+#include <dlfcn.h>
+
+#include <mutex>
+
 #include "rl_env_kernels.h"
 #include "rl_env_host.h"
+#include "rl_env_specgen.h"
+
+// Step kernels specialised on a task at RUN time (robot_lab_amd/jit.py): a plugin is a shared object compiled from this library's own headers
+// + the task's generated Spec, registered through rl_env_register_spec_plugin (include/rl_env.h) and tried by rl_env_create after the Specs
+// built into the library.  RL_ENV_ABI_STAMP: a digest of the csrc headers, given to hipcc by __graft_entry__.build() and by the plugin
+// build alike - a plugin compiled against other headers is refused.
+#define RL_ENV_PLUGINS 1
+#ifndef RL_ENV_ABI_STAMP
+#define RL_ENV_ABI_STAMP "unstamped"
+#endif
+namespace {
+struct SpecPlugin {
+  int id = 0;
+  int (*matches)(const void* tables) = nullptr;
+  int (*launch)(const void* cfg, const void* S, const void* T, int sub, size_t lds1, void* stream) = nullptr;
+};
+std::vector<SpecPlugin>& spec_plugins() {
+  static std::vector<SpecPlugin> v;
+  return v;
+}
+std::mutex& spec_plugins_mutex() {
+  static std::mutex m;
+  return m;
+}
+}  // namespace
 
 // launchers of the other two lane mappings (rl_env_sub.inl: their own translation units unless RL_ENV_SINGLE_TU)
 extern "C" __attribute__((visibility("hidden"))) int rl_env_launch_sub1(const void* cfg, const void* S, const void* T, int inst, size_t lds1, void* stream);
@@ -213,8 +242,22 @@ struct Backend {
     return 0;
   }
   int spec_id = 0;  // env_spec.h: the Spec whose constants equal this env's tables (rl_env_host.h create), 0: the interpreter
+  int (*plugin_launch)(const void*, const void*, const void*, int, size_t, void*) = nullptr;  // spec_id >= 1000: the run-time compiled kernels
+  int match_plugin(const void* tables) {  // a registered plugin whose constants equal these tables (rl_env_register_spec_plugin)
+    std::lock_guard<std::mutex> lk(spec_plugins_mutex());
+    for (const SpecPlugin& p : spec_plugins())
+      if (p.matches(tables)) {
+        plugin_launch = p.launch;
+        return p.id;
+      }
+    return 0;
+  }
   int launch(const KState& S, const void* T, int CL, void* stream) {  // CL: chain length, + 100 for a merged instance, + 400 for the rot / pad quadruped; S.mode: what to run
     hipStream_t st = (hipStream_t)stream;
+    if (spec_id >= 1000 && plugin_launch && S.mode == KMODE_STEP) {  // (a plugin built for another lane mapping answers -2: the interpreter below)
+      const int rc = plugin_launch(&cfg, &S, T, sub, lds_bytes, stream);
+      if (rc != -2) return check((hipError_t)rc);
+    }
     if (spec_id != 0 && S.mode == KMODE_STEP) {  // the step kernel specialised on this task, when the build has it for the lane mapping
       int rc = -2;
       switch (spec_id) {

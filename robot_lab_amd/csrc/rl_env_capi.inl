@@ -161,6 +161,50 @@ int rl_env_destroy(rl_env* env) {
   return 0;
 }
 
+// The C++ source of the Spec of a task (csrc/rl_env_specgen.h): build-time tooling (tools/gen_specs.py) and the first step of specialising a
+// task at run time (robot_lab_amd/jit.py).  Returns the length written (0: the task cannot be specialised - rl_env_last_error says why;
+// -1: `cap` too small).  Host code: needs no device.
+int rl_env_spec_source(const rl_env_desc* desc, const char* struct_name, const char* task, int id, char* out, int cap) {
+  if (!desc || !struct_name || !task || !out) return 0;
+  const std::string src = rl::spec_source(*desc, struct_name, task, id);
+  if (src.empty()) return 0;
+  if ((int)src.size() + 1 > cap) return -1;
+  memcpy(out, src.c_str(), src.size() + 1);
+  return (int)src.size();
+}
+
+#ifdef RL_ENV_PLUGINS
+const char* rl_env_abi_stamp(void) { return RL_ENV_ABI_STAMP; }
+int32_t rl_env_spec_plugin_count(void) { return (int32_t)spec_plugins().size(); }
+int rl_env_register_spec_plugin(const char* so_path) {
+  if (!so_path) return rl::fail("null path");
+  void* h = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return rl::fail(std::string("dlopen failed: ") + dlerror());
+  SpecPlugin p;
+  auto abi = reinterpret_cast<const char* (*)()>(dlsym(h, "rl_spec_plugin_abi"));
+  auto idf = reinterpret_cast<int (*)()>(dlsym(h, "rl_spec_plugin_id"));
+  p.matches = reinterpret_cast<int (*)(const void*)>(dlsym(h, "rl_spec_plugin_matches"));
+  p.launch = reinterpret_cast<int (*)(const void*, const void*, const void*, int, size_t, void*)>(dlsym(h, "rl_spec_plugin_launch"));
+  if (!abi || !idf || !p.matches || !p.launch) { dlclose(h); return rl::fail(std::string(so_path) + " does not export the rl_spec_plugin_* entry points"); }
+  if (std::string(abi()) != RL_ENV_ABI_STAMP) {  // compiled against other headers than this library: KState / Tables / LaunchCfg may differ
+    const std::string theirs = abi();
+    dlclose(h);
+    return rl::fail(std::string(so_path) + " was compiled against csrc headers " + theirs + ", this library against " RL_ENV_ABI_STAMP);
+  }
+  p.id = idf();
+  if (p.id < 1000) { dlclose(h); return rl::fail("plugin spec ids start at 1000 (below: the Specs built into the library)"); }
+  std::lock_guard<std::mutex> lk(spec_plugins_mutex());
+  for (const SpecPlugin& q : spec_plugins())
+    if (q.id == p.id) return 0;  // already registered (the handle of the second dlopen is the same object: leave it)
+  spec_plugins().push_back(p);
+  return 0;
+}
+#else  // (the CPU lane emulator: plugins are HIP code objects)
+const char* rl_env_abi_stamp(void) { return "emulator"; }
+int32_t rl_env_spec_plugin_count(void) { return 0; }
+int rl_env_register_spec_plugin(const char*) { return rl::fail("the CPU lane emulator loads no step-kernel plugins"); }
+#endif
+
 const char* rl_env_last_error(void) { return rl::last_error().c_str(); }
 uint64_t rl_env_desc_size(void) { return sizeof(rl_env_desc); }
 

@@ -602,6 +602,8 @@ struct EnvImpl {
 #define RL_SPEC_MATCH(NAME, ID) if (spec_id == 0 && spec_matches<NAME>(tables)) spec_id = ID;
       RL_SPEC_LIST(RL_SPEC_MATCH)
 #undef RL_SPEC_MATCH
+      // ... or one compiled for this task at run time and registered with the library (rl_env_register_spec_plugin: robot_lab_amd/jit.py)
+      if (spec_id == 0) spec_id = be.match_plugin(&tables);
     }
     be.spec_id = spec_id;
     CL = tables.CL;

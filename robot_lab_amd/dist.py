@@ -116,6 +116,7 @@ class LearnerGroup:
 # termination counts, the metric sums, the sum of the terrain levels and the env count - issued on a SIDE stream, so that 256 bytes
 # of pure latency (10 - 20 us over xGMI) never sit on the step's critical path; the means are taken after the reduction.
 LOG_SLOT_TERRAIN_SUM, LOG_SLOT_NUM_ENVS = 6, 7  # spare words of a log slot (csrc/env_tables.h: 0 count, 1 - 3 terminations, 4 - 5 metrics, 8.. term sums)
+LOG_SLOT_CMD_LIN, LOG_SLOT_CMD_ANG, LOG_SLOT_RANKS, LOG_SLOT_FRESH = 60, 61, 62, 63  # (8 + MAX_T = 48 <= 60; 63 = LOG_FRESH of the kernel)
 _side_streams: dict = {}
 
 
@@ -150,32 +151,61 @@ class EpisodeLogFuture:
             out["Episode_Termination/illegal_contact"] = s[3]
         if e.desc.terrain.curriculum and not e.desc.terrain.is_plane:
             out["Curriculum/terrain_levels"] = s[LOG_SLOT_TERRAIN_SUM] / torch.clamp(s[LOG_SLOT_NUM_ENVS], min=1.0)
+        ranks = torch.clamp(s[LOG_SLOT_RANKS], min=1.0)
+        if e.desc.task.cur_cmd_lin:  # the ranks' live upper bounds (each rank runs its own curriculum decision): their mean
+            out["Curriculum/command_levels_lin_vel"] = s[LOG_SLOT_CMD_LIN] / ranks
+        if e.desc.task.cur_cmd_ang:
+            out["Curriculum/command_levels_ang_vel"] = s[LOG_SLOT_CMD_ANG] / ranks
         out["episodes"], out["num_envs"] = s[0], s[LOG_SLOT_NUM_ENVS]  # (not reference keys: how many episodes / envs stand behind the means)
         self._out = out
         return out
 
 
-def pack_episode_log(env) -> torch.Tensor:
-    """This rank's packed vector: the log slot of the most recent step that reset an env (csrc/env_terms.h step_front: the device-side
-    ring resolves an empty slot to its predecessor), its spare words carrying the sum of the terrain levels and the env count."""
+def pack_episode_log(env, steps: int = 1) -> torch.Tensor:
+    """This rank's packed vector.  `steps` = 1: the log slot of the most recent step that reset an env (csrc/env_terms.h step_front: the
+    device-side ring resolves an empty slot to its predecessor).  `steps` > 1: the SUM over the last `steps` steps of the slots whose step
+    itself reset somebody (their LOG_FRESH word; an inherited slot repeats its predecessor and is skipped) - every episode that ended
+    inside the window counts once, which is what rsl_rl's logger gets by averaging the `ep_infos` of all steps of a rollout; a
+    window without a single reset falls back to the `steps` = 1 form.  Spare words: the sum of the terrain levels, the env count, the
+    live command-range upper bounds of the command_levels_* curricula and a 1 per rank (so that the reduced vector knows the world size)."""
     e = env.unwrapped if hasattr(env, "unwrapped") else env
     k = e._native.log_slot()
     log = e._bufs["LOG"]
-    cur, prev = log[k].sum(0), log[(k - 1) % log.shape[0]].sum(0)  # (a slot is RL_LOG_PARTS partial rows)
+    R = log.shape[0]
+    cur, prev = log[k].sum(0), log[(k - 1) % R].sum(0)  # (a slot is RL_LOG_PARTS partial rows)
     vec = torch.where(cur[0] > 0, cur, prev).clone()
+    steps = max(1, min(int(steps), R - 4, int(e.common_step_counter)))  # (the device keeps the last R - 3 steps)
+    if steps > 1:
+        idx = torch.tensor([(k - i) % R for i in range(steps)], device=log.device)
+        rows = log[idx].sum(1)                                   # [steps, LOG_SIZE]
+        fresh = (rows[:, LOG_SLOT_FRESH] > 0).to(rows.dtype)[:, None]
+        window = (rows * fresh).sum(0)
+        vec = torch.where(window[0] > 0, window, vec)
     if e.desc.terrain.curriculum and not e.desc.terrain.is_plane:
         vec[LOG_SLOT_TERRAIN_SUM] = e.terrain_levels.float().sum()
     vec[LOG_SLOT_NUM_ENVS] = float(e.num_envs)
+    vec[LOG_SLOT_FRESH] = 0.0
+    if e.desc.task.cur_cmd_lin:
+        vec[LOG_SLOT_CMD_LIN] = e.command_levels[1]
+    if e.desc.task.cur_cmd_ang:
+        vec[LOG_SLOT_CMD_ANG] = e.command_levels[5]
+    vec[LOG_SLOT_RANKS] = 1.0
     return vec
 
 
-def reduce_episode_log(env, group=None) -> EpisodeLogFuture:
+def reduce_episode_log(env, group=None, steps: int | None = None) -> EpisodeLogFuture:
     """SUM all-reduce of the packed episode-metric vector over the ranks of `group` (a torch.distributed process group; None: the default
-    group when one is initialised, else this rank alone), off the caller's stream.  Collective: every rank of the group calls it."""
+    group when one is initialised, else this rank alone), off the caller's stream.  Collective: every rank of the group calls it.
+    `steps`: the window the episode statistics cover (pack_episode_log); None = the env steps since this env's previous call (a rollout,
+    when called once per iteration), 1 on the first call."""
     import torch.distributed as dist
 
     e = env.unwrapped if hasattr(env, "unwrapped") else env
-    vec = pack_episode_log(e)
+    if steps is None:
+        last = getattr(e, "_log_reduced_at", None)
+        steps = 1 if last is None else max(1, int(e.common_step_counter) - last)
+    e._log_reduced_at = int(e.common_step_counter)
+    vec = pack_episode_log(e, steps)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return EpisodeLogFuture(e, vec, None, None)
     if dist.get_backend(group) == "gloo":  # the share-GPU self-test / CPU tier: host tensors (a host sync - never the production path)

@@ -23,6 +23,7 @@ There is no CPU path: without `librl_env_hip.so` or without a GPU the constructo
 from __future__ import annotations
 
 import collections
+import os
 import weakref
 
 import math
@@ -235,7 +236,8 @@ class ManagerBasedRLEnv(_EnvBase):
 
     def __init__(self, cfg=None, render_mode=None, *, desc: EnvDesc | None = None, extra: dict | None = None,
                  num_envs: int | None = None, seed: int | None = None, device: str | None = None, terrain_seed: int = 0,
-                 lib_path: str | None = None, inspection: bool = False, **kwargs):
+                 lib_path: str | None = None, inspection: bool = False, specialise: bool | None = None, **kwargs):
+        self._task_name = cfg if isinstance(cfg, str) else (type(cfg).__name__ if cfg is not None else "task")
         if isinstance(cfg, str):  # a compiled descriptor bundle id / path (robot_lab_amd/data)
             desc, extra = load_bundle(cfg)
             cfg = None
@@ -268,6 +270,14 @@ class ManagerBasedRLEnv(_EnvBase):
         heights, terrain_origins, env_origins = build_world(desc, extra or {}, self.num_envs, terrain_seed)
         with torch.cuda.device(self._dev_index):
             self._native = NativeEnv(desc, heights, terrain_origins, env_origins, self.num_envs, self._seed, self._dev_index, lib_path)
+            # `specialise` (None: RL_ENV_JIT=1): a task the library has no specialised step kernel for gets one compiled now - or loaded from
+            # the cache - and the env is created again on it (robot_lab_amd/jit.py; any failure there: one log line and this interpreter env)
+            from . import jit
+
+            if jit.enabled(specialise) and self._native.spec_id() == 0 and os.environ.get("RL_ENV_SPEC", "1") != "0":
+                if jit.specialise(self._native.lib, desc, os.path.basename(str(self._task_name)), 16 // max(1, self._native.envs_per_wavefront())):
+                    self._native.close()
+                    self._native = NativeEnv(desc, heights, terrain_origins, env_origins, self.num_envs, self._seed, self._dev_index, lib_path)
         self.num_actions = self._native.num_actions
         self.max_episode_length = self._native.max_episode_length
         self.max_episode_length_s = float(desc.task.episode_length_s)

@@ -508,6 +508,7 @@ struct Backend {
   void zero(void* p, size_t n) { std::memset(p, 0, n); }
   void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
   void h2d_stream(void* d, const void* s, size_t n, void*) { std::memcpy(d, s, n); }
+  int match_plugin(const void*) { return 0; }  // (run-time compiled Specs are HIP code objects: the emulator has none)
   int spec_id = 0;  // env_spec.h: the Spec whose constants equal the env's tables (0: the interpreter)
   // the specialised lane programs the emulator carries: every Spec with one lane per limb and with the mapping its kernel runs at the
   // BASELINE size (quadrupeds: 16 lanes per env; trunk + limbs: 32), A1 also with two sub-lanes per limb
@@ -625,14 +626,7 @@ struct Backend {
 
 // build-time tooling (emulator library only): the C++ source of the Spec of a task (csrc/rl_env_specgen.h; tools/gen_specs.py).
 // Returns the length written (0: the task cannot be specialised - rl_env_last_error says why; -1: `cap` too small).
-extern "C" int rl_env_spec_source(const rl_env_desc* desc, const char* struct_name, const char* task, int id, char* out, int cap) {
-  if (!desc || !struct_name || !task || !out) return 0;
-  const std::string src = rl::spec_source(*desc, struct_name, task, id);
-  if (src.empty()) return 0;
-  if ((int)src.size() + 1 > cap) return -1;
-  std::memcpy(out, src.c_str(), src.size() + 1);
-  return (int)src.size();
-}
+// (rl_env_spec_source: csrc/rl_env_capi.inl - the HIP library exports it too, for specialisation at run time)
 
 // test hook (emulator library only): the lane program's randomness primitive, for tests/test_philox.py
 extern "C" float rl_test_uniform01(uint64_t seed, uint32_t env, uint32_t counter, uint32_t stream, uint32_t index) {

@@ -131,6 +131,10 @@ class _EmuEnvView:
         self._levels = host_view(nat, "TERRAIN_LEVEL")
 
     @property
+    def common_step_counter(self):
+        return self._native.step_count
+
+    @property
     def terrain_levels(self):
         return torch.from_numpy(self._levels[: self.num_envs].copy())
 
@@ -148,9 +152,10 @@ def _log_shard(rank, emu_lib):
     nat.reset()
     ep = np.zeros(N, dtype=np.int64)
     ep[: 3 + 2 * rank] = nat.max_episode_length - 1  # 3 envs of rank 0, 5 of rank 1 time out on the first step
+    ep[10:12] = nat.max_episode_length - 3           # ... and two more of each rank on the third
     host_view(nat, "EPISODE_LENGTH")[:] = ep
     rng = np.random.default_rng(7 + rank)
-    for _ in range(2):  # the second step resets nobody: the log a caller sees is still the first step's
+    for _ in range(4):  # the second and the fourth step reset nobody: the log a caller sees after them is still their predecessor's
         nat.step(rng.uniform(-1, 1, (N, desc.model.num_dof)).astype(np.float32).ctypes.data)
     return _EmuEnvView(nat, desc, N)
 
@@ -163,8 +168,9 @@ def _log_worker(rank, world, port, emu_lib, q):
     from robot_lab_amd.dist import pack_episode_log, reduce_episode_log
 
     env = _log_shard(rank, emu_lib)
-    local = pack_episode_log(env).numpy().copy()
-    fut = reduce_episode_log(env)
+    assert float(pack_episode_log(env)[0]) == 2.0  # one step: the log of the most recent step that reset an env (the third)
+    local = pack_episode_log(env, 4).numpy().copy()  # the window of a rollout: every episode that ended inside it, once
+    fut = reduce_episode_log(env, steps=4)
     res = {k: float(v) for k, v in fut.result().items()}
     q.put((rank, local, fut.vector().numpy().copy(), res))
     dist.barrier()
@@ -183,13 +189,14 @@ def test_reduce_episode_log_gives_the_jobs_means(emu_lib):
         p.join(60)
         assert p.exitcode == 0
     total = got[0][1] + got[1][1]
-    assert got[0][1][0] == 3 and got[1][1][0] == 5 and got[0][1][7] == N  # each rank's own vector: its resets, its env count
+    assert got[0][1][0] == 5 and got[1][1][0] == 7 and got[0][1][7] == N  # each rank's own vector: its resets (3 + 2, 5 + 2), its env count
+    assert got[0][1][62] == 1.0 and total[62] == world                     # a 1 per rank: the reduced vector knows the world size
     for rank, local, reduced, res in got:
         np.testing.assert_allclose(reduced, total, rtol=1e-6)          # every rank holds the same reduced vector = the sum over the shards
-        assert res["episodes"] == 8 and res["num_envs"] == world * N
-        assert res["Episode_Termination/time_out"] == 8
-        # a mean over the job's 8 ended episodes, not over one rank's: (sum_0 + sum_1) / 8 / 20 s
-        want = total[8] / 8.0 / 20.0
+        assert res["episodes"] == 12 and res["num_envs"] == world * N
+        assert res["Episode_Termination/time_out"] == 12
+        # a mean over the job's 12 ended episodes, not over one rank's: (sum_0 + sum_1) / 12 / 20 s
+        want = total[8] / 12.0 / 20.0
         first = [k for k in res if k.startswith("Episode_Reward/")][0]
         assert abs(res[first] - want) <= 1e-6 * max(1.0, abs(want))
         assert abs(res["Curriculum/terrain_levels"] - total[6] / (world * N)) < 1e-6
@@ -197,5 +204,7 @@ def test_reduce_episode_log_gives_the_jobs_means(emu_lib):
     from robot_lab_amd.dist import reduce_episode_log
 
     env = _log_shard(0, emu_lib)
-    r = reduce_episode_log(env).result()
-    assert float(r["episodes"]) == 3 and float(r["num_envs"]) == N
+    r = reduce_episode_log(env).result()  # (first call of this env: the one-step form)
+    assert float(r["episodes"]) == 2 and float(r["num_envs"]) == N
+    r = reduce_episode_log(env, steps=4).result()
+    assert float(r["episodes"]) == 5

@@ -25,8 +25,17 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("task,sid,sub,wg", CASES)
-def test_specialised_kernel_equals_interpreter_kernel(task, sid, sub, wg, monkeypatch):
+# Tasks the library has NO built-in Spec for, specialised at run time (robot_lab_amd/jit.py: Spec source from the library, hipcc on the
+# box, plugin registered, env created again on it): a quadruped of another make, a wheeled one on the merged instance, a humanoid
+JIT_CASES = [
+    ("RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0", "jit", "4", "-4"),
+    ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", "jit", "4", ""),
+    ("RobotLab-Isaac-Velocity-Rough-RobotEra-Xbot-v0", "jit", "8", "-4"),
+]
+
+
+@pytest.mark.parametrize("task,sid,sub,wg", CASES + JIT_CASES)
+def test_specialised_kernel_equals_interpreter_kernel(task, sid, sub, wg, monkeypatch, tmp_path):
     import torch
 
     from robot_lab_amd.env import ManagerBasedRLEnv
@@ -36,7 +45,13 @@ def test_specialised_kernel_equals_interpreter_kernel(task, sid, sub, wg, monkey
     if wg:
         monkeypatch.setenv("RL_ENV_WG", wg)
     monkeypatch.setenv("RL_ENV_SPEC", "1")
-    a = ManagerBasedRLEnv(task, num_envs=N, seed=11, device="cuda:0")
+    if sid == "jit":
+        monkeypatch.setenv("RL_ENV_JIT_CACHE", str(tmp_path))
+        a = ManagerBasedRLEnv(task, num_envs=N, seed=11, device="cuda:0", specialise=True)
+        assert a._native.spec_id() >= 1000 and "specialised" in repr(a), repr(a)
+        sid = a._native.spec_id()
+    else:
+        a = ManagerBasedRLEnv(task, num_envs=N, seed=11, device="cuda:0")
     monkeypatch.setenv("RL_ENV_SPEC", "0")
     b = ManagerBasedRLEnv(task, num_envs=N, seed=11, device="cuda:0")
     assert a._native.spec_id() == sid and b._native.spec_id() == 0

@@ -1,0 +1,78 @@
+"""Step kernels specialised on a task at RUN time (robot_lab_amd/jit.py; include/rl_env.h "specialising ANY task"), CPU tier: everything up
+to the device - the Spec source out of the product library, the plugin cross-compiled for gfx950 (hipcc needs no GPU), the ABI guard, the
+registry.  The kernels themselves against the interpreter: tests/test_gpu_specs.py::test_run_time_specialised_kernel_equals_interpreter."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from robot_lab_amd import capi, jit
+from robot_lab_amd.scene import build_world, load_bundle
+
+B2 = "RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return capi.load_library()
+
+
+@pytest.fixture(scope="module")
+def cache(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("jit_cache"))
+    old = os.environ.get("RL_ENV_JIT_CACHE")
+    os.environ["RL_ENV_JIT_CACHE"] = d
+    yield d
+    if old is None:
+        os.environ.pop("RL_ENV_JIT_CACHE", None)
+    else:
+        os.environ["RL_ENV_JIT_CACHE"] = old
+
+
+def _desc(task):
+    desc, extra = load_bundle(task)
+    build_world(desc, extra, 16, 0)
+    return desc
+
+
+def test_library_carries_the_stamp_of_this_tree(lib):
+    assert lib.rl_env_abi_stamp().decode() == jit.abi_stamp()
+
+
+def test_spec_source_from_the_product_library(lib):
+    src = jit.spec_source(lib, _desc(B2), "Spec_X", B2, 1234)
+    assert src.startswith("struct Spec_X {") and "ID = 1234" in src and "using TP = TopoQuad3;" in src
+    # a task with reward kinds the specialised evaluation does not implement says so (and would stay on the interpreter)
+    hs = "RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0"
+    assert jit.spec_source(lib, _desc(hs), "Spec_Y", hs, 1235) is None
+    assert "no specialised evaluation" in lib.rl_env_last_error().decode()
+
+
+def test_plugin_compiles_registers_and_is_cached(lib, cache):
+    n0 = lib.rl_env_spec_plugin_count()
+    path = jit.build_plugin(lib, _desc(B2), B2, 4)
+    assert path and os.path.isfile(path) and os.path.dirname(path) == cache
+    so = ctypes.CDLL(path)
+    for name in ("rl_spec_plugin_abi", "rl_spec_plugin_id", "rl_spec_plugin_matches", "rl_spec_plugin_launch"):
+        assert hasattr(so, name)
+    so.rl_spec_plugin_abi.restype = ctypes.c_char_p
+    assert so.rl_spec_plugin_abi().decode() == jit.abi_stamp() and so.rl_spec_plugin_id() >= 1000
+    t = os.path.getmtime(path)
+    assert jit.build_plugin(lib, _desc(B2), B2, 4) == path and os.path.getmtime(path) == t  # second time: the cache
+    assert jit.build_plugin(lib, _desc(B2), B2, 2) != path                                    # another lane mapping: another object
+    assert jit.specialise(lib, _desc(B2), B2, 4)
+    assert lib.rl_env_spec_plugin_count() == n0 + 1
+    assert jit.specialise(lib, _desc(B2), B2, 4) and lib.rl_env_spec_plugin_count() == n0 + 1
+
+
+def test_plugin_built_against_other_headers_is_refused(lib, cache, tmp_path):
+    src = jit.plugin_source(jit.spec_source(lib, _desc(B2), "Spec_Z", B2, 4321), "Spec_Z", 4321)
+    hip = tmp_path / "z.hip"
+    hip.write_text(src)
+    out = str(tmp_path / "z.so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, *jit.ENV_FLAGS, jit.stamp_flag("0123456789abcdef"), "-DRL_ENV_SPEC_SUB=4", "-shared", "-fPIC", "-o", out, str(hip)], check=True)
+    assert lib.rl_env_register_spec_plugin(out.encode()) != 0
+    assert "compiled against csrc headers 0123456789abcdef" in lib.rl_env_last_error().decode()
+    assert lib.rl_env_register_spec_plugin(b"/nonexistent/plugin.so") != 0

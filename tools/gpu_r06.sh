@@ -77,4 +77,9 @@ d)
     grep -A2 "env_kernel" $OUT/${v}_fetch.txt | head -6
   done
   ;;
+e)
+  # step kernels specialised at run time: the GPU tests of the plugin path, then every task with and without
+  timeout 900 python -m pytest tests/test_gpu_specs.py -m gpu -q -x -k "jit or Flat" > $OUT/pytest_specs_jit.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs_jit.log; tail -5 $OUT/pytest_specs_jit.log
+  timeout 2400 python tools/bench_every_task.py --jit > $OUT/all_tasks_jit.txt 2> $OUT/all_tasks_jit.err; cat $OUT/all_tasks_jit.txt | cut -c1-250
+  ;;
 esac
