@@ -51,13 +51,16 @@ constexpr uint64_t spec_rel_mask() {  // bodies whose position / velocity relati
   uint64_t m = 0;
   for (int t = 0; t < SP::N_REW; ++t) {
     const int kd = SP::REW[t].kind;
-    if (kd == 15 /*FEET_HEIGHT_BODY*/ || kd == 19 /*FEET_SLIDE*/ || kd == 27 /*FEET_HEIGHT*/) m |= SP::REW[t].body_mask;
+    if (kd == 15 /*FEET_HEIGHT_BODY*/ || kd == 19 /*FEET_SLIDE*/ || kd == 27 /*FEET_HEIGHT*/ || kd == 31 /*HANDSTAND_FEET_HEIGHT_EXP*/) m |= SP::REW[t].body_mask;
+    if (kd == 37 /*FEET_DISTANCE_Y_EXP*/ || kd == 38 /*FEET_DISTANCE_XY_EXP*/)
+      for (int i = 0; i < SP::REW[t].n_idx; ++i) m |= 1ull << SP::REW[t].idx_a[i];
   }
   return m;
 }
-// reward kinds the specialised evaluation implements (tools/gen_specs.py refuses a task with any other)
+// reward kinds the specialised evaluation implements (a task with any other runs the interpreter: tools/gen_specs.py / robot_lab_amd/jit.py
+// say so).  0 .. 38; not action_mirror (39) / action_sync (40): weight 0 in every shipped cfg.
 constexpr bool spec_kind_supported(int kd) {
-  return (kd >= 0 && kd <= 30) || kd == 34;
+  return kd >= 0 && kd <= 38;
 }
 
 // host: is the env's compiled table image exactly what the Spec was generated from?

@@ -885,6 +885,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
     // partial sums of this lane: a0 a term's main accumulator, ax its extra ones (variance: four moments; biped: the minimum)
     float a0[NT], ax[NT][4];
     float gait_air[4] = {0.f, 0.f, 0.f, 0.f}, gait_con[4] = {0.f, 0.f, 0.f, 0.f};  // the four feet of a gait term (one such term at most is specialised)
+    float wq[4] = {0.f, 0.f, 0.f, 0.f};  // |qd| of the wheel joints of a wheel_vel_penalty term (one such term at most)
     static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value;
       a0[t] = 0.f;
@@ -920,6 +921,13 @@ struct EnvProgram : EnvLane<Ctx, TP> {
           }
         });
         a0[t] = part;
+      } else if constexpr (kd == REW_WHEEL_VEL_PENALTY) {  // rewards.py:132-153: pairs (wheel body, wheel joint) - here the joints' |qd|, by the limb that owns
+        static_assert(SP::REW[t].n_idx <= 4, "wheel pairs");  // the joint, into wq[pair] (summed over the limbs below); the bodies' first-air flags: body loop
+        static_for<0, SP::REW[t].n_idx>([&](auto pc) __attribute__((always_inline)) {
+          constexpr int pi = decltype(pc)::value;
+          constexpr int jid = SP::REW[t].idx_b[pi], kj = SP::JOINT_K[jid], jj = SP::JOINT_J[jid];
+          wq[pi] = my_k == kj ? fabsf(this->qd[jj]) : 0.f;  // (counted by limb kj alone - a trunk joint sits in every lane; gsum below)
+        });
       } else if constexpr (kd == REW_JOINT_MIRROR) {  // rewards.py:259-278: a pair is counted by the limb of its first joint; the partner's angle comes over by DPP
         float part = 0.f;
         static_for<0, SP::REW[t].n_idx>([&](auto pc) __attribute__((always_inline)) {
@@ -966,9 +974,27 @@ struct EnvProgram : EnvLane<Ctx, TP> {
               gait_air[f] += is ? ca : 0.f;
               gait_con[f] += is ? cc : 0.f;
             });
+          } else if constexpr (kd == REW_WHEEL_VEL_PENALTY) {  // first-air flag of the pair's wheel body, by the lane that owns the body's slot
+            static_for<0, SP::REW[t].n_idx>([&](auto fc) __attribute__((always_inline)) {
+              constexpr int f = decltype(fc)::value;
+              ax[t][f] += valid && b == SP::REW[t].idx_a[f] && ca > 0.f && ca < fc_hi ? 1.f : 0.f;
+            });
+          } else if constexpr (kd == REW_FEET_DISTANCE_Y_EXP || kd == REW_FEET_DISTANCE_XY_EXP) {  // rewards.py:439-461, 464-505
+            static_for<0, SP::REW[t].n_idx>([&](auto fc) __attribute__((always_inline)) {
+              constexpr int f = decltype(fc)::value;
+              const float ey = ((f & 1) ? -0.5f : 0.5f) * p1 - relp.y;
+              const float ex = kd == REW_FEET_DISTANCE_XY_EXP ? (f < 2 ? 0.5f : -0.5f) * SP::REW[t].p[2] - relp.x : 0.f;
+              a0[t] += valid && b == SP::REW[t].idx_a[f] ? ex * ex + ey * ey : 0.f;
+            });
           } else if constexpr (BM != 0ull) {
             const bool on = valid && in_body_mask<BM>(b);
-            if constexpr (kd == REW_UNDESIRED_CONTACTS) a0[t] += on && hm > p0 ? 1.f : 0.f;                      // rewards.py:665-675
+            if constexpr (kd == REW_HANDSTAND_FEET_AIR_TIME) a0[t] += on && cc > 0.f && cc < fc_hi ? la - p0 : 0.f;  // .../unitree_a1_handstand/env/rewards.py:40-47
+            else if constexpr (kd == REW_HANDSTAND_FEET_ON_AIR) a0[t] += on && !(ca > 0.f && ca < fc_hi) ? 1.f : 0.f;  // .../env/rewards.py:31-37
+            else if constexpr (kd == REW_HANDSTAND_FEET_HEIGHT_EXP) {                                               // .../env/rewards.py:18-28
+              const float dz = pos.z + dot(Rwb.r2, relp) - p1;
+              a0[t] += on ? dz * dz : 0.f;
+            }
+            else if constexpr (kd == REW_UNDESIRED_CONTACTS) a0[t] += on && hm > p0 ? 1.f : 0.f;                      // rewards.py:665-675
             else if constexpr (kd == REW_CONTACT_FORCES) a0[t] += on ? fmaxf(hm - p0, 0.f) : 0.f;                 // [UPSTREAM] contact_forces
             else if constexpr (kd == REW_FEET_CONTACT_WITHOUT_CMD || kd == REW_FEET_CONTACT) a0[t] += on && cc > 0.f && cc < fc_hi ? 1.f : 0.f;  // rewards.py:416-425, 399-413
             else if constexpr (kd == REW_FEET_AIR_TIME) a0[t] += on && cc > 0.f && cc < fc_hi ? la - p0 : 0.f;    // rewards.py:340-360
@@ -1020,6 +1046,34 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         f = ((cmd_norm > p2 || bv > p1) ? run : p0 * run) * gate;
       } else if constexpr (kd == REW_JOINT_MIRROR) {
         f = cx.gsum(a0[t]) * p0 * gate;
+      } else if constexpr (kd == REW_WHEEL_VEL_PENALTY) {
+        const bool running = cmd_norm > p1 || bv > p0;
+        float part = 0.f;
+        static_for<0, SP::REW[t].n_idx>([&](auto pc) __attribute__((always_inline)) {
+          constexpr int pi = decltype(pc)::value;
+          const float fa = cx.esum(ax[t][pi]), aq = cx.gsum(wq[pi]);  // (collectives: every lane)
+          part += (running ? fa : 1.f) * aq;
+        });
+        f = part;
+      } else if constexpr (kd == REW_BASE_HEIGHT_L2) {  // rewards.py:616-644; the 3 x 3 base ray caster (velocity_env_cfg.py:78-85): ray r by lane r % LPE
+        float tgt = p0;
+        if constexpr (p1 > 0.5f) {
+          float hs = 0.f;
+#pragma unroll
+          for (int r0 = 0; r0 < 9; r0 += LPE) {
+            const int r9 = r0 + my_li < 9 ? r0 + my_li : 8;
+            const int iy = r9 / 3, ix = r9 - 3 * iy;
+            const float lx = (float)(ix - 1) * 0.05f, ly = (float)(iy - 1) * 0.05f;
+            float hz;
+            V3 nn;
+            terrain_sample(this->u, this->S.terrain, this->pos.x, this->pos.y, this->yaw_c * lx - this->yaw_s * ly, this->yaw_s * lx + this->yaw_c * ly, hz, nn);
+            hs += r0 + my_li < 9 ? hz : 0.f;
+          }
+          tgt += cx.esum(hs) * (1.0f / 9.0f);
+        }
+        f = (this->pos.z - tgt) * (this->pos.z - tgt) * gate;
+      } else if constexpr (kd == REW_FEET_DISTANCE_Y_EXP || kd == REW_FEET_DISTANCE_XY_EXP) {
+        f = fexp(-cx.esum(a0[t]) * frcp(p0)) * gate;
       } else if constexpr (kd == REW_FEET_GAIT) {  // GaitReward, rewards.py:156-256
         float air[4], con[4];
 #pragma unroll
@@ -1037,6 +1091,9 @@ struct EnvProgram : EnvLane<Ctx, TP> {
         else if constexpr (kd == REW_FEET_CONTACT_WITHOUT_CMD) f = s0 * (cmd_norm < 0.1f ? 1.f : 0.f) * gate;
         else if constexpr (kd == REW_FEET_CONTACT) f = (s0 != p0 ? 1.f : 0.f) * moving * gate;
         else if constexpr (kd == REW_FEET_AIR_TIME) f = s0 * moving * gate;
+        else if constexpr (kd == REW_HANDSTAND_FEET_AIR_TIME) f = s0;
+        else if constexpr (kd == REW_HANDSTAND_FEET_HEIGHT_EXP) f = fexp(-s0 * frcp(p0));
+        else if constexpr (kd == REW_HANDSTAND_FEET_ON_AIR) f = s0 == 0.f ? 1.f : 0.f;
         else if constexpr (kd == REW_FEET_STUMBLE) f = (s0 > 0.f ? 1.f : 0.f) * gate;
         else if constexpr (kd == REW_FEET_HEIGHT_BODY || kd == REW_FEET_HEIGHT) f = s0 * moving * gate;
         else if constexpr (kd == REW_FEET_SLIDE) f = s0 * gate;

@@ -31,6 +31,11 @@ JIT_CASES = [
     ("RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0", "jit", "4", "-4"),
     ("RobotLab-Isaac-Velocity-Rough-Deeprobotics-M20-v0", "jit", "4", ""),
     ("RobotLab-Isaac-Velocity-Rough-RobotEra-Xbot-v0", "jit", "8", "-4"),
+    # the reward kinds no built-in Spec uses: base_height_l2 (its 3 x 3 ray caster), wheel_vel_penalty, feet_distance_y_exp (Tita); the hand-stand terms
+    ("RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0", "jit", "4", "-4"),
+    ("RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0", "jit", "1", ""),
+    ("RobotLab-Isaac-Velocity-Rough-HandStand-Unitree-A1-v0", "jit", "4", "-4"),
+    ("RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0", "jit", "2", ""),
 ]
 
 

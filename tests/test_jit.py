@@ -43,9 +43,17 @@ def test_library_carries_the_stamp_of_this_tree(lib):
 def test_spec_source_from_the_product_library(lib):
     src = jit.spec_source(lib, _desc(B2), "Spec_X", B2, 1234)
     assert src.startswith("struct Spec_X {") and "ID = 1234" in src and "using TP = TopoQuad3;" in src
-    # a task with reward kinds the specialised evaluation does not implement says so (and would stay on the interpreter)
-    hs = "RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0"
-    assert jit.spec_source(lib, _desc(hs), "Spec_Y", hs, 1235) is None
+    # the kinds the built-in Specs never needed (hand-stand terms, base_height_l2, wheel_vel_penalty, feet_distance_*) are specialisable too
+    for task in ("RobotLab-Isaac-Velocity-Flat-HandStand-Unitree-A1-v0", "RobotLab-Isaac-Velocity-Rough-DDTRobot-Tita-v0"):
+        assert jit.spec_source(lib, _desc(task), "Spec_Y", task, 1235) is not None, lib.rl_env_last_error()
+    # a task with a reward kind the specialised evaluation does not implement (action_sync: weight 0 in every shipped cfg) says so and would
+    # stay on the interpreter
+    from helpers import A1_SYNC_GROUPS, set_action_sync
+
+    a1 = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
+    d = _desc(a1)
+    set_action_sync(d, "joint_power", A1_SYNC_GROUPS)
+    assert jit.spec_source(lib, d, "Spec_W", a1, 1236) is None
     assert "no specialised evaluation" in lib.rl_env_last_error().decode()
 
 

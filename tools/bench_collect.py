@@ -42,7 +42,7 @@ storage = RolloutStorage(N, T, od, cd, A, seed=1, device="cuda:0")
 
 GRAPH = os.environ.get("RL_GRAPH", "1") == "1"  # the whole iteration as one hipGraph launch (robot_lab_amd/collect.py)
 SMALL = os.environ.get("RL_CRITIC_SMALL", "1") == "1"  # (overlap) the critic through rl_mlp_forward_small
-OVERLAP = os.environ.get("RL_OVERLAP", "1") == "1"  # the critic of step t on a second stream under env step t (0: actor + critic as one launch in front of act)
+OVERLAP = os.environ.get("RL_OVERLAP", "0") == "1"  # the critic of step t on a second stream under env step t (0: actor + critic as one launch in front of act)
 if GRAPH and FUSED and PAIR:
     from robot_lab_amd.collect import Collector  # noqa: E402
 

@@ -82,4 +82,58 @@ e)
   timeout 900 python -m pytest tests/test_gpu_specs.py -m gpu -q -x -k "jit or Flat" > $OUT/pytest_specs_jit.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs_jit.log; tail -5 $OUT/pytest_specs_jit.log
   timeout 2400 python tools/bench_every_task.py --jit > $OUT/all_tasks_jit.txt 2> $OUT/all_tasks_jit.err; cat $OUT/all_tasks_jit.txt | cut -c1-250
   ;;
+f)
+  # the reward kinds added to the specialised evaluation (hand-stand terms, base_height_l2, wheel_vel_penalty, feet_distance_*): plugin kernels vs interpreter
+  timeout 900 python -m pytest tests/test_gpu_specs.py -m gpu -q -k "jit" > $OUT/pytest_specs_jit.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs_jit.log; tail -25 $OUT/pytest_specs_jit.log
+  timeout 600 python tools/bench_every_task.py --jit 2>/dev/null | grep -i "tita\|handstand" | cut -c1-250
+  ;;
+z)
+  # FINAL TREE: the whole GPU tier, smoke(), the bench lines of the BASELINE configs, kernel traces + counter passes, phase clocks, the collection loop
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -4 $OUT/pytest_gpu.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  mv gpurun_out/spec_vs_interpreter.jsonl gpurun_out/train_distributed_8ranks.json $OUT/ 2>/dev/null
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
+  grep -E "smoke|rc=|Error" $OUT/smoke.log | tail -8
+  timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_driver_flags.json 2> /dev/null
+  for t in $GO2 $GO2W; do timeout 200 python bench.py --task $t --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_$(echo $t | cut -d- -f6).json 2>/dev/null; done
+  timeout 200 python bench.py --task $G1 --num-envs 2048 --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_G1.json 2>/dev/null
+  timeout 200 python bench.py --task RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0 --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_A1_Flat.json 2>/dev/null
+  python - <<PY | tee $OUT/baseline_configs.txt
+import json
+for n in ("bench_default", "bench_driver_flags", "bench_Go2", "bench_Go2W", "bench_G1", "bench_A1_Flat"):
+    try:
+        d = json.load(open("$OUT/%s.json" % n))
+    except Exception as ex:
+        print(n, "unreadable", ex); continue
+    print("%-20s %-62s value %7.2f M env-steps/s  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f  resets in window %s  %s" % (n, d["config"]["workload"].split(",")[0], d["value"] / 1e6, d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d.get("window", {}).get("envs_reset_in_window"), d["config"].get("step_kernel")))
+d = json.load(open("$OUT/bench_default.json"))
+for leg in ("mid_batch", "large_batch"):
+    print(leg, {k: d.get(leg, {}).get(k) for k in ("envs_per_gpu", "value", "ms_per_step", "roofline_frac", "envs_per_wavefront")})
+print("cpu_baseline", {k: d["cpu_baseline"].get(k) for k in ("value", "cores", "kind", "per_core")}, d["cpu_baseline"].get("reference_terms_cpu", {}))
+PY
+  A1S="python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --large-batch-envs 0"
+  A1FULL="python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline"
+  G1S="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --large-batch-envs 0 --task $G1 --num-envs 2048"
+  SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+  WAIT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"
+  prof a1_kernel_stats "$A1FULL" --kernel-trace --stats
+  prof g1_kernel_stats "$G1S" --kernel-trace --stats
+  for cfg in "a1:$A1S" "g1:$G1S"; do
+    name=${cfg%%:*}; cmd=${cfg#*:}
+    prof ${name}_pmc_fetch "$cmd" --pmc FETCH_SIZE
+    prof ${name}_pmc_write "$cmd" --pmc WRITE_SIZE
+    prof ${name}_pmc_sq "$cmd" --pmc $SQ
+    prof ${name}_pmc_wait "$cmd" --pmc $WAIT
+  done
+  head -9 $OUT/a1_kernel_stats.txt; head -6 $OUT/g1_kernel_stats.txt
+  RL_ENV_LIB=$V/clockspec_34.so timeout 200 python tools/phase_clock.py $A1 4096 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_a1.txt
+  RL_ENV_LIB=$V/clockspec_78.so timeout 200 python tools/phase_clock.py $G1 2048 2>&1 | grep -v amdgpu.ids > $OUT/phase_clock_g1.txt
+  head -30 $OUT/phase_clock_g1.txt
+  timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -1 > $OUT/collect.txt
+  timeout 300 python tools/bench_collect.py $G1 2048 20 2>/dev/null | tail -1 >> $OUT/collect.txt
+  cat $OUT/collect.txt
+  timeout 120 python tools/train_demo.py --iterations 300 2>/dev/null | tail -4 > $OUT/train_demo_a1_flat_300.txt; cat $OUT/train_demo_a1_flat_300.txt
+  ;;
 esac
