@@ -87,6 +87,21 @@ f)
   timeout 900 python -m pytest tests/test_gpu_specs.py -m gpu -q -k "jit" > $OUT/pytest_specs_jit.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs_jit.log; tail -25 $OUT/pytest_specs_jit.log
   timeout 600 python tools/bench_every_task.py --jit 2>/dev/null | grep -i "tita\|handstand" | cut -c1-250
   ;;
+zz)
+  # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
+  # smoke(), the default bench line and the driver's flags
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -4 $OUT/pytest_gpu.log
+  mkdir -p $OUT/teacher_forced && mv gpurun_out/teacher_forced_*.json $OUT/teacher_forced/ 2>/dev/null
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
+  grep -E "smoke|rc=|Error" $OUT/smoke.log | tail -8
+  timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+  timeout 100 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> /dev/null
+  python -c "
+import json
+for n in ('bench_default','bench_driver_flags'):
+    d=json.load(open('$OUT/%s.json' % n)); print(n, 'value %.2f M  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']), d['config'].get('step_kernel'), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'), d.get('cpu_baseline',{}).get('value'))"
+  ;;
 z)
   # FINAL TREE: the whole GPU tier, smoke(), the bench lines of the BASELINE configs, kernel traces + counter passes, phase clocks, the collection loop
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
