@@ -87,6 +87,24 @@ f)
   timeout 900 python -m pytest tests/test_gpu_specs.py -m gpu -q -k "jit" > $OUT/pytest_specs_jit.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs_jit.log; tail -25 $OUT/pytest_specs_jit.log
   timeout 600 python tools/bench_every_task.py --jit 2>/dev/null | grep -i "tita\|handstand" | cut -c1-250
   ;;
+g)
+  # soak: humanoids that are never reset (RL_ENV_TERMS=0: they fall and lie on the ground for thousands of steps - the trunk-link contacts of
+  # csrc/env_step.h substep_aba_trunk under load), and the default A1 / G1 runs; finiteness and envelopes
+  for t in $G1 RobotLab-Isaac-Velocity-Rough-Booster-T1-v0 $GR1; do
+    RL_ENV_TERMS=0 timeout 400 python tools/soak.py $t 2000 random 2048 2>&1 | grep -v amdgpu | tail -5 >> $OUT/soak_no_terminations.txt
+    RL_ENV_TERMS=0 timeout 400 python tools/soak.py $t 1000 zero 2048 2>&1 | grep -v amdgpu | tail -3 >> $OUT/soak_no_terminations.txt
+  done
+  cat $OUT/soak_no_terminations.txt | cut -c1-260
+  timeout 400 python tools/soak.py $A1 3000 random 4096 2>&1 | grep -v amdgpu | tail -3 > $OUT/soak.txt
+  timeout 400 python tools/soak.py $G1 3000 random 2048 2>&1 | grep -v amdgpu | tail -3 >> $OUT/soak.txt
+  cat $OUT/soak.txt | cut -c1-260
+  ;;
+h)
+  # G1 Velocity-Flat under the reference's cfg with the stand-in learner, after the trunk-link-share fix: does it still settle into the crouch of
+  # rounds 3 - 5 (open finding)?  600 iterations, the posture of the batch every 50
+  timeout 900 python tools/train_demo.py --task RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0 --iterations 600 --print-every 50 2>/dev/null | tail -16 > $OUT/train_g1_flat_600.txt
+  cat $OUT/train_g1_flat_600.txt | cut -c1-260
+  ;;
 zz)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
