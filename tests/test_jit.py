@@ -84,3 +84,13 @@ def test_plugin_built_against_other_headers_is_refused(lib, cache, tmp_path):
     assert lib.rl_env_register_spec_plugin(out.encode()) != 0
     assert "compiled against csrc headers 0123456789abcdef" in lib.rl_env_last_error().decode()
     assert lib.rl_env_register_spec_plugin(b"/nonexistent/plugin.so") != 0
+
+
+def test_failures_fall_back_to_the_interpreter(lib, monkeypatch):
+    """An unwritable cache directory, a compiler that is not there: one log line and False (the caller keeps its interpreter env), never an exception."""
+    monkeypatch.setenv("RL_ENV_JIT_CACHE", "/proc/nonexistent/cache")
+    assert jit.specialise(lib, _desc(B2), B2, 4) is False
+    monkeypatch.delenv("RL_ENV_JIT_CACHE")
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("RL_ENV_JIT_CACHE", "/tmp")
+    assert jit.build_plugin(lib, _desc("RobotLab-Isaac-Velocity-Rough-Unitree-B2W-v0"), "b2w", 2) is None

@@ -105,6 +105,15 @@ h)
   timeout 900 python tools/train_demo.py --task RobotLab-Isaac-Velocity-Flat-Unitree-G1-v0 --iterations 600 --print-every 50 2>/dev/null | tail -16 > $OUT/train_g1_flat_600.txt
   cat $OUT/train_g1_flat_600.txt | cut -c1-260
   ;;
+i)
+  # stress of the run-time specialisation: the oracle parity tiers with RL_ENV_JIT=1, i.e. EVERY task of the free-run / teacher-forced / all-tasks
+  # tests on a step kernel specialised at create (24 ids x kernel shapes against the fp64 oracle, not only against the interpreter)
+  export RL_ENV_JIT=1 RL_ENV_JIT_CACHE=/tmp/jit_cache_tier
+  timeout 3000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_teacher_forced.py tests/test_gpu_all_tasks.py tests/test_gpu_edge_cases.py tests/test_gpu_episode_stats.py -m gpu -q > $OUT/pytest_jit_tier.log 2>&1; echo "rc=$?" >> $OUT/pytest_jit_tier.log
+  tail -12 $OUT/pytest_jit_tier.log
+  ls /tmp/jit_cache_tier | wc -l
+  grep -c "compiling a step kernel" $OUT/pytest_jit_tier.log
+  ;;
 zz)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
