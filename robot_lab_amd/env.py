@@ -270,7 +270,7 @@ class ManagerBasedRLEnv(_EnvBase):
         heights, terrain_origins, env_origins = build_world(desc, extra or {}, self.num_envs, terrain_seed)
         with torch.cuda.device(self._dev_index):
             self._native = NativeEnv(desc, heights, terrain_origins, env_origins, self.num_envs, self._seed, self._dev_index, lib_path)
-            # `specialise` (None: RL_ENV_JIT=1): a task the library has no specialised step kernel for gets one compiled now - or loaded from
+            # `specialise` (None: RL_ENV_JIT, default on): a task the library has no specialised step kernel for gets one compiled now - or loaded from
             # the cache - and the env is created again on it (robot_lab_amd/jit.py; any failure there: one log line and this interpreter env)
             from . import jit
 

@@ -11,6 +11,12 @@ EMU_LIB = os.path.join(ROOT, "tests", "emu", "librl_env_emu.so")
 REFERENCE = "/root/reference/source/robot_lab"
 
 
+# Step kernels specialised at run time (robot_lab_amd/jit.py) are ON by default for users; the tiers pin them OFF and opt in case by case
+# (tests/test_gpu_specs.py JIT_CASES, tests/test_jit.py), so that what a test runs - and how long a tier takes - does not depend on what a
+# box's cache holds.  RL_ENV_JIT=1 from outside runs a whole tier on run-time specialised kernels (profiles/r06i_pytest_jit_tier_tail.txt).
+os.environ.setdefault("RL_ENV_JIT", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
     config.addinivalue_line("markers", "reference: needs /root/reference (skipped where it is absent)")
