@@ -114,6 +114,21 @@ i)
   ls /tmp/jit_cache_tier | wc -l
   grep -c "compiling a step kernel" $OUT/pytest_jit_tier.log
   ;;
+zz2)
+  # after the run-time specialisation became the default: the whole GPU tier again (the tiers pin it off: same run time), smoke(), the default
+  # bench line, and a task without a built-in Spec through bench.py with no flag at all
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -4 $OUT/pytest_gpu.log
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?" >> $OUT/smoke.log
+  grep -E "smoke|rc=|Error|jit" $OUT/smoke.log | tail -8
+  timeout 400 python bench.py --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err; grep jit $OUT/bench_default.err
+  timeout 400 python bench.py --task RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_B2.json 2> $OUT/bench_B2.err; grep jit $OUT/bench_B2.err
+  RL_ENV_JIT=0 timeout 400 python bench.py --task RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0 --no-cpu-baseline --large-batch-envs 0 > $OUT/bench_B2_nojit.json 2> /dev/null
+  python -c "
+import json
+for n in ('bench_default','bench_B2','bench_B2_nojit'):
+    d=json.load(open('$OUT/%s.json' % n)); print(n, 'value %.2f M  kernel_ms %.4f' % (d['value']/1e6, d['roofline']['kernel_ms']), d['config'].get('step_kernel'))"
+  ;;
 zz)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
