@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 TASK = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
 
 
-def _setup(use_graph, N=256, T=24, overlap=False, critic_small=False):
+def _setup(use_graph, N=256, T=24, overlap=False, critic_small=False, task=TASK, specialise=None):
     import torch
 
     from robot_lab_amd.collect import Collector
@@ -17,7 +17,7 @@ def _setup(use_graph, N=256, T=24, overlap=False, critic_small=False):
     from robot_lab_amd.policy import MlpPolicy
     from robot_lab_amd.rollout import RolloutStorage
 
-    env = ManagerBasedRLEnv(TASK, num_envs=N, seed=11, device="cuda:0")
+    env = ManagerBasedRLEnv(task, num_envs=N, seed=11, device="cuda:0", specialise=specialise)
     obs, _ = env.reset()
     od, cd, A = obs["policy"].shape[1], obs["critic"].shape[1], env.num_actions
     rng = np.random.default_rng(0)
@@ -100,4 +100,24 @@ def test_overlapped_collection_equals_the_serial_one(small):
         timeouts += int(st_o.dones.sum())
     assert timeouts > 0
     for e in (env_s, env_o):
+        e.close()
+
+
+def test_graph_replay_on_a_run_time_specialised_env(monkeypatch, tmp_path):
+    """The captured collection loop around an env whose step kernel is a run-time plugin (robot_lab_amd/jit.py): the plugin's launches are
+    captured and replayed like the library's own - graph == eager bit for bit, and both on the specialised kernel."""
+    import torch
+
+    monkeypatch.setenv("RL_ENV_JIT_CACHE", str(tmp_path))
+    task = "RobotLab-Isaac-Velocity-Rough-Unitree-B2-v0"
+    env_e, st_e, eager = _setup(False, task=task, specialise=True)
+    env_g, st_g, graph = _setup(True, task=task, specialise=True)
+    assert env_e._native.spec_id() >= 1000 and env_g._native.spec_id() == env_e._native.spec_id()
+    for it in range(3):
+        eager.collect(), graph.collect()
+        torch.cuda.synchronize()
+        for name in ("observations", "privileged_observations", "actions", "values", "rewards", "dones", "returns", "advantages"):
+            a, b = getattr(st_e, name), getattr(st_g, name)
+            assert torch.equal(a, b), f"iteration {it}: {name} differs (max |d| {float((a.float() - b.float()).abs().max()):.3e})"
+    for e in (env_e, env_g):
         e.close()

@@ -129,6 +129,10 @@ import json
 for n in ('bench_default','bench_B2','bench_B2_nojit'):
     d=json.load(open('$OUT/%s.json' % n)); print(n, 'value %.2f M  kernel_ms %.4f' % (d['value']/1e6, d['roofline']['kernel_ms']), d['config'].get('step_kernel'))"
   ;;
+j)
+  # the captured collection loop around a run-time specialised env
+  timeout 600 python -m pytest tests/test_gpu_collect.py -m gpu -q > $OUT/pytest_collect.log 2>&1; echo "rc=$?" >> $OUT/pytest_collect.log; tail -5 $OUT/pytest_collect.log
+  ;;
 zz)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
