@@ -57,6 +57,25 @@ constexpr uint64_t spec_rel_mask() {  // bodies whose position / velocity relati
   }
   return m;
 }
+// Axis kinds of the limb joints (round 6): SP::AXIS_KIND[j] = 0 / 1 / 2 when limb joint j of EVERY limb turns about +-e_x / e_y / e_z of its
+// joint frame (exactly: components 0 and +-1 after the tables' normalisation), 3 otherwise.  The kinematics of a Spec then compose
+// R_parent * Rot(e_i, q) in its sparse form (12 multiply-adds and no Rodrigues matrix instead of ~50 instructions, env_step.h
+// chain_kinematics) - five kinematics passes per step on the quadrupeds.  The interpreter (NoSpec) and the trunk + limbs instances: general.
+template <class SP>
+constexpr int spec_axis_kind(int j) {
+  if constexpr (SP::ON) return SP::AXIS_KIND[j];
+  else return 3;
+}
+// the kind the tables of limb k give joint slot j (host: spec generator and spec_matches)
+template <class LT>
+inline int table_axis_kind(const LT& L, int j) {
+  int kind = 3;
+  for (int i = 0; i < 3; ++i) {
+    const float a = L.axis[j][i], b = L.axis[j][(i + 1) % 3], c = L.axis[j][(i + 2) % 3];
+    if ((a == 1.0f || a == -1.0f) && b == 0.0f && c == 0.0f) kind = i;
+  }
+  return kind;
+}
 // reward kinds the specialised evaluation implements (a task with any other runs the interpreter: tools/gen_specs.py / robot_lab_amd/jit.py
 // say so).  0 .. 38; not action_mirror (39) / action_sync (40): weight 0 in every shipped cfg.
 constexpr bool spec_kind_supported(int kd) {
@@ -71,6 +90,9 @@ inline bool spec_matches(const TablesT<TopoMax>& T) {
       T.n_bodies != SP::N_BODIES)
     return false;
   if (T.n_rewards != SP::N_REW || T.cur_lin || T.cur_ang) return false;
+  for (int j = 0; j < SP::TP::CL; ++j)  // a joint the Spec composes in sparse form must be axis-aligned in every limb of THIS env's tables
+    for (int k = 0; k < NLANE; ++k)
+      if (SP::AXIS_KIND[j] != 3 && table_axis_kind(T.lane[k], j) != SP::AXIS_KIND[j]) return false;
   // the joint map: task joint jid = slot JOINT_J[jid] of limb JOINT_K[jid], and nothing else is owned
   int owned = 0;
   for (int k = 0; k < NLANE; ++k)

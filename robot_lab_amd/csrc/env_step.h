@@ -17,6 +17,7 @@
 #pragma once
 #include <type_traits>
 
+#include "env_spec.h"
 #include "env_tables.h"
 
 // RL_PHASE(id, "name") marks a phase boundary of the lane program.  Product builds: nothing.  Analysis builds of the device code:
@@ -323,7 +324,20 @@ struct NoJoint {
 };
 // `restart`: bit i = trunk joint i hangs off the base (the trunk is one serial spine, or - Booster T1: a waist and a neck on the base -
 // several serial pieces that each start at the base; a piece is a run of consecutive trunk joints)
-template <class TP, class CT, class FT = NoJoint, class FL = NoJoint>
+// Rp * Rot(sg e_KIND, ang): a rotation about a basis vector of the joint frame touches two columns of Rp (env_spec.h spec_axis_kind)
+template <int KIND>
+RL_FN M3 mul_axis_rot(const M3& Rp, float sg, float ang) {
+  float s, c;
+  fsincos(ang, s, c);
+  s *= sg;
+  auto row = [&](V3 r) -> V3 {
+    if constexpr (KIND == 0) return {r.x, c * r.y + s * r.z, c * r.z - s * r.y};
+    else if constexpr (KIND == 1) return {c * r.x - s * r.z, r.y, s * r.x + c * r.z};
+    else return {c * r.x + s * r.y, c * r.y - s * r.x, r.z};
+  };
+  return {row(Rp.r0), row(Rp.r1), row(Rp.r2)};
+}
+template <class TP, class SP = NoSpec, class CT, class FT = NoJoint, class FL = NoJoint>
 RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT& C, uint32_t restart = 0u, FT&& on_trunk = FT{}, FL&& on_limb = FL{}) {
   constexpr int CL = TP::CL, NW = TP::NW;
   M3 Rp = identity3(), Ra = identity3();
@@ -346,19 +360,28 @@ RL_FN void chain_kinematics(const LaneTabT<TP>& L, const float (&q)[TP::JX], CT&
   }
   Rp = Ra;
   pp = pa;
-#pragma unroll
-  for (int j = 0; j < CL; ++j) {
+  static_for<0, CL>([&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int KIND = spec_axis_kind<SP>(j);
     V3 al, oj;
     joint_origin_axis(L, j, oj, al);
     V3 pj = pp + mul(Rp, oj);
     if (TP::ROT) Rp = mul(Rp, ld_m3(L.rot0[TP::ROT ? j : 0]));
-    M3 Rj = mul(Rp, rodrigues(al, q[j]));
-    const V3 aw = mul(Rp, al);
+    M3 Rj;
+    V3 aw;
+    if constexpr (KIND == 3) {
+      Rj = mul(Rp, rodrigues(al, q[j]));
+      aw = mul(Rp, al);
+    } else {  // the joint turns about +- a basis vector of its frame in every limb (the sign: this limb's table)
+      const float sg = KIND == 0 ? al.x : (KIND == 1 ? al.y : al.z);
+      Rj = mul_axis_rot<KIND>(Rp, sg, q[j]);
+      aw = sg * (KIND == 0 ? col0(Rp) : (KIND == 1 ? col1(Rp) : col2(Rp)));
+    }
     C.set(j, Rj, pj, aw);
     on_limb(j, aw, pj);
     Rp = Rj;
     pp = pj;
-  }
+  });
 }
 
 template <class TP, class LT>
@@ -564,7 +587,7 @@ struct LsFor {  // lane scratchpad layout of an instance
   using type = LsLayout<ROWS, STASH, GRAN, STASH_GRAN>;
 };
 
-template <class Ctx, class TP>
+template <class Ctx, class TP, class SP = NoSpec>
 struct EnvLane {
   static constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NB = TP::NB, SPL = TP::SPL, NBS = TP::NBS, NGRP = TP::CL + 1;
   using LS = typename LsFor<TP, Ctx::SUB>::type;
@@ -598,7 +621,7 @@ struct EnvLane {
       return;
     }
 #endif
-    chain_kinematics<TP>(L, q, C, u.trunk_restart, on_trunk, on_limb);
+    chain_kinematics<TP, SP>(L, q, C, u.trunk_restart, on_trunk, on_limb);
   }
   RL_FN ChainTP new_chain() const { return ChainTP(LDSU ? ctx.limb_chain() : nullptr); }
 
@@ -1315,7 +1338,7 @@ struct EnvLane {
   RL_FN void substeps_aba(const float (&q_tgt)[JX], const float (&qd_tgt)[JX], int n) {
     const uint32_t slot_valid = (uint32_t)ctx.uniform_i((int)T.slot_valid);
     ChainTP C = new_chain();
-    chain_kinematics<TP>(L, q, C);
+    chain_kinematics<TP, SP>(L, q, C);
     M3 Rwb = quat_to_mat(quat);
     GroupFetch gf[NIT];
     bool fetched[NIT];
@@ -1339,7 +1362,7 @@ struct EnvLane {
       integrate(Rwb, V0, nu0, qdn);
       if (s + 1 < n) {
         RL_PHASE(2, "sub.actuators+kinematics");
-        chain_kinematics<TP>(L, q, C);
+        chain_kinematics<TP, SP>(L, q, C);
         Rwb = quat_to_mat(quat);
         fetch_all(C, Rwb, slot_valid, gf, fetched);
       }

@@ -345,8 +345,8 @@ RL_FN float term_value(const TabT& T, const Uni& u, const float* __restrict__ te
 
 
 template <class Ctx, class TP, class SP = NoSpec>
-struct EnvProgram : EnvLane<Ctx, TP> {
-  using Base = EnvLane<Ctx, TP>;
+struct EnvProgram : EnvLane<Ctx, TP, SP> {
+  using Base = EnvLane<Ctx, TP, SP>;
   using ChainTP = typename Base::ChainTP;
   static constexpr Layout LY = Base::LY;
   static constexpr int CL = TP::CL, NW = TP::NW, JX = TP::JX, NBS = TP::NBS;
@@ -766,7 +766,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       const bool any_rel = ctx.uniform_i((int)(rel_mask != 0ull)) != 0;
       ChainTP C = this->new_chain();
       // (trunk + limbs instance: the chain words in LDS already hold the kinematics of the final joint positions, step() stage 3)
-      if (any_rel && NW == 0) chain_kinematics<TP>(L, q, C);
+      if (any_rel && NW == 0) chain_kinematics<TP, SP>(L, q, C);
 #pragma unroll
       for (int i = 0; i < Base::MAXOWN; ++i) {
         const int s = this->own[i];
@@ -947,7 +947,7 @@ struct EnvProgram : EnvLane<Ctx, TP> {
       constexpr uint64_t REL = spec_rel_mask<SP>();
       ChainTP C = this->new_chain();
       // (trunk + limbs instance: the chain words in LDS already hold the kinematics of the final joint positions, step() stage 3)
-      if constexpr (REL != 0ull && NW == 0) chain_kinematics<TP>(L, q, C);
+      if constexpr (REL != 0ull && NW == 0) chain_kinematics<TP, SP>(L, q, C);
 #pragma unroll
       for (int i = 0; i < Base::MAXOWN; ++i) {
         const int so = this->own[i];

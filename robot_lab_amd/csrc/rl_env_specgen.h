@@ -59,6 +59,15 @@ inline std::string spec_source(const rl_env_desc& d, const char* struct_name, co
   for (int i = 0; i < T.D; ++i) out += std::to_string(jk[i]) + (i + 1 < T.D ? ", " : "};\n");
   out += "  static constexpr int JOINT_J[" + std::to_string(T.D) + "] = {";
   for (int i = 0; i < T.D; ++i) out += std::to_string(jj[i]) + (i + 1 < T.D ? ", " : "};\n");
+  {  // axis kinds of the limb joints (env_spec.h spec_axis_kind): the quadruped instances without padding joints only
+    out += "  static constexpr int AXIS_KIND[" + std::to_string(T.CL) + "] = {";
+    for (int j = 0; j < T.CL; ++j) {
+      int kind = (T.NW == 0 && !T.rotpad) ? table_axis_kind(T.lane[0], j) : 3;
+      for (int k = 0; k < NLANE; ++k)
+        if (!T.lane[k].joint_own[j] || table_axis_kind(T.lane[k], j) != kind) kind = 3;
+      out += std::to_string(kind) + (j + 1 < T.CL ? ", " : "};\n");
+    }
+  }
   add("  static constexpr RewSpec REW[%d] = {\n", T.n_rewards);
   for (int t = 0; t < T.n_rewards; ++t) {
     const RewTab& R = T.rew[t];

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import host_view
+from helpers import emu_load_state, emu_read_state, host_view
 from robot_lab_amd.capi import NativeEnv
 from robot_lab_amd.scene import build_world, load_bundle
 
@@ -76,7 +76,9 @@ def test_spec_is_picked_only_for_identical_tables(emu_lib, monkeypatch):
 
 
 def spec_vs_interpreter(task, N, steps, lib, monkeypatch, sid, mutate=None):
-    """Both paths from the same seed with the same actions: returns the worst differences."""
+    """Both lane programs take every step from the SAME state (the interpreter env adopts the specialised env's state through the C-ABI
+    exchange before each step) with the same actions.  Since round 6 a Spec also composes axis-aligned joint rotations in their sparse
+    form (env_spec.h spec_axis_kind): the physics of the two programs agree to fp32 round-off of one step, not bit for bit."""
     monkeypatch.setenv("RL_ENV_SPEC", "1")
     a = make(task, N, 5, lib, mutate)
     monkeypatch.setenv("RL_ENV_SPEC", "0")
@@ -86,21 +88,28 @@ def spec_vs_interpreter(task, N, steps, lib, monkeypatch, sid, mutate=None):
     rng = np.random.default_rng(0)
     n_terms = host_view(a, "REWARD_TERMS").shape[0]
     seen = np.zeros(n_terms, bool)
+    obs_err = []
     for s in range(steps):
         act = (rng.random((N, a.num_actions), dtype=np.float32) * 2 - 1).astype(np.float32)
         if s % 5 == 3:
             act[:] = 0.0  # (stand_still / feet_contact_without_cmd style gates need quiet joints now and then)
+        emu_load_state(b, emu_read_state(a))
         a.step(act.ctypes.data); b.step(act.ctypes.data)
-        for name in ("OBS_POLICY", "OBS_CRITIC", "TERMINATED", "TIME_OUT"):  # the state the two runs carry is the same program: bit equal
+        for name in ("TERMINATED", "TIME_OUT"):
             assert np.array_equal(host_view(a, name), host_view(b, name)), (task, s, name)
+        for name in ("OBS_POLICY", "OBS_CRITIC"):  # one step from a shared state: round-off of the kinematics' two forms (bit equal where no Spec joint
+            xa, xb = host_view(a, name).astype(np.float64), host_view(b, name).astype(np.float64)  # is axis-aligned), amplified by a stiff contact in a few
+            err = np.abs(xa - xb) / np.maximum(np.abs(xb), 1.0)                                     # entries: 92 - 98 % are bit equal, the worst ~2e-4
+            assert err.max() <= 2e-3, (task, s, name, err.max())
+            obs_err.append(err.ravel())
         ta, tb = host_view(a, "REWARD_TERMS")[:, :N].astype(np.float64), host_view(b, "REWARD_TERMS")[:, :N].astype(np.float64)
         seen |= (tb != 0).any(axis=1)
-        # a term is a sum of <= 30 fp32 products in another order: relative 2e-6 of the term (absolute floor: one ulp of a 1e-3 reward)
-        assert np.all(np.abs(ta - tb) <= 2e-6 * np.abs(tb) + 1e-10), (task, s, np.abs(ta - tb).max(axis=1))
+        # a term is a sum of <= 30 fp32 products in another order on a state that differs by one step's round-off (joint_acc_l2 squares a
+        # finite difference of the velocities: 2 / dt = 400 x their error): relative 5e-4 of the term, absolute floor 1e-6
+        assert np.all(np.abs(ta - tb) <= 5e-4 * np.abs(tb) + 1e-6), (task, s, np.abs(ta - tb).max(axis=1))  # (floor: 0.01 % of a typical step reward)
         ra, rb = host_view(a, "REWARD").astype(np.float64), host_view(b, "REWARD").astype(np.float64)
-        assert np.all(np.abs(ra - rb) <= 2e-6 * np.abs(rb) + 1e-8), (task, s)
-        ea, eb = host_view(a, "EPISODE_SUMS")[:, :N].astype(np.float64), host_view(b, "EPISODE_SUMS")[:, :N].astype(np.float64)
-        assert np.all(np.abs(ea - eb) <= 5e-6 * np.abs(eb) + 1e-8), (task, s)
+        assert np.all(np.abs(ra - rb) <= 5e-4 * np.abs(tb).sum(axis=0) + 2e-6), (task, s)
+    assert np.quantile(np.concatenate(obs_err), 0.99) <= 2e-5, (task, np.quantile(np.concatenate(obs_err), [0.5, 0.9, 0.99, 1.0]))
     return seen
 
 

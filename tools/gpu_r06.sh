@@ -133,6 +133,18 @@ j)
   # the captured collection loop around a run-time specialised env
   timeout 600 python -m pytest tests/test_gpu_collect.py -m gpu -q > $OUT/pytest_collect.log 2>&1; echo "rc=$?" >> $OUT/pytest_collect.log; tail -5 $OUT/pytest_collect.log
   ;;
+k)
+  # axis-aligned joint rotations composed in their sparse form by the Specs (env_spec.h spec_axis_kind): the specialised A1 / Go2W kernels
+  # of the commit before against the tree's, one call; then the spec / canary / teacher-forced tiers of the quadrupeds
+  timeout 400 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/old_34.so $V/new_34.so > $OUT/axis_kind_ab.txt 2>&1
+  timeout 400 python tools/ab_bench.py --task $GO2W --num-envs 4096 --rounds 3 --steady $V/old_1044.so $V/new_1044.so >> $OUT/axis_kind_ab.txt 2>&1
+  grep -v amdgpu $OUT/axis_kind_ab.txt
+  timeout 900 python -m pytest tests/test_gpu_specs.py tests/test_gpu_canary.py -m gpu -q -x > $OUT/pytest_specs_canary.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs_canary.log; tail -4 $OUT/pytest_specs_canary.log
+  timeout 900 python -m pytest tests/test_gpu_teacher_forced.py -m gpu -q -x -k "A1 or Go2 or Go2W or M20 or B2W" > $OUT/pytest_tf.log 2>&1; echo "rc=$?" >> $OUT/pytest_tf.log; tail -4 $OUT/pytest_tf.log
+  timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_default.json 2> /dev/null; python -c "
+import json
+d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  kernel_ms %.4f frac %.4f' % (d['value']/1e6, d['roofline']['kernel_ms'], d['roofline']['frac']), d['config'].get('step_kernel'))"
+  ;;
 zz)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
@@ -148,7 +160,7 @@ import json
 for n in ('bench_default','bench_driver_flags'):
     d=json.load(open('$OUT/%s.json' % n)); print(n, 'value %.2f M  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']), d['config'].get('step_kernel'), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'), d.get('cpu_baseline',{}).get('value'))"
   ;;
-z)
+z|z2)
   # FINAL TREE: the whole GPU tier, smoke(), the bench lines of the BASELINE configs, kernel traces + counter passes, phase clocks, the collection loop
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   tail -4 $OUT/pytest_gpu.log
