@@ -145,6 +145,10 @@ k)
 import json
 d=json.load(open('$OUT/bench_default.json')); print('bench_default value %.2f M  kernel_ms %.4f frac %.4f' % (d['value']/1e6, d['roofline']['kernel_ms'], d['roofline']['frac']), d['config'].get('step_kernel'))"
   ;;
+l)
+  timeout 900 python -m pytest tests/test_gpu_specs.py -m gpu -q > $OUT/pytest_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs.log; tail -5 $OUT/pytest_specs.log
+  mv gpurun_out/spec_vs_interpreter.jsonl $OUT/ 2>/dev/null
+  ;;
 zz)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
