@@ -27,6 +27,11 @@
 //                     [wavefront][id] behind the reward-term rows (tools/phase_clock.py reads them): s_waitcnt 0, read the clock,
 //                     add the interval to the phase that ends, read the clock again - the bookkeeping itself is not counted.
 // The ids index tools/phase_clock.py PHASES.
+// RL_PK: the joint elimination and the contact blocks on packed fp32 pairs (rl_math.h F2p; eliminate_pk below).  On by default - one call,
+// specialised kernels: A1 33.95 -> 33.61 us, G1 86.19 -> 84.65 (profiles/r06m_a1_pk_ab.txt, r06m_g1_pk_ab.txt); -DRL_NO_PK: the scalar form.
+#if !defined(RL_NO_PK) && !defined(RL_PK)
+#define RL_PK 1
+#endif
 #if defined(RL_PHASE_MARKS) && defined(__HIP_DEVICE_COMPILE__)
 #define RL_PHASE(id, name) asm volatile("; PHASE " name)
 #elif defined(RL_PHASE_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
@@ -1140,6 +1145,13 @@ struct EnvLane {
     float A[B6::size];  // 6 x 6 symmetric, [omega; v] order
     float r[6];
   };
+#ifdef RL_PK_CONTACT_ALL  // (A/B switches: the contact blocks on packed pairs in every instance / in none)
+  static constexpr bool PK_CONTACT = true;
+#elif defined(RL_NO_PK_CONTACT)
+  static constexpr bool PK_CONTACT = false;
+#else
+  static constexpr bool PK_CONTACT = NW > 0;
+#endif
   struct GroupFetch {
     float rad[SPL];
     V3 cb[SPL], cw[SPL];
@@ -1227,6 +1239,28 @@ struct EnvLane {
         b6[B6::at(2, 3)] = -kt * x.y; b6[B6::at(2, 4)] = kt * x.x;
         b6[B6::at(3, 3)] = kt; b6[B6::at(4, 4)] = kt; b6[B6::at(5, 5)] = kt;
         auto add_to = [&](LinkRec& d) __attribute__((always_inline)) {
+#ifdef RL_PK  // the same sums pair by pair (eliminate_pk has the pairing of the packed triangle): d.A += b + (kn g) g^T, d.r += fb g
+          // (not the merged instances: their two call sites - base share or link - are tail-merged into one body behind a SELECTED record
+          // address, and both records leave the registers: 208 - 544 B of private memory per lane, the build's gate)
+          if constexpr (!M0 && PK_CONTACT) {
+          const F2p g01 = pk2(g6[0], g6[1]), g23 = pk2(g6[2], g6[3]), g45 = pk2(g6[4], g6[5]);
+          const F2p k01 = pk_mul(pk1(kn), g01), k23 = pk_mul(pk1(kn), g23), k45 = pk_mul(pk1(kn), g45);
+          auto up = [&](int i, float kg, F2p g, bool has_b) __attribute__((always_inline)) {
+            F2p a = pk_fma(pk1(kg), g, pk2(d.A[i], d.A[i + 1]));
+            if (has_b) a = pk_add(a, pk2(b6[i], b6[i + 1]));
+            d.A[i] = a.x; d.A[i + 1] = a.y;
+          };
+          up(0, k01.x, g01, true); up(2, k01.x, g23, true); up(4, k01.x, g45, true);
+          d.A[6] += b6[6] + k01.y * g6[1]; up(7, k01.y, g23, true); up(9, k01.y, g45, true);
+          up(11, k23.x, g23, true); up(13, k23.x, g45, true);
+          d.A[15] += b6[15] + k23.y * g6[3]; up(16, k23.y, g45, false);
+          up(18, k45.x, g45, true);
+          d.A[20] += b6[20] + k45.y * g6[5];
+          const F2p r01 = pk_fma(pk1(fb), g01, pk2(d.r[0], d.r[1])), r23 = pk_fma(pk1(fb), g23, pk2(d.r[2], d.r[3])), r45 = pk_fma(pk1(fb), g45, pk2(d.r[4], d.r[5]));
+          d.r[0] = r01.x; d.r[1] = r01.y; d.r[2] = r23.x; d.r[3] = r23.y; d.r[4] = r45.x; d.r[5] = r45.y;
+          return;
+          }
+#endif
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
             d.r[i] += fb * g6[i];
@@ -1371,6 +1405,54 @@ struct EnvLane {
     }
   }
 
+  // One joint of the elimination on the packed upper triangle (row r of SymIdx<6> holds columns r .. 5 in consecutive words: pairs
+  // (0,1) (2,3) (4,5) of row 0, (2,3) (4,5) of rows 1 and 2, (4,5) of rows 3 and 4 start on the same column parity as the pairs of U / D)
+  // as packed fp32 arithmetic (rl_math.h F2p): U = A s - every pair once down its columns, (U_c, U_c+1) += (A_rc, A_rc+1) s_r, and once
+  // along its row, U_r += (A_rc, A_rc+1) . (s_c, s_c+1); D = d + s . U and u = t + s . rho as three pairs each; the rank-1 update pair by pair.
+  // ~58 instead of 82 vector instructions per joint on paper, ~65 as compiled (a pair is an even-aligned register pair: some copies remain).
+  RL_FN static void eliminate_pk(float (&A)[B6::size], float (&rho)[6], const float (&s)[6], float D0, float u0, float (&Uh)[6], float& ui) {
+    const F2p s23 = pk2(s[2], s[3]), s45 = pk2(s[4], s[5]);
+    F2p u01 = pk_mul(pk2(A[0], A[1]), pk1(s[0]));
+    F2p u23 = pk_mul(pk2(A[2], A[3]), pk1(s[0]));
+    F2p u45 = pk_mul(pk2(A[4], A[5]), pk1(s[0]));
+    u23 = pk_fma(pk2(A[7], A[8]), pk1(s[1]), u23);
+    u45 = pk_fma(pk2(A[9], A[10]), pk1(s[1]), u45);
+    u23 = pk_fma(pk2(A[11], A[12]), pk1(s[2]), u23);
+    u45 = pk_fma(pk2(A[13], A[14]), pk1(s[2]), u45);
+    u45 = pk_fma(pk2(A[16], A[17]), pk1(s[3]), u45);
+    u45 = pk_fma(pk2(A[18], A[19]), pk1(s[4]), u45);
+    const F2p R0 = pk_fma(pk2(A[4], A[5]), s45, pk_mul(pk2(A[2], A[3]), s23));
+    const F2p R1 = pk_fma(pk2(A[9], A[10]), s45, pk_mul(pk2(A[7], A[8]), s23));
+    const F2p R2 = pk_mul(pk2(A[13], A[14]), s45);
+    const F2p R3 = pk_mul(pk2(A[16], A[17]), s45);
+    float U[6];
+    U[0] = fmaf(A[1], s[1], u01.x) + (R0.x + R0.y);
+    U[1] = fmaf(A[6], s[1], u01.y) + (R1.x + R1.y);
+    U[2] = fmaf(A[12], s[3], u23.x) + (R2.x + R2.y);
+    U[3] = fmaf(A[15], s[3], u23.y) + (R3.x + R3.y);
+    U[4] = fmaf(A[19], s[5], u45.x);
+    U[5] = fmaf(A[20], s[5], u45.y);
+    const F2p s01 = pk2(s[0], s[1]), U01 = pk2(U[0], U[1]), U23 = pk2(U[2], U[3]), U45 = pk2(U[4], U[5]);
+    const F2p d2 = pk_fma(U45, s45, pk_fma(U23, s23, pk_mul(U01, s01)));
+    const F2p w2 = pk_fma(pk2(rho[4], rho[5]), s45, pk_fma(pk2(rho[2], rho[3]), s23, pk_mul(pk2(rho[0], rho[1]), s01)));
+    const float inv = frcp(D0 + (d2.x + d2.y));
+    ui = (u0 + (w2.x + w2.y)) * inv;
+    const F2p h01 = pk_mul(U01, pk1(inv)), h23 = pk_mul(U23, pk1(inv)), h45 = pk_mul(U45, pk1(inv));
+    Uh[0] = h01.x; Uh[1] = h01.y; Uh[2] = h23.x; Uh[3] = h23.y; Uh[4] = h45.x; Uh[5] = h45.y;
+    auto down = [&](int i, F2p h, float ur) __attribute__((always_inline)) {
+      const F2p a = pk_fma(pk1(-ur), h, pk2(A[i], A[i + 1]));
+      A[i] = a.x; A[i + 1] = a.y;
+    };
+    down(0, h01, U[0]); down(2, h23, U[0]); down(4, h45, U[0]);
+    A[6] = fmaf(-U[1], Uh[1], A[6]); down(7, h23, U[1]); down(9, h45, U[1]);
+    down(11, h23, U[2]); down(13, h45, U[2]);
+    A[15] = fmaf(-U[3], Uh[3], A[15]); down(16, h45, U[3]);
+    down(18, h45, U[4]);
+    A[20] = fmaf(-U[5], Uh[5], A[20]);
+    const F2p r01 = pk_fma(pk1(-ui), U01, pk2(rho[0], rho[1])), r23 = pk_fma(pk1(-ui), U23, pk2(rho[2], rho[3])), r45 = pk_fma(pk1(-ui), U45, pk2(rho[4], rho[5]));
+    rho[0] = r01.x; rho[1] = r01.y; rho[2] = r23.x; rho[3] = r23.y; rho[4] = r45.x; rho[5] = r45.y;
+  }
+
   RL_FN void aba_solve(const ChainTP& C, const M3& Rwb, const SV V0, const SV a0, const float (&tau_e)[JX], const float (&pd_diag)[JX],
                        const float (&pd_rhs)[JX], const GroupFetch (&gf)[NIT], const bool (&fetched)[NIT], float (&nu0)[NB], float (&qdn)[JX],
                        uint32_t& active_mask, SV (&Vnew)[NIT], const float D_own = 0.f, const float uu_own = 0.f) {
@@ -1451,6 +1533,9 @@ struct EnvLane {
         if (TP::PAD) D += j >= L.nj ? 1.0f : 0.f;  // an inert padding joint (zero axis, no gains): the identity row, as joint_terms() of the trunk + limbs instances
         uu = arm * qd[j] + dt * tau_e[j] + pd_rhs[j] + dt * u.limit_k * viol;
       }
+#ifdef RL_PK
+      eliminate_pk(P.A, P.r, s6, D, uu, Uh[j], ui[j]);
+#else
       float U6[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
@@ -1471,6 +1556,7 @@ struct EnvLane {
 #pragma unroll
         for (int c = r; c < 6; ++c) P.A[B6::at(r, c)] -= U6[r] * Uh[j][c];
       }
+#endif
     });
     // the lane's share of the base link's contacts (group 0, owned by sub-lane 0 in iteration 0), when anybody has one
     if (M0) {  // flagged slots of any sub-lane
@@ -1574,13 +1660,21 @@ struct EnvLane {
         st4(w + 8 * q, F4{r.A[B6::at(q, 0)], r.A[B6::at(q, 1)], r.A[B6::at(q, 2)], r.A[B6::at(q, 3)]});
         st4(w + 8 * q + 4, F4{r.A[B6::at(q, 4)], r.A[B6::at(q, 5)], r.r[q], 0.f});
       }
-    } else {
-#pragma unroll
-      for (int v = 0; v < 5; ++v) st4(w + 4 * v, F4{r.A[4 * v], r.A[4 * v + 1], r.A[4 * v + 2], r.A[4 * v + 3]});
-      st4(w + 20, F4{r.A[20], r.r[0], r.r[1], r.r[2]});
-      st4(w + 24, F4{r.r[3], r.r[4], r.r[5], 0.f});
+    } else {  // seven vectors in the order of rec_pos_A / rec_pos_r: every 8-byte half is one pair of the packed arithmetic
+      st4(w, F4{r.A[0], r.A[1], r.A[2], r.A[3]});
+      st4(w + 4, F4{r.A[4], r.A[5], r.A[7], r.A[8]});
+      st4(w + 8, F4{r.A[9], r.A[10], r.A[11], r.A[12]});
+      st4(w + 12, F4{r.A[13], r.A[14], r.A[16], r.A[17]});
+      st4(w + 16, F4{r.A[18], r.A[19], r.A[6], r.A[15]});
+      st4(w + 20, F4{r.r[0], r.r[1], r.r[2], r.r[3]});
+      st4(w + 24, F4{r.r[4], r.r[5], r.A[20], 0.f});
     }
   }
+  // word of a packed record in LDS that holds entry i of the upper triangle / rho_r: the pairs eliminate_pk works on - (0,1) (2,3) (4,5)
+  // (7,8) (9,10) (11,12) (13,14) (16,17) (18,19), rho (0,1) (2,3) (4,5) - are the 8-byte halves of the record's 16-byte vectors, so
+  // that add_rec is 13 packed additions on the loaded register pairs as they are (+ the three lone diagonal entries 6, 15, 20)
+  static constexpr int rec_pos_A(int i) { return i <= 5 ? i : i == 6 ? 18 : i <= 14 ? i - 1 : i == 15 ? 19 : i <= 19 ? i - 2 : 26; }
+  static constexpr int rec_pos_r(int r) { return 20 + r; }
   RL_FN static void add_rec(const float* w, LinkRec& P) {  // (the replicated elimination: the whole record into every lane)
     if constexpr (REC_ROWS) {
 #pragma unroll
@@ -1595,13 +1689,26 @@ struct EnvLane {
       F4 v[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) v[i] = ld4(w + 4 * i);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) { P.A[4 * i] += v[i].x; P.A[4 * i + 1] += v[i].y; P.A[4 * i + 2] += v[i].z; P.A[4 * i + 3] += v[i].w; }
-      P.A[20] += v[5].x; P.r[0] += v[5].y; P.r[1] += v[5].z; P.r[2] += v[5].w;
-      P.r[3] += v[6].x; P.r[4] += v[6].y; P.r[5] += v[6].z;
+      auto acc = [&](float& a, float& b, float x, float y) __attribute__((always_inline)) {
+#ifdef RL_PK
+        const F2p t = pk_add(pk2(a, b), pk2(x, y));
+        a = t.x; b = t.y;
+#else
+        a += x; b += y;
+#endif
+      };
+      acc(P.A[0], P.A[1], v[0].x, v[0].y); acc(P.A[2], P.A[3], v[0].z, v[0].w);
+      acc(P.A[4], P.A[5], v[1].x, v[1].y); acc(P.A[7], P.A[8], v[1].z, v[1].w);
+      acc(P.A[9], P.A[10], v[2].x, v[2].y); acc(P.A[11], P.A[12], v[2].z, v[2].w);
+      acc(P.A[13], P.A[14], v[3].x, v[3].y); acc(P.A[16], P.A[17], v[3].z, v[3].w);
+      acc(P.A[18], P.A[19], v[4].x, v[4].y);
+      P.A[6] += v[4].z; P.A[15] += v[4].w;
+      acc(P.r[0], P.r[1], v[5].x, v[5].y); acc(P.r[2], P.r[3], v[5].z, v[5].w);
+      acc(P.r[4], P.r[5], v[6].x, v[6].y);
+      P.A[20] += v[6].z;
     }
   }
-  RL_FN static float* rho_word(float* w, int r) { return REC_ROWS ? w + 8 * r + 6 : w + B6::size + r; }  // rho_r of a record at w
+  RL_FN static float* rho_word(float* w, int r) { return REC_ROWS ? w + 8 * r + 6 : w + rec_pos_r(r); }  // rho_r of a record at w
   RL_FN static void atomic_add_rec(float* w, const LinkRec& r) {  // ds_add_f32 of a whole record (several lanes of an env add into one)
     if constexpr (REC_ROWS) {
 #pragma unroll
@@ -1612,9 +1719,9 @@ struct EnvLane {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(w + i, r.A[i]);
+      for (int i = 0; i < B6::size; ++i) Ctx::limb_atomic_add(w + rec_pos_A(i), r.A[i]);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + B6::size + i, r.r[i]);
+      for (int i = 0; i < 6; ++i) Ctx::limb_atomic_add(w + rec_pos_r(i), r.r[i]);
     }
   }
 
@@ -1802,6 +1909,10 @@ struct EnvLane {
 
   // P -= (P S)(P S)^T / D etc. for one joint with motion subspace s6 and joint-local terms (D0, u0); returns U / D and u / D
   RL_FN void eliminate(LinkRec& P, const float (&s6)[6], float D, float uu, float (&Uh)[6], float& ui) const {
+#ifdef RL_PK
+    eliminate_pk(P.A, P.r, s6, D, uu, Uh, ui);
+    return;
+#endif
     float U6[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {

@@ -59,6 +59,29 @@ RL_FN float opaque(float x) {
 #else
 RL_FN float opaque(float x) { return x; }
 #endif
+// Two fp32 values in an even-aligned register pair: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do both lanes of the pair in the four
+// cycles one v_fma_f32 takes (a scalar operand is broadcast through op_sel, a negation is a source modifier).  Written out by hand where
+// the data IS a stream of pairs (the packed upper triangle of a link record, env_step.h -DRL_PK) - the SLP vectoriser's own pairing
+// costs ~90 registers and 14 % of the step (__graft_entry__.py ENV_FLAGS).  Host: two fmaf - the same arithmetic in the same order.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float F2p __attribute__((ext_vector_type(2)));
+RL_FN F2p pk_fma(F2p a, F2p b, F2p c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct F2p {
+  float x, y;
+};
+RL_FN F2p pk_fma(F2p a, F2p b, F2p c) { return F2p{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+RL_FN F2p pk_mul(F2p a, F2p b) { return a * b; }
+RL_FN F2p pk_add(F2p a, F2p b) { return a + b; }
+#else
+RL_FN F2p pk_mul(F2p a, F2p b) { return F2p{a.x * b.x, a.y * b.y}; }
+RL_FN F2p pk_add(F2p a, F2p b) { return F2p{a.x + b.x, a.y + b.y}; }
+#endif
+RL_FN F2p pk2(float a, float b) { return F2p{a, b}; }
+RL_FN F2p pk1(float a) { return F2p{a, a}; }
+
 RL_FN float ftanh(float x) {  // x >= 0 in every use (speed norms); 1 - 2 / (e^{2x} + 1)
   return 1.0f - 2.0f * frcp(fexp(2.0f * fminf(x, 20.0f)) + 1.0f);
 }

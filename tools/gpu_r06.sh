@@ -149,6 +149,35 @@ l)
   timeout 900 python -m pytest tests/test_gpu_specs.py -m gpu -q > $OUT/pytest_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs.log; tail -5 $OUT/pytest_specs.log
   mv gpurun_out/spec_vs_interpreter.jsonl $OUT/ 2>/dev/null
   ;;
+m)
+  # packed fp32 arithmetic written by hand in the joint elimination (-DRL_PK: env_step.h eliminate_pk) and -fno-signed-zeros (x + 0 of a zeroed
+  # link record folds away), each and both against the tree, one call: the specialised A1 and G1 kernels
+  timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/base_34.so $V/nsz_34.so $V/pk_34.so $V/pknsz_34.so > $OUT/a1_pk_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/base_78.so $V/nsz_78.so $V/pk_78.so $V/pknsz_78.so > $OUT/g1_pk_ab.txt 2>&1
+  grep -v amdgpu $OUT/a1_pk_ab.txt $OUT/g1_pk_ab.txt
+  ;;
+n)
+  # the tree's defaults (packed elimination + contact blocks + the pair-aligned LDS record of the trunk + limbs instances, -fno-signed-zeros)
+  # against the flags and sources of call z2 (base_*: -DRL_NO_PK -fsigned-zeros) and against call m's pknsz_* (elimination only)
+  timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/base_34.so $V/pknsz_34.so $V/pk2_34.so > $OUT/a1_pk2_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $GO2W --num-envs 4096 --rounds 3 --steady $V/base_1044.so $V/pk2_1044.so > $OUT/go2w_pk2_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/base_78.so $V/pknsz_78.so $V/pk2_78.so > $OUT/g1_pk2_ab.txt 2>&1
+  grep -v amdgpu $OUT/a1_pk2_ab.txt $OUT/go2w_pk2_ab.txt $OUT/g1_pk2_ab.txt
+  ;;
+o)
+  # the packed contact blocks alone: pk3 = without them (-DRL_NO_PK_CONTACT on G1; the quadrupeds' default) against pk2 = with them
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/pk3_78.so $V/pk2_78.so > $OUT/g1_pk_contact_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/pk3_34.so $V/pk2_34.so > $OUT/a1_pk_contact_ab.txt 2>&1
+  grep -v amdgpu $OUT/g1_pk_contact_ab.txt $OUT/a1_pk_contact_ab.txt
+  ;;
+p)
+  # -ffinite-math-only on top of the tree's flags (x * 0 and the products with the identity frame at the root of every kinematic chain fold,
+  # fmin / fmax without the canonicalising copy): ~150 of a substep's 2.3 k vector instructions on A1
+  timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/pk3_34.so $V/fin_34.so > $OUT/a1_finite_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $GO2W --num-envs 4096 --rounds 3 --steady $V/pk2_1044.so $V/fin_1044.so > $OUT/go2w_finite_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/pk2_78.so $V/fin_78.so > $OUT/g1_finite_ab.txt 2>&1
+  grep -v amdgpu $OUT/a1_finite_ab.txt $OUT/go2w_finite_ab.txt $OUT/g1_finite_ab.txt
+  ;;
 zz)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
