@@ -41,8 +41,14 @@ TASKS = [
 
 
 @pytest.mark.parametrize("task", TASKS)
-def test_lane_program_matches_oracle(task, emu_lib):
-    N = 8 if any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1", "GR1", "T1")) else 16  # big models: the fp64 oracle is the slow side
+def test_lane_program_matches_oracle(task, emu_lib, monkeypatch):
+    big = any(r in task for r in ("G1", "ATOM01", "Xbot", "Gen1", "Loong", "Tita", "Z1", "GR1", "T1"))
+    N = 8 if big else 16  # big models: the fp64 oracle is the slow side
+    if big:
+        # the trunk + limbs instances add into env-shared words (ds_add_f32; lane THREADS here: the order of the additions is the scheduler's,
+        # and over six free-running steps a last-bit difference can flip one contact - seen once in ~30 tier runs: GR1T2, one body's force
+        # at step 1).  Lanes as fibers of one thread: one order.  The quadrupeds keep exercising the thread mode.
+        monkeypatch.setenv("RL_EMU_FIBERS", "1")
     # GR1 (55 kg on two feet, drive stiffness up to 250 N m / rad): the fp32 program sits 3 - 5 x further from the fp64 oracle than on
     # the 35 kg G1 - root state to 3e-4, joint velocities to 1.4e-2, contact forces to 0.4 N over these six steps, not growing -
     # so its bands are 6 x the others'

@@ -5,7 +5,7 @@
 #   bash tools/ablate.sh            # builds robot_lab_amd/csrc/variants/abl_*.so;  then on the GPU box:
 #   python tools/ab_bench.py --rounds 2 robot_lab_amd/csrc/variants/abl_*.so
 cd "$(dirname "$0")/../robot_lab_amd/csrc"
-B="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -fno-signed-zeros -mllvm -amdgpu-remove-redundant-endcf=false -std=c++17 -shared -fPIC -DRL_ENV_SINGLE_TU -DRL_ENV_ONLY=${1:-34}"
+B="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -fno-signed-zeros -ffinite-math-only -mllvm -amdgpu-remove-redundant-endcf=false -std=c++17 -shared -fPIC -DRL_ENV_SINGLE_TU -DRL_ENV_ONLY=${1:-34}"
 $B -o variants/abl_full.so rl_env.hip &
 $B -DRL_ABL_NO_REWARDS -o variants/abl_norewards.so rl_env.hip &
 $B -DRL_ABL_NO_OBS -o variants/abl_noobs.so rl_env.hip &

@@ -11,6 +11,6 @@ if [ "$REV" != "-" ]; then
   SRC=$(mktemp -d /tmp/variant_src.XXXXXX)
   git -C $ROOT archive $REV robot_lab_amd/csrc include | tar -x -C $SRC
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -fno-signed-zeros -mllvm -amdgpu-remove-redundant-endcf=false -std=c++17 -shared -fPIC -DRL_ENV_SINGLE_TU -DRL_ENV_ONLY=$INST "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -fno-signed-zeros -ffinite-math-only -mllvm -amdgpu-remove-redundant-endcf=false -std=c++17 -shared -fPIC -DRL_ENV_SINGLE_TU -DRL_ENV_ONLY=$INST "$@" \
   -o $OUT/${NAME}_${INST}.so $SRC/robot_lab_amd/csrc/rl_env.hip && echo "built $OUT/${NAME}_${INST}.so from $REV $*"
 [ "$REV" != "-" ] && rm -rf $SRC

@@ -193,7 +193,7 @@ import json
 for n in ('bench_default','bench_driver_flags'):
     d=json.load(open('$OUT/%s.json' % n)); print(n, 'value %.2f M  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']), d['config'].get('step_kernel'), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'), d.get('cpu_baseline',{}).get('value'))"
   ;;
-z|z2)
+z|z2|z3)
   # FINAL TREE: the whole GPU tier, smoke(), the bench lines of the BASELINE configs, kernel traces + counter passes, phase clocks, the collection loop
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   tail -4 $OUT/pytest_gpu.log

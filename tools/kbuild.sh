@@ -3,7 +3,7 @@
 # instruction profile:   tools/kbuild.sh <outdir> <CL*10+SUB, e.g. 34 | 44 | 74> [extra hipcc flags]
 OUT=$1; INST=${2:-34}; shift; shift
 mkdir -p $OUT && cd $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -fno-signed-zeros -mllvm -amdgpu-remove-redundant-endcf=false -std=c++17 -shared -fPIC -DRL_ENV_SINGLE_TU -DRL_ENV_ONLY=$INST -DRL_PHASE_MARKS -save-temps -o lib_marks.so /root/repo/robot_lab_amd/csrc/rl_env.hip "$@" 2>&1 | grep -E "error" -A6 | head -40
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -fno-signed-zeros -ffinite-math-only -mllvm -amdgpu-remove-redundant-endcf=false -std=c++17 -shared -fPIC -DRL_ENV_SINGLE_TU -DRL_ENV_ONLY=$INST -DRL_PHASE_MARKS -save-temps -o lib_marks.so /root/repo/robot_lab_amd/csrc/rl_env.hip "$@" 2>&1 | grep -E "error" -A6 | head -40
 python - <<PY
 import re
 s=open('$OUT/rl_env-hip-amdgcn-amd-amdhsa-gfx950.s').read()
