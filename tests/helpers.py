@@ -268,6 +268,8 @@ class OracleWithTwin:
         self.twin.phys.solve_dtype = np.float32
         self.gain, self.rng = gain, np.random.default_rng(seed)
         self.done_differs = np.zeros(self.ora.N, dtype=bool)  # envs whose twin took a different reset decision at some step
+        self.max_outlier_envs = 0   # envs that may leave the band altogether (a free run that took another branch); see close()
+        self.outlier_envs = set()
         self.ora.phys.margins = {}  # smallest distance to every switch of the model over the whole run (Physics._margin keeps minima)
 
     def _perturb(self):
@@ -303,6 +305,17 @@ class OracleWithTwin:
         self.masked = int((~ok_env).sum())
         keep = np.moveaxis(np.broadcast_to(np.expand_dims(ok_env, tuple(i for i in range(want.ndim) if i != env_axis)), want.shape), 0, 0)
         bad = (np.abs(got - want) > atol + rtol * np.abs(want) + self.gain * np.abs(tw - want)) & keep
+        if bad.any() and self.max_outlier_envs > 0:
+            # a caller that names a KNOWN case may let whole envs go: a free run in which the implementation's round-off took one env through
+            # a switch the oracle and its twin did not take is out in every field from then on.  The envs are remembered - the budget is per
+            # run, not per field - and printed.
+            envs = set(np.nonzero(np.moveaxis(bad, env_axis, 0).reshape(self.ora.N, -1).any(axis=1))[0].tolist())
+            if len(self.outlier_envs | envs) <= self.max_outlier_envs:
+                self.outlier_envs |= envs
+                print(f"\n[free-run outlier] {name}: env(s) {sorted(envs)} outside the band, worst |err| {np.abs(got - want)[bad].max():.3e}")
+                idx = [slice(None)] * want.ndim
+                idx[env_axis] = sorted(self.outlier_envs)
+                bad[tuple(idx)] = False
         assert not bad.any(), (f"{name}: {int(bad.sum())} of {bad.size} entries outside atol {atol} + rtol {rtol} + {self.gain} x twin drift; "
                                f"worst |err| {np.abs(got - want)[bad].max():.3e} where the twin drifted {np.abs(tw - want)[bad].max():.3e}")
 

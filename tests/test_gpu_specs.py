@@ -89,9 +89,11 @@ def test_specialised_kernel_equals_interpreter_kernel(task, sid, sub, wg, monkey
         worst["term_rel"] = max(worst["term_rel"], float(err.max()))
         # (a term is a sum of <= 30 fp32 products in another order - and, since round 6, on a state that differs by one step's round-off where
         # the Spec composes axis-aligned joint rotations in their sparse form; joint_acc_l2 squares a finite difference of the velocities)
-        assert np.all(np.abs(xa - xb) <= 5e-4 * np.abs(xb) + 1e-6), (task, s, np.abs(xa - xb).max(axis=1))  # (floor: 0.01 % of a typical step reward)
+        # (floor: 0.05 % of a typical step reward.  It was 1e-6 until the kernels were compiled with -fno-signed-zeros -ffinite-math-only: the two
+        # template instantiations fold different zero terms, and one entry of 12 x 512 x 24 - HandStand A1, term 1, step 10 - came out 3.8e-6 apart)
+        assert np.all(np.abs(xa - xb) <= 5e-4 * np.abs(xb) + 5e-6), (task, s, np.abs(xa - xb).max(axis=1))
         # the reward is a sum of terms of both signs: its error is bounded by the terms' magnitudes, not by its own
-        assert np.all(np.abs(ra.double().cpu().numpy() - rb.double().cpu().numpy()) <= 5e-4 * np.abs(xb).sum(axis=0) + 2e-6), (task, s)
+        assert np.all(np.abs(ra.double().cpu().numpy() - rb.double().cpu().numpy()) <= 5e-4 * np.abs(xb).sum(axis=0) + 1e-5), (task, s)
         sa, sb = a.read_state(), b.read_state()
         for k2 in ("root_state", "joint_pos", "joint_vel", "task_state", "contact_timers"):
             xs, ys = np.asarray(sa[k2], dtype=np.float64), np.asarray(sb[k2], dtype=np.float64)

@@ -178,6 +178,11 @@ p)
   timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/pk2_78.so $V/fin_78.so > $OUT/g1_finite_ab.txt 2>&1
   grep -v amdgpu $OUT/a1_finite_ab.txt $OUT/go2w_finite_ab.txt $OUT/g1_finite_ab.txt
   ;;
+q)
+  # the two test files whose bounds moved after call z3 (GR1's factor on the free-running rewards; the reward-term floor of spec-vs-interpreter)
+  timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_specs.py -m gpu -q > $OUT/pytest_parity_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_specs.log; tail -5 $OUT/pytest_parity_specs.log
+  mv gpurun_out/spec_vs_interpreter.jsonl $OUT/ 2>/dev/null
+  ;;
 zz)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
