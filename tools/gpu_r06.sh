@@ -183,7 +183,14 @@ q)
   timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_specs.py -m gpu -q > $OUT/pytest_parity_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_parity_specs.log; tail -5 $OUT/pytest_parity_specs.log
   mv gpurun_out/spec_vs_interpreter.jsonl $OUT/ 2>/dev/null
   ;;
-zz)
+r)
+  # the scheduler: LLVM's max-ILP strategy (-mllvm -amdgpu-sched-strategy=max-ilp) instead of the default max-occupancy one - these kernels
+  # run one wavefront per SIMD whatever the register count, so there is no occupancy to protect
+  timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/cur_34.so $V/ilp_34.so > $OUT/a1_sched_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/cur_78.so $V/ilp_78.so > $OUT/g1_sched_ab.txt 2>&1
+  grep -v amdgpu $OUT/a1_sched_ab.txt $OUT/g1_sched_ab.txt
+  ;;
+zz|zz3)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
