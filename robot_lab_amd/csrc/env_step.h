@@ -120,6 +120,28 @@ RL_FN F2 ld2(const float* p) {  // 4-byte aligned 8-byte load
   return {p[0], p[1]};
 #endif
 }
+// The heightfield in HBM: the caller's row-major grid.  -DRL_TERRAIN_PAIRS (analysis switch; rl_env_host.h builds the array): rows ix and
+// ix + 1 interleaved, hf2[(ix * ny + iy) * 2 + {0, 1}] = {h(ix, iy), h(ix + 1, iy)}, so that the four corners of cell (ix, iy) are FOUR
+// CONSECUTIVE WORDS - one 16-byte load and 1.25 cache lines per query instead of two 8-byte loads in two rows 16 KB apart (2.1 lines), at
+// twice the grid's bytes.  Measured in one call and NOT kept: A1 32.57 / 32.62 us, Go2W 38.82 / 38.62, G1 82.27 / 82.28
+// (profiles/r06s_*_hf2_ab.txt) - the lookups are batched loads whose latency is covered either way; their line count is not what the step waits for.
+#ifdef RL_TERRAIN_PAIRS
+constexpr bool TERRAIN_PAIRS = true;
+#else
+constexpr bool TERRAIN_PAIRS = false;
+#endif
+struct F4h {
+  float x, y, z, w;
+};
+RL_FN F4h ld4_a8(const float* p) {  // 8-byte aligned 16-byte load
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f4v __attribute__((ext_vector_type(4), aligned(8)));
+  f4v v = *reinterpret_cast<const f4v*>(p);
+  return {v.x, v.y, v.z, v.w};
+#else
+  return {p[0], p[1], p[2], p[3]};
+#endif
+}
 struct TerrainPatch {
   float h00, h01, h10, h11, fx, fy;
 };
@@ -168,10 +190,14 @@ RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, con
   // arithmetic above meaningless - (int)NaN is 0, (float)(-cx) rounds - and an unclamped cell index then reads far outside the
   // heightfield (a GPU memory fault took the whole launch down on a model with a zero velocity limit, profiles/r03p_all_tasks.txt)
   const int ix = imin(imax(tb.cx + (int)ox, 0), u.nx - 2), iy = imin(imax(tb.cy + (int)oy, 0), u.ny - 2);
-  // (iy, iy+1) are adjacent in memory: two 8-byte loads per query instead of four 4-byte ones
-  const float* b = hf + (uint32_t)ix * (uint32_t)u.ny + (uint32_t)iy;
-  F2 r0 = ld2(b), r1 = ld2(b + u.ny);
-  p.h00 = r0.x; p.h01 = r0.y; p.h10 = r1.x; p.h11 = r1.y;
+  if constexpr (TERRAIN_PAIRS) {  // {h(ix, iy), h(ix + 1, iy), h(ix, iy + 1), h(ix + 1, iy + 1)}: one load
+    const F4h r = ld4_a8(hf + (((uint32_t)ix * (uint32_t)u.ny + (uint32_t)iy) << 1));
+    p.h00 = r.x; p.h10 = r.y; p.h01 = r.z; p.h11 = r.w;
+  } else {  // (iy, iy+1) are adjacent in memory: two 8-byte loads per query instead of four 4-byte ones
+    const float* b = hf + (uint32_t)ix * (uint32_t)u.ny + (uint32_t)iy;
+    F2 r0 = ld2(b), r1 = ld2(b + u.ny);
+    p.h00 = r0.x; p.h01 = r0.y; p.h10 = r1.x; p.h11 = r1.y;
+  }
   return p;
 }
 RL_FN TerrainPatch terrain_fetch(const Uni& u, const float* __restrict__ hf, float bx, float by, float dx, float dy) {

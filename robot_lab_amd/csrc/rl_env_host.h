@@ -646,10 +646,21 @@ struct EnvImpl {
     if (!desc.terrain.is_plane) {
       if (!terrain_heights || !terrain_origins) return fail("heightfield terrain needs heights and sub-terrain origins");
       size_t nh = (size_t)desc.terrain.nx * desc.terrain.ny;
+      if (desc.terrain.nx < 2 || desc.terrain.ny < 2) return fail("heightfield terrain needs at least 2 x 2 samples");
+      if (TERRAIN_PAIRS) nh = (size_t)(desc.terrain.nx - 1) * desc.terrain.ny * 2;  // rows ix, ix + 1 interleaved (env_step.h TerrainPatch)
       terrain_dev = alloc<float>(nh);
       terrain_origins_dev = alloc<float>((size_t)desc.terrain.num_rows * desc.terrain.num_cols * 3);
       if (alloc_failed) return fail("device allocation failed (terrain): " + be.error());
-      be.h2d(terrain_dev, terrain_heights, nh * sizeof(float));
+      if (TERRAIN_PAIRS) {
+        std::vector<float> h2(nh);
+        const size_t ny = (size_t)desc.terrain.ny;
+        for (size_t ix = 0; ix + 1 < (size_t)desc.terrain.nx; ++ix)
+          for (size_t iy = 0; iy < ny; ++iy) {
+            h2[(ix * ny + iy) * 2] = terrain_heights[ix * ny + iy];
+            h2[(ix * ny + iy) * 2 + 1] = terrain_heights[(ix + 1) * ny + iy];
+          }
+        be.h2d(terrain_dev, h2.data(), nh * sizeof(float));
+      } else be.h2d(terrain_dev, terrain_heights, nh * sizeof(float));
       be.h2d(terrain_origins_dev, terrain_origins, (size_t)desc.terrain.num_rows * desc.terrain.num_cols * 3 * sizeof(float));
     } else {
       if (!env_origins) return fail("plane terrain needs env_origins");

@@ -190,6 +190,14 @@ r)
   timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/cur_78.so $V/ilp_78.so > $OUT/g1_sched_ab.txt 2>&1
   grep -v amdgpu $OUT/a1_sched_ab.txt $OUT/g1_sched_ab.txt
   ;;
+s)
+  # the heightfield with rows ix, ix + 1 interleaved (env_step.h RL_TERRAIN_PAIRS: one 16-byte load per query) against the plain row-major grid
+  # (two 8-byte loads): the specialised A1, Go2W and G1 kernels, one call
+  timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/cur_34.so $V/hf2_34.so > $OUT/a1_hf2_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $GO2W --num-envs 4096 --rounds 3 --steady $V/cur_1044.so $V/hf2_1044.so > $OUT/go2w_hf2_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/cur_78.so $V/hf2_78.so > $OUT/g1_hf2_ab.txt 2>&1
+  grep -v amdgpu $OUT/a1_hf2_ab.txt $OUT/go2w_hf2_ab.txt $OUT/g1_hf2_ab.txt
+  ;;
 zz|zz3)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
@@ -205,7 +213,7 @@ import json
 for n in ('bench_default','bench_driver_flags'):
     d=json.load(open('$OUT/%s.json' % n)); print(n, 'value %.2f M  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']), d['config'].get('step_kernel'), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'), d.get('cpu_baseline',{}).get('value'))"
   ;;
-z|z2|z3)
+z|z2|z3|z4)
   # FINAL TREE: the whole GPU tier, smoke(), the bench lines of the BASELINE configs, kernel traces + counter passes, phase clocks, the collection loop
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   tail -4 $OUT/pytest_gpu.log
