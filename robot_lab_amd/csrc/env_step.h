@@ -1713,8 +1713,23 @@ struct EnvLane {
       }
     } else {
       F4 v[7];
+      ld_rec(w, v);
+      acc_rec(v, P);
+    }
+  }
+  // the two halves of add_rec for the packed layout: the record's seven vectors into registers / onto P (the limb elimination issues
+  // the loads of the NEXT joint's record before it eliminates the current one - substep_aba_trunk)
+#ifdef RL_NO_REC_PREFETCH
+  static constexpr bool REC_PREFETCH = false;
+#else
+  static constexpr bool REC_PREFETCH = !REC_ROWS;
+#endif
+  RL_FN static void ld_rec(const float* w, F4 (&v)[7]) {
 #pragma unroll
-      for (int i = 0; i < 7; ++i) v[i] = ld4(w + 4 * i);
+    for (int i = 0; i < 7; ++i) v[i] = ld4(w + 4 * i);
+  }
+  RL_FN static void acc_rec(const F4 (&v)[7], LinkRec& P) {
+    {
       auto acc = [&](float& a, float& b, float x, float y) __attribute__((always_inline)) {
 #ifdef RL_PK
         const F2p t = pk_add(pk2(a, b), pk2(x, y));
@@ -2249,11 +2264,30 @@ struct EnvLane {
       for (int i = 0; i < B6::size; ++i) P.A[i] = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) P.r[i] = 0.f;
+      // REC_PREFETCH: the NEXT joint's link record and axis / origin are in flight while this joint is eliminated (and below: the trunk's
+      // accumulators likewise, the outward pass's U / D, u / D, axes and origins of all limb joints in one batch in front of its chain) -
+      // a lone wavefront otherwise waits out one LDS round trip per joint, behind stores the compiler cannot move the reads across.
+      // G1 82.05 -> 80.14 us (profiles/r06t_g1_prefetch_ab.txt, r06u_g1_prefetch2_ab.txt); -DRL_NO_REC_PREFETCH: read where consumed.
+      F4 rnext[7];
+      V3 axn{0.f, 0.f, 0.f}, pjn{0.f, 0.f, 0.f};
+      if constexpr (REC_PREFETCH) {
+        ld_rec(this->rec_words(CL), rnext);
+        C.axp(CL - 1, axn, pjn);
+      }
       static_for_down<CL - 1>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        add_rec(this->rec_words(j + 1), P);
         V3 ax, pj;
-        C.axp(j, ax, pj);
+        if constexpr (REC_PREFETCH) {
+          acc_rec(rnext, P);
+          ax = axn; pj = pjn;
+          if constexpr (j > 0) {
+            ld_rec(this->rec_words(j), rnext);
+            C.axp(j - 1, axn, pjn);
+          }
+        } else {
+          add_rec(this->rec_words(j + 1), P);
+          C.axp(j, ax, pj);
+        }
         const V3 lx = cross(pj, ax);
         const float s6[6] = {ax.x, ax.y, ax.z, lx.x, lx.y, lx.z};
         float D, uu, Uh[6], ui;
@@ -2280,9 +2314,13 @@ struct EnvLane {
       for (int i = 0; i < B6::size; ++i) Pb.A[i] = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) Pb.r[i] = 0.f;
+      if constexpr (REC_PREFETCH) ld_rec(trunk_words(NW), rnext);
 #pragma unroll
       for (int d = NW; d >= 1; --d) {
-        add_rec(trunk_words(d), P);
+        if constexpr (REC_PREFETCH) {
+          acc_rec(rnext, P);
+          ld_rec(trunk_words(d - 1), rnext);
+        } else add_rec(trunk_words(d), P);
         const float s6[6] = {Sw[d - 1].a.x, Sw[d - 1].a.y, Sw[d - 1].a.z, Sw[d - 1].l.x, Sw[d - 1].l.y, Sw[d - 1].l.z};
         float D, uu;
         joint_terms(CL + d - 1, d - 1 >= T.nw_used, tau_e, pd_diag, pd_rhs, D, uu);
@@ -2294,7 +2332,8 @@ struct EnvLane {
           for (int i = 0; i < 6; ++i) { Pb.r[i] += P.r[i]; P.r[i] = 0.f; }
         }
       }
-      add_rec(trunk_words(0), P);
+      if constexpr (REC_PREFETCH) acc_rec(rnext, P);
+      else add_rec(trunk_words(0), P);
 #pragma unroll
       for (int i = 0; i < B6::size; ++i) P.A[i] += Pb.A[i];
 #pragma unroll
@@ -2338,13 +2377,24 @@ struct EnvLane {
         if (L.grp0_depth == i + 1) vcg = vc;
       }
       vc = vca;
+      F4 po0[CL], po1[CL];
+      V3 pax[CL], ppj[CL];
+      if constexpr (REC_PREFETCH) {
+#pragma unroll
+        for (int j = 0; j < CL; ++j) { po0[j] = ld4(va_words(j)); po1[j] = ld4(va_words(j) + 4); }
+#pragma unroll
+        for (int j = 0; j < CL; ++j) C.axp(j, pax[j], ppj[j]);
+      }
 #pragma unroll
       for (int j = 0; j < CL; ++j) {
-        const F4 o0 = ld4(va_words(j)), o1 = ld4(va_words(j) + 4);
+        F4 o0, o1;
+        if constexpr (REC_PREFETCH) { o0 = po0[j]; o1 = po1[j]; }
+        else { o0 = ld4(va_words(j)); o1 = ld4(va_words(j) + 4); }
         const float t = o1.z - (o0.x * va[0] + o0.y * va[1] + o0.z * va[2] + o0.w * va[3] + o1.x * va[4] + o1.y * va[5]);
         qdn[j] = t;
         V3 ax, pj;
-        C.axp(j, ax, pj);
+        if constexpr (REC_PREFETCH) { ax = pax[j]; pj = ppj[j]; }
+        else C.axp(j, ax, pj);
         const V3 lx = cross(pj, ax);
         va[0] += ax.x * t; va[1] += ax.y * t; va[2] += ax.z * t;
         va[3] += lx.x * t; va[4] += lx.y * t; va[5] += lx.z * t;

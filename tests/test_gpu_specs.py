@@ -95,14 +95,20 @@ def test_specialised_kernel_equals_interpreter_kernel(task, sid, sub, wg, monkey
         # the reward is a sum of terms of both signs: its error is bounded by the terms' magnitudes, not by its own
         assert np.all(np.abs(ra.double().cpu().numpy() - rb.double().cpu().numpy()) <= 5e-4 * np.abs(xb).sum(axis=0) + 1e-5), (task, s)
         sa, sb = a.read_state(), b.read_state()
-        for k2 in ("root_state", "joint_pos", "joint_vel", "task_state", "contact_timers"):
+        for k2 in ("root_state", "joint_pos", "joint_vel", "task_state"):
             xs, ys = np.asarray(sa[k2], dtype=np.float64), np.asarray(sb[k2], dtype=np.float64)
             worst["state"] = max(worst["state"], float((np.abs(xs - ys) / np.maximum(np.abs(ys), 1.0)).max()))  # (relative: wheel speeds are tens of rad/s)
+        # the contact timers are DISCRETE in what moves them (|F| against the 1 N threshold per substep): a force that sits on the threshold
+        # flips with the last bit and the two timers then differ by whole substeps (round 6, A1 Rough sub2 after -ffinite-math-only: one entry of
+        # 24 steps x 512 envs x 17 bodies x 4 timers, 0.025 s apart).  Counted, not bounded by the state tolerance; re-synced with the state.
+        tflip = np.abs(np.asarray(sa["contact_timers"], dtype=np.float64) - np.asarray(sb["contact_timers"], dtype=np.float64)) > 1e-6
+        worst["timer_entries_apart"] = worst.get("timer_entries_apart", 0) + int(tflip.sum())
         assert np.array_equal(sa["episode_length"], sb["episode_length"])
     # the physics of the two kernels differ by the kinematics' two forms where a Spec joint is axis-aligned (round-off of ONE step, amplified by
     # a stiff contact in a few entries), else not at all: nearly every entry bit equal, the 99th percentile at 2e-5, nothing past 2e-3
     worst["obs_p99"] = float(np.quantile(np.concatenate(obs_err), 0.99))
     assert worst["obs"] <= 2e-3 and worst["state"] <= 2e-3 and worst["obs_p99"] <= 2e-5, worst
+    assert worst["timer_entries_apart"] <= 8, worst  # (of ~1e6 compared: at most a couple of threshold flips, each up to four timer words)
     assert seen.sum() >= len(seen) - 2, f"only {seen.sum()} of {len(seen)} terms ever non-zero"
     print("\n[spec-vs-interpreter]", json.dumps(dict(task=task, sub=sub, wg=wg, **worst)))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

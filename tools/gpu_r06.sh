@@ -198,6 +198,20 @@ s)
   timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/cur_78.so $V/hf2_78.so > $OUT/g1_hf2_ab.txt 2>&1
   grep -v amdgpu $OUT/a1_hf2_ab.txt $OUT/go2w_hf2_ab.txt $OUT/g1_hf2_ab.txt
   ;;
+t)
+  # G1: the next joint's link record (and the outward pass's U / D, u / D of all limb joints) read ahead of the chain that consumes them
+  # (-DRL_REC_PREFETCH), against the tree; then the spec-vs-interpreter tests with the contact timers counted apart from the state bound
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/cur2_78.so $V/pref_78.so $V/pref2_78.so > $OUT/g1_prefetch_ab.txt 2>&1
+  grep -v amdgpu $OUT/g1_prefetch_ab.txt
+  timeout 900 python -m pytest tests/test_gpu_specs.py -m gpu -q > $OUT/pytest_specs.log 2>&1; echo "rc=$?" >> $OUT/pytest_specs.log; tail -4 $OUT/pytest_specs.log
+  mv gpurun_out/spec_vs_interpreter.jsonl $OUT/ 2>/dev/null
+  ;;
+u)
+  # G1 read-ahead, second step: + the trunk accumulators and the next joint's axis / origin (pf3 = the tree), + the outward pass's axes / origins
+  # in its batch (pf4, -DRL_OUT_AXP_BATCH), against no read-ahead at all (nopf)
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/nopf_78.so $V/pref2_78.so $V/pf3_78.so $V/pf4_78.so > $OUT/g1_prefetch2_ab.txt 2>&1
+  grep -v amdgpu $OUT/g1_prefetch2_ab.txt
+  ;;
 zz|zz3)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
@@ -213,7 +227,7 @@ import json
 for n in ('bench_default','bench_driver_flags'):
     d=json.load(open('$OUT/%s.json' % n)); print(n, 'value %.2f M  ms_per_step %.4f  kernel_ms %.4f  roofline.frac %.4f' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']), d['config'].get('step_kernel'), d.get('large_batch',{}).get('value'), d.get('mid_batch',{}).get('value'), d.get('cpu_baseline',{}).get('value'))"
   ;;
-z|z2|z3|z4)
+z|z2|z3|z4|z5)
   # FINAL TREE: the whole GPU tier, smoke(), the bench lines of the BASELINE configs, kernel traces + counter passes, phase clocks, the collection loop
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   tail -4 $OUT/pytest_gpu.log
