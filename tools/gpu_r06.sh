@@ -212,6 +212,11 @@ u)
   timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/nopf_78.so $V/pref2_78.so $V/pf3_78.so $V/pf4_78.so > $OUT/g1_prefetch2_ab.txt 2>&1
   grep -v amdgpu $OUT/g1_prefetch2_ab.txt
   ;;
+v)
+  # G1: the trunk joints' table reads as one batch in front of the kinematic chain + the link twist kept from the rigid record for the contacts
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/pf4_78.so $V/fin2_78.so > $OUT/g1_batch3_ab.txt 2>&1
+  grep -v amdgpu $OUT/g1_batch3_ab.txt
+  ;;
 zz|zz3)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
