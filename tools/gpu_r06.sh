@@ -217,6 +217,12 @@ v)
   timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/pf4_78.so $V/fin2_78.so > $OUT/g1_batch3_ab.txt 2>&1
   grep -v amdgpu $OUT/g1_batch3_ab.txt
   ;;
+w)
+  # A1: the observation rows as streaming (non-temporal) stores, and one word of every line of the wavefront's state tiles requested before the
+  # table image is staged (the state's latency under the staging round trip), each and both
+  timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/cur3_34.so $V/nt_34.so $V/touch_34.so $V/nttouch_34.so > $OUT/a1_nt_touch_ab.txt 2>&1
+  grep -v amdgpu $OUT/a1_nt_touch_ab.txt
+  ;;
 zz|zz3)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
