@@ -223,6 +223,12 @@ w)
   timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/cur3_34.so $V/nt_34.so $V/touch_34.so $V/nttouch_34.so > $OUT/a1_nt_touch_ab.txt 2>&1
   grep -v amdgpu $OUT/a1_nt_touch_ab.txt
   ;;
+x)
+  # the heightfield's lines as streaming (non-temporal) loads, alone and with the streaming observation stores + the early state touch of call w
+  timeout 600 python tools/ab_bench.py --task $A1 --num-envs 4096 --rounds 3 --steady $V/cur3_34.so $V/tnt_34.so $V/nttouch_34.so $V/tntall_34.so > $OUT/a1_terrain_nt_ab.txt 2>&1
+  timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/cur3_78.so $V/tnt_78.so > $OUT/g1_terrain_nt_ab.txt 2>&1
+  grep -v amdgpu $OUT/a1_terrain_nt_ab.txt $OUT/g1_terrain_nt_ab.txt
+  ;;
 zz|zz3)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
