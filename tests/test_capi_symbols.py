@@ -118,3 +118,19 @@ def test_self_collision_descriptor_errors_are_reported(emu_lib):
 
     with pytest.raises(capi.RlEnvError, match="trunk \\+ limbs instance"):
         create("RobotLab-Isaac-Velocity-Flat-Unitree-A1-v0", pairs_on_a_quadruped)
+
+
+def test_build_notices_changed_flags(tmp_path, monkeypatch):
+    """`build()` must rebuild the env library when ENV_FLAGS differ from what csrc/build_info.json recorded: time stamps do not see a
+    flag (round 6 measured a library built without one that `__graft_entry__.py` already listed)."""
+    import json
+
+    import __graft_entry__ as g
+
+    info = tmp_path / "build_info.json"
+    monkeypatch.setattr(g, "BUILD_INFO", str(info))
+    assert g._flags_changed()  # nothing recorded
+    info.write_text(json.dumps({"flags": " ".join(g.ENV_FLAGS)}))
+    assert not g._flags_changed()
+    info.write_text(json.dumps({"flags": " ".join(g.ENV_FLAGS[:-1])}))
+    assert g._flags_changed()

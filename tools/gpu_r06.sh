@@ -229,6 +229,15 @@ x)
   timeout 600 python tools/ab_bench.py --task $G1 --num-envs 2048 --rounds 3 --steady $V/cur3_78.so $V/tnt_78.so > $OUT/g1_terrain_nt_ab.txt 2>&1
   grep -v amdgpu $OUT/a1_terrain_nt_ab.txt $OUT/g1_terrain_nt_ab.txt
   ;;
+y)
+  # the collection loop (actor + critic pair, act, env step + record, GAE as one hipGraph) around the env library of the tree and around the
+  # variant with streaming observation stores + the early state touch (call w): what the NEXT kernel finds in L2 is part of this loop's time
+  for rep in 1 2; do
+    RL_ENV_LIB=$GRAFT_REPO_ROOT/$V/cur3_34.so timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -1 | sed "s/^/cur3    /" >> $OUT/collect_nt_ab.txt
+    RL_ENV_LIB=$GRAFT_REPO_ROOT/$V/nttouch_34.so timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -1 | sed "s/^/nttouch /" >> $OUT/collect_nt_ab.txt
+  done
+  cut -c1-200 $OUT/collect_nt_ab.txt
+  ;;
 zz|zz3)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
