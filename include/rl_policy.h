@@ -18,6 +18,8 @@
 
 #include <stdint.h>
 
+#include "rl_act.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -56,6 +58,14 @@ int rl_mlp_forward_small(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_
  * ya = A(xa), yb = B(xb).  Same results as two rl_mlp_forward calls; the two networks' workgroups share the CUs. */
 int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b, const float* xb_dev, float* yb_dev, int32_t n_rows,
                         void* stream);
+
+/* rl_mlp_forward_pair with the rollout step's stochastic head in its epilogue (include/rl_act.h; VERDICT r5 item 2: "sampling / log-prob /
+ * storage in the actor's epilogue"): the actor's workgroups sample a = mu + sigma eps for their rows, write actions_out and the slot's actions /
+ * mu / sigma / log-prob and copy their observation rows into the slot; the critic's workgroups copy their privileged-observation rows; pass
+ * `ep->s_values` as yb_dev and V lands in the slot.  What rl_rollout_act launches a kernel for.  Returns 0 when done in the launch, 1 when
+ * this size / precision runs a kernel without the epilogue (NOTHING was launched: call rl_mlp_forward_pair and rl_rollout_act), -1 on error. */
+int rl_mlp_forward_pair_act(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b, const float* xb_dev, float* yb_dev, int32_t n_rows,
+                            const rl_act_epilogue* ep, void* stream);
 
 int32_t rl_mlp_in_dim(const rl_mlp* m);
 int32_t rl_mlp_out_dim(const rl_mlp* m);

@@ -30,6 +30,8 @@
 
 #include <stdint.h>
 
+#include "rl_act.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -63,6 +65,15 @@ int rl_rollout_create(int32_t num_envs, int32_t num_steps, int32_t obs_dim, int3
  * its value is needed by the storage, the time-out bootstrap and GAE only). */
 int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, const float* mean, const float* std, const float* values,
                    float* actions_out, void* stream);
+
+/* rl_rollout_act WITHOUT a launch of its own: the current step's sampling, log-prob and slot addresses as a descriptor (include/rl_act.h)
+ * for the launch that produces `mean` - rl_mlp_forward_pair_act (include/rl_policy.h) samples in the actor's epilogue, copies obs / critic_obs
+ * into the slot and lets the critic write V straight into `out->s_values`.  `clip` >= 0: actions_out is clamped to +-clip (RslRlVecEnvWrapper's
+ * clip_actions: the env sees the clamped action, the storage keeps the sample).  No state changes here; rl_rollout_act_done marks the step as
+ * acted once that launch is enqueued (then rl_rollout_record / rl_rollout_record_slots close it as after rl_rollout_act).  Same numbers as
+ * rl_rollout_act bit for bit. */
+int rl_rollout_act_epilogue(rl_rollout* r, const float* std, float* actions_out, float clip, rl_act_epilogue* out);
+int rl_rollout_act_done(rl_rollout* r);
 
 /* PPO.process_env_step + the second half of add_transitions: rewards [N] f32, terminated / time_outs [N] u8 (the
  * env's RL_BUF_TERMINATED / RL_BUF_TIME_OUT); closes step t and advances to t + 1. */

@@ -34,9 +34,13 @@ class Collector:
     than the critic's time.  G1 2048: 138.6 / 140.6 / 153.1.  So the serial loop stays the default.  Same numbers bit for bit (tests/test_gpu_collect.py)."""
 
     def __init__(self, env, actor, critic, storage, action_std: torch.Tensor, gamma: float = 0.99, lam: float = 0.95,
-                 normalize_advantage: bool = True, use_graph: bool = True, clip_actions: float | None = None, overlap: bool = False, critic_small: bool = True):
+                 normalize_advantage: bool = True, use_graph: bool = True, clip_actions: float | None = None, overlap: bool = False, critic_small: bool = True,
+                 fused_act: bool = True):
         self.env, self.actor, self.critic, self.storage = env, actor, critic, storage
         self.overlap = overlap
+        # sampling / log-prob / the slot's first half in the epilogue of the actor + critic launch (include/rl_act.h): one launch and one gap
+        # less per step than actor + critic, then `act` (VERDICT r5 item 2, second half); same storage bit for bit (tests/test_gpu_collect.py)
+        self.fused_act = fused_act
         self.critic_small = critic_small  # (overlap) the critic through the small-footprint launch that fits beside the env kernel's workgroups
         self._side = torch.cuda.Stream(device=env.device) if overlap else None
         self.std, self.gamma, self.lam, self.normalize = action_std, gamma, lam, normalize_advantage
@@ -54,10 +58,13 @@ class Collector:
         st, env = self.storage, self.env
         st.clear()
         for _ in range(self.T):
-            mean, values = self.actor.forward_pair(obs["policy"], self.critic, obs["critic"])
-            actions = st.act(obs["policy"], obs["critic"], mean, self.std, values)
-            if self.clip_actions is not None:
-                actions = actions.clamp(-self.clip_actions, self.clip_actions)
+            if self.fused_act:
+                actions = st.act_fused(self.actor, self.critic, obs["policy"], obs["critic"], self.std, self.clip_actions)
+            else:
+                mean, values = self.actor.forward_pair(obs["policy"], self.critic, obs["critic"])
+                actions = st.act(obs["policy"], obs["critic"], mean, self.std, values)
+                if self.clip_actions is not None:
+                    actions = actions.clamp(-self.clip_actions, self.clip_actions)
             obs, _, _, _, _ = env.step(actions, rollout=st, gamma=self.gamma)
         st.compute_returns(self.critic(obs["critic"]), self.gamma, self.lam, self.normalize)
         return obs

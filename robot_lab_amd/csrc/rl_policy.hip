@@ -22,6 +22,9 @@
 #include <vector>
 
 #include "../../include/rl_policy.h"
+#define RL_FN __host__ __device__ __forceinline__
+#include "rl_math.h"
+#include "rollout/rl_sample.h"
 
 namespace {
 
@@ -593,7 +596,8 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_split_kernel(MlpPair q, int n_
 // weight buffers.  LDS: (widest even-layer input + widest odd-layer input) x 32 rows x three bf16 planes - 147 KB for the A1 critic.
 // The actor's workgroups finish early (0.47x the critic's flops); the call is as long as a critic workgroup.
 template <int WAVES>
-__device__ __forceinline__ void stage_rows_s2(const MlpParams& P, const float* __restrict__ x, uint16_t* __restrict__ dst, int tstride, int row0, int n_rows, int lane, int wave) {
+__device__ __forceinline__ void stage_rows_s2(const MlpParams& P, const float* __restrict__ x, uint16_t* __restrict__ dst, int tstride, int row0, int n_rows, int lane, int wave,
+                                              float* __restrict__ copy_dst = nullptr) {
   // 32 rows over WAVES wavefronts (rows wave, wave + WAVES, ...), all loads of the wavefront in flight before the first LDS write
   constexpr int JMAX = KMAX / 64, H = 2 * MT / WAVES;
   const int K0 = P.KB32[0] * 32;
@@ -607,6 +611,20 @@ __device__ __forceinline__ void stage_rows_s2(const MlpParams& P, const float* _
     for (int j = 0; j < JMAX; ++j) {
       const int c = lane + 64 * j;
       v[h][j] = (64 * j < K0 && live && c < P.in_dim) ? xr[c] : 0.f;
+    }
+  }
+  if (copy_dst != nullptr) {  // (act epilogue, include/rl_act.h) the rows go into the rollout slot while they are in registers: stores that ride under the layers
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int r = wave + WAVES * h;
+      if (row0 + r < n_rows) {
+        float* __restrict__ dr = copy_dst + (size_t)(row0 + r) * P.in_dim;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+          const int c = lane + 64 * j;
+          if (64 * j < K0 && c < P.in_dim) dr[c] = v[h][j];
+        }
+      }
     }
   }
 #pragma unroll
@@ -624,8 +642,11 @@ __device__ __forceinline__ void stage_rows_s2(const MlpParams& P, const float* _
     }
 }
 
+// ep.num_envs > 0: the rollout step's stochastic head behind the actor's last layer (include/rl_act.h), see the end of the kernel.  (A run-time
+// flag of the ONE kernel, not a second instantiation: with two kernels calling them the layer functions stop being inlined - 248 registers and
+// 84 B of scratch instead of 162 and none, 36.6 -> 47.8 us for the pair.)
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void mlp_split2_kernel(MlpPair q, int n_rows, int cols_a0, int cols_a1, int cols_b0, int cols_b1) {
+__global__ __launch_bounds__(64 * WAVES) void mlp_split2_kernel(MlpPair q, int n_rows, int cols_a0, int cols_a1, int cols_b0, int cols_b1, rl_act_epilogue ep) {
   extern __shared__ float4 smem4[];
   uint16_t* base = reinterpret_cast<uint16_t*>(smem4);
   const bool two = q.b != nullptr;
@@ -640,7 +661,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_split2_kernel(MlpPair q, int n
   const int ts0 = c0 * MT * 3, ts1 = c1 * MT * 3;
   uint16_t* buf0 = base;
   uint16_t* buf1 = base + 2 * ts0;
-  stage_rows_s2<WAVES>(P, x, buf0, ts0, row0, n_rows, lane, wave);
+  stage_rows_s2<WAVES>(P, x, buf0, ts0, row0, n_rows, lane, wave, ep.num_envs > 0 ? (second ? ep.s_critic_obs : ep.s_obs) : nullptr);
   __syncthreads();
   for (int l = 0; l < P.n_layers; ++l) {
     const int nt = P.NTS[l];
@@ -653,6 +674,29 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_split2_kernel(MlpPair q, int n
       else layer_s<1, WAVES, 2, 3>(P, l, xin, xout, y, row0, n_rows, lane, first, tsi, tso);
     }
     __syncthreads();
+  }
+  if (ep.num_envs > 0) {
+    // The workgroup's 32 rows of the step's transition, first half (what act_kernel of rl_rollout.hip does in a launch of its own):
+    // the actor's workgroup samples from the means it has just written (visible to the whole workgroup behind the barrier above) -
+    // one thread per (row, Philox block of 4 actions), an env's log-prob partials meet in LDS in ascending block order.  (Both networks'
+    // workgroups copied their observation rows into the slot when they staged them; the critic's V went to the slot as `y`.  The actor is
+    // the shorter network: its workgroups sample while the critic's are still in their layers.)
+    float* part = reinterpret_cast<float*>(base);  // (the activation buffers are dead)
+    const int rows = min(2 * MT, n_rows - row0);
+    if (!second) {
+      const int A = ep.act_dim, nblk = (A + 3) >> 2;
+      const int el = tid / nblk, blk = tid - el * nblk, e = row0 + el;
+      const bool live = el < rows;
+      float logp = 0.f;
+      if (live) logp = rl::act_block(ep, y, e, blk);
+      part[tid] = logp;
+      __syncthreads();
+      if (live && blk == 0) {
+        float sacc = 0.f;
+        for (int i = 0; i < nblk; ++i) sacc += part[tid + i];  // fixed order: blocks 0, 1, ...
+        ep.s_logp[e] = sacc;
+      }
+    }
   }
 }
 
@@ -687,8 +731,8 @@ bool split_wanted() {  // (read at every call: the tests switch it inside one pr
 constexpr size_t LDS_MAX = 160 * 1024;
 size_t split_lds_bytes(const rl_mlp* m) { return (size_t)(m->cols[0] + m->cols[1]) * MT * 3 * sizeof(uint16_t); }
 // 32 rows x one network per workgroup (mlp_split2_kernel) once that fills the chip's CUs; RL_MLP_SPLIT_RT=1|2 forces either kernel
-int launch_split2(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* xb, float* yb, int n_rows, void* stream) {
-  const size_t la = 2 * split_lds_bytes(a), lb = b ? 2 * split_lds_bytes(b) : 0, lds = std::max(la, lb);
+int launch_split2(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* xb, float* yb, int n_rows, void* stream, const rl_act_epilogue* ep = nullptr) {
+  const size_t la = 2 * split_lds_bytes(a), lb = b ? 2 * split_lds_bytes(b) : 0, lds = std::max({la, lb, (size_t)(ep ? 512 * sizeof(float) : 0)});
   static size_t configured[64] = {};
   if (lds > configured[a->device & 63]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_split2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -697,8 +741,9 @@ int launch_split2(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float*
   }
   MlpPair q{a->dP, b ? b->dP : nullptr, xa, xb, ya, yb, nullptr};
   const int tiles = (n_rows + 2 * MT - 1) / (2 * MT);
+  rl_act_epilogue off{};  // (num_envs = 0: no epilogue)
   hipLaunchKernelGGL(mlp_split2_kernel<8>, dim3(b ? 2 * tiles : tiles), dim3(512), lds, (hipStream_t)stream, q, n_rows, a->cols[0], a->cols[1],
-                     b ? b->cols[0] : 0, b ? b->cols[1] : 0);
+                     b ? b->cols[0] : 0, b ? b->cols[1] : 0, ep ? *ep : off);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
 }
@@ -895,6 +940,25 @@ int rl_mlp_forward_pair(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b
 #endif
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
+}
+
+// include/rl_policy.h: the pair launch with the rollout step's stochastic head in its epilogue - on the kernel the collection loop runs at
+// rollout sizes (32 rows x one network per workgroup, split precision); any other size / precision reports 1 and launches nothing
+int rl_mlp_forward_pair_act(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_mlp* b, const float* xb_dev, float* yb_dev, int32_t n_rows,
+                            const rl_act_epilogue* ep, void* stream) {
+  if (!a || !b || !xa_dev || !ya_dev || !xb_dev || !yb_dev || !ep) return fail("null argument");
+  if (n_rows <= 0) return 0;
+  if (a->device != b->device) return fail("the two networks live on different devices");
+  if (ep->num_envs != n_rows || ep->obs_dim != a->P.in_dim || ep->critic_dim != b->P.in_dim || ep->act_dim != a->P.out_dim || b->P.out_dim != 1)
+    return fail("rl_mlp_forward_pair_act: the epilogue's sizes are not the networks' (rows, obs_dim, critic_dim, act_dim; the critic has one output)");
+  const char* e = getenv("RL_MLP_SPLIT_RT");
+  const int forced = e ? atoi(e) : 0;
+  const size_t need2 = 2 * std::max(split_lds_bytes(a), split_lds_bytes(b));
+  const bool split2 = split_wanted() && a->P.n_layers == b->P.n_layers && split_lds_bytes(a) + split_lds_bytes(b) <= LDS_MAX && need2 <= LDS_MAX &&
+                      (forced == 2 || (forced != 1 && (size_t)n_rows * 2 >= 8192)) && (ep->act_dim + 3) / 4 * 32 <= 512;
+  if (!split2) return 1;
+  if (hipSetDevice(a->device) != hipSuccess) return fail("hipSetDevice failed");
+  return launch_split2(a, xa_dev, ya_dev, b, xb_dev, yb_dev, n_rows, stream, ep);
 }
 
 int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream) {

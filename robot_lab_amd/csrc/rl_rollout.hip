@@ -21,10 +21,10 @@
 #include "../../include/rl_rollout.h"
 #define RL_FN __host__ __device__ __forceinline__
 #include "rl_math.h"
+#include "rollout/rl_sample.h"
 
 namespace {
 
-constexpr uint32_t STREAM_POLICY = 7;  // Philox stream of the action noise (the env uses streams 1..6)
 constexpr int BLOCK = 256;
 constexpr int MAX_PARTIALS = 4096;
 
@@ -48,9 +48,7 @@ struct ActArgs {
   float *actions_out, *s_obs, *s_critic, *s_actions, *s_mu, *s_sigma, *s_logp, *s_values;
   int N, obs_dim, critic_dim, act_dim;
   int copy_blocks_obs, copy_blocks_critic, sample_blocks;
-  uint64_t seed;
-  const uint32_t* counter_base;  // Philox counter of the launch = *counter_base + counter (graph replays advance the device word)
-  uint32_t counter;
+  rl_act_epilogue ep;  // the sampling half (slot pointers, std, seed, counter: Philox counter of the launch = *counter_base + counter)
 };
 
 __device__ inline void stream_copy(const float* __restrict__ src, float* __restrict__ dst, size_t n, int block, int nblocks) {
@@ -65,20 +63,6 @@ __device__ inline void stream_copy(const float* __restrict__ src, float* __restr
   float4* d4 = reinterpret_cast<float4*>(dst);
   for (size_t i = (size_t)block * BLOCK + threadIdx.x; i < n4; i += (size_t)nblocks * BLOCK) d4[i] = s4[i];
   if (block == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
-}
-
-// standard normals of one Philox block: (u0, u1) and (u2, u3) -> two Box-Muller pairs; u in [0, 1) -> 1 - u in (0, 1]
-__device__ inline void normal4(uint64_t seed, uint32_t env, uint32_t counter, uint32_t blk, float (&z)[4]) {
-  float u[4];
-  rl::uniform01x4(seed, env, counter, STREAM_POLICY, blk, u);
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const float r = sqrtf(-2.0f * logf(1.0f - u[2 * p]));
-    float s, c;
-    sincosf(6.28318530717958647692f * u[2 * p + 1], &s, &c);
-    z[2 * p] = r * c;
-    z[2 * p + 1] = r * s;
-  }
 }
 
 __global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
@@ -104,25 +88,7 @@ __global__ __launch_bounds__(BLOCK) void act_kernel(ActArgs a) {
   const int e = b * epb + el;
   const bool live = el < epb && e < a.N;
   float logp = 0.f;
-  if (live) {
-    const float* mu = a.mean + (size_t)e * A;
-    float z[4];
-    normal4(a.seed, (uint32_t)e, *a.counter_base + a.counter, (uint32_t)blk, z);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 4 * blk + i;
-      if (j >= A) break;
-      const float m = mu[j], sd = a.std[j];
-      const float act = m + sd * z[i];
-      const float q = (act - m) / sd;  // as the reference evaluates Normal.log_prob on the sampled action
-      logp += -0.5f * q * q - logf(sd) - 0.91893853320467274178f;
-      const size_t o = (size_t)e * A + j;
-      a.actions_out[o] = act;
-      a.s_actions[o] = act;
-      a.s_mu[o] = m;
-      a.s_sigma[o] = sd;
-    }
-  }
+  if (live) logp = rl::act_block(a.ep, a.mean, e, blk);  // (csrc/rl_sample.h: shared with the actor launch's epilogue, include/rl_act.h)
   part[threadIdx.x] = logp;
   __syncthreads();
   if (live && blk == 0) {
@@ -311,6 +277,32 @@ int rl_rollout_create(int32_t num_envs, int32_t num_steps, int32_t obs_dim, int3
   return 0;
 }
 
+static void fill_epilogue(rl_rollout* r, const float* std, float* actions_out, float clip, rl_act_epilogue* e) {
+  const int t = r->step;
+  e->actions_out = actions_out;
+  e->s_obs = slot<float>(r, RL_RO_OBS, t); e->s_critic_obs = slot<float>(r, RL_RO_CRITIC_OBS, t); e->s_actions = slot<float>(r, RL_RO_ACTIONS, t);
+  e->s_mu = slot<float>(r, RL_RO_MU, t); e->s_sigma = slot<float>(r, RL_RO_SIGMA, t); e->s_logp = slot<float>(r, RL_RO_LOG_PROB, t);
+  e->s_values = slot<float>(r, RL_RO_VALUES, t);
+  e->std = std; e->counter_base = r->counter_base; e->seed = r->seed; e->counter = r->counter - r->anchor;
+  e->num_envs = r->N; e->obs_dim = r->obs_dim; e->critic_dim = r->critic_dim; e->act_dim = r->act_dim; e->clip = clip;
+}
+
+// include/rl_rollout.h: the current step's act as a descriptor for the actor / critic launch (include/rl_act.h) - no launch, no state change;
+// rl_rollout_act_done marks the step as acted once that launch is enqueued
+int rl_rollout_act_epilogue(rl_rollout* r, const float* std, float* actions_out, float clip, rl_act_epilogue* out) {
+  if (!r || !std || !actions_out || !out) return fail("NULL argument");
+  if (r->step >= r->T) return fail("rollout storage overflow: call rl_rollout_clear after num_steps transitions");
+  if (r->acted) return fail("rl_rollout_act_epilogue: the step is already acted (rl_rollout_record closes it)");
+  fill_epilogue(r, std, actions_out, clip, out);
+  return 0;
+}
+int rl_rollout_act_done(rl_rollout* r) {
+  if (!r) return fail("NULL argument");
+  if (r->acted) return fail("rl_rollout_act_done called twice without rl_rollout_record");
+  r->acted = true;
+  return 0;
+}
+
 int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, const float* mean, const float* std, const float* values,
                    float* actions_out, void* stream) {
   if (!r || !obs || !mean || !std || !actions_out) return fail("NULL argument");  // (critic_obs / values may be NULL: include/rl_rollout.h)
@@ -323,7 +315,8 @@ int rl_rollout_act(rl_rollout* r, const float* obs, const float* critic_obs, con
   a.s_obs = slot<float>(r, RL_RO_OBS, t); a.s_critic = slot<float>(r, RL_RO_CRITIC_OBS, t); a.s_actions = slot<float>(r, RL_RO_ACTIONS, t);
   a.s_mu = slot<float>(r, RL_RO_MU, t); a.s_sigma = slot<float>(r, RL_RO_SIGMA, t); a.s_logp = slot<float>(r, RL_RO_LOG_PROB, t);
   a.s_values = slot<float>(r, RL_RO_VALUES, t);
-  a.N = r->N; a.obs_dim = r->obs_dim; a.critic_dim = r->critic_dim; a.act_dim = r->act_dim; a.seed = r->seed; a.counter_base = r->counter_base; a.counter = r->counter - r->anchor;
+  a.N = r->N; a.obs_dim = r->obs_dim; a.critic_dim = r->critic_dim; a.act_dim = r->act_dim;
+  fill_epilogue(r, std, actions_out, -1.f, &a.ep);
   // 4 float4 per thread of the copy blocks
   a.copy_blocks_obs = std::max(1, blocks_for(((size_t)r->N * r->obs_dim) >> 4));
   a.copy_blocks_critic = critic_obs ? std::max(1, blocks_for(((size_t)r->N * r->critic_dim) >> 4)) : 0;

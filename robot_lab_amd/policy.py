@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 POLICY_LIB = os.path.join(_HERE, "csrc", "librl_policy_hip.so")
-POLICY_EXPORTS = ["rl_mlp_create", "rl_mlp_set_weights", "rl_mlp_forward", "rl_mlp_forward_small", "rl_mlp_forward_pair", "rl_mlp_in_dim", "rl_mlp_out_dim", "rl_mlp_destroy", "rl_mlp_last_error"]
+POLICY_EXPORTS = ["rl_mlp_create", "rl_mlp_set_weights", "rl_mlp_forward", "rl_mlp_forward_small", "rl_mlp_forward_pair", "rl_mlp_forward_pair_act", "rl_mlp_in_dim", "rl_mlp_out_dim", "rl_mlp_destroy", "rl_mlp_last_error"]
 ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2}
 _lib = None
 
@@ -39,6 +39,7 @@ def load_policy_library(path: str | None = None) -> C.CDLL:
     lib.rl_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rl_mlp_forward_small.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rl_mlp_forward_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rl_mlp_forward_pair_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rl_mlp_in_dim.argtypes = [C.c_void_p]
     lib.rl_mlp_out_dim.argtypes = [C.c_void_p]
     lib.rl_mlp_destroy.argtypes = [C.c_void_p]
@@ -125,6 +126,19 @@ class MlpPolicy:
                                         C.c_void_p(other_obs.data_ptr()), C.c_void_p(other._out.data_ptr()), n, C.c_void_p(stream)) != 0:
             raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
         return self._out, other._out
+
+    def forward_pair_act(self, obs_ptr, other: "MlpPolicy", other_obs_ptr, ep) -> int:
+        """The actor (self) / critic (other) launch with the rollout step's stochastic head in its epilogue (include/rl_policy.h
+        rl_mlp_forward_pair_act; `ep`: a filled `rollout.ActEpilogue`, whose `s_values` receives V).  0: done; 1: not available for this size."""
+        n = int(ep.num_envs)
+        if self._out is None or self._out.shape[0] != n:
+            self._out = self._torch.empty(n, self.out_dim, device=self.device, dtype=self._torch.float32)
+        stream = self._torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.rl_mlp_forward_pair_act(self.handle, obs_ptr, C.c_void_p(self._out.data_ptr()), other.handle, other_obs_ptr, C.c_void_p(ep.s_values), n,
+                                              C.byref(ep), C.c_void_p(stream))
+        if rc < 0:
+            raise RlPolicyError((self.lib.rl_mlp_last_error() or b"").decode())
+        return rc
 
     def __call__(self, obs):
         """obs: float32 device tensor [N, in_dim] (or a dict / TensorDict with a "policy" entry, as rsl_rl passes)."""

@@ -17,7 +17,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROLLOUT_LIB = os.path.join(_HERE, "csrc", "librl_rollout_hip.so")
-ROLLOUT_EXPORTS = ["rl_rollout_create", "rl_rollout_act", "rl_rollout_record", "rl_rollout_record_slots", "rl_rollout_values_slot", "rl_rollout_store_critic_obs", "rl_rollout_compute_returns", "rl_rollout_clear",
+ROLLOUT_EXPORTS = ["rl_rollout_create", "rl_rollout_act", "rl_rollout_act_epilogue", "rl_rollout_act_done", "rl_rollout_record", "rl_rollout_record_slots", "rl_rollout_values_slot", "rl_rollout_store_critic_obs", "rl_rollout_compute_returns", "rl_rollout_clear",
                    "rl_rollout_get_buffer", "rl_rollout_step", "rl_rollout_destroy", "rl_rollout_last_error",
                    "rl_rollout_graph_begin", "rl_rollout_graph_end", "rl_rollout_graph_launching"]
 # name -> (rl_rollout_buffer id, dtype, has a trailing feature dim)
@@ -26,6 +26,14 @@ BUFFERS = dict(observations=(0, np.float32, True), privileged_observations=(1, n
                values=(6, np.float32, False), rewards=(7, np.float32, False), dones=(8, np.uint8, False),
                returns=(9, np.float32, False), advantages=(10, np.float32, False))
 _lib = None
+
+
+class ActEpilogue(C.Structure):
+    """include/rl_act.h `rl_act_epilogue`: the step's sampling / log-prob / slot addresses for the actor launch's epilogue."""
+    _fields_ = [("actions_out", C.c_void_p), ("s_obs", C.c_void_p), ("s_critic_obs", C.c_void_p), ("s_actions", C.c_void_p), ("s_mu", C.c_void_p),
+                ("s_sigma", C.c_void_p), ("s_logp", C.c_void_p), ("s_values", C.c_void_p), ("std", C.c_void_p), ("counter_base", C.c_void_p),
+                ("seed", C.c_uint64), ("counter", C.c_uint32), ("num_envs", C.c_int32), ("obs_dim", C.c_int32), ("critic_dim", C.c_int32),
+                ("act_dim", C.c_int32), ("clip", C.c_float)]
 
 
 class RlRolloutError(RuntimeError):
@@ -43,6 +51,8 @@ def load_rollout_library(path: str | None = None) -> C.CDLL:
     vp = C.c_void_p
     lib.rl_rollout_create.argtypes = [C.c_int32] * 5 + [C.c_uint64, C.c_int32, C.POINTER(vp)]
     lib.rl_rollout_act.argtypes = [vp] * 8
+    lib.rl_rollout_act_epilogue.argtypes = [vp, vp, vp, C.c_float, C.POINTER(ActEpilogue)]
+    lib.rl_rollout_act_done.argtypes = [vp]
     lib.rl_rollout_record.argtypes = [vp, vp, vp, vp, C.c_float, vp]
     lib.rl_rollout_record_slots.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.rl_rollout_values_slot.argtypes = [vp, C.POINTER(vp)]
@@ -122,6 +132,25 @@ class RolloutStorage:
                 None if privileged_obs is None else self._f32(privileged_obs, (N, self.privileged_observations.shape[-1])),
                 self._f32(action_mean, (N, A)), self._f32(action_std, (A,)), None if values is None else self._f32(values.view(-1), (N,)), self._p(self._actions)]
         if self.lib.rl_rollout_act(self.handle, *args, self._stream()) != 0:
+            raise RlRolloutError(self._err())
+        return self._actions
+
+    def act_fused(self, actor, critic, obs, privileged_obs, action_std, clip_actions=None):
+        """`act` inside the actor / critic launch (include/rl_act.h): sampling, log-prob and the slot's first half in the epilogue of
+        `rl_mlp_forward_pair_act`, V straight into the values slot - no launch between the networks and env.step.  Falls back to the
+        pair launch + `act` when the networks' kernel for this size has no epilogue.  Returns the actions env.step consumes (clamped to
+        +-clip_actions when given; the storage keeps the sample).  Same numbers as `act`, bit for bit."""
+        N, A = self.num_envs, self.actions.shape[-1]
+        ep = ActEpilogue()
+        if self.lib.rl_rollout_act_epilogue(self.handle, self._f32(action_std, (A,)), self._p(self._actions), -1.0 if clip_actions is None else float(clip_actions),
+                                            C.byref(ep)) != 0:
+            raise RlRolloutError(self._err())
+        rc = actor.forward_pair_act(self._f32(obs, (N, self.observations.shape[-1])), critic, self._f32(privileged_obs, (N, self.privileged_observations.shape[-1])), ep)
+        if rc == 1:  # this size / precision runs a kernel without the epilogue
+            mean, values = actor.forward_pair(obs, critic, privileged_obs)
+            actions = self.act(obs, privileged_obs, mean, action_std, values)
+            return actions if clip_actions is None else actions.clamp(-clip_actions, clip_actions)
+        if self.lib.rl_rollout_act_done(self.handle) != 0:
             raise RlRolloutError(self._err())
         return self._actions
 

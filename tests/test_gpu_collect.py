@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 TASK = "RobotLab-Isaac-Velocity-Rough-Unitree-A1-v0"
 
 
-def _setup(use_graph, N=256, T=24, overlap=False, critic_small=False, task=TASK, specialise=None):
+def _setup(use_graph, N=256, T=24, overlap=False, critic_small=False, task=TASK, specialise=None, fused_act=True, clip_actions=None):
     import torch
 
     from robot_lab_amd.collect import Collector
@@ -29,7 +29,8 @@ def _setup(use_graph, N=256, T=24, overlap=False, critic_small=False, task=TASK,
     actor, critic = net([od, 512, 256, 128, A]), net([cd, 512, 256, 128, 1])
     storage = RolloutStorage(N, T, od, cd, A, seed=3, device="cuda:0")
     std = torch.full((A,), 0.5, device="cuda:0")
-    return env, storage, Collector(env, actor, critic, storage, std, use_graph=use_graph, overlap=overlap, critic_small=critic_small)
+    return env, storage, Collector(env, actor, critic, storage, std, use_graph=use_graph, overlap=overlap, critic_small=critic_small, fused_act=fused_act,
+                                   clip_actions=clip_actions)
 
 
 @pytest.mark.parametrize("overlap", [True, False])
@@ -120,4 +121,42 @@ def test_graph_replay_on_a_run_time_specialised_env(monkeypatch, tmp_path):
             a, b = getattr(st_e, name), getattr(st_g, name)
             assert torch.equal(a, b), f"iteration {it}: {name} differs (max |d| {float((a.float() - b.float()).abs().max()):.3e})"
     for e in (env_e, env_g):
+        e.close()
+
+
+@pytest.mark.parametrize("clip", [None, 0.8])
+def test_act_in_the_actor_launch_equals_the_act_kernel(clip, monkeypatch):
+    """The step's stochastic head in the epilogue of the actor + critic launch (include/rl_act.h, rl_mlp_forward_pair_act; VERDICT r5 item 2,
+    second half) against actor + critic, then the act kernel: the same sampling function, the same slots - the storages must agree bit for
+    bit, graph replays included, with and without the wrapper's action clamp.  RL_MLP_SPLIT_RT=2 puts the 256-env pair on the kernel that
+    carries the epilogue (the one rollout sizes run: 32 rows x one network per workgroup); a size without it falls back to act()."""
+    import torch
+
+    monkeypatch.setenv("RL_MLP_SPLIT_RT", "2")
+    env_a, st_a, fused = _setup(True, fused_act=True, clip_actions=clip)
+    env_b, st_b, plain = _setup(True, fused_act=False, clip_actions=clip)
+    # the fused launch is really taken at this size
+    from robot_lab_amd.rollout import ActEpilogue
+    import ctypes as C
+
+    ep = ActEpilogue()
+    assert st_a.lib.rl_rollout_act_epilogue(st_a.handle, C.c_void_p(fused.std.data_ptr()), C.c_void_p(st_a._actions.data_ptr()), -1.0, C.byref(ep)) == 0
+    obs = fused.obs
+    assert fused.actor.forward_pair_act(C.c_void_p(obs["policy"].data_ptr()), fused.critic, C.c_void_p(obs["critic"].data_ptr()), ep) == 0
+    torch.cuda.synchronize()
+    for it in range(3):  # 0: eager + capture, 1..: replays
+        oa, ob = fused.collect(), plain.collect()
+        torch.cuda.synchronize()
+        for name in ("observations", "privileged_observations", "actions", "mu", "sigma", "actions_log_prob", "values", "rewards", "dones", "returns",
+                     "advantages"):
+            a, b = getattr(st_a, name), getattr(st_b, name)
+            assert torch.equal(a, b), f"iteration {it}: {name} differs (max |d| {float((a.float() - b.float()).abs().max()):.3e})"
+        assert torch.equal(oa["policy"], ob["policy"]) and torch.equal(oa["critic"], ob["critic"])
+        assert torch.equal(env_a.episode_length_buf, env_b.episode_length_buf)
+    if clip is not None:
+        assert float(st_a.actions.abs().max()) > clip  # the storage keeps the sample; the env saw the clamped action (equal states above)
+    # a size whose pair kernel has no epilogue reports so and launches nothing
+    monkeypatch.setenv("RL_MLP_SPLIT_RT", "1")
+    assert fused.actor.forward_pair_act(C.c_void_p(obs["policy"].data_ptr()), fused.critic, C.c_void_p(obs["critic"].data_ptr()), ep) == 1
+    for e in (env_a, env_b):
         e.close()

@@ -42,11 +42,12 @@ storage = RolloutStorage(N, T, od, cd, A, seed=1, device="cuda:0")
 
 GRAPH = os.environ.get("RL_GRAPH", "1") == "1"  # the whole iteration as one hipGraph launch (robot_lab_amd/collect.py)
 SMALL = os.environ.get("RL_CRITIC_SMALL", "1") == "1"  # (overlap) the critic through rl_mlp_forward_small
+FUSED_ACT = os.environ.get("RL_FUSED_ACT", "1") == "1"  # sampling / log-prob / the slot's first half in the actor + critic launch's epilogue (0: the act kernel)
 OVERLAP = os.environ.get("RL_OVERLAP", "0") == "1"  # the critic of step t on a second stream under env step t (0: actor + critic as one launch in front of act)
 if GRAPH and FUSED and PAIR:
     from robot_lab_amd.collect import Collector  # noqa: E402
 
-    col = Collector(env, actor, critic, storage, std, GAMMA, LAM, use_graph=True, overlap=OVERLAP, critic_small=SMALL)
+    col = Collector(env, actor, critic, storage, std, GAMMA, LAM, use_graph=True, overlap=OVERLAP, critic_small=SMALL, fused_act=FUSED_ACT)
     iteration = lambda obs: col.collect()  # noqa: E731
 else:
 

@@ -238,6 +238,25 @@ y)
   done
   cut -c1-200 $OUT/collect_nt_ab.txt
   ;;
+aa)
+  # the act kernel's work in the epilogue of the actor + critic launch (include/rl_act.h): collection tests, then the collection loop with and without
+  timeout 900 python -m pytest tests/test_gpu_collect.py tests/test_rollout.py tests/test_policy.py tests/test_gpu_train.py -m gpu -q -x > $OUT/pytest_collect.log 2>&1; echo "rc=$?" >> $OUT/pytest_collect.log; tail -6 $OUT/pytest_collect.log
+  for rep in 1 2; do
+    RL_FUSED_ACT=0 timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -1 | sed "s/^/act kernel  /" >> $OUT/collect_fused_ab.txt
+    RL_FUSED_ACT=1 timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -1 | sed "s/^/fused       /" >> $OUT/collect_fused_ab.txt
+  done
+  RL_FUSED_ACT=0 timeout 300 python tools/bench_collect.py $G1 2048 20 2>/dev/null | tail -1 | sed "s/^/act kernel  /" >> $OUT/collect_fused_ab.txt
+  RL_FUSED_ACT=1 timeout 300 python tools/bench_collect.py $G1 2048 20 2>/dev/null | tail -1 | sed "s/^/fused       /" >> $OUT/collect_fused_ab.txt
+  cut -c1-200 $OUT/collect_fused_ab.txt
+  ;;
+ab)
+  # kernel traces of the collection loop with the act kernel and with the act epilogue
+  for m in 0 1; do
+    ( cd /tmp && RL_FUSED_ACT=$m timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_$m -- python $GRAFT_REPO_ROOT/tools/bench_collect.py $A1 4096 20 > $GRAFT_REPO_ROOT/$OUT/collect_$m.txt 2> /dev/null )
+    DB=$(find $OUT/prof_$m -name "*.db" | head -1); python tools/rocpd_summary.py $DB > $OUT/collect_trace_$m.txt 2>&1; rm -rf $OUT/prof_$m
+    tail -1 $OUT/collect_$m.txt | cut -c1-200; head -9 $OUT/collect_trace_$m.txt | cut -c1-150
+  done
+  ;;
 zz|zz3)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
