@@ -512,7 +512,8 @@ __device__ inline void layer_s(const MlpParams& P, int l, const uint16_t* __rest
 }
 
 template <int WAVES>
-__device__ __forceinline__ void stage_rows_s(const MlpParams& P, const float* __restrict__ x, uint16_t* __restrict__ dst, int row0, int n_rows, int lane, int wave) {
+__device__ __forceinline__ void stage_rows_s(const MlpParams& P, const float* __restrict__ x, uint16_t* __restrict__ dst, int row0, int n_rows, int lane, int wave,
+                                             float* __restrict__ copy_dst = nullptr) {
   // 16 rows over WAVES wavefronts; every load of the wavefront is in flight before the first LDS write (see stage_rows)
   constexpr int JMAX = KMAX / 64, H = MT / WAVES;
   const int K0 = P.KB32[0] * 32;
@@ -526,6 +527,20 @@ __device__ __forceinline__ void stage_rows_s(const MlpParams& P, const float* __
     for (int j = 0; j < JMAX; ++j) {
       const int c = lane + 64 * j;
       v[h][j] = (64 * j < K0 && live && c < P.in_dim) ? xr[c] : 0.f;
+    }
+  }
+  if (copy_dst != nullptr) {  // (act epilogue, include/rl_act.h) the rows go into the rollout slot while they are in registers
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int r = wave + WAVES * h;
+      if (row0 + r < n_rows) {
+        float* __restrict__ dr = copy_dst + (size_t)(row0 + r) * P.in_dim;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+          const int c = lane + 64 * j;
+          if (64 * j < K0 && c < P.in_dim) dr[c] = v[h][j];
+        }
+      }
     }
   }
 #pragma unroll
@@ -559,7 +574,7 @@ struct SplitLds {
   int a1, b0, b1;  // offsets (in bf16 units) of A's second buffer and of B's two buffers; A's first buffer starts at 0
 };
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void mlp_split_kernel(MlpPair q, int n_rows, SplitLds o) {
+__global__ __launch_bounds__(64 * WAVES) void mlp_split_kernel(MlpPair q, int n_rows, SplitLds o, rl_act_epilogue ep) {  // (ep.num_envs > 0: as mlp_split2_kernel)
   extern __shared__ float4 smem4[];
   uint16_t* base = reinterpret_cast<uint16_t*>(smem4);
   const MlpParams& A = *q.a;
@@ -567,8 +582,9 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_split_kernel(MlpPair q, int n_
   const MlpParams& B = two ? *q.b : *q.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * MT;
-  stage_rows_s<WAVES>(A, q.xa, base, row0, n_rows, lane, wave);
-  if (two) stage_rows_s<WAVES>(B, q.xb, base + o.b0, row0, n_rows, lane, wave);
+  const bool act = ep.num_envs > 0;
+  stage_rows_s<WAVES>(A, q.xa, base, row0, n_rows, lane, wave, act ? ep.s_obs : nullptr);
+  if (two) stage_rows_s<WAVES>(B, q.xb, base + o.b0, row0, n_rows, lane, wave, act ? ep.s_critic_obs : nullptr);
   __syncthreads();
   const bool a_first = ((wave >> 2) & 1) == 0;
   for (int l = 0; l < A.n_layers; ++l) {
@@ -583,6 +599,22 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_split_kernel(MlpPair q, int n_
       split_segment<WAVES>(P, l, base + ((l & 1) ? odd : even), base + ((l & 1) ? even : odd), isA ? q.ya : q.yb, row0, n_rows, lane, isA ? wave : firstB);
     }
     __syncthreads();
+  }
+  if (act) {  // the 16 rows' stochastic head (see mlp_split2_kernel): one thread per (row, Philox block of 4 actions)
+    float* part = reinterpret_cast<float*>(base);
+    const int rows = min(MT, n_rows - row0);
+    const int nA = ep.act_dim, nblk = (nA + 3) >> 2;
+    const int el = tid / nblk, blk = tid - el * nblk, e = row0 + el;
+    const bool live = el < rows;
+    float logp = 0.f;
+    if (live) logp = rl::act_block(ep, q.ya, e, blk);
+    part[tid] = logp;
+    __syncthreads();
+    if (live && blk == 0) {
+      float sacc = 0.f;
+      for (int i = 0; i < nblk; ++i) sacc += part[tid + i];
+      ep.s_logp[e] = sacc;
+    }
   }
 }
 
@@ -747,14 +779,14 @@ int launch_split2(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float*
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
 }
-int launch_split(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* xb, float* yb, int n_rows, void* stream) {
+int launch_split(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* xb, float* yb, int n_rows, void* stream, const rl_act_epilogue* ep = nullptr) {
   {
     const char* e = getenv("RL_MLP_SPLIT_RT");
     const int forced = e ? atoi(e) : 0;
     const size_t need2 = 2 * std::max(split_lds_bytes(a), b ? split_lds_bytes(b) : (size_t)0);
     // from 4096 rows on (128 row tiles x 2 networks = one workgroup per CU; a single network: 8192 rows)
     const bool big = (size_t)n_rows * (b ? 2 : 1) >= 8192;
-    if (need2 <= LDS_MAX && (forced == 2 || (forced != 1 && big))) return launch_split2(a, xa, ya, b, xb, yb, n_rows, stream);
+    if (need2 <= LDS_MAX && (forced == 2 || (forced != 1 && big))) return launch_split2(a, xa, ya, b, xb, yb, n_rows, stream, ep);
   }
   const size_t la = split_lds_bytes(a), lb = b ? split_lds_bytes(b) : 0;
   static size_t configured[64] = {};  // the LDS opt-in belongs to the (kernel, device) pair
@@ -765,7 +797,8 @@ int launch_split(rl_mlp* a, const float* xa, float* ya, rl_mlp* b, const float* 
   }
   MlpPair q{a->dP, b ? b->dP : nullptr, xa, xb, ya, yb, nullptr};
   SplitLds o{a->cols[0] * MT * 3, (int)(la / 2), (int)(la / 2) + (b ? b->cols[0] * MT * 3 : 0)};
-  hipLaunchKernelGGL(mlp_split_kernel<16>, dim3((n_rows + MT - 1) / MT), dim3(1024), la + lb, (hipStream_t)stream, q, n_rows, o);
+  rl_act_epilogue off{};  // (num_envs = 0: no epilogue)
+  hipLaunchKernelGGL(mlp_split_kernel<16>, dim3((n_rows + MT - 1) / MT), dim3(1024), la + lb, (hipStream_t)stream, q, n_rows, o, ep ? *ep : off);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail(hipGetErrorString(e));
 }
@@ -951,14 +984,12 @@ int rl_mlp_forward_pair_act(rl_mlp* a, const float* xa_dev, float* ya_dev, rl_ml
   if (a->device != b->device) return fail("the two networks live on different devices");
   if (ep->num_envs != n_rows || ep->obs_dim != a->P.in_dim || ep->critic_dim != b->P.in_dim || ep->act_dim != a->P.out_dim || b->P.out_dim != 1)
     return fail("rl_mlp_forward_pair_act: the epilogue's sizes are not the networks' (rows, obs_dim, critic_dim, act_dim; the critic has one output)");
-  const char* e = getenv("RL_MLP_SPLIT_RT");
-  const int forced = e ? atoi(e) : 0;
-  const size_t need2 = 2 * std::max(split_lds_bytes(a), split_lds_bytes(b));
-  const bool split2 = split_wanted() && a->P.n_layers == b->P.n_layers && split_lds_bytes(a) + split_lds_bytes(b) <= LDS_MAX && need2 <= LDS_MAX &&
-                      (forced == 2 || (forced != 1 && (size_t)n_rows * 2 >= 8192)) && (ep->act_dim + 3) / 4 * 32 <= 512;
-  if (!split2) return 1;
+  // the split-precision pair kernels carry the epilogue (16 rows of both networks, or 32 rows of one, per workgroup: launch_split picks);
+  // (act_dim + 3) / 4 Philox blocks per row must fit the workgroup's threads in both
+  const bool split = split_wanted() && a->P.n_layers == b->P.n_layers && split_lds_bytes(a) + split_lds_bytes(b) <= LDS_MAX && (ep->act_dim + 3) / 4 * 32 <= 512;
+  if (!split) return 1;
   if (hipSetDevice(a->device) != hipSuccess) return fail("hipSetDevice failed");
-  return launch_split2(a, xa_dev, ya_dev, b, xb_dev, yb_dev, n_rows, stream, ep);
+  return launch_split(a, xa_dev, ya_dev, b, xb_dev, yb_dev, n_rows, stream, ep);
 }
 
 int rl_mlp_forward(rl_mlp* m, const float* x_dev, float* y_dev, int32_t n_rows, void* stream) {

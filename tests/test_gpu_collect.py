@@ -124,15 +124,16 @@ def test_graph_replay_on_a_run_time_specialised_env(monkeypatch, tmp_path):
         e.close()
 
 
-@pytest.mark.parametrize("clip", [None, 0.8])
-def test_act_in_the_actor_launch_equals_the_act_kernel(clip, monkeypatch):
+@pytest.mark.parametrize("clip,rt", [(None, "2"), (0.8, "2"), (None, "1")])
+def test_act_in_the_actor_launch_equals_the_act_kernel(clip, rt, monkeypatch):
     """The step's stochastic head in the epilogue of the actor + critic launch (include/rl_act.h, rl_mlp_forward_pair_act; VERDICT r5 item 2,
     second half) against actor + critic, then the act kernel: the same sampling function, the same slots - the storages must agree bit for
-    bit, graph replays included, with and without the wrapper's action clamp.  RL_MLP_SPLIT_RT=2 puts the 256-env pair on the kernel that
-    carries the epilogue (the one rollout sizes run: 32 rows x one network per workgroup); a size without it falls back to act()."""
+    bit, graph replays included, with and without the wrapper's action clamp.  Both split-precision pair kernels carry the epilogue:
+    RL_MLP_SPLIT_RT=2 puts the 256-env pair on the one rollout sizes >= 4096 run (32 rows x one network per workgroup), =1 on the one
+    smaller batches run (16 rows x both networks); the exact-f32 kernels have none and the caller falls back to act()."""
     import torch
 
-    monkeypatch.setenv("RL_MLP_SPLIT_RT", "2")
+    monkeypatch.setenv("RL_MLP_SPLIT_RT", rt)
     env_a, st_a, fused = _setup(True, fused_act=True, clip_actions=clip)
     env_b, st_b, plain = _setup(True, fused_act=False, clip_actions=clip)
     # the fused launch is really taken at this size
@@ -155,8 +156,8 @@ def test_act_in_the_actor_launch_equals_the_act_kernel(clip, monkeypatch):
         assert torch.equal(env_a.episode_length_buf, env_b.episode_length_buf)
     if clip is not None:
         assert float(st_a.actions.abs().max()) > clip  # the storage keeps the sample; the env saw the clamped action (equal states above)
-    # a size whose pair kernel has no epilogue reports so and launches nothing
-    monkeypatch.setenv("RL_MLP_SPLIT_RT", "1")
+    # a pair kernel without the epilogue (the exact-f32 path) reports so and launches nothing
+    monkeypatch.setenv("RL_MLP_PRECISION", "f32")
     assert fused.actor.forward_pair_act(C.c_void_p(obs["policy"].data_ptr()), fused.critic, C.c_void_p(obs["critic"].data_ptr()), ep) == 1
     for e in (env_a, env_b):
         e.close()

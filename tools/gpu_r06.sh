@@ -257,7 +257,18 @@ ab)
     tail -1 $OUT/collect_$m.txt | cut -c1-200; head -9 $OUT/collect_trace_$m.txt | cut -c1-150
   done
   ;;
-zz|zz3)
+ac)
+  # the epilogue in the 16-row pair kernel too (batches below 4096 rows: G1 2048): collection tests, then G1 and A1 with and without
+  timeout 900 python -m pytest tests/test_gpu_collect.py tests/test_rollout.py tests/test_policy.py tests/test_gpu_train.py -m gpu -q -x > $OUT/pytest_collect.log 2>&1; echo "rc=$?" >> $OUT/pytest_collect.log; tail -4 $OUT/pytest_collect.log
+  for rep in 1 2; do
+    RL_FUSED_ACT=0 timeout 300 python tools/bench_collect.py $G1 2048 20 2>/dev/null | tail -1 | sed "s/^/act kernel  /" >> $OUT/collect_fused_ab.txt
+    RL_FUSED_ACT=1 timeout 300 python tools/bench_collect.py $G1 2048 20 2>/dev/null | tail -1 | sed "s/^/fused       /" >> $OUT/collect_fused_ab.txt
+  done
+  RL_FUSED_ACT=0 timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -1 | sed "s/^/act kernel  /" >> $OUT/collect_fused_ab.txt
+  RL_FUSED_ACT=1 timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -1 | sed "s/^/fused       /" >> $OUT/collect_fused_ab.txt
+  cut -c1-200 $OUT/collect_fused_ab.txt
+  ;;
+zz|zz3|zz4)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
   timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
