@@ -268,6 +268,11 @@ ac)
   RL_FUSED_ACT=1 timeout 300 python tools/bench_collect.py $A1 4096 40 2>/dev/null | tail -1 | sed "s/^/fused       /" >> $OUT/collect_fused_ab.txt
   cut -c1-200 $OUT/collect_fused_ab.txt
   ;;
+ad)
+  # every task id on the last tree, with the library's kernel and specialised at run time (the sweep of call e, after the packed pairs, the
+  # flags and the read-ahead)
+  timeout 2400 python tools/bench_every_task.py --jit > $OUT/all_tasks_jit.txt 2> $OUT/all_tasks_jit.err; cat $OUT/all_tasks_jit.txt | cut -c1-250
+  ;;
 zz|zz3|zz4)
   # THE LAST TREE (after call f: reward kinds 31-38 in the specialised evaluation - templates the built-in Specs do not instantiate): the whole GPU tier,
   # smoke(), the default bench line and the driver's flags
